@@ -1,0 +1,528 @@
+// Implicit-GEMM 3-D convolution for gfx950 on the exact-fp32 matrix pipe
+// (v_mfma_f32_32x32x2_f32: bitwise a k-ordered fmaf chain, 157 TF peak = VALU peak, far easier to keep busy).
+//
+// One kernel serves every "gather" form the U-Net+VAE hot path needs (reference call sites:
+// layers/resnet.py:30-37,80-87,96-103  layers/downsample.py:28-35  layers/upsample.py:28-33
+// layers/decoder.py:55-63  layers/vae.py:92-99) and their data-gradients:
+//   out[n, o*os+oo, co] (+)= act( bias[co] + sum_t sum_ci in[n, o*s + off_t, ci] * Wp[t][ci][co] )
+//     K1    : 1 tap, s=1                    (1x1x1 conv, also its data-gradient with transposed Wp)
+//     K3S1  : 27 taps off=t-1, s=1          (TF 'same' pad 1; data-gradient = same form, taps flipped in Wp)
+//     DOWN  : 27 taps off=t,   s=2          (TF 'same' on even sizes pads (0,1); also d/dx of Conv3DTranspose)
+//     UP(p) : per output-parity class p, taps {k=0:0, k=2:-1} (even) / {k=1:0} (odd), s=1, os=2, oo=p
+//             (Conv3DTranspose k3 s2 'same' in gather form: every output voxel written once, no atomics;
+//              also d/dx of the stride-2 conv)
+//
+// Data layout: activations NDHWC fp32 with an explicit pixel stride (ld) so a tensor can be a channel
+// slice of a wider "level slab" (virtual concatenation, encoder.py:83-91 / decoder.py:75).
+// Weights are pre-packed (bts_conv_pack) as Wp[tap][kgroup(8 ch)][half][Npad][4] so that one
+// 16-byte load per lane feeds four MFMAs: lane (half h, column n) holds channels kg*8+h*4+{0..3}.
+//
+// Work decomposition: 256-thread workgroup = 4 waves; output tile = (32*MS*WM voxels) x (32*NS*WN couts);
+// input halo tile for KGS*8 channels staged global->regs->LDS, double buffered (one barrier per stage);
+// weight fragments come straight from L2/L1 (shared by the 4 waves), input fragments from LDS via
+// ds_read_b128 with a 16B-odd voxel stride (S = KGS*8+4 dwords) so 16-lane groups hit distinct slots.
+#include "common.h"
+#include "bts_internal.h"
+
+#define MAXSLOT 8
+
+struct IgemmParams {
+  const float* x;
+  const float* wp;
+  const float* bias;
+  float* y;
+  int N, Di, Hi, Wi, Cin, ldx;
+  int Do, Ho, Wo;  // iteration (class) grid
+  int Cout, ldy, Npad, KG;
+  int ODa, OHa, OWa;  // actual output tensor dims
+  int os, ooz, ooy, oox;
+  int s, loz, loy, lox;
+  int IZ, IY, IX;
+  int lgTX, lgTY, TZ;
+  int ntz, nty, ntx;
+  int ntaps, flags;
+  int tap_lds[27];
+  int tap_w[27];
+};
+
+#define IG_FLAG_BIAS 1
+#define IG_FLAG_ACCUM 2
+#define IG_FLAG_SIGMOID 4
+#define IG_FLAG_VECIN 8
+#define IG_FLAG_VECOUT 16
+
+template <int MS, int NS, int WM, int WN, int KGS>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+  constexpr int S = KGS * 8 + 4;  // dwords per staged voxel (pad 4: 16B-odd stride)
+  constexpr int QPV = KGS * 2;    // float4 slots per voxel
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int h = lane >> 5, l32 = lane & 31;
+
+  int b = blockIdx.x;
+  const int tx = b % p.ntx; b /= p.ntx;
+  const int ty = b % p.nty; b /= p.nty;
+  const int tz = b % p.ntz;
+  const int n = b / p.ntz;
+  const int TX = 1 << p.lgTX, TY = 1 << p.lgTY;
+  const int oz0 = tz * p.TZ, oy0 = ty * TY, ox0 = tx * TX;
+  const int iz0 = oz0 * p.s + p.loz, iy0 = oy0 * p.s + p.loy, ix0 = ox0 * p.s + p.lox;
+  const int tileVox = p.IZ * p.IY * p.IX;
+  const int bufDw = tileVox * S;
+
+  // ---- staging map: slot e -> (voxel, quad); global element offset (or -1 if zero padding) ----
+  const int nslots = tileVox * QPV;
+  long goff[MAXSLOT];
+  int loff[MAXSLOT];
+  int cq[MAXSLOT];
+#pragma unroll
+  for (int i = 0; i < MAXSLOT; ++i) {
+    const int e = tid + i * 256;
+    goff[i] = -1;
+    loff[i] = -1;
+    cq[i] = 0;
+    if (e < nslots) {
+      const int vox = e / QPV, q = e - vox * QPV;
+      const int vx = vox % p.IX;
+      const int r = vox / p.IX;
+      const int vy = r % p.IY, vz = r / p.IY;
+      const int gz = iz0 + vz, gy = iy0 + vy, gx = ix0 + vx;
+      loff[i] = vox * S + q * 4;
+      cq[i] = q * 4;
+      if (gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi)
+        goff[i] = ((((long)n * p.Di + gz) * p.Hi + gy) * p.Wi + gx) * (long)p.ldx + q * 4;
+    }
+  }
+
+  // ---- fragment bases ----
+  int bbase[MS];
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms) {
+    const int m = (wm * MS + ms) * 32 + l32;
+    const int mx = m & (TX - 1);
+    const int my = (m >> p.lgTX) & (TY - 1);
+    const int mz = m >> (p.lgTX + p.lgTY);
+    bbase[ms] = ((mz * p.s * p.IY + my * p.s) * p.IX + mx * p.s) * S + h * 4;
+  }
+  const float* wbase[NS];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    int ncol = ((blockIdx.y * WN + wn) * NS + ns) * 32 + l32;
+    if (ncol >= p.Npad) ncol = p.Npad - 1;  // tile wider than the padded cout range: results are discarded
+    wbase[ns] = p.wp + ((long)h * p.Npad + ncol) * 4;
+  }
+  const long wstepKG = (long)2 * p.Npad * 4;  // floats between consecutive k-groups
+
+  f32x16 acc[MS][NS];
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
+
+  const int nstages = (p.KG + KGS - 1) / KGS;
+  const bool vecin = (p.flags & IG_FLAG_VECIN) != 0;
+
+  f32x4 pre[MAXSLOT];
+  auto fetch = [&](int st) {
+    const int c0 = st * KGS * 8;
+#pragma unroll
+    for (int i = 0; i < MAXSLOT; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (goff[i] >= 0) {
+        const int c = c0 + cq[i];
+        const float* src = p.x + goff[i] + c0;
+        if (vecin) {
+          if (c < p.Cin) v = *reinterpret_cast<const f32x4*>(src);
+        } else {
+          if (c + 0 < p.Cin) v[0] = src[0];
+          if (c + 1 < p.Cin) v[1] = src[1];
+          if (c + 2 < p.Cin) v[2] = src[2];
+          if (c + 3 < p.Cin) v[3] = src[3];
+        }
+      }
+      pre[i] = v;
+    }
+  };
+  auto commit = [&](float* buf) {
+#pragma unroll
+    for (int i = 0; i < MAXSLOT; ++i)
+      if (loff[i] >= 0) *reinterpret_cast<f32x4*>(buf + loff[i]) = pre[i];
+  };
+
+  fetch(0);
+  commit(lds);
+  __syncthreads();
+
+  for (int st = 0; st < nstages; ++st) {
+    const float* cur = lds + (st & 1) * bufDw;
+    float* nxt = lds + ((st + 1) & 1) * bufDw;
+    const bool more = (st + 1) < nstages;
+    if (more) fetch(st + 1);
+
+#pragma unroll
+    for (int kgl = 0; kgl < KGS; ++kgl) {
+      const int kg = st * KGS + kgl;
+      if (kg < p.KG) {
+        for (int t = 0; t < p.ntaps; ++t) {
+          const int tl = p.tap_lds[t] + kgl * 8;
+          const long wo = ((long)p.tap_w[t] * p.KG + kg) * wstepKG;
+          f32x4 a[NS], bq[MS];
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns) a[ns] = *reinterpret_cast<const f32x4*>(wbase[ns] + wo);
+#pragma unroll
+          for (int ms = 0; ms < MS; ++ms) bq[ms] = *reinterpret_cast<const f32x4*>(cur + bbase[ms] + tl);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+              for (int ns = 0; ns < NS; ++ns)
+                acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ns][j], bq[ms][j], acc[ms][ns], 0, 0, 0);
+        }
+      }
+    }
+    if (more) commit(nxt);
+    __syncthreads();
+  }
+
+  // ---- epilogue: D rows = couts (4 consecutive per register quad), cols = voxels ----
+  const bool vecout = (p.flags & IG_FLAG_VECOUT) != 0;
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms) {
+    const int m = (wm * MS + ms) * 32 + l32;
+    const int mx = m & (TX - 1);
+    const int my = (m >> p.lgTX) & (TY - 1);
+    const int mz = m >> (p.lgTX + p.lgTY);
+    const int oz = oz0 + mz, oy = oy0 + my, ox = ox0 + mx;
+    if (oz >= p.Do || oy >= p.Ho || ox >= p.Wo) continue;
+    const long pix = (((long)n * p.ODa + (oz * p.os + p.ooz)) * p.OHa + (oy * p.os + p.ooy)) * p.OWa + (ox * p.os + p.oox);
+    float* yrow = p.y + pix * p.ldy;
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      const int nb = ((blockIdx.y * WN + wn) * NS + ns) * 32;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = nb + 8 * g + 4 * h;
+        if (co >= p.Cout) continue;
+        f32x4 v = {acc[ms][ns][4 * g + 0], acc[ms][ns][4 * g + 1], acc[ms][ns][4 * g + 2], acc[ms][ns][4 * g + 3]};
+        if (p.flags & IG_FLAG_BIAS) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (co + j < p.Cout) v[j] += p.bias[co + j];
+        }
+        if (p.flags & IG_FLAG_SIGMOID) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = sigmoidf_(v[j]);
+        }
+        if (vecout) {
+          f32x4* dst = reinterpret_cast<f32x4*>(yrow + co);
+          if (p.flags & IG_FLAG_ACCUM) {
+            f32x4 o = *dst;
+            v += o;
+          }
+          *dst = v;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (co + j < p.Cout) {
+              float r = v[j];
+              if (p.flags & IG_FLAG_ACCUM) r += yrow[co + j];
+              yrow[co + j] = r;
+            }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight packing (role = forward or data-gradient). Source layouts are the reference's Keras layouts:
+// Conv3D (kd,kh,kw,Cin,Cout) -- resnet.py:30-37,80-87; Conv3DTranspose (kd,kh,kw,Cout,Cin) -- upsample.py:28-33.
+// The encoder's dense connections feed block j the list [o_{j-1}, o_0..o_{j-1}] (encoder.py:83-87): the
+// duplicated slice is folded here (Wp = W[first copy] + W[second copy]) so the kernel reads the level slab
+// [o_0..o_{j-1}] once.
+// ---------------------------------------------------------------------------------------------
+struct PackParams {
+  const float* w;
+  float* wp;
+  int ntaps, K, N, KG, Npad;
+  long sT, sK, sN;  // source strides for (tap, k, n)
+  int flip;         // tap t reads source tap ntaps-1-t
+  int cin_is_k;     // 1: the (possibly folded) input-channel axis is k, 0: it is n, -1: no fold
+  int shift, dup_start;
+};
+
+__global__ void pack_kernel(const PackParams q) {
+  const long total = (long)q.ntaps * q.KG * 2 * q.Npad * 4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 3);
+    long r = i >> 2;
+    const int n = (int)(r % q.Npad); r /= q.Npad;
+    const int hh = (int)(r & 1); r >>= 1;
+    const int kg = (int)(r % q.KG);
+    const int t = (int)(r / q.KG);
+    const int k = kg * 8 + hh * 4 + j;
+    float v = 0.f;
+    if (k < q.K && n < q.N) {
+      const int ts = q.flip ? (q.ntaps - 1 - t) : t;
+      int kk = k, nn = n, k2 = -1, n2 = -1;
+      if (q.cin_is_k == 1) {
+        if (k >= q.dup_start) k2 = k - q.dup_start;
+        kk = k + q.shift;
+        n2 = n;
+      } else if (q.cin_is_k == 0) {
+        if (n >= q.dup_start) n2 = n - q.dup_start;
+        nn = n + q.shift;
+        k2 = k;
+      }
+      v = q.w[ts * q.sT + kk * q.sK + nn * q.sN];
+      if (q.shift > 0 && k2 >= 0 && n2 >= 0) v += q.w[ts * q.sT + k2 * q.sK + n2 * q.sN];
+    }
+    q.wp[i] = v;
+  }
+}
+
+static inline int npad32(int n) { return (n + 31) / 32 * 32; }
+
+extern "C" long bts_conv_packed_floats(int kind, int role, int Cin, int Cout) {
+  const int ntaps = (kind == BTS_CONV_K1) ? 1 : 27;
+  const int K = (role == BTS_ROLE_FWD) ? Cin : Cout;
+  const int N = (role == BTS_ROLE_FWD) ? Cout : Cin;
+  return (long)ntaps * ((K + 7) / 8) * 2 * npad32(N) * 4;
+}
+
+extern "C" int bts_conv_pack(int kind, int role, const float* w, float* wp, int Cin_ref, int Cout, int Cin_slab,
+                             int dup_start, int dup_shift, hipStream_t stream) {
+  if (kind < 0 || kind > 3 || role < 0 || role > 1) return BTS_ERR_UNSUPPORTED;
+  if (dup_shift > 0 && (kind == BTS_CONV_K3S2 || kind == BTS_CONV_K3S2T)) return BTS_ERR_UNSUPPORTED;
+  if (Cin_slab + dup_shift != Cin_ref) return BTS_ERR_SHAPE;
+  PackParams q;
+  q.w = w;
+  q.wp = wp;
+  q.ntaps = (kind == BTS_CONV_K1) ? 1 : 27;
+  q.shift = dup_shift;
+  q.dup_start = dup_shift > 0 ? dup_start : (1 << 30);
+  long sCin, sCout;
+  if (kind == BTS_CONV_K3S2T) { sCout = Cin_ref; sCin = 1; }  // (t, Cout, Cin)
+  else { sCin = Cout; sCout = 1; }                            // (t, Cin, Cout)
+  q.sT = (long)Cin_ref * Cout;
+  if (role == BTS_ROLE_FWD) {
+    q.K = Cin_slab; q.N = Cout; q.sK = sCin; q.sN = sCout; q.flip = 0; q.cin_is_k = 1;
+  } else {
+    q.K = Cout; q.N = Cin_slab; q.sK = sCout; q.sN = sCin; q.cin_is_k = 0;
+    q.flip = (kind == BTS_CONV_K3S1) ? 1 : 0;
+  }
+  q.KG = (q.K + 7) / 8;
+  q.Npad = npad32(q.N);
+  const long total = (long)q.ntaps * q.KG * 2 * q.Npad * 4;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, stream, q);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Launch logic
+// ---------------------------------------------------------------------------------------------
+enum Geo { GEO_K1 = 0, GEO_S1 = 1, GEO_DOWN = 2, GEO_UP = 3 };
+
+template <int MS, int NS, int WM, int WN, int KGS>
+static int launch_cfg(IgemmParams& p, hipStream_t stream) {
+  constexpr int S = KGS * 8 + 4;
+  const int tileVox = p.IZ * p.IY * p.IX;
+  if (tileVox * KGS * 2 > 256 * MAXSLOT) return BTS_ERR_SHAPE;
+  const size_t shmem = (size_t)2 * tileVox * S * sizeof(float);
+  auto kern = igemm_kernel<MS, NS, WM, WN, KGS>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  const int NT = 32 * NS * WN;
+  dim3 grid(p.N * p.ntz * p.nty * p.ntx, (p.Npad + NT - 1) / NT);
+  hipLaunchKernelGGL(kern, grid, dim3(256), shmem, stream, p);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+// geometry + config selection for one gather-conv launch
+static int launch_igemm(int geo, const float* x, const float* wp, const float* bias, float* y, int N, int Di, int Hi,
+                        int Wi, int Cin, int ldx, int Do, int Ho, int Wo, int Cout, int ldy, int ODa, int OHa, int OWa,
+                        int pz, int py, int px, int flags, hipStream_t stream) {
+  IgemmParams p;
+  p.x = x; p.wp = wp; p.bias = bias; p.y = y;
+  p.N = N; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.ldx = ldx;
+  p.Do = Do; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.ldy = ldy;
+  p.Npad = npad32(Cout); p.KG = (Cin + 7) / 8;
+  p.ODa = ODa; p.OHa = OHa; p.OWa = OWa;
+  p.os = 1; p.ooz = p.ooy = p.oox = 0;
+  p.s = 1;
+  p.flags = flags;
+  if ((ldx % 4 == 0) && (Cin % 4 == 0) && (((uintptr_t)x) % 16 == 0)) p.flags |= IG_FLAG_VECIN;
+  if ((ldy % 4 == 0) && (Cout % 4 == 0) && (((uintptr_t)y) % 16 == 0)) p.flags |= IG_FLAG_VECOUT;
+
+  // tap table: offsets relative to o*s
+  int offz[27], offy[27], offx[27], tw[27], nt = 0;
+  int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  if (geo == GEO_K1) {
+    offz[0] = offy[0] = offx[0] = 0; tw[0] = 0; nt = 1;
+  } else if (geo == GEO_S1) {
+    for (int t = 0; t < 27; ++t) { offz[t] = t / 9 - 1; offy[t] = (t / 3) % 3 - 1; offx[t] = t % 3 - 1; tw[t] = t; }
+    nt = 27;
+    lo[0] = lo[1] = lo[2] = -1; hi[0] = hi[1] = hi[2] = 1;
+  } else if (geo == GEO_DOWN) {
+    for (int t = 0; t < 27; ++t) { offz[t] = t / 9; offy[t] = (t / 3) % 3; offx[t] = t % 3; tw[t] = t; }
+    nt = 27;
+    hi[0] = hi[1] = hi[2] = 2;
+    p.s = 2;
+  } else {  // GEO_UP, parity class (pz,py,px)
+    const int par[3] = {pz, py, px};
+    int kz[2], ky[2], kx[2], dz[2], dy[2], dx[2], nz, ny, nx;
+    auto axis = [](int pp, int* k, int* d) {
+      if (pp == 0) { k[0] = 0; d[0] = 0; k[1] = 2; d[1] = -1; return 2; }
+      k[0] = 1; d[0] = 0; return 1;
+    };
+    nz = axis(par[0], kz, dz); ny = axis(par[1], ky, dy); nx = axis(par[2], kx, dx);
+    for (int a = 0; a < nz; ++a)
+      for (int bb = 0; bb < ny; ++bb)
+        for (int c = 0; c < nx; ++c) {
+          offz[nt] = dz[a]; offy[nt] = dy[bb]; offx[nt] = dx[c];
+          tw[nt] = (kz[a] * 3 + ky[bb]) * 3 + kx[c];
+          ++nt;
+        }
+    lo[0] = par[0] == 0 ? -1 : 0; lo[1] = par[1] == 0 ? -1 : 0; lo[2] = par[2] == 0 ? -1 : 0;
+    p.os = 2; p.ooz = pz; p.ooy = py; p.oox = px;
+  }
+  p.ntaps = nt;
+  p.loz = lo[0]; p.loy = lo[1]; p.lox = lo[2];
+
+  // ---- config selection ----
+  const long vox = (long)Do * Ho * Wo;
+  const int k1 = (geo == GEO_K1);
+  int M;  // voxels per workgroup tile
+  int cfg;
+  // cfg ids: 0:(2,1,4,1) M256 N32 | 1:(2,2,4,1) M256 N64 | 2:(1,2,2,2) M64 N128 | 3:(1,1,2,2) M64 N64 | 4:(1,1,4,1) M128 N32
+  if (geo == GEO_DOWN) {
+    M = 64;
+    cfg = (p.Npad >= 128) ? 2 : 3;
+    if (p.Npad <= 32) cfg = 3;
+  } else {
+    const long wg256 = (long)N * ((vox + 255) / 256) * ((p.Npad + 63) / 64);
+    if (p.Npad <= 32) {
+      if ((long)N * ((vox + 255) / 256) >= 512) { M = 256; cfg = 0; }
+      else { M = 128; cfg = 4; }
+    } else if (wg256 >= 512) { M = 256; cfg = 1; }
+    else {
+      M = 64;
+      const long wg64_128 = (long)N * ((vox + 63) / 64) * ((p.Npad + 127) / 128);
+      cfg = (p.Npad >= 128 && wg64_128 >= 384) ? 2 : 3;
+    }
+  }
+  // tile dims (powers of two in x,y)
+  int TX = 32;
+  while (TX > 4 && TX / 2 >= Wo) TX /= 2;  // smallest pow2 >= Wo, capped at 32
+  if (geo == GEO_DOWN && TX > 8) TX = 8;
+  if (TX > M) TX = M;
+  int TY = 4;
+  while (TY > 1 && TY / 2 >= Ho) TY /= 2;
+  if (TX * TY > M) TY = M / TX;
+  int TZ = M / (TX * TY);
+  // prefer shrinking z extent into y when the volume is shallow in z
+  while (TZ > 1 && TZ / 2 >= Do && TY * 2 <= 64) { TZ /= 2; TY *= 2; }
+  p.lgTX = ilog2(TX); p.lgTY = ilog2(TY); p.TZ = TZ;
+  p.ntx = (Wo + TX - 1) / TX; p.nty = (Ho + TY - 1) / TY; p.ntz = (Do + TZ - 1) / TZ;
+  p.IX = (TX - 1) * p.s + (hi[2] - lo[2] + 1);
+  p.IY = (TY - 1) * p.s + (hi[1] - lo[1] + 1);
+  p.IZ = (TZ - 1) * p.s + (hi[0] - lo[0] + 1);
+  const int KGS = k1 ? 4 : 1;
+  const int S = KGS * 8 + 4;
+  for (int t = 0; t < nt; ++t) {
+    p.tap_lds[t] = (((offz[t] - lo[0]) * p.IY + (offy[t] - lo[1])) * p.IX + (offx[t] - lo[2])) * S;
+    p.tap_w[t] = tw[t];
+  }
+  for (int t = nt; t < 27; ++t) { p.tap_lds[t] = 0; p.tap_w[t] = 0; }
+
+  if (k1) {
+    switch (cfg) {
+      case 0: return launch_cfg<2, 1, 4, 1, 4>(p, stream);
+      case 1: return launch_cfg<2, 2, 4, 1, 4>(p, stream);
+      case 2: return launch_cfg<1, 2, 2, 2, 4>(p, stream);
+      case 3: return launch_cfg<1, 1, 2, 2, 4>(p, stream);
+      default: return launch_cfg<1, 1, 4, 1, 4>(p, stream);
+    }
+  }
+  switch (cfg) {
+    case 0: return launch_cfg<2, 1, 4, 1, 1>(p, stream);
+    case 1: return launch_cfg<2, 2, 4, 1, 1>(p, stream);
+    case 2: return launch_cfg<1, 2, 2, 2, 1>(p, stream);
+    case 3: return launch_cfg<1, 1, 2, 2, 1>(p, stream);
+    default: return launch_cfg<1, 1, 4, 1, 1>(p, stream);
+  }
+}
+
+static int geo_of_kind_fwd(int kind) {
+  switch (kind) {
+    case BTS_CONV_K1: return GEO_K1;
+    case BTS_CONV_K3S1: return GEO_S1;
+    case BTS_CONV_K3S2: return GEO_DOWN;
+    default: return GEO_UP;
+  }
+}
+
+// Forward. x:(N,D,H,W,Cin) ld=ldx ; y:(N,Do,Ho,Wo,Cout) ld=ldy with (Do,Ho,Wo) = (D,H,W) | (D/2,..) | (2D,..).
+extern "C" int bts_conv3d_fwd(int kind, const float* x, const float* wp_fwd, const float* bias, float* y, int N, int D,
+                              int H, int W, int Cin, int ldx, int Cout, int ldy, int flags, hipStream_t stream) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldy < Cout) return BTS_ERR_SHAPE;
+  int f = 0;
+  if (bias) f |= IG_FLAG_BIAS;
+  if (flags & BTS_CONV_FLAG_SIGMOID) f |= IG_FLAG_SIGMOID;
+  if (flags & BTS_CONV_FLAG_ACCUM) f |= IG_FLAG_ACCUM;
+  const int geo = geo_of_kind_fwd(kind);
+  if (geo == GEO_K1 || geo == GEO_S1)
+    return launch_igemm(geo, x, wp_fwd, bias, y, N, D, H, W, Cin, ldx, D, H, W, Cout, ldy, D, H, W, 0, 0, 0, f, stream);
+  if (geo == GEO_DOWN) {
+    if ((D | H | W) & 1) return BTS_ERR_SHAPE;  // TF 'same' pads (0,1) only for even sizes
+    return launch_igemm(geo, x, wp_fwd, bias, y, N, D, H, W, Cin, ldx, D / 2, H / 2, W / 2, Cout, ldy, D / 2, H / 2,
+                        W / 2, 0, 0, 0, f, stream);
+  }
+  for (int c = 0; c < 8; ++c) {
+    int r = launch_igemm(GEO_UP, x, wp_fwd, bias, y, N, D, H, W, Cin, ldx, D, H, W, Cout, ldy, 2 * D, 2 * H, 2 * W,
+                         (c >> 2) & 1, (c >> 1) & 1, c & 1, f, stream);
+    if (r != BTS_OK) return r;
+  }
+  return BTS_OK;
+}
+
+// Data gradient. dy has the forward output's shape, dx the forward input's shape (N,D,H,W,Cin).
+// wp_bwd is the BTS_ROLE_BWD_DATA packing. flags: BTS_CONV_FLAG_ACCUM adds into dx.
+extern "C" int bts_conv3d_bwd_data(int kind, const float* dy, const float* wp_bwd, float* dx, int N, int D, int H, int W,
+                                   int Cin, int lddx, int Cout, int lddy, int flags, hipStream_t stream) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || lddx < Cin || lddy < Cout) return BTS_ERR_SHAPE;
+  int f = 0;
+  if (flags & BTS_CONV_FLAG_ACCUM) f |= IG_FLAG_ACCUM;
+  if (kind == BTS_CONV_K1 || kind == BTS_CONV_K3S1)
+    return launch_igemm(kind == BTS_CONV_K1 ? GEO_K1 : GEO_S1, dy, wp_bwd, nullptr, dx, N, D, H, W, Cout, lddy, D, H, W,
+                        Cin, lddx, D, H, W, 0, 0, 0, f, stream);
+  if (kind == BTS_CONV_K3S2) {  // gather form over the fine grid's parity classes
+    if ((D | H | W) & 1) return BTS_ERR_SHAPE;
+    for (int c = 0; c < 8; ++c) {
+      int r = launch_igemm(GEO_UP, dy, wp_bwd, nullptr, dx, N, D / 2, H / 2, W / 2, Cout, lddy, D / 2, H / 2, W / 2, Cin,
+                           lddx, D, H, W, (c >> 2) & 1, (c >> 1) & 1, c & 1, f, stream);
+      if (r != BTS_OK) return r;
+    }
+    return BTS_OK;
+  }
+  // transposed conv: d/dx is the stride-2 'same' conv of dy (fine grid 2D x 2H x 2W) -> coarse grid
+  return launch_igemm(GEO_DOWN, dy, wp_bwd, nullptr, dx, N, 2 * D, 2 * H, 2 * W, Cout, lddy, D, H, W, Cin, lddx, D, H, W,
+                      0, 0, 0, f, stream);
+}

@@ -1,0 +1,379 @@
+// GroupNormalization (+ fused ReLU) forward and backward, HBM-bound streaming kernels for gfx950.
+// Reference: layers/group_norm.py:83-124 (call), :42-81 (build). Two semantics:
+//   BTS_GN_SLAB    channels_last path: the raw reshape [N,D,H,W,C]->[N,G,D,H,W,C/G] makes group g the g-th
+//                  contiguous 1/G chunk of each sample's flattened (D,H,W,C) memory; affine index for an
+//                  element with channel c is g*(C/G) + (c mod C/G)   (group_norm.py:93-100,115-120)
+//   BTS_GN_CHANNEL channels_first path: textbook GroupNorm, affine index = c
+// Statistics: population variance, eps inside the sqrt (group_norm.py:105-107). Sums are carried in fp64
+// (short fp32 runs per lane, fp64 across lanes/blocks) and combined in a fixed order, so results are
+// reproducible run to run; no float atomics.
+// x is always a dense NDHWC tensor (ld == C: the raw conv output); y / dy may be channel slices (ld >= C).
+#include "common.h"
+#include "bts_internal.h"
+
+#define GN_BLOCKS_MAX 256
+
+struct GnGeom {
+  int N, C, G, cg, mode;
+  long V;      // voxels per sample
+  long E;      // elements per sample = V*C
+  long L;      // elements per group = E/G
+  int B;       // blocks per reduction unit (slab: per (n,g); channel: per n)
+  long span;   // elements per block (multiple of 1024)
+};
+
+static int gn_geom(GnGeom& g, int N, long V, int C, int G, int mode) {
+  if (N <= 0 || V <= 0 || C <= 0 || G <= 0) return BTS_ERR_SHAPE;
+  if (C < G || C % G != 0) return BTS_ERR_SHAPE;  // group_norm.py:51-59 (ValueError at the Python layer)
+  if (C % 4 != 0 || (C & (C - 1)) != 0 || C > 1024) return BTS_ERR_UNSUPPORTED;
+  g.N = N; g.C = C; g.G = G; g.cg = C / G; g.mode = mode; g.V = V; g.E = V * C; g.L = g.E / G;
+  if (g.E % G != 0 || g.L % 4 != 0) return BTS_ERR_UNSUPPORTED;
+  const long unit = (mode == BTS_GN_SLAB) ? g.L : g.E;
+  const int units = (mode == BTS_GN_SLAB) ? N * G : N;
+  long B = (2048 + units - 1) / units;  // aim for ~2048 blocks in flight
+  if (B > GN_BLOCKS_MAX) B = GN_BLOCKS_MAX;
+  long span = (unit + B - 1) / B;
+  span = (span + 1023) / 1024 * 1024;
+  g.span = span;
+  g.B = (int)((unit + span - 1) / span);
+  return BTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward statistics
+// ---------------------------------------------------------------------------------------------
+// slab: grid (B, N*G). partial[(ng*B + b)*2 + {0,1}] = (sum x, sum x^2)
+__global__ __launch_bounds__(256) void gn_stats_slab_kernel(const float* __restrict__ x, double* partial, long L, long span) {
+  __shared__ double sh[8];
+  const long base = (long)blockIdx.y * L;
+  const long lo = (long)blockIdx.x * span;
+  long hi = lo + span;
+  if (hi > L) hi = L;
+  double s = 0.0, ss = 0.0;
+  for (long i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + base + i);
+    const float a = (v[0] + v[1]) + (v[2] + v[3]);
+    const float b = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    s += (double)a;
+    ss += (double)b;
+  }
+  const double rs = block_sum_f64(s, sh);
+  const double rss = block_sum_f64(ss, sh + 4);
+  if (threadIdx.x == 0) {
+    const long o = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+    partial[o] = rs;
+    partial[o + 1] = rss;
+  }
+}
+
+// channel: grid (B, N). partial[((n*B + b)*C + c)*2 + {0,1}] per channel
+__global__ __launch_bounds__(256) void gn_stats_channel_kernel(const float* __restrict__ x, double* partial, long E, long span, int C) {
+  __shared__ double sh[256 * 8];
+  const long base = (long)blockIdx.y * E;
+  const long lo = (long)blockIdx.x * span;
+  long hi = lo + span;
+  if (hi > E) hi = E;
+  double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+  for (long i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + base + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s[e] += (double)v[e]; ss[e] += (double)v[e] * (double)v[e]; }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { sh[threadIdx.x * 8 + e] = s[e]; sh[threadIdx.x * 8 + 4 + e] = ss[e]; }
+  __syncthreads();
+  const int P4 = C / 4;  // threads with equal (tid % P4) hold the same 4 channels (1024 % C == 0)
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int e = c & 3, r = c >> 2;
+    double a = 0.0, b = 0.0;
+    if (P4 <= 256)
+      for (int k = r; k < 256; k += P4) { a += sh[k * 8 + e]; b += sh[k * 8 + 4 + e]; }
+    const long o = (((long)blockIdx.y * gridDim.x + blockIdx.x) * C + c) * 2;
+    partial[o] = a;
+    partial[o + 1] = b;
+  }
+}
+
+// one thread per (n,g)
+__global__ void gn_stats_finalize_kernel(const double* partial, float* mean, float* rstd, int NG, int B, int C, int G,
+                                         int mode, double count, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NG) return;
+  double s = 0.0, ss = 0.0;
+  if (mode == BTS_GN_SLAB) {
+    for (int b = 0; b < B; ++b) { s += partial[((long)i * B + b) * 2]; ss += partial[((long)i * B + b) * 2 + 1]; }
+  } else {
+    const int n = i / G, g = i % G, cg = C / G;
+    for (int b = 0; b < B; ++b)
+      for (int c = g * cg; c < (g + 1) * cg; ++c) {
+        const long o = (((long)n * B + b) * C + c) * 2;
+        s += partial[o];
+        ss += partial[o + 1];
+      }
+  }
+  const double m = s / count;
+  double var = ss / count - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[i] = (float)m;
+  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+extern "C" long bts_gn_workspace(int N, long V, int C, int G, int mode) {
+  GnGeom g;
+  if (gn_geom(g, N, V, C, G, mode) != BTS_OK) return -1;
+  // forward: 2 doubles per block (slab) or 2*C per block (channel); backward: 2*C doubles per (n, block-row)
+  const long fwd = (mode == BTS_GN_SLAB) ? (long)N * G * g.B * 2 : (long)N * g.B * C * 2;
+  const long bwd = (mode == BTS_GN_SLAB) ? (long)N * G * g.B * g.cg * 2 : (long)N * g.B * C * 2;
+  return (fwd > bwd ? fwd : bwd) * 8 + 256;
+}
+
+extern "C" int bts_gn_stats(const float* x, float* mean, float* rstd, void* workspace, long workspace_bytes, int N,
+                            long V, int C, int G, int mode, float eps, hipStream_t stream) {
+  GnGeom g;
+  int r = gn_geom(g, N, V, C, G, mode);
+  if (r != BTS_OK) return r;
+  if (workspace_bytes < bts_gn_workspace(N, V, C, G, mode)) return BTS_ERR_WORKSPACE;
+  if (((uintptr_t)x) & 15) return BTS_ERR_ALIGN;
+  double* partial = reinterpret_cast<double*>(workspace);
+  if (mode == BTS_GN_SLAB) {
+    hipLaunchKernelGGL(gn_stats_slab_kernel, dim3(g.B, N * G), dim3(256), 0, stream, x, partial, g.L, g.span);
+  } else {
+    hipLaunchKernelGGL(gn_stats_channel_kernel, dim3(g.B, N), dim3(256), 0, stream, x, partial, g.E, g.span, C);
+  }
+  BTS_LAUNCH_CHECK();
+  const int NG = N * G;
+  hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3((NG + 63) / 64), dim3(64), 0, stream, partial, mean, rstd, NG, g.B,
+                     C, G, mode, (double)g.L, eps);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward apply (+ReLU), y may be strided
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       long total4, long E, long L, int C, int G, int cg, int ldy,
+                                                       int mode, int relu) {
+  for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total4; f += (long)gridDim.x * blockDim.x) {
+    const long i = f * 4;
+    const long n = i / E;
+    const long r = i - n * E;
+    const int c = (int)(r % C);
+    const long pix = i / C;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+    f32x4 o;
+    if (mode == BTS_GN_SLAB) {
+      const int g = (int)(r / L);
+      const float m = mean[n * G + g], rs = rstd[n * G + g];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int idx = g * cg + ((c + e) % cg);
+        o[e] = (v[e] - m) * rs * gamma[idx] + beta[idx];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int g = (c + e) / cg;
+        o[e] = (v[e] - mean[n * G + g]) * rstd[n * G + g] * gamma[c + e] + beta[c + e];
+      }
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(y + pix * ldy + c) = o;
+  }
+}
+
+extern "C" int bts_gn_apply(const float* x, float* y, const float* gamma, const float* beta, const float* mean,
+                            const float* rstd, int N, long V, int C, int ldy, int G, int mode, int relu,
+                            hipStream_t stream) {
+  GnGeom g;
+  int r = gn_geom(g, N, V, C, G, mode);
+  if (r != BTS_OK) return r;
+  if (ldy < C || ldy % 4 != 0 || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 15)) return BTS_ERR_ALIGN;
+  const long total4 = (long)N * g.E / 4;
+  int blocks = (int)((total4 + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, stream, x, y, gamma, beta, mean, rstd, total4, g.E,
+                     g.L, C, G, g.cg, ldy, mode, relu);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward (SURVEY Appendix A'): with xh = (x-mean)*rstd, y = gamma_b*xh + beta_b, dyE = dy * [y>0] (if relu)
+//   A_j = sum dyE*xh , B_j = sum dyE  per (n, g, j = c mod cg)      -> dgamma[idx] += sum_n A_j, dbeta likewise
+//   c1 = sum_j gamma_j B_j / L , c2 = sum_j gamma_j A_j / L
+//   dx = (dyE*gamma_b - c1 - xh*c2) * rstd
+// ---------------------------------------------------------------------------------------------
+// slab: grid (B, N*G), partial[((ng*B + b)*cg + j)*2 + {A,B}] ; channel: grid (B, N), partial[((n*B+b)*C + c)*2 ..]
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            double* partial, long E, long L, long span, int C, int G,
+                                                            int cg, int lddy, int mode, int relu) {
+  __shared__ double sh[256 * 8];
+  const bool slab = (mode == BTS_GN_SLAB);
+  const int n = slab ? blockIdx.y / G : blockIdx.y;
+  const int gs = slab ? blockIdx.y % G : 0;
+  const long unitBase = slab ? (long)gs * L : 0;  // offset inside the sample
+  const long unitLen = slab ? L : E;
+  const long lo = (long)blockIdx.x * span;
+  long hi = lo + span;
+  if (hi > unitLen) hi = unitLen;
+  double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+  for (long i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+    const long r = unitBase + i;  // element index inside the sample
+    const int c = (int)(r % C);
+    const long pix = (long)n * (E / C) + r / C;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (long)n * E + r);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dy + pix * lddy + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int g = slab ? gs : (c + e) / cg;
+      const int idx = slab ? gs * cg + ((c + e) % cg) : (c + e);
+      const float xh = (v[e] - mean[n * G + g]) * rstd[n * G + g];
+      float de = d[e];
+      if (relu && !(xh * gamma[idx] + beta[idx] > 0.f)) de = 0.f;
+      a[e] += (double)(de * xh);
+      b[e] += (double)de;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { sh[threadIdx.x * 8 + e] = a[e]; sh[threadIdx.x * 8 + 4 + e] = b[e]; }
+  __syncthreads();
+  // a thread's 4 elements sit at (unitBase + lo + 4*tid + e + 1024*k): channel phase is fixed per thread because
+  // 1024 % C == 0, span % 1024 == 0 and (slab) L % cg == 0. Output period P: cg (slab, j = c mod cg) or C (channel).
+  const int P = slab ? cg : C;
+  for (int j = threadIdx.x; j < P; j += 256) {
+    double sa = 0.0, sb = 0.0;
+    if (P >= 4) {
+      const int e = j & 3, rr = j >> 2, P4 = P >> 2;
+      for (int k = rr; k < 256; k += P4) { sa += sh[k * 8 + e]; sb += sh[k * 8 + 4 + e]; }
+    } else {  // P == 2 (or 1): elements e with (e % P) == j of every thread
+      for (int k = 0; k < 256; ++k)
+        for (int e = j; e < 4; e += P) { sa += sh[k * 8 + e]; sb += sh[k * 8 + 4 + e]; }
+    }
+    const long o = (((long)blockIdx.y * gridDim.x + blockIdx.x) * P + j) * 2;
+    partial[o] = sa;
+    partial[o + 1] = sb;
+  }
+}
+
+// one block; thread per affine index idx (C of them): reduces over blocks and samples, writes dgamma/dbeta,
+// then thread per (n,g) computes c1,c2.
+__global__ void gn_bwd_finalize_kernel(const double* partial, const float* gamma, float* dgamma, float* dbeta,
+                                       float* c1, float* c2, double* scratch /*N*C*2*/, int N, int B, int C, int G,
+                                       int mode, double L, int accum) {
+  const int cg = C / G;
+  const bool slab = (mode == BTS_GN_SLAB);
+  // per (n, idx): A, B summed over blocks
+  for (int t = threadIdx.x; t < N * C; t += blockDim.x) {
+    const int n = t / C, idx = t % C;
+    double sa = 0.0, sb = 0.0;
+    if (slab) {
+      const int g = idx / cg, j = idx % cg;
+      for (int b = 0; b < B; ++b) {
+        const long o = ((((long)n * G + g) * B + b) * cg + j) * 2;
+        sa += partial[o];
+        sb += partial[o + 1];
+      }
+    } else {
+      for (int b = 0; b < B; ++b) {
+        const long o = (((long)n * B + b) * C + idx) * 2;
+        sa += partial[o];
+        sb += partial[o + 1];
+      }
+    }
+    scratch[t * 2] = sa;
+    scratch[t * 2 + 1] = sb;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < C; idx += blockDim.x) {
+    double sa = 0.0, sb = 0.0;
+    for (int n = 0; n < N; ++n) { sa += scratch[(n * C + idx) * 2]; sb += scratch[(n * C + idx) * 2 + 1]; }
+    if (dgamma) dgamma[idx] = accum ? dgamma[idx] + (float)sa : (float)sa;
+    if (dbeta) dbeta[idx] = accum ? dbeta[idx] + (float)sb : (float)sb;
+  }
+  for (int t = threadIdx.x; t < N * G; t += blockDim.x) {
+    const int n = t / G, g = t % G;
+    double s1 = 0.0, s2 = 0.0;
+    for (int j = 0; j < cg; ++j) {
+      const int idx = g * cg + j;
+      s1 += (double)gamma[idx] * scratch[(n * C + idx) * 2 + 1];
+      s2 += (double)gamma[idx] * scratch[(n * C + idx) * 2];
+    }
+    c1[t] = (float)(s1 / L);
+    c2[t] = (float)(s2 / L);
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ dx, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ c1,
+                                                           const float* __restrict__ c2, long total4, long E, long L,
+                                                           int C, int G, int cg, int lddy, int mode, int relu) {
+  for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total4; f += (long)gridDim.x * blockDim.x) {
+    const long i = f * 4;
+    const long n = i / E;
+    const long r = i - n * E;
+    const int c = (int)(r % C);
+    const long pix = i / C;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dy + pix * lddy + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int g = (mode == BTS_GN_SLAB) ? (int)(r / L) : (c + e) / cg;
+      const int idx = (mode == BTS_GN_SLAB) ? g * cg + ((c + e) % cg) : (c + e);
+      const float rs = rstd[n * G + g];
+      const float xh = (v[e] - mean[n * G + g]) * rs;
+      float de = d[e];
+      if (relu && !(xh * gamma[idx] + beta[idx] > 0.f)) de = 0.f;
+      o[e] = (de * gamma[idx] - c1[n * G + g] - xh * c2[n * G + g]) * rs;
+    }
+    *reinterpret_cast<f32x4*>(dx + i) = o;
+  }
+}
+
+// gn backward: dx dense (ld == C). small_ws: >= (N*G*2 floats + N*C*2 doubles) scratch inside workspace tail.
+extern "C" int bts_gn_bwd(const float* x, const float* dy, float* dx, const float* gamma, const float* beta,
+                          const float* mean, const float* rstd, float* dgamma, float* dbeta, void* workspace,
+                          long workspace_bytes, int N, long V, int C, int lddy, int G, int mode, int relu,
+                          int accumulate_params, hipStream_t stream) {
+  GnGeom g;
+  int r = gn_geom(g, N, V, C, G, mode);
+  if (r != BTS_OK) return r;
+  if (lddy < C || lddy % 4 != 0 || (((uintptr_t)x) & 15) || (((uintptr_t)dy) & 15) || (((uintptr_t)dx) & 15)) return BTS_ERR_ALIGN;
+  const long part_bytes = bts_gn_workspace(N, V, C, G, mode);
+  const long extra = (long)N * C * 2 * 8 + (long)N * G * 2 * 4 + 64;
+  if (workspace_bytes < part_bytes + extra) return BTS_ERR_WORKSPACE;
+  double* partial = reinterpret_cast<double*>(workspace);
+  double* scratch = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + ((part_bytes + 15) & ~15L));
+  float* c1 = reinterpret_cast<float*>(scratch + (long)N * C * 2);
+  float* c2 = c1 + (long)N * G;
+  const bool slab = (mode == BTS_GN_SLAB);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(g.B, slab ? N * G : N), dim3(256), 0, stream, x, dy, gamma, beta, mean,
+                     rstd, partial, g.E, g.L, g.span, C, G, g.cg, lddy, mode, relu);
+  BTS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, gamma, dgamma, dbeta, c1, c2,
+                     scratch, N, g.B, C, G, mode, (double)g.L, accumulate_params);
+  BTS_LAUNCH_CHECK();
+  const long total4 = (long)N * g.E / 4;
+  int blocks = (int)((total4 + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, stream, x, dy, dx, gamma, beta, mean, rstd, c1, c2,
+                     total4, g.E, g.L, C, G, g.cg, lddy, mode, relu);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+extern "C" long bts_gn_bwd_workspace(int N, long V, int C, int G, int mode) {
+  const long p = bts_gn_workspace(N, V, C, G, mode);
+  if (p < 0) return -1;
+  return ((p + 15) & ~15L) + (long)N * C * 2 * 8 + (long)N * G * 2 * 4 + 64;
+}

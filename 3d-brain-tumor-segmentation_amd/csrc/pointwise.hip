@@ -1,0 +1,154 @@
+// Element-wise pieces of the hot path (all HBM-bound, 16 B per lane, grid-stride):
+//   dropout on the input volume           layers/encoder.py:39,71   (y = x*mask/(1-rate), mask injectable)
+//   counter-based uniform / normal draws  (tf.random.normal in layers/vae.py:12; Dropout's mask)
+//   VAE reparameterisation z = mu + exp(0.5*logvar)*eps   layers/vae.py:9-13,123-125  (+ backward)
+//   small utilities (fill, axpy, strided add/copy, scalar add) used by the gradient tape.
+#include "common.h"
+#include "bts_internal.h"
+
+static inline int ew_blocks(long n, int per_thread = 1) {
+  long b = (n / per_thread + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > 8192) b = 8192;
+  return (int)b;
+}
+
+__device__ __forceinline__ uint32_t mix32(uint64_t z) {  // splitmix64 finaliser
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+__device__ __forceinline__ float u01(uint64_t seed, uint64_t i) {  // [0,1)
+  return (float)(mix32(seed * 0xD1342543DE82EF95ull + i) >> 8) * (1.0f / 16777216.0f);
+}
+
+__global__ void dropout_mask_kernel(uint8_t* mask, long n, float rate, uint64_t seed) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    mask[i] = u01(seed, (uint64_t)i) >= rate ? 1 : 0;
+}
+extern "C" int bts_dropout_mask(uint8_t* mask, long n, float rate, uint64_t seed, hipStream_t stream) {
+  if (n <= 0) return BTS_ERR_SHAPE;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, mask, n, rate, seed);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+__global__ void dropout_apply_kernel(const float* x, const uint8_t* mask, float* y, long n, float scale) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = mask[i] ? x[i] * scale : 0.f;
+}
+// y = x * mask / (1 - rate)
+extern "C" int bts_dropout_apply(const float* x, const uint8_t* mask, float* y, long n, float rate, hipStream_t stream) {
+  if (n <= 0 || rate < 0.f || rate >= 1.f) return BTS_ERR_SHAPE;
+  hipLaunchKernelGGL(dropout_apply_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, x, mask, y, n, 1.0f / (1.0f - rate));
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+__global__ void normal_kernel(float* out, long n, uint64_t seed) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float u1 = fmaxf(u01(seed, 2 * (uint64_t)i), 5.9604645e-8f);
+    const float u2 = u01(seed, 2 * (uint64_t)i + 1);
+    out[i] = sqrtf(-2.f * logf(u1)) * cosf(6.28318530718f * u2);
+  }
+}
+extern "C" int bts_normal(float* out, long n, uint64_t seed, hipStream_t stream) {
+  if (n <= 0) return BTS_ERR_SHAPE;
+  hipLaunchKernelGGL(normal_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, out, n, seed);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+// proj: (N, 2L) = [z_mean | z_logvar]; z: (N, L)
+__global__ void vae_sample_fwd_kernel(const float* proj, const float* eps, float* z, int N, int L) {
+  const int total = N * L;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int n = i / L, k = i % L;
+    z[i] = proj[n * 2 * L + k] + expf(0.5f * proj[n * 2 * L + L + k]) * eps[i];
+  }
+}
+extern "C" int bts_vae_sample_fwd(const float* proj, const float* eps, float* z, int N, int L, hipStream_t stream) {
+  if (N <= 0 || L <= 0) return BTS_ERR_SHAPE;
+  hipLaunchKernelGGL(vae_sample_fwd_kernel, dim3(ew_blocks((long)N * L)), dim3(256), 0, stream, proj, eps, z, N, L);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+// dproj[:, :L] += dz ; dproj[:, L:] += dz * 0.5*exp(0.5*logvar)*eps
+__global__ void vae_sample_bwd_kernel(const float* proj, const float* eps, const float* dz, float* dproj, int N, int L) {
+  const int total = N * L;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int n = i / L, k = i % L;
+    dproj[n * 2 * L + k] += dz[i];
+    dproj[n * 2 * L + L + k] += dz[i] * 0.5f * expf(0.5f * proj[n * 2 * L + L + k]) * eps[i];
+  }
+}
+extern "C" int bts_vae_sample_bwd(const float* proj, const float* eps, const float* dz, float* dproj, int N, int L,
+                                  hipStream_t stream) {
+  if (N <= 0 || L <= 0) return BTS_ERR_SHAPE;
+  hipLaunchKernelGGL(vae_sample_bwd_kernel, dim3(ew_blocks((long)N * L)), dim3(256), 0, stream, proj, eps, dz, dproj, N, L);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+__global__ void fill_kernel(float* p, long n, float v) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+extern "C" int bts_fill(float* p, long n, float v, hipStream_t stream) {
+  if (n <= 0) return BTS_OK;
+  hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, p, n, v);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+__global__ void axpy_kernel(float* y, const float* x, long n, float a) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = fmaf(a, x[i], y[i]);
+}
+extern "C" int bts_axpy(float* y, const float* x, long n, float a, hipStream_t stream) {
+  if (n <= 0) return BTS_OK;
+  hipLaunchKernelGGL(axpy_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, y, x, n, a);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+// dst[r*ldd + c] (+)= src[r*lds + c]   (channel-slice copy / accumulate; virtual-concat bookkeeping)
+__global__ void add_strided_kernel(float* dst, const float* src, long rows, int C, int ldd, int lds_, int accum) {
+  const long total = rows * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    const float v = src[r * lds_ + c];
+    float* d = dst + r * ldd + c;
+    *d = accum ? *d + v : v;
+  }
+}
+extern "C" int bts_add_strided(float* dst, const float* src, long rows, int C, int ldd, int lds_, int accumulate,
+                               hipStream_t stream) {
+  if (rows <= 0 || C <= 0 || ldd < C || lds_ < C) return BTS_ERR_SHAPE;
+  hipLaunchKernelGGL(add_strided_kernel, dim3(ew_blocks(rows * C)), dim3(256), 0, stream, dst, src, rows, C, ldd, lds_, accumulate);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+__global__ void scalar_lincomb_kernel(float* out, const float* a, const float* b, float ca, float cb) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = ca * a[0] + (b ? cb * b[0] : 0.f);
+}
+// out = ca*a + cb*b on 1-element device buffers (loss + sum(model.losses), train.py:145-146)
+extern "C" int bts_scalar_lincomb(float* out, const float* a, const float* b, float ca, float cb, hipStream_t stream) {
+  hipLaunchKernelGGL(scalar_lincomb_kernel, dim3(1), dim3(64), 0, stream, out, a, b, ca, cb);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+// dx = dy * [y > 0]   (stand-alone ReLU gradient, Dense activation='relu' in layers/vae.py:105-109)
+__global__ void relu_bwd_kernel(const float* y, const float* dy, float* dx, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+extern "C" int bts_relu_bwd(const float* y, const float* dy, float* dx, long n, hipStream_t stream) {
+  if (n <= 0) return BTS_OK;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, y, dy, dx, n);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}

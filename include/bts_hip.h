@@ -1,0 +1,141 @@
+/* bts_hip.h -- C ABI of the MI355X (gfx950) 3D U-Net+VAE segmentation engine (libbts_hip.so).
+ *
+ * Every entry point: plain pointers + sizes, returns int status (0 = ok, >0 = hipError_t, <0 = engine
+ * code below), enqueues asynchronously on the caller's hipStream_t, never allocates, never synchronises.
+ * Activations are fp32 NDHWC with an explicit pixel stride `ld` (floats between consecutive voxels), so
+ * a tensor may be a channel slice of a wider slab (virtual Concatenate).
+ * Weights are passed in the reference's Keras layouts and re-packed by bts_conv_pack().
+ *
+ * The reference (vliu15/3d-brain-tumor-segmentation) has no FFI of its own: its boundary is the Keras
+ * layer protocol. Each function below cites the reference call site whose arithmetic it replaces.
+ */
+#ifndef BTS_HIP_H
+#define BTS_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* bts_stream_t; /* == hipStream_t */
+
+#define BTS_OK 0
+#define BTS_ERR_SHAPE (-1)
+#define BTS_ERR_ALIGN (-2)
+#define BTS_ERR_UNSUPPORTED (-3)
+#define BTS_ERR_WORKSPACE (-4)
+
+/* convolution kinds */
+#define BTS_CONV_K1 0    /* Conv3D k=1 s=1            layers/resnet.py:30-37, layers/decoder.py:55-63 */
+#define BTS_CONV_K3S1 1  /* Conv3D k=3 s=1 'same'     layers/resnet.py:80-87,96-103, layers/vae.py:92-99 */
+#define BTS_CONV_K3S2 2  /* Conv3D k=3 s=2 'same'     layers/downsample.py:28-35 (even sizes: pad (0,1)) */
+#define BTS_CONV_K3S2T 3 /* Conv3DTranspose k=3 s=2   layers/upsample.py:28-33 (output 2x, tap at 2n cropped) */
+#define BTS_ROLE_FWD 0
+#define BTS_ROLE_BWD_DATA 1
+#define BTS_CONV_FLAG_SIGMOID 1 /* fused activation='sigmoid' (decoder.py:60) */
+#define BTS_CONV_FLAG_ACCUM 2   /* add into the destination instead of overwriting */
+
+/* GroupNormalization modes (layers/group_norm.py:83-124) */
+#define BTS_GN_SLAB 0    /* channels_last reference semantics: groups = contiguous 1/G chunks of (D,H,W,C) */
+#define BTS_GN_CHANNEL 1 /* channels_first reference semantics (true GroupNorm) on NDHWC memory */
+
+/* ---- declarations are appended below, grouped by reference call site ---- */
+
+/* ===== convolutions (layers/resnet.py:30-37,80-87,96-103; downsample.py:28-35; upsample.py:28-33; decoder.py:55-63; vae.py:92-99) ===== */
+/* number of floats of the packed weight image for (kind, role); Cin is the slab (folded) input-channel count */
+long bts_conv_packed_floats(int kind, int role, int Cin, int Cout);
+/* w: reference Keras layout ((kd,kh,kw,Cin_ref,Cout) or, for K3S2T, (kd,kh,kw,Cout,Cin_ref)); wp: packed image.
+ * Cin_slab + dup_shift == Cin_ref. dup_shift>0 folds the encoder's duplicated dense-connection slice
+ * (encoder.py:83-87: inputs [o_{j-1}, o_0..o_{j-1}] -> slab [o_0..o_{j-1}], dup_start = (j-1)*F, dup_shift = F). */
+int bts_conv_pack(int kind, int role, const float* w, float* wp, int Cin_ref, int Cout, int Cin_slab, int dup_start,
+                  int dup_shift, bts_stream_t stream);
+/* y = act(conv(x) + bias). x (N,D,H,W,Cin) stride ldx; y (N,D',H',W',Cout) stride ldy; D' = D | D/2 | 2D. */
+int bts_conv3d_fwd(int kind, const float* x, const float* wp_fwd, const float* bias, float* y, int N, int D, int H, int W,
+                   int Cin, int ldx, int Cout, int ldy, int flags, bts_stream_t stream);
+/* dx (+)= conv^T(dy). (D,H,W) are the forward INPUT dims. Replaces tf.GradientTape for these ops (train.py:142-151). */
+int bts_conv3d_bwd_data(int kind, const float* dy, const float* wp_bwd, float* dx, int N, int D, int H, int W, int Cin,
+                        int lddx, int Cout, int lddy, int flags, bts_stream_t stream);
+long bts_conv3d_bwd_weight_workspace(int kind, int N, int D, int H, int W, int Cin, int Cout);
+/* dw in the reference layout (Cin_ref = Cin + dup_shift); db (may be NULL; not produced for K3S2T: use bts_colsum). */
+int bts_conv3d_bwd_weight(int kind, const float* x, const float* dy, float* dw, float* db, void* workspace,
+                          long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int lddy,
+                          int dup_start, int dup_shift, int accumulate, bts_stream_t stream);
+
+/* ===== GroupNormalization (layers/group_norm.py:83-124) ===== */
+long bts_gn_workspace(int N, long V, int C, int G, int mode);
+long bts_gn_bwd_workspace(int N, long V, int C, int G, int mode);
+/* mean,rstd: (N*G) floats. x dense NDHWC (ld == C). */
+int bts_gn_stats(const float* x, float* mean, float* rstd, void* workspace, long workspace_bytes, int N, long V, int C,
+                 int G, int mode, float eps, bts_stream_t stream);
+/* y = [relu](gamma_b*(x-mean)*rstd + beta_b); y may be a channel slice (ldy >= C). */
+int bts_gn_apply(const float* x, float* y, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                 int N, long V, int C, int ldy, int G, int mode, int relu, bts_stream_t stream);
+int bts_gn_bwd(const float* x, const float* dy, float* dx, const float* gamma, const float* beta, const float* mean,
+               const float* rstd, float* dgamma, float* dbeta, void* workspace, long workspace_bytes, int N, long V, int C,
+               int lddy, int G, int mode, int relu, int accumulate_params, bts_stream_t stream);
+
+/* ===== squeeze-excitation gate + block epilogue (layers/resnet.py:116-138) ===== */
+long bts_colsum_workspace(int N, long rows, int C);
+int bts_colsum(const float* x, float* out, void* workspace, long workspace_bytes, int N, long rows, int C, int ld,
+               float scale, int sum_over_n, int accumulate, bts_stream_t stream);
+int bts_se_mlp_fwd(const float* gap, const float* w1, const float* w2, float* h, float* ch, int N, int F, int R,
+                   bts_stream_t stream);
+/* out = res*(sigmoid(res.wsp)+ch) + relu(GN2(c2)); c2 may be NULL (gate only). sp: (N*V) saved for backward. */
+int bts_block_epilogue_fwd(const float* res, const float* c2, float* out, float* sp, const float* wsp, const float* ch,
+                           const float* gamma, const float* beta, const float* mean, const float* rstd, int N, long V,
+                           int F, int ldo, int G, int mode, bts_stream_t stream);
+long bts_se_bwd_workspace(int N, long V, int F, int R);
+int bts_se_bwd(const float* dout, const float* res, const float* sp, const float* gap, const float* h, const float* ch,
+               const float* w1, const float* w2, const float* wsp, float* dres, float* ds, float* dgap, float* dw1,
+               float* dw2, float* dwsp, void* workspace, long workspace_bytes, int N, long V, int F, int R, int lddo,
+               int accumulate_params, bts_stream_t stream);
+
+/* ===== element-wise (layers/encoder.py:39,71; layers/vae.py:9-13) ===== */
+int bts_dropout_mask(uint8_t* mask, long n, float rate, uint64_t seed, bts_stream_t stream);
+int bts_dropout_apply(const float* x, const uint8_t* mask, float* y, long n, float rate, bts_stream_t stream);
+int bts_normal(float* out, long n, uint64_t seed, bts_stream_t stream);
+int bts_vae_sample_fwd(const float* proj, const float* eps, float* z, int N, int L, bts_stream_t stream);
+int bts_vae_sample_bwd(const float* proj, const float* eps, const float* dz, float* dproj, int N, int L, bts_stream_t stream);
+int bts_fill(float* p, long n, float v, bts_stream_t stream);
+int bts_axpy(float* y, const float* x, long n, float a, bts_stream_t stream);
+int bts_add_strided(float* dst, const float* src, long rows, int C, int ldd, int lds_, int accumulate, bts_stream_t stream);
+int bts_scalar_lincomb(float* out, const float* a, const float* b, float ca, float cb, bts_stream_t stream);
+int bts_relu_bwd(const float* y, const float* dy, float* dx, long n, bts_stream_t stream);
+
+/* ===== Dense (layers/vae.py:61-64,105-109) ===== */
+long bts_dense_workspace(int N, int in, int out);
+int bts_dense_fwd(const float* x, const float* w, const float* bias, float* y, void* workspace, long workspace_bytes, int N,
+                  int in, int out, int relu, bts_stream_t stream);
+int bts_dense_bwd(const float* x, const float* w, const float* g, float* dx, float* dw, float* db, int N, int in, int out,
+                  int accumulate_dx, int accumulate_params, bts_stream_t stream);
+
+/* ===== loss / metric / regulariser (util.py:13-24,35-57; train.py:146) ===== */
+long bts_loss_workspace(void);
+/* sums: 3C+4 doubles = I[C],P[C],T[C], sum (x-y_vae)^2, KL sum, numel_x, numel_z -- all-reduce these for data parallel */
+int bts_loss_sums(const float* y_pred, const float* y, const float* x, const float* y_vae, const float* proj, double* sums,
+                  void* workspace, long workspace_bytes, int N, long V, int C, int ldp, int ldy, int Cx, int ldx, int ldv,
+                  int Lz, bts_stream_t stream);
+int bts_loss_value(const double* sums, float* loss, float* parts, int C, int has_vae, bts_stream_t stream);
+int bts_loss_bwd(const float* y_pred, const float* y, const float* x, const float* y_vae, const float* proj,
+                 const double* sums, const float* gscale, float* dlogit, float* dyvae, float* dproj, int N, long V, int C,
+                 int ldp, int ldy, int Cx, int ldx, int ldv, int Lz, int through_sigmoid, bts_stream_t stream);
+/* table: (cells*C*3) doubles, cells = W if channels_last_axes else 1; labels: (N*V) uint8 or NULL */
+int bts_dice_metric_sums(const float* y_true, const float* y_pred, uint8_t* labels, double* table, int N, long V, int W,
+                         int C, int ldt, int ldp, int channels_last_axes, bts_stream_t stream);
+int bts_dice_metric_value(const double* table, float* out, int W, int C, int channels_last_axes, bts_stream_t stream);
+long bts_l2_workspace(void);
+int bts_l2_reg_fwd(const float* params, const long* off, const long* len, const float* coef, int nranges, float* out,
+                   void* workspace, long workspace_bytes, bts_stream_t stream);
+int bts_l2_reg_bwd(const float* params, float* grads, const long* off, const long* len, const float* coef, int nranges,
+                   const float* gscale, bts_stream_t stream);
+
+/* ===== optimiser (util.py:60-84; Keras Adam, epsilon un-corrected) ===== */
+int bts_adam_tf_step(float* p, const float* g, float* m, float* v, long n, float lr_t, float beta1, float beta2, float eps,
+                     float gmul, bts_stream_t stream);
+
+/* library identification */
+const char* bts_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BTS_HIP_H */
