@@ -152,3 +152,21 @@ extern "C" int bts_relu_bwd(const float* y, const float* dy, float* dx, long n, 
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
+
+// dx = dy * y*(1-y)   (gradient through the fused activation='sigmoid' of the output conv, decoder.py:60)
+__global__ void sigmoid_bwd_kernel(const float* y, const float* dy, float* dx, long rows, int C, int ldy, int lddy) {
+  const long n = rows * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    const float v = y[r * ldy + c];
+    dx[i] = dy[r * lddy + c] * v * (1.f - v);
+  }
+}
+extern "C" int bts_sigmoid_bwd(const float* y, const float* dy, float* dx, long rows, int C, int ldy, int lddy,
+                               hipStream_t stream) {
+  if (rows <= 0 || C <= 0) return BTS_ERR_SHAPE;
+  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(ew_blocks(rows * C)), dim3(256), 0, stream, y, dy, dx, rows, C, ldy, lddy);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}

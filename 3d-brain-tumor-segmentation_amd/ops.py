@@ -1,0 +1,359 @@
+"""Thin, checked Python wrappers over the C ABI (include/bts_hip.h): torch tensors in, raw pointers out.
+
+torch is used for device memory and the current HIP stream only.  Every function enqueues on
+torch.cuda.current_stream() and raises RuntimeError on a non-zero status -- there is no CPU path.
+Activations are [N,D,H,W,C] fp32 tensors whose last-dim stride is 1 and whose voxel stride (`ld`) may exceed C
+(channel slices of a slab).
+"""
+import ctypes
+
+import torch
+
+from ._lib import lib
+
+K1, K3S1, K3S2, K3S2T = 0, 1, 2, 3
+ROLE_FWD, ROLE_BWD = 0, 1
+FLAG_SIGMOID, FLAG_ACCUM = 1, 2
+GN_SLAB, GN_CHANNEL = 0, 1
+
+_workspaces = {}
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def workspace(nbytes, device):
+    """one grow-only scratch buffer per device; all users are ordered on the same stream"""
+    key = (device.type, device.index)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def _check(t, name='tensor'):
+    if not t.is_cuda:
+        raise RuntimeError('%s must live on the GPU (no CPU fallback exists for the product path)' % name)
+    if t.dtype != torch.float32:
+        raise RuntimeError('%s must be float32' % name)
+
+
+def ld_of(t):
+    """voxel stride of an NDHWC view (validates that the view is a channel slice of a dense NDHWC buffer)"""
+    _check(t)
+    if t.dim() != 5 or t.stride(4) != 1 and t.shape[4] != 1:
+        raise RuntimeError('expected an [N,D,H,W,C] tensor with unit channel stride, got strides %s' % (t.stride(),))
+    n, d, h, w, c = t.shape
+    ld = t.stride(3)
+    if w == 1:
+        ld = t.stride(2) if h > 1 else (t.stride(1) if d > 1 else (t.stride(0) if n > 1 else c))
+    exp = (d * h * w * ld, h * w * ld, w * ld, ld)
+    for i in range(4):
+        if t.shape[i] > 1 and t.stride(i) != exp[i]:
+            raise RuntimeError('tensor is not a channel slice of a dense NDHWC buffer: strides %s' % (t.stride(),))
+    if ld < c:
+        raise RuntimeError('bad voxel stride')
+    return ld
+
+
+def conv_kind_taps(kind):
+    return 1 if kind == K1 else 27
+
+
+def conv_pack(kind, role, w, cin_ref, cout, cin_slab=None, dup_start=0, dup_shift=0):
+    """reference-layout kernel -> packed image for the implicit-GEMM kernel"""
+    _check(w, 'kernel')
+    cin_slab = cin_ref if cin_slab is None else cin_slab
+    n = lib().query('bts_conv_packed_floats', kind, role, cin_slab, cout)
+    wp = torch.empty(n, dtype=torch.float32, device=w.device)
+    lib().call('bts_conv_pack', kind, role, _p(w.contiguous()), _p(wp), cin_ref, cout, cin_slab, dup_start, dup_shift,
+               _stream())
+    return wp
+
+
+def conv_out_shape(kind, x_shape, cout):
+    n, d, h, w, _ = x_shape
+    if kind == K3S2:
+        return (n, d // 2, h // 2, w // 2, cout)
+    if kind == K3S2T:
+        return (n, 2 * d, 2 * h, 2 * w, cout)
+    return (n, d, h, w, cout)
+
+
+def conv_fwd(kind, x, wp, bias, cout, out=None, sigmoid=False):
+    n, d, h, w, cin = x.shape
+    if out is None:
+        out = torch.empty(conv_out_shape(kind, x.shape, cout), dtype=torch.float32, device=x.device)
+    lib().call('bts_conv3d_fwd', kind, _p(x), _p(wp), _p(bias), _p(out), n, d, h, w, cin, ld_of(x), cout, ld_of(out),
+               FLAG_SIGMOID if sigmoid else 0, _stream())
+    return out
+
+
+def conv_bwd_data(kind, dy, wp_bwd, dx, accumulate):
+    """dx: [N,D,H,W,Cin] view of the forward input's gradient"""
+    n, d, h, w, cin = dx.shape
+    cout = dy.shape[4]
+    lib().call('bts_conv3d_bwd_data', kind, _p(dy), _p(wp_bwd), _p(dx), n, d, h, w, cin, ld_of(dx), cout, ld_of(dy),
+               FLAG_ACCUM if accumulate else 0, _stream())
+    return dx
+
+
+def conv_bwd_weight(kind, x, dy, dw, db, dup_start=0, dup_shift=0, accumulate=False):
+    n, d, h, w, cin = x.shape
+    cout = dy.shape[4]
+    nb = lib().query('bts_conv3d_bwd_weight_workspace', kind, n, d, h, w, cin, cout)
+    ws = workspace(nb, x.device)
+    lib().call('bts_conv3d_bwd_weight', kind, _p(x), _p(dy), _p(dw), _p(db), _p(ws), nb, n, d, h, w, cin, ld_of(x), cout,
+               ld_of(dy), dup_start, dup_shift, 1 if accumulate else 0, _stream())
+
+
+def gn_stats(x, groups, mode, eps=1e-5):
+    """x dense [N,D,H,W,C] -> (mean, rstd) each (N*G,)"""
+    if not x.is_contiguous():
+        raise RuntimeError('GroupNormalization statistics need a dense tensor')
+    n, c = x.shape[0], x.shape[4]
+    v = x.shape[1] * x.shape[2] * x.shape[3]
+    nb = lib().query('bts_gn_workspace', n, v, c, groups, mode)
+    ws = workspace(nb, x.device)
+    mean = torch.empty(n * groups, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    lib().call('bts_gn_stats', _p(x), _p(mean), _p(rstd), _p(ws), nb, n, v, c, groups, mode, eps, _stream())
+    return mean, rstd
+
+
+def gn_apply(x, gamma, beta, mean, rstd, groups, mode, relu, out=None):
+    n, c = x.shape[0], x.shape[4]
+    v = x.shape[1] * x.shape[2] * x.shape[3]
+    if out is None:
+        out = torch.empty_like(x)
+    lib().call('bts_gn_apply', _p(x), _p(out), _p(gamma), _p(beta), _p(mean), _p(rstd), n, v, c, ld_of(out), groups, mode,
+               1 if relu else 0, _stream())
+    return out
+
+
+def gn_bwd(x, dy, gamma, beta, mean, rstd, dgamma, dbeta, groups, mode, relu, accumulate_params=False):
+    n, c = x.shape[0], x.shape[4]
+    v = x.shape[1] * x.shape[2] * x.shape[3]
+    nb = lib().query('bts_gn_bwd_workspace', n, v, c, groups, mode)
+    ws = workspace(nb, x.device)
+    dx = torch.empty_like(x)
+    lib().call('bts_gn_bwd', _p(x), _p(dy), _p(dx), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dgamma), _p(dbeta), _p(ws),
+               nb, n, v, c, ld_of(dy), groups, mode, 1 if relu else 0, 1 if accumulate_params else 0, _stream())
+    return dx
+
+
+def colsum(x, scale=1.0, sum_over_n=False, out=None, accumulate=False):
+    """x [N,...,C] (channel slice allowed) -> [N,C] (or [C]) column sums * scale"""
+    n, c = x.shape[0], x.shape[-1]
+    rows = x.numel() // (n * c)
+    ld = ld_of(x) if x.dim() == 5 else x.stride(-2)
+    nb = lib().query('bts_colsum_workspace', n, rows, c)
+    ws = workspace(nb, x.device)
+    if out is None:
+        out = torch.empty((c,) if sum_over_n else (n, c), dtype=torch.float32, device=x.device)
+    lib().call('bts_colsum', _p(x), _p(out), _p(ws), nb, n, rows, c, ld, float(scale), 1 if sum_over_n else 0,
+               1 if accumulate else 0, _stream())
+    return out
+
+
+def se_mlp_fwd(gap, w1, w2):
+    n, f = gap.shape
+    r = w1.shape[1]
+    h = torch.empty((n, r), dtype=torch.float32, device=gap.device)
+    ch = torch.empty((n, f), dtype=torch.float32, device=gap.device)
+    lib().call('bts_se_mlp_fwd', _p(gap), _p(w1), _p(w2), _p(h), _p(ch), n, f, r, _stream())
+    return h, ch
+
+
+def block_epilogue_fwd(res, c2, out, wsp, ch, gamma, beta, mean, rstd, groups, mode):
+    n, f = res.shape[0], res.shape[4]
+    v = res.shape[1] * res.shape[2] * res.shape[3]
+    sp = torch.empty(n * v, dtype=torch.float32, device=res.device)
+    lib().call('bts_block_epilogue_fwd', _p(res), _p(c2), _p(out), _p(sp), _p(wsp), _p(ch), _p(gamma), _p(beta), _p(mean),
+               _p(rstd), n, v, f, ld_of(out), groups, mode, _stream())
+    return sp
+
+
+def se_bwd(dout, res, sp, gap, h, ch, w1, w2, wsp, dw1, dw2, dwsp, accumulate_params=False):
+    n, f = res.shape[0], res.shape[4]
+    v = res.shape[1] * res.shape[2] * res.shape[3]
+    r = w1.shape[1]
+    nb = lib().query('bts_se_bwd_workspace', n, v, f, r)
+    ws = workspace(nb, res.device)
+    dres = torch.empty_like(res)
+    ds = torch.empty(n * v, dtype=torch.float32, device=res.device)
+    dgap = torch.empty((n, f), dtype=torch.float32, device=res.device)
+    lib().call('bts_se_bwd', _p(dout), _p(res), _p(sp), _p(gap), _p(h), _p(ch), _p(w1), _p(w2), _p(wsp), _p(dres), _p(ds),
+               _p(dgap), _p(dw1), _p(dw2), _p(dwsp), _p(ws), nb, n, v, f, r, ld_of(dout), 1 if accumulate_params else 0,
+               _stream())
+    return dres
+
+
+def dropout_mask(shape, rate, seed, device):
+    m = torch.empty(shape, dtype=torch.uint8, device=device)
+    lib().call('bts_dropout_mask', _p(m), m.numel(), float(rate), int(seed) & (2 ** 64 - 1), _stream())
+    return m
+
+
+def dropout_apply(x, mask, rate):
+    y = torch.empty_like(x)
+    lib().call('bts_dropout_apply', _p(x), _p(mask), _p(y), x.numel(), float(rate), _stream())
+    return y
+
+
+def normal(shape, seed, device):
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    lib().call('bts_normal', _p(out), out.numel(), int(seed) & (2 ** 64 - 1), _stream())
+    return out
+
+
+def vae_sample_fwd(proj, eps):
+    n, l2 = proj.shape
+    z = torch.empty((n, l2 // 2), dtype=torch.float32, device=proj.device)
+    lib().call('bts_vae_sample_fwd', _p(proj), _p(eps), _p(z), n, l2 // 2, _stream())
+    return z
+
+
+def vae_sample_bwd(proj, eps, dz, dproj):
+    n, l2 = proj.shape
+    lib().call('bts_vae_sample_bwd', _p(proj), _p(eps), _p(dz), _p(dproj), n, l2 // 2, _stream())
+
+
+def fill(t, v):
+    lib().call('bts_fill', _p(t), t.numel(), float(v), _stream())
+    return t
+
+
+def axpy(y, x, a=1.0):
+    lib().call('bts_axpy', _p(y), _p(x), y.numel(), float(a), _stream())
+
+
+def add_strided(dst, src, accumulate):
+    """dst[..., :C] (+)= src[..., :C] for NDHWC channel-slice views"""
+    c = src.shape[-1]
+    rows = src.numel() // c
+    ldd = ld_of(dst) if dst.dim() == 5 else dst.stride(-2)
+    lds = ld_of(src) if src.dim() == 5 else src.stride(-2)
+    lib().call('bts_add_strided', _p(dst), _p(src), rows, c, ldd, lds, 1 if accumulate else 0, _stream())
+
+
+def scalar_lincomb(a, b, ca=1.0, cb=1.0):
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    lib().call('bts_scalar_lincomb', _p(out), _p(a), _p(b), float(ca), float(cb), _stream())
+    return out
+
+
+def relu_bwd(y, dy):
+    dx = torch.empty_like(y)
+    lib().call('bts_relu_bwd', _p(y), _p(dy), _p(dx), y.numel(), _stream())
+    return dx
+
+
+def sigmoid_bwd(y, dy):
+    c = y.shape[-1]
+    rows = y.numel() // c
+    dx = torch.empty(y.shape, dtype=torch.float32, device=y.device)
+    lib().call('bts_sigmoid_bwd', _p(y), _p(dy), _p(dx), rows, c, ld_of(y), ld_of(dy), _stream())
+    return dx
+
+
+def dense_fwd(x, w, b, relu):
+    n, fin = x.shape
+    fout = w.shape[1]
+    nb = lib().query('bts_dense_workspace', n, fin, fout)
+    ws = workspace(nb, x.device)
+    y = torch.empty((n, fout), dtype=torch.float32, device=x.device)
+    lib().call('bts_dense_fwd', _p(x), _p(w), _p(b), _p(y), _p(ws), nb, n, fin, fout, 1 if relu else 0, _stream())
+    return y
+
+
+def dense_bwd(x, w, g, dx, dw, db, accumulate_dx=False, accumulate_params=False):
+    n, fin = x.shape
+    fout = w.shape[1]
+    lib().call('bts_dense_bwd', _p(x), _p(w), _p(g), _p(dx), _p(dw), _p(db), n, fin, fout, 1 if accumulate_dx else 0,
+               1 if accumulate_params else 0, _stream())
+
+
+def loss_sums(y_pred, y, x, y_vae, proj):
+    """-> sums (3C+4,) float64 device tensor (see include/bts_hip.h)"""
+    n, c = y_pred.shape[0], y_pred.shape[4]
+    v = y_pred.shape[1] * y_pred.shape[2] * y_pred.shape[3]
+    sums = torch.empty(3 * c + 4, dtype=torch.float64, device=y_pred.device)
+    nb = lib().query('bts_loss_workspace')
+    ws = workspace(nb, y_pred.device)
+    has_vae = x is not None
+    cx = x.shape[4] if has_vae else 0
+    lz = proj.shape[1] // 2 if proj is not None else 0
+    lib().call('bts_loss_sums', _p(y_pred), _p(y), _p(x), _p(y_vae), _p(proj), _p(sums), _p(ws), nb, n, v, c, ld_of(y_pred),
+               ld_of(y), cx, ld_of(x) if has_vae else 0, ld_of(y_vae) if has_vae else 0, lz, _stream())
+    return sums
+
+
+def loss_value(sums, c, has_vae=True):
+    loss = torch.empty(1, dtype=torch.float32, device=sums.device)
+    parts = torch.empty(3, dtype=torch.float32, device=sums.device)
+    lib().call('bts_loss_value', _p(sums), _p(loss), _p(parts), c, 1 if has_vae else 0, _stream())
+    return loss, parts
+
+
+def loss_bwd(y_pred, y, x, y_vae, proj, sums, gscale, dypred, dyvae, dproj, through_sigmoid=False):
+    n, c = y_pred.shape[0], y_pred.shape[4]
+    v = y_pred.shape[1] * y_pred.shape[2] * y_pred.shape[3]
+    has_vae = x is not None
+    cx = x.shape[4] if has_vae else 0
+    lz = proj.shape[1] // 2 if proj is not None else 0
+    lib().call('bts_loss_bwd', _p(y_pred), _p(y), _p(x), _p(y_vae), _p(proj), _p(sums), _p(gscale), _p(dypred), _p(dyvae),
+               _p(dproj), n, v, c, ld_of(y_pred), ld_of(y), cx, ld_of(x) if has_vae else 0, ld_of(y_vae) if has_vae else 0,
+               lz, 1 if through_sigmoid else 0, _stream())
+
+
+def dice_metric_sums(y_true, y_pred, channels_last_axes=True, want_labels=True):
+    n, d, h, w, c = y_pred.shape
+    cells = w if channels_last_axes else 1
+    table = torch.empty(cells * c * 3, dtype=torch.float64, device=y_pred.device)
+    labels = torch.empty((n, d, h, w), dtype=torch.uint8, device=y_pred.device) if want_labels else None
+    lib().call('bts_dice_metric_sums', _p(y_true), _p(y_pred), _p(labels), _p(table), n, d * h * w, w, c, ld_of(y_true),
+               ld_of(y_pred), 1 if channels_last_axes else 0, _stream())
+    return table, labels
+
+
+def dice_metric_value(table, w, c, channels_last_axes=True):
+    out = torch.empty(2, dtype=torch.float32, device=table.device)
+    lib().call('bts_dice_metric_value', _p(table), _p(out), w, c, 1 if channels_last_axes else 0, _stream())
+    return out
+
+
+def _ranges(ranges):
+    nr = len(ranges)
+    off = (ctypes.c_long * max(nr, 1))(*[r[0] for r in ranges])
+    ln = (ctypes.c_long * max(nr, 1))(*[r[1] for r in ranges])
+    cf = (ctypes.c_float * max(nr, 1))(*[r[2] for r in ranges])
+    return off, ln, cf, nr
+
+
+def l2_reg_fwd(params_flat, ranges):
+    """ranges: [(offset, length, coefficient)] (<= 4) into the flat parameter buffer"""
+    off, ln, cf, nr = _ranges(ranges)
+    out = torch.empty(1, dtype=torch.float32, device=params_flat.device)
+    nb = lib().query('bts_l2_workspace')
+    ws = workspace(nb, params_flat.device)
+    lib().call('bts_l2_reg_fwd', _p(params_flat), ctypes.cast(off, ctypes.c_void_p), ctypes.cast(ln, ctypes.c_void_p),
+               ctypes.cast(cf, ctypes.c_void_p), nr, _p(out), _p(ws), nb, _stream())
+    return out
+
+
+def l2_reg_bwd(params_flat, grads_flat, ranges, gscale=None):
+    off, ln, cf, nr = _ranges(ranges)
+    lib().call('bts_l2_reg_bwd', _p(params_flat), _p(grads_flat), ctypes.cast(off, ctypes.c_void_p),
+               ctypes.cast(ln, ctypes.c_void_p), ctypes.cast(cf, ctypes.c_void_p), nr, _p(gscale), _stream())
+
+
+def adam_tf_step(p, g, m, v, lr_t, beta1, beta2, eps, gmul=1.0):
+    lib().call('bts_adam_tf_step', _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr_t), float(beta1), float(beta2),
+               float(eps), float(gmul), _stream())

@@ -100,6 +100,8 @@ int bts_axpy(float* y, const float* x, long n, float a, bts_stream_t stream);
 int bts_add_strided(float* dst, const float* src, long rows, int C, int ldd, int lds_, int accumulate, bts_stream_t stream);
 int bts_scalar_lincomb(float* out, const float* a, const float* b, float ca, float cb, bts_stream_t stream);
 int bts_relu_bwd(const float* y, const float* dy, float* dx, long n, bts_stream_t stream);
+/* dx (rows,C dense) = dy*y*(1-y): gradient through the fused output sigmoid (decoder.py:60) */
+int bts_sigmoid_bwd(const float* y, const float* dy, float* dx, long rows, int C, int ldy, int lddy, bts_stream_t stream);
 
 /* ===== Dense (layers/vae.py:61-64,105-109) ===== */
 long bts_dense_workspace(int N, int in, int out);
