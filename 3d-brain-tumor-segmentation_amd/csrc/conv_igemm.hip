@@ -323,7 +323,7 @@ extern "C" int bts_conv_pack(int kind, int role, const float* w, float* wp, int 
   const long total = (long)q.ntaps * q.KG * 2 * q.Npad * 4;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, stream, q);
+  (void)hipGetLastError(); hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, stream, q);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
@@ -348,12 +348,35 @@ static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   }
   const int NT = 32 * NS * WN;
   dim3 grid(p.N * p.ntz * p.nty * p.ntx, (p.Npad + NT - 1) / NT);
-  hipLaunchKernelGGL(kern, grid, dim3(256), shmem, stream, p);
+  (void)hipGetLastError(); hipLaunchKernelGGL(kern, grid, dim3(256), shmem, stream, p);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
 
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+// cfg ids: 0:(2,1,4,1) M256 N32 | 1:(2,2,4,1) M256 N64 | 2:(1,2,2,2) M64 N128 | 3:(1,1,2,2) M64 N64 | 4:(1,1,4,1) M128 N32
+static int choose_cfg(int geo, int N, int Do, int Ho, int Wo, int Npad, int* Mout) {
+  const long vox = (long)Do * Ho * Wo;
+  int M, cfg;
+  if (geo == GEO_DOWN) {
+    M = 64;
+    cfg = (Npad >= 128) ? 2 : 3;
+  } else {
+    const long wg256 = (long)N * ((vox + 255) / 256) * ((Npad + 63) / 64);
+    if (Npad <= 32) {
+      if ((long)N * ((vox + 255) / 256) >= 512) { M = 256; cfg = 0; }
+      else { M = 128; cfg = 4; }
+    } else if (wg256 >= 512) { M = 256; cfg = 1; }
+    else {
+      M = 64;
+      const long wg64_128 = (long)N * ((vox + 63) / 64) * ((Npad + 127) / 128);
+      cfg = (Npad >= 128 && wg64_128 >= 384) ? 2 : 3;
+    }
+  }
+  *Mout = M;
+  return cfg;
+}
 
 // geometry + config selection for one gather-conv launch
 static int launch_igemm(int geo, const float* x, const float* wp, const float* bias, float* y, int N, int Di, int Hi,
@@ -407,27 +430,9 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
   p.loz = lo[0]; p.loy = lo[1]; p.lox = lo[2];
 
   // ---- config selection ----
-  const long vox = (long)Do * Ho * Wo;
   const int k1 = (geo == GEO_K1);
   int M;  // voxels per workgroup tile
-  int cfg;
-  // cfg ids: 0:(2,1,4,1) M256 N32 | 1:(2,2,4,1) M256 N64 | 2:(1,2,2,2) M64 N128 | 3:(1,1,2,2) M64 N64 | 4:(1,1,4,1) M128 N32
-  if (geo == GEO_DOWN) {
-    M = 64;
-    cfg = (p.Npad >= 128) ? 2 : 3;
-    if (p.Npad <= 32) cfg = 3;
-  } else {
-    const long wg256 = (long)N * ((vox + 255) / 256) * ((p.Npad + 63) / 64);
-    if (p.Npad <= 32) {
-      if ((long)N * ((vox + 255) / 256) >= 512) { M = 256; cfg = 0; }
-      else { M = 128; cfg = 4; }
-    } else if (wg256 >= 512) { M = 256; cfg = 1; }
-    else {
-      M = 64;
-      const long wg64_128 = (long)N * ((vox + 63) / 64) * ((p.Npad + 127) / 128);
-      cfg = (p.Npad >= 128 && wg64_128 >= 384) ? 2 : 3;
-    }
-  }
+  const int cfg = choose_cfg(geo, N, Do, Ho, Wo, p.Npad, &M);
   // tile dims (powers of two in x,y)
   int TX = 32;
   while (TX > 4 && TX / 2 >= Wo) TX /= 2;  // smallest pow2 >= Wo, capped at 32
@@ -525,4 +530,22 @@ extern "C" int bts_conv3d_bwd_data(int kind, const float* dy, const float* wp_bw
   // transposed conv: d/dx is the stride-2 'same' conv of dy (fine grid 2D x 2H x 2W) -> coarse grid
   return launch_igemm(GEO_DOWN, dy, wp_bwd, nullptr, dx, N, 2 * D, 2 * H, 2 * W, Cout, lddy, D, H, W, Cin, lddx, D, H, W,
                       0, 0, 0, f, stream);
+}
+
+// Which igemm_kernel<...> instantiation a call resolves to: returns cfg + 8*(KGS==4); cfg ids as in choose_cfg.
+// Lets the host attribute measured launch times to kernel symbols (bench.py roofline).
+extern "C" int bts_conv3d_fwd_config(int kind, int N, int D, int H, int W, int Cin, int Cout) {
+  int M;
+  const int geo = geo_of_kind_fwd(kind);
+  int Do = D, Ho = H, Wo = W;
+  if (geo == GEO_DOWN) { Do = D / 2; Ho = H / 2; Wo = W / 2; }
+  return choose_cfg(geo, N, Do, Ho, Wo, npad32(Cout), &M) + (geo == GEO_K1 ? 8 : 0);
+}
+extern "C" int bts_conv3d_bwd_data_config(int kind, int N, int D, int H, int W, int Cin, int Cout) {
+  int M;
+  int geo = GEO_S1, Do = D, Ho = H, Wo = W;
+  if (kind == BTS_CONV_K1) geo = GEO_K1;
+  else if (kind == BTS_CONV_K3S2) { geo = GEO_UP; Do = D / 2; Ho = H / 2; Wo = W / 2; }
+  else if (kind == BTS_CONV_K3S2T) geo = GEO_DOWN;
+  return choose_cfg(geo, N, Do, Ho, Wo, npad32(Cin), &M) + (geo == GEO_K1 ? 8 : 0);
 }

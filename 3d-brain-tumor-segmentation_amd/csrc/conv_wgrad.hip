@@ -354,7 +354,7 @@ extern "C" int bts_conv3d_bwd_weight(int kind, const float* x, const float* dy, 
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(wgrad_kernel, dim3(pl.nsp, pl.npct, pl.nqct), dim3(256), pl.shmem, stream, p);
+  (void)hipGetLastError(); hipLaunchKernelGGL(wgrad_kernel, dim3(pl.nsp, pl.npct, pl.nqct), dim3(256), pl.shmem, stream, p);
   BTS_LAUNCH_CHECK();
   WfinParams f;
   f.partial = p.partial; f.partial_b = p.partial_b; f.dw = dw; f.db = p.want_bias ? db : nullptr;
@@ -369,7 +369,7 @@ extern "C" int bts_conv3d_bwd_weight(int kind, const float* x, const float* dy, 
   const long total = (long)ntaps * Cp * Cq;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, stream, f);
+  (void)hipGetLastError(); hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, stream, f);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }

@@ -73,10 +73,10 @@ extern "C" int bts_dense_fwd(const float* x, const float* w, const float* bias, 
   int rpc;
   const int chunks = dense_chunks(in, &rpc);
   float* partial = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL(dense_fwd_kernel, dim3(chunks, (out + 255) / 256, (N + DENSE_NB - 1) / DENSE_NB), dim3(256), 0, stream,
+  (void)hipGetLastError(); hipLaunchKernelGGL(dense_fwd_kernel, dim3(chunks, (out + 255) / 256, (N + DENSE_NB - 1) / DENSE_NB), dim3(256), 0, stream,
                      x, w, partial, N, in, out, rpc);
   BTS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(dense_fwd_finalize_kernel, dim3((N * out + 255) / 256), dim3(256), 0, stream, partial, bias, y, N, out,
+  (void)hipGetLastError(); hipLaunchKernelGGL(dense_fwd_finalize_kernel, dim3((N * out + 255) / 256), dim3(256), 0, stream, partial, bias, y, N, out,
                      chunks, relu);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
@@ -119,10 +119,10 @@ extern "C" int bts_dense_bwd(const float* x, const float* w, const float* g, flo
   long total = (long)in * out;
   long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(dense_bwd_w_kernel, dim3((int)blocks), dim3(256), 0, stream, x, g, dw, db, N, in, out, accumulate_params);
+  (void)hipGetLastError(); hipLaunchKernelGGL(dense_bwd_w_kernel, dim3((int)blocks), dim3(256), 0, stream, x, g, dw, db, N, in, out, accumulate_params);
   BTS_LAUNCH_CHECK();
   if (dx) {
-    hipLaunchKernelGGL(dense_bwd_x_kernel, dim3((in + 3) / 4), dim3(256), 0, stream, w, g, dx, N, in, out, accumulate_dx);
+    (void)hipGetLastError(); hipLaunchKernelGGL(dense_bwd_x_kernel, dim3((in + 3) / 4), dim3(256), 0, stream, w, g, dx, N, in, out, accumulate_dx);
     BTS_LAUNCH_CHECK();
   }
   return BTS_OK;

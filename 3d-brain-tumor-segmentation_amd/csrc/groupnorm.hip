@@ -20,14 +20,15 @@ struct GnGeom {
   long L;      // elements per group = E/G
   int B;       // blocks per reduction unit (slab: per (n,g); channel: per n)
   long span;   // elements per block (multiple of 1024)
+  int generic; // 1: shape outside the vectorised fast path (C or L not a multiple of 4, C not a power of two)
 };
 
 static int gn_geom(GnGeom& g, int N, long V, int C, int G, int mode) {
   if (N <= 0 || V <= 0 || C <= 0 || G <= 0) return BTS_ERR_SHAPE;
   if (C < G || C % G != 0) return BTS_ERR_SHAPE;  // group_norm.py:51-59 (ValueError at the Python layer)
-  if (C % 4 != 0 || (C & (C - 1)) != 0 || C > 1024) return BTS_ERR_UNSUPPORTED;
   g.N = N; g.C = C; g.G = G; g.cg = C / G; g.mode = mode; g.V = V; g.E = V * C; g.L = g.E / G;
-  if (g.E % G != 0 || g.L % 4 != 0) return BTS_ERR_UNSUPPORTED;
+  if (g.E % G != 0) return BTS_ERR_UNSUPPORTED;
+  g.generic = (C % 4 != 0 || (C & (C - 1)) != 0 || C > 1024 || g.L % 4 != 0) ? 1 : 0;
   const long unit = (mode == BTS_GN_SLAB) ? g.L : g.E;
   const int units = (mode == BTS_GN_SLAB) ? N * G : N;
   long B = (2048 + units - 1) / units;  // aim for ~2048 blocks in flight
@@ -118,6 +119,113 @@ __global__ void gn_stats_finalize_kernel(const double* partial, float* mean, flo
   rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// generic (any C, any L) path: one workgroup per (n,g); used only for shapes the vectorised path rejects
+// (tiny test configurations, e.g. 2-channel GroupNorm). Same math, same fixed-order fp64 sums.
+// element e of group (n,g): slab -> sample offset g*L + e ; channel -> voxel e/cg, channel g*cg + e%cg
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ long gn_elem_offset(long e, int g, long L, int C, int cg, int mode) {
+  return (mode == BTS_GN_SLAB) ? (long)g * L + e : (e / cg) * C + (long)g * cg + (e % cg);
+}
+__global__ __launch_bounds__(256) void gn_stats_generic_kernel(const float* x, float* mean, float* rstd, long E, long L, int C,
+                                                               int G, int cg, int mode, float eps) {
+  __shared__ double sh[8];
+  const int n = blockIdx.x / G, g = blockIdx.x % G;
+  double s = 0.0, ss = 0.0;
+  for (long e = threadIdx.x; e < L; e += blockDim.x) {
+    const double v = (double)x[(long)n * E + gn_elem_offset(e, g, L, C, cg, mode)];
+    s += v; ss += v * v;
+  }
+  const double rs = block_sum_f64(s, sh);
+  const double rss = block_sum_f64(ss, sh + 4);
+  if (threadIdx.x == 0) {
+    const double m = rs / (double)L;
+    double var = rss / (double)L - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[blockIdx.x] = (float)m;
+    rstd[blockIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+__global__ void gn_apply_generic_kernel(const float* x, float* y, const float* gamma, const float* beta, const float* mean,
+                                        const float* rstd, long total, long E, long L, int C, int G, int cg, int ldy,
+                                        int mode, int relu) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / E, r = i - n * E;
+    const int c = (int)(r % C);
+    const int g = (mode == BTS_GN_SLAB) ? (int)(r / L) : c / cg;
+    const int idx = (mode == BTS_GN_SLAB) ? g * cg + (c % cg) : c;
+    float o = (x[i] - mean[n * G + g]) * rstd[n * G + g] * gamma[idx] + beta[idx];
+    if (relu) o = fmaxf(o, 0.f);
+    y[(i / C) * ldy + c] = o;
+  }
+}
+// per (n,g): c1 = sum(dyE*gamma)/L, c2 = sum(dyE*gamma*xh)/L
+__global__ __launch_bounds__(256) void gn_bwd_group_generic_kernel(const float* x, const float* dy, const float* gamma,
+                                                                   const float* beta, const float* mean, const float* rstd,
+                                                                   float* c1, float* c2, long E, long L, int C, int G, int cg,
+                                                                   int lddy, int mode, int relu) {
+  __shared__ double sh[8];
+  const int n = blockIdx.x / G, g = blockIdx.x % G;
+  const float m = mean[blockIdx.x], rs = rstd[blockIdx.x];
+  double s1 = 0.0, s2 = 0.0;
+  for (long e = threadIdx.x; e < L; e += blockDim.x) {
+    const long r = gn_elem_offset(e, g, L, C, cg, mode);
+    const int c = (int)(r % C);
+    const int idx = (mode == BTS_GN_SLAB) ? g * cg + (c % cg) : c;
+    const float xh = (x[(long)n * E + r] - m) * rs;
+    float de = dy[((long)n * (E / C) + r / C) * lddy + c];
+    if (relu && !(xh * gamma[idx] + beta[idx] > 0.f)) de = 0.f;
+    s1 += (double)(de * gamma[idx]);
+    s2 += (double)(de * gamma[idx] * xh);
+  }
+  const double r1 = block_sum_f64(s1, sh);
+  const double r2 = block_sum_f64(s2, sh + 4);
+  if (threadIdx.x == 0) { c1[blockIdx.x] = (float)(r1 / (double)L); c2[blockIdx.x] = (float)(r2 / (double)L); }
+}
+// per affine index idx: dgamma = sum dyE*xh, dbeta = sum dyE over all samples / elements mapped to idx
+__global__ __launch_bounds__(256) void gn_bwd_param_generic_kernel(const float* x, const float* dy, const float* gamma,
+                                                                   const float* beta, const float* mean, const float* rstd,
+                                                                   float* dgamma, float* dbeta, int N, long E, long L, int C,
+                                                                   int G, int cg, int lddy, int mode, int relu, int accum) {
+  __shared__ double sh[8];
+  const int idx = blockIdx.x;
+  const int g = idx / cg, j = idx % cg;
+  double sa = 0.0, sb = 0.0;
+  for (int n = 0; n < N; ++n)
+    for (long e = threadIdx.x; e < L; e += blockDim.x) {
+      const long r = gn_elem_offset(e, g, L, C, cg, mode);
+      const int c = (int)(r % C);
+      if ((c % cg) != j) continue;
+      const float xh = (x[(long)n * E + r] - mean[n * G + g]) * rstd[n * G + g];
+      float de = dy[((long)n * (E / C) + r / C) * lddy + c];
+      if (relu && !(xh * gamma[idx] + beta[idx] > 0.f)) de = 0.f;
+      sa += (double)(de * xh);
+      sb += (double)de;
+    }
+  const double ra = block_sum_f64(sa, sh);
+  const double rb = block_sum_f64(sb, sh + 4);
+  if (threadIdx.x == 0) {
+    if (dgamma) dgamma[idx] = accum ? dgamma[idx] + (float)ra : (float)ra;
+    if (dbeta) dbeta[idx] = accum ? dbeta[idx] + (float)rb : (float)rb;
+  }
+}
+__global__ void gn_bwd_apply_generic_kernel(const float* x, const float* dy, float* dx, const float* gamma, const float* beta,
+                                            const float* mean, const float* rstd, const float* c1, const float* c2, long total,
+                                            long E, long L, int C, int G, int cg, int lddy, int mode, int relu) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / E, r = i - n * E;
+    const int c = (int)(r % C);
+    const int g = (mode == BTS_GN_SLAB) ? (int)(r / L) : c / cg;
+    const int idx = (mode == BTS_GN_SLAB) ? g * cg + (c % cg) : c;
+    const float rs = rstd[n * G + g];
+    const float xh = (x[i] - mean[n * G + g]) * rs;
+    float de = dy[(i / C) * lddy + c];
+    if (relu && !(xh * gamma[idx] + beta[idx] > 0.f)) de = 0.f;
+    dx[i] = (de * gamma[idx] - c1[n * G + g] - xh * c2[n * G + g]) * rs;
+  }
+}
+
 extern "C" long bts_gn_workspace(int N, long V, int C, int G, int mode) {
   GnGeom g;
   if (gn_geom(g, N, V, C, G, mode) != BTS_OK) return -1;
@@ -133,16 +241,21 @@ extern "C" int bts_gn_stats(const float* x, float* mean, float* rstd, void* work
   int r = gn_geom(g, N, V, C, G, mode);
   if (r != BTS_OK) return r;
   if (workspace_bytes < bts_gn_workspace(N, V, C, G, mode)) return BTS_ERR_WORKSPACE;
+  if (g.generic) {
+    (void)hipGetLastError(); hipLaunchKernelGGL(gn_stats_generic_kernel, dim3(N * G), dim3(256), 0, stream, x, mean, rstd, g.E, g.L, C, G, g.cg, mode, eps);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+  }
   if (((uintptr_t)x) & 15) return BTS_ERR_ALIGN;
   double* partial = reinterpret_cast<double*>(workspace);
   if (mode == BTS_GN_SLAB) {
-    hipLaunchKernelGGL(gn_stats_slab_kernel, dim3(g.B, N * G), dim3(256), 0, stream, x, partial, g.L, g.span);
+    (void)hipGetLastError(); hipLaunchKernelGGL(gn_stats_slab_kernel, dim3(g.B, N * G), dim3(256), 0, stream, x, partial, g.L, g.span);
   } else {
-    hipLaunchKernelGGL(gn_stats_channel_kernel, dim3(g.B, N), dim3(256), 0, stream, x, partial, g.E, g.span, C);
+    (void)hipGetLastError(); hipLaunchKernelGGL(gn_stats_channel_kernel, dim3(g.B, N), dim3(256), 0, stream, x, partial, g.E, g.span, C);
   }
   BTS_LAUNCH_CHECK();
   const int NG = N * G;
-  hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3((NG + 63) / 64), dim3(64), 0, stream, partial, mean, rstd, NG, g.B,
+  (void)hipGetLastError(); hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3((NG + 63) / 64), dim3(64), 0, stream, partial, mean, rstd, NG, g.B,
                      C, G, mode, (double)g.L, eps);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
@@ -193,11 +306,21 @@ extern "C" int bts_gn_apply(const float* x, float* y, const float* gamma, const 
   GnGeom g;
   int r = gn_geom(g, N, V, C, G, mode);
   if (r != BTS_OK) return r;
-  if (ldy < C || ldy % 4 != 0 || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 15)) return BTS_ERR_ALIGN;
+  if (g.generic || ldy % 4 != 0) {
+    if (ldy < C) return BTS_ERR_ALIGN;
+    const long total = (long)N * g.E;
+    int gb = (int)((total + 255) / 256);
+    if (gb > 8192) gb = 8192;
+    (void)hipGetLastError(); hipLaunchKernelGGL(gn_apply_generic_kernel, dim3(gb), dim3(256), 0, stream, x, y, gamma, beta, mean, rstd, total, g.E, g.L,
+                       C, G, g.cg, ldy, mode, relu);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+  }
+  if (ldy < C || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 15)) return BTS_ERR_ALIGN;
   const long total4 = (long)N * g.E / 4;
   int blocks = (int)((total4 + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, stream, x, y, gamma, beta, mean, rstd, total4, g.E,
+  (void)hipGetLastError(); hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, stream, x, y, gamma, beta, mean, rstd, total4, g.E,
                      g.L, C, G, g.cg, ldy, mode, relu);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
@@ -348,7 +471,26 @@ extern "C" int bts_gn_bwd(const float* x, const float* dy, float* dx, const floa
   GnGeom g;
   int r = gn_geom(g, N, V, C, G, mode);
   if (r != BTS_OK) return r;
-  if (lddy < C || lddy % 4 != 0 || (((uintptr_t)x) & 15) || (((uintptr_t)dy) & 15) || (((uintptr_t)dx) & 15)) return BTS_ERR_ALIGN;
+  if (lddy < C) return BTS_ERR_ALIGN;
+  if (g.generic || lddy % 4 != 0) {
+    if (workspace_bytes < (long)N * G * 2 * 4 + 64) return BTS_ERR_WORKSPACE;
+    float* gc1 = reinterpret_cast<float*>(workspace);
+    float* gc2 = gc1 + (long)N * G;
+    (void)hipGetLastError(); hipLaunchKernelGGL(gn_bwd_group_generic_kernel, dim3(N * G), dim3(256), 0, stream, x, dy, gamma, beta, mean, rstd, gc1, gc2,
+                       g.E, g.L, C, G, g.cg, lddy, mode, relu);
+    BTS_LAUNCH_CHECK();
+    (void)hipGetLastError(); hipLaunchKernelGGL(gn_bwd_param_generic_kernel, dim3(C), dim3(256), 0, stream, x, dy, gamma, beta, mean, rstd, dgamma, dbeta,
+                       N, g.E, g.L, C, G, g.cg, lddy, mode, relu, accumulate_params);
+    BTS_LAUNCH_CHECK();
+    const long total = (long)N * g.E;
+    int gb = (int)((total + 255) / 256);
+    if (gb > 8192) gb = 8192;
+    (void)hipGetLastError(); hipLaunchKernelGGL(gn_bwd_apply_generic_kernel, dim3(gb), dim3(256), 0, stream, x, dy, dx, gamma, beta, mean, rstd, gc1, gc2,
+                       total, g.E, g.L, C, G, g.cg, lddy, mode, relu);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+  }
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)dy) & 15) || (((uintptr_t)dx) & 15)) return BTS_ERR_ALIGN;
   const long part_bytes = bts_gn_workspace(N, V, C, G, mode);
   const long extra = (long)N * C * 2 * 8 + (long)N * G * 2 * 4 + 64;
   if (workspace_bytes < part_bytes + extra) return BTS_ERR_WORKSPACE;
@@ -357,16 +499,16 @@ extern "C" int bts_gn_bwd(const float* x, const float* dy, float* dx, const floa
   float* c1 = reinterpret_cast<float*>(scratch + (long)N * C * 2);
   float* c2 = c1 + (long)N * G;
   const bool slab = (mode == BTS_GN_SLAB);
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(g.B, slab ? N * G : N), dim3(256), 0, stream, x, dy, gamma, beta, mean,
+  (void)hipGetLastError(); hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(g.B, slab ? N * G : N), dim3(256), 0, stream, x, dy, gamma, beta, mean,
                      rstd, partial, g.E, g.L, g.span, C, G, g.cg, lddy, mode, relu);
   BTS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, gamma, dgamma, dbeta, c1, c2,
+  (void)hipGetLastError(); hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, gamma, dgamma, dbeta, c1, c2,
                      scratch, N, g.B, C, G, mode, (double)g.L, accumulate_params);
   BTS_LAUNCH_CHECK();
   const long total4 = (long)N * g.E / 4;
   int blocks = (int)((total4 + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, stream, x, dy, dx, gamma, beta, mean, rstd, c1, c2,
+  (void)hipGetLastError(); hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, stream, x, dy, dx, gamma, beta, mean, rstd, c1, c2,
                      total4, g.E, g.L, C, G, g.cg, lddy, mode, relu);
   BTS_LAUNCH_CHECK();
   return BTS_OK;

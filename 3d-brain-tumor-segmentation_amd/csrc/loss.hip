@@ -81,10 +81,10 @@ extern "C" int bts_loss_sums(const float* y_pred, const float* y, const float* x
   long blocks = (NV + 255) / 256;
   if (blocks > LOSS_BLOCKS) blocks = LOSS_BLOCKS;
   double* partial = reinterpret_cast<double*>(workspace);
-  hipLaunchKernelGGL(loss_partial_kernel, dim3((int)blocks), dim3(256), 0, stream, y_pred, y, x, y_vae, partial, NV, C, ldp,
+  (void)hipGetLastError(); hipLaunchKernelGGL(loss_partial_kernel, dim3((int)blocks), dim3(256), 0, stream, y_pred, y, x, y_vae, partial, NV, C, ldp,
                      ldy, Cx, ldx, ldv);
   BTS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(loss_sums_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, proj, sums, (int)blocks, C, N, Lz,
+  (void)hipGetLastError(); hipLaunchKernelGGL(loss_sums_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, proj, sums, (int)blocks, C, N, Lz,
                      (double)NV * Cx);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
@@ -105,7 +105,7 @@ __global__ void loss_value_kernel(const double* sums, float* loss, float* parts,
   if (parts) { parts[0] = (float)d; parts[1] = (float)l2; parts[2] = (float)kl; }
 }
 extern "C" int bts_loss_value(const double* sums, float* loss, float* parts, int C, int has_vae, hipStream_t stream) {
-  hipLaunchKernelGGL(loss_value_kernel, dim3(1), dim3(64), 0, stream, sums, loss, parts, C, has_vae);
+  (void)hipGetLastError(); hipLaunchKernelGGL(loss_value_kernel, dim3(1), dim3(64), 0, stream, sums, loss, parts, C, has_vae);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
@@ -161,7 +161,7 @@ extern "C" int bts_loss_bwd(const float* y_pred, const float* y, const float* x,
   const long NV = (long)N * V;
   long blocks = (NV + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(loss_bwd_kernel, dim3((int)blocks), dim3(256), 0, stream, y_pred, y, x, y_vae, proj, sums, gscale, dlogit,
+  (void)hipGetLastError(); hipLaunchKernelGGL(loss_bwd_kernel, dim3((int)blocks), dim3(256), 0, stream, y_pred, y, x, y_vae, proj, sums, gscale, dlogit,
                      dyvae, dproj, NV, C, ldp, ldy, Cx, ldx, ldv, N, Lz, through_sigmoid);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
@@ -212,12 +212,12 @@ extern "C" int bts_dice_metric_sums(const float* y_true, const float* y_pred, ui
   const int cells = channels_last_axes ? W : 1;
   const int tsz = cells * C * 3;
   if ((size_t)tsz * 8 > 60 * 1024) return BTS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(zero_f64_kernel, dim3((tsz + 255) / 256), dim3(256), 0, stream, table, tsz);
+  (void)hipGetLastError(); hipLaunchKernelGGL(zero_f64_kernel, dim3((tsz + 255) / 256), dim3(256), 0, stream, table, tsz);
   BTS_LAUNCH_CHECK();
   const long NV = (long)N * V;
   long blocks = (NV + 255) / 256;
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(dice_metric_kernel, dim3((int)blocks), dim3(256), tsz * sizeof(double), stream, y_true, y_pred, labels,
+  (void)hipGetLastError(); hipLaunchKernelGGL(dice_metric_kernel, dim3((int)blocks), dim3(256), tsz * sizeof(double), stream, y_true, y_pred, labels,
                      table, NV, C, ldt, ldp, cells, W);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
@@ -236,7 +236,7 @@ __global__ void dice_metric_value_kernel(const double* table, float* out, int ce
 }
 extern "C" int bts_dice_metric_value(const double* table, float* out, int W, int C, int channels_last_axes,
                                      hipStream_t stream) {
-  hipLaunchKernelGGL(dice_metric_value_kernel, dim3(1), dim3(64), 0, stream, table, out, channels_last_axes ? W : 1, C);
+  (void)hipGetLastError(); hipLaunchKernelGGL(dice_metric_value_kernel, dim3(1), dim3(64), 0, stream, table, out, channels_last_axes ? W : 1, C);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
@@ -292,9 +292,9 @@ extern "C" int bts_l2_reg_fwd(const float* params, const long* off, const long* 
   if (r != BTS_OK) return r;
   if (workspace_bytes < bts_l2_workspace()) return BTS_ERR_WORKSPACE;
   double* partial = reinterpret_cast<double*>(workspace);
-  hipLaunchKernelGGL(l2_partial_kernel, dim3(1024), dim3(256), 0, stream, params, partial, rg);
+  (void)hipGetLastError(); hipLaunchKernelGGL(l2_partial_kernel, dim3(1024), dim3(256), 0, stream, params, partial, rg);
   BTS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(l2_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, out, 1024);
+  (void)hipGetLastError(); hipLaunchKernelGGL(l2_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, out, 1024);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
@@ -303,7 +303,7 @@ extern "C" int bts_l2_reg_bwd(const float* params, float* grads, const long* off
   L2Ranges rg;
   int r = l2_make(rg, off, len, coef, nranges);
   if (r != BTS_OK) return r;
-  hipLaunchKernelGGL(l2_grad_kernel, dim3(2048), dim3(256), 0, stream, params, grads, gscale, rg);
+  (void)hipGetLastError(); hipLaunchKernelGGL(l2_grad_kernel, dim3(2048), dim3(256), 0, stream, params, grads, gscale, rg);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }

@@ -44,7 +44,7 @@ extern "C" int bts_adam_tf_step(float* p, const float* g, float* m, float* v, lo
   long blocks = (n4 + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, stream, p, g, m, v, n4, n, lr_t, beta1, beta2, eps, gmul);
+  (void)hipGetLastError(); hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, stream, p, g, m, v, n4, n, lr_t, beta1, beta2, eps, gmul);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }

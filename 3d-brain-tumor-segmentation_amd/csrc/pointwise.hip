@@ -30,7 +30,7 @@ __global__ void dropout_mask_kernel(uint8_t* mask, long n, float rate, uint64_t 
 }
 extern "C" int bts_dropout_mask(uint8_t* mask, long n, float rate, uint64_t seed, hipStream_t stream) {
   if (n <= 0) return BTS_ERR_SHAPE;
-  hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, mask, n, rate, seed);
+  (void)hipGetLastError(); hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, mask, n, rate, seed);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
@@ -42,7 +42,7 @@ __global__ void dropout_apply_kernel(const float* x, const uint8_t* mask, float*
 // y = x * mask / (1 - rate)
 extern "C" int bts_dropout_apply(const float* x, const uint8_t* mask, float* y, long n, float rate, hipStream_t stream) {
   if (n <= 0 || rate < 0.f || rate >= 1.f) return BTS_ERR_SHAPE;
-  hipLaunchKernelGGL(dropout_apply_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, x, mask, y, n, 1.0f / (1.0f - rate));
+  (void)hipGetLastError(); hipLaunchKernelGGL(dropout_apply_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, x, mask, y, n, 1.0f / (1.0f - rate));
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
@@ -56,7 +56,7 @@ __global__ void normal_kernel(float* out, long n, uint64_t seed) {
 }
 extern "C" int bts_normal(float* out, long n, uint64_t seed, hipStream_t stream) {
   if (n <= 0) return BTS_ERR_SHAPE;
-  hipLaunchKernelGGL(normal_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, out, n, seed);
+  (void)hipGetLastError(); hipLaunchKernelGGL(normal_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, out, n, seed);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
@@ -71,7 +71,7 @@ __global__ void vae_sample_fwd_kernel(const float* proj, const float* eps, float
 }
 extern "C" int bts_vae_sample_fwd(const float* proj, const float* eps, float* z, int N, int L, hipStream_t stream) {
   if (N <= 0 || L <= 0) return BTS_ERR_SHAPE;
-  hipLaunchKernelGGL(vae_sample_fwd_kernel, dim3(ew_blocks((long)N * L)), dim3(256), 0, stream, proj, eps, z, N, L);
+  (void)hipGetLastError(); hipLaunchKernelGGL(vae_sample_fwd_kernel, dim3(ew_blocks((long)N * L)), dim3(256), 0, stream, proj, eps, z, N, L);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
@@ -87,7 +87,7 @@ __global__ void vae_sample_bwd_kernel(const float* proj, const float* eps, const
 extern "C" int bts_vae_sample_bwd(const float* proj, const float* eps, const float* dz, float* dproj, int N, int L,
                                   hipStream_t stream) {
   if (N <= 0 || L <= 0) return BTS_ERR_SHAPE;
-  hipLaunchKernelGGL(vae_sample_bwd_kernel, dim3(ew_blocks((long)N * L)), dim3(256), 0, stream, proj, eps, dz, dproj, N, L);
+  (void)hipGetLastError(); hipLaunchKernelGGL(vae_sample_bwd_kernel, dim3(ew_blocks((long)N * L)), dim3(256), 0, stream, proj, eps, dz, dproj, N, L);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
@@ -97,7 +97,7 @@ __global__ void fill_kernel(float* p, long n, float v) {
 }
 extern "C" int bts_fill(float* p, long n, float v, hipStream_t stream) {
   if (n <= 0) return BTS_OK;
-  hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, p, n, v);
+  (void)hipGetLastError(); hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, p, n, v);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
@@ -107,7 +107,7 @@ __global__ void axpy_kernel(float* y, const float* x, long n, float a) {
 }
 extern "C" int bts_axpy(float* y, const float* x, long n, float a, hipStream_t stream) {
   if (n <= 0) return BTS_OK;
-  hipLaunchKernelGGL(axpy_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, y, x, n, a);
+  (void)hipGetLastError(); hipLaunchKernelGGL(axpy_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, y, x, n, a);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
@@ -126,7 +126,7 @@ __global__ void add_strided_kernel(float* dst, const float* src, long rows, int 
 extern "C" int bts_add_strided(float* dst, const float* src, long rows, int C, int ldd, int lds_, int accumulate,
                                hipStream_t stream) {
   if (rows <= 0 || C <= 0 || ldd < C || lds_ < C) return BTS_ERR_SHAPE;
-  hipLaunchKernelGGL(add_strided_kernel, dim3(ew_blocks(rows * C)), dim3(256), 0, stream, dst, src, rows, C, ldd, lds_, accumulate);
+  (void)hipGetLastError(); hipLaunchKernelGGL(add_strided_kernel, dim3(ew_blocks(rows * C)), dim3(256), 0, stream, dst, src, rows, C, ldd, lds_, accumulate);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
@@ -136,7 +136,7 @@ __global__ void scalar_lincomb_kernel(float* out, const float* a, const float* b
 }
 // out = ca*a + cb*b on 1-element device buffers (loss + sum(model.losses), train.py:145-146)
 extern "C" int bts_scalar_lincomb(float* out, const float* a, const float* b, float ca, float cb, hipStream_t stream) {
-  hipLaunchKernelGGL(scalar_lincomb_kernel, dim3(1), dim3(64), 0, stream, out, a, b, ca, cb);
+  (void)hipGetLastError(); hipLaunchKernelGGL(scalar_lincomb_kernel, dim3(1), dim3(64), 0, stream, out, a, b, ca, cb);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
@@ -148,7 +148,7 @@ __global__ void relu_bwd_kernel(const float* y, const float* dy, float* dx, long
 }
 extern "C" int bts_relu_bwd(const float* y, const float* dy, float* dx, long n, hipStream_t stream) {
   if (n <= 0) return BTS_OK;
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, y, dy, dx, n);
+  (void)hipGetLastError(); hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, y, dy, dx, n);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
@@ -166,7 +166,7 @@ __global__ void sigmoid_bwd_kernel(const float* y, const float* dy, float* dx, l
 extern "C" int bts_sigmoid_bwd(const float* y, const float* dy, float* dx, long rows, int C, int ldy, int lddy,
                                hipStream_t stream) {
   if (rows <= 0 || C <= 0) return BTS_ERR_SHAPE;
-  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(ew_blocks(rows * C)), dim3(256), 0, stream, y, dy, dx, rows, C, ldy, lddy);
+  (void)hipGetLastError(); hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(ew_blocks(rows * C)), dim3(256), 0, stream, y, dy, dx, rows, C, ldy, lddy);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }

@@ -91,10 +91,10 @@ extern "C" int bts_colsum(const float* x, float* out, void* workspace, long work
   const long rspan = (rows + B - 1) / B;
   const int vec = (C % 4 == 0) && (ld % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
   double* partial = reinterpret_cast<double*>(workspace);
-  hipLaunchKernelGGL(colsum_kernel, dim3(B, N), dim3(256), 0, stream, x, partial, rows, C, ld, rspan, vec);
+  (void)hipGetLastError(); hipLaunchKernelGGL(colsum_kernel, dim3(B, N), dim3(256), 0, stream, x, partial, rows, C, ld, rspan, vec);
   BTS_LAUNCH_CHECK();
   const int total = sum_over_n ? C : N * C;
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, partial, out, N, B, C,
+  (void)hipGetLastError(); hipLaunchKernelGGL(colsum_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, partial, out, N, B, C,
                      (double)scale, accumulate, sum_over_n);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
@@ -126,7 +126,7 @@ __global__ void se_mlp_fwd_kernel(const float* gap, const float* w1, const float
 extern "C" int bts_se_mlp_fwd(const float* gap, const float* w1, const float* w2, float* h, float* ch, int N, int F, int R,
                               hipStream_t stream) {
   if (N <= 0 || F <= 0 || R <= 0) return BTS_ERR_SHAPE;
-  hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(N), dim3(256), (F + R) * sizeof(float), stream, gap, w1, w2, h, ch, F, R);
+  (void)hipGetLastError(); hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(N), dim3(256), (F + R) * sizeof(float), stream, gap, w1, w2, h, ch, F, R);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void block_epilogue_kernel(
       const long rin = (v - n * V) * F + c;  // element index inside the sample
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int g = (mode == BTS_GN_SLAB) ? (int)(rin / L) : (c + e) / cg;
+        const int g = (mode == BTS_GN_SLAB) ? (int)((rin + e) / L) : (c + e) / cg;
         const int idx = (mode == BTS_GN_SLAB) ? g * cg + ((c + e) % cg) : (c + e);
         const float y = (x[e] - mean[n * G + g]) * rstd[n * G + g] * gamma[idx] + beta[idx];
         o4[e] += fmaxf(y, 0.f);
@@ -184,7 +184,7 @@ extern "C" int bts_block_epilogue_fwd(const float* res, const float* c2, float* 
   if (blocks > 8192) blocks = 8192;
   const int cg = c2 ? F / G : 1;
   const long L = c2 ? V * F / G : 1;
-  hipLaunchKernelGGL(block_epilogue_kernel, dim3((int)blocks), dim3(256), 0, stream, res, c2, out, sp, wsp, ch, gamma,
+  (void)hipGetLastError(); hipLaunchKernelGGL(block_epilogue_kernel, dim3((int)blocks), dim3(256), 0, stream, res, c2, out, sp, wsp, ch, gamma,
                      beta, mean, rstd, NV, V, F, ldo, G, cg, L, mode);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
@@ -333,15 +333,15 @@ extern "C" int bts_se_bwd(const float* dout, const float* res, const float* sp, 
   const int B = se_bwd_blocks(V, N, F, &vspan);
   double* partial = reinterpret_cast<double*>(workspace);
   double* scratch = partial + (long)N * B * F * 2;
-  hipLaunchKernelGGL(se_bwd_reduce_kernel, dim3(B, N), dim3(256), 0, stream, dout, res, sp, ds, partial, V, F, lddo, vspan);
+  (void)hipGetLastError(); hipLaunchKernelGGL(se_bwd_reduce_kernel, dim3(B, N), dim3(256), 0, stream, dout, res, sp, ds, partial, V, F, lddo, vspan);
   BTS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(1), dim3(256), 0, stream, partial, gap, h, ch, w1, w2, dw1, dw2, dwsp, dgap,
+  (void)hipGetLastError(); hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(1), dim3(256), 0, stream, partial, gap, h, ch, w1, w2, dw1, dw2, dwsp, dgap,
                      scratch, N, B, F, R, 1.0 / (double)V, accumulate_params);
   BTS_LAUNCH_CHECK();
   const long total = (long)N * V * (F / 4);
   long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(se_bwd_apply_kernel, dim3((int)blocks), dim3(256), 0, stream, dout, sp, ds, ch, wsp, dgap, dres,
+  (void)hipGetLastError(); hipLaunchKernelGGL(se_bwd_apply_kernel, dim3((int)blocks), dim3(256), 0, stream, dout, sp, ds, ch, wsp, dgap, dres,
                      (long)N * V, V, F, lddo);
   BTS_LAUNCH_CHECK();
   return BTS_OK;

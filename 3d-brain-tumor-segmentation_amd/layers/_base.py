@@ -1,0 +1,150 @@
+"""Keras-like Layer protocol for the engine (the drop-in boundary): objects constructed with config
+kwargs, weights created in build(input_shape), invoked as layer(inputs, training=...), exposing get_config(),
+.trainable_variables and .losses.  Initialisers follow SURVEY A.11 (Keras VarianceScaling / Glorot)."""
+import math
+
+import torch
+
+from .. import ops
+from ..tape import Param, Tensor, as_tensor, bump_weights_epoch, current_tape, default_device, weights_epoch
+
+_gen = torch.Generator()
+_gen.manual_seed(0)
+
+
+def set_seed(seed):
+    """seed the host-side weight initialiser (the reference seeds nothing: SURVEY F11)"""
+    _gen.manual_seed(int(seed))
+
+
+def _fans(shape, transposed=False):
+    rf = 1
+    for s in shape[:-2]:
+        rf *= s
+    if len(shape) < 2:
+        return shape[0], shape[0]
+    cin, cout = (shape[-1], shape[-2]) if transposed else (shape[-2], shape[-1])
+    return rf * cin, rf * cout
+
+
+def initialise(shape, init, transposed=False):
+    """host-side draw in fp64, rounded to fp32"""
+    if init == 'zeros':
+        return torch.zeros(shape, dtype=torch.float32)
+    if init == 'ones':
+        return torch.ones(shape, dtype=torch.float32)
+    fi, fo = _fans(shape, transposed)
+    if init in ('he_normal', 'glorot_normal'):
+        std = math.sqrt(2.0 / fi) if init == 'he_normal' else math.sqrt(2.0 / (fi + fo))
+        s = std / 0.87962566103423978  # Keras truncated-normal variance correction
+        t = torch.empty(shape, dtype=torch.float64)
+        torch.nn.init.trunc_normal_(t, 0.0, s, -2 * s, 2 * s, generator=_gen)
+        return t.float()
+    if init == 'glorot_uniform':
+        lim = math.sqrt(6.0 / (fi + fo))
+        return ((torch.rand(shape, dtype=torch.float64, generator=_gen) * 2 - 1) * lim).float()
+    raise ValueError('unknown initializer %r' % (init,))
+
+
+class Layer(object):
+    def __init__(self, name=None):
+        self.built = False
+        self.name = name or self.__class__.__name__
+        self._params = []
+        self._sublayers = []
+        self._packs = {}
+
+    # ---- Keras protocol ----
+    def add_weight(self, name, shape, initializer, l2=0.0, transposed=False):
+        t = initialise(tuple(int(s) for s in shape), initializer, transposed).to(default_device())
+        p = Param(t, '%s/%s' % (self.name, name), l2=l2, init=initializer)
+        p.owner = self
+        self._params.append(p)
+        return p
+
+    def track(self, layer):
+        self._sublayers.append(layer)
+        return layer
+
+    def build(self, input_shape):
+        self.built = True
+
+    def compute_output_shape(self, input_shape):
+        return tuple(input_shape)
+
+    def call(self, inputs, training=None):
+        raise NotImplementedError
+
+    def __call__(self, inputs, training=None, **kwargs):
+        if not self.built:
+            self.build(_shape_of(inputs))
+            self.built = True
+        return self.call(inputs, training=training, **kwargs)
+
+    @property
+    def trainable_variables(self):
+        out = list(self._params)
+        for l in self._sublayers:
+            out.extend(l.trainable_variables)
+        return out
+
+    @property
+    def losses(self):
+        """regularisation terms, one 1-element Tensor per regularised variable (Keras: layer.losses)"""
+        out = []
+        for p in self.trainable_variables:
+            if p.l2 > 0:
+                out.append(_l2_term(p))
+        return out
+
+    def get_config(self):
+        return dict(getattr(self, 'config', {}))
+
+    # ---- packed weight images for the implicit-GEMM kernel, rebuilt when parameters change ----
+    def packed(self, key, kind, role, param, cin_ref, cout, cin_slab=None, dup_start=0, dup_shift=0):
+        ent = self._packs.get(key)
+        if ent is None or ent[0] != weights_epoch():
+            wp = ops.conv_pack(kind, role, param.t, cin_ref, cout, cin_slab, dup_start, dup_shift)
+            ent = (weights_epoch(), wp)
+            self._packs[key] = ent
+        return ent[1]
+
+
+def _l2_term(p):
+    flat = p.t.reshape(-1)
+    val = Tensor(ops.l2_reg_fwd(flat, [(0, flat.numel(), p.l2)]))
+    tape = current_tape()
+    if tape is not None:
+        def backward():
+            g = val.grad
+            if g is None:
+                return
+            buf, acc = p.grad_slot()
+            if not acc:
+                ops.fill(buf, 0.0)
+            ops.l2_reg_bwd(flat, buf.reshape(-1), [(0, flat.numel(), p.l2)], g)
+        tape.record(backward)
+    return val
+
+
+def _shape_of(x):
+    if isinstance(x, (tuple, list)) and len(x) and not isinstance(x[0], int):
+        return [_shape_of(e) for e in x]
+    if isinstance(x, Tensor):
+        return tuple(x.shape)
+    if hasattr(x, 'shape'):
+        return tuple(x.shape)
+    return tuple(x)
+
+
+def check_data_format(data_format):
+    if data_format == 'channels_first':
+        raise NotImplementedError(
+            "data_format='channels_first' (the reference's --gpu layout) is a SURVEY 8(f-4) 'next' row: the kernels "
+            'already implement its GroupNorm semantics (BTS_GN_CHANNEL) but the public NCDHW layout is not wired yet')
+    if data_format != 'channels_last':
+        raise ValueError('unknown data_format %r' % (data_format,))
+
+
+__all__ = ['Layer', 'Param', 'Tensor', 'as_tensor', 'bump_weights_epoch', 'check_data_format', 'current_tape',
+           'initialise', 'set_seed']

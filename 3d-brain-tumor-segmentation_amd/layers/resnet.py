@@ -1,0 +1,169 @@
+"""ResnetBlock -- drop-in for layers/resnet.py of the reference (constructor :8-113, call :116-138).
+
+    res  = conv1x1(inputs)                                    :118
+    chse = sigmoid(W2^T relu(W1^T GAP(res)))                  :121-124
+    spse = sigmoid(conv1x1(res; F->1, no bias))               :127
+    res  = res * (spse + chse)                                :130   (gate on the SHORTCUT, sum of the two gates)
+    a = relu(GN1(conv3(inputs))) ; c = relu(GN2(conv3(a)))    :133-136
+    return res + c                                            :137
+
+One layer call = one tape node: forward launches ~12 HIP kernels, backward ~20 (SURVEY Appendix A').
+`inputs` may be a channel-slice view of a level slab; `out` an output slice; `fold=(dup_start, dup_shift)` tells the
+block that the reference would have seen [o_{j-1}, slab...] (encoder.py:83-87) so its weights carry dup_shift extra
+input channels that are folded at pack time.
+"""
+import torch
+
+from .. import ops
+from ._base import Layer, Tensor, as_tensor, check_data_format, current_tape
+from .group_norm import GroupNormalization
+
+
+class ResnetBlock(Layer):
+    def __init__(self, filters, data_format='channels_last', groups=8, reduction=2, l2_scale=1e-5, name=None):
+        super(ResnetBlock, self).__init__(name=name)
+        check_data_format(data_format)
+        self.config = {'filters': filters, 'data_format': data_format, 'reduction': reduction, 'l2_scale': l2_scale,
+                       'groups': groups}
+        if filters % reduction != 0:
+            raise ValueError('Reduction ratio, {}, must be a factor of number of channels, {}.'.format(reduction, filters))
+        self.filters = filters
+        self.groups = groups
+        self.reduction = reduction
+        self.l2_scale = l2_scale
+        self.norm1 = self.track(GroupNormalization(groups=groups, axis=-1, beta_initializer='zeros',
+                                                   gamma_initializer='ones', beta_regularizer=l2_scale,
+                                                   gamma_regularizer=l2_scale, name=self.name + '/gn1'))
+        self.norm2 = self.track(GroupNormalization(groups=groups, axis=-1, beta_initializer='zeros',
+                                                   gamma_initializer='zeros', beta_regularizer=l2_scale,
+                                                   gamma_regularizer=l2_scale, name=self.name + '/gn2'))
+
+    def build(self, input_shape, fold=None):
+        cin = input_shape[-1] + (fold[1] if fold else 0)
+        f, l2 = self.filters, self.l2_scale
+        self.cin_ref = cin
+        self.ptwise_k = self.add_weight('ptwise_k', (1, 1, 1, cin, f), 'he_normal', l2)
+        self.ptwise_b = self.add_weight('ptwise_b', (f,), 'zeros')
+        self.se_w1 = self.add_weight('se_w1', (f, f // self.reduction), 'he_normal', l2)
+        self.se_w2 = self.add_weight('se_w2', (f // self.reduction, f), 'he_normal', l2)
+        self.spatial_k = self.add_weight('spatial_k', (1, 1, 1, f, 1), 'he_normal', l2)
+        self.conv1_k = self.add_weight('conv1_k', (3, 3, 3, cin, f), 'he_normal', l2)
+        self.conv1_b = self.add_weight('conv1_b', (f,), 'zeros')
+        self.norm1.build((None, None, None, None, f))
+        self.conv2_k = self.add_weight('conv2_k', (3, 3, 3, f, f), 'he_normal', l2)
+        self.conv2_b = self.add_weight('conv2_b', (f,), 'zeros')
+        self.norm2.build((None, None, None, None, f))
+        self.built = True
+
+    @property
+    def trainable_variables(self):
+        # creation order of the reference constructor: ptwise, SE denses, spatial, conv1, GN1, conv2, GN2
+        n1, n2 = self.norm1._params, self.norm2._params
+        p = self._params
+        return p[:7] + n1 + p[7:9] + n2
+
+    def compute_output_shape(self, input_shape):
+        return tuple(input_shape[:-1]) + (self.filters,)
+
+    def __call__(self, inputs, training=None, out=None, fold=None):
+        if not self.built:
+            self.build(tuple(inputs.shape), fold)
+        return self.call(inputs, training=training, out=out, fold=fold)
+
+    def call(self, inputs, training=None, out=None, fold=None):
+        x = as_tensor(inputs)
+        f, g = self.filters, self.groups
+        n, d, h, w, cin = x.shape
+        dup_start, dup_shift = fold if fold else (0, 0)
+        if cin + dup_shift != self.cin_ref:
+            raise ValueError('ResnetBlock built for %d input channels, got %d' % (self.cin_ref, cin + dup_shift))
+        v = d * h * w
+        K1, K3 = ops.K1, ops.K3S1
+        pk = lambda key, kind, role, p, ci, co, folded: self.packed(
+            key, kind, role, p, ci, co, cin if folded else None, dup_start if folded else 0, dup_shift if folded else 0)
+        wp_pt = pk('pt_f', K1, ops.ROLE_FWD, self.ptwise_k, self.cin_ref, f, True)
+        wp_c1 = pk('c1_f', K3, ops.ROLE_FWD, self.conv1_k, self.cin_ref, f, True)
+        wp_c2 = pk('c2_f', K3, ops.ROLE_FWD, self.conv2_k, f, f, False)
+        # shortcut + gates
+        res = ops.conv_fwd(K1, x.t, wp_pt, self.ptwise_b.t, f)
+        gap = ops.colsum(res, scale=1.0 / v)
+        hbuf, ch = ops.se_mlp_fwd(gap, self.se_w1.t, self.se_w2.t)
+        # conv branch
+        c1 = ops.conv_fwd(K3, x.t, wp_c1, self.conv1_b.t, f)
+        m1, r1 = ops.gn_stats(c1, g, ops.GN_SLAB, self.norm1.epsilon)
+        a = ops.gn_apply(c1, self.norm1.gamma.t, self.norm1.beta.t, m1, r1, g, ops.GN_SLAB, True)
+        c2 = ops.conv_fwd(K3, a, wp_c2, self.conv2_b.t, f)
+        m2, r2 = ops.gn_stats(c2, g, ops.GN_SLAB, self.norm2.epsilon)
+        if out is None:
+            out = Tensor(torch.empty((n, d, h, w, f), dtype=torch.float32, device=x.t.device))
+        wsp = self.spatial_k.t.reshape(-1)
+        sp = ops.block_epilogue_fwd(res, c2, out.t, wsp, ch, self.norm2.gamma.t, self.norm2.beta.t, m2, r2, g, ops.GN_SLAB)
+        tape = current_tape()
+        if tape is not None:
+            def backward():
+                self._backward(x, out, res, gap, hbuf, ch, sp, c1, m1, r1, a, c2, m2, r2, dup_start, dup_shift)
+            tape.record(backward)
+        return out
+
+    def _backward(self, x, out, res, gap, hbuf, ch, sp, c1, m1, r1, a, c2, m2, r2, dup_start, dup_shift):
+        dout = out.grad
+        if dout is None:
+            return
+        f, g = self.filters, self.groups
+        cin = x.shape[-1]
+        K1, K3 = ops.K1, ops.K3S1
+        n1, n2 = self.norm1, self.norm2
+        from .group_norm import group_norm_backward
+        # ---- conv branch: GN2 -> conv2 -> GN1 -> conv1
+        dc2 = group_norm_backward(n2, c2, dout, n2.gamma.t, n2.beta.t, m2, r2, True)
+        wpb2 = self.packed('c2_b', K3, ops.ROLE_BWD, self.conv2_k, f, f)
+        da = torch.empty_like(a)
+        ops.conv_bwd_data(K3, dc2, wpb2, da, False)
+        _wgrad(K3, a, dc2, self.conv2_k, self.conv2_b)
+        del dc2
+        dc1 = group_norm_backward(n1, c1, da, n1.gamma.t, n1.beta.t, m1, r1, True)
+        del da
+        need_dx = x.requires_grad
+        if need_dx:
+            dx, acc = x.grad_slot()
+            wpb1 = self.packed('c1_b', K3, ops.ROLE_BWD, self.conv1_k, self.cin_ref, f, cin, dup_start, dup_shift)
+            ops.conv_bwd_data(K3, dc1, wpb1, dx, acc)
+        _wgrad(K3, x.t, dc1, self.conv1_k, self.conv1_b, dup_start, dup_shift)
+        del dc1
+        # ---- gate branch
+        gw1, a1 = self.se_w1.grad_slot()
+        gw2, a2 = self.se_w2.grad_slot()
+        gws, a3 = self.spatial_k.grad_slot()
+        if not (a1 == a2 == a3):
+            for buf, acc_ in ((gw1, a1), (gw2, a2), (gws, a3)):
+                if not acc_:
+                    ops.fill(buf, 0.0)
+            a1 = True
+        dres = ops.se_bwd(dout, res, sp, gap, hbuf, ch, self.se_w1.t, self.se_w2.t, self.spatial_k.t.reshape(-1), gw1, gw2,
+                          gws.reshape(-1), accumulate_params=a1)
+        if need_dx:
+            dx, acc = x.grad_slot()
+            wpbp = self.packed('pt_b', K1, ops.ROLE_BWD, self.ptwise_k, self.cin_ref, f, cin, dup_start, dup_shift)
+            ops.conv_bwd_data(K1, dres, wpbp, dx, acc)
+        _wgrad(K1, x.t, dres, self.ptwise_k, self.ptwise_b, dup_start, dup_shift)
+
+    def get_config(self):
+        return self.config
+
+
+def _wgrad(kind, x, dy, kparam, bparam, dup_start=0, dup_shift=0):
+    """weight + bias gradient into the parameters' grad slots"""
+    dw, aw = kparam.grad_slot()
+    db, ab = (None, aw) if bparam is None else bparam.grad_slot()
+    if bparam is not None and aw != ab:
+        if not aw:
+            ops.fill(dw, 0.0)
+        if not ab:
+            ops.fill(db, 0.0)
+        aw = True
+    if kind == ops.K3S2T:
+        ops.conv_bwd_weight(kind, x, dy, dw, None, accumulate=aw)
+        if bparam is not None:
+            ops.colsum(dy, sum_over_n=True, out=db, accumulate=aw)
+    else:
+        ops.conv_bwd_weight(kind, x, dy, dw, db, dup_start, dup_shift, accumulate=aw)

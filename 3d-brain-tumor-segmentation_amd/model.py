@@ -1,0 +1,171 @@
+"""Model -- drop-in for model.py of the reference (constructor :9-56, call :58-71).
+
+Model(**model_args)(x, training, inference) -> (y_pred, y_vae, z_mean, z_logvar), or (y_pred, None, None, None) when
+inference=True (the VAE branch is skipped, :67-68).  After the first call all variables are re-homed into ONE flat
+fp32 parameter buffer (plus flat gradient / Adam-moment buffers) so that the optimiser, the L2 regulariser and the
+RCCL gradient all-reduce each touch a single contiguous range.
+"""
+import numpy as np
+import torch
+
+from . import ops, parallel
+from .layers._base import Layer, Tensor, as_tensor, check_data_format, current_tape
+from .layers.decoder import Decoder
+from .layers.encoder import Encoder
+from .layers.vae import VariationalAutoencoder
+from .tape import bump_weights_epoch
+
+
+class Model(Layer):
+    def __init__(self, data_format='channels_last', groups=8, reduction=2, l2_scale=1e-5, dropout=0.2,
+                 downsampling='conv', upsampling='conv', base_filters=16, depth=4, in_ch=2, out_ch=3):
+        super(Model, self).__init__(name='model')
+        check_data_format(data_format)
+        self.data_format = data_format
+        self.epoch = _EpochVariable()                                              # model.py:29
+        self.in_ch = in_ch
+        self.encoder = self.track(Encoder(data_format=data_format, groups=groups, reduction=reduction, l2_scale=l2_scale,
+                                          dropout=dropout, downsampling=downsampling, base_filters=base_filters,
+                                          depth=depth, _reserve_for_decoder=True))
+        self.decoder = self.track(Decoder(data_format=data_format, groups=groups, reduction=reduction, l2_scale=l2_scale,
+                                          upsampling=upsampling, base_filters=base_filters, depth=depth, out_ch=out_ch))
+        self.vae = self.track(VariationalAutoencoder(data_format=data_format, groups=groups, reduction=reduction,
+                                                     l2_scale=l2_scale, upsampling=upsampling,
+                                                     base_filters=base_filters, depth=depth, out_ch=in_ch))
+        self.flat_params = None
+        self.flat_grads = None
+        self._l2_ranges = None
+
+    # ---- build: weights for a given input shape, no kernels launched ----
+    def build(self, input_shape):
+        shp = tuple(input_shape)
+        self.encoder.build(shp)
+        res_shapes = []
+        s = shp
+        for i in range(self.encoder.depth):
+            f = self.encoder.base_filters * 2 ** i
+            s = s[:4] + (f * (i + 1),)
+            res_shapes.append(s)
+            if i < self.encoder.depth - 1:
+                s = (s[0], s[1] // 2, s[2] // 2, s[3] // 2, f)
+        self.decoder.build((res_shapes[-1], res_shapes[:-1]))
+        self.vae.build(res_shapes[-1])
+        self.built = True
+        self._flatten_parameters()
+
+    def _flatten_parameters(self):
+        """one contiguous buffer: [ l2_scale-regularised | fixed-1e-5-regularised | unregularised ]"""
+        ps = self.trainable_variables
+        coefs = sorted(set(p.l2 for p in ps if p.l2 > 0), reverse=True)
+        groups = [[p for p in ps if p.l2 == c] for c in coefs] + [[p for p in ps if p.l2 <= 0]]
+        total = sum(p.t.numel() for p in ps)
+        pad = (-total) % 4
+        dev = ps[0].t.device
+        flat = torch.empty(total + pad, dtype=torch.float32, device=dev)
+        grads = torch.zeros(total + pad, dtype=torch.float32, device=dev)
+        if pad:
+            flat[total:] = 0
+        off = 0
+        ranges = []
+        for gi, grp in enumerate(groups):
+            start = off
+            for p in grp:
+                n = p.t.numel()
+                flat[off:off + n].copy_(p.t.reshape(-1))
+                p.t = flat[off:off + n].view(p.t.shape)
+                p._gview = grads[off:off + n].view(p.t.shape)
+                off += n
+            if gi < len(coefs) and off > start:
+                ranges.append((start, off - start, coefs[gi]))
+        if len(ranges) > 4:
+            raise RuntimeError('more than 4 distinct L2 coefficients')
+        self.flat_params, self.flat_grads, self._l2_ranges = flat, grads, ranges
+        self.n_params = total
+        bump_weights_epoch()
+
+    def call(self, inputs, training=None, inference=None):
+        assert (not inference or not training), 'Cannot run training and inference modes simultaneously.'
+        x = as_tensor(inputs)
+        residuals = self.encoder(x, training=training)
+        y_pred = self.decoder((residuals[-1], residuals[:-1]), training=training)
+        if inference:
+            return (y_pred, None, None, None)
+        y_vae, z_mean, z_logvar = self.vae(residuals[-1], training=training)
+        return (y_pred, y_vae, z_mean, z_logvar)
+
+    def __call__(self, inputs, training=None, inference=None):
+        if not self.built:
+            self.build(tuple(inputs.shape))
+        return self.call(inputs, training=training, inference=inference)
+
+    @property
+    def trainable_variables(self):
+        return self.encoder.trainable_variables + self.decoder.trainable_variables + self.vae.trainable_variables
+
+    @property
+    def losses(self):
+        """[sum of all L2 regularisers] as a single fused term (train.py:146 reduces the list with a sum anyway)"""
+        if self.flat_params is None or not self._l2_ranges:
+            return Layer.losses.fget(self)
+        val = Tensor(ops.l2_reg_fwd(self.flat_params, self._l2_ranges))
+        tape = current_tape()
+        if tape is not None:
+            gen = tape.gen
+
+            def backward():
+                g = val.grad
+                if g is None:
+                    return
+                # every parameter's gradient has been written by its layer by now (this node replays last)
+                for p in self.trainable_variables:
+                    if p._gen != gen:
+                        ops.fill(p._gview, 0.0)
+                        p._gen = gen
+                k = parallel.l2_grad_scale()  # rank-identical term: pre-divide so the summing all-reduce restores it
+                ops.l2_reg_bwd(self.flat_params, self.flat_grads, [(o, l, c * k) for o, l, c in self._l2_ranges], g)
+            tape.nodes.insert(0, backward)  # replay after all layer nodes regardless of where .losses was read
+        return [val]
+
+    # ---- weights I/O (train.py:100,201 use Keras HDF5; h5py is absent here, so a flat .npz keyed by variable name) ----
+    def save_weights(self, path):
+        d = {p.name: p.t.detach().cpu().numpy() for p in self.trainable_variables}
+        d['epoch'] = np.asarray(self.epoch.value().numpy())
+        np.savez(path if str(path).endswith('.npz') else str(path) + '.npz', **d)
+
+    def load_weights(self, path):
+        z = np.load(path if str(path).endswith('.npz') else str(path) + '.npz')
+        for p in self.trainable_variables:
+            p.t.copy_(torch.from_numpy(z[p.name]).to(p.t.device).reshape(p.t.shape))
+        if 'epoch' in z:
+            self.epoch.assign(int(z['epoch']))
+        bump_weights_epoch()
+
+    def set_weights_from(self, named):
+        """named: dict name -> array (oracle ParamSet naming, 'encoder/L0/B0/ptwise_k' ...) for parity runs"""
+        for p in self.trainable_variables:
+            key = p.name.replace('/gn1/gamma', '/gn1_g').replace('/gn1/beta', '/gn1_b').replace('/gn2/gamma', '/gn2_g') \
+                .replace('/gn2/beta', '/gn2_b').replace('/gn/gamma', '/gn_g').replace('/gn/beta', '/gn_b')
+            v = named[key]
+            v = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+            p.t.copy_(torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(p.t.device).reshape(p.t.shape))
+        bump_weights_epoch()
+
+    def oracle_name(self, p):
+        return p.name.replace('/gn1/gamma', '/gn1_g').replace('/gn1/beta', '/gn1_b').replace('/gn2/gamma', '/gn2_g') \
+            .replace('/gn2/beta', '/gn2_b').replace('/gn/gamma', '/gn_g').replace('/gn/beta', '/gn_b')
+
+
+class _EpochVariable(object):
+    """tf.Variable(0, name='epoch', trainable=False) stand-in (model.py:29; train.py:133-135)"""
+
+    def __init__(self):
+        self._v = 0
+
+    def assign(self, v):
+        self._v = int(v)
+
+    def value(self):
+        return self
+
+    def numpy(self):
+        return self._v

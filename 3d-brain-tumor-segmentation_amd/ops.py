@@ -18,6 +18,43 @@ GN_SLAB, GN_CHANNEL = 0, 1
 
 _workspaces = {}
 
+# ---- optional live kernel timing (bench.py roofline): HIP events on the launch stream around selected launches ----
+PROFILE = None  # None = off; else a list of (symbol, algorithmic_flops, n_launches, start_event, end_event)
+
+_CFG = {0: '2,1,4,1', 1: '2,2,4,1', 2: '1,2,2,2', 3: '1,1,2,2', 4: '1,1,4,1'}
+
+
+def _igemm_symbol(cfg):
+    return 'igemm_kernel<%s,%d>' % (_CFG[cfg & 7], 4 if cfg & 8 else 1)
+
+
+class _Timed(object):
+    def __init__(self, symbol, flops, launches=1):
+        self.symbol, self.flops, self.launches = symbol, flops, launches
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.append((self.symbol, self.flops, self.launches, self.e0, self.e1))
+        return False
+
+
+def conv_flops(kind, n, d, h, w, cin, cout):
+    """algorithmic FLOPs of one conv call, SURVEY 8(d) convention (MAC = 2; (d,h,w) = forward INPUT dims)"""
+    v = n * d * h * w
+    if kind == K1:
+        return 2.0 * cin * cout * v
+    if kind == K3S2:
+        return 2.0 * 27 * cin * cout * (v // 8)
+    return 2.0 * 27 * cin * cout * v   # K3S1; K3S2T counts 27*Cin*Cout*V_in MACs
+
 
 def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
@@ -90,8 +127,12 @@ def conv_fwd(kind, x, wp, bias, cout, out=None, sigmoid=False):
     n, d, h, w, cin = x.shape
     if out is None:
         out = torch.empty(conv_out_shape(kind, x.shape, cout), dtype=torch.float32, device=x.device)
-    lib().call('bts_conv3d_fwd', kind, _p(x), _p(wp), _p(bias), _p(out), n, d, h, w, cin, ld_of(x), cout, ld_of(out),
-               FLAG_SIGMOID if sigmoid else 0, _stream())
+    sym = None
+    if PROFILE is not None:
+        sym = _igemm_symbol(lib()._bts_conv3d_fwd_config(kind, n, d, h, w, cin, cout))
+    with _Timed(sym, conv_flops(kind, n, d, h, w, cin, cout), 8 if kind == K3S2T else 1):
+        lib().call('bts_conv3d_fwd', kind, _p(x), _p(wp), _p(bias), _p(out), n, d, h, w, cin, ld_of(x), cout, ld_of(out),
+                   FLAG_SIGMOID if sigmoid else 0, _stream())
     return out
 
 
@@ -99,8 +140,12 @@ def conv_bwd_data(kind, dy, wp_bwd, dx, accumulate):
     """dx: [N,D,H,W,Cin] view of the forward input's gradient"""
     n, d, h, w, cin = dx.shape
     cout = dy.shape[4]
-    lib().call('bts_conv3d_bwd_data', kind, _p(dy), _p(wp_bwd), _p(dx), n, d, h, w, cin, ld_of(dx), cout, ld_of(dy),
-               FLAG_ACCUM if accumulate else 0, _stream())
+    sym = None
+    if PROFILE is not None:
+        sym = _igemm_symbol(lib()._bts_conv3d_bwd_data_config(kind, n, d, h, w, cin, cout))
+    with _Timed(sym, conv_flops(kind, n, d, h, w, cin, cout), 8 if kind == K3S2 else 1):
+        lib().call('bts_conv3d_bwd_data', kind, _p(dy), _p(wp_bwd), _p(dx), n, d, h, w, cin, ld_of(dx), cout, ld_of(dy),
+                   FLAG_ACCUM if accumulate else 0, _stream())
     return dx
 
 
@@ -109,8 +154,9 @@ def conv_bwd_weight(kind, x, dy, dw, db, dup_start=0, dup_shift=0, accumulate=Fa
     cout = dy.shape[4]
     nb = lib().query('bts_conv3d_bwd_weight_workspace', kind, n, d, h, w, cin, cout)
     ws = workspace(nb, x.device)
-    lib().call('bts_conv3d_bwd_weight', kind, _p(x), _p(dy), _p(dw), _p(db), _p(ws), nb, n, d, h, w, cin, ld_of(x), cout,
-               ld_of(dy), dup_start, dup_shift, 1 if accumulate else 0, _stream())
+    with _Timed('wgrad_kernel', conv_flops(kind, n, d, h, w, cin, cout)):
+        lib().call('bts_conv3d_bwd_weight', kind, _p(x), _p(dy), _p(dw), _p(db), _p(ws), nb, n, d, h, w, cin, ld_of(x),
+                   cout, ld_of(dy), dup_start, dup_shift, 1 if accumulate else 0, _stream())
 
 
 def gn_stats(x, groups, mode, eps=1e-5):

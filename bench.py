@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py -- training volumes/s (2ch x 128^3) of the MI355X-native 3D U-Net+VAE engine.
+
+One "step" = one pass of the hot path over one resident batch: forward (training=True), Dice+0.1*MSE+0.1*KL+L2 loss,
+Dice metric, full backward, TF-form Adam (train.py:140-152 of the reference), CLI-default model (base_filters=32,
+reduction=8, depth=4, groups=8; args.py:121-143), fp32.  N=1: BASELINE.json configs[1] (batch 1 per GPU).
+N>1 (torchrun): one process per GPU, one sample per rank (weak scaling), RCCL all-reduce of the 13 loss sums and of the
+flat 168.7 MB gradient buffer.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  "roofline":     dominant kernel (by summed time in the timed region), algorithmic FLOPs / measured HIP-event time
+  "cpu_baseline": the oracle's identical step on the host cores, bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
+
+
+def cpu_baseline(max_seconds=30.0):
+    """oracle (torch-CPU restatement) train step; kind 'port' (the reference needs TensorFlow, absent here)"""
+    import torch
+    from oracle import torch_ref as R
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    cfg = R.default_config(base_filters=32, reduction=8)
+    crop = (64, 64, 64)
+    x, y, mask, eps = R.synthetic_batch(1, crop, latent=128, seed=1234)
+    P = R.build_params(cfg, crop, seed=0)
+    for k in P:
+        P[k] = P[k].float()
+    state = {}
+    t0 = time.time()
+    R.train_step(P, cfg, x, y, mask, eps, state, 1e-4, 1)
+    t = time.time() - t0
+    frac = (64 ** 3) / float(128 ** 3)
+    sample = '1 fwd+bwd+Adam step, fp32, CLI-default model on a 2ch x 64^3 crop (1/8 of a 128^3 volume)'
+    val = frac / t
+    if t * 8 < max_seconds:   # fast host: time the real 128^3 volume too
+        crop = (128, 128, 128)
+        x, y, mask, eps = R.synthetic_batch(1, crop, latent=128, seed=1234)
+        P = R.build_params(cfg, crop, seed=0)
+        for k in P:
+            P[k] = P[k].float()
+        t0 = time.time()
+        R.train_step(P, cfg, x, y, mask, eps, {}, 1e-4, 1)
+        t = time.time() - t0
+        val = 1.0 / t
+        sample = '1 fwd+bwd+Adam step, fp32, CLI-default model on one 2ch x 128^3 volume'
+    return {'value': val, 'unit': 'volumes/s', 'cores': cores, 'kind': 'port', 'sample': sample,
+            'seconds': round(t, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--crop', type=int, default=128)
+    ap.add_argument('--batch', type=int, default=1, help='samples per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import bts_amd  # noqa: F401
+    from bts_amd import ops, parallel
+    from bts_amd.model import Model
+    from bts_amd.util import DiceCoefficient, DiceVAELoss, ScheduledOptim, train_step
+    from oracle import torch_ref as R   # synthetic input generator only
+
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU execution path exists for the product)')
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    if world > 1:
+        parallel.init_from_env('nccl')
+    dev = torch.device('cuda', local)
+
+    crop = (args.crop,) * 3
+    nb = args.batch
+    kw = dict(base_filters=32, reduction=8, depth=4, groups=8)
+    model = Model(**kw)
+    model.build((nb,) + crop + (2,))
+    parallel.broadcast_parameters(model)
+    x, y, _, _ = R.synthetic_batch(nb, crop, latent=128, seed=1234 + rank)
+    x, y = x.to(dev), y.to(dev)
+    opt = ScheduledOptim(1e-4)
+    opt(epoch=0)
+    loss_fn, dice_fn = DiceVAELoss(), DiceCoefficient()
+
+    for _ in range(args.warmup):
+        loss, macro, micro = train_step(model, opt, loss_fn, dice_fn, x, y)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    do_prof = (not args.no_profile)
+    if do_prof:
+        ops.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, macro, micro = train_step(model, opt, loss_fn, dice_fn, x, y)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    prof = ops.PROFILE
+    ops.PROFILE = None
+
+    if rank != 0:
+        return
+    volumes = world * nb * args.steps
+    out = {
+        'metric': 'training volumes/sec (2ch x %d^3)' % args.crop, 'value': volumes / dt, 'unit': 'volumes/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[1]: 2ch x %d^3, batch %d per GPU, fp32, full fwd+bwd with '
+                               'Dice+KL+L2 VAE loss + Dice metric + TF-form Adam; CLI-default model '
+                               '(base_filters=32, depth=4, groups=8, reduction=8; 42,174,773 params)' % (args.crop, nb),
+                   'parallelism': 'dp%d' % world, 'global_batch': world * nb},
+        'loss': float(loss), 'macro_dice': float(macro),
+    }
+    if do_prof and prof:
+        agg = {}
+        for sym, flops, nl, e0, e1 in prof:
+            a = agg.setdefault(sym, [0.0, 0.0, 0])
+            a[0] += e0.elapsed_time(e1) * 1e-3
+            a[1] += flops
+            a[2] += nl
+        dom = max(agg.items(), key=lambda kv: kv[1][0])
+        sym, (tsec, fl, nl) = dom
+        ach = fl / tsec / 1e12
+        out['roofline'] = {
+            'kernel': sym, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+            'launches_per_step': nl / args.steps, 'avg_launch_ms': 1e3 * tsec / nl,
+            'algorithmic_gflop_per_launch': fl / nl / 1e9,
+            'time_share_of_step': tsec / dt,
+        }
+        out['kernel_breakdown'] = {k: {'ms_per_step': 1e3 * v[0] / args.steps, 'tflops': v[1] / v[0] / 1e12,
+                                       'launches_per_step': v[2] / args.steps} for k, v in sorted(agg.items())}
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline()
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

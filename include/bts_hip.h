@@ -54,6 +54,10 @@ int bts_conv3d_fwd(int kind, const float* x, const float* wp_fwd, const float* b
 /* dx (+)= conv^T(dy). (D,H,W) are the forward INPUT dims. Replaces tf.GradientTape for these ops (train.py:142-151). */
 int bts_conv3d_bwd_data(int kind, const float* dy, const float* wp_bwd, float* dx, int N, int D, int H, int W, int Cin,
                         int lddx, int Cout, int lddy, int flags, bts_stream_t stream);
+/* which igemm_kernel<MS,NS,WM,WN,KGS> instantiation a call resolves to (id 0..4, +8 for the 1x1x1 staging variant);
+ * used by bench.py to attribute measured launch times to kernel symbols */
+int bts_conv3d_fwd_config(int kind, int N, int D, int H, int W, int Cin, int Cout);
+int bts_conv3d_bwd_data_config(int kind, int N, int D, int H, int W, int Cin, int Cout);
 long bts_conv3d_bwd_weight_workspace(int kind, int N, int D, int H, int W, int Cin, int Cout);
 /* dw in the reference layout (Cin_ref = Cin + dup_shift); db (may be NULL; not produced for K3S2T: use bts_colsum). */
 int bts_conv3d_bwd_weight(int kind, const float* x, const float* dy, float* dw, float* db, void* workspace,

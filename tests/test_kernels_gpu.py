@@ -151,7 +151,8 @@ def test_conv_folded_duplicate_slice(kind):
 
 
 GN_CASES = [(1, (8, 8, 8), 32, 8), (2, (8, 8, 16), 16, 8), (1, (16, 16, 16), 64, 8), (2, (4, 4, 4), 256, 8),
-            (1, (8, 8, 8), 16, 2), (1, (2, 2, 2), 16, 8), (1, (32, 32, 32), 32, 8)]
+            (1, (8, 8, 8), 16, 2), (1, (2, 2, 2), 16, 8), (1, (32, 32, 32), 32, 8),
+            (2, (4, 4, 4), 2, 2), (1, (1, 1, 1), 16, 8), (1, (2, 4, 2), 12, 3)]
 
 
 @pytest.mark.parametrize('mode', [0, 1])
