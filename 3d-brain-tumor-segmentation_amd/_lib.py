@@ -7,6 +7,10 @@ import ctypes
 import os
 import re
 
+import torch  # noqa: F401  -- MUST precede the dlopen below: torch ships its own libamdhip64/libhsa-runtime64; loading
+#                      ours first would put a second HIP runtime in the process (kernel launches then fail with
+#                      hipErrorNoDevice).  With torch's runtime resident, libbts_hip.so binds to the same one.
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(_ROOT, 'include', 'bts_hip.h')

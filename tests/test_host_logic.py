@@ -1,0 +1,106 @@
+"""CPU: host-side mirror of the reference's call surface (model.py / layers.* / util.py): constructor kwargs and
+defaults, lazy build, variable inventory, error behaviour, and that the product fails loudly without a GPU."""
+import inspect
+import math
+
+import pytest
+import torch
+
+import bts_amd  # noqa: F401
+from bts_amd.layers import decoder, downsample, encoder, group_norm, resnet, upsample, vae
+from bts_amd.model import Model
+from bts_amd import parallel, util
+from oracle import torch_ref as R
+
+
+def test_constructor_defaults_match_reference_model_py():
+    sig = inspect.signature(Model.__init__)
+    exp = dict(data_format='channels_last', groups=8, reduction=2, l2_scale=1e-5, dropout=0.2, downsampling='conv',
+               upsampling='conv', base_filters=16, depth=4, in_ch=2, out_ch=3)          # model.py:9-20
+    assert {k: v.default for k, v in sig.parameters.items() if k != 'self'} == exp
+    assert list(inspect.signature(resnet.ResnetBlock.__init__).parameters)[1:6] == \
+        ['filters', 'data_format', 'groups', 'reduction', 'l2_scale']                   # resnet.py:9-13
+    gn = inspect.signature(group_norm.GroupNormalization.__init__).parameters
+    assert gn['groups'].default == 8 and gn['axis'].default == -1 and gn['epsilon'].default == 1e-5   # group_norm.py:10-13
+    assert downsample.get_downsampling('conv') is downsample.ConvDownsample
+    assert downsample.get_downsampling('max') is downsample.MaxDownsample
+    assert downsample.get_downsampling('avg') is None                                   # downsample.py:7-11
+    assert upsample.get_upsampling('conv') is upsample.ConvUpsample
+    assert upsample.get_upsampling('linear') is upsample.LinearUpsample
+    assert callable(vae.sample) and encoder.Encoder and decoder.Decoder
+
+
+@pytest.mark.parametrize('kw,count', [(dict(base_filters=32, reduction=8), 42174773), (dict(), 10636061)])
+def test_parameter_inventory(kw, count):
+    m = Model(**kw)
+    m.build((1, 128, 128, 128, 2))
+    assert m.n_params == count
+    P = R.build_params(R.default_config(**kw), (128, 128, 128))
+    names = [m.oracle_name(p) for p in m.trainable_variables]
+    assert sorted(names) == sorted(P.keys())
+    for p in m.trainable_variables:
+        assert tuple(p.t.shape) == tuple(P[m.oracle_name(p)].shape), p.name
+        assert p.l2 == pytest.approx(P.l2[m.oracle_name(p)]), p.name
+    # flat buffer: one contiguous, 16B-aligned range; L2-regularised variables first
+    assert m.flat_params.numel() >= count and m.flat_params.numel() % 4 == 0
+    off, ln, coef = m._l2_ranges[0]
+    assert off == 0 and coef == 1e-5 and ln == sum(p.t.numel() for p in m.trainable_variables if p.l2 > 0)
+    # unproj is created last inside the VAE (vae.py:105)
+    vnames = [p.name for p in m.vae.trainable_variables]
+    assert vnames[-2:] == ['vae/unproj_k', 'vae/unproj_b']
+
+
+def test_initialisers_follow_keras_variance_scaling():
+    m = Model(base_filters=32, reduction=8)
+    m.build((1, 128, 128, 128, 2))
+    d = {p.name: p for p in m.trainable_variables}
+    k = d['encoder/L1/B0/conv1_k'].t            # he_normal: std = sqrt(2/fan_in), fan_in = 27*32
+    assert float(k.std()) == pytest.approx(math.sqrt(2.0 / (27 * 32)), rel=0.03)
+    assert float(k.abs().max()) <= 2 * math.sqrt(2.0 / (27 * 32)) / 0.87962566103423978 + 1e-6
+    u = d['decoder/L0/up/conv_k'].t             # glorot_uniform, (3,3,3,Cout=32,Cin=64)
+    lim = math.sqrt(6.0 / (27 * 64 + 27 * 32))
+    assert float(u.abs().max()) <= lim and float(u.abs().max()) > 0.95 * lim
+    assert float(d['encoder/L0/B0/gn2/gamma'].t.abs().max()) == 0.0        # resnet.py:104-110
+    assert float(d['encoder/L0/B0/gn1/gamma'].t.min()) == 1.0
+    assert float(d['encoder/L0/B0/conv1_b'].t.abs().max()) == 0.0
+
+
+def test_error_behaviour_matches_reference():
+    with pytest.raises(ValueError, match='Reduction ratio'):
+        resnet.ResnetBlock(filters=6, reduction=4)                                      # resnet.py:39-42
+    g = group_norm.GroupNormalization(groups=8)
+    with pytest.raises(ValueError, match='cannot be'):
+        g.build((1, 4, 4, 4, 4))                                                        # group_norm.py:51-54
+    g = group_norm.GroupNormalization(groups=3)
+    with pytest.raises(ValueError, match='multiple'):
+        g.build((1, 4, 4, 4, 8))                                                        # group_norm.py:56-59
+    with pytest.raises(NotImplementedError):
+        Model(data_format='channels_first')
+
+
+def test_scheduled_optim_schedule():
+    opt = util.ScheduledOptim(learning_rate=1e-4)
+    assert opt.n_epochs == 300.0                                                        # util.py:68 (train.py:105 never overrides)
+    for e in (0, 1, 150, 299):
+        opt(epoch=e)
+        assert opt.learning_rate == pytest.approx(1e-4 * (1.0 - e / 300.0) ** 0.9)
+    opt.iterations = 1
+    assert opt._lr_t() == pytest.approx(opt.learning_rate * math.sqrt(1 - 0.999) / (1 - 0.9))
+
+
+def test_product_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    m = Model(base_filters=4, groups=2, depth=2)
+    with pytest.raises(RuntimeError, match='no CPU'):
+        m(torch.zeros((1, 8, 8, 8, 2)))
+    from bts_amd import ops
+    with pytest.raises(RuntimeError, match='GPU'):
+        ops.conv_pack(1, 0, torch.zeros((3, 3, 3, 4, 4)), 4, 4)
+
+
+def test_bucket_ranges_cover_flat_buffer():
+    n = 42174776
+    r = parallel.bucket_ranges(n, 4, 64 << 20)
+    assert r[0] == (0, 16777216) and sum(l for _, l in r) == n and all(a + l == b for (a, l), (b, _) in zip(r, r[1:]))
+    assert parallel.world() == 1 and parallel.l2_grad_scale() == 1.0
