@@ -165,27 +165,42 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const bool more = (st + 1) < nstages;
     if (more) fetch(st + 1);
 
+    // flattened (k-group, tap) sequence of this stage; weight fragments are prefetched one step ahead so the L2
+    // round trip of step q+1 overlaps the MFMAs of step q
+    const int kg0 = st * KGS;
+    int nkg = p.KG - kg0;
+    if (nkg > KGS) nkg = KGS;
+    const int nq = nkg * p.ntaps;
+    f32x4 a_nx[NS];
+    {
+      const long wo = ((long)p.tap_w[0] * p.KG + kg0) * wstepKG;
 #pragma unroll
-    for (int kgl = 0; kgl < KGS; ++kgl) {
-      const int kg = st * KGS + kgl;
-      if (kg < p.KG) {
-        for (int t = 0; t < p.ntaps; ++t) {
-          const int tl = p.tap_lds[t] + kgl * 8;
-          const long wo = ((long)p.tap_w[t] * p.KG + kg) * wstepKG;
-          f32x4 a[NS], bq[MS];
+      for (int ns = 0; ns < NS; ++ns) a_nx[ns] = *reinterpret_cast<const f32x4*>(wbase[ns] + wo);
+    }
+    int t = 0, kgl = 0;
+    for (int q = 0; q < nq; ++q) {
+      f32x4 a[NS], bq[MS];
 #pragma unroll
-          for (int ns = 0; ns < NS; ++ns) a[ns] = *reinterpret_cast<const f32x4*>(wbase[ns] + wo);
+      for (int ns = 0; ns < NS; ++ns) a[ns] = a_nx[ns];
+      const int tl = p.tap_lds[t] + kgl * 8;
 #pragma unroll
-          for (int ms = 0; ms < MS; ++ms) bq[ms] = *reinterpret_cast<const f32x4*>(cur + bbase[ms] + tl);
+      for (int ms = 0; ms < MS; ++ms) bq[ms] = *reinterpret_cast<const f32x4*>(cur + bbase[ms] + tl);
+      int tn = t + 1, kn = kgl;
+      if (tn == p.ntaps) { tn = 0; kn = kgl + 1; }
+      if (q + 1 < nq) {
+        const long wo = ((long)p.tap_w[tn] * p.KG + (kg0 + kn)) * wstepKG;
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int ms = 0; ms < MS; ++ms)
-#pragma unroll
-              for (int ns = 0; ns < NS; ++ns)
-                acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ns][j], bq[ms][j], acc[ms][ns], 0, 0, 0);
-        }
+        for (int ns = 0; ns < NS; ++ns) a_nx[ns] = *reinterpret_cast<const f32x4*>(wbase[ns] + wo);
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns)
+            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ns][j], bq[ms][j], acc[ms][ns], 0, 0, 0);
+      t = tn;
+      kgl = kn;
     }
     if (more) commit(nxt);
     __syncthreads();

@@ -3,34 +3,44 @@
 //   dW[t][pc][qc] = sum_{n,v} P[n, v*s + off_t, pc] * Q[n, v, qc]        db[qc] = sum_{n,v} Q[n, v, qc]
 //     Conv3D k1 / k3s1 / k3s2 : P = layer input x, Q = dy  -> dW in (t, Cin, Cout)
 //     Conv3DTranspose k3s2    : P = dy (fine grid, s=2), Q = x (coarse grid) -> dW in (t, Cout, Cin)
-// GEMM view per tap: M = 32 P-channels, N = 32 Q-channels, K = voxels (v_mfma_f32_32x32x2_f32, 2 voxels per
-// instruction). A workgroup walks a run of spatial sub-tiles; the 4 waves split the 27 taps (or, for the 1x1x1
-// conv, split the voxels). P halo tile and Q tile are staged in LDS as [voxel][32 ch] so both fragment reads are
-// conflict-free ds_read_b32. Per-workgroup partial sums go to a workspace and are combined in a fixed order by
-// the finalize kernel (bitwise reproducible; no float atomics).
+//     "swapped" k3s1          : P = dy, Q = x with negated tap offsets (u = v + off_t): used when Cout <= 8 so the
+//                               tiny channel count sits on the packable P side
+// GEMM view: M = 32 rows (P channels of one tap, or -- when P has <= 16 channels -- packed (tap, channel) pairs),
+// N = 32 Q-channels, K = voxels (v_mfma_f32_32x32x2_f32 consumes 2 voxels per instruction).
+// A 512-thread workgroup (8 waves) walks a run of spatial sub-tiles; the waves split the row-tiles (27 taps) or, when
+// there are at most 4 row-tiles, the voxel pairs.  P halo tile and Q tile live in LDS as [voxel][channels] so both
+// fragment reads are conflict-free ds_read_b32; the next sub-tile is prefetched global->registers while the current
+// one is multiplied (double-buffered LDS, one barrier per sub-tile).  Per-workgroup partials go to a workspace and are
+// combined in a fixed order by the finalize kernel (bitwise reproducible; no float atomics).
 #include "common.h"
 #include "bts_internal.h"
 
-#define WG_MAXT 7
+#define WG_THREADS 512
+#define WG_WAVES 8
+#define WG_MAXT 4
+#define WG_PSLOTS 8
+#define WG_QSLOTS 4
 
 struct WgradParams {
   const float* p;
   const float* q;
-  float* partial;     // [nsp][pct][qct][ntaps][32][32]
-  double* partial_b;  // [nsp][qct][32]  (bias partials; only pct==0 workgroups write)
+  float* partial;     // [nsp][npct][nqct][ntiles][32][32]
+  double* partial_b;  // [nsp][nqct][32]
   int N, Dp, Hp, Wp, Cp, ldp;
   int Dq, Hq, Wq, Cq, ldq;
   int s, loz, loy, lox;
   int IZ, IY, IX;
   int lgTX, lgTY, TZ;
   int ntz, nty, ntx;
-  int ntaps;
+  int ntaps, ntiles, cpad, lgSP;
   int nsub, sub_per_wg;
   int want_bias;
-  int tap_lds[27];
+  int tap_vox[27];  // voxel offset of each tap inside the P halo tile
 };
 
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+__device__ __forceinline__ int fast_div(int a, float inv) { return (int)(((float)a + 0.5f) * inv); }
+
+__global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -39,10 +49,113 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   const int pct = blockIdx.y, qct = blockIdx.z;
   const int TX = 1 << p.lgTX, TY = 1 << p.lgTY;
   const int M = TX * TY * p.TZ;
+  const int SP = 1 << p.lgSP;
   const int tileVoxP = p.IZ * p.IY * p.IX;
-  float* ldsP = lds;
-  float* ldsQ = lds + tileVoxP * 32;
-  const bool ksplit = p.ntaps < 4;
+  const int bufDw = tileVoxP * SP + M * 32;
+  const bool ksplit = p.ntiles <= WG_MAXT;  // few row-tiles: every wave takes all of them, waves split the voxel pairs
+
+  // ---- per-lane row offsets (dwords inside the P tile) for this wave's row-tiles ----
+  int rowoff[WG_MAXT];
+#pragma unroll
+  for (int i = 0; i < WG_MAXT; ++i) {
+    const int tile = ksplit ? i : wave + WG_WAVES * i;
+    int off = 0;
+    if (tile < p.ntiles) {
+      if (p.cpad == 32) off = (p.tap_vox[tile] << p.lgSP) + l32;
+      else {
+        const int ci = tile * 32 + l32;
+        int tap = ci / p.cpad;
+        const int ch = ci - tap * p.cpad;
+        if (tap >= p.ntaps) tap = 0;  // junk row, never read back
+        off = (p.tap_vox[tap] << p.lgSP) + ch;
+      }
+    }
+    rowoff[i] = off;
+  }
+
+  // ---- staging slots: voxel decomposition is the same for every sub-tile ----
+  const int qpvP = SP >> 2;  // float4 per P voxel
+  const float invIX = 1.0f / (float)p.IX, invIYX = 1.0f / (float)(p.IY * p.IX);
+  int pvz[WG_PSLOTS], pvy[WG_PSLOTS], pvx[WG_PSLOTS], pl[WG_PSLOTS];
+#pragma unroll
+  for (int i = 0; i < WG_PSLOTS; ++i) {
+    const int e = tid + i * WG_THREADS;
+    pl[i] = -1;
+    pvz[i] = pvy[i] = pvx[i] = 0;
+    if (e < tileVoxP * qpvP) {
+      const int vox = e >> (p.lgSP - 2), qd = e & (qpvP - 1);
+      const int vz = fast_div(vox, invIYX);
+      const int r = vox - vz * p.IY * p.IX;
+      const int vy = fast_div(r, invIX);
+      pvz[i] = vz; pvy[i] = vy; pvx[i] = r - vy * p.IX;
+      pl[i] = (vox << p.lgSP) + qd * 4;
+    }
+  }
+  const int pc0 = pct * 32;
+  const int vecP = (p.ldp % 4 == 0) && (p.Cp % 4 == 0) && ((((uintptr_t)p.p) & 15) == 0);
+  const int vecQ = (p.ldq % 4 == 0) && (p.Cq % 4 == 0) && ((((uintptr_t)p.q) & 15) == 0);
+
+  f32x4 preP[WG_PSLOTS], preQ[WG_QSLOTS];
+  auto fetch = [&](int sub) {
+    int b = sub;
+    const int tx = b % p.ntx; b /= p.ntx;
+    const int ty = b % p.nty; b /= p.nty;
+    const int tz = b % p.ntz;
+    const int n = b / p.ntz;
+    const int oz0 = tz * p.TZ, oy0 = ty * TY, ox0 = tx * TX;
+    const int iz0 = oz0 * p.s + p.loz, iy0 = oy0 * p.s + p.loy, ix0 = ox0 * p.s + p.lox;
+#pragma unroll
+    for (int i = 0; i < WG_PSLOTS; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pl[i] >= 0) {
+        const int gz = iz0 + pvz[i], gy = iy0 + pvy[i], gx = ix0 + pvx[i];
+        const int c = pc0 + (pl[i] & (SP - 1));
+        if (gz >= 0 && gz < p.Dp && gy >= 0 && gy < p.Hp && gx >= 0 && gx < p.Wp && c < p.Cp) {
+          const float* src = p.p + ((((long)n * p.Dp + gz) * p.Hp + gy) * p.Wp + gx) * (long)p.ldp + c;
+          if (vecP) v = *reinterpret_cast<const f32x4*>(src);
+          else {
+            v[0] = src[0];
+            if (c + 1 < p.Cp) v[1] = src[1];
+            if (c + 2 < p.Cp) v[2] = src[2];
+            if (c + 3 < p.Cp) v[3] = src[3];
+          }
+        }
+      }
+      preP[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < WG_QSLOTS; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const int e = tid + i * WG_THREADS;
+      if (e < M * 8) {
+        const int m = e >> 3, qd = e & 7;
+        const int gz = oz0 + (m >> (p.lgTX + p.lgTY)), gy = oy0 + ((m >> p.lgTX) & (TY - 1)), gx = ox0 + (m & (TX - 1));
+        const int c = qct * 32 + qd * 4;
+        if (gz < p.Dq && gy < p.Hq && gx < p.Wq && c < p.Cq) {
+          const float* src = p.q + ((((long)n * p.Dq + gz) * p.Hq + gy) * p.Wq + gx) * (long)p.ldq + c;
+          if (vecQ) v = *reinterpret_cast<const f32x4*>(src);
+          else {
+            v[0] = src[0];
+            if (c + 1 < p.Cq) v[1] = src[1];
+            if (c + 2 < p.Cq) v[2] = src[2];
+            if (c + 3 < p.Cq) v[3] = src[3];
+          }
+        }
+      }
+      preQ[i] = v;
+    }
+  };
+  auto commit = [&](float* buf) {
+#pragma unroll
+    for (int i = 0; i < WG_PSLOTS; ++i)
+      if (pl[i] >= 0) *reinterpret_cast<f32x4*>(buf + pl[i]) = preP[i];
+    float* bq = buf + tileVoxP * SP;
+#pragma unroll
+    for (int i = 0; i < WG_QSLOTS; ++i) {
+      const int e = tid + i * WG_THREADS;
+      if (e < M * 8) *reinterpret_cast<f32x4*>(bq + e * 4) = preQ[i];
+    }
+  };
 
   f32x16 acc[WG_MAXT];
 #pragma unroll
@@ -54,140 +167,77 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   const int sub0 = blockIdx.x * p.sub_per_wg;
   int sub1 = sub0 + p.sub_per_wg;
   if (sub1 > p.nsub) sub1 = p.nsub;
-  const int vecP = (p.ldp % 4 == 0) && (p.Cp % 4 == 0) && ((((uintptr_t)p.p) & 15) == 0);
-  const int vecQ = (p.ldq % 4 == 0) && (p.Cq % 4 == 0) && ((((uintptr_t)p.q) & 15) == 0);
+  const int nsteps = M >> 1;
 
+  if (sub0 < sub1) {
+    fetch(sub0);
+    commit(lds);
+  }
+  __syncthreads();
+  int cur = 0;
   for (int sub = sub0; sub < sub1; ++sub) {
-    int b = sub;
-    const int tx = b % p.ntx; b /= p.ntx;
-    const int ty = b % p.nty; b /= p.nty;
-    const int tz = b % p.ntz;
-    const int n = b / p.ntz;
-    const int oz0 = tz * p.TZ, oy0 = ty * TY, ox0 = tx * TX;
-    const int iz0 = oz0 * p.s + p.loz, iy0 = oy0 * p.s + p.loy, ix0 = ox0 * p.s + p.lox;
-
-    __syncthreads();  // previous sub-tile fully consumed
-    // ---- stage P halo tile: [voxel][32] ----
-    for (int e = tid; e < tileVoxP * 8; e += 256) {
-      const int vox = e >> 3, qd = e & 7;
-      const int vx = vox % p.IX;
-      const int r = vox / p.IX;
-      const int vy = r % p.IY, vz = r / p.IY;
-      const int gz = iz0 + vz, gy = iy0 + vy, gx = ix0 + vx;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      const int c = pct * 32 + qd * 4;
-      if (gz >= 0 && gz < p.Dp && gy >= 0 && gy < p.Hp && gx >= 0 && gx < p.Wp && c < p.Cp) {
-        const float* src = p.p + ((((long)n * p.Dp + gz) * p.Hp + gy) * p.Wp + gx) * (long)p.ldp + c;
-        if (vecP) v = *reinterpret_cast<const f32x4*>(src);
-        else {
-          v[0] = src[0];
-          if (c + 1 < p.Cp) v[1] = src[1];
-          if (c + 2 < p.Cp) v[2] = src[2];
-          if (c + 3 < p.Cp) v[3] = src[3];
-        }
-      }
-      *reinterpret_cast<f32x4*>(ldsP + vox * 32 + qd * 4) = v;
-    }
-    // ---- stage Q tile: [m][32]; voxels outside the grid are zero so they contribute nothing ----
-    for (int e = tid; e < M * 8; e += 256) {
-      const int m = e >> 3, qd = e & 7;
-      const int mx = m & (TX - 1);
-      const int my = (m >> p.lgTX) & (TY - 1);
-      const int mz = m >> (p.lgTX + p.lgTY);
-      const int gz = oz0 + mz, gy = oy0 + my, gx = ox0 + mx;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      const int c = qct * 32 + qd * 4;
-      if (gz < p.Dq && gy < p.Hq && gx < p.Wq && c < p.Cq) {
-        const float* src = p.q + ((((long)n * p.Dq + gz) * p.Hq + gy) * p.Wq + gx) * (long)p.ldq + c;
-        if (vecQ) v = *reinterpret_cast<const f32x4*>(src);
-        else {
-          v[0] = src[0];
-          if (c + 1 < p.Cq) v[1] = src[1];
-          if (c + 2 < p.Cq) v[2] = src[2];
-          if (c + 3 < p.Cq) v[3] = src[3];
-        }
-      }
-      *reinterpret_cast<f32x4*>(ldsQ + m * 32 + qd * 4) = v;
-    }
-    __syncthreads();
+    const float* bp = lds + cur * bufDw;
+    const float* bq = bp + tileVoxP * SP;
+    const bool more = (sub + 1) < sub1;
+    if (more) fetch(sub + 1);
 
     if (p.want_bias && pct == 0) {
       const int c = tid & 31, part = tid >> 5;
       float s = 0.f;
-      for (int m = part; m < M; m += 8) s += ldsQ[m * 32 + c];
+      for (int m = part; m < M; m += 16) s += bq[m * 32 + c];
       bsum += (double)s;
     }
-
-    const int nsteps = M >> 1;
-    if (!ksplit) {
-      for (int st = 0; st < nsteps; ++st) {
-        const int m = 2 * st + h;
-        const int mx = m & (TX - 1);
-        const int my = (m >> p.lgTX) & (TY - 1);
-        const int mz = m >> (p.lgTX + p.lgTY);
-        const int poff = ((mz * p.s * p.IY + my * p.s) * p.IX + mx * p.s) * 32 + l32;
-        const float qv = ldsQ[m * 32 + l32];
+    const int st0 = ksplit ? wave : 0, stinc = ksplit ? WG_WAVES : 1;
+    for (int st = st0; st < nsteps; st += stinc) {
+      const int m = 2 * st + h;
+      const int mx = m & (TX - 1);
+      const int my = (m >> p.lgTX) & (TY - 1);
+      const int mz = m >> (p.lgTX + p.lgTY);
+      const int pvox = ((mz * p.s * p.IY + my * p.s) * p.IX + mx * p.s) << p.lgSP;
+      const float qv = bq[m * 32 + l32];
 #pragma unroll
-        for (int i = 0; i < WG_MAXT; ++i) {
-          const int t = wave + 4 * i;
-          if (t < p.ntaps) {
-            const float pv = ldsP[poff + p.tap_lds[t]];
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, qv, acc[i], 0, 0, 0);
-          }
-        }
-      }
-    } else {
-      // 1x1x1 conv (ntaps==1..3): waves split the voxel pairs; every wave handles all taps
-      for (int st = wave; st < nsteps; st += 4) {
-        const int m = 2 * st + h;
-        const int mx = m & (TX - 1);
-        const int my = (m >> p.lgTX) & (TY - 1);
-        const int mz = m >> (p.lgTX + p.lgTY);
-        const int poff = ((mz * p.s * p.IY + my * p.s) * p.IX + mx * p.s) * 32 + l32;
-        const float qv = ldsQ[m * 32 + l32];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          if (i < p.ntaps) {
-            const float pv = ldsP[poff + p.tap_lds[i]];
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, qv, acc[i], 0, 0, 0);
-          }
+      for (int i = 0; i < WG_MAXT; ++i) {
+        const int tile = ksplit ? i : wave + WG_WAVES * i;
+        if (tile < p.ntiles) {
+          const float pv = bp[pvox + rowoff[i]];
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, qv, acc[i], 0, 0, 0);
         }
       }
     }
+    if (more) commit(lds + (cur ^ 1) * bufDw);
+    __syncthreads();
+    cur ^= 1;
   }
 
   // ---- write partials ----
-  const long tileBase = ((((long)blockIdx.x * gridDim.y + pct) * gridDim.z + qct) * p.ntaps) * 1024;
+  const long tileBase = ((((long)blockIdx.x * gridDim.y + pct) * gridDim.z + qct) * p.ntiles) * 1024;
   if (!ksplit) {
 #pragma unroll
     for (int i = 0; i < WG_MAXT; ++i) {
-      const int t = wave + 4 * i;
-      if (t < p.ntaps) {
-        float* dst = p.partial + tileBase + (long)t * 1024;
+      const int tile = wave + WG_WAVES * i;
+      if (tile < p.ntiles) {
+        float* dst = p.partial + tileBase + (long)tile * 1024;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;  // P channel
-          dst[row * 32 + l32] = acc[i][r];
-        }
+        for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l32] = acc[i][r];
       }
     }
   } else {
-    // cross-wave fixed-order reduction through LDS (reuse the staging buffers)
-    for (int i = 0; i < p.ntaps; ++i) {
-      __syncthreads();
+    // cross-wave fixed-order reduction through LDS (staging buffers are free now)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        float v = 0.f;
-        // static register selection
-        if (i == 0) v = acc[0][r];
-        else if (i == 1) v = acc[1][r];
-        else v = acc[2][r];
-        lds[wave * 1024 + row * 32 + l32] = v;
+    for (int i = 0; i < WG_MAXT; ++i) {
+      if (i < p.ntiles) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lds[wave * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l32] = acc[i][r];
+        __syncthreads();
+        float* dst = p.partial + tileBase + (long)i * 1024;
+        for (int e = tid; e < 1024; e += WG_THREADS) {
+          float s = lds[e];
+#pragma unroll
+          for (int w = 1; w < WG_WAVES; ++w) s += lds[w * 1024 + e];
+          dst[e] = s;
+        }
       }
-      __syncthreads();
-      float* dst = p.partial + tileBase + (long)i * 1024;
-      for (int e = tid; e < 1024; e += 256) dst[e] = ((lds[e] + lds[1024 + e]) + lds[2048 + e]) + lds[3072 + e];
     }
   }
   if (p.want_bias && pct == 0) {
@@ -197,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     __syncthreads();
     if (tid < 32) {
       double s = 0.0;
-      for (int part = 0; part < 8; ++part) s += shd[part * 32 + tid];
+      for (int part = 0; part < 16; ++part) s += shd[part * 32 + tid];
       p.partial_b[((long)blockIdx.x * gridDim.z + qct) * 32 + tid] = s;
     }
   }
@@ -208,37 +258,61 @@ struct WfinParams {
   const double* partial_b;
   float* dw;
   float* db;
-  int nsp, npct, nqct, ntaps, Cp, Cq;
+  int nsp, npct, nqct, ntaps, ntiles, cpad, Cp, Cq;
   long sT, sP, sQ;
-  int fold_on_p;  // 1: the P-channel axis is the (possibly folded) reference Cin axis
+  int fold_axis;  // 0 none, 1 the P-channel axis is the (possibly folded) reference Cin axis, 2 the Q axis is
   int shift, dup_start;
   int accum;
 };
 
-// dW[t][r(pc)][qc] (+)= sum_wg partial ; folded slab channel pc maps to reference channel pc+shift and, if
-// pc >= dup_start, also to pc-dup_start (both copies of the duplicated slice see the same input: encoder.py:83-87).
-__global__ void wgrad_finalize_kernel(const WfinParams f) {
-  const long total = (long)f.ntaps * f.Cp * f.Cq;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int qc = (int)(i % f.Cq);
-    long r = i / f.Cq;
+// dW[t][pc][qc] (+)= sum_wg partial. 256 threads = 32 consecutive qc x 8 partial-lanes, fixed-order combine.
+// Folded slab channel c maps to reference channel c+shift and, if c >= dup_start, also to c-dup_start (both copies of
+// the duplicated slice see the same input: encoder.py:83-87).
+__global__ __launch_bounds__(256) void wgrad_finalize_kernel(const WfinParams f) {
+  __shared__ float sh[8][33];
+  const int e = threadIdx.x & 31, wl = threadIdx.x >> 5;
+  const long rows = (long)f.ntaps * f.Cp * f.nqct;  // one row = 32 consecutive qc of one (t, pc, qct)
+  const long wgStride = (long)f.npct * f.nqct * f.ntiles * 1024;
+  for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int qct = (int)(row % f.nqct);
+    long r = row / f.nqct;
     const int pc = (int)(r % f.Cp);
     const int t = (int)(r / f.Cp);
-    const int pct = pc >> 5, qct = qc >> 5;
-    const long off = (((long)pct * f.nqct + qct) * f.ntaps + t) * 1024 + (pc & 31) * 32 + (qc & 31);
-    const long wgStride = (long)f.npct * f.nqct * f.ntaps * 1024;
+    long off;
+    if (f.cpad == 32) off = ((((long)(pc >> 5)) * f.nqct + qct) * f.ntiles + t) * 1024 + (pc & 31) * 32 + e;
+    else {
+      const int ci = t * f.cpad + pc;
+      off = ((long)qct * f.ntiles + (ci >> 5)) * 1024 + (ci & 31) * 32 + e;
+    }
     float s = 0.f;
-    for (int w = 0; w < f.nsp; ++w) s += f.partial[w * wgStride + off];
-    const int pr = f.fold_on_p ? pc + f.shift : pc;
-    float* d1 = f.dw + t * f.sT + pr * f.sP + qc * f.sQ;
-    *d1 = f.accum ? (*d1 + s) : s;
-    if (f.fold_on_p && f.shift > 0 && pc >= f.dup_start) {
-      float* d2 = f.dw + t * f.sT + (pc - f.dup_start) * f.sP + qc * f.sQ;
-      *d2 = f.accum ? (*d2 + s) : s;
+    for (int w = wl; w < f.nsp; w += 8) s += f.partial[w * wgStride + off];
+    __syncthreads();
+    sh[wl][e] = s;
+    __syncthreads();
+    if (wl == 0) {
+      float tot = sh[0][e];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) tot += sh[k][e];
+      const int qc = qct * 32 + e;
+      if (qc < f.Cq) {
+        const int pr = (f.fold_axis == 1) ? pc + f.shift : pc;
+        const int qr = (f.fold_axis == 2) ? qc + f.shift : qc;
+        float* d1 = f.dw + t * f.sT + pr * f.sP + qr * f.sQ;
+        *d1 = f.accum ? (*d1 + tot) : tot;
+        if (f.shift > 0) {
+          if (f.fold_axis == 1 && pc >= f.dup_start) {
+            float* d2 = f.dw + t * f.sT + (pc - f.dup_start) * f.sP + qr * f.sQ;
+            *d2 = f.accum ? (*d2 + tot) : tot;
+          } else if (f.fold_axis == 2 && qc >= f.dup_start) {
+            float* d2 = f.dw + t * f.sT + pr * f.sP + (qc - f.dup_start) * f.sQ;
+            *d2 = f.accum ? (*d2 + tot) : tot;
+          }
+        }
+      }
     }
   }
-  if (f.db) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < f.Cq; i += (long)gridDim.x * blockDim.x) {
+  if (f.db && blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < f.Cq; i += blockDim.x) {
       double s = 0.0;
       for (int w = 0; w < f.nsp; ++w) s += f.partial_b[((long)w * f.nqct + (i >> 5)) * 32 + (i & 31)];
       f.db[i] = f.accum ? (f.db[i] + (float)s) : (float)s;
@@ -256,8 +330,9 @@ struct WgradPlan {
   long partial_b_doubles;
 };
 
-static int plan_wgrad(WgradPlan& pl, int ntaps, int s, int N, int Dp, int Hp, int Wp_, int Cp, int Dq, int Hq, int Wq,
-                      int Cq) {
+// neg: tap offsets are negated (swapped-role form, s == 1 only)
+static int plan_wgrad(WgradPlan& pl, int ntaps, int s, int neg, int N, int Dp, int Hp, int Wp_, int Cp, int Dq, int Hq,
+                      int Wq, int Cq) {
   WgradParams& p = pl.p;
   p.N = N; p.Dp = Dp; p.Hp = Hp; p.Wp = Wp_; p.Cp = Cp;
   p.Dq = Dq; p.Hq = Hq; p.Wq = Wq; p.Cq = Cq;
@@ -266,6 +341,13 @@ static int plan_wgrad(WgradPlan& pl, int ntaps, int s, int N, int Dp, int Hp, in
   if (ntaps == 27 && s == 1) { lo = -1; span = 3; }
   if (ntaps == 27 && s == 2) { lo = 0; span = 3; }
   p.loz = p.loy = p.lox = lo;
+  // (tap, channel) row packing when P has few channels
+  int cpad = 32;
+  if (Cp <= 16 && ntaps == 27) { cpad = 2; while (cpad < Cp) cpad *= 2; }
+  p.cpad = cpad;
+  const int SP = cpad == 32 ? 32 : (cpad < 4 ? 4 : cpad);
+  p.lgSP = ilog2w(SP);
+  p.ntiles = (cpad == 32) ? ntaps : (ntaps * cpad + 31) / 32;
   // sub-tile: 128 voxels for s=1 (16x4x2), 32 voxels for s=2 (8x4x1); 1x1x1: 256 voxels (32x4x2)
   int TX, TY, TZ;
   if (ntaps == 1) { TX = 32; TY = 4; TZ = 2; }
@@ -273,103 +355,124 @@ static int plan_wgrad(WgradPlan& pl, int ntaps, int s, int N, int Dp, int Hp, in
   else { TX = 8; TY = 4; TZ = 1; }
   while (TX > 2 && TX / 2 >= Wq) { TX /= 2; if (TY * 2 <= 8) TY *= 2; else TZ *= 2; }
   while (TY > 1 && TY / 2 >= Hq) { TY /= 2; TZ *= 2; }
+  while (TZ > 1 && TZ / 2 >= Dq && TX * TY * (TZ / 2) >= 2) TZ /= 2;
   p.lgTX = ilog2w(TX); p.lgTY = ilog2w(TY); p.TZ = TZ;
   p.ntx = (Wq + TX - 1) / TX; p.nty = (Hq + TY - 1) / TY; p.ntz = (Dq + TZ - 1) / TZ;
   p.IX = (TX - 1) * s + span; p.IY = (TY - 1) * s + span; p.IZ = (TZ - 1) * s + span;
   const int tileVoxP = p.IZ * p.IY * p.IX;
   const int M = TX * TY * TZ;
-  pl.shmem = (size_t)(tileVoxP + M) * 32 * sizeof(float);
-  if (pl.shmem < 4 * 1024 * sizeof(float)) pl.shmem = 4 * 1024 * sizeof(float);
+  if (tileVoxP * (SP / 4) > WG_THREADS * WG_PSLOTS || M * 8 > WG_THREADS * WG_QSLOTS) return BTS_ERR_SHAPE;
+  pl.shmem = (size_t)2 * (tileVoxP * SP + M * 32) * sizeof(float);
+  if (pl.shmem < (size_t)WG_WAVES * 1024 * sizeof(float)) pl.shmem = (size_t)WG_WAVES * 1024 * sizeof(float);
   if (pl.shmem > 160 * 1024) return BTS_ERR_SHAPE;
-  for (int t = 0; t < 27; ++t) p.tap_lds[t] = 0;
+  for (int t = 0; t < 27; ++t) p.tap_vox[t] = 0;
   if (ntaps == 27)
     for (int t = 0; t < 27; ++t) {
-      const int oz = t / 9 + (s == 1 ? -1 : 0), oy = (t / 3) % 3 + (s == 1 ? -1 : 0), ox = t % 3 + (s == 1 ? -1 : 0);
-      p.tap_lds[t] = (((oz - lo) * p.IY + (oy - lo)) * p.IX + (ox - lo)) * 32;
+      int oz = t / 9 + (s == 1 ? -1 : 0), oy = (t / 3) % 3 + (s == 1 ? -1 : 0), ox = t % 3 + (s == 1 ? -1 : 0);
+      if (neg) { oz = -oz; oy = -oy; ox = -ox; }
+      p.tap_vox[t] = ((oz - lo) * p.IY + (oy - lo)) * p.IX + (ox - lo);
     }
   p.nsub = N * p.ntz * p.nty * p.ntx;
-  pl.npct = (Cp + 31) / 32;
+  pl.npct = (cpad == 32) ? (Cp + 31) / 32 : 1;
   pl.nqct = (Cq + 31) / 32;
-  long want = 1024 / ((long)pl.npct * pl.nqct);
+  long want = 512 / ((long)pl.npct * pl.nqct);
   if (want < 1) want = 1;
   if (want > p.nsub) want = p.nsub;
   p.sub_per_wg = (int)((p.nsub + want - 1) / want);
   pl.nsp = (p.nsub + p.sub_per_wg - 1) / p.sub_per_wg;
-  pl.partial_floats = (long)pl.nsp * pl.npct * pl.nqct * ntaps * 1024;
+  pl.partial_floats = (long)pl.nsp * pl.npct * pl.nqct * p.ntiles * 1024;
   pl.partial_b_doubles = (long)pl.nsp * pl.nqct * 32;
   return BTS_OK;
 }
 
-static int wgrad_dims(int kind, int D, int H, int W, int Cin, int Cout, int& ntaps, int& s, int& Dp, int& Hp, int& Wp_,
-                      int& Cp, int& Dq, int& Hq, int& Wq, int& Cq) {
-  ntaps = (kind == BTS_CONV_K1) ? 1 : 27;
-  s = 1;
-  Dp = D; Hp = H; Wp_ = W; Cp = Cin; Dq = D; Hq = H; Wq = W; Cq = Cout;
+struct WgradRoles {
+  int ntaps, s, neg, swapped, transposed;
+  int Dp, Hp, Wp, Cp, Dq, Hq, Wq, Cq;
+};
+
+static int wgrad_roles(WgradRoles& r, int kind, int D, int H, int W, int Cin, int Cout) {
+  r.ntaps = (kind == BTS_CONV_K1) ? 1 : 27;
+  r.s = 1; r.neg = 0; r.swapped = 0; r.transposed = 0;
+  r.Dp = D; r.Hp = H; r.Wp = W; r.Cp = Cin; r.Dq = D; r.Hq = H; r.Wq = W; r.Cq = Cout;
   if (kind == BTS_CONV_K3S2) {
     if ((D | H | W) & 1) return BTS_ERR_SHAPE;
-    s = 2; Dq = D / 2; Hq = H / 2; Wq = W / 2;
+    r.s = 2; r.Dq = D / 2; r.Hq = H / 2; r.Wq = W / 2;
   } else if (kind == BTS_CONV_K3S2T) {  // P = dy on the fine grid (2D), Q = x on the coarse grid
-    s = 2; Dp = 2 * D; Hp = 2 * H; Wp_ = 2 * W; Cp = Cout; Cq = Cin;
+    r.transposed = 1;
+    r.s = 2; r.Dp = 2 * D; r.Hp = 2 * H; r.Wp = 2 * W; r.Cp = Cout; r.Cq = Cin;
+  } else if (kind == BTS_CONV_K3S1 && Cout <= 8 && Cin > Cout) {
+    r.swapped = 1; r.neg = 1; r.Cp = Cout; r.Cq = Cin;  // P = dy (tiny), Q = x
   }
   return BTS_OK;
 }
 
+extern "C" int bts_colsum(const float* x, float* out, void* workspace, long workspace_bytes, int N, long rows, int C,
+                          int ld, float scale, int sum_over_n, int accumulate, hipStream_t stream);
+extern "C" long bts_colsum_workspace(int N, long rows, int C);
+
 // workspace bytes for bts_conv3d_bwd_weight; (D,H,W) are the forward INPUT dims, Cin the slab (folded) count
 extern "C" long bts_conv3d_bwd_weight_workspace(int kind, int N, int D, int H, int W, int Cin, int Cout) {
-  int ntaps, s, Dp, Hp, Wp_, Cp, Dq, Hq, Wq, Cq;
-  if (wgrad_dims(kind, D, H, W, Cin, Cout, ntaps, s, Dp, Hp, Wp_, Cp, Dq, Hq, Wq, Cq) != BTS_OK) return -1;
+  WgradRoles r;
+  if (wgrad_roles(r, kind, D, H, W, Cin, Cout) != BTS_OK) return -1;
   WgradPlan pl;
-  if (plan_wgrad(pl, ntaps, s, N, Dp, Hp, Wp_, Cp, Dq, Hq, Wq, Cq) != BTS_OK) return -1;
-  return pl.partial_floats * 4 + pl.partial_b_doubles * 8 + 256;
+  if (plan_wgrad(pl, r.ntaps, r.s, r.neg, N, r.Dp, r.Hp, r.Wp, r.Cp, r.Dq, r.Hq, r.Wq, r.Cq) != BTS_OK) return -1;
+  const long base = ((pl.partial_floats * 4 + pl.partial_b_doubles * 8 + 256 + 15) & ~15L);
+  return base + (r.swapped ? bts_colsum_workspace(N, (long)D * H * W, Cout) : 0);
 }
 
 // dw is in the reference layout with Cin_ref = Cin + dup_shift input channels; db may be null.
 extern "C" int bts_conv3d_bwd_weight(int kind, const float* x, const float* dy, float* dw, float* db, void* workspace,
                                      long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout,
                                      int lddy, int dup_start, int dup_shift, int accumulate, hipStream_t stream) {
-  int ntaps, s, Dp, Hp, Wp_, Cp, Dq, Hq, Wq, Cq;
-  int r = wgrad_dims(kind, D, H, W, Cin, Cout, ntaps, s, Dp, Hp, Wp_, Cp, Dq, Hq, Wq, Cq);
+  WgradRoles ro;
+  int r = wgrad_roles(ro, kind, D, H, W, Cin, Cout);
   if (r != BTS_OK) return r;
   if (dup_shift > 0 && (kind == BTS_CONV_K3S2 || kind == BTS_CONV_K3S2T)) return BTS_ERR_UNSUPPORTED;
   WgradPlan pl;
-  r = plan_wgrad(pl, ntaps, s, N, Dp, Hp, Wp_, Cp, Dq, Hq, Wq, Cq);
+  r = plan_wgrad(pl, ro.ntaps, ro.s, ro.neg, N, ro.Dp, ro.Hp, ro.Wp, ro.Cp, ro.Dq, ro.Hq, ro.Wq, ro.Cq);
   if (r != BTS_OK) return r;
-  const long need = pl.partial_floats * 4 + pl.partial_b_doubles * 8 + 256;
+  const long need = bts_conv3d_bwd_weight_workspace(kind, N, D, H, W, Cin, Cout);
   if (workspace_bytes < need || workspace == nullptr) return BTS_ERR_WORKSPACE;
   WgradParams& p = pl.p;
-  const bool transposed = (kind == BTS_CONV_K3S2T);
-  p.p = transposed ? dy : x;
-  p.q = transposed ? x : dy;
-  p.ldp = transposed ? lddy : ldx;
-  p.ldq = transposed ? ldx : lddy;
+  const bool pIsDy = ro.transposed || ro.swapped;
+  p.p = pIsDy ? dy : x;
+  p.q = pIsDy ? x : dy;
+  p.ldp = pIsDy ? lddy : ldx;
+  p.ldq = pIsDy ? ldx : lddy;
   p.partial = reinterpret_cast<float*>(workspace);
   uintptr_t pb = (uintptr_t)(p.partial + pl.partial_floats);
   pb = (pb + 15) & ~(uintptr_t)15;
   p.partial_b = reinterpret_cast<double*>(pb);
-  // bias gradient = column sums of dy: dy is Q except for the transposed conv, where db is computed elsewhere
-  p.want_bias = (db != nullptr && !transposed) ? 1 : 0;
+  // bias gradient = column sums of dy: dy is Q in the plain form only
+  p.want_bias = (db != nullptr && !pIsDy) ? 1 : 0;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  (void)hipGetLastError(); hipLaunchKernelGGL(wgrad_kernel, dim3(pl.nsp, pl.npct, pl.nqct), dim3(256), pl.shmem, stream, p);
+  (void)hipGetLastError(); hipLaunchKernelGGL(wgrad_kernel, dim3(pl.nsp, pl.npct, pl.nqct), dim3(WG_THREADS), pl.shmem, stream, p);
   BTS_LAUNCH_CHECK();
   WfinParams f;
   f.partial = p.partial; f.partial_b = p.partial_b; f.dw = dw; f.db = p.want_bias ? db : nullptr;
-  f.nsp = pl.nsp; f.npct = pl.npct; f.nqct = pl.nqct; f.ntaps = ntaps; f.Cp = Cp; f.Cq = Cq;
+  f.nsp = pl.nsp; f.npct = pl.npct; f.nqct = pl.nqct; f.ntaps = ro.ntaps; f.ntiles = p.ntiles; f.cpad = p.cpad;
+  f.Cp = ro.Cp; f.Cq = ro.Cq;
   const int Cin_ref = Cin + dup_shift;
   f.sT = (long)Cin_ref * Cout;
-  if (transposed) { f.sP = Cin_ref; f.sQ = 1; f.fold_on_p = 0; }  // (t, Cout, Cin): P = cout, Q = cin
-  else { f.sP = Cout; f.sQ = 1; f.fold_on_p = 1; }                // (t, Cin, Cout)
+  if (ro.transposed) { f.sP = Cin_ref; f.sQ = 1; f.fold_axis = 0; }   // (t, Cout, Cin): P = cout, Q = cin
+  else if (ro.swapped) { f.sP = 1; f.sQ = Cout; f.fold_axis = 2; }     // (t, Cin, Cout): P = cout, Q = cin
+  else { f.sP = Cout; f.sQ = 1; f.fold_axis = 1; }                     // (t, Cin, Cout): P = cin, Q = cout
   f.shift = dup_shift;
   f.dup_start = dup_shift > 0 ? dup_start : (1 << 30);
   f.accum = accumulate;
-  const long total = (long)ntaps * Cp * Cq;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
+  long rows = (long)ro.ntaps * ro.Cp * pl.nqct;
+  int blocks = (int)(rows < 4096 ? rows : 4096);
   (void)hipGetLastError(); hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, stream, f);
   BTS_LAUNCH_CHECK();
+  if (db != nullptr && ro.swapped) {  // bias gradient of the swapped form: plain column sum of dy
+    char* cw = reinterpret_cast<char*>(workspace) + ((pl.partial_floats * 4 + pl.partial_b_doubles * 8 + 256 + 15) & ~15L);
+    const long rowsv = (long)D * H * W;
+    return bts_colsum(dy, db, cw, bts_colsum_workspace(N, rowsv, Cout), N, rowsv, Cout, lddy, 1.0f, 1, accumulate, stream);
+  }
   return BTS_OK;
 }

@@ -95,28 +95,33 @@ __global__ __launch_bounds__(256) void gn_stats_channel_kernel(const float* __re
   }
 }
 
-// one thread per (n,g)
-__global__ void gn_stats_finalize_kernel(const double* partial, float* mean, float* rstd, int NG, int B, int C, int G,
-                                         int mode, double count, float eps) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per (n,g): lanes split the partial blocks, fixed-order shuffle tree
+__global__ __launch_bounds__(256) void gn_stats_finalize_kernel(const double* partial, float* mean, float* rstd, int NG, int B,
+                                                                int C, int G, int mode, double count, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= NG) return;
   double s = 0.0, ss = 0.0;
   if (mode == BTS_GN_SLAB) {
-    for (int b = 0; b < B; ++b) { s += partial[((long)i * B + b) * 2]; ss += partial[((long)i * B + b) * 2 + 1]; }
+    for (int b = lane; b < B; b += 64) { s += partial[((long)i * B + b) * 2]; ss += partial[((long)i * B + b) * 2 + 1]; }
   } else {
     const int n = i / G, g = i % G, cg = C / G;
-    for (int b = 0; b < B; ++b)
-      for (int c = g * cg; c < (g + 1) * cg; ++c) {
-        const long o = (((long)n * B + b) * C + c) * 2;
-        s += partial[o];
-        ss += partial[o + 1];
-      }
+    for (int k = lane; k < B * cg; k += 64) {
+      const int b = k / cg, c = g * cg + k % cg;
+      const long o = (((long)n * B + b) * C + c) * 2;
+      s += partial[o];
+      ss += partial[o + 1];
+    }
   }
-  const double m = s / count;
-  double var = ss / count - m * m;
-  if (var < 0.0) var = 0.0;
-  mean[i] = (float)m;
-  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+  s = wave_sum_f64(s);
+  ss = wave_sum_f64(ss);
+  if (lane == 0) {
+    const double m = s / count;
+    double var = ss / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[i] = (float)m;
+    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 
@@ -255,7 +260,7 @@ extern "C" int bts_gn_stats(const float* x, float* mean, float* rstd, void* work
   }
   BTS_LAUNCH_CHECK();
   const int NG = N * G;
-  (void)hipGetLastError(); hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3((NG + 63) / 64), dim3(64), 0, stream, partial, mean, rstd, NG, g.B,
+  (void)hipGetLastError(); hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3((NG + 3) / 4), dim3(256), 0, stream, partial, mean, rstd, NG, g.B,
                      C, G, mode, (double)g.L, eps);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
@@ -386,35 +391,37 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-// one block; thread per affine index idx (C of them): reduces over blocks and samples, writes dgamma/dbeta,
-// then thread per (n,g) computes c1,c2.
-__global__ void gn_bwd_finalize_kernel(const double* partial, const float* gamma, float* dgamma, float* dbeta,
-                                       float* c1, float* c2, double* scratch /*N*C*2*/, int N, int B, int C, int G,
-                                       int mode, double L, int accum) {
+// stage A: one wave per (n, idx): sum the per-block partials (lanes split the blocks) -> scratch[(n*C+idx)*2 + {A,B}]
+__global__ __launch_bounds__(256) void gn_bwd_finalize_a_kernel(const double* partial, double* scratch, int N, int B, int C,
+                                                                int G, int mode) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= N * C) return;
   const int cg = C / G;
-  const bool slab = (mode == BTS_GN_SLAB);
-  // per (n, idx): A, B summed over blocks
-  for (int t = threadIdx.x; t < N * C; t += blockDim.x) {
-    const int n = t / C, idx = t % C;
-    double sa = 0.0, sb = 0.0;
-    if (slab) {
-      const int g = idx / cg, j = idx % cg;
-      for (int b = 0; b < B; ++b) {
-        const long o = ((((long)n * G + g) * B + b) * cg + j) * 2;
-        sa += partial[o];
-        sb += partial[o + 1];
-      }
-    } else {
-      for (int b = 0; b < B; ++b) {
-        const long o = (((long)n * B + b) * C + idx) * 2;
-        sa += partial[o];
-        sb += partial[o + 1];
-      }
+  const int n = t / C, idx = t % C;
+  double sa = 0.0, sb = 0.0;
+  if (mode == BTS_GN_SLAB) {
+    const int g = idx / cg, j = idx % cg;
+    for (int b = lane; b < B; b += 64) {
+      const long o = ((((long)n * G + g) * B + b) * cg + j) * 2;
+      sa += partial[o];
+      sb += partial[o + 1];
     }
-    scratch[t * 2] = sa;
-    scratch[t * 2 + 1] = sb;
+  } else {
+    for (int b = lane; b < B; b += 64) {
+      const long o = (((long)n * B + b) * C + idx) * 2;
+      sa += partial[o];
+      sb += partial[o + 1];
+    }
   }
-  __syncthreads();
+  sa = wave_sum_f64(sa);
+  sb = wave_sum_f64(sb);
+  if (lane == 0) { scratch[t * 2] = sa; scratch[t * 2 + 1] = sb; }
+}
+// stage B (one block): dgamma/dbeta over samples, then c1,c2 per (n,g)
+__global__ void gn_bwd_finalize_kernel(const float* gamma, float* dgamma, float* dbeta, float* c1, float* c2,
+                                       const double* scratch /*N*C*2*/, int N, int C, int G, double L, int accum) {
+  const int cg = C / G;
   for (int idx = threadIdx.x; idx < C; idx += blockDim.x) {
     double sa = 0.0, sb = 0.0;
     for (int n = 0; n < N; ++n) { sa += scratch[(n * C + idx) * 2]; sb += scratch[(n * C + idx) * 2 + 1]; }
@@ -502,8 +509,10 @@ extern "C" int bts_gn_bwd(const float* x, const float* dy, float* dx, const floa
   (void)hipGetLastError(); hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(g.B, slab ? N * G : N), dim3(256), 0, stream, x, dy, gamma, beta, mean,
                      rstd, partial, g.E, g.L, g.span, C, G, g.cg, lddy, mode, relu);
   BTS_LAUNCH_CHECK();
-  (void)hipGetLastError(); hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, gamma, dgamma, dbeta, c1, c2,
-                     scratch, N, g.B, C, G, mode, (double)g.L, accumulate_params);
+  (void)hipGetLastError(); hipLaunchKernelGGL(gn_bwd_finalize_a_kernel, dim3((N * C + 3) / 4), dim3(256), 0, stream, partial, scratch, N, g.B, C, G, mode);
+  BTS_LAUNCH_CHECK();
+  (void)hipGetLastError(); hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), 0, stream, gamma, dgamma, dbeta, c1, c2, scratch, N, C, G,
+                     (double)g.L, accumulate_params);
   BTS_LAUNCH_CHECK();
   const long total4 = (long)N * g.E / 4;
   int blocks = (int)((total4 + 255) / 256);

@@ -55,18 +55,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
 }
 
-__global__ void colsum_finalize_kernel(const double* partial, float* out, int N, int B, int C, double scale, int accum,
-                                       int sum_over_n) {
+// one wave per output element: lanes split the partial blocks, fixed-order shuffle tree
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const double* partial, float* out, int N, int B, int C,
+                                                              double scale, int accum, int sum_over_n) {
+  const int lane = threadIdx.x & 63;
   const int total = sum_over_n ? C : N * C;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    double s = 0.0;
-    if (sum_over_n) {
-      for (int n = 0; n < N; ++n)
-        for (int b = 0; b < B; ++b) s += partial[((long)n * B + b) * C + i];
-    } else {
-      const int n = i / C, c = i % C;
-      for (int b = 0; b < B; ++b) s += partial[((long)n * B + b) * C + c];
-    }
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= total) return;
+  double s = 0.0;
+  if (sum_over_n) {
+    for (int k = lane; k < N * B; k += 64) s += partial[(long)k * C + i];
+  } else {
+    const int n = i / C, c = i % C;
+    for (int b = lane; b < B; b += 64) s += partial[((long)n * B + b) * C + c];
+  }
+  s = wave_sum_f64(s);
+  if (lane == 0) {
     const float v = (float)(s * scale);
     out[i] = accum ? out[i] + v : v;
   }
@@ -94,7 +98,7 @@ extern "C" int bts_colsum(const float* x, float* out, void* workspace, long work
   (void)hipGetLastError(); hipLaunchKernelGGL(colsum_kernel, dim3(B, N), dim3(256), 0, stream, x, partial, rows, C, ld, rspan, vec);
   BTS_LAUNCH_CHECK();
   const int total = sum_over_n ? C : N * C;
-  (void)hipGetLastError(); hipLaunchKernelGGL(colsum_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, partial, out, N, B, C,
+  (void)hipGetLastError(); hipLaunchKernelGGL(colsum_finalize_kernel, dim3((total + 3) / 4), dim3(256), 0, stream, partial, out, N, B, C,
                      (double)scale, accumulate, sum_over_n);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
@@ -236,6 +240,23 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float* __restr
   }
 }
 
+// stage 2a: one wave per (n,c): sum the per-block partials -> red[(n*F+c)*2 + {ch, w}]
+__global__ __launch_bounds__(256) void se_bwd_partial_reduce_kernel(const double* partial, double* red, int N, int B, int F) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= N * F) return;
+  const int n = i / F, c = i % F;
+  double a = 0.0, b = 0.0;
+  for (int k = lane; k < B; k += 64) {
+    const long o = (((long)n * B + k) * F + c) * 2;
+    a += partial[o];
+    b += partial[o + 1];
+  }
+  a = wave_sum_f64(a);
+  b = wave_sum_f64(b);
+  if (lane == 0) { red[i * 2] = a; red[i * 2 + 1] = b; }
+}
+
 // stage 2 (one block): finish the sums, SE-MLP backward, emit dgap (already divided by V) for stage 3
 __global__ void se_mlp_bwd_kernel(const double* partial, const float* gap, const float* hbuf, const float* ch,
                                   const float* w1, const float* w2, float* dw1, float* dw2, float* dwsp, float* dgap,
@@ -244,15 +265,13 @@ __global__ void se_mlp_bwd_kernel(const double* partial, const float* gap, const
   double* dz1 = scratch + (long)N * F;
   for (int i = threadIdx.x; i < N * F; i += blockDim.x) {
     const int n = i / F, c = i % F;
-    double s = 0.0;
-    for (int b = 0; b < B; ++b) s += partial[(((long)n * B + b) * F + c) * 2];
+    const double s = partial[((long)n * F + c) * 2];
     const double cc = (double)ch[i];
     dz2[i] = s * cc * (1.0 - cc);
   }
   for (int c = threadIdx.x; c < F; c += blockDim.x) {
     double s = 0.0;
-    for (int n = 0; n < N; ++n)
-      for (int b = 0; b < B; ++b) s += partial[(((long)n * B + b) * F + c) * 2 + 1];
+    for (int n = 0; n < N; ++n) s += partial[((long)n * F + c) * 2 + 1];
     dwsp[c] = accum ? dwsp[c] + (float)s : (float)s;
   }
   __syncthreads();
@@ -319,7 +338,7 @@ static int se_bwd_blocks(long V, int N, int F, long* vspan) {
 extern "C" long bts_se_bwd_workspace(int N, long V, int F, int R) {
   long vspan;
   const int B = se_bwd_blocks(V, N, F, &vspan);
-  return (long)N * B * F * 2 * 8 + ((long)N * F + (long)N * R) * 8 + 128;
+  return (long)N * B * F * 2 * 8 + ((long)N * F * 3 + (long)N * R) * 8 + 128;
 }
 
 // Gate backward. Outputs: dres (dense N,V,F), ds (N*V scratch), dgap (N*F scratch), parameter grads dw1,dw2,dwsp.
@@ -332,10 +351,13 @@ extern "C" int bts_se_bwd(const float* dout, const float* res, const float* sp, 
   long vspan;
   const int B = se_bwd_blocks(V, N, F, &vspan);
   double* partial = reinterpret_cast<double*>(workspace);
-  double* scratch = partial + (long)N * B * F * 2;
+  double* red = partial + (long)N * B * F * 2;
+  double* scratch = red + (long)N * F * 2;
   (void)hipGetLastError(); hipLaunchKernelGGL(se_bwd_reduce_kernel, dim3(B, N), dim3(256), 0, stream, dout, res, sp, ds, partial, V, F, lddo, vspan);
   BTS_LAUNCH_CHECK();
-  (void)hipGetLastError(); hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(1), dim3(256), 0, stream, partial, gap, h, ch, w1, w2, dw1, dw2, dwsp, dgap,
+  (void)hipGetLastError(); hipLaunchKernelGGL(se_bwd_partial_reduce_kernel, dim3((N * F + 3) / 4), dim3(256), 0, stream, partial, red, N, B, F);
+  BTS_LAUNCH_CHECK();
+  (void)hipGetLastError(); hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(1), dim3(256), 0, stream, red, gap, h, ch, w1, w2, dw1, dw2, dwsp, dgap,
                      scratch, N, B, F, R, 1.0 / (double)V, accumulate_params);
   BTS_LAUNCH_CHECK();
   const long total = (long)N * V * (F / 4);
