@@ -51,8 +51,52 @@ struct IgemmParams {
 #define IG_FLAG_VECIN 8
 #define IG_FLAG_VECOUT 16
 
+// One stage of the implicit GEMM: nkg k-groups (8 input channels each) x NT taps, fully unrolled over the taps.
+template <int NT, int MS, int NS>
+__device__ __forceinline__ void stage_taps(const IgemmParams& p, const float* cur, const int (&bbase)[MS],
+                                           const int (&lane_woff)[NS], int kg0, int nkg, f32x16 (&acc)[MS][NS]) {
+  const int wstepKG = 2 * p.Npad * 4;       // floats between consecutive k-groups of one tap
+  const int wstepTap = p.KG * wstepKG;      // floats between consecutive taps
+  int tl[NT], tw[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { tl[t] = p.tap_lds[t]; tw[t] = p.tap_w[t] * wstepTap; }
+  for (int kgl = 0; kgl < nkg; ++kgl) {
+    const int wk = (kg0 + kgl) * wstepKG;
+    const float* lb = cur + kgl * 8;
+    f32x4 a[3][NS], b[2][MS];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      a[0][ns] = *reinterpret_cast<const f32x4*>(p.wp + (lane_woff[ns] + wk + tw[0]));
+      if (NT > 1) a[1][ns] = *reinterpret_cast<const f32x4*>(p.wp + (lane_woff[ns] + wk + tw[NT > 1 ? 1 : 0]));
+    }
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) b[0][ms] = *reinterpret_cast<const f32x4*>(lb + bbase[ms] + tl[0]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t + 2 < NT) {
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+          a[(t + 2) % 3][ns] = *reinterpret_cast<const f32x4*>(p.wp + (lane_woff[ns] + wk + tw[t + 2 < NT ? t + 2 : 0]));
+      }
+      if (t + 1 < NT) {
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+          b[(t + 1) % 2][ms] = *reinterpret_cast<const f32x4*>(lb + bbase[ms] + tl[t + 1 < NT ? t + 1 : 0]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns)
+            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t % 3][ns][j], b[t % 2][ms][j], acc[ms][ns], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);  // keep the hand-written 2-deep pipeline: no hoisting of later taps' loads
+    }
+  }
+}
+
 template <int MS, int NS, int WM, int WN, int KGS>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   constexpr int S = KGS * 8 + 4;  // dwords per staged voxel (pad 4: 16B-odd stride)
   constexpr int QPV = KGS * 2;    // float4 slots per voxel
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -108,14 +152,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const int mz = m >> (p.lgTX + p.lgTY);
     bbase[ms] = ((mz * p.s * p.IY + my * p.s) * p.IX + mx * p.s) * S + h * 4;
   }
-  const float* wbase[NS];
+  int lane_woff[NS];  // float offset of this lane's weight quad inside one (tap, k-group) image
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) {
     int ncol = ((blockIdx.y * WN + wn) * NS + ns) * 32 + l32;
     if (ncol >= p.Npad) ncol = p.Npad - 1;  // tile wider than the padded cout range: results are discarded
-    wbase[ns] = p.wp + ((long)h * p.Npad + ncol) * 4;
+    lane_woff[ns] = (h * p.Npad + ncol) * 4;
   }
-  const long wstepKG = (long)2 * p.Npad * 4;  // floats between consecutive k-groups
 
   f32x16 acc[MS][NS];
 #pragma unroll
@@ -165,42 +208,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const bool more = (st + 1) < nstages;
     if (more) fetch(st + 1);
 
-    // flattened (k-group, tap) sequence of this stage; weight fragments are prefetched one step ahead so the L2
-    // round trip of step q+1 overlaps the MFMAs of step q
+    // k-groups of this stage x taps: fully unrolled tap sequence (tables hoisted to SGPRs), weight fragments
+    // prefetched two taps ahead and input fragments one tap ahead so their latencies sit under the MFMAs
     const int kg0 = st * KGS;
     int nkg = p.KG - kg0;
     if (nkg > KGS) nkg = KGS;
-    const int nq = nkg * p.ntaps;
-    f32x4 a_nx[NS];
-    {
-      const long wo = ((long)p.tap_w[0] * p.KG + kg0) * wstepKG;
-#pragma unroll
-      for (int ns = 0; ns < NS; ++ns) a_nx[ns] = *reinterpret_cast<const f32x4*>(wbase[ns] + wo);
-    }
-    int t = 0, kgl = 0;
-    for (int q = 0; q < nq; ++q) {
-      f32x4 a[NS], bq[MS];
-#pragma unroll
-      for (int ns = 0; ns < NS; ++ns) a[ns] = a_nx[ns];
-      const int tl = p.tap_lds[t] + kgl * 8;
-#pragma unroll
-      for (int ms = 0; ms < MS; ++ms) bq[ms] = *reinterpret_cast<const f32x4*>(cur + bbase[ms] + tl);
-      int tn = t + 1, kn = kgl;
-      if (tn == p.ntaps) { tn = 0; kn = kgl + 1; }
-      if (q + 1 < nq) {
-        const long wo = ((long)p.tap_w[tn] * p.KG + (kg0 + kn)) * wstepKG;
-#pragma unroll
-        for (int ns = 0; ns < NS; ++ns) a_nx[ns] = *reinterpret_cast<const f32x4*>(wbase[ns] + wo);
+    if constexpr (KGS == 1) {
+      switch (p.ntaps) {
+        case 27: stage_taps<27, MS, NS>(p, cur, bbase, lane_woff, kg0, nkg, acc); break;
+        case 8: stage_taps<8, MS, NS>(p, cur, bbase, lane_woff, kg0, nkg, acc); break;
+        case 4: stage_taps<4, MS, NS>(p, cur, bbase, lane_woff, kg0, nkg, acc); break;
+        case 2: stage_taps<2, MS, NS>(p, cur, bbase, lane_woff, kg0, nkg, acc); break;
+        default: stage_taps<1, MS, NS>(p, cur, bbase, lane_woff, kg0, nkg, acc); break;
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int ms = 0; ms < MS; ++ms)
-#pragma unroll
-          for (int ns = 0; ns < NS; ++ns)
-            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ns][j], bq[ms][j], acc[ms][ns], 0, 0, 0);
-      t = tn;
-      kgl = kn;
+    } else {  // the 4-k-group staging variant only serves the 1x1x1 convolutions
+      stage_taps<1, MS, NS>(p, cur, bbase, lane_woff, kg0, nkg, acc);
     }
     if (more) commit(nxt);
     __syncthreads();
