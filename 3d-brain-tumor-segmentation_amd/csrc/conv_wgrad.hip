@@ -12,6 +12,7 @@
 // fragment reads are conflict-free ds_read_b32; the next sub-tile is prefetched global->registers while the current
 // one is multiplied (double-buffered LDS, one barrier per sub-tile).  Per-workgroup partials go to a workspace and are
 // combined in a fixed order by the finalize kernel (bitwise reproducible; no float atomics).
+#include <stdlib.h>
 #include "common.h"
 #include "bts_internal.h"
 
@@ -26,6 +27,7 @@ struct WgradParams {
   const float* q;
   float* partial;     // [nsp][npct][nqct][ntiles][32][32]
   double* partial_b;  // [nsp][nqct][32]
+  const float* zeros;  // >= 16 zero bytes (source for padding lanes of the LDS-DMA staging)
   int N, Dp, Hp, Wp, Cp, ldp;
   int Dq, Hq, Wq, Cq, ldq;
   int s, loz, loy, lox;
@@ -35,11 +37,92 @@ struct WgradParams {
   int ntaps, ntiles, cpad, lgSP;
   int nsub, sub_per_wg;
   int want_bias;
+  int dbg;  // profiling aid (BTS_WGRAD_DBG): 1 = skip the MFMA sweep, 2 = skip re-staging after the first sub-tile
   int tap_vox[27];  // voxel offset of each tap inside the P halo tile
 };
 
 __device__ __forceinline__ int fast_div(int a, float inv) { return (int)(((float)a + 0.5f) * inv); }
 
+// MFMA sweep over the voxel pairs of one staged sub-tile for a wave that owns T row-tiles. Two voxel pairs per
+// iteration; all LDS reads are issued (and pinned with a scheduling barrier) before the 2*T MFMAs so the LDS latency
+// overlaps the matrix pipe instead of serialising read -> wait -> MFMA.
+template <int T>
+__device__ __forceinline__ void wgrad_pair(const float* bp, const float* bq, int pv0, int pv1, int qo0, int qo1,
+                                           const int (&rowoff)[WG_MAXT], f32x16 (&acc)[WG_MAXT]) {
+  float a0[T], a1[T];
+  const float q0 = bq[qo0], q1 = bq[qo1];
+#pragma unroll
+  for (int i = 0; i < T; ++i) { a0[i] = bp[pv0 + rowoff[i]]; a1[i] = bp[pv1 + rowoff[i]]; }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], q0, acc[i], 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], q1, acc[i], 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int T>
+__device__ __forceinline__ void wgrad_single(const float* bp, const float* bq, int pv0, int qo0,
+                                             const int (&rowoff)[WG_MAXT], f32x16 (&acc)[WG_MAXT]) {
+  float a0[T];
+  const float q0 = bq[qo0];
+#pragma unroll
+  for (int i = 0; i < T; ++i) a0[i] = bp[pv0 + rowoff[i]];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], q0, acc[i], 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// all voxel pairs, row by row (x fastest): addresses advance by constant strides inside a row
+template <int T>
+__device__ __forceinline__ void wgrad_rows(const WgradParams& p, const float* bp, const float* bq,
+                                           const int (&rowoff)[WG_MAXT], f32x16 (&acc)[WG_MAXT], int h, int l32) {
+  const int TX = 1 << p.lgTX, TYm = (1 << p.lgTY) - 1;
+  const int nrows = p.TZ << p.lgTY;
+  const int pstep = (2 * p.s) << p.lgSP;  // dwords between consecutive voxel pairs of a row
+  for (int row = 0; row < nrows; ++row) {
+    const int my = row & TYm, mz = row >> p.lgTY;
+    int pv = (((mz * p.s * p.IY + my * p.s) * p.IX + h * p.s) << p.lgSP);
+    int qo = ((row << p.lgTX) + h) * 32 + l32;
+    int xs = 0;
+    for (; xs + 2 <= (TX >> 1); xs += 2) {
+      wgrad_pair<T>(bp, bq, pv, pv + pstep, qo, qo + 64, rowoff, acc);
+      pv += 2 * pstep;
+      qo += 128;
+    }
+    if (xs < (TX >> 1)) wgrad_single<T>(bp, bq, pv, qo, rowoff, acc);
+  }
+}
+
+// strided subset of the voxel pairs (waves split the pairs): generic addressing
+template <int T>
+__device__ __forceinline__ void wgrad_strided(const WgradParams& p, const float* bp, const float* bq,
+                                              const int (&rowoff)[WG_MAXT], f32x16 (&acc)[WG_MAXT], int st0, int stinc,
+                                              int nsteps, int h, int l32) {
+  const int TXm = (1 << p.lgTX) - 1, TYm = (1 << p.lgTY) - 1, lgXY = p.lgTX + p.lgTY;
+  auto pvox_of = [&](int st) {
+    const int m = 2 * st + h;
+    return ((((m >> lgXY) * p.s * p.IY + ((m >> p.lgTX) & TYm) * p.s) * p.IX + (m & TXm) * p.s) << p.lgSP);
+  };
+  int st = st0;
+  for (; st + stinc < nsteps; st += 2 * stinc)
+    wgrad_pair<T>(bp, bq, pvox_of(st), pvox_of(st + stinc), (2 * st + h) * 32 + l32, (2 * (st + stinc) + h) * 32 + l32,
+                  rowoff, acc);
+  if (st < nsteps) wgrad_single<T>(bp, bq, pvox_of(st), (2 * st + h) * 32 + l32, rowoff, acc);
+}
+
+template <int T>
+__device__ __forceinline__ void wgrad_steps(const WgradParams& p, const float* bp, const float* bq, const int (&rowoff)[WG_MAXT],
+                                            f32x16 (&acc)[WG_MAXT], int st0, int stinc, int nsteps, int h, int l32) {
+  if (stinc == 1) wgrad_rows<T>(p, bp, bq, rowoff, acc, h, l32);
+  else wgrad_strided<T>(p, bp, bq, rowoff, acc, st0, stinc, nsteps, h, l32);
+}
+
+// GLDS = true: tiles are staged with direct global->LDS DMA (global_load_lds_dwordx4: no staging registers, the copy of
+// the next sub-tile is fully asynchronous under the MFMA sweep).  The LDS image is lane-linear by construction (slot e
+// lives at byte 16*e), padding lanes read 16 zero bytes from p.zeros.  GLDS = false: register-staged fallback for
+// channel counts / strides that are not 16-byte granular.
+template <bool GLDS>
 __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -51,7 +134,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams 
   const int M = TX * TY * p.TZ;
   const int SP = 1 << p.lgSP;
   const int tileVoxP = p.IZ * p.IY * p.IX;
-  const int bufDw = tileVoxP * SP + M * 32;
+  const int pRegion = ((tileVoxP * (SP >> 2) + 63) & ~63) * 4;  // dwords, padded to whole wave-loads (64 x 16 B)
+  const int qRegion = ((M * 8 + 63) & ~63) * 4;
+  const int bufDw = pRegion + qRegion;
   const bool ksplit = p.ntiles <= WG_MAXT;  // few row-tiles: every wave takes all of them, waves split the voxel pairs
 
   // ---- per-lane row offsets (dwords inside the P tile) for this wave's row-tiles ----
@@ -73,25 +158,21 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams 
     rowoff[i] = off;
   }
 
-  // ---- staging slots: voxel decomposition is the same for every sub-tile ----
+  int ntw = 0;  // row-tiles owned by this wave
+#pragma unroll
+  for (int i = 0; i < WG_MAXT; ++i) {
+    const int tile = ksplit ? i : wave + WG_WAVES * i;
+    if (tile < p.ntiles) ntw = i + 1;
+  }
+
   const int qpvP = SP >> 2;  // float4 per P voxel
   const float invIX = 1.0f / (float)p.IX, invIYX = 1.0f / (float)(p.IY * p.IX);
-  int pvz[WG_PSLOTS], pvy[WG_PSLOTS], pvx[WG_PSLOTS], pl[WG_PSLOTS];
-#pragma unroll
-  for (int i = 0; i < WG_PSLOTS; ++i) {
-    const int e = tid + i * WG_THREADS;
-    pl[i] = -1;
-    pvz[i] = pvy[i] = pvx[i] = 0;
-    if (e < tileVoxP * qpvP) {
-      const int vox = e >> (p.lgSP - 2), qd = e & (qpvP - 1);
-      const int vz = fast_div(vox, invIYX);
-      const int r = vox - vz * p.IY * p.IX;
-      const int vy = fast_div(r, invIX);
-      pvz[i] = vz; pvy[i] = vy; pvx[i] = r - vy * p.IX;
-      pl[i] = (vox << p.lgSP) + qd * 4;
-    }
-  }
+  // Staging slots: slot e of a tile covers float4 #e of its LDS image ([voxel][SP] resp. [m][32]), so the LDS offset is
+  // simply 4*e; the voxel decomposition is recomputed per sub-tile (a dozen VALU ops) rather than kept in registers:
+  // spilled slot tables would be reloaded through the VM counter and serialise the prefetch loads.
   const int pc0 = pct * 32;
+  const int nPslots = tileVoxP * qpvP, nQslots = M * 8;
+  const int IYX = p.IY * p.IX;
   const int vecP = (p.ldp % 4 == 0) && (p.Cp % 4 == 0) && ((((uintptr_t)p.p) & 15) == 0);
   const int vecQ = (p.ldq % 4 == 0) && (p.Cq % 4 == 0) && ((((uintptr_t)p.q) & 15) == 0);
 
@@ -104,14 +185,23 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams 
     const int n = b / p.ntz;
     const int oz0 = tz * p.TZ, oy0 = ty * TY, ox0 = tx * TX;
     const int iz0 = oz0 * p.s + p.loz, iy0 = oy0 * p.s + p.loy, ix0 = ox0 * p.s + p.lox;
+    // wave-uniform tile origins (may be negative for the halo): pointer arithmetic stays scalar
+    const float* pbase = p.p + ((((long)n * p.Dp + iz0) * p.Hp + iy0) * p.Wp + ix0) * (long)p.ldp;
+    const float* qbase = p.q + ((((long)n * p.Dq + oz0) * p.Hq + oy0) * p.Wq + ox0) * (long)p.ldq;
 #pragma unroll
     for (int i = 0; i < WG_PSLOTS; ++i) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pl[i] >= 0) {
-        const int gz = iz0 + pvz[i], gy = iy0 + pvy[i], gx = ix0 + pvx[i];
-        const int c = pc0 + (pl[i] & (SP - 1));
-        if (gz >= 0 && gz < p.Dp && gy >= 0 && gy < p.Hp && gx >= 0 && gx < p.Wp && c < p.Cp) {
-          const float* src = p.p + ((((long)n * p.Dp + gz) * p.Hp + gy) * p.Wp + gx) * (long)p.ldp + c;
+      const int e = tid + i * WG_THREADS;
+      if (e < nPslots) {
+        const int vox = e >> (p.lgSP - 2), qd = e & (qpvP - 1);
+        const int vz = fast_div(vox, invIYX);
+        const int r = vox - vz * IYX;
+        const int vy = fast_div(r, invIX);
+        const int vx = r - vy * p.IX;
+        const int c = pc0 + qd * 4;
+        if ((unsigned)(iz0 + vz) < (unsigned)p.Dp && (unsigned)(iy0 + vy) < (unsigned)p.Hp &&
+            (unsigned)(ix0 + vx) < (unsigned)p.Wp && c < p.Cp) {
+          const float* src = pbase + (((vz * p.Hp + vy) * p.Wp + vx) * p.ldp + c);
           if (vecP) v = *reinterpret_cast<const f32x4*>(src);
           else {
             v[0] = src[0];
@@ -127,12 +217,12 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams 
     for (int i = 0; i < WG_QSLOTS; ++i) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       const int e = tid + i * WG_THREADS;
-      if (e < M * 8) {
+      if (e < nQslots) {
         const int m = e >> 3, qd = e & 7;
-        const int gz = oz0 + (m >> (p.lgTX + p.lgTY)), gy = oy0 + ((m >> p.lgTX) & (TY - 1)), gx = ox0 + (m & (TX - 1));
+        const int mz = m >> (p.lgTX + p.lgTY), my = (m >> p.lgTX) & (TY - 1), mx = m & (TX - 1);
         const int c = qct * 32 + qd * 4;
-        if (gz < p.Dq && gy < p.Hq && gx < p.Wq && c < p.Cq) {
-          const float* src = p.q + ((((long)n * p.Dq + gz) * p.Hq + gy) * p.Wq + gx) * (long)p.ldq + c;
+        if (oz0 + mz < p.Dq && oy0 + my < p.Hq && ox0 + mx < p.Wq && c < p.Cq) {
+          const float* src = qbase + (((mz * p.Hq + my) * p.Wq + mx) * p.ldq + c);
           if (vecQ) v = *reinterpret_cast<const f32x4*>(src);
           else {
             v[0] = src[0];
@@ -145,15 +235,68 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams 
       preQ[i] = v;
     }
   };
+  // direct-to-LDS staging of one sub-tile into buffer `buf` (every lane of every issuing wave is active)
+  auto fetch_glds = [&](int sub, float* buf) {
+    int b = sub;
+    const int tx = b % p.ntx; b /= p.ntx;
+    const int ty = b % p.nty; b /= p.nty;
+    const int tz = b % p.ntz;
+    const int n = b / p.ntz;
+    const int oz0 = tz * p.TZ, oy0 = ty * TY, ox0 = tx * TX;
+    const int iz0 = oz0 * p.s + p.loz, iy0 = oy0 * p.s + p.loy, ix0 = ox0 * p.s + p.lox;
+    const float* pbase = p.p + ((((long)n * p.Dp + iz0) * p.Hp + iy0) * p.Wp + ix0) * (long)p.ldp;
+    const float* qbase = p.q + ((((long)n * p.Dq + oz0) * p.Hq + oy0) * p.Wq + ox0) * (long)p.ldq;
+#pragma unroll
+    for (int i = 0; i < WG_PSLOTS; ++i) {
+      const int e0 = wave * 64 + i * WG_THREADS;  // wave-uniform first slot of this wave-load
+      if (e0 * 4 < pRegion) {
+        const int e = e0 + lane;
+        const float* src = p.zeros;
+        if (e < nPslots) {
+          const int vox = e >> (p.lgSP - 2), qd = e & (qpvP - 1);
+          const int vz = fast_div(vox, invIYX);
+          const int r = vox - vz * IYX;
+          const int vy = fast_div(r, invIX);
+          const int vx = r - vy * p.IX;
+          const int c = pc0 + qd * 4;
+          if ((unsigned)(iz0 + vz) < (unsigned)p.Dp && (unsigned)(iy0 + vy) < (unsigned)p.Hp &&
+              (unsigned)(ix0 + vx) < (unsigned)p.Wp && c < p.Cp)
+            src = pbase + (((vz * p.Hp + vy) * p.Wp + vx) * p.ldp + c);
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(buf + e0 * 4), 16, 0, 0);
+      }
+    }
+    float* bqd = buf + pRegion;
+#pragma unroll
+    for (int i = 0; i < WG_QSLOTS; ++i) {
+      const int e0 = wave * 64 + i * WG_THREADS;
+      if (e0 * 4 < qRegion) {
+        const int e = e0 + lane;
+        const float* src = p.zeros;
+        if (e < nQslots) {
+          const int m = e >> 3, qd = e & 7;
+          const int mz = m >> (p.lgTX + p.lgTY), my = (m >> p.lgTX) & (TY - 1), mx = m & (TX - 1);
+          const int c = qct * 32 + qd * 4;
+          if (oz0 + mz < p.Dq && oy0 + my < p.Hq && ox0 + mx < p.Wq && c < p.Cq)
+            src = qbase + (((mz * p.Hq + my) * p.Wq + mx) * p.ldq + c);
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(bqd + e0 * 4), 16, 0, 0);
+      }
+    }
+  };
   auto commit = [&](float* buf) {
 #pragma unroll
-    for (int i = 0; i < WG_PSLOTS; ++i)
-      if (pl[i] >= 0) *reinterpret_cast<f32x4*>(buf + pl[i]) = preP[i];
-    float* bq = buf + tileVoxP * SP;
+    for (int i = 0; i < WG_PSLOTS; ++i) {
+      const int e = tid + i * WG_THREADS;
+      if (e < nPslots) *reinterpret_cast<f32x4*>(buf + e * 4) = preP[i];
+    }
+    float* bq = buf + pRegion;
 #pragma unroll
     for (int i = 0; i < WG_QSLOTS; ++i) {
       const int e = tid + i * WG_THREADS;
-      if (e < M * 8) *reinterpret_cast<f32x4*>(bq + e * 4) = preQ[i];
+      if (e < nQslots) *reinterpret_cast<f32x4*>(bq + e * 4) = preQ[i];
     }
   };
 
@@ -170,16 +313,24 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams 
   const int nsteps = M >> 1;
 
   if (sub0 < sub1) {
-    fetch(sub0);
-    commit(lds);
+    if constexpr (GLDS) {
+      fetch_glds(sub0, lds);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      fetch(sub0);
+      commit(lds);
+    }
   }
   __syncthreads();
   int cur = 0;
   for (int sub = sub0; sub < sub1; ++sub) {
     const float* bp = lds + cur * bufDw;
-    const float* bq = bp + tileVoxP * SP;
+    const float* bq = bp + pRegion;
     const bool more = (sub + 1) < sub1;
-    if (more) fetch(sub + 1);
+    if (more && p.dbg != 2) {
+      if constexpr (GLDS) fetch_glds(sub + 1, lds + (cur ^ 1) * bufDw);
+      else fetch(sub + 1);
+    }
 
     if (p.want_bias && pct == 0) {
       const int c = tid & 31, part = tid >> 5;
@@ -188,25 +339,19 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams 
       bsum += (double)s;
     }
     const int st0 = ksplit ? wave : 0, stinc = ksplit ? WG_WAVES : 1;
-    for (int st = st0; st < nsteps; st += stinc) {
-      const int m = 2 * st + h;
-      const int mx = m & (TX - 1);
-      const int my = (m >> p.lgTX) & (TY - 1);
-      const int mz = m >> (p.lgTX + p.lgTY);
-      const int pvox = ((mz * p.s * p.IY + my * p.s) * p.IX + mx * p.s) << p.lgSP;
-      const float qv = bq[m * 32 + l32];
-#pragma unroll
-      for (int i = 0; i < WG_MAXT; ++i) {
-        const int tile = ksplit ? i : wave + WG_WAVES * i;
-        if (tile < p.ntiles) {
-          const float pv = bp[pvox + rowoff[i]];
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, qv, acc[i], 0, 0, 0);
-        }
-      }
+    if (p.dbg != 1) switch (ntw) {  // wave-uniform: number of row-tiles this wave owns -> branch-free MFMA bodies
+      case 4: wgrad_steps<4>(p, bp, bq, rowoff, acc, st0, stinc, nsteps, h, l32); break;
+      case 3: wgrad_steps<3>(p, bp, bq, rowoff, acc, st0, stinc, nsteps, h, l32); break;
+      case 2: wgrad_steps<2>(p, bp, bq, rowoff, acc, st0, stinc, nsteps, h, l32); break;
+      case 1: wgrad_steps<1>(p, bp, bq, rowoff, acc, st0, stinc, nsteps, h, l32); break;
+      default: break;
     }
-    if (more) commit(lds + (cur ^ 1) * bufDw);
+    if (more && p.dbg != 2) {
+      if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else commit(lds + (cur ^ 1) * bufDw);
+    }
     __syncthreads();
-    cur ^= 1;
+    if (p.dbg != 2) cur ^= 1;
   }
 
   // ---- write partials ----
@@ -362,7 +507,7 @@ static int plan_wgrad(WgradPlan& pl, int ntaps, int s, int neg, int N, int Dp, i
   const int tileVoxP = p.IZ * p.IY * p.IX;
   const int M = TX * TY * TZ;
   if (tileVoxP * (SP / 4) > WG_THREADS * WG_PSLOTS || M * 8 > WG_THREADS * WG_QSLOTS) return BTS_ERR_SHAPE;
-  pl.shmem = (size_t)2 * (tileVoxP * SP + M * 32) * sizeof(float);
+  pl.shmem = (size_t)2 * ((((tileVoxP * (SP / 4) + 63) & ~63) + ((M * 8 + 63) & ~63)) * 4) * sizeof(float);
   if (pl.shmem < (size_t)WG_WAVES * 1024 * sizeof(float)) pl.shmem = (size_t)WG_WAVES * 1024 * sizeof(float);
   if (pl.shmem > 160 * 1024) return BTS_ERR_SHAPE;
   for (int t = 0; t < 27; ++t) p.tap_vox[t] = 0;
@@ -417,7 +562,7 @@ extern "C" long bts_conv3d_bwd_weight_workspace(int kind, int N, int D, int H, i
   WgradPlan pl;
   if (plan_wgrad(pl, r.ntaps, r.s, r.neg, N, r.Dp, r.Hp, r.Wp, r.Cp, r.Dq, r.Hq, r.Wq, r.Cq) != BTS_OK) return -1;
   const long base = ((pl.partial_floats * 4 + pl.partial_b_doubles * 8 + 256 + 15) & ~15L);
-  return base + (r.swapped ? bts_colsum_workspace(N, (long)D * H * W, Cout) : 0);
+  return base + (r.swapped ? bts_colsum_workspace(N, (long)D * H * W, Cout) : 0) + 128;
 }
 
 // dw is in the reference layout with Cin_ref = Cin + dup_shift input channels; db may be null.
@@ -445,13 +590,27 @@ extern "C" int bts_conv3d_bwd_weight(int kind, const float* x, const float* dy, 
   p.partial_b = reinterpret_cast<double*>(pb);
   // bias gradient = column sums of dy: dy is Q in the plain form only
   p.want_bias = (db != nullptr && !pIsDy) ? 1 : 0;
+  { const char* e = getenv("BTS_WGRAD_DBG"); p.dbg = e ? atoi(e) : 0; }
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  (void)hipGetLastError(); hipLaunchKernelGGL(wgrad_kernel, dim3(pl.nsp, pl.npct, pl.nqct), dim3(WG_THREADS), pl.shmem, stream, p);
+  // 64 zero bytes at the tail of the workspace feed the padding lanes of the LDS-DMA staging
+  char* ztail = reinterpret_cast<char*>(workspace) + ((need - 64) & ~15L);
+  p.zeros = reinterpret_cast<const float*>(ztail);
+  const bool glds = (p.ldp % 4 == 0) && (p.Cp % 4 == 0) && ((((uintptr_t)p.p) & 15) == 0) && (p.ldq % 4 == 0) &&
+                    (p.Cq % 4 == 0) && ((((uintptr_t)p.q) & 15) == 0) && getenv("BTS_WGRAD_NOGLDS") == nullptr;
+  if (glds) {
+    hipError_t e = hipMemsetAsync(ztail, 0, 64, stream);
+    if (e != hipSuccess) return (int)e;
+    (void)hipGetLastError(); hipLaunchKernelGGL(wgrad_kernel<true>, dim3(pl.nsp, pl.npct, pl.nqct), dim3(WG_THREADS), pl.shmem, stream, p);
+  } else {
+    (void)hipGetLastError(); hipLaunchKernelGGL(wgrad_kernel<false>, dim3(pl.nsp, pl.npct, pl.nqct), dim3(WG_THREADS), pl.shmem, stream, p);
+  }
   BTS_LAUNCH_CHECK();
   WfinParams f;
   f.partial = p.partial; f.partial_b = p.partial_b; f.dw = dw; f.db = p.want_bias ? db : nullptr;
