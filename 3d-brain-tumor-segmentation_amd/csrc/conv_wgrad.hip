@@ -43,79 +43,69 @@ struct WgradParams {
 
 __device__ __forceinline__ int fast_div(int a, float inv) { return (int)(((float)a + 0.5f) * inv); }
 
-// MFMA sweep over the voxel pairs of one staged sub-tile for a wave that owns T row-tiles. Two voxel pairs per
-// iteration; all LDS reads are issued (and pinned with a scheduling barrier) before the 2*T MFMAs so the LDS latency
-// overlaps the matrix pipe instead of serialising read -> wait -> MFMA.
+// MFMA sweep over the voxel pairs ("steps") of one staged sub-tile for a wave that owns T row-tiles.
+// Software pipelined by hand: the LDS reads of step k+1 are issued before the T MFMAs of step k, so LDS latency and the
+// address arithmetic sit in the shadow of the matrix pipe.  Step indices are wave-uniform (scalar address part); the
+// per-lane part (row offset of the tile, half-wave voxel, channel) is folded into laneoff[] once.
+// The fragment reads are inline-asm ds_read_b32 with hand-counted s_waitcnt lgkmcnt(N): hipcc cannot count LDS
+// operations across the loop back-edge and would otherwise wait lgkmcnt(0) right after issuing the prefetch.
 template <int T>
-__device__ __forceinline__ void wgrad_pair(const float* bp, const float* bq, int pv0, int pv1, int qo0, int qo1,
-                                           const int (&rowoff)[WG_MAXT], f32x16 (&acc)[WG_MAXT]) {
-  float a0[T], a1[T];
-  const float q0 = bq[qo0], q1 = bq[qo1];
-#pragma unroll
-  for (int i = 0; i < T; ++i) { a0[i] = bp[pv0 + rowoff[i]]; a1[i] = bp[pv1 + rowoff[i]]; }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], q0, acc[i], 0, 0, 0);
-#pragma unroll
-  for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], q1, acc[i], 0, 0, 0);
-  __builtin_amdgcn_sched_barrier(0);
+struct WgFrag {
+  float q, a[T];
+};
+__device__ __forceinline__ float lds_read_b32_async(unsigned byte_addr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(byte_addr));
+  return v;
 }
-template <int T>
-__device__ __forceinline__ void wgrad_single(const float* bp, const float* bq, int pv0, int qo0,
-                                             const int (&rowoff)[WG_MAXT], f32x16 (&acc)[WG_MAXT]) {
-  float a0[T];
-  const float q0 = bq[qo0];
-#pragma unroll
-  for (int i = 0; i < T; ++i) a0[i] = bp[pv0 + rowoff[i]];
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], q0, acc[i], 0, 0, 0);
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
-
-// all voxel pairs, row by row (x fastest): addresses advance by constant strides inside a row
-template <int T>
-__device__ __forceinline__ void wgrad_rows(const WgradParams& p, const float* bp, const float* bq,
-                                           const int (&rowoff)[WG_MAXT], f32x16 (&acc)[WG_MAXT], int h, int l32) {
-  const int TX = 1 << p.lgTX, TYm = (1 << p.lgTY) - 1;
-  const int nrows = p.TZ << p.lgTY;
-  const int pstep = (2 * p.s) << p.lgSP;  // dwords between consecutive voxel pairs of a row
-  for (int row = 0; row < nrows; ++row) {
-    const int my = row & TYm, mz = row >> p.lgTY;
-    int pv = (((mz * p.s * p.IY + my * p.s) * p.IX + h * p.s) << p.lgSP);
-    int qo = ((row << p.lgTX) + h) * 32 + l32;
-    int xs = 0;
-    for (; xs + 2 <= (TX >> 1); xs += 2) {
-      wgrad_pair<T>(bp, bq, pv, pv + pstep, qo, qo + 64, rowoff, acc);
-      pv += 2 * pstep;
-      qo += 128;
-    }
-    if (xs < (TX >> 1)) wgrad_single<T>(bp, bq, pv, qo, rowoff, acc);
-  }
-}
-
-// strided subset of the voxel pairs (waves split the pairs): generic addressing
-template <int T>
-__device__ __forceinline__ void wgrad_strided(const WgradParams& p, const float* bp, const float* bq,
-                                              const int (&rowoff)[WG_MAXT], f32x16 (&acc)[WG_MAXT], int st0, int stinc,
-                                              int nsteps, int h, int l32) {
-  const int TXm = (1 << p.lgTX) - 1, TYm = (1 << p.lgTY) - 1, lgXY = p.lgTX + p.lgTY;
-  auto pvox_of = [&](int st) {
-    const int m = 2 * st + h;
-    return ((((m >> lgXY) * p.s * p.IY + ((m >> p.lgTX) & TYm) * p.s) * p.IX + (m & TXm) * p.s) << p.lgSP);
-  };
-  int st = st0;
-  for (; st + stinc < nsteps; st += 2 * stinc)
-    wgrad_pair<T>(bp, bq, pvox_of(st), pvox_of(st + stinc), (2 * st + h) * 32 + l32, (2 * (st + stinc) + h) * 32 + l32,
-                  rowoff, acc);
-  if (st < nsteps) wgrad_single<T>(bp, bq, pvox_of(st), (2 * st + h) * 32 + l32, rowoff, acc);
-}
-
 template <int T>
 __device__ __forceinline__ void wgrad_steps(const WgradParams& p, const float* bp, const float* bq, const int (&rowoff)[WG_MAXT],
                                             f32x16 (&acc)[WG_MAXT], int st0, int stinc, int nsteps, int h, int l32) {
-  if (stinc == 1) wgrad_rows<T>(p, bp, bq, rowoff, acc, h, l32);
-  else wgrad_strided<T>(p, bp, bq, rowoff, acc, st0, stinc, nsteps, h, l32);
+  const int TXm = (1 << p.lgTX) - 1, TYm = (1 << p.lgTY) - 1, lgXY = p.lgTX + p.lgTY;
+  const unsigned bpb = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)bp;  // LDS byte addresses
+  const unsigned bqb = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)bq;
+  unsigned laneoff[T];
+#pragma unroll
+  for (int i = 0; i < T; ++i) laneoff[i] = bpb + 4u * (unsigned)(rowoff[i] + ((h * p.s) << p.lgSP));
+  const unsigned qlane = bqb + 4u * (unsigned)(h * 32 + l32);
+  const int nK = (nsteps - st0 + stinc - 1) / stinc;
+  auto load = [&](WgFrag<T>& f, int k) {
+    const int m = 2 * (st0 + k * stinc);  // wave-uniform
+    const int pvu = (((m >> lgXY) * p.s * p.IY + ((m >> p.lgTX) & TYm) * p.s) * p.IX + (m & TXm) * p.s) << p.lgSP;
+    f.q = lds_read_b32_async(qlane + (unsigned)(m * 128));
+#pragma unroll
+    for (int i = 0; i < T; ++i) f.a[i] = lds_read_b32_async(laneoff[i] + (unsigned)(pvu * 4));
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mma = [&](const WgFrag<T>& f) {
+#pragma unroll
+    for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i], f.q, acc[i], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  WgFrag<T> A, B;
+  int k = 0;
+  if (nK > 0) load(A, 0);
+  for (; k + 1 < nK; k += 2) {
+    load(B, k + 1);
+    wait_lgkm<T + 1>();  // A's T+1 reads are older than B's T+1: they have landed
+    mma(A);
+    if (k + 2 < nK) {
+      load(A, k + 2);
+      wait_lgkm<T + 1>();
+    } else {
+      wait_lgkm<0>();
+    }
+    mma(B);
+  }
+  if (k < nK) {
+    wait_lgkm<0>();
+    mma(A);
+  }
 }
 
 // GLDS = true: tiles are staged with direct global->LDS DMA (global_load_lds_dwordx4: no staging registers, the copy of
