@@ -43,6 +43,16 @@ struct IgemmParams {
   int ntaps, flags;
   int tap_lds[27];
   int tap_w[27];
+  // split-K: blockIdx.z handles k-groups [z*kg_per, ...); raw partials go to part[z][voxel][Npad] (no bias/act)
+  int ksplit, kg_per;
+  float* part;
+  long ws_bytes, ws_need;  // host-side planning only
+  int plan_only;
+  // merged launch of the 8 output-parity classes of the UP geometry (blockIdx.z = class)
+  int ncls;
+  int cls_nt[8];
+  int cls_tl[8][8];
+  int cls_tw[8][8];
 };
 
 #define IG_FLAG_BIAS 1
@@ -53,13 +63,14 @@ struct IgemmParams {
 
 // One stage of the implicit GEMM: nkg k-groups (8 input channels each) x NT taps, fully unrolled over the taps.
 template <int NT, int MS, int NS>
-__device__ __forceinline__ void stage_taps(const IgemmParams& p, const float* cur, const int (&bbase)[MS],
-                                           const int (&lane_woff)[NS], int kg0, int nkg, f32x16 (&acc)[MS][NS]) {
+__device__ __forceinline__ void stage_taps(const IgemmParams& p, const int* tlp, const int* twp, const float* cur,
+                                           const int (&bbase)[MS], const int (&lane_woff)[NS], int kg0, int nkg,
+                                           f32x16 (&acc)[MS][NS]) {
   const int wstepKG = 2 * p.Npad * 4;       // floats between consecutive k-groups of one tap
   const int wstepTap = p.KG * wstepKG;      // floats between consecutive taps
   int tl[NT], tw[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) { tl[t] = p.tap_lds[t]; tw[t] = p.tap_w[t] * wstepTap; }
+  for (int t = 0; t < NT; ++t) { tl[t] = tlp[t]; tw[t] = twp[t] * wstepTap; }
   for (int kgl = 0; kgl < nkg; ++kgl) {
     const int wk = (kg0 + kgl) * wstepKG;
     const float* lb = cur + kgl * 8;
@@ -113,6 +124,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   const int tz = b % p.ntz;
   const int n = b / p.ntz;
   const int TX = 1 << p.lgTX, TY = 1 << p.lgTY;
+  int ntaps = p.ntaps, ooz = p.ooz, ooy = p.ooy, oox = p.oox;
+  const int* tlp = p.tap_lds;
+  const int* twp = p.tap_w;
+  if (p.ncls > 1) {
+    const int cls = blockIdx.z;
+    ntaps = p.cls_nt[cls]; tlp = p.cls_tl[cls]; twp = p.cls_tw[cls];
+    ooz = (cls >> 2) & 1; ooy = (cls >> 1) & 1; oox = cls & 1;
+  }
   const int oz0 = tz * p.TZ, oy0 = ty * TY, ox0 = tx * TX;
   const int iz0 = oz0 * p.s + p.loz, iy0 = oy0 * p.s + p.loy, ix0 = ox0 * p.s + p.lox;
   const int tileVox = p.IZ * p.IY * p.IX;
@@ -168,12 +187,19 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
 
-  const int nstages = (p.KG + KGS - 1) / KGS;
+  int kgBeg = 0, kgEnd = p.KG;
+  if (p.ksplit > 1) {
+    kgBeg = blockIdx.z * p.kg_per;
+    kgEnd = kgBeg + p.kg_per;
+    if (kgEnd > p.KG) kgEnd = p.KG;
+  }
+  const int stBeg = kgBeg / KGS;  // kg_per is a multiple of KGS
+  const int nstages = (kgEnd - kgBeg + KGS - 1) / KGS;
   const bool vecin = (p.flags & IG_FLAG_VECIN) != 0;
 
   f32x4 pre[MAXSLOT];
   auto fetch = [&](int st) {
-    const int c0 = st * KGS * 8;
+    const int c0 = (stBeg + st) * KGS * 8;
 #pragma unroll
     for (int i = 0; i < MAXSLOT; ++i) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -210,22 +236,46 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 
     // k-groups of this stage x taps: fully unrolled tap sequence (tables hoisted to SGPRs), weight fragments
     // prefetched two taps ahead and input fragments one tap ahead so their latencies sit under the MFMAs
-    const int kg0 = st * KGS;
-    int nkg = p.KG - kg0;
+    const int kg0 = (stBeg + st) * KGS;
+    int nkg = kgEnd - kg0;
     if (nkg > KGS) nkg = KGS;
     if constexpr (KGS == 1) {
-      switch (p.ntaps) {
-        case 27: stage_taps<27, MS, NS>(p, cur, bbase, lane_woff, kg0, nkg, acc); break;
-        case 8: stage_taps<8, MS, NS>(p, cur, bbase, lane_woff, kg0, nkg, acc); break;
-        case 4: stage_taps<4, MS, NS>(p, cur, bbase, lane_woff, kg0, nkg, acc); break;
-        case 2: stage_taps<2, MS, NS>(p, cur, bbase, lane_woff, kg0, nkg, acc); break;
-        default: stage_taps<1, MS, NS>(p, cur, bbase, lane_woff, kg0, nkg, acc); break;
+      switch (ntaps) {
+        case 27: stage_taps<27, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc); break;
+        case 8: stage_taps<8, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc); break;
+        case 4: stage_taps<4, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc); break;
+        case 2: stage_taps<2, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc); break;
+        default: stage_taps<1, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc); break;
       }
     } else {  // the 4-k-group staging variant only serves the 1x1x1 convolutions
-      stage_taps<1, MS, NS>(p, cur, bbase, lane_woff, kg0, nkg, acc);
+      stage_taps<1, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc);
     }
     if (more) commit(nxt);
     __syncthreads();
+  }
+
+  // ---- split-K: raw partial tile to the workspace, finished by igemm_reduce_kernel ----
+  if (p.ksplit > 1) {
+    const long nvox = (long)p.N * p.Do * p.Ho * p.Wo;
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+      const int m = (wm * MS + ms) * 32 + l32;
+      const int oz = oz0 + (m >> (p.lgTX + p.lgTY)), oy = oy0 + ((m >> p.lgTX) & (TY - 1)), ox = ox0 + (m & (TX - 1));
+      if (oz >= p.Do || oy >= p.Ho || ox >= p.Wo) continue;
+      const long v = (((long)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
+      float* row = p.part + ((long)blockIdx.z * nvox + v) * p.Npad;
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        const int nb = ((blockIdx.y * WN + wn) * NS + ns) * 32;
+        if (nb >= p.Npad) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v4 = {acc[ms][ns][4 * g + 0], acc[ms][ns][4 * g + 1], acc[ms][ns][4 * g + 2], acc[ms][ns][4 * g + 3]};
+          *reinterpret_cast<f32x4*>(row + nb + 8 * g + 4 * h) = v4;
+        }
+      }
+    }
+    return;
   }
 
   // ---- epilogue: D rows = couts (4 consecutive per register quad), cols = voxels ----
@@ -238,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     const int mz = m >> (p.lgTX + p.lgTY);
     const int oz = oz0 + mz, oy = oy0 + my, ox = ox0 + mx;
     if (oz >= p.Do || oy >= p.Ho || ox >= p.Wo) continue;
-    const long pix = (((long)n * p.ODa + (oz * p.os + p.ooz)) * p.OHa + (oy * p.os + p.ooy)) * p.OWa + (ox * p.os + p.oox);
+    const long pix = (((long)n * p.ODa + (oz * p.os + ooz)) * p.OHa + (oy * p.os + ooy)) * p.OWa + (ox * p.os + oox);
     float* yrow = p.y + pix * p.ldy;
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
@@ -275,6 +325,23 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
         }
       }
     }
+  }
+}
+
+// split-K finish: y[v][co] (+)= act(bias[co] + sum_z part[z][v][co]); fixed summation order (deterministic)
+__global__ __launch_bounds__(256) void igemm_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                           float* __restrict__ y, long nvox, int Cout, int Npad, int ldy,
+                                                           int ksplit, int flags) {
+  const long total = nvox * Cout;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long v = i / Cout;
+    const int co = (int)(i - v * Cout);
+    float s = 0.f;
+    for (int z = 0; z < ksplit; ++z) s += part[((long)z * nvox + v) * Npad + co];
+    if (flags & IG_FLAG_BIAS) s += bias[co];
+    if (flags & IG_FLAG_SIGMOID) s = sigmoidf_(s);
+    float* d = y + v * ldy + co;
+    *d = (flags & IG_FLAG_ACCUM) ? *d + s : s;
   }
 }
 
@@ -378,15 +445,47 @@ static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   const size_t shmem = (size_t)2 * tileVox * S * sizeof(float);
   auto kern = igemm_kernel<MS, NS, WM, WN, KGS>;
   static bool attr_done = false;
-  if (!attr_done) {
+  if (!attr_done && !p.plan_only) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
   const int NT = 32 * NS * WN;
-  dim3 grid(p.N * p.ntz * p.nty * p.ntx, (p.Npad + NT - 1) / NT);
+  dim3 grid(p.N * p.ntz * p.nty * p.ntx, (p.Npad + NT - 1) / NT, p.ncls > 1 ? p.ncls : 1);
+  // split-K when the tile grid cannot fill the chip and the contraction is long (tiny spatial grids, wide channels)
+  p.ksplit = 1;
+  p.kg_per = p.KG;
+  p.ws_need = 0;
+  const long wgs = (long)grid.x * grid.y;
+  if (p.ncls <= 1 && wgs < 192 && p.KG >= 4 * KGS) {
+    int ks = (int)((384 + wgs - 1) / wgs);
+    const int maxks = p.KG / (2 * KGS);
+    if (ks > maxks) ks = maxks;
+    if (ks > 64) ks = 64;
+    if (ks > 1) {
+      int per = (p.KG + ks - 1) / ks;
+      per = (per + KGS - 1) / KGS * KGS;
+      ks = (p.KG + per - 1) / per;
+      const long need = (long)ks * p.N * p.Do * p.Ho * p.Wo * p.Npad * 4;
+      if (ks > 1 && (p.plan_only || (p.part != nullptr && p.ws_bytes >= need))) {
+        p.ksplit = ks;
+        p.kg_per = per;
+        p.ws_need = need;
+        grid.z = ks;
+      }
+    }
+  }
+  if (p.plan_only) return BTS_OK;
   (void)hipGetLastError(); hipLaunchKernelGGL(kern, grid, dim3(256), shmem, stream, p);
   BTS_LAUNCH_CHECK();
+  if (p.ksplit > 1) {
+    const long nvox = (long)p.N * p.Do * p.Ho * p.Wo;
+    long blocks = (nvox * p.Cout + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    (void)hipGetLastError(); hipLaunchKernelGGL(igemm_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, p.part, p.bias, p.y, nvox, p.Cout,
+                       p.Npad, p.ldy, p.ksplit, p.flags);
+    BTS_LAUNCH_CHECK();
+  }
   return BTS_OK;
 }
 
@@ -418,8 +517,13 @@ static int choose_cfg(int geo, int N, int Do, int Ho, int Wo, int Npad, int* Mou
 // geometry + config selection for one gather-conv launch
 static int launch_igemm(int geo, const float* x, const float* wp, const float* bias, float* y, int N, int Di, int Hi,
                         int Wi, int Cin, int ldx, int Do, int Ho, int Wo, int Cout, int ldy, int ODa, int OHa, int OWa,
-                        int pz, int py, int px, int flags, hipStream_t stream) {
+                        int pz, int py, int px, int flags, hipStream_t stream, void* ws = nullptr, long ws_bytes = 0,
+                        long* need_out = nullptr) {
   IgemmParams p;
+  p.part = reinterpret_cast<float*>(ws);
+  p.ws_bytes = ws_bytes;
+  p.plan_only = need_out != nullptr;
+  p.ws_need = 0;
   p.x = x; p.wp = wp; p.bias = bias; p.y = y;
   p.N = N; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.ldx = ldx;
   p.Do = Do; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.ldy = ldy;
@@ -445,7 +549,11 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
     nt = 27;
     hi[0] = hi[1] = hi[2] = 2;
     p.s = 2;
-  } else {  // GEO_UP, parity class (pz,py,px)
+  } else if (pz < 0) {  // GEO_UP, all 8 parity classes in one launch: common halo (offset -1 on every axis)
+    lo[0] = lo[1] = lo[2] = -1;
+    p.os = 2;
+    nt = 8;  // placeholder; per-class tables are filled below once the tile geometry is known
+  } else {  // GEO_UP, single parity class (pz,py,px)
     const int par[3] = {pz, py, px};
     int kz[2], ky[2], kx[2], dz[2], dy[2], dx[2], nz, ny, nx;
     auto axis = [](int pp, int* k, int* d) {
@@ -464,12 +572,13 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
     p.os = 2; p.ooz = pz; p.ooy = py; p.oox = px;
   }
   p.ntaps = nt;
+  p.ncls = 1;
   p.loz = lo[0]; p.loy = lo[1]; p.lox = lo[2];
 
   // ---- config selection ----
   const int k1 = (geo == GEO_K1);
   int M;  // voxels per workgroup tile
-  const int cfg = choose_cfg(geo, N, Do, Ho, Wo, p.Npad, &M);
+  const int cfg = choose_cfg(geo, (geo == GEO_UP && pz < 0) ? 8 * N : N, Do, Ho, Wo, p.Npad, &M);
   // tile dims (powers of two in x,y)
   int TX = 32;
   while (TX > 4 && TX / 2 >= Wo) TX /= 2;  // smallest pow2 >= Wo, capped at 32
@@ -493,23 +602,48 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
     p.tap_w[t] = tw[t];
   }
   for (int t = nt; t < 27; ++t) { p.tap_lds[t] = 0; p.tap_w[t] = 0; }
-
-  if (k1) {
-    switch (cfg) {
-      case 0: return launch_cfg<2, 1, 4, 1, 4>(p, stream);
-      case 1: return launch_cfg<2, 2, 4, 1, 4>(p, stream);
-      case 2: return launch_cfg<1, 2, 2, 2, 4>(p, stream);
-      case 3: return launch_cfg<1, 1, 2, 2, 4>(p, stream);
-      default: return launch_cfg<1, 1, 4, 1, 4>(p, stream);
+  if (geo == GEO_UP && pz < 0) {
+    p.ncls = 8;
+    for (int c = 0; c < 8; ++c) {
+      const int par[3] = {(c >> 2) & 1, (c >> 1) & 1, c & 1};
+      int k[3][2], d[3][2], n[3];
+      for (int a = 0; a < 3; ++a) {
+        if (par[a] == 0) { k[a][0] = 0; d[a][0] = 0; k[a][1] = 2; d[a][1] = -1; n[a] = 2; }
+        else { k[a][0] = 1; d[a][0] = 0; n[a] = 1; }
+      }
+      int ct = 0;
+      for (int a = 0; a < n[0]; ++a)
+        for (int bb = 0; bb < n[1]; ++bb)
+          for (int cc = 0; cc < n[2]; ++cc) {
+            p.cls_tl[c][ct] = (((d[0][a] + 1) * p.IY + (d[1][bb] + 1)) * p.IX + (d[2][cc] + 1)) * S;
+            p.cls_tw[c][ct] = (k[0][a] * 3 + k[1][bb]) * 3 + k[2][cc];
+            ++ct;
+          }
+      p.cls_nt[c] = ct;
+      for (; ct < 8; ++ct) { p.cls_tl[c][ct] = 0; p.cls_tw[c][ct] = 0; }
     }
   }
-  switch (cfg) {
-    case 0: return launch_cfg<2, 1, 4, 1, 1>(p, stream);
-    case 1: return launch_cfg<2, 2, 4, 1, 1>(p, stream);
-    case 2: return launch_cfg<1, 2, 2, 2, 1>(p, stream);
-    case 3: return launch_cfg<1, 1, 2, 2, 1>(p, stream);
-    default: return launch_cfg<1, 1, 4, 1, 1>(p, stream);
+
+  int rc;
+  if (k1) {
+    switch (cfg) {
+      case 0: rc = launch_cfg<2, 1, 4, 1, 4>(p, stream); break;
+      case 1: rc = launch_cfg<2, 2, 4, 1, 4>(p, stream); break;
+      case 2: rc = launch_cfg<1, 2, 2, 2, 4>(p, stream); break;
+      case 3: rc = launch_cfg<1, 1, 2, 2, 4>(p, stream); break;
+      default: rc = launch_cfg<1, 1, 4, 1, 4>(p, stream); break;
+    }
+  } else {
+    switch (cfg) {
+      case 0: rc = launch_cfg<2, 1, 4, 1, 1>(p, stream); break;
+      case 1: rc = launch_cfg<2, 2, 4, 1, 1>(p, stream); break;
+      case 2: rc = launch_cfg<1, 2, 2, 2, 1>(p, stream); break;
+      case 3: rc = launch_cfg<1, 1, 2, 2, 1>(p, stream); break;
+      default: rc = launch_cfg<1, 1, 4, 1, 1>(p, stream); break;
+    }
   }
+  if (need_out) *need_out = p.ws_need;
+  return rc;
 }
 
 static int geo_of_kind_fwd(int kind) {
@@ -521,9 +655,9 @@ static int geo_of_kind_fwd(int kind) {
   }
 }
 
-// Forward. x:(N,D,H,W,Cin) ld=ldx ; y:(N,Do,Ho,Wo,Cout) ld=ldy with (Do,Ho,Wo) = (D,H,W) | (D/2,..) | (2D,..).
-extern "C" int bts_conv3d_fwd(int kind, const float* x, const float* wp_fwd, const float* bias, float* y, int N, int D,
-                              int H, int W, int Cin, int ldx, int Cout, int ldy, int flags, hipStream_t stream) {
+static int conv_fwd_impl(int kind, const float* x, const float* wp_fwd, const float* bias, float* y, void* ws, long ws_bytes,
+                         long* need_out, int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, int flags,
+                         hipStream_t stream) {
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldy < Cout) return BTS_ERR_SHAPE;
   int f = 0;
   if (bias) f |= IG_FLAG_BIAS;
@@ -531,42 +665,64 @@ extern "C" int bts_conv3d_fwd(int kind, const float* x, const float* wp_fwd, con
   if (flags & BTS_CONV_FLAG_ACCUM) f |= IG_FLAG_ACCUM;
   const int geo = geo_of_kind_fwd(kind);
   if (geo == GEO_K1 || geo == GEO_S1)
-    return launch_igemm(geo, x, wp_fwd, bias, y, N, D, H, W, Cin, ldx, D, H, W, Cout, ldy, D, H, W, 0, 0, 0, f, stream);
+    return launch_igemm(geo, x, wp_fwd, bias, y, N, D, H, W, Cin, ldx, D, H, W, Cout, ldy, D, H, W, 0, 0, 0, f, stream, ws,
+                        ws_bytes, need_out);
   if (geo == GEO_DOWN) {
     if ((D | H | W) & 1) return BTS_ERR_SHAPE;  // TF 'same' pads (0,1) only for even sizes
     return launch_igemm(geo, x, wp_fwd, bias, y, N, D, H, W, Cin, ldx, D / 2, H / 2, W / 2, Cout, ldy, D / 2, H / 2,
-                        W / 2, 0, 0, 0, f, stream);
+                        W / 2, 0, 0, 0, f, stream, ws, ws_bytes, need_out);
   }
-  for (int c = 0; c < 8; ++c) {
-    int r = launch_igemm(GEO_UP, x, wp_fwd, bias, y, N, D, H, W, Cin, ldx, D, H, W, Cout, ldy, 2 * D, 2 * H, 2 * W,
-                         (c >> 2) & 1, (c >> 1) & 1, c & 1, f, stream);
-    if (r != BTS_OK) return r;
-  }
-  return BTS_OK;
+  return launch_igemm(GEO_UP, x, wp_fwd, bias, y, N, D, H, W, Cin, ldx, D, H, W, Cout, ldy, 2 * D, 2 * H, 2 * W, -1, -1, -1,
+                      f, stream, ws, ws_bytes, need_out);
 }
 
-// Data gradient. dy has the forward output's shape, dx the forward input's shape (N,D,H,W,Cin).
-// wp_bwd is the BTS_ROLE_BWD_DATA packing. flags: BTS_CONV_FLAG_ACCUM adds into dx.
-extern "C" int bts_conv3d_bwd_data(int kind, const float* dy, const float* wp_bwd, float* dx, int N, int D, int H, int W,
-                                   int Cin, int lddx, int Cout, int lddy, int flags, hipStream_t stream) {
+// Forward. x:(N,D,H,W,Cin) ld=ldx ; y:(N,Do,Ho,Wo,Cout) ld=ldy with (Do,Ho,Wo) = (D,H,W) | (D/2,..) | (2D,..).
+// workspace (may be NULL) enables split-K for grids too small to fill the chip; size from bts_conv3d_fwd_workspace.
+extern "C" int bts_conv3d_fwd(int kind, const float* x, const float* wp_fwd, const float* bias, float* y, void* workspace,
+                              long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy,
+                              int flags, hipStream_t stream) {
+  return conv_fwd_impl(kind, x, wp_fwd, bias, y, workspace, workspace_bytes, nullptr, N, D, H, W, Cin, ldx, Cout, ldy, flags,
+                       stream);
+}
+extern "C" long bts_conv3d_fwd_workspace(int kind, int N, int D, int H, int W, int Cin, int Cout) {
+  long need = 0;
+  if (conv_fwd_impl(kind, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &need, N, D, H, W, Cin, Cin, Cout, Cout, 0,
+                    nullptr) != BTS_OK)
+    return -1;
+  return need;
+}
+
+static int conv_bwd_impl(int kind, const float* dy, const float* wp_bwd, float* dx, void* ws, long ws_bytes, long* need_out,
+                         int N, int D, int H, int W, int Cin, int lddx, int Cout, int lddy, int flags, hipStream_t stream) {
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || lddx < Cin || lddy < Cout) return BTS_ERR_SHAPE;
   int f = 0;
   if (flags & BTS_CONV_FLAG_ACCUM) f |= IG_FLAG_ACCUM;
   if (kind == BTS_CONV_K1 || kind == BTS_CONV_K3S1)
     return launch_igemm(kind == BTS_CONV_K1 ? GEO_K1 : GEO_S1, dy, wp_bwd, nullptr, dx, N, D, H, W, Cout, lddy, D, H, W,
-                        Cin, lddx, D, H, W, 0, 0, 0, f, stream);
+                        Cin, lddx, D, H, W, 0, 0, 0, f, stream, ws, ws_bytes, need_out);
   if (kind == BTS_CONV_K3S2) {  // gather form over the fine grid's parity classes
     if ((D | H | W) & 1) return BTS_ERR_SHAPE;
-    for (int c = 0; c < 8; ++c) {
-      int r = launch_igemm(GEO_UP, dy, wp_bwd, nullptr, dx, N, D / 2, H / 2, W / 2, Cout, lddy, D / 2, H / 2, W / 2, Cin,
-                           lddx, D, H, W, (c >> 2) & 1, (c >> 1) & 1, c & 1, f, stream);
-      if (r != BTS_OK) return r;
-    }
-    return BTS_OK;
+    return launch_igemm(GEO_UP, dy, wp_bwd, nullptr, dx, N, D / 2, H / 2, W / 2, Cout, lddy, D / 2, H / 2, W / 2, Cin, lddx,
+                        D, H, W, -1, -1, -1, f, stream, ws, ws_bytes, need_out);
   }
   // transposed conv: d/dx is the stride-2 'same' conv of dy (fine grid 2D x 2H x 2W) -> coarse grid
   return launch_igemm(GEO_DOWN, dy, wp_bwd, nullptr, dx, N, 2 * D, 2 * H, 2 * W, Cout, lddy, D, H, W, Cin, lddx, D, H, W,
-                      0, 0, 0, f, stream);
+                      0, 0, 0, f, stream, ws, ws_bytes, need_out);
+}
+
+// Data gradient. dy has the forward output's shape, dx the forward input's shape (N,D,H,W,Cin).
+// wp_bwd is the BTS_ROLE_BWD_DATA packing. flags: BTS_CONV_FLAG_ACCUM adds into dx.
+extern "C" int bts_conv3d_bwd_data(int kind, const float* dy, const float* wp_bwd, float* dx, void* workspace,
+                                   long workspace_bytes, int N, int D, int H, int W, int Cin, int lddx, int Cout, int lddy,
+                                   int flags, hipStream_t stream) {
+  return conv_bwd_impl(kind, dy, wp_bwd, dx, workspace, workspace_bytes, nullptr, N, D, H, W, Cin, lddx, Cout, lddy, flags,
+                       stream);
+}
+extern "C" long bts_conv3d_bwd_data_workspace(int kind, int N, int D, int H, int W, int Cin, int Cout) {
+  long need = 0;
+  if (conv_bwd_impl(kind, nullptr, nullptr, nullptr, nullptr, 0, &need, N, D, H, W, Cin, Cin, Cout, Cout, 0, nullptr) != BTS_OK)
+    return -1;
+  return need;
 }
 
 // Which igemm_kernel<...> instantiation a call resolves to: returns cfg + 8*(KGS==4); cfg ids as in choose_cfg.
@@ -576,7 +732,7 @@ extern "C" int bts_conv3d_fwd_config(int kind, int N, int D, int H, int W, int C
   const int geo = geo_of_kind_fwd(kind);
   int Do = D, Ho = H, Wo = W;
   if (geo == GEO_DOWN) { Do = D / 2; Ho = H / 2; Wo = W / 2; }
-  return choose_cfg(geo, N, Do, Ho, Wo, npad32(Cout), &M) + (geo == GEO_K1 ? 8 : 0);
+  return choose_cfg(geo, geo == GEO_UP ? 8 * N : N, Do, Ho, Wo, npad32(Cout), &M) + (geo == GEO_K1 ? 8 : 0);
 }
 extern "C" int bts_conv3d_bwd_data_config(int kind, int N, int D, int H, int W, int Cin, int Cout) {
   int M;
@@ -584,5 +740,5 @@ extern "C" int bts_conv3d_bwd_data_config(int kind, int N, int D, int H, int W, 
   if (kind == BTS_CONV_K1) geo = GEO_K1;
   else if (kind == BTS_CONV_K3S2) { geo = GEO_UP; Do = D / 2; Ho = H / 2; Wo = W / 2; }
   else if (kind == BTS_CONV_K3S2T) geo = GEO_DOWN;
-  return choose_cfg(geo, N, Do, Ho, Wo, npad32(Cin), &M) + (geo == GEO_K1 ? 8 : 0);
+  return choose_cfg(geo, geo == GEO_UP ? 8 * N : N, Do, Ho, Wo, npad32(Cin), &M) + (geo == GEO_K1 ? 8 : 0);
 }

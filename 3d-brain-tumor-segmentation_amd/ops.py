@@ -130,9 +130,11 @@ def conv_fwd(kind, x, wp, bias, cout, out=None, sigmoid=False):
     sym = None
     if PROFILE is not None:
         sym = _igemm_symbol(lib()._bts_conv3d_fwd_config(kind, n, d, h, w, cin, cout))
-    with _Timed(sym, conv_flops(kind, n, d, h, w, cin, cout), 8 if kind == K3S2T else 1):
-        lib().call('bts_conv3d_fwd', kind, _p(x), _p(wp), _p(bias), _p(out), n, d, h, w, cin, ld_of(x), cout, ld_of(out),
-                   FLAG_SIGMOID if sigmoid else 0, _stream())
+    nb = lib().query('bts_conv3d_fwd_workspace', kind, n, d, h, w, cin, cout)
+    ws = workspace(nb, x.device) if nb > 0 else None
+    with _Timed(sym, conv_flops(kind, n, d, h, w, cin, cout)):
+        lib().call('bts_conv3d_fwd', kind, _p(x), _p(wp), _p(bias), _p(out), _p(ws), nb, n, d, h, w, cin, ld_of(x), cout,
+                   ld_of(out), FLAG_SIGMOID if sigmoid else 0, _stream())
     return out
 
 
@@ -143,9 +145,11 @@ def conv_bwd_data(kind, dy, wp_bwd, dx, accumulate):
     sym = None
     if PROFILE is not None:
         sym = _igemm_symbol(lib()._bts_conv3d_bwd_data_config(kind, n, d, h, w, cin, cout))
-    with _Timed(sym, conv_flops(kind, n, d, h, w, cin, cout), 8 if kind == K3S2 else 1):
-        lib().call('bts_conv3d_bwd_data', kind, _p(dy), _p(wp_bwd), _p(dx), n, d, h, w, cin, ld_of(dx), cout, ld_of(dy),
-                   FLAG_ACCUM if accumulate else 0, _stream())
+    nb = lib().query('bts_conv3d_bwd_data_workspace', kind, n, d, h, w, cin, cout)
+    ws = workspace(nb, dy.device) if nb > 0 else None
+    with _Timed(sym, conv_flops(kind, n, d, h, w, cin, cout)):
+        lib().call('bts_conv3d_bwd_data', kind, _p(dy), _p(wp_bwd), _p(dx), _p(ws), nb, n, d, h, w, cin, ld_of(dx), cout,
+                   ld_of(dy), FLAG_ACCUM if accumulate else 0, _stream())
     return dx
 
 

@@ -49,11 +49,16 @@ long bts_conv_packed_floats(int kind, int role, int Cin, int Cout);
 int bts_conv_pack(int kind, int role, const float* w, float* wp, int Cin_ref, int Cout, int Cin_slab, int dup_start,
                   int dup_shift, bts_stream_t stream);
 /* y = act(conv(x) + bias). x (N,D,H,W,Cin) stride ldx; y (N,D',H',W',Cout) stride ldy; D' = D | D/2 | 2D. */
-int bts_conv3d_fwd(int kind, const float* x, const float* wp_fwd, const float* bias, float* y, int N, int D, int H, int W,
-                   int Cin, int ldx, int Cout, int ldy, int flags, bts_stream_t stream);
+/* workspace (may be NULL / 0) lets grids too small to fill the chip split the contraction over workgroups (deterministic
+ * two-stage reduction); size from bts_conv3d_fwd_workspace (0 when the shape does not need it). */
+long bts_conv3d_fwd_workspace(int kind, int N, int D, int H, int W, int Cin, int Cout);
+int bts_conv3d_fwd(int kind, const float* x, const float* wp_fwd, const float* bias, float* y, void* workspace,
+                   long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, int flags,
+                   bts_stream_t stream);
 /* dx (+)= conv^T(dy). (D,H,W) are the forward INPUT dims. Replaces tf.GradientTape for these ops (train.py:142-151). */
-int bts_conv3d_bwd_data(int kind, const float* dy, const float* wp_bwd, float* dx, int N, int D, int H, int W, int Cin,
-                        int lddx, int Cout, int lddy, int flags, bts_stream_t stream);
+long bts_conv3d_bwd_data_workspace(int kind, int N, int D, int H, int W, int Cin, int Cout);
+int bts_conv3d_bwd_data(int kind, const float* dy, const float* wp_bwd, float* dx, void* workspace, long workspace_bytes,
+                        int N, int D, int H, int W, int Cin, int lddx, int Cout, int lddy, int flags, bts_stream_t stream);
 /* which igemm_kernel<MS,NS,WM,WN,KGS> instantiation a call resolves to (id 0..4, +8 for the 1x1x1 staging variant);
  * used by bench.py to attribute measured launch times to kernel symbols */
 int bts_conv3d_fwd_config(int kind, int N, int D, int H, int W, int Cin, int Cout);

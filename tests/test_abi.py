@@ -55,9 +55,9 @@ def test_argument_validation_without_gpu(cdll):
     from bts_amd._lib import lib
     L = lib()
     # bad shapes are rejected with BTS_ERR_SHAPE (-1) before any HIP call
-    assert L._bts_conv3d_fwd(1, None, None, None, None, 0, 8, 8, 8, 4, 4, 4, 4, 0, None) == -1
-    assert L._bts_conv3d_fwd(2, None, None, None, None, 1, 7, 8, 8, 4, 4, 4, 4, 0, None) == -1   # odd size for s2
-    assert L._bts_conv3d_fwd(1, None, None, None, None, 1, 8, 8, 8, 8, 4, 4, 4, 0, None) == -1   # ld < C
+    assert L._bts_conv3d_fwd(1, None, None, None, None, None, 0, 0, 8, 8, 8, 4, 4, 4, 4, 0, None) == -1
+    assert L._bts_conv3d_fwd(2, None, None, None, None, None, 0, 1, 7, 8, 8, 4, 4, 4, 4, 0, None) == -1   # odd size for s2
+    assert L._bts_conv3d_fwd(1, None, None, None, None, None, 0, 1, 8, 8, 8, 8, 4, 4, 4, 0, None) == -1   # ld < C
     assert L._bts_conv_pack(7, 0, None, None, 4, 4, 4, 0, 0, None) == -3                          # unknown kind
     assert L._bts_gn_stats(None, None, None, None, 0, 1, 8, 6, 4, 0, 1e-5, None) == -1            # C % G != 0
     assert L._bts_gn_workspace(1, 512, 32, 8, 0) > 0
@@ -66,3 +66,6 @@ def test_argument_validation_without_gpu(cdll):
     assert L._bts_adam_tf_step(None, None, None, None, 0, 1e-4, 0.9, 0.999, 1e-7, 1.0, None) == -1
     # kernel-symbol query used by bench.py
     assert L._bts_conv3d_fwd_config(1, 1, 128, 128, 128, 32, 32) == 0
+    # split-K planning is host-only: the VAE's 1024->16 stride-2 conv on 16^3 needs a workspace, the 128^3 convs do not
+    assert L._bts_conv3d_fwd_workspace(2, 1, 16, 16, 16, 1024, 16) > 0
+    assert L._bts_conv3d_fwd_workspace(1, 1, 128, 128, 128, 32, 32) == 0
