@@ -404,7 +404,7 @@ struct WfinParams {
 // Folded slab channel c maps to reference channel c+shift and, if c >= dup_start, also to c-dup_start (both copies of
 // the duplicated slice see the same input: encoder.py:83-87).
 __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const WfinParams f) {
-  __shared__ float sh[8][33];
+  __shared__ double sh[8][33];
   const int e = threadIdx.x & 31, wl = threadIdx.x >> 5;
   const long rows = (long)f.ntaps * f.Cp * f.nqct;  // one row = 32 consecutive qc of one (t, pc, qct)
   const long wgStride = (long)f.npct * f.nqct * f.ntiles * 1024;
@@ -419,15 +419,16 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const WfinParams f)
       const int ci = t * f.cpad + pc;
       off = ((long)qct * f.ntiles + (ci >> 5)) * 1024 + (ci & 31) * 32 + e;
     }
-    float s = 0.f;
-    for (int w = wl; w < f.nsp; w += 8) s += f.partial[w * wgStride + off];
+    double s = 0.0;  // fp64 combine of the per-workgroup fp32 partials (free: this pass is bandwidth-bound)
+    for (int w = wl; w < f.nsp; w += 8) s += (double)f.partial[w * wgStride + off];
     __syncthreads();
     sh[wl][e] = s;
     __syncthreads();
     if (wl == 0) {
-      float tot = sh[0][e];
+      double totd = sh[0][e];
 #pragma unroll
-      for (int k = 1; k < 8; ++k) tot += sh[k][e];
+      for (int k = 1; k < 8; ++k) totd += sh[k][e];
+      const float tot = (float)totd;
       const int qc = qct * 32 + e;
       if (qc < f.Cq) {
         const int pr = (f.fold_axis == 1) ? pc + f.shift : pc;
@@ -443,6 +444,50 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const WfinParams f)
             *d2 = f.accum ? (*d2 + tot) : tot;
           }
         }
+      }
+    }
+  }
+  if (f.db && blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < f.Cq; i += blockDim.x) {
+      double s = 0.0;
+      for (int w = 0; w < f.nsp; ++w) s += f.partial_b[((long)w * f.nqct + (i >> 5)) * 32 + (i & 31)];
+      f.db[i] = f.accum ? (f.db[i] + (float)s) : (float)s;
+    }
+  }
+}
+
+// Same combine for few partials (nsp <= 16): one thread per output element, partials read coalesced along qc.
+__global__ __launch_bounds__(256) void wgrad_finalize_flat_kernel(const WfinParams f) {
+  const int nq = f.nqct * 32;
+  const long total = (long)f.ntaps * f.Cp * nq;
+  const long wgStride = (long)f.npct * f.nqct * f.ntiles * 1024;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int qc = (int)(i % nq);
+    long r = i / nq;
+    const int pc = (int)(r % f.Cp);
+    const int t = (int)(r / f.Cp);
+    if (qc >= f.Cq) continue;
+    const int qct = qc >> 5, e = qc & 31;
+    long off;
+    if (f.cpad == 32) off = ((((long)(pc >> 5)) * f.nqct + qct) * f.ntiles + t) * 1024 + (pc & 31) * 32 + e;
+    else {
+      const int ci = t * f.cpad + pc;
+      off = ((long)qct * f.ntiles + (ci >> 5)) * 1024 + (ci & 31) * 32 + e;
+    }
+    double totd = 0.0;
+    for (int w = 0; w < f.nsp; ++w) totd += (double)f.partial[w * wgStride + off];
+    const float tot = (float)totd;
+    const int pr = (f.fold_axis == 1) ? pc + f.shift : pc;
+    const int qr = (f.fold_axis == 2) ? qc + f.shift : qc;
+    float* d1 = f.dw + t * f.sT + pr * f.sP + qr * f.sQ;
+    *d1 = f.accum ? (*d1 + tot) : tot;
+    if (f.shift > 0) {
+      if (f.fold_axis == 1 && pc >= f.dup_start) {
+        float* d2 = f.dw + t * f.sT + (pc - f.dup_start) * f.sP + qr * f.sQ;
+        *d2 = f.accum ? (*d2 + tot) : tot;
+      } else if (f.fold_axis == 2 && qc >= f.dup_start) {
+        float* d2 = f.dw + t * f.sT + pr * f.sP + (qc - f.dup_start) * f.sQ;
+        *d2 = f.accum ? (*d2 + tot) : tot;
       }
     }
   }
@@ -615,8 +660,14 @@ extern "C" int bts_conv3d_bwd_weight(int kind, const float* x, const float* dy, 
   f.dup_start = dup_shift > 0 ? dup_start : (1 << 30);
   f.accum = accumulate;
   long rows = (long)ro.ntaps * ro.Cp * pl.nqct;
-  int blocks = (int)(rows < 4096 ? rows : 4096);
-  (void)hipGetLastError(); hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, stream, f);
+  if (pl.nsp <= 16) {
+    long blocks = (rows * 32 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    (void)hipGetLastError(); hipLaunchKernelGGL(wgrad_finalize_flat_kernel, dim3((int)blocks), dim3(256), 0, stream, f);
+  } else {
+    int blocks = (int)(rows < 4096 ? rows : 4096);
+    (void)hipGetLastError(); hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, stream, f);
+  }
   BTS_LAUNCH_CHECK();
   if (db != nullptr && ro.swapped) {  // bias gradient of the swapped form: plain column sum of dy
     char* cw = reinterpret_cast<char*>(workspace) + ((pl.partial_floats * 4 + pl.partial_b_doubles * 8 + 256 + 15) & ~15L);

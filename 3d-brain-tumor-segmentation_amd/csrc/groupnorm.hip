@@ -353,12 +353,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
   long hi = lo + span;
   if (hi > unitLen) hi = unitLen;
   double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
-  for (long i = lo + threadIdx.x * 4; i < hi; i += 1024) {
-    const long r = unitBase + i;  // element index inside the sample
-    const int c = (int)(r % C);
-    const long pix = (long)n * (E / C) + r / C;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (long)n * E + r);
-    const f32x4 d = *reinterpret_cast<const f32x4*>(dy + pix * lddy + c);
+  const long npix = E / C;
+  auto body = [&](const f32x4 v, const f32x4 d, int c) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int g = slab ? gs : (c + e) / cg;
@@ -369,6 +365,24 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
       a[e] += (double)(de * xh);
       b[e] += (double)de;
     }
+  };
+  long i = lo + threadIdx.x * 4;
+  for (; i + 1024 < hi; i += 2048) {  // two independent 16-B loads per stream in flight
+    const long r0 = unitBase + i, r1 = r0 + 1024;
+    const int c0 = (int)(r0 % C), c1 = (int)(r1 % C);
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + (long)n * E + r0);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(x + (long)n * E + r1);
+    const f32x4 d0 = *reinterpret_cast<const f32x4*>(dy + ((long)n * npix + r0 / C) * lddy + c0);
+    const f32x4 d1 = *reinterpret_cast<const f32x4*>(dy + ((long)n * npix + r1 / C) * lddy + c1);
+    body(v0, d0, c0);
+    body(v1, d1, c1);
+  }
+  for (; i < hi; i += 1024) {
+    const long r = unitBase + i;
+    const int c = (int)(r % C);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (long)n * E + r);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dy + ((long)n * npix + r / C) * lddy + c);
+    body(v, d, c);
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) { sh[threadIdx.x * 8 + e] = a[e]; sh[threadIdx.x * 8 + 4 + e] = b[e]; }
