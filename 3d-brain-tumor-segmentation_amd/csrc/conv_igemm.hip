@@ -21,6 +21,7 @@
 // input halo tile for KGS*8 channels staged global->regs->LDS, double buffered (one barrier per stage);
 // weight fragments come straight from L2/L1 (shared by the 4 waves), input fragments from LDS via
 // ds_read_b128 with a 16B-odd voxel stride (S = KGS*8+4 dwords) so 16-lane groups hit distinct slots.
+#include <stdlib.h>
 #include "common.h"
 #include "bts_internal.h"
 
@@ -41,6 +42,7 @@ struct IgemmParams {
   int lgTX, lgTY, TZ;
   int ntz, nty, ntx;
   int ntaps, flags;
+  int tap_sz, tap_sy, tap_sx;  // LDS dword strides of the (z,y,x) tap axes (27-tap geometries)
   int tap_lds[27];
   int tap_w[27];
   // split-K: blockIdx.z handles k-groups [z*kg_per, ...); raw partials go to part[z][voxel][Npad] (no bias/act)
@@ -48,6 +50,7 @@ struct IgemmParams {
   float* part;
   long ws_bytes, ws_need;  // host-side planning only
   int plan_only;
+  int dbg;  // profiling aid (BTS_IGEMM_DBG): 1 = skip the MFMA sweep, 2 = skip re-staging after the first stage
   // merged launch of the 8 output-parity classes of the UP geometry (blockIdx.z = class)
   int ncls;
   int cls_nt[8];
@@ -68,17 +71,28 @@ __device__ __forceinline__ void stage_taps(const IgemmParams& p, const int* tlp,
                                            f32x16 (&acc)[MS][NS]) {
   const int wstepKG = 2 * p.Npad * 4;       // floats between consecutive k-groups of one tap
   const int wstepTap = p.KG * wstepKG;      // floats between consecutive taps
+  // 27-tap geometries (k3s1, DOWN): LDS offset and weight tap index are arithmetic in the compile-time tap number, so
+  // nothing is loaded inside the tap sequence (an s_load there shares lgkmcnt with the ds_read prefetch and drains it);
+  // the UP parity classes (<= 8 taps) keep their small tables in SGPRs.
   int tl[NT], tw[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) { tl[t] = tlp[t]; tw[t] = twp[t] * wstepTap; }
+  for (int t = 0; t < NT; ++t) {
+    if (NT == 27) {
+      tl[t] = (t / 9) * p.tap_sz + ((t / 3) % 3) * p.tap_sy + (t % 3) * p.tap_sx;
+      tw[t] = t * wstepTap;
+    } else {
+      tl[t] = tlp[t];
+      tw[t] = twp[t] * wstepTap;
+    }
+  }
   for (int kgl = 0; kgl < nkg; ++kgl) {
     const int wk = (kg0 + kgl) * wstepKG;
     const float* lb = cur + kgl * 8;
     f32x4 a[3][NS], b[2][MS];
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
-      a[0][ns] = *reinterpret_cast<const f32x4*>(p.wp + (lane_woff[ns] + wk + tw[0]));
-      if (NT > 1) a[1][ns] = *reinterpret_cast<const f32x4*>(p.wp + (lane_woff[ns] + wk + tw[NT > 1 ? 1 : 0]));
+      a[0][ns] = *reinterpret_cast<const f32x4*>((p.wp + (wk + tw[0])) + lane_woff[ns]);
+      if (NT > 1) a[1][ns] = *reinterpret_cast<const f32x4*>((p.wp + (wk + tw[NT > 1 ? 1 : 0])) + lane_woff[ns]);
     }
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) b[0][ms] = *reinterpret_cast<const f32x4*>(lb + bbase[ms] + tl[0]);
@@ -87,13 +101,14 @@ __device__ __forceinline__ void stage_taps(const IgemmParams& p, const int* tlp,
       if (t + 2 < NT) {
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns)
-          a[(t + 2) % 3][ns] = *reinterpret_cast<const f32x4*>(p.wp + (lane_woff[ns] + wk + tw[t + 2 < NT ? t + 2 : 0]));
+          a[(t + 2) % 3][ns] = *reinterpret_cast<const f32x4*>((p.wp + (wk + tw[t + 2 < NT ? t + 2 : 0])) + lane_woff[ns]);  // scalar base + lane offset
       }
       if (t + 1 < NT) {
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
           b[(t + 1) % 2][ms] = *reinterpret_cast<const f32x4*>(lb + bbase[ms] + tl[t + 1 < NT ? t + 1 : 0]);
       }
+      __builtin_amdgcn_sched_barrier(0);  // prefetches are issued before this tap's MFMAs, not sunk behind them
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -232,14 +247,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     const float* cur = lds + (st & 1) * bufDw;
     float* nxt = lds + ((st + 1) & 1) * bufDw;
     const bool more = (st + 1) < nstages;
-    if (more) fetch(st + 1);
+    if (more && p.dbg != 2) fetch(st + 1);
 
     // k-groups of this stage x taps: fully unrolled tap sequence (tables hoisted to SGPRs), weight fragments
     // prefetched two taps ahead and input fragments one tap ahead so their latencies sit under the MFMAs
     const int kg0 = (stBeg + st) * KGS;
     int nkg = kgEnd - kg0;
     if (nkg > KGS) nkg = KGS;
-    if constexpr (KGS == 1) {
+    if (p.dbg == 1) {
+    } else if constexpr (KGS == 1) {
       switch (ntaps) {
         case 27: stage_taps<27, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc); break;
         case 8: stage_taps<8, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc); break;
@@ -250,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     } else {  // the 4-k-group staging variant only serves the 1x1x1 convolutions
       stage_taps<1, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc);
     }
-    if (more) commit(nxt);
+    if (more && p.dbg != 2) commit(nxt);
     __syncthreads();
   }
 
@@ -523,6 +539,7 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
   p.part = reinterpret_cast<float*>(ws);
   p.ws_bytes = ws_bytes;
   p.plan_only = need_out != nullptr;
+  { const char* e = getenv("BTS_IGEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
   p.ws_need = 0;
   p.x = x; p.wp = wp; p.bias = bias; p.y = y;
   p.N = N; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.ldx = ldx;
@@ -602,6 +619,7 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
     p.tap_w[t] = tw[t];
   }
   for (int t = nt; t < 27; ++t) { p.tap_lds[t] = 0; p.tap_w[t] = 0; }
+  p.tap_sz = p.IY * p.IX * S; p.tap_sy = p.IX * S; p.tap_sx = S;
   if (geo == GEO_UP && pz < 0) {
     p.ncls = 8;
     for (int c = 0; c < 8; ++c) {
