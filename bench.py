@@ -23,6 +23,29 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
 
 
+def pmc_traffic_bytes(symbol):
+    """HBM bytes per launch of `symbol` from the committed rocprofv3 PMC passes (scripts/pmc_traffic.sh ->
+    profiles/rNN_pmc_traffic.json): (2*FETCH_SIZE + WRITE_SIZE) KiB -- on gfx950 FETCH_SIZE reports half of the bytes of
+    wide (16 B/lane) coalesced reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is taken as is.  None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+    if not files:
+        return None, None
+    tab = json.load(open(files[-1]))
+    norm = lambda n: n.replace('void ', '').replace(' ', '')
+    key = norm(symbol)
+    best = None
+    for k, v in tab.items():
+        nk = norm(k)
+        if (nk == key or (('<' not in key) and nk.split('<')[0] == key)) and 'FETCH_SIZE_KiB_mean' in v \
+                and 'WRITE_SIZE_KiB_mean' in v:
+            if best is None or v['launches'] > best['launches']:
+                best = v
+    if best is None:
+        return None, None
+    return (2.0 * best['FETCH_SIZE_KiB_mean'] + best['WRITE_SIZE_KiB_mean']) * 1024.0, os.path.basename(files[-1])
+
+
 CPU_BASELINE_THREADS = 16   # torch-CPU conv3d stops scaling (and thrashes badly) far below the GPU box's 256 hardware threads
 
 
@@ -158,9 +181,10 @@ def main():
         dom = max(agg.items(), key=lambda kv: kv[1][0])
         sym, (tsec, fl, nl) = dom
         ach = fl / tsec / 1e12
+        traffic, tsrc = pmc_traffic_bytes(sym)
         out['roofline'] = {
             'kernel': sym, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+            'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': tsrc,
             'launches_per_step': nl / args.steps, 'avg_launch_ms': 1e3 * tsec / nl,
             'algorithmic_gflop_per_launch': fl / nl / 1e9,
             'time_share_of_step': tsec / dt,
