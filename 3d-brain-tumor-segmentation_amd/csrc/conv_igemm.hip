@@ -27,6 +27,10 @@
 
 #define MAXSLOT 8
 
+int bts_prof_on();
+void bts_prof_begin(int sym, double flops, hipStream_t stream);
+void bts_prof_end(hipStream_t stream);
+
 struct IgemmParams {
   const float* x;
   const float* wp;
@@ -492,7 +496,14 @@ static int launch_cfg(IgemmParams& p, hipStream_t stream) {
     }
   }
   if (p.plan_only) return BTS_OK;
+  const bool prof = bts_prof_on();
+  if (prof) {
+    constexpr int cfgid = (MS == 2 && NS == 1) ? 0 : (MS == 2 && NS == 2) ? 1 : (MS == 1 && NS == 2) ? 2 : (WN == 2) ? 3 : 4;
+    const double taps = (p.ncls > 1) ? 27.0 : (double)p.ntaps;
+    bts_prof_begin(cfgid + (KGS == 4 ? 8 : 0), 2.0 * taps * p.Cin * p.Cout * (double)p.N * p.Do * p.Ho * p.Wo, stream);
+  }
   (void)hipGetLastError(); hipLaunchKernelGGL(kern, grid, dim3(256), shmem, stream, p);
+  if (prof) bts_prof_end(stream);
   BTS_LAUNCH_CHECK();
   if (p.ksplit > 1) {
     const long nvox = (long)p.N * p.Do * p.Ho * p.Wo;

@@ -16,6 +16,10 @@
 #include "common.h"
 #include "bts_internal.h"
 
+int bts_prof_on();
+void bts_prof_begin(int sym, double flops, hipStream_t stream);
+void bts_prof_end(hipStream_t stream);
+
 #define WG_THREADS 512
 #define WG_WAVES 8
 #define WG_MAXT 4
@@ -639,13 +643,18 @@ extern "C" int bts_conv3d_bwd_weight(int kind, const float* x, const float* dy, 
   p.zeros = reinterpret_cast<const float*>(ztail);
   const bool glds = (p.ldp % 4 == 0) && (p.Cp % 4 == 0) && ((((uintptr_t)p.p) & 15) == 0) && (p.ldq % 4 == 0) &&
                     (p.Cq % 4 == 0) && ((((uintptr_t)p.q) & 15) == 0) && getenv("BTS_WGRAD_NOGLDS") == nullptr;
+  const bool prof = bts_prof_on();
   if (glds) {
     hipError_t e = hipMemsetAsync(ztail, 0, 64, stream);
     if (e != hipSuccess) return (int)e;
+  }
+  if (prof) bts_prof_begin(glds ? 100 : 101, 2.0 * ro.ntaps * (double)ro.Cp * ro.Cq * (double)N * ro.Dq * ro.Hq * ro.Wq, stream);
+  if (glds) {
     (void)hipGetLastError(); hipLaunchKernelGGL(wgrad_kernel<true>, dim3(pl.nsp, pl.npct, pl.nqct), dim3(WG_THREADS), pl.shmem, stream, p);
   } else {
     (void)hipGetLastError(); hipLaunchKernelGGL(wgrad_kernel<false>, dim3(pl.nsp, pl.npct, pl.nqct), dim3(WG_THREADS), pl.shmem, stream, p);
   }
+  if (prof) bts_prof_end(stream);
   BTS_LAUNCH_CHECK();
   WfinParams f;
   f.partial = p.partial; f.partial_b = p.partial_b; f.dw = dw; f.db = p.want_bias ? db : nullptr;

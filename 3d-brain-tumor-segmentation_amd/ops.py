@@ -18,32 +18,32 @@ GN_SLAB, GN_CHANNEL = 0, 1
 
 _workspaces = {}
 
-# ---- optional live kernel timing (bench.py roofline): HIP events on the launch stream around selected launches ----
-PROFILE = None  # None = off; else a list of (symbol, algorithmic_flops, n_launches, start_event, end_event)
-
+# ---- optional live kernel timing (bench.py roofline): the library records HIP events on the launch stream around its
+# igemm_kernel / wgrad_kernel launches (bts_profile_*), i.e. the same per-launch durations rocprofv3 reports ----
 _CFG = {0: '2,1,4,1', 1: '2,2,4,1', 2: '1,2,2,2', 3: '1,1,2,2', 4: '1,1,4,1'}
 
 
-def _igemm_symbol(cfg):
-    return 'igemm_kernel<%s,%d>' % (_CFG[cfg & 7], 4 if cfg & 8 else 1)
+def kernel_symbol(sym):
+    if sym == 100:
+        return 'wgrad_kernel<true>'
+    if sym == 101:
+        return 'wgrad_kernel<false>'
+    return 'igemm_kernel<%s,%d>' % (_CFG[sym & 7], 4 if sym & 8 else 1)
 
 
-class _Timed(object):
-    def __init__(self, symbol, flops, launches=1):
-        self.symbol, self.flops, self.launches = symbol, flops, launches
+def profile_enable(on):
+    lib().call('bts_profile_enable', 1 if on else 0)
 
-    def __enter__(self):
-        if PROFILE is not None:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e1 = torch.cuda.Event(enable_timing=True)
-            self.e0.record()
-        return self
 
-    def __exit__(self, *a):
-        if PROFILE is not None:
-            self.e1.record()
-            PROFILE.append((self.symbol, self.flops, self.launches, self.e0, self.e1))
-        return False
+def profile_records():
+    """-> [(symbol, algorithmic_flops, ms)] ; synchronise the device first"""
+    L = lib()
+    out = []
+    sym, fl, ms = ctypes.c_int(), ctypes.c_double(), ctypes.c_float()
+    for i in range(L._bts_profile_count()):
+        L.call('bts_profile_get', i, ctypes.byref(sym), ctypes.byref(fl), ctypes.byref(ms))
+        out.append((kernel_symbol(sym.value), fl.value, ms.value))
+    return out
 
 
 def conv_flops(kind, n, d, h, w, cin, cout):
@@ -127,12 +127,9 @@ def conv_fwd(kind, x, wp, bias, cout, out=None, sigmoid=False):
     n, d, h, w, cin = x.shape
     if out is None:
         out = torch.empty(conv_out_shape(kind, x.shape, cout), dtype=torch.float32, device=x.device)
-    sym = None
-    if PROFILE is not None:
-        sym = _igemm_symbol(lib()._bts_conv3d_fwd_config(kind, n, d, h, w, cin, cout))
     nb = lib().query('bts_conv3d_fwd_workspace', kind, n, d, h, w, cin, cout)
     ws = workspace(nb, x.device) if nb > 0 else None
-    with _Timed(sym, conv_flops(kind, n, d, h, w, cin, cout)):
+    if True:
         lib().call('bts_conv3d_fwd', kind, _p(x), _p(wp), _p(bias), _p(out), _p(ws), nb, n, d, h, w, cin, ld_of(x), cout,
                    ld_of(out), FLAG_SIGMOID if sigmoid else 0, _stream())
     return out
@@ -142,12 +139,9 @@ def conv_bwd_data(kind, dy, wp_bwd, dx, accumulate):
     """dx: [N,D,H,W,Cin] view of the forward input's gradient"""
     n, d, h, w, cin = dx.shape
     cout = dy.shape[4]
-    sym = None
-    if PROFILE is not None:
-        sym = _igemm_symbol(lib()._bts_conv3d_bwd_data_config(kind, n, d, h, w, cin, cout))
     nb = lib().query('bts_conv3d_bwd_data_workspace', kind, n, d, h, w, cin, cout)
     ws = workspace(nb, dy.device) if nb > 0 else None
-    with _Timed(sym, conv_flops(kind, n, d, h, w, cin, cout)):
+    if True:
         lib().call('bts_conv3d_bwd_data', kind, _p(dy), _p(wp_bwd), _p(dx), _p(ws), nb, n, d, h, w, cin, ld_of(dx), cout,
                    ld_of(dy), FLAG_ACCUM if accumulate else 0, _stream())
     return dx
@@ -158,7 +152,7 @@ def conv_bwd_weight(kind, x, dy, dw, db, dup_start=0, dup_shift=0, accumulate=Fa
     cout = dy.shape[4]
     nb = lib().query('bts_conv3d_bwd_weight_workspace', kind, n, d, h, w, cin, cout)
     ws = workspace(nb, x.device)
-    with _Timed('wgrad_kernel', conv_flops(kind, n, d, h, w, cin, cout)):
+    if True:
         lib().call('bts_conv3d_bwd_weight', kind, _p(x), _p(dy), _p(dw), _p(db), _p(ws), nb, n, d, h, w, cin, ld_of(x),
                    cout, ld_of(dy), dup_start, dup_shift, 1 if accumulate else 0, _stream())
 

@@ -142,7 +142,7 @@ def main():
     torch.cuda.synchronize()
     do_prof = (not args.no_profile)
     if do_prof:
-        ops.PROFILE = []
+        ops.profile_enable(True)   # HIP events on the launch stream around every igemm_kernel / wgrad_kernel launch
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, macro, micro = train_step(model, opt, loss_fn, dice_fn, x, y)
@@ -155,8 +155,10 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
-    prof = ops.PROFILE
-    ops.PROFILE = None
+    prof = None
+    if do_prof:
+        ops.profile_enable(False)
+        prof = ops.profile_records()
 
     if rank != 0:
         return
@@ -173,11 +175,11 @@ def main():
     }
     if do_prof and prof:
         agg = {}
-        for sym, flops, nl, e0, e1 in prof:
+        for sym, flops, ms in prof:
             a = agg.setdefault(sym, [0.0, 0.0, 0])
-            a[0] += e0.elapsed_time(e1) * 1e-3
+            a[0] += ms * 1e-3
             a[1] += flops
-            a[2] += nl
+            a[2] += 1
         dom = max(agg.items(), key=lambda kv: kv[1][0])
         sym, (tsec, fl, nl) = dom
         ach = fl / tsec / 1e12

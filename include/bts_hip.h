@@ -146,6 +146,14 @@ int bts_adam_tf_step(float* p, const float* g, float* m, float* v, long n, float
 /* library identification */
 const char* bts_version(void);
 
+/* ===== optional in-library timing of the two dominant kernels (bench.py roofline) ===== */
+/* HIP events recorded on the launch stream immediately around igemm_kernel / wgrad_kernel launches.
+ * bts_profile_enable(1) clears and starts recording, (0) stops; read the records after synchronising the stream.
+ * sym: 0..4 = igemm_kernel<2,1,4,1|2,2,4,1|1,2,2,2|1,1,2,2|1,1,4,1>, +8 = its 1x1x1 staging variant; 100/101 = wgrad_kernel<true/false> */
+int bts_profile_enable(int on);
+int bts_profile_count(void);
+int bts_profile_get(int i, int* sym, double* flops, float* ms);
+
 #ifdef __cplusplus
 }
 #endif
