@@ -462,7 +462,10 @@ static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   constexpr int S = KGS * 8 + 4;
   const int tileVox = p.IZ * p.IY * p.IX;
   if (tileVox * KGS * 2 > 256 * MAXSLOT) return BTS_ERR_SHAPE;
-  const size_t shmem = (size_t)2 * tileVox * S * sizeof(float);
+  // a single stage (all channels fit one staging pass, e.g. the 1x1x1 convs with Cin <= 32) needs no second buffer:
+  // half the LDS -> twice the resident workgroups to hide the (then un-overlapped) staging latency
+  const int nstages_all = (p.KG + KGS - 1) / KGS;
+  const size_t shmem = (size_t)(nstages_all > 1 ? 2 : 1) * tileVox * S * sizeof(float);
   auto kern = igemm_kernel<MS, NS, WM, WN, KGS>;
   static bool attr_done = false;
   if (!attr_done && !p.plan_only) {

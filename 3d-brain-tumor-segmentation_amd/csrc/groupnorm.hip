@@ -354,14 +354,23 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
   if (hi > unitLen) hi = unitLen;
   double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
   const long npix = E / C;
+  // the channel phase of a thread never changes inside this loop (1024 % C == 0, span % 1024 == 0): fetch its four
+  // affine parameters and, in slab mode, the group statistics once
+  const int cph = (int)((unitBase + lo + threadIdx.x * 4) % C);
+  float gam[4], bet[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = slab ? gs * cg + ((cph + e) % cg) : (cph + e);
+    gam[e] = gamma[idx];
+    bet[e] = beta[idx];
+  }
   auto body = [&](const f32x4 v, const f32x4 d, int c) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int g = slab ? gs : (c + e) / cg;
-      const int idx = slab ? gs * cg + ((c + e) % cg) : (c + e);
       const float xh = (v[e] - mean[n * G + g]) * rstd[n * G + g];
       float de = d[e];
-      if (relu && !(xh * gamma[idx] + beta[idx] > 0.f)) de = 0.f;
+      if (relu && !(xh * gam[e] + bet[e] > 0.f)) de = 0.f;
       a[e] += (double)(de * xh);
       b[e] += (double)de;
     }
@@ -461,24 +470,31 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ rstd, const float* __restrict__ c1,
                                                            const float* __restrict__ c2, long total4, long E, long L,
                                                            int C, int G, int cg, int lddy, int mode, int relu) {
-  for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total4; f += (long)gridDim.x * blockDim.x) {
+  // grid stride (gridDim*1024 elements) is a multiple of C (power of two <= 1024): a thread's channel phase is fixed,
+  // so in channel mode its four affine parameters are loop invariant (slab mode: they also depend on the group)
+  const long f0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const int cph = (int)((f0 * 4) % C);
+  const bool fixed = ((long)gridDim.x * 1024) % C == 0;
+  for (long f = f0; f < total4; f += (long)gridDim.x * blockDim.x) {
     const long i = f * 4;
     const long n = i / E;
     const long r = i - n * E;
-    const int c = (int)(r % C);
+    const int c = fixed ? cph : (int)(r % C);
     const long pix = i / C;
     const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
     const f32x4 d = *reinterpret_cast<const f32x4*>(dy + pix * lddy + c);
+    const int gsl = (int)(r / L);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int g = (mode == BTS_GN_SLAB) ? (int)(r / L) : (c + e) / cg;
+      const int g = (mode == BTS_GN_SLAB) ? gsl : (c + e) / cg;
       const int idx = (mode == BTS_GN_SLAB) ? g * cg + ((c + e) % cg) : (c + e);
       const float rs = rstd[n * G + g];
       const float xh = (v[e] - mean[n * G + g]) * rs;
       float de = d[e];
-      if (relu && !(xh * gamma[idx] + beta[idx] > 0.f)) de = 0.f;
-      o[e] = (de * gamma[idx] - c1[n * G + g] - xh * c2[n * G + g]) * rs;
+      const float ga = gamma[idx];
+      if (relu && !(xh * ga + beta[idx] > 0.f)) de = 0.f;
+      o[e] = (de * ga - c1[n * G + g] - xh * c2[n * G + g]) * rs;
     }
     *reinterpret_cast<f32x4*>(dx + i) = o;
   }
