@@ -49,6 +49,12 @@ struct IgemmParams {
   int tap_sz, tap_sy, tap_sx;  // LDS dword strides of the (z,y,x) tap axes (27-tap geometries)
   int tap_lds[27];
   int tap_w[27];
+  // fused second output (FUSE2): y2 = bias2 + 1x1x1 conv of the same input with wp2 (K1 packing), evaluated at the centre
+  // tap of the 27-tap sweep -- the ResNet block's shortcut conv shares conv1's input tile (resnet.py:118,134)
+  const float* wp2;
+  const float* bias2;
+  float* y2;
+  int ldy2;
   // split-K: blockIdx.z handles k-groups [z*kg_per, ...); raw partials go to part[z][voxel][Npad] (no bias/act)
   int ksplit, kg_per;
   float* part;
@@ -69,10 +75,10 @@ struct IgemmParams {
 #define IG_FLAG_VECOUT 16
 
 // One stage of the implicit GEMM: nkg k-groups (8 input channels each) x NT taps, fully unrolled over the taps.
-template <int NT, int MS, int NS>
+template <int NT, int MS, int NS, bool F2 = false>
 __device__ __forceinline__ void stage_taps(const IgemmParams& p, const int* tlp, const int* twp, const float* cur,
                                            const int (&bbase)[MS], const int (&lane_woff)[NS], int kg0, int nkg,
-                                           f32x16 (&acc)[MS][NS]) {
+                                           f32x16 (&acc)[MS][NS], f32x16 (*acc2)[NS] = nullptr) {
   const int wstepKG = 2 * p.Npad * 4;       // floats between consecutive k-groups of one tap
   const int wstepTap = p.KG * wstepKG;      // floats between consecutive taps
   // 27-tap geometries (k3s1, DOWN): LDS offset and weight tap index are arithmetic in the compile-time tap number, so
@@ -93,6 +99,7 @@ __device__ __forceinline__ void stage_taps(const IgemmParams& p, const int* tlp,
     const int wk = (kg0 + kgl) * wstepKG;
     const float* lb = cur + kgl * 8;
     f32x4 a[3][NS], b[2][MS];
+    f32x4 a2s[NS];
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
       a[0][ns] = *reinterpret_cast<const f32x4*>((p.wp + (wk + tw[0])) + lane_woff[ns]);
@@ -112,7 +119,20 @@ __device__ __forceinline__ void stage_taps(const IgemmParams& p, const int* tlp,
         for (int ms = 0; ms < MS; ++ms)
           b[(t + 1) % 2][ms] = *reinterpret_cast<const f32x4*>(lb + bbase[ms] + tl[t + 1 < NT ? t + 1 : 0]);
       }
+      if (F2 && NT == 27 && t == 11) {  // shortcut-conv weights, two taps ahead of the centre tap
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) a2s[ns] = *reinterpret_cast<const f32x4*>((p.wp2 + wk) + lane_woff[ns]);
+      }
       __builtin_amdgcn_sched_barrier(0);  // prefetches are issued before this tap's MFMAs, not sunk behind them
+      if (F2 && NT == 27 && t == 13) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+              acc2[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2s[ns][j], b[t % 2][ms][j], acc2[ms][ns], 0, 0, 0);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -125,7 +145,7 @@ __device__ __forceinline__ void stage_taps(const IgemmParams& p, const int* tlp,
   }
 }
 
-template <int MS, int NS, int WM, int WN, int KGS>
+template <int MS, int NS, int WM, int WN, int KGS, bool FUSE2 = false>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   constexpr int S = KGS * 8 + 4;  // dwords per staged voxel (pad 4: 16B-odd stride)
   constexpr int QPV = KGS * 2;    // float4 slots per voxel
@@ -205,6 +225,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
+  f32x16 acc2[FUSE2 ? MS : 1][NS];
+  if (FUSE2) {
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[ms][ns][r] = 0.f;
+  }
 
   int kgBeg = 0, kgEnd = p.KG;
   if (p.ksplit > 1) {
@@ -261,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     if (p.dbg == 1) {
     } else if constexpr (KGS == 1) {
       switch (ntaps) {
-        case 27: stage_taps<27, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc); break;
+        case 27: stage_taps<27, MS, NS, FUSE2>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc, acc2); break;
         case 8: stage_taps<8, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc); break;
         case 4: stage_taps<4, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc); break;
         case 2: stage_taps<2, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc); break;
@@ -342,6 +371,20 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
               if (p.flags & IG_FLAG_ACCUM) r += yrow[co + j];
               yrow[co + j] = r;
             }
+        }
+        if (FUSE2) {  // shortcut output: bias only, dense or strided rows, same cout tiling
+          float* y2row = p.y2 + pix * p.ldy2;
+          f32x4 v2 = {acc2[FUSE2 ? ms : 0][ns][4 * g + 0], acc2[FUSE2 ? ms : 0][ns][4 * g + 1],
+                      acc2[FUSE2 ? ms : 0][ns][4 * g + 2], acc2[FUSE2 ? ms : 0][ns][4 * g + 3]};
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (p.bias2 && co + j < p.Cout) v2[j] += p.bias2[co + j];
+          if (vecout && (p.ldy2 % 4 == 0)) *reinterpret_cast<f32x4*>(y2row + co) = v2;
+          else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (co + j < p.Cout) y2row[co + j] = v2[j];
+          }
         }
       }
     }
@@ -457,7 +500,7 @@ extern "C" int bts_conv_pack(int kind, int role, const float* w, float* wp, int 
 // ---------------------------------------------------------------------------------------------
 enum Geo { GEO_K1 = 0, GEO_S1 = 1, GEO_DOWN = 2, GEO_UP = 3 };
 
-template <int MS, int NS, int WM, int WN, int KGS>
+template <int MS, int NS, int WM, int WN, int KGS, bool FUSE2 = false>
 static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   constexpr int S = KGS * 8 + 4;
   const int tileVox = p.IZ * p.IY * p.IX;
@@ -466,7 +509,7 @@ static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   // half the LDS -> twice the resident workgroups to hide the (then un-overlapped) staging latency
   const int nstages_all = (p.KG + KGS - 1) / KGS;
   const size_t shmem = (size_t)(nstages_all > 1 ? 2 : 1) * tileVox * S * sizeof(float);
-  auto kern = igemm_kernel<MS, NS, WM, WN, KGS>;
+  auto kern = igemm_kernel<MS, NS, WM, WN, KGS, FUSE2>;
   static bool attr_done = false;
   if (!attr_done && !p.plan_only) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -480,7 +523,7 @@ static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   p.kg_per = p.KG;
   p.ws_need = 0;
   const long wgs = (long)grid.x * grid.y;
-  if (p.ncls <= 1 && wgs < 192 && p.KG >= 4 * KGS) {
+  if (!FUSE2 && p.ncls <= 1 && wgs < 192 && p.KG >= 4 * KGS) {
     int ks = (int)((384 + wgs - 1) / wgs);
     const int maxks = p.KG / (2 * KGS);
     if (ks > maxks) ks = maxks;
@@ -548,8 +591,10 @@ static int choose_cfg(int geo, int N, int Do, int Ho, int Wo, int Npad, int* Mou
 static int launch_igemm(int geo, const float* x, const float* wp, const float* bias, float* y, int N, int Di, int Hi,
                         int Wi, int Cin, int ldx, int Do, int Ho, int Wo, int Cout, int ldy, int ODa, int OHa, int OWa,
                         int pz, int py, int px, int flags, hipStream_t stream, void* ws = nullptr, long ws_bytes = 0,
-                        long* need_out = nullptr) {
+                        long* need_out = nullptr, const float* wp2 = nullptr, const float* bias2 = nullptr,
+                        float* y2 = nullptr, int ldy2 = 0) {
   IgemmParams p;
+  p.wp2 = wp2; p.bias2 = bias2; p.y2 = y2; p.ldy2 = ldy2;
   p.part = reinterpret_cast<float*>(ws);
   p.ws_bytes = ws_bytes;
   p.plan_only = need_out != nullptr;
@@ -665,6 +710,14 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
       case 3: rc = launch_cfg<1, 1, 2, 2, 4>(p, stream); break;
       default: rc = launch_cfg<1, 1, 4, 1, 4>(p, stream); break;
     }
+  } else if (p.wp2 != nullptr) {  // fused shortcut conv: every tiling but the 64-accumulator one has the registers
+    switch (cfg) {
+      case 0: rc = launch_cfg<2, 1, 4, 1, 1, true>(p, stream); break;
+      case 2: rc = launch_cfg<1, 2, 2, 2, 1, true>(p, stream); break;
+      case 3: rc = launch_cfg<1, 1, 2, 2, 1, true>(p, stream); break;
+      case 4: rc = launch_cfg<1, 1, 4, 1, 1, true>(p, stream); break;
+      default: rc = BTS_ERR_UNSUPPORTED; break;
+    }
   } else {
     switch (cfg) {
       case 0: rc = launch_cfg<2, 1, 4, 1, 1>(p, stream); break;
@@ -755,6 +808,23 @@ extern "C" long bts_conv3d_bwd_data_workspace(int kind, int N, int D, int H, int
   if (conv_bwd_impl(kind, nullptr, nullptr, nullptr, nullptr, 0, &need, N, D, H, W, Cin, Cin, Cout, Cout, 0, nullptr) != BTS_OK)
     return -1;
   return need;
+}
+
+// Fused pair of the ResNet block (resnet.py:118 and :133-134): y = conv3x3x3(x) + bias, y2 = conv1x1x1(x) + bias2 from ONE
+// pass over x. wp_fwd: K3S1 forward packing, wp2: K1 forward packing of the shortcut kernel (same Cin/Cout).
+// Returns BTS_ERR_UNSUPPORTED when the selected tiling has no register room for the second accumulator set
+// (bts_conv3d_fwd_can_fuse tells beforehand): the caller then issues the two convolutions separately.
+extern "C" int bts_conv3d_fwd_can_fuse(int N, int D, int H, int W, int Cin, int Cout) {
+  int M;
+  return choose_cfg(GEO_S1, N, D, H, W, npad32(Cout), &M) != 1;
+}
+extern "C" int bts_conv3d_fwd_fused2(const float* x, const float* wp_fwd, const float* bias, float* y, const float* wp2,
+                                     const float* bias2, float* y2, int N, int D, int H, int W, int Cin, int ldx, int Cout,
+                                     int ldy, int ldy2, hipStream_t stream) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldy < Cout || ldy2 < Cout) return BTS_ERR_SHAPE;
+  if (!wp2 || !y2) return BTS_ERR_SHAPE;
+  return launch_igemm(GEO_S1, x, wp_fwd, bias, y, N, D, H, W, Cin, ldx, D, H, W, Cout, ldy, D, H, W, 0, 0, 0,
+                      bias ? IG_FLAG_BIAS : 0, stream, nullptr, 0, nullptr, wp2, bias2, y2, ldy2);
 }
 
 // Which igemm_kernel<...> instantiation a call resolves to: returns cfg + 8*(KGS==4); cfg ids as in choose_cfg.

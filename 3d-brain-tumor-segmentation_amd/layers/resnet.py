@@ -84,12 +84,17 @@ class ResnetBlock(Layer):
         wp_pt = pk('pt_f', K1, ops.ROLE_FWD, self.ptwise_k, self.cin_ref, f, True)
         wp_c1 = pk('c1_f', K3, ops.ROLE_FWD, self.conv1_k, self.cin_ref, f, True)
         wp_c2 = pk('c2_f', K3, ops.ROLE_FWD, self.conv2_k, f, f, False)
-        # shortcut + gates
-        res = ops.conv_fwd(K1, x.t, wp_pt, self.ptwise_b.t, f)
+        # shortcut conv + conv1 share the input tile: one fused pass where the tiling has the registers for it
+        fused = ops.conv_fwd_fused2(x.t, wp_c1, self.conv1_b.t, wp_pt, self.ptwise_b.t, f)
+        if fused is not None:
+            c1, res = fused
+        else:
+            res = ops.conv_fwd(K1, x.t, wp_pt, self.ptwise_b.t, f)
+            c1 = ops.conv_fwd(K3, x.t, wp_c1, self.conv1_b.t, f)
+        # gates
         gap = ops.colsum(res, scale=1.0 / v)
         hbuf, ch = ops.se_mlp_fwd(gap, self.se_w1.t, self.se_w2.t)
         # conv branch
-        c1 = ops.conv_fwd(K3, x.t, wp_c1, self.conv1_b.t, f)
         m1, r1 = ops.gn_stats(c1, g, ops.GN_SLAB, self.norm1.epsilon)
         a = ops.gn_apply(c1, self.norm1.gamma.t, self.norm1.beta.t, m1, r1, g, ops.GN_SLAB, True)
         c2 = ops.conv_fwd(K3, a, wp_c2, self.conv2_b.t, f)

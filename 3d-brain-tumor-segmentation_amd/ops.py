@@ -135,6 +135,19 @@ def conv_fwd(kind, x, wp, bias, cout, out=None, sigmoid=False):
     return out
 
 
+def conv_fwd_fused2(x, wp3, bias3, wp1, bias1, cout):
+    """(c1, res) = (conv3x3x3(x)+bias3, conv1x1x1(x)+bias1) from one pass over x, or None when the selected tiling cannot
+    hold the second accumulator set (the caller then launches the two convolutions separately)"""
+    n, d, h, w, cin = x.shape
+    if not lib()._bts_conv3d_fwd_can_fuse(n, d, h, w, cin, cout):
+        return None
+    c1 = torch.empty((n, d, h, w, cout), dtype=torch.float32, device=x.device)
+    res = torch.empty_like(c1)
+    lib().call('bts_conv3d_fwd_fused2', _p(x), _p(wp3), _p(bias3), _p(c1), _p(wp1), _p(bias1), _p(res), n, d, h, w, cin,
+               ld_of(x), cout, cout, cout, _stream())
+    return c1, res
+
+
 def conv_bwd_data(kind, dy, wp_bwd, dx, accumulate):
     """dx: [N,D,H,W,Cin] view of the forward input's gradient"""
     n, d, h, w, cin = dx.shape

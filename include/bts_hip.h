@@ -55,6 +55,12 @@ long bts_conv3d_fwd_workspace(int kind, int N, int D, int H, int W, int Cin, int
 int bts_conv3d_fwd(int kind, const float* x, const float* wp_fwd, const float* bias, float* y, void* workspace,
                    long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, int flags,
                    bts_stream_t stream);
+/* ResNet block pair from one pass over x: y = conv3x3x3(x)+bias (resnet.py:133-134), y2 = conv1x1x1(x)+bias2 (resnet.py:118).
+ * wp2 is the BTS_CONV_K1 forward packing. bts_conv3d_fwd_can_fuse() == 0 -> call the two convolutions separately. */
+int bts_conv3d_fwd_can_fuse(int N, int D, int H, int W, int Cin, int Cout);
+int bts_conv3d_fwd_fused2(const float* x, const float* wp_fwd, const float* bias, float* y, const float* wp2,
+                          const float* bias2, float* y2, int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy,
+                          int ldy2, bts_stream_t stream);
 /* dx (+)= conv^T(dy). (D,H,W) are the forward INPUT dims. Replaces tf.GradientTape for these ops (train.py:142-151). */
 long bts_conv3d_bwd_data_workspace(int kind, int N, int D, int H, int W, int Cin, int Cout);
 int bts_conv3d_bwd_data(int kind, const float* dy, const float* wp_bwd, float* dx, void* workspace, long workspace_bytes,

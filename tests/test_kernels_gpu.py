@@ -120,6 +120,28 @@ def test_conv_strided_views_and_sigmoid():
     check_close(sg[..., :32], slab[..., :32].double(), 'input slice untouched', rtol=0, atol=0)
 
 
+@pytest.mark.parametrize('n,dims,cin,cout', [(1, (16, 16, 32), 32, 32), (1, (8, 8, 8), 24, 128), (2, (4, 4, 8), 2, 32),
+                                             (1, (16, 16, 16), 64, 64)])
+def test_conv_fused_shortcut_pair(n, dims, cin, cout):
+    """resnet.py:118 + :133-134 in one pass over x: bts_conv3d_fwd_fused2 == the two separate convolutions"""
+    from bts_amd import ops
+    d, h, w = dims
+    x = rnd((n, d, h, w, cin), 50)
+    w3, b3 = rnd((3, 3, 3, cin, cout), 51, 0.2), rnd((cout,), 52)
+    w1, b1 = rnd((1, 1, 1, cin, cout), 53, 0.3), rnd((cout,), 54)
+    xg = x.to(dev())
+    wp3 = ops.conv_pack(ops.K3S1, ops.ROLE_FWD, w3.to(dev()), cin, cout)
+    wp1 = ops.conv_pack(ops.K1, ops.ROLE_FWD, w1.to(dev()), cin, cout)
+    out = ops.conv_fwd_fused2(xg, wp3, b3.to(dev()), wp1, b1.to(dev()), cout)
+    if out is None:   # tiling without room for the second accumulator set: the engine falls back to two launches
+        pytest.skip('not fusable at this shape')
+    c1, res = out
+    r3 = R.conv3d(x.double(), w3.double(), b3.double())
+    r1 = R.conv3d(x.double(), w1.double(), b1.double())
+    check_contraction(c1, r3, R.conv3d(x.double().abs(), w3.double().abs(), b3.double().abs()), 'fused conv3')
+    check_contraction(res, r1, R.conv3d(x.double().abs(), w1.double().abs(), b1.double().abs()), 'fused conv1')
+
+
 @pytest.mark.parametrize('kind', [0, 1])
 def test_conv_folded_duplicate_slice(kind):
     """encoder.py:83-87: block j sees [o_{j-1}, o_0..o_{j-1}]; the engine reads the slab [o_0..o_{j-1}] once with

@@ -1,5 +1,5 @@
 """-m gpu: full-model forward / backward / Adam parity of the HIP engine against the fp64 oracle, on the same seeded
-inputs and weights.  Tolerances: y_pred max-abs <= 1e-4, gradients <= 5e-4 relative to the gradient's
+inputs and weights.  Tolerances: y_pred max-abs <= 1e-4, gradients <= 1e-3 relative to the gradient's
 max-abs (a ReLU mask that flips at a pre-activation within fp32 rounding of zero moves a weight gradient by one term), argmax label map bit-exact, loss and Dice within 1e-5 / 1e-4."""
 import pytest
 import torch
@@ -105,7 +105,7 @@ def test_train_step_parity(name):
         if err > worst[0]:
             worst = (err, p.name)
         dev32 = maxerr(grads_32[model.oracle_name(p)], gr) / scale
-        assert err <= max(5e-4, 4 * dev32, 0.25 * gdev) or maxerr(g, gr) <= 1e-9, \
+        assert err <= max(1e-3, 4 * dev32, 0.25 * gdev) or maxerr(g, gr) <= 1e-9, \
             'grad %s rel err %.3e (fp32-torch deviates %.3e; scale %.3e)' % (p.name, err, dev32, scale)
     print('worst grad rel err', worst)
     # one Adam step (TF form)
