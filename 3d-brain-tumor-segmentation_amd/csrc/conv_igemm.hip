@@ -98,26 +98,36 @@ __device__ __forceinline__ void stage_taps(const IgemmParams& p, const int* tlp,
   for (int kgl = 0; kgl < nkg; ++kgl) {
     const int wk = (kg0 + kgl) * wstepKG;
     const float* lb = cur + kgl * 8;
-    f32x4 a[3][NS], b[2][MS];
+    // prefetch depths: weights (L2, ~500-900 cycles) AD taps ahead, input fragments (LDS, ~130 cycles) BD taps ahead;
+    // deep enough that a single wave per SIMD keeps the matrix pipe fed while its partner workgroup is in its prologue
+    constexpr int AD = 2, BD = 1;  // deeper (3/2) measured neutral on MI355X and costs registers
+    f32x4 a[AD + 1][NS], b[BD + 1][MS];
     f32x4 a2s[NS];
 #pragma unroll
-    for (int ns = 0; ns < NS; ++ns) {
-      a[0][ns] = *reinterpret_cast<const f32x4*>((p.wp + (wk + tw[0])) + lane_woff[ns]);
-      if (NT > 1) a[1][ns] = *reinterpret_cast<const f32x4*>((p.wp + (wk + tw[NT > 1 ? 1 : 0])) + lane_woff[ns]);
-    }
-#pragma unroll
-    for (int ms = 0; ms < MS; ++ms) b[0][ms] = *reinterpret_cast<const f32x4*>(lb + bbase[ms] + tl[0]);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (t + 2 < NT) {
+    for (int q = 0; q < AD; ++q)
+      if (q < NT) {
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns)
-          a[(t + 2) % 3][ns] = *reinterpret_cast<const f32x4*>((p.wp + (wk + tw[t + 2 < NT ? t + 2 : 0])) + lane_woff[ns]);  // scalar base + lane offset
+          a[q][ns] = *reinterpret_cast<const f32x4*>((p.wp + (wk + tw[q < NT ? q : 0])) + lane_woff[ns]);
       }
-      if (t + 1 < NT) {
+#pragma unroll
+    for (int q = 0; q < BD; ++q)
+      if (q < NT) {
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) b[q][ms] = *reinterpret_cast<const f32x4*>(lb + bbase[ms] + tl[q < NT ? q : 0]);
+      }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t + AD < NT) {
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+          a[(t + AD) % (AD + 1)][ns] =
+              *reinterpret_cast<const f32x4*>((p.wp + (wk + tw[t + AD < NT ? t + AD : 0])) + lane_woff[ns]);  // scalar base + lane offset
+      }
+      if (t + BD < NT) {
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
-          b[(t + 1) % 2][ms] = *reinterpret_cast<const f32x4*>(lb + bbase[ms] + tl[t + 1 < NT ? t + 1 : 0]);
+          b[(t + BD) % (BD + 1)][ms] = *reinterpret_cast<const f32x4*>(lb + bbase[ms] + tl[t + BD < NT ? t + BD : 0]);
       }
       if (F2 && NT == 27 && t == 11) {  // shortcut-conv weights, two taps ahead of the centre tap
 #pragma unroll
@@ -131,7 +141,7 @@ __device__ __forceinline__ void stage_taps(const IgemmParams& p, const int* tlp,
           for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns)
-              acc2[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2s[ns][j], b[t % 2][ms][j], acc2[ms][ns], 0, 0, 0);
+              acc2[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2s[ns][j], b[t % (BD + 1)][ms][j], acc2[ms][ns], 0, 0, 0);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -139,7 +149,7 @@ __device__ __forceinline__ void stage_taps(const IgemmParams& p, const int* tlp,
         for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
           for (int ns = 0; ns < NS; ++ns)
-            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t % 3][ns][j], b[t % 2][ms][j], acc[ms][ns], 0, 0, 0);
+            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t % (AD + 1)][ns][j], b[t % (BD + 1)][ms][j], acc[ms][ns], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);  // keep the hand-written 2-deep pipeline: no hoisting of later taps' loads
     }
   }
