@@ -75,7 +75,7 @@ struct IgemmParams {
 #define IG_FLAG_VECOUT 16
 
 // One stage of the implicit GEMM: nkg k-groups (8 input channels each) x NT taps, fully unrolled over the taps.
-template <int NT, int MS, int NS, bool F2 = false>
+template <int NT, int MS, int NS, bool F2 = false, bool FIXG = false>
 __device__ __forceinline__ void stage_taps(const IgemmParams& p, const int* tlp, const int* twp, const float* cur,
                                            const int (&bbase)[MS], const int (&lane_woff)[NS], int kg0, int nkg,
                                            f32x16 (&acc)[MS][NS], f32x16 (*acc2)[NS] = nullptr) {
@@ -88,7 +88,10 @@ __device__ __forceinline__ void stage_taps(const IgemmParams& p, const int* tlp,
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     if (NT == 27) {
-      tl[t] = (t / 9) * p.tap_sz + ((t / 3) % 3) * p.tap_sy + (t % 3) * p.tap_sx;
+      // FIXG: the 32x4xTZ tile of the big-grid configs has a compile-time halo geometry (IX=34, IY=6, S=12), so every
+      // tap offset folds into the ds_read immediate: no per-tap address VALU, no address registers
+      tl[t] = FIXG ? (((t / 9) * 6 + (t / 3) % 3) * 34 + (t % 3)) * 12
+                   : (t / 9) * p.tap_sz + ((t / 3) % 3) * p.tap_sy + (t % 3) * p.tap_sx;
       tw[t] = t * wstepTap;
     } else {
       tl[t] = tlp[t];
@@ -155,8 +158,12 @@ __device__ __forceinline__ void stage_taps(const IgemmParams& p, const int* tlp,
   }
 }
 
-template <int MS, int NS, int WM, int WN, int KGS, bool FUSE2 = false>
+template <int MS, int NS, int WM, int WN, int KGS, bool FUSE2 = false, bool FIXG = false>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
+  // MS == 4 (512-voxel tile, 16 MFMAs per tap for 32-cout layers): its 59 KB halo tile is single-buffered so that two
+  // workgroups still fit a CU; the partner workgroup covers the (short) LDS refill between stages
+  constexpr int NSLOT = (MS == 4) ? 10 : MAXSLOT;
+  constexpr bool SINGLE = (MS == 4);
   constexpr int S = KGS * 8 + 4;  // dwords per staged voxel (pad 4: 16B-odd stride)
   constexpr int QPV = KGS * 2;    // float4 slots per voxel
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -186,27 +193,27 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   const int tileVox = p.IZ * p.IY * p.IX;
   const int bufDw = tileVox * S;
 
-  // ---- staging map: slot e -> (voxel, quad); global element offset (or -1 if zero padding) ----
+  // ---- staging map: slot e = tid + i*256 -> (voxel, quad). Only a 32-bit element offset relative to the tile origin
+  //      is kept per slot (-1 = zero padding); LDS offset and channel quad are recomputed from e (QPV is a constant).
   const int nslots = tileVox * QPV;
-  long goff[MAXSLOT];
-  int loff[MAXSLOT];
-  int cq[MAXSLOT];
+  const float* xbase = p.x + ((((long)n * p.Di + iz0) * p.Hi + iy0) * p.Wi + ix0) * (long)p.ldx;  // wave-uniform
+  int goff[NSLOT];
+  const int IYX = p.IY * p.IX;
+  const float invIX = 1.0f / (float)p.IX, invIYX = 1.0f / (float)IYX;
 #pragma unroll
-  for (int i = 0; i < MAXSLOT; ++i) {
+  for (int i = 0; i < NSLOT; ++i) {
     const int e = tid + i * 256;
     goff[i] = -1;
-    loff[i] = -1;
-    cq[i] = 0;
     if (e < nslots) {
       const int vox = e / QPV, q = e - vox * QPV;
-      const int vx = vox % p.IX;
-      const int r = vox / p.IX;
-      const int vy = r % p.IY, vz = r / p.IY;
-      const int gz = iz0 + vz, gy = iy0 + vy, gx = ix0 + vx;
-      loff[i] = vox * S + q * 4;
-      cq[i] = q * 4;
-      if (gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi)
-        goff[i] = ((((long)n * p.Di + gz) * p.Hi + gy) * p.Wi + gx) * (long)p.ldx + q * 4;
+      // exact small-integer division by float reciprocal (operands < 2^16): the prologue is on every workgroup's
+      // critical path, integer division would cost ~50 VALU instructions per slot
+      const int vz = (int)(((float)vox + 0.5f) * invIYX);
+      const int r = vox - vz * IYX;
+      const int vy = (int)(((float)r + 0.5f) * invIX);
+      const int vx = r - vy * p.IX;
+      if ((unsigned)(iz0 + vz) < (unsigned)p.Di && (unsigned)(iy0 + vy) < (unsigned)p.Hi && (unsigned)(ix0 + vx) < (unsigned)p.Wi)
+        goff[i] = ((vz * p.Hi + vy) * p.Wi + vx) * p.ldx + q * 4;
     }
   }
 
@@ -255,15 +262,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   const int nstages = (kgEnd - kgBeg + KGS - 1) / KGS;
   const bool vecin = (p.flags & IG_FLAG_VECIN) != 0;
 
-  f32x4 pre[MAXSLOT];
+  f32x4 pre[NSLOT];
   auto fetch = [&](int st) {
     const int c0 = (stBeg + st) * KGS * 8;
 #pragma unroll
-    for (int i = 0; i < MAXSLOT; ++i) {
+    for (int i = 0; i < NSLOT; ++i) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (goff[i] >= 0) {
-        const int c = c0 + cq[i];
-        const float* src = p.x + goff[i] + c0;
+        const int c = c0 + ((tid + i * 256) % QPV) * 4;
+        const float* src = xbase + goff[i] + c0;
         if (vecin) {
           if (c < p.Cin) v = *reinterpret_cast<const f32x4*>(src);
         } else {
@@ -278,8 +285,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   };
   auto commit = [&](float* buf) {
 #pragma unroll
-    for (int i = 0; i < MAXSLOT; ++i)
-      if (loff[i] >= 0) *reinterpret_cast<f32x4*>(buf + loff[i]) = pre[i];
+    for (int i = 0; i < NSLOT; ++i) {
+      const int e = tid + i * 256;
+      if (e < nslots) *reinterpret_cast<f32x4*>(buf + (e / QPV) * S + (e % QPV) * 4) = pre[i];
+    }
   };
 
   fetch(0);
@@ -287,8 +296,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   __syncthreads();
 
   for (int st = 0; st < nstages; ++st) {
-    const float* cur = lds + (st & 1) * bufDw;
-    float* nxt = lds + ((st + 1) & 1) * bufDw;
+    const float* cur = SINGLE ? lds : lds + (st & 1) * bufDw;
+    float* nxt = SINGLE ? lds : lds + ((st + 1) & 1) * bufDw;
     const bool more = (st + 1) < nstages;
     if (more && p.dbg != 2) fetch(st + 1);
 
@@ -300,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     if (p.dbg == 1) {
     } else if constexpr (KGS == 1) {
       switch (ntaps) {
-        case 27: stage_taps<27, MS, NS, FUSE2>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc, acc2); break;
+        case 27: stage_taps<27, MS, NS, FUSE2, FIXG>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc, acc2); break;
         case 8: stage_taps<8, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc); break;
         case 4: stage_taps<4, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc); break;
         case 2: stage_taps<2, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc); break;
@@ -309,6 +318,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     } else {  // the 4-k-group staging variant only serves the 1x1x1 convolutions
       stage_taps<1, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc);
     }
+    if (SINGLE) __syncthreads();  // every wave has finished reading the tile before it is overwritten
     if (more && p.dbg != 2) commit(nxt);
     __syncthreads();
   }
@@ -510,16 +520,16 @@ extern "C" int bts_conv_pack(int kind, int role, const float* w, float* wp, int 
 // ---------------------------------------------------------------------------------------------
 enum Geo { GEO_K1 = 0, GEO_S1 = 1, GEO_DOWN = 2, GEO_UP = 3 };
 
-template <int MS, int NS, int WM, int WN, int KGS, bool FUSE2 = false>
+template <int MS, int NS, int WM, int WN, int KGS, bool FUSE2 = false, bool FIXG = false>
 static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   constexpr int S = KGS * 8 + 4;
   const int tileVox = p.IZ * p.IY * p.IX;
-  if (tileVox * KGS * 2 > 256 * MAXSLOT) return BTS_ERR_SHAPE;
+  if (tileVox * KGS * 2 > 256 * ((MS == 4) ? 10 : MAXSLOT)) return BTS_ERR_SHAPE;
   // a single stage (all channels fit one staging pass, e.g. the 1x1x1 convs with Cin <= 32) needs no second buffer:
   // half the LDS -> twice the resident workgroups to hide the (then un-overlapped) staging latency
   const int nstages_all = (p.KG + KGS - 1) / KGS;
-  const size_t shmem = (size_t)(nstages_all > 1 ? 2 : 1) * tileVox * S * sizeof(float);
-  auto kern = igemm_kernel<MS, NS, WM, WN, KGS, FUSE2>;
+  const size_t shmem = (size_t)((nstages_all > 1 && MS != 4) ? 2 : 1) * tileVox * S * sizeof(float);
+  auto kern = igemm_kernel<MS, NS, WM, WN, KGS, FUSE2, FIXG>;
   static bool attr_done = false;
   if (!attr_done && !p.plan_only) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -554,7 +564,7 @@ static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   if (p.plan_only) return BTS_OK;
   const bool prof = bts_prof_on();
   if (prof) {
-    constexpr int cfgid = (MS == 2 && NS == 1) ? 0 : (MS == 2 && NS == 2) ? 1 : (MS == 1 && NS == 2) ? 2 : (WN == 2) ? 3 : 4;
+    constexpr int cfgid = (MS == 4) ? 5 : (MS == 2 && NS == 1) ? 0 : (MS == 2 && NS == 2) ? 1 : (MS == 1 && NS == 2) ? 2 : (WN == 2) ? 3 : 4;
     const double taps = (p.ncls > 1) ? 27.0 : (double)p.ntaps;
     bts_prof_begin(cfgid + (KGS == 4 ? 8 : 0), 2.0 * taps * p.Cin * p.Cout * (double)p.N * p.Do * p.Ho * p.Wo, stream);
   }
@@ -584,7 +594,9 @@ static int choose_cfg(int geo, int N, int Do, int Ho, int Wo, int Npad, int* Mou
   } else {
     const long wg256 = (long)N * ((vox + 255) / 256) * ((Npad + 63) / 64);
     if (Npad <= 32) {
-      if ((long)N * ((vox + 255) / 256) >= 512) { M = 256; cfg = 0; }
+      if (geo == GEO_S1 && Wo >= 32 && Ho >= 4 && Do >= 4 && (long)N * ((vox + 511) / 512) >= 1024 &&
+          getenv("BTS_IGEMM_M512") != nullptr) { M = 512; cfg = 5; }  // measured equal to M=256 on MI355X: opt-in only
+      else if ((long)N * ((vox + 255) / 256) >= 512) { M = 256; cfg = 0; }
       else { M = 128; cfg = 4; }
     } else if (wg256 >= 512) { M = 256; cfg = 1; }
     else {
@@ -664,7 +676,8 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
   // ---- config selection ----
   const int k1 = (geo == GEO_K1);
   int M;  // voxels per workgroup tile
-  const int cfg = choose_cfg(geo, (geo == GEO_UP && pz < 0) ? 8 * N : N, Do, Ho, Wo, p.Npad, &M);
+  int cfg = choose_cfg(geo, (geo == GEO_UP && pz < 0) ? 8 * N : N, Do, Ho, Wo, p.Npad, &M);
+  if (p.wp2 != nullptr && cfg == 5) { cfg = 0; M = 256; }  // the fused pair needs the registers of the 256-voxel tiling
   // tile dims (powers of two in x,y)
   int TX = 32;
   while (TX > 4 && TX / 2 >= Wo) TX /= 2;  // smallest pow2 >= Wo, capped at 32
@@ -712,7 +725,17 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
   }
 
   int rc;
-  if (k1) {
+  const bool fixg = (geo == GEO_S1) && p.IX == 34 && p.IY == 6;
+  if (fixg && !k1 && (cfg == 0 || cfg == 1 || cfg == 5)) {
+    if (p.wp2 != nullptr) {
+      if (cfg == 0) rc = launch_cfg<2, 1, 4, 1, 1, true, true>(p, stream);
+      else rc = BTS_ERR_UNSUPPORTED;
+    } else {
+      if (cfg == 0) rc = launch_cfg<2, 1, 4, 1, 1, false, true>(p, stream);
+      else if (cfg == 5) rc = launch_cfg<4, 1, 4, 1, 1, false, true>(p, stream);
+      else rc = launch_cfg<2, 2, 4, 1, 1, false, true>(p, stream);
+    }
+  } else if (k1) {
     switch (cfg) {
       case 0: rc = launch_cfg<2, 1, 4, 1, 4>(p, stream); break;
       case 1: rc = launch_cfg<2, 2, 4, 1, 4>(p, stream); break;
@@ -723,6 +746,7 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
   } else if (p.wp2 != nullptr) {  // fused shortcut conv: every tiling but the 64-accumulator one has the registers
     switch (cfg) {
       case 0: rc = launch_cfg<2, 1, 4, 1, 1, true>(p, stream); break;
+      case 5: rc = BTS_ERR_UNSUPPORTED; break;  // M=512 tiling exists only with the compile-time halo geometry
       case 2: rc = launch_cfg<1, 2, 2, 2, 1, true>(p, stream); break;
       case 3: rc = launch_cfg<1, 1, 2, 2, 1, true>(p, stream); break;
       case 4: rc = launch_cfg<1, 1, 4, 1, 1, true>(p, stream); break;
@@ -731,6 +755,7 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
   } else {
     switch (cfg) {
       case 0: rc = launch_cfg<2, 1, 4, 1, 1>(p, stream); break;
+      case 5: rc = BTS_ERR_UNSUPPORTED; break;
       case 1: rc = launch_cfg<2, 2, 4, 1, 1>(p, stream); break;
       case 2: rc = launch_cfg<1, 2, 2, 2, 1>(p, stream); break;
       case 3: rc = launch_cfg<1, 1, 2, 2, 1>(p, stream); break;

@@ -20,7 +20,7 @@ _workspaces = {}
 
 # ---- optional live kernel timing (bench.py roofline): the library records HIP events on the launch stream around its
 # igemm_kernel / wgrad_kernel launches (bts_profile_*), i.e. the same per-launch durations rocprofv3 reports ----
-_CFG = {0: '2,1,4,1', 1: '2,2,4,1', 2: '1,2,2,2', 3: '1,1,2,2', 4: '1,1,4,1'}
+_CFG = {0: '2,1,4,1', 1: '2,2,4,1', 2: '1,2,2,2', 3: '1,1,2,2', 4: '1,1,4,1', 5: '4,1,4,1'}
 
 
 def kernel_symbol(sym):
