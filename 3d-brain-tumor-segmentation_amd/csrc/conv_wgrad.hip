@@ -41,6 +41,7 @@ struct WgradParams {
   int ntaps, ntiles, cpad, lgSP;
   int nsub, sub_per_wg;
   int want_bias;
+  int fixg;  // 1/2: the sub-tile is the unclamped 16x4x2 (stride 1) / 8x4x1 (stride 2) 27-tap geometry -> fixed sweep
   int dbg;  // profiling aid (BTS_WGRAD_DBG): 1 = skip the MFMA sweep, 2 = skip re-staging after the first sub-tile
   int tap_vox[27];  // voxel offset of each tap inside the P halo tile
 };
@@ -86,29 +87,108 @@ __device__ __forceinline__ void wgrad_steps(const WgradParams& p, const float* b
     for (int i = 0; i < T; ++i) f.a[i] = lds_read_b32_async(laneoff[i] + (unsigned)(pvu * 4));
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto mma = [&](const WgFrag<T>& f) {
+  // One step = T MFMAs on the fragment fetched one step earlier.  The next fragment's address arithmetic and LDS reads
+  // are issued right after the first MFMA so they retire in the shadow of the matrix pipe (a wave blocks on MFMA issue
+  // while the pipe is busy; anything placed before the burst would instead serialise with it), and the burst runs at
+  // raised priority so the two waves of a SIMD alternate whole bursts instead of dragging each other through them
+  // (scripts/ubench/mfma_lds_feed.hip: 142 -> 154 TFLOP/s at 2 waves/SIMD).
+  auto step = [&](const WgFrag<T>& cur, WgFrag<T>& nxt, int knext) {
+    wait_lgkm<0>();
+    __builtin_amdgcn_s_setprio(1);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[0], cur.q, acc[0], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load(nxt, knext);
 #pragma unroll
-    for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i], f.q, acc[i], 0, 0, 0);
+    for (int i = 1; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[i], cur.q, acc[i], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };
   WgFrag<T> A, B;
-  int k = 0;
-  if (nK > 0) load(A, 0);
-  for (; k + 1 < nK; k += 2) {
-    load(B, k + 1);
-    wait_lgkm<T + 1>();  // A's T+1 reads are older than B's T+1: they have landed
-    mma(A);
-    if (k + 2 < nK) {
-      load(A, k + 2);
-      wait_lgkm<T + 1>();
-    } else {
-      wait_lgkm<0>();
-    }
-    mma(B);
+  if (nK <= 0) return;
+  load(A, 0);
+  const int last = nK - 1;
+  for (int k = 0; k < nK; k += 2) {
+    step(A, B, k + 1 < last ? k + 1 : last);  // the final prefetch re-reads the last fragment (never consumed)
+    if (k + 1 >= nK) break;
+    step(B, A, k + 2 < last ? k + 2 : last);
   }
-  if (k < nK) {
-    wait_lgkm<0>();
-    mma(A);
+  wait_lgkm<0>();
+}
+
+// ---- fixed-geometry sweep (3x3x3 taps, 32-channel P voxels, unclamped sub-tile) ---------------------------------------
+// Measured cost model (scripts/ubench/wgrad_sweep.hip): next to the matrix pipe EVERY issued instruction costs ~4 cycles
+// of SIMD time, scalar ones included, so the general step above (13 SALU + 6 VALU + T+1 LDS reads per T MFMAs) tops out
+// at ~105 TFLOP/s.  Here the sub-tile geometry and the wave's tap set are template parameters: all tap / voxel offsets
+// become DS immediates off two per-row base registers and a step is T+1 ds_read_b32 + T MFMAs and nothing else.
+template <int S, int TX, int TY>
+struct WgGeo {
+  static constexpr int IX = (TX - 1) * S + 3, IY = (TY - 1) * S + 3;
+  static constexpr int JR = TX / 2;                         // voxel-pair steps per x-row
+  static constexpr int STEP_B = 2 * S * 128;                // P bytes per step (two voxels, 128 B each, stride S)
+  static constexpr int ROW_B = S * IX * 128;                // next y-row
+  static constexpr int PLANE_B = S * IY * IX * 128 - (TY - 1) * ROW_B;  // from the last row of a plane to the next plane
+  static constexpr int tap_b(int t) { return (((t / 9) * IY + (t / 3) % 3) * IX + t % 3) * 128; }
+};
+template <int T, int WAVE, typename G, int J>
+__device__ __forceinline__ void wgf_load(WgFrag<T>& f, unsigned vp, unsigned vq) {
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.q) : "v"(vq), "n"(J * 256));
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.a[0]) : "v"(vp), "n"(G::tap_b(WAVE) + J * G::STEP_B));
+  if constexpr (T > 1) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.a[1]) : "v"(vp), "n"(G::tap_b(WAVE + 8) + J * G::STEP_B));
+  if constexpr (T > 2) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.a[2]) : "v"(vp), "n"(G::tap_b(WAVE + 16) + J * G::STEP_B));
+  if constexpr (T > 3) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.a[3]) : "v"(vp), "n"(G::tap_b(WAVE + 24) + J * G::STEP_B));
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int T, int WAVE, typename G, int J>
+__device__ __forceinline__ void wgf_step(const WgFrag<T>& cur, WgFrag<T>& nxt, f32x16 (&acc)[WG_MAXT], unsigned vp, unsigned vq,
+                                         unsigned vpn, unsigned vqn) {
+  wait_lgkm<0>();
+  __builtin_amdgcn_s_setprio(1);
+  acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[0], cur.q, acc[0], 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (J + 1 < G::JR) wgf_load<T, WAVE, G, J + 1>(nxt, vp, vq);
+  else wgf_load<T, WAVE, G, 0>(nxt, vpn, vqn);
+#pragma unroll
+  for (int i = 1; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[i], cur.q, acc[i], 0, 0, 0);
+  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int T, int WAVE, typename G, int J>
+__device__ __forceinline__ void wgf_row(WgFrag<T>& A, WgFrag<T>& B, f32x16 (&acc)[WG_MAXT], unsigned vp, unsigned vq, unsigned vpn,
+                                        unsigned vqn) {
+  wgf_step<T, WAVE, G, J>(A, B, acc, vp, vq, vpn, vqn);
+  wgf_step<T, WAVE, G, J + 1>(B, A, acc, vp, vq, vpn, vqn);
+  if constexpr (J + 2 < G::JR) wgf_row<T, WAVE, G, J + 2>(A, B, acc, vp, vq, vpn, vqn);
+}
+template <int WAVE, int S, int TX, int TY, int TZ>
+__device__ __forceinline__ void wgrad_sweep_fixed(const float* bp, const float* bq, f32x16 (&acc)[WG_MAXT], int h, int l32) {
+  using G = WgGeo<S, TX, TY>;
+  constexpr int T = (WAVE + 24 < 27) ? 4 : 3;
+  unsigned vp = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)bp + 4u * (unsigned)(l32 + h * S * 32);
+  unsigned vq = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)bq + 4u * (unsigned)(h * 32 + l32);
+  WgFrag<T> A, B;
+  wgf_load<T, WAVE, G, 0>(A, vp, vq);
+#pragma unroll 1
+  for (int r = 0; r < TY * TZ; ++r) {
+    const bool lastrow = (r == TY * TZ - 1);
+    const int incp = lastrow ? 0 : (((r + 1) & (TY - 1)) == 0 ? G::PLANE_B : G::ROW_B);
+    const unsigned vpn = vp + (unsigned)incp, vqn = vq + (lastrow ? 0u : (unsigned)(G::JR * 256));
+    wgf_row<T, WAVE, G, 0>(A, B, acc, vp, vq, vpn, vqn);  // the last row's final prefetch re-reads its own start
+    vp = vpn; vq = vqn;
+  }
+  wait_lgkm<0>();
+}
+template <int S, int TX, int TY, int TZ>
+__device__ __forceinline__ void wgrad_sweep_fixed_dispatch(int wave, const float* bp, const float* bq, f32x16 (&acc)[WG_MAXT], int h,
+                                                           int l32) {
+  switch (wave) {
+    case 0: wgrad_sweep_fixed<0, S, TX, TY, TZ>(bp, bq, acc, h, l32); break;
+    case 1: wgrad_sweep_fixed<1, S, TX, TY, TZ>(bp, bq, acc, h, l32); break;
+    case 2: wgrad_sweep_fixed<2, S, TX, TY, TZ>(bp, bq, acc, h, l32); break;
+    case 3: wgrad_sweep_fixed<3, S, TX, TY, TZ>(bp, bq, acc, h, l32); break;
+    case 4: wgrad_sweep_fixed<4, S, TX, TY, TZ>(bp, bq, acc, h, l32); break;
+    case 5: wgrad_sweep_fixed<5, S, TX, TY, TZ>(bp, bq, acc, h, l32); break;
+    case 6: wgrad_sweep_fixed<6, S, TX, TY, TZ>(bp, bq, acc, h, l32); break;
+    default: wgrad_sweep_fixed<7, S, TX, TY, TZ>(bp, bq, acc, h, l32); break;
   }
 }
 
@@ -321,7 +401,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams 
     const float* bp = lds + cur * bufDw;
     const float* bq = bp + pRegion;
     const bool more = (sub + 1) < sub1;
-    if (more && p.dbg != 2) {
+    if (more && p.dbg < 2) {
       if constexpr (GLDS) fetch_glds(sub + 1, lds + (cur ^ 1) * bufDw);
       else fetch(sub + 1);
     }
@@ -333,19 +413,21 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams 
       bsum += (double)s;
     }
     const int st0 = ksplit ? wave : 0, stinc = ksplit ? WG_WAVES : 1;
-    if (p.dbg != 1) switch (ntw) {  // wave-uniform: number of row-tiles this wave owns -> branch-free MFMA bodies
+    if (p.fixg == 1 && p.dbg != 1) wgrad_sweep_fixed_dispatch<1, 16, 4, 2>(wave, bp, bq, acc, h, l32);
+    else if (p.fixg == 2 && p.dbg != 1) wgrad_sweep_fixed_dispatch<2, 8, 4, 1>(wave, bp, bq, acc, h, l32);
+    else if (p.dbg != 1) switch ((p.dbg == 4 && ntw > 3) ? 3 : ntw) {  // wave-uniform: number of row-tiles this wave owns -> branch-free MFMA bodies
       case 4: wgrad_steps<4>(p, bp, bq, rowoff, acc, st0, stinc, nsteps, h, l32); break;
       case 3: wgrad_steps<3>(p, bp, bq, rowoff, acc, st0, stinc, nsteps, h, l32); break;
       case 2: wgrad_steps<2>(p, bp, bq, rowoff, acc, st0, stinc, nsteps, h, l32); break;
       case 1: wgrad_steps<1>(p, bp, bq, rowoff, acc, st0, stinc, nsteps, h, l32); break;
       default: break;
     }
-    if (more && p.dbg != 2) {
+    if (more && p.dbg < 2) {
       if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else commit(lds + (cur ^ 1) * bufDw);
     }
-    __syncthreads();
-    if (p.dbg != 2) cur ^= 1;
+    if (p.dbg != 3) __syncthreads();
+    if (p.dbg < 2) cur ^= 1;
   }
 
   // ---- write partials ----
@@ -556,6 +638,11 @@ static int plan_wgrad(WgradPlan& pl, int ntaps, int s, int neg, int N, int Dp, i
       if (neg) { oz = -oz; oy = -oy; ox = -ox; }
       p.tap_vox[t] = ((oz - lo) * p.IY + (oy - lo)) * p.IX + (ox - lo);
     }
+  p.fixg = 0;
+  if (ntaps == 27 && cpad == 32 && !neg && getenv("BTS_WGRAD_NOFIX") == nullptr) {
+    if (s == 1 && TX == 16 && TY == 4 && TZ == 2) p.fixg = 1;
+    if (s == 2 && TX == 8 && TY == 4 && TZ == 1) p.fixg = 2;
+  }
   p.nsub = N * p.ntz * p.nty * p.ntx;
   pl.npct = (cpad == 32) ? (Cp + 31) / 32 : 1;
   pl.nqct = (Cq + 31) / 32;

@@ -41,6 +41,8 @@ def main():
                                                               'wgrad ms', 'TF'))
     for kind, d, cin, cout, label in SHAPES:
         x = torch.randn((1, d, d, d, cin), device=D)
+        if os.environ.get('BTS_BENCH_ZERO'):  # data-dependent power: all-zero operands let the clocks stay up
+            x.zero_()
         k = 1 if kind == 0 else 3
         w = torch.randn((k, k, k, cout, cin) if kind == 3 else (k, k, k, cin, cout), device=D) * 0.1
         b = torch.randn(cout, device=D)
@@ -48,6 +50,8 @@ def main():
         wpb = ops.conv_pack(kind, ops.ROLE_BWD, w, cin, cout)
         y = ops.conv_fwd(kind, x, wp, b, cout)
         dy = torch.randn_like(y)
+        if os.environ.get('BTS_BENCH_ZERO'):
+            dy.zero_()
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
         db = torch.empty_like(b)
