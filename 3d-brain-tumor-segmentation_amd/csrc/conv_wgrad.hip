@@ -42,6 +42,7 @@ struct WgradParams {
   int nsub, sub_per_wg;
   int want_bias;
   int fixg;  // 1/2: the sub-tile is the unclamped 16x4x2 (stride 1) / 8x4x1 (stride 2) 27-tap geometry -> fixed sweep
+  int fastf;  // fixed geometry AND whole tiles / whole 32-channel groups: per-lane staging offsets are precomputed once
   int dbg;  // profiling aid (BTS_WGRAD_DBG): 1 = skip the MFMA sweep, 2 = skip re-staging after the first sub-tile
   int tap_vox[27];  // voxel offset of each tap inside the P halo tile
 };
@@ -196,8 +197,11 @@ __device__ __forceinline__ void wgrad_sweep_fixed_dispatch(int wave, const float
 // the next sub-tile is fully asynchronous under the MFMA sweep).  The LDS image is lane-linear by construction (slot e
 // lives at byte 16*e), padding lanes read 16 zero bytes from p.zeros.  GLDS = false: register-staged fallback for
 // channel counts / strides that are not 16-byte granular.
-template <bool GLDS>
+// MODE 0: register staging, 1: LDS-DMA staging, 2: LDS-DMA staging with precomputed slot offsets (p.fastf).
+// FIXG 0: general sweep, 1/2: fixed-geometry sweep (p.fixg).  Separate kernels so each keeps its own register budget.
+template <int MODE, int FIXG>
 __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams p) {
+  constexpr bool GLDS = MODE >= 1, FAST = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -359,6 +363,87 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams 
                                          (__attribute__((address_space(3))) void*)(bqd + e0 * 4), 16, 0, 0);
       }
     }
+  };
+  // Fast staging (p.fastf): slot -> (voxel, channel quad) never changes, so the byte offset of every slot relative to
+  // the tile origin and its halo-face membership are computed ONCE; per sub-tile an interior tile costs one
+  // global_load_lds (scalar base + 32-bit lane offset) per slot and nothing else -- next to the matrix pipe every
+  // issued instruction costs ~4 cycles of SIMD time.  Face slots of boundary tiles are zero-filled with ds_write.
+  unsigned relP[WG_PSLOTS], relQ[WG_QSLOTS], faceP[2] = {0u, 0u};
+  if constexpr (FAST) {
+#pragma unroll
+    for (int i = 0; i < WG_PSLOTS; ++i) {
+      const int e = wave * 64 + lane + i * WG_THREADS;
+      int vz = -p.loz, vy = -p.loy, vx = -p.lox, qd = 0;  // padding lanes re-read an always-valid voxel (never consumed)
+      unsigned face = 0;
+      if (e < nPslots) {
+        const int vox = e >> 3;
+        qd = e & 7;
+        vz = fast_div(vox, invIYX);
+        const int r = vox - vz * IYX;
+        vy = fast_div(r, invIX);
+        vx = r - vy * p.IX;
+        face = (vz == 0 ? 1u : 0u) | (vz == p.IZ - 1 ? 2u : 0u) | (vy == 0 ? 4u : 0u) | (vy == p.IY - 1 ? 8u : 0u) |
+               (vx == 0 ? 16u : 0u) | (vx == p.IX - 1 ? 32u : 0u);
+      }
+      relP[i] = (unsigned)((((vz * p.Hp + vy) * p.Wp + vx) * p.ldp + pc0 + qd * 4) * 4);
+      faceP[i >> 2] |= face << (8 * (i & 3));
+    }
+#pragma unroll
+    for (int i = 0; i < WG_QSLOTS; ++i) {
+      const int e = wave * 64 + lane + i * WG_THREADS;
+      int mz = 0, my = 0, mx = 0, qd = 0;
+      if (e < nQslots) {
+        const int m = e >> 3;
+        qd = e & 7;
+        mz = m >> (p.lgTX + p.lgTY); my = (m >> p.lgTX) & (TY - 1); mx = m & (TX - 1);
+      }
+      relQ[i] = (unsigned)((((mz * p.Hq + my) * p.Wq + mx) * p.ldq + qct * 32 + qd * 4) * 4);
+    }
+  }
+  // per-sub-tile staging state (wave-uniform), set by fast_prep and consumed by the per-slot issue functions
+  const char* f_pbase = nullptr;
+  const char* f_qbase = nullptr;
+  unsigned f_tmask = 0;
+  float* f_buf = nullptr;
+  auto fast_prep = [&](int sub, float* buf) {
+    int b = sub;
+    const int tx = b % p.ntx; b /= p.ntx;
+    const int ty = b % p.nty; b /= p.nty;
+    const int tz = b % p.ntz;
+    const int n = b / p.ntz;
+    const int oz0 = tz * p.TZ, oy0 = ty * TY, ox0 = tx * TX;
+    const int iz0 = oz0 * p.s + p.loz, iy0 = oy0 * p.s + p.loy, ix0 = ox0 * p.s + p.lox;
+    f_pbase = reinterpret_cast<const char*>(p.p + ((((long)n * p.Dp + iz0) * p.Hp + iy0) * p.Wp + ix0) * (long)p.ldp);
+    f_qbase = reinterpret_cast<const char*>(p.q + ((((long)n * p.Dq + oz0) * p.Hq + oy0) * p.Wq + ox0) * (long)p.ldq);
+    // faces of the halo tile that lie outside the image (stride 1: one-voxel halo on both sides; stride 2: high side only)
+    const unsigned lowf = p.loz < 0 ? 1u : 0u;
+    f_tmask = ((tz == 0) ? lowf : 0u) | ((tz == p.ntz - 1) ? 2u : 0u) | ((ty == 0) ? 4u * lowf : 0u) |
+              ((ty == p.nty - 1) ? 8u : 0u) | ((tx == 0) ? 16u * lowf : 0u) | ((tx == p.ntx - 1) ? 32u : 0u);
+    f_buf = buf;
+  };
+  auto fast_slot_p = [&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    const int e0 = wave * 64 + i * WG_THREADS;
+    if (e0 * 4 < pRegion) {
+      if (f_tmask == 0 || ((faceP[i >> 2] >> (8 * (i & 3))) & f_tmask) == 0)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(f_pbase + relP[i]),
+                                         (__attribute__((address_space(3))) void*)(f_buf + e0 * 4), 16, 0, 0);
+      else
+        *reinterpret_cast<f32x4*>(f_buf + (e0 + lane) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto fast_slot_q = [&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    const int e0 = wave * 64 + i * WG_THREADS;
+    if (e0 * 4 < qRegion)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(f_qbase + relQ[i]),
+                                       (__attribute__((address_space(3))) void*)(f_buf + pRegion + e0 * 4), 16, 0, 0);
+  };
+  auto fetch_fast = [&](int sub, float* buf) {  // everything at once (prologue only)
+    fast_prep(sub, buf);
+    fast_slot_p(IC<0>{}); fast_slot_p(IC<1>{}); fast_slot_p(IC<2>{}); fast_slot_p(IC<3>{});
+    fast_slot_p(IC<4>{}); fast_slot_p(IC<5>{}); fast_slot_p(IC<6>{}); fast_slot_p(IC<7>{});
+    fast_slot_q(IC<0>{}); fast_slot_q(IC<1>{}); fast_slot_q(IC<2>{}); fast_slot_q(IC<3>{});
   };
   auto commit = [&](float* buf) {
 #pragma unroll
@@ -643,6 +728,11 @@ static int plan_wgrad(WgradPlan& pl, int ntaps, int s, int neg, int N, int Dp, i
     if (s == 1 && TX == 16 && TY == 4 && TZ == 2) p.fixg = 1;
     if (s == 2 && TX == 8 && TY == 4 && TZ == 1) p.fixg = 2;
   }
+  p.fastf = 0;
+  if (p.fixg && Wq % TX == 0 && Hq % TY == 0 && Dq % TZ == 0 && Cp % 32 == 0 && Cq % 32 == 0 &&
+      getenv("BTS_WGRAD_NOFASTF") == nullptr)
+    p.fastf = 1;  // (the 32-bit staging offsets are range-checked where the leading dimensions are known)
+  if (!p.fastf) p.fixg = 0;  // the fixed sweep only ships together with the fast staging
   p.nsub = N * p.ntz * p.nty * p.ntx;
   pl.npct = (cpad == 32) ? (Cp + 31) / 32 : 1;
   pl.nqct = (Cq + 31) / 32;
@@ -717,12 +807,14 @@ extern "C" int bts_conv3d_bwd_weight(int kind, const float* x, const float* dy, 
   // bias gradient = column sums of dy: dy is Q in the plain form only
   p.want_bias = (db != nullptr && !pIsDy) ? 1 : 0;
   { const char* e = getenv("BTS_WGRAD_DBG"); p.dbg = e ? atoi(e) : 0; }
+  typedef void (*WgKernel)(const WgradParams);
+  static const WgKernel kernels[4] = {wgrad_kernel<0, 0>, wgrad_kernel<1, 0>, wgrad_kernel<2, 1>, wgrad_kernel<2, 2>};
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
+    for (int i = 0; i < 4; ++i) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[i]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+    }
     attr_done = true;
   }
   // 64 zero bytes at the tail of the workspace feed the padding lanes of the LDS-DMA staging
@@ -730,17 +822,17 @@ extern "C" int bts_conv3d_bwd_weight(int kind, const float* x, const float* dy, 
   p.zeros = reinterpret_cast<const float*>(ztail);
   const bool glds = (p.ldp % 4 == 0) && (p.Cp % 4 == 0) && ((((uintptr_t)p.p) & 15) == 0) && (p.ldq % 4 == 0) &&
                     (p.Cq % 4 == 0) && ((((uintptr_t)p.q) & 15) == 0) && getenv("BTS_WGRAD_NOGLDS") == nullptr;
+  if (p.fastf && ((double)p.IZ * p.Hp * p.Wp * p.ldp * 4.0 >= 4.0e9 || (double)p.TZ * p.Hq * p.Wq * p.ldq * 4.0 >= 4.0e9 || !glds))
+    p.fastf = p.fixg = 0;
   const bool prof = bts_prof_on();
   if (glds) {
     hipError_t e = hipMemsetAsync(ztail, 0, 64, stream);
     if (e != hipSuccess) return (int)e;
   }
-  if (prof) bts_prof_begin(glds ? 100 : 101, 2.0 * ro.ntaps * (double)ro.Cp * ro.Cq * (double)N * ro.Dq * ro.Hq * ro.Wq, stream);
-  if (glds) {
-    (void)hipGetLastError(); hipLaunchKernelGGL(wgrad_kernel<true>, dim3(pl.nsp, pl.npct, pl.nqct), dim3(WG_THREADS), pl.shmem, stream, p);
-  } else {
-    (void)hipGetLastError(); hipLaunchKernelGGL(wgrad_kernel<false>, dim3(pl.nsp, pl.npct, pl.nqct), dim3(WG_THREADS), pl.shmem, stream, p);
-  }
+  const int kidx = !glds ? 0 : (p.fastf ? 1 + p.fixg : 1);
+  static const int ksym[4] = {100, 104, 109, 110};  // 100 + (MODE << 2 | FIXG)
+  if (prof) bts_prof_begin(ksym[kidx], 2.0 * ro.ntaps * (double)ro.Cp * ro.Cq * (double)N * ro.Dq * ro.Hq * ro.Wq, stream);
+  (void)hipGetLastError(); hipLaunchKernelGGL(kernels[kidx], dim3(pl.nsp, pl.npct, pl.nqct), dim3(WG_THREADS), pl.shmem, stream, p);
   if (prof) bts_prof_end(stream);
   BTS_LAUNCH_CHECK();
   WfinParams f;
