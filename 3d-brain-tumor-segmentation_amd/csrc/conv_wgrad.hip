@@ -13,6 +13,7 @@
 // one is multiplied (double-buffered LDS, one barrier per sub-tile).  Per-workgroup partials go to a workspace and are
 // combined in a fixed order by the finalize kernel (bitwise reproducible; no float atomics).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "bts_internal.h"
 
@@ -43,7 +44,7 @@ struct WgradParams {
   int want_bias;
   int fixg;  // 1/2: the sub-tile is the unclamped 16x4x2 (stride 1) / 8x4x1 (stride 2) 27-tap geometry -> fixed sweep
   int fastf;  // fixed geometry AND whole tiles / whole 32-channel groups: per-lane staging offsets are precomputed once
-  int dbg;  // profiling aid (BTS_WGRAD_DBG): 1 = skip the MFMA sweep, 2 = skip re-staging after the first sub-tile
+  int dbg;  // profiling aid (BTS_WGRAD_DBG), see the sub-tile loop
   int tap_vox[27];  // voxel offset of each tap inside the P halo tile
 };
 
@@ -119,78 +120,59 @@ __device__ __forceinline__ void wgrad_steps(const WgradParams& p, const float* b
 // ---- fixed-geometry sweep (3x3x3 taps, 32-channel P voxels, unclamped sub-tile) ---------------------------------------
 // Measured cost model (scripts/ubench/wgrad_sweep.hip): next to the matrix pipe EVERY issued instruction costs ~4 cycles
 // of SIMD time, scalar ones included, so the general step above (13 SALU + 6 VALU + T+1 LDS reads per T MFMAs) tops out
-// at ~105 TFLOP/s.  Here the sub-tile geometry and the wave's tap set are template parameters: all tap / voxel offsets
-// become DS immediates off two per-row base registers and a step is T+1 ds_read_b32 + T MFMAs and nothing else.
-template <int S, int TX, int TY>
+// at ~105 TFLOP/s.  Here the sub-tile geometry is a template parameter and the whole sub-tile is one straight-line
+// sequence: every voxel offset is a DS immediate off T+1 per-wave base registers (tile base + tap offset of row-tile i),
+// a step is T+1 ds_read_b32 + T MFMAs and nothing else.  The staging of the NEXT sub-tile is not issued up front by all
+// waves at once but handed in as `stage(IC<K>)`, a few instructions at a time in the MFMA shadow of chosen steps.
+template <int I>
+struct IC { static constexpr int value = I; };
+template <int S, int TX, int TY, int TZ>
 struct WgGeo {
   static constexpr int IX = (TX - 1) * S + 3, IY = (TY - 1) * S + 3;
-  static constexpr int JR = TX / 2;                         // voxel-pair steps per x-row
-  static constexpr int STEP_B = 2 * S * 128;                // P bytes per step (two voxels, 128 B each, stride S)
-  static constexpr int ROW_B = S * IX * 128;                // next y-row
-  static constexpr int PLANE_B = S * IY * IX * 128 - (TY - 1) * ROW_B;  // from the last row of a plane to the next plane
-  static constexpr int tap_b(int t) { return (((t / 9) * IY + (t / 3) % 3) * IX + t % 3) * 128; }
+  static constexpr int JR = TX / 2;       // voxel-pair steps per x-row
+  static constexpr int NS = JR * TY * TZ;  // steps per sub-tile
+  // P byte offset (before the tap offset) of the first voxel of step K; Q is simply [m][32]
+  static constexpr int p_b(int K) {
+    const int r = K / JR, j = K % JR, z = r / TY, y = r % TY;
+    return ((z * S * IY + y * S) * IX + 2 * j * S) * 128;
+  }
 };
-template <int T, int WAVE, typename G, int J>
-__device__ __forceinline__ void wgf_load(WgFrag<T>& f, unsigned vp, unsigned vq) {
-  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.q) : "v"(vq), "n"(J * 256));
-  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.a[0]) : "v"(vp), "n"(G::tap_b(WAVE) + J * G::STEP_B));
-  if constexpr (T > 1) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.a[1]) : "v"(vp), "n"(G::tap_b(WAVE + 8) + J * G::STEP_B));
-  if constexpr (T > 2) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.a[2]) : "v"(vp), "n"(G::tap_b(WAVE + 16) + J * G::STEP_B));
-  if constexpr (T > 3) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.a[3]) : "v"(vp), "n"(G::tap_b(WAVE + 24) + J * G::STEP_B));
+template <int T, typename G, int K>
+__device__ __forceinline__ void wgx_load(WgFrag<T>& f, const unsigned (&vp)[WG_MAXT], unsigned vq) {
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.q) : "v"(vq), "n"(K * 256));
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.a[0]) : "v"(vp[0]), "n"(G::p_b(K)));
+  if constexpr (T > 1) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.a[1]) : "v"(vp[1]), "n"(G::p_b(K)));
+  if constexpr (T > 2) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.a[2]) : "v"(vp[2]), "n"(G::p_b(K)));
+  if constexpr (T > 3) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.a[3]) : "v"(vp[3]), "n"(G::p_b(K)));
   __builtin_amdgcn_sched_barrier(0);
 }
-template <int T, int WAVE, typename G, int J>
-__device__ __forceinline__ void wgf_step(const WgFrag<T>& cur, WgFrag<T>& nxt, f32x16 (&acc)[WG_MAXT], unsigned vp, unsigned vq,
-                                         unsigned vpn, unsigned vqn) {
-  wait_lgkm<0>();
+// Three rotating fragments: the reads of step K+2 are issued in step K, so a fragment has two full MFMA bursts to land.
+// lgkmcnt(T+1): LDS operations retire in order, so at most the T+1 youngest (fragment K+1) are still in flight.
+template <int T, typename G, int K, typename F>
+__device__ __forceinline__ void wgx_steps(WgFrag<T>& f0, WgFrag<T>& f1, WgFrag<T>& f2, f32x16 (&acc)[WG_MAXT],
+                                          const unsigned (&vp)[WG_MAXT], unsigned vq, F& stage) {
+  if constexpr (K + 1 < G::NS) wait_lgkm<T + 1>();
+  else wait_lgkm<0>();
   __builtin_amdgcn_s_setprio(1);
-  acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[0], cur.q, acc[0], 0, 0, 0);
+  acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0.a[0], f0.q, acc[0], 0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (J + 1 < G::JR) wgf_load<T, WAVE, G, J + 1>(nxt, vp, vq);
-  else wgf_load<T, WAVE, G, 0>(nxt, vpn, vqn);
+  if constexpr (K + 2 < G::NS) wgx_load<T, G, K + 2>(f2, vp, vq);
+  stage(IC<K>{});
+  if constexpr (K + 2 >= G::NS && K + 1 < G::NS) wait_lgkm<T + 1>();  // staging writes issued here must not hide fragment K+1
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int i = 1; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[i], cur.q, acc[i], 0, 0, 0);
+  for (int i = 1; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0.a[i], f0.q, acc[i], 0, 0, 0);
   __builtin_amdgcn_s_setprio(0);
   __builtin_amdgcn_sched_barrier(0);
+  if constexpr (K + 1 < G::NS) wgx_steps<T, G, K + 1>(f1, f2, f0, acc, vp, vq, stage);
 }
-template <int T, int WAVE, typename G, int J>
-__device__ __forceinline__ void wgf_row(WgFrag<T>& A, WgFrag<T>& B, f32x16 (&acc)[WG_MAXT], unsigned vp, unsigned vq, unsigned vpn,
-                                        unsigned vqn) {
-  wgf_step<T, WAVE, G, J>(A, B, acc, vp, vq, vpn, vqn);
-  wgf_step<T, WAVE, G, J + 1>(B, A, acc, vp, vq, vpn, vqn);
-  if constexpr (J + 2 < G::JR) wgf_row<T, WAVE, G, J + 2>(A, B, acc, vp, vq, vpn, vqn);
-}
-template <int WAVE, int S, int TX, int TY, int TZ>
-__device__ __forceinline__ void wgrad_sweep_fixed(const float* bp, const float* bq, f32x16 (&acc)[WG_MAXT], int h, int l32) {
-  using G = WgGeo<S, TX, TY>;
-  constexpr int T = (WAVE + 24 < 27) ? 4 : 3;
-  unsigned vp = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)bp + 4u * (unsigned)(l32 + h * S * 32);
-  unsigned vq = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)bq + 4u * (unsigned)(h * 32 + l32);
-  WgFrag<T> A, B;
-  wgf_load<T, WAVE, G, 0>(A, vp, vq);
-#pragma unroll 1
-  for (int r = 0; r < TY * TZ; ++r) {
-    const bool lastrow = (r == TY * TZ - 1);
-    const int incp = lastrow ? 0 : (((r + 1) & (TY - 1)) == 0 ? G::PLANE_B : G::ROW_B);
-    const unsigned vpn = vp + (unsigned)incp, vqn = vq + (lastrow ? 0u : (unsigned)(G::JR * 256));
-    wgf_row<T, WAVE, G, 0>(A, B, acc, vp, vq, vpn, vqn);  // the last row's final prefetch re-reads its own start
-    vp = vpn; vq = vqn;
-  }
+template <int T, typename G, typename F>
+__device__ __forceinline__ void wgrad_sweep_fixed(const unsigned (&vp)[WG_MAXT], unsigned vq, f32x16 (&acc)[WG_MAXT], F& stage) {
+  WgFrag<T> A, B, C;
+  wgx_load<T, G, 0>(A, vp, vq);
+  wgx_load<T, G, 1>(B, vp, vq);
+  wgx_steps<T, G, 0>(A, B, C, acc, vp, vq, stage);
   wait_lgkm<0>();
-}
-template <int S, int TX, int TY, int TZ>
-__device__ __forceinline__ void wgrad_sweep_fixed_dispatch(int wave, const float* bp, const float* bq, f32x16 (&acc)[WG_MAXT], int h,
-                                                           int l32) {
-  switch (wave) {
-    case 0: wgrad_sweep_fixed<0, S, TX, TY, TZ>(bp, bq, acc, h, l32); break;
-    case 1: wgrad_sweep_fixed<1, S, TX, TY, TZ>(bp, bq, acc, h, l32); break;
-    case 2: wgrad_sweep_fixed<2, S, TX, TY, TZ>(bp, bq, acc, h, l32); break;
-    case 3: wgrad_sweep_fixed<3, S, TX, TY, TZ>(bp, bq, acc, h, l32); break;
-    case 4: wgrad_sweep_fixed<4, S, TX, TY, TZ>(bp, bq, acc, h, l32); break;
-    case 5: wgrad_sweep_fixed<5, S, TX, TY, TZ>(bp, bq, acc, h, l32); break;
-    case 6: wgrad_sweep_fixed<6, S, TX, TY, TZ>(bp, bq, acc, h, l32); break;
-    default: wgrad_sweep_fixed<7, S, TX, TY, TZ>(bp, bq, acc, h, l32); break;
-  }
 }
 
 // GLDS = true: tiles are staged with direct global->LDS DMA (global_load_lds_dwordx4: no staging registers, the copy of
@@ -473,7 +455,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams 
 
   if (sub0 < sub1) {
     if constexpr (GLDS) {
-      fetch_glds(sub0, lds);
+      if constexpr (FAST) fetch_fast(sub0, lds);
+      else fetch_glds(sub0, lds);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
       fetch(sub0);
@@ -486,9 +469,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams 
     const float* bp = lds + cur * bufDw;
     const float* bq = bp + pRegion;
     const bool more = (sub + 1) < sub1;
-    if (more && p.dbg < 2) {
-      if constexpr (GLDS) fetch_glds(sub + 1, lds + (cur ^ 1) * bufDw);
-      else fetch(sub + 1);
+    // BTS_WGRAD_DBG (timing only, results are wrong): 1 skip the sweep, 2 no re-staging, 3 = 2 + no barriers,
+    // 4 = 2 + at most 3 row-tiles per wave, 5 stage but keep reading buffer 0, 7 = always stage the first sub-tile
+    const bool dofetch = more && (p.dbg < 2 || p.dbg >= 5);
+    if constexpr (FIXG == 0) {
+      if (dofetch) {
+        if constexpr (GLDS) fetch_glds(sub + 1, lds + (cur ^ 1) * bufDw);
+        else fetch(sub + 1);
+      }
     }
 
     if (p.want_bias && pct == 0) {
@@ -497,17 +485,44 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams 
       for (int m = part; m < M; m += 16) s += bq[m * 32 + c];
       bsum += (double)s;
     }
-    const int st0 = ksplit ? wave : 0, stinc = ksplit ? WG_WAVES : 1;
-    if (p.fixg == 1 && p.dbg != 1) wgrad_sweep_fixed_dispatch<1, 16, 4, 2>(wave, bp, bq, acc, h, l32);
-    else if (p.fixg == 2 && p.dbg != 1) wgrad_sweep_fixed_dispatch<2, 8, 4, 1>(wave, bp, bq, acc, h, l32);
-    else if (p.dbg != 1) switch ((p.dbg == 4 && ntw > 3) ? 3 : ntw) {  // wave-uniform: number of row-tiles this wave owns -> branch-free MFMA bodies
-      case 4: wgrad_steps<4>(p, bp, bq, rowoff, acc, st0, stinc, nsteps, h, l32); break;
-      case 3: wgrad_steps<3>(p, bp, bq, rowoff, acc, st0, stinc, nsteps, h, l32); break;
-      case 2: wgrad_steps<2>(p, bp, bq, rowoff, acc, st0, stinc, nsteps, h, l32); break;
-      case 1: wgrad_steps<1>(p, bp, bq, rowoff, acc, st0, stinc, nsteps, h, l32); break;
-      default: break;
+    if constexpr (FIXG != 0) {
+      using G = typename std::conditional<FIXG == 1, WgGeo<1, 16, 4, 2>, WgGeo<2, 8, 4, 1>>::type;
+      // staging schedule: tile decode at step 0, then one slot every few steps (8 P + 4 Q slots per wave at most)
+      constexpr int P0 = 1, PD = (G::NS >= 64) ? 5 : 1, Q0 = P0 + 8 * PD, QD = (G::NS >= 64) ? 5 : 1;
+      static_assert(Q0 + 3 * QD < G::NS, "staging schedule does not fit the sub-tile");
+      auto stage = [&](auto kc) {
+        constexpr int K = decltype(kc)::value;
+        if constexpr (K == 0) {
+          if (dofetch) fast_prep(p.dbg == 7 ? sub0 : sub + 1, lds + (cur ^ 1) * bufDw);
+        } else if constexpr (K >= P0 && K < Q0 && (K - P0) % PD == 0) {
+          if (dofetch) fast_slot_p(IC<(K - P0) / PD>{});
+        } else if constexpr (K >= Q0 && K <= Q0 + 3 * QD && (K - Q0) % QD == 0) {
+          if (dofetch) fast_slot_q(IC<(K - Q0) / QD>{});
+        }
+      };
+      const unsigned bpb = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)bp;
+      const unsigned vq = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)bq + 4u * (unsigned)(h * 32 + l32);
+      unsigned vp[WG_MAXT];
+#pragma unroll
+      for (int i = 0; i < WG_MAXT; ++i) vp[i] = bpb + 4u * (unsigned)(rowoff[i] + ((h * p.s) << 5));
+      if (p.dbg == 1) {
+        if (dofetch) fetch_fast(sub + 1, lds + (cur ^ 1) * bufDw);
+      } else if (ntw == 4 && p.dbg != 4) {
+        wgrad_sweep_fixed<4, G>(vp, vq, acc, stage);
+      } else {
+        wgrad_sweep_fixed<3, G>(vp, vq, acc, stage);
+      }
+    } else {
+      const int st0 = ksplit ? wave : 0, stinc = ksplit ? WG_WAVES : 1;
+      if (p.dbg != 1) switch ((p.dbg == 4 && ntw > 3) ? 3 : ntw) {  // wave-uniform: row-tiles this wave owns -> branch-free MFMA bodies
+        case 4: wgrad_steps<4>(p, bp, bq, rowoff, acc, st0, stinc, nsteps, h, l32); break;
+        case 3: wgrad_steps<3>(p, bp, bq, rowoff, acc, st0, stinc, nsteps, h, l32); break;
+        case 2: wgrad_steps<2>(p, bp, bq, rowoff, acc, st0, stinc, nsteps, h, l32); break;
+        case 1: wgrad_steps<1>(p, bp, bq, rowoff, acc, st0, stinc, nsteps, h, l32); break;
+        default: break;
+      }
     }
-    if (more && p.dbg < 2) {
+    if (dofetch) {
       if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else commit(lds + (cur ^ 1) * bufDw);
     }
