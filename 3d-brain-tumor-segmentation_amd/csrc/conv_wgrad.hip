@@ -586,13 +586,15 @@ struct WfinParams {
   int accum;
 };
 
-// dW[t][pc][qc] (+)= sum_wg partial. 256 threads = 32 consecutive qc x 8 partial-lanes, fixed-order combine.
+// dW[t][pc][qc] (+)= sum_wg partial.  One block per row (32 consecutive qc of one (t, pc, qct)): 256 threads = 8 float4
+// columns x 32 partial-lanes, every lane streams its share of the nsp partials (4 independent 16-byte loads in flight),
+// fp64 accumulate, fixed-order combine through LDS (bitwise reproducible).  The pass is pure HBM streaming.
 // Folded slab channel c maps to reference channel c+shift and, if c >= dup_start, also to c-dup_start (both copies of
 // the duplicated slice see the same input: encoder.py:83-87).
 __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const WfinParams f) {
-  __shared__ double sh[8][33];
-  const int e = threadIdx.x & 31, wl = threadIdx.x >> 5;
-  const long rows = (long)f.ntaps * f.Cp * f.nqct;  // one row = 32 consecutive qc of one (t, pc, qct)
+  __shared__ double sh[32][33];
+  const int q4 = threadIdx.x & 7, wl = threadIdx.x >> 3;
+  const long rows = (long)f.ntaps * f.Cp * f.nqct;
   const long wgStride = (long)f.npct * f.nqct * f.ntiles * 1024;
   for (long row = blockIdx.x; row < rows; row += gridDim.x) {
     const int qct = (int)(row % f.nqct);
@@ -600,20 +602,36 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const WfinParams f)
     const int pc = (int)(r % f.Cp);
     const int t = (int)(r / f.Cp);
     long off;
-    if (f.cpad == 32) off = ((((long)(pc >> 5)) * f.nqct + qct) * f.ntiles + t) * 1024 + (pc & 31) * 32 + e;
+    if (f.cpad == 32) off = ((((long)(pc >> 5)) * f.nqct + qct) * f.ntiles + t) * 1024 + (pc & 31) * 32;
     else {
       const int ci = t * f.cpad + pc;
-      off = ((long)qct * f.ntiles + (ci >> 5)) * 1024 + (ci & 31) * 32 + e;
+      off = ((long)qct * f.ntiles + (ci >> 5)) * 1024 + (ci & 31) * 32;
     }
-    double s = 0.0;  // fp64 combine of the per-workgroup fp32 partials (free: this pass is bandwidth-bound)
-    for (int w = wl; w < f.nsp; w += 8) s += (double)f.partial[w * wgStride + off];
+    const float* src = f.partial + off + q4 * 4;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // fp64 combine of the per-workgroup fp32 partials
+    int w = wl;
+    for (; w + 96 < f.nsp; w += 128) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src + (long)w * wgStride);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(src + (long)(w + 32) * wgStride);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(src + (long)(w + 64) * wgStride);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(src + (long)(w + 96) * wgStride);
+      s0 += (double)a[0]; s1 += (double)a[1]; s2 += (double)a[2]; s3 += (double)a[3];
+      s0 += (double)b[0]; s1 += (double)b[1]; s2 += (double)b[2]; s3 += (double)b[3];
+      s0 += (double)c[0]; s1 += (double)c[1]; s2 += (double)c[2]; s3 += (double)c[3];
+      s0 += (double)d[0]; s1 += (double)d[1]; s2 += (double)d[2]; s3 += (double)d[3];
+    }
+    for (; w < f.nsp; w += 32) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src + (long)w * wgStride);
+      s0 += (double)a[0]; s1 += (double)a[1]; s2 += (double)a[2]; s3 += (double)a[3];
+    }
     __syncthreads();
-    sh[wl][e] = s;
+    sh[wl][q4 * 4 + 0] = s0; sh[wl][q4 * 4 + 1] = s1; sh[wl][q4 * 4 + 2] = s2; sh[wl][q4 * 4 + 3] = s3;
     __syncthreads();
-    if (wl == 0) {
+    if (threadIdx.x < 32) {
+      const int e = threadIdx.x;
       double totd = sh[0][e];
 #pragma unroll
-      for (int k = 1; k < 8; ++k) totd += sh[k][e];
+      for (int k = 1; k < 32; ++k) totd += sh[k][e];
       const float tot = (float)totd;
       const int qc = qct * 32 + e;
       if (qc < f.Cq) {
@@ -633,11 +651,20 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const WfinParams f)
       }
     }
   }
-  if (f.db && blockIdx.x == 0) {
-    for (int i = threadIdx.x; i < f.Cq; i += blockDim.x) {
-      double s = 0.0;
-      for (int w = 0; w < f.nsp; ++w) s += f.partial_b[((long)w * f.nqct + (i >> 5)) * 32 + (i & 31)];
-      f.db[i] = f.accum ? (f.db[i] + (float)s) : (float)s;
+  // bias: block qct combines the per-workgroup fp64 column sums of its 32 channels (32 channels x 8 partial-lanes)
+  if (f.db && (int)blockIdx.x < f.nqct) {
+    const int e = threadIdx.x & 31, l8 = threadIdx.x >> 5, qct = blockIdx.x;
+    double s = 0.0;
+    for (int w = l8; w < f.nsp; w += 8) s += f.partial_b[((long)w * f.nqct + qct) * 32 + e];
+    __syncthreads();
+    sh[l8][e] = s;
+    __syncthreads();
+    if (l8 == 0 && qct * 32 + e < f.Cq) {
+      double tot = sh[0][e];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) tot += sh[k][e];
+      const int i = qct * 32 + e;
+      f.db[i] = f.accum ? (f.db[i] + (float)tot) : (float)tot;
     }
   }
 }
