@@ -31,10 +31,17 @@ def rank():
     return 0
 
 
+def active():
+    """a process group exists: the exchanges C1-C3 run (also on a 1-rank group, which is how the RCCL path is smoke-tested
+    on a single-GPU box: BTS_FORCE_PG=1)"""
+    d = torch.distributed
+    return d.is_available() and d.is_initialized()
+
+
 def init_from_env(backend=None):
     """torchrun-style bring-up: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT"""
     ws = int(os.environ.get('WORLD_SIZE', '1'))
-    if ws <= 1 or torch.distributed.is_initialized():
+    if (ws <= 1 and not os.environ.get('BTS_FORCE_PG')) or torch.distributed.is_initialized():
         return
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if torch.cuda.is_available():
@@ -43,12 +50,13 @@ def init_from_env(backend=None):
     else:
         backend = backend or 'gloo'
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    torch.distributed.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=ws)
+    os.environ.setdefault('MASTER_PORT', '29533')
+    torch.distributed.init_process_group(backend=backend, rank=int(os.environ.get('RANK', '0')), world_size=ws)
 
 
 def all_reduce_sum(t):
     """in-place sum over ranks (C3); no-op on one rank"""
-    if world() > 1:
+    if active():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
     return t
 
@@ -60,7 +68,7 @@ def bucket_ranges(n, elem_bytes=4, bucket_bytes=BUCKET_BYTES):
 
 def all_reduce_flat(flat, bucket_bytes=BUCKET_BYTES):
     """bucketed in-place sum of a flat buffer (C1)"""
-    if world() <= 1:
+    if not active():
         return flat
     handles = []
     for off, ln in bucket_ranges(flat.numel(), flat.element_size(), bucket_bytes):
@@ -77,14 +85,14 @@ def l2_grad_scale():
 
 def all_reduce_gradients(model):
     """C1 on the model's flat gradient buffer. Returns the scale the optimiser must apply to the summed gradient."""
-    if world() > 1:
+    if active():
         all_reduce_flat(model.flat_grads)
     return 1.0
 
 
 def broadcast_parameters(model, src=0):
     """C2"""
-    if world() > 1:
+    if active():
         torch.distributed.broadcast(model.flat_params, src=src)
         from .tape import bump_weights_epoch
         bump_weights_epoch()

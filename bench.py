@@ -118,7 +118,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or os.environ.get('BTS_FORCE_PG'):   # BTS_FORCE_PG=1: 1-rank RCCL group, smoke-tests the N>1 code path
         parallel.init_from_env('nccl')
     dev = torch.device('cuda', local)
 
@@ -137,7 +137,7 @@ def main():
     for _ in range(args.warmup):
         loss, macro, micro = train_step(model, opt, loss_fn, dice_fn, x, y)
     torch.cuda.synchronize()
-    if world > 1:
+    if parallel.active():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     do_prof = (not args.no_profile)
@@ -147,11 +147,11 @@ def main():
     for _ in range(args.steps):
         loss, macro, micro = train_step(model, opt, loss_fn, dice_fn, x, y)
     torch.cuda.synchronize()
-    if world > 1:
+    if parallel.active():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if parallel.active():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
@@ -161,6 +161,8 @@ def main():
         prof = ops.profile_records()
 
     if rank != 0:
+        if parallel.active():
+            torch.distributed.destroy_process_group()
         return
     volumes = world * nb * args.steps
     out = {
@@ -195,7 +197,9 @@ def main():
                                        'launches_per_step': v[2] / args.steps} for k, v in sorted(agg.items())}
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    if parallel.active():
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':
