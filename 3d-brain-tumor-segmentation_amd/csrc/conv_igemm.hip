@@ -445,33 +445,59 @@ struct PackParams {
   int shift, dup_start;
 };
 
+__device__ __forceinline__ float pack_elem(const PackParams& q, long i) {
+  const int j = (int)(i & 3);
+  long r = i >> 2;
+  const int n = (int)(r % q.Npad); r /= q.Npad;
+  const int hh = (int)(r & 1); r >>= 1;
+  const int kg = (int)(r % q.KG);
+  const int t = (int)(r / q.KG);
+  const int k = kg * 8 + hh * 4 + j;
+  float v = 0.f;
+  if (k < q.K && n < q.N) {
+    const int ts = q.flip ? (q.ntaps - 1 - t) : t;
+    int kk = k, nn = n, k2 = -1, n2 = -1;
+    if (q.cin_is_k == 1) {
+      if (k >= q.dup_start) k2 = k - q.dup_start;
+      kk = k + q.shift;
+      n2 = n;
+    } else if (q.cin_is_k == 0) {
+      if (n >= q.dup_start) n2 = n - q.dup_start;
+      nn = n + q.shift;
+      k2 = k;
+    }
+    v = q.w[ts * q.sT + kk * q.sK + nn * q.sN];
+    if (q.shift > 0 && k2 >= 0 && n2 >= 0) v += q.w[ts * q.sT + k2 * q.sK + n2 * q.sN];
+  }
+  return v;
+}
+
 __global__ void pack_kernel(const PackParams q) {
   const long total = (long)q.ntaps * q.KG * 2 * q.Npad * 4;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int j = (int)(i & 3);
-    long r = i >> 2;
-    const int n = (int)(r % q.Npad); r /= q.Npad;
-    const int hh = (int)(r & 1); r >>= 1;
-    const int kg = (int)(r % q.KG);
-    const int t = (int)(r / q.KG);
-    const int k = kg * 8 + hh * 4 + j;
-    float v = 0.f;
-    if (k < q.K && n < q.N) {
-      const int ts = q.flip ? (q.ntaps - 1 - t) : t;
-      int kk = k, nn = n, k2 = -1, n2 = -1;
-      if (q.cin_is_k == 1) {
-        if (k >= q.dup_start) k2 = k - q.dup_start;
-        kk = k + q.shift;
-        n2 = n;
-      } else if (q.cin_is_k == 0) {
-        if (n >= q.dup_start) n2 = n - q.dup_start;
-        nn = n + q.shift;
-        k2 = k;
-      }
-      v = q.w[ts * q.sT + kk * q.sK + nn * q.sN];
-      if (q.shift > 0 && k2 >= 0 && n2 >= 0) v += q.w[ts * q.sT + k2 * q.sK + n2 * q.sN];
-    }
-    q.wp[i] = v;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    q.wp[i] = pack_elem(q, i);
+}
+
+// All layers' weight images in one launch (the optimiser step invalidates every image at once; 120 separate 5 us
+// launches per training step otherwise).  Descriptor table in device memory, block -> entry by binary search.
+#define PACK_BLOCK_ELEMS 2048
+struct PackDesc {
+  PackParams q;
+  long first_block, total;
+};
+__global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restrict__ descs, int n) {
+  int lo = 0, hi = n - 1;
+  const long b = blockIdx.x;
+  while (lo < hi) {  // last entry with first_block <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].first_block <= b) lo = mid; else hi = mid - 1;
+  }
+  const PackDesc d = descs[lo];
+  const long i0 = (b - d.first_block) * PACK_BLOCK_ELEMS;
+#pragma unroll
+  for (int u = 0; u < PACK_BLOCK_ELEMS / 256; ++u) {
+    const long i = i0 + threadIdx.x + u * 256;
+    if (i < d.total) d.q.wp[i] = pack_elem(d.q, i);
   }
 }
 
@@ -484,12 +510,11 @@ extern "C" long bts_conv_packed_floats(int kind, int role, int Cin, int Cout) {
   return (long)ntaps * ((K + 7) / 8) * 2 * npad32(N) * 4;
 }
 
-extern "C" int bts_conv_pack(int kind, int role, const float* w, float* wp, int Cin_ref, int Cout, int Cin_slab,
-                             int dup_start, int dup_shift, hipStream_t stream) {
+static int pack_params(PackParams& q, int kind, int role, const float* w, float* wp, int Cin_ref, int Cout, int Cin_slab,
+                       int dup_start, int dup_shift) {
   if (kind < 0 || kind > 3 || role < 0 || role > 1) return BTS_ERR_UNSUPPORTED;
   if (dup_shift > 0 && (kind == BTS_CONV_K3S2 || kind == BTS_CONV_K3S2T)) return BTS_ERR_UNSUPPORTED;
   if (Cin_slab + dup_shift != Cin_ref) return BTS_ERR_SHAPE;
-  PackParams q;
   q.w = w;
   q.wp = wp;
   q.ntaps = (kind == BTS_CONV_K1) ? 1 : 27;
@@ -507,10 +532,42 @@ extern "C" int bts_conv_pack(int kind, int role, const float* w, float* wp, int 
   }
   q.KG = (q.K + 7) / 8;
   q.Npad = npad32(q.N);
+  return BTS_OK;
+}
+
+extern "C" int bts_conv_pack(int kind, int role, const float* w, float* wp, int Cin_ref, int Cout, int Cin_slab,
+                             int dup_start, int dup_shift, hipStream_t stream) {
+  PackParams q;
+  const int r = pack_params(q, kind, role, w, wp, Cin_ref, Cout, Cin_slab, dup_start, dup_shift);
+  if (r != BTS_OK) return r;
   const long total = (long)q.ntaps * q.KG * 2 * q.Npad * 4;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   (void)hipGetLastError(); hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, stream, q);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+extern "C" long bts_conv_pack_desc_bytes(void) { return (long)sizeof(PackDesc); }
+
+// Fill descriptor #index of a HOST table (bts_conv_pack_desc_bytes() bytes per entry); first_block = sum of the block
+// counts returned for the entries before it.  Returns this entry's block count (> 0) or a negative engine code.
+extern "C" long bts_conv_pack_desc(void* host_table, int index, long first_block, int kind, int role, const float* w, float* wp,
+                                   int Cin_ref, int Cout, int Cin_slab, int dup_start, int dup_shift) {
+  PackDesc d;
+  const int r = pack_params(d.q, kind, role, w, wp, Cin_ref, Cout, Cin_slab, dup_start, dup_shift);
+  if (r != BTS_OK) return r;
+  d.total = (long)d.q.ntaps * d.q.KG * 2 * d.q.Npad * 4;
+  d.first_block = first_block;
+  reinterpret_cast<PackDesc*>(host_table)[index] = d;
+  return (d.total + PACK_BLOCK_ELEMS - 1) / PACK_BLOCK_ELEMS;
+}
+
+// table_dev: the host table copied to device memory by the caller; total_blocks = sum of all block counts
+extern "C" int bts_conv_pack_batch(const void* table_dev, int n, long total_blocks, hipStream_t stream) {
+  if (n <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffL) return BTS_ERR_SHAPE;
+  (void)hipGetLastError(); hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream,
+                     reinterpret_cast<const PackDesc*>(table_dev), n);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }

@@ -867,7 +867,7 @@ extern "C" int bts_conv3d_bwd_weight(int kind, const float* x, const float* dy, 
   if (p.fastf && ((double)p.IZ * p.Hp * p.Wp * p.ldp * 4.0 >= 4.0e9 || (double)p.TZ * p.Hq * p.Wq * p.ldq * 4.0 >= 4.0e9 || !glds))
     p.fastf = p.fixg = 0;
   const bool prof = bts_prof_on();
-  if (glds) {
+  if (glds && !p.fastf) {  // only the general LDS-DMA staging reads the zero source
     hipError_t e = hipMemsetAsync(ztail, 0, 64, stream);
     if (e != hipSuccess) return (int)e;
   }

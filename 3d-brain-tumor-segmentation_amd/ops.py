@@ -9,7 +9,7 @@ import ctypes
 
 import torch
 
-from ._lib import lib
+from ._lib import ERRORS, lib
 
 K1, K3S1, K3S2, K3S2T = 0, 1, 2, 3
 ROLE_FWD, ROLE_BWD = 0, 1
@@ -110,6 +110,46 @@ def conv_pack(kind, role, w, cin_ref, cout, cin_slab=None, dup_start=0, dup_shif
     lib().call('bts_conv_pack', kind, role, _p(w.contiguous()), _p(wp), cin_ref, cout, cin_slab, dup_start, dup_shift,
                _stream())
     return wp
+
+
+class PackTable(object):
+    """Device-resident descriptor table for bts_conv_pack_batch: entries = [(kind, role, w, wp, cin_ref, cout, cin_slab,
+    dup_start, dup_shift)] with torch tensors w (reference layout) / wp (packed image).  Rebuilt only when a pointer or
+    the entry list changes."""
+
+    def __init__(self):
+        self.key = None
+        self.dev = None
+        self.n = 0
+        self.blocks = 0
+
+    def run(self, entries):
+        if not entries:
+            return
+        key = tuple((e[0], e[1], e[2].data_ptr(), e[3].data_ptr()) + tuple(e[4:]) for e in entries)
+        if key != self.key:
+            L = lib()
+            nb = L._bts_conv_pack_desc_bytes()
+            host = (ctypes.c_char * (nb * len(entries)))()
+            first = 0
+            for i, (kind, role, w, wp, cin_ref, cout, cin_slab, dup_start, dup_shift) in enumerate(entries):
+                _check(w, 'kernel')
+                _check(wp, 'packed image')
+                if not w.is_contiguous():
+                    raise ValueError('conv_pack_batch: kernels must be contiguous')
+                r = L._bts_conv_pack_desc(ctypes.cast(host, ctypes.c_void_p), i, first, kind, role, _p(w), _p(wp), cin_ref,
+                                          cout, cin_slab, dup_start, dup_shift)
+                if r <= 0:
+                    raise RuntimeError('bts_conv_pack_desc failed: %s' % ERRORS.get(r, r))
+                first += r
+            dev = entries[0][3].device
+            self.dev = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
+            self.key, self.n, self.blocks = key, len(entries), first
+        lib().call('bts_conv_pack_batch', _p(self.dev), self.n, self.blocks, _stream())
+
+
+def conv_packed_empty(kind, role, cin_slab, cout, device):
+    return torch.empty(lib().query('bts_conv_packed_floats', kind, role, cin_slab, cout), dtype=torch.float32, device=device)
 
 
 def conv_out_shape(kind, x_shape, cout):

@@ -48,6 +48,14 @@ long bts_conv_packed_floats(int kind, int role, int Cin, int Cout);
  * (encoder.py:83-87: inputs [o_{j-1}, o_0..o_{j-1}] -> slab [o_0..o_{j-1}], dup_start = (j-1)*F, dup_shift = F). */
 int bts_conv_pack(int kind, int role, const float* w, float* wp, int Cin_ref, int Cout, int Cin_slab, int dup_start,
                   int dup_shift, bts_stream_t stream);
+/* All weight images in one launch (every image goes stale together at the optimiser step, train.py:152): the caller
+ * fills a HOST table of bts_conv_pack_desc_bytes()-sized descriptors with bts_conv_pack_desc (arguments as bts_conv_pack;
+ * returns the entry's block count > 0, or a negative engine code; first_block = running sum of those counts), copies it
+ * to device memory and passes it with the total block count. */
+long bts_conv_pack_desc_bytes(void);
+long bts_conv_pack_desc(void* host_table, int index, long first_block, int kind, int role, const float* w, float* wp,
+                        int Cin_ref, int Cout, int Cin_slab, int dup_start, int dup_shift);
+int bts_conv_pack_batch(const void* table_dev, int n, long total_blocks, bts_stream_t stream);
 /* y = act(conv(x) + bias). x (N,D,H,W,Cin) stride ldx; y (N,D',H',W',Cout) stride ldy; D' = D | D/2 | 2D. */
 /* workspace (may be NULL / 0) lets grids too small to fill the chip split the contraction over workgroups (deterministic
  * two-stage reduction); size from bts_conv3d_fwd_workspace (0 when the shape does not need it). */
