@@ -55,6 +55,7 @@ CONV_CASES = [
     # kind, N, (D,H,W), Cin, Cout
     (1, 1, (8, 8, 8), 8, 32), (1, 2, (16, 16, 32), 32, 32), (1, 1, (8, 12, 20), 16, 64), (1, 1, (16, 16, 16), 2, 32),
     (1, 1, (8, 8, 8), 32, 2), (1, 1, (4, 4, 4), 40, 128), (1, 1, (32, 32, 64), 32, 32), (1, 1, (6, 10, 14), 12, 20),
+    (1, 1, (16, 16, 48), 64, 64),
     (0, 1, (8, 8, 8), 32, 32), (0, 2, (16, 16, 16), 64, 32), (0, 1, (8, 8, 16), 32, 3), (0, 1, (4, 4, 4), 256, 128),
     (0, 1, (8, 8, 8), 2, 32), (0, 1, (32, 32, 32), 64, 32),
     (2, 1, (8, 8, 8), 32, 32), (2, 2, (16, 16, 16), 32, 64), (2, 1, (4, 4, 4), 128, 16), (2, 1, (8, 16, 32), 16, 32),
@@ -170,6 +171,29 @@ def test_conv_folded_duplicate_slice(kind):
     dw = torch.empty_like(wg)
     ops.conv_bwd_weight(kind, sg, dy.to(dev()), dw, None, (j - 1) * f, f)
     check_close(dw, wd.grad, 'folded bwd_weight', rtol=1e-4, atol=1e-4)
+
+
+def test_conv_pack_batch_matches_single():
+    """bts_conv_pack_batch (one launch for every weight image) must produce bit-identical images to bts_conv_pack."""
+    from bts_amd import ops
+    specs = [(1, 0, 32, 32, 32, 0, 0), (1, 1, 32, 32, 32, 0, 0), (0, 0, 48, 16, 32, 16, 16), (0, 1, 48, 16, 32, 16, 16),
+             (2, 0, 16, 24, 16, 0, 0), (3, 1, 8, 40, 8, 0, 0), (1, 0, 2, 32, 2, 0, 0), (1, 1, 32, 3, 32, 0, 0)]
+    entries, singles = [], []
+    for i, (kind, role, cin_ref, cout, cin_slab, dstart, dshift) in enumerate(specs):
+        k = 1 if kind == 0 else 3
+        shape = (k, k, k, cout, cin_ref) if kind == 3 else (k, k, k, cin_ref, cout)
+        w = rnd(shape, 40 + i, 0.3).to(dev())
+        singles.append(ops.conv_pack(kind, role, w, cin_ref, cout, cin_slab, dstart, dshift))
+        wp = ops.conv_packed_empty(kind, role, cin_slab, cout, w.device)
+        wp.fill_(float('nan'))
+        entries.append((kind, role, w, wp, cin_ref, cout, cin_slab, dstart, dshift))
+    table = ops.PackTable()
+    table.run(entries)
+    table.run(entries)  # cached table path
+    torch.cuda.synchronize()
+    for e, ref in zip(entries, singles):
+        assert e[3].shape == ref.shape
+        assert torch.equal(e[3], ref), 'batched image differs for %r' % (e[:2] + e[4:],)
 
 
 GN_CASES = [(1, (8, 8, 8), 32, 8), (2, (8, 8, 16), 16, 8), (1, (16, 16, 16), 64, 8), (2, (4, 4, 4), 256, 8),
