@@ -778,11 +778,34 @@ static int plan_wgrad(WgradPlan& pl, int ntaps, int s, int neg, int N, int Dp, i
   p.nsub = N * p.ntz * p.nty * p.ntx;
   pl.npct = (cpad == 32) ? (Cp + 31) / 32 : 1;
   pl.nqct = (Cq + 31) / 32;
-  long want = 512 / ((long)pl.npct * pl.nqct);
-  if (want < 1) want = 1;
-  if (want > p.nsub) want = p.nsub;
-  p.sub_per_wg = (int)((p.nsub + want - 1) / want);
-  pl.nsp = (p.nsub + p.sub_per_wg - 1) / p.sub_per_wg;
+  // K-split count nsp (workgroups per (P,Q) channel-tile pair).  One workgroup is resident per CU, so the launch runs in
+  // rounds of 256; cost model in units of one sub-tile sweep: rounds x (sub-tiles per WG + 0.5 fixed) + the partials'
+  // write/combine traffic (~0.0023 per workgroup).  Smallest cost wins, ties go to fewer partials.
+  {
+    const long pairs = (long)pl.npct * pl.nqct;
+    const char* ov = getenv("BTS_WGRAD_WGS");  // experiment override: target workgroup count
+    long best = 1;
+    if (ov) {
+      best = atol(ov) / pairs;
+    } else {
+      double bestc = 1e30;
+      long maxn = 2048 / pairs;
+      if (maxn < 1) maxn = 1;
+      if (maxn > p.nsub) maxn = p.nsub;
+      for (long n = 1; n <= maxn; ++n) {
+        const long spw = (p.nsub + n - 1) / n;
+        const long ne = (p.nsub + spw - 1) / spw;
+        if (ne != n) continue;
+        const long rounds = (ne * pairs + 255) / 256;
+        const double c = (double)rounds * ((double)spw + 0.5) + 0.0023 * (double)(ne * pairs);
+        if (c < bestc - 1e-9) { bestc = c; best = n; }
+      }
+    }
+    if (best < 1) best = 1;
+    if (best > p.nsub) best = p.nsub;
+    p.sub_per_wg = (int)((p.nsub + best - 1) / best);
+    pl.nsp = (p.nsub + p.sub_per_wg - 1) / p.sub_per_wg;
+  }
   pl.partial_floats = (long)pl.nsp * pl.npct * pl.nqct * p.ntiles * 1024;
   pl.partial_b_doubles = (long)pl.nsp * pl.nqct * 32;
   return BTS_OK;
