@@ -104,6 +104,15 @@ def test_conv_fwd_bwd(kind, n, dims, cin, cout):
         check_contraction(db, bd.grad, dy.double().abs().sum(dim=(0, 1, 2, 3)), 'colsum bias grad')
 
 
+@pytest.mark.parametrize('kind,n,dims,cin,cout', [(3, 1, (8, 8, 16), 32, 32), (3, 2, (4, 8, 8), 16, 64), (3, 1, (6, 10, 12), 8, 20),
+                                                  (3, 1, (2, 4, 40), 24, 32), (2, 1, (16, 16, 32), 32, 32), (2, 2, (8, 12, 20), 16, 40)])
+def test_conv_up_merged_classes(monkeypatch, kind, n, dims, cin, cout):
+    """Conv3DTranspose forward / stride-2 data gradient through upm_kernel (all 8 output-parity classes per workgroup):
+    forced on for grids the heuristic would leave to the per-class path, incl. ragged tiles and accumulate."""
+    monkeypatch.setenv('BTS_IGEMM_UPM_MIN', '1')
+    test_conv_fwd_bwd(kind, n, dims, cin, cout)
+
+
 def test_conv_strided_views_and_sigmoid():
     """channel slices of a slab as conv input and output (virtual Concatenate), fused sigmoid"""
     from bts_amd import ops
