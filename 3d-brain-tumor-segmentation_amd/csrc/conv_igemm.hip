@@ -753,6 +753,147 @@ static int launch_upm(const float* x, const float* wp, const float* bias, float*
 }
 
 // ---------------------------------------------------------------------------------------------
+// 1x1x1 convolution as a streaming GEMM (resnet.py:96-103 shortcut, decoder.py:55-63 output head, vae.py pointwise convs,
+// and their data gradients).  These layers are HBM-bound (<= 64 FLOP/B), so nothing is staged: the B fragment of the
+// MFMA (voxel l32, channels kg*8 + 4h .. +3) IS a 16-byte global load of that voxel's row, the A fragment the matching
+// quad of the packed weights (L1/L2 resident).  A wave owns 64 voxels x 32*NS couts; latency is covered by occupancy
+// (~100 VGPRs -> 4 waves per SIMD), not by a software pipeline.
+// ---------------------------------------------------------------------------------------------
+struct K1sParams {
+  const float* x;
+  const float* wp;
+  const float* bias;
+  float* y;
+  long nvox;
+  int Cin, ldx, Cout, ldy, Npad, KG, flags;
+};
+template <int NS>
+__global__ __launch_bounds__(256, 4) void k1s_kernel(const K1sParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, l32 = lane & 31;
+  const long v0 = (long)blockIdx.x * 256 + wave * 64;
+  const float* xrow[2];
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms) {
+    long v = v0 + ms * 32 + l32;
+    if (v >= p.nvox) v = p.nvox - 1;  // clamped loads, masked stores
+    xrow[ms] = p.x + v * p.ldx + h * 4;
+  }
+  int woff[NS];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    int ncol = (blockIdx.y * NS + ns) * 32 + l32;
+    if (ncol >= p.Npad) ncol = p.Npad - 1;
+    woff[ns] = (h * p.Npad + ncol) * 4;
+  }
+  const int wstepKG = 2 * p.Npad * 4;
+  f32x16 acc[2][NS];
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
+  // U k-groups per step (fewer for the wider tile: 128-VGPR budget), next step's operands requested before this
+  // step's MFMAs
+  constexpr int U = (NS == 1) ? 2 : 1;
+  f32x4 b[2][U][2], a[2][U][NS];
+  auto load = [&](int buf, int kg) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = (kg + u < p.KG) ? kg + u : p.KG - 1;
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms) b[buf][u][ms] = *reinterpret_cast<const f32x4*>(xrow[ms] + k * 8);
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) a[buf][u][ns] = *reinterpret_cast<const f32x4*>((p.wp + k * wstepKG) + woff[ns]);
+    }
+  };
+  auto mma = [&](int buf, int kg) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (kg + u < p.KG) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+              acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][u][ns][j], b[buf][u][ms][j], acc[ms][ns], 0, 0, 0);
+      }
+    }
+  };
+  load(0, 0);
+  for (int kg = 0; kg < p.KG; kg += 2 * U) {
+    if (kg + U < p.KG) load(1, kg + U);
+    mma(0, kg);
+    if (kg + U < p.KG) {
+      if (kg + 2 * U < p.KG) load(0, kg + 2 * U);
+      mma(1, kg + U);
+    }
+  }
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms) {
+    const long v = v0 + ms * 32 + l32;
+    if (v >= p.nvox) continue;
+    float* yrow = p.y + v * p.ldy;
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      const int nb = (blockIdx.y * NS + ns) * 32;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = nb + 8 * g + 4 * h;
+        if (co >= p.Cout) continue;
+        f32x4 val = {acc[ms][ns][4 * g + 0], acc[ms][ns][4 * g + 1], acc[ms][ns][4 * g + 2], acc[ms][ns][4 * g + 3]};
+        if (p.flags & IG_FLAG_BIAS) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (co + j < p.Cout) val[j] += p.bias[co + j];
+        }
+        if (p.flags & IG_FLAG_SIGMOID) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) val[j] = sigmoidf_(val[j]);
+        }
+        if ((p.flags & IG_FLAG_VECOUT) && co + 3 < p.Cout) {
+          f32x4* dst = reinterpret_cast<f32x4*>(yrow + co);
+          if (p.flags & IG_FLAG_ACCUM) val += *dst;
+          *dst = val;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (co + j < p.Cout) yrow[co + j] = (p.flags & IG_FLAG_ACCUM) ? yrow[co + j] + val[j] : val[j];
+        }
+      }
+    }
+  }
+}
+
+// returns BTS_OK when taken, 1 when the shape is left to the staged igemm path
+static int launch_k1s(const float* x, const float* wp, const float* bias, float* y, long nvox, int Cin, int ldx, int Cout, int ldy,
+                      int flags, hipStream_t stream) {
+  if (getenv("BTS_IGEMM_NOK1S") != nullptr) return 1;
+  if ((Cin & 7) || (ldx & 3) || (((uintptr_t)x) & 15)) return 1;  // whole k-groups, 16-byte row quads
+  const long min_vox = getenv("BTS_IGEMM_K1S_MIN") ? atol(getenv("BTS_IGEMM_K1S_MIN")) : 256 * 256;  // (tests force 1)
+  if (nvox < min_vox) return 1;  // small grids (deep levels): too few workgroups, keep the split-K capable path
+  K1sParams p;
+  p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.nvox = nvox;
+  p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.ldy = ldy; p.Npad = npad32(Cout); p.KG = Cin / 8;
+  p.flags = flags & (IG_FLAG_BIAS | IG_FLAG_ACCUM | IG_FLAG_SIGMOID);
+  if ((ldy % 4 == 0) && (((uintptr_t)y) % 16 == 0)) p.flags |= IG_FLAG_VECOUT;
+  const long gx = (nvox + 255) / 256;
+  if (gx > 0x7fffffffL) return 1;
+  const bool prof = bts_prof_on();
+  const int ns = (p.Npad >= 64) ? 2 : 1;
+  if (prof) bts_prof_begin(21, 2.0 * Cin * (double)Cout * (double)nvox, stream);
+  (void)hipGetLastError();
+  if (ns == 2) hipLaunchKernelGGL(k1s_kernel<2>, dim3((unsigned)gx, (p.Npad + 63) / 64), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(k1s_kernel<1>, dim3((unsigned)gx, 1), dim3(256), 0, stream, p);
+  if (prof) bts_prof_end(stream);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Launch logic
 // ---------------------------------------------------------------------------------------------
 enum Geo { GEO_K1 = 0, GEO_S1 = 1, GEO_DOWN = 2, GEO_UP = 3 };
@@ -856,6 +997,10 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
                         int pz, int py, int px, int flags, hipStream_t stream, void* ws = nullptr, long ws_bytes = 0,
                         long* need_out = nullptr, const float* wp2 = nullptr, const float* bias2 = nullptr,
                         float* y2 = nullptr, int ldy2 = 0) {
+  if (geo == GEO_K1 && wp2 == nullptr && need_out == nullptr) {
+    const int r = launch_k1s(x, wp, bias, y, (long)N * Di * Hi * Wi, Cin, ldx, Cout, ldy, flags, stream);
+    if (r != 1) return r;
+  }
   if (geo == GEO_UP && pz < 0 && wp2 == nullptr && !(flags & ~(IG_FLAG_BIAS | IG_FLAG_ACCUM | IG_FLAG_SIGMOID | IG_FLAG_VECIN | IG_FLAG_VECOUT))) {
     // merged parity classes (no workspace needed); shapes it declines fall through to the per-class launch
     if (need_out != nullptr) {

@@ -26,6 +26,8 @@ _CFG = {0: '2,1,4,1', 1: '2,2,4,1', 2: '1,2,2,2', 3: '1,1,2,2', 4: '1,1,4,1', 5:
 def kernel_symbol(sym):
     if sym == 20:
         return 'upm_kernel'
+    if sym == 21:
+        return 'k1s_kernel'
     if sym >= 100:  # 100 + (MODE << 2 | FIXG)
         return 'wgrad_kernel<%d,%d>' % ((sym - 100) >> 2, (sym - 100) & 3)
     return 'igemm_kernel<%s,%d>' % (_CFG[sym & 7], 4 if sym & 8 else 1)

@@ -113,6 +113,27 @@ def test_conv_up_merged_classes(monkeypatch, kind, n, dims, cin, cout):
     test_conv_fwd_bwd(kind, n, dims, cin, cout)
 
 
+@pytest.mark.parametrize('n,dims,cin,cout', [(1, (8, 8, 8), 32, 32), (2, (4, 6, 10), 64, 3), (1, (8, 8, 16), 24, 72), (1, (3, 5, 7), 256, 128),
+                                             (1, (16, 16, 16), 8, 32)])
+def test_conv_k1_streaming(monkeypatch, n, dims, cin, cout):
+    """1x1x1 conv through k1s_kernel (operands straight from global memory), forced on for small grids: ragged voxel
+    counts, cout not a multiple of 4, accumulate; plus sigmoid + strided slab views."""
+    from bts_amd import ops
+    monkeypatch.setenv('BTS_IGEMM_K1S_MIN', '1')
+    test_conv_fwd_bwd(0, n, dims, cin, cout)
+    d, h, w = dims
+    slab = rnd((n, d, h, w, cin + 8), 31)
+    wt = rnd((1, 1, 1, cin, cout), 32, 0.2)
+    b = rnd((cout,), 33)
+    ref = torch.sigmoid(R.conv3d(slab[..., 8:].double(), wt.double(), b.double()))
+    sg = slab.to(dev())
+    wp = ops.conv_pack(0, ops.ROLE_FWD, wt.to(dev()), cin, cout)
+    out = torch.zeros((n, d, h, w, cout + 4), device=dev())
+    ops.conv_fwd(0, sg[..., 8:], wp, b.to(dev()), cout, out=out[..., 4:], sigmoid=True)
+    check_close(out[..., 4:], ref, 'k1s strided sigmoid', rtol=1e-5, atol=1e-6)
+    assert float(out[..., :4].abs().max()) == 0.0
+
+
 def test_conv_strided_views_and_sigmoid():
     """channel slices of a slab as conv input and output (virtual Concatenate), fused sigmoid"""
     from bts_amd import ops
