@@ -894,6 +894,140 @@ static int launch_k1s(const float* x, const float* wp, const float* bias, float*
 }
 
 // ---------------------------------------------------------------------------------------------
+// 3x3x3 stride-1 conv with 1..4 output channels (VAE reconstruction head 32 -> 2, vae.py:92-99 / model.py:72) on the
+// vector ALU: padding 2 couts to an MFMA N of 32 wastes 94 % of the matrix pipe (0.99 ms at 128^3).  One output voxel
+// per lane; the halo tile is staged 8 channels at a time in the igemm layout (conflict-free ds_read_b128), the
+// wave-uniform weights come straight out of the packed image through scalar loads (v_fma with an SGPR operand), so the
+// LDS serves only the 2 x 27 activation quads per voxel and slab.  Latency is covered by occupancy (4 workgroups / CU).
+// ---------------------------------------------------------------------------------------------
+struct DscParams {
+  const float* x;
+  const float* wp;
+  const float* bias;
+  float* y;
+  int N, D, H, W, Cin, ldx, Cout, ldy, Npad, KG, ntx, nty, ntz, flags;
+};
+template <int CO>
+__global__ __launch_bounds__(256, 4) void dsc_kernel(const DscParams p) {
+  constexpr int S = 12, TX = 32, TY = 4, TZ = 2, IX = TX + 2, IY = TY + 2, IZ = TZ + 2;
+  constexpr int tileVox = IZ * IY * IX, nslots = tileVox * 2, NSL = (nslots + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float lds[tileVox * S];
+  const int tid = threadIdx.x;
+  int b = blockIdx.x;
+  const int tx = b % p.ntx; b /= p.ntx;
+  const int ty = b % p.nty; b /= p.nty;
+  const int tz = b % p.ntz;
+  const int n = b / p.ntz;
+  const int iz0 = tz * TZ - 1, iy0 = ty * TY - 1, ix0 = tx * TX - 1;
+  const float* xbase = p.x + ((((long)n * p.D + iz0) * p.H + iy0) * p.W + ix0) * (long)p.ldx;
+  int goff[NSL];
+#pragma unroll
+  for (int i = 0; i < NSL; ++i) {
+    const int e = tid + i * 256;
+    goff[i] = -1;
+    if (e < nslots) {
+      const int vox = e >> 1, q = e & 1;
+      const int vz = vox / (IY * IX), r = vox - vz * (IY * IX), vy = r / IX, vx = r - vy * IX;
+      if ((unsigned)(iz0 + vz) < (unsigned)p.D && (unsigned)(iy0 + vy) < (unsigned)p.H && (unsigned)(ix0 + vx) < (unsigned)p.W)
+        goff[i] = ((vz * p.H + vy) * p.W + vx) * p.ldx + q * 4;
+    }
+  }
+  const int mx = tid & (TX - 1), my = (tid >> 5) & (TY - 1), mz = tid >> 7;
+  const float* lb = lds + ((mz * IY + my) * IX + mx) * S;
+  float acc[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+  const int wstepKG = 2 * p.Npad * 4, wstepTap = p.KG * wstepKG;
+  f32x4 pre[NSL];
+  auto fetch = [&](int kg) {
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (goff[i] >= 0) v = *reinterpret_cast<const f32x4*>(xbase + goff[i] + kg * 8);
+      pre[i] = v;
+    }
+  };
+  fetch(0);
+  for (int kg = 0; kg < p.KG; ++kg) {
+    __syncthreads();  // previous slab fully consumed
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+      const int e = tid + i * 256;
+      if (e < nslots) *reinterpret_cast<f32x4*>(lds + (e >> 1) * S + (e & 1) * 4) = pre[i];
+    }
+    __syncthreads();
+    if (kg + 1 < p.KG) fetch(kg + 1);  // next slab's global loads fly under this slab's arithmetic
+    const float* wk = p.wp + kg * wstepKG;  // wave-uniform: scalar loads
+    // one x-row of taps (3 taps x 2 halves x CO quads) per scalar-load batch: SMEM returns out of order, so every use
+    // of a scalar load drains lgkmcnt to 0 -- batching makes that 9 drains per slab instead of 54
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      float w[3][2][CO * 4];
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int q = 0; q < CO * 4; ++q) w[dx][hh][q] = wk[(r * 3 + dx) * wstepTap + hh * p.Npad * 4 + q];
+      f32x4 xv[3][2];
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const float* src = lb + (((r / 3) * IY + r % 3) * IX + dx) * S;
+        xv[dx][0] = *reinterpret_cast<const f32x4*>(src);
+        xv[dx][1] = *reinterpret_cast<const f32x4*>(src + 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int c = 0; c < CO; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[c] = fmaf(xv[dx][hh][j], w[dx][hh][c * 4 + j], acc[c]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const int oz = tz * TZ + mz, oy = ty * TY + my, ox = tx * TX + mx;
+  if (oz >= p.D || oy >= p.H || ox >= p.W) return;
+  float* yrow = p.y + ((((long)n * p.D + oz) * p.H + oy) * p.W + ox) * (long)p.ldy;
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    if (c < p.Cout) {
+      float v = acc[c];
+      if (p.flags & IG_FLAG_BIAS) v += p.bias[c];
+      if (p.flags & IG_FLAG_SIGMOID) v = sigmoidf_(v);
+      if (p.flags & IG_FLAG_ACCUM) v += yrow[c];
+      yrow[c] = v;
+    }
+  }
+}
+
+// returns BTS_OK when taken, 1 when the shape is left to the MFMA path
+static int launch_dsc(const float* x, const float* wp, const float* bias, float* y, int N, int D, int H, int W, int Cin, int ldx,
+                      int Cout, int ldy, int flags, hipStream_t stream) {
+  if (getenv("BTS_IGEMM_NODSC") != nullptr) return 1;
+  if (Cout > 4 || (Cin & 7) || (ldx & 3) || (((uintptr_t)x) & 15)) return 1;
+  const long tiles = (long)N * ((D + 1) / 2) * ((H + 3) / 4) * ((W + 31) / 32);
+  const long min_tiles = getenv("BTS_IGEMM_DSC_MIN") ? atol(getenv("BTS_IGEMM_DSC_MIN")) : 1024;  // (tests force 1)
+  if (tiles < min_tiles || tiles > 0x7fffffffL) return 1;
+  DscParams p;
+  p.x = x; p.wp = wp; p.bias = bias; p.y = y;
+  p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.ldy = ldy;
+  p.Npad = npad32(Cout); p.KG = Cin / 8;
+  p.ntx = (W + 31) / 32; p.nty = (H + 3) / 4; p.ntz = (D + 1) / 2;
+  p.flags = flags & (IG_FLAG_BIAS | IG_FLAG_ACCUM | IG_FLAG_SIGMOID);
+  const bool prof = bts_prof_on();
+  if (prof) bts_prof_begin(22, 2.0 * 27.0 * Cin * (double)Cout * (double)N * D * H * W, stream);
+  (void)hipGetLastError();
+  if (Cout <= 2) hipLaunchKernelGGL(dsc_kernel<2>, dim3((unsigned)tiles), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(dsc_kernel<4>, dim3((unsigned)tiles), dim3(256), 0, stream, p);
+  if (prof) bts_prof_end(stream);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Launch logic
 // ---------------------------------------------------------------------------------------------
 enum Geo { GEO_K1 = 0, GEO_S1 = 1, GEO_DOWN = 2, GEO_UP = 3 };
@@ -997,6 +1131,10 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
                         int pz, int py, int px, int flags, hipStream_t stream, void* ws = nullptr, long ws_bytes = 0,
                         long* need_out = nullptr, const float* wp2 = nullptr, const float* bias2 = nullptr,
                         float* y2 = nullptr, int ldy2 = 0) {
+  if (geo == GEO_S1 && wp2 == nullptr && need_out == nullptr && Cout <= 4) {
+    const int r = launch_dsc(x, wp, bias, y, N, Di, Hi, Wi, Cin, ldx, Cout, ldy, flags, stream);
+    if (r != 1) return r;
+  }
   if (geo == GEO_K1 && wp2 == nullptr && need_out == nullptr) {
     const int r = launch_k1s(x, wp, bias, y, (long)N * Di * Hi * Wi, Cin, ldx, Cout, ldy, flags, stream);
     if (r != 1) return r;

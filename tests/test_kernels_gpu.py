@@ -134,6 +134,25 @@ def test_conv_k1_streaming(monkeypatch, n, dims, cin, cout):
     assert float(out[..., :4].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('n,dims,cin,cout', [(1, (8, 8, 8), 32, 2), (2, (6, 10, 40), 16, 3), (1, (4, 4, 4), 8, 1), (1, (16, 16, 32), 32, 4)])
+def test_conv_small_cout_direct(monkeypatch, n, dims, cin, cout):
+    """3x3x3 conv with <= 4 output channels through dsc_kernel (vector-ALU direct form), forced on for small grids:
+    ragged tiles, all cout counts, bias; plus sigmoid into a strided slab view."""
+    from bts_amd import ops
+    monkeypatch.setenv('BTS_IGEMM_DSC_MIN', '1')
+    test_conv_fwd_bwd(1, n, dims, cin, cout)
+    d, h, w = dims
+    slab = rnd((n, d, h, w, cin + 8), 51)
+    wt = rnd((3, 3, 3, cin, cout), 52, 0.2)
+    b = rnd((cout,), 53)
+    ref = torch.sigmoid(R.conv3d(slab[..., 8:].double(), wt.double(), b.double()))
+    wp = ops.conv_pack(1, ops.ROLE_FWD, wt.to(dev()), cin, cout)
+    out = torch.zeros((n, d, h, w, cout + 4), device=dev())
+    ops.conv_fwd(1, slab.to(dev())[..., 8:], wp, b.to(dev()), cout, out=out[..., 4:], sigmoid=True)
+    check_close(out[..., 4:], ref, 'dsc strided sigmoid', rtol=1e-5, atol=2e-6)
+    assert float(out[..., :4].abs().max()) == 0.0
+
+
 def test_conv_strided_views_and_sigmoid():
     """channel slices of a slab as conv input and output (virtual Concatenate), fused sigmoid"""
     from bts_amd import ops
