@@ -14,7 +14,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: torch ships its ow
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(_ROOT, 'include', 'bts_hip.h')
-LIBPATH = os.path.join(_HERE, 'libbts_hip.so')
+LIBPATH = os.environ.get('BTS_HIP_LIB') or os.path.join(_HERE, 'libbts_hip.so')  # override: A/B timing of two builds
 
 _CT = {
     'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float, 'uint64_t': ctypes.c_uint64,
