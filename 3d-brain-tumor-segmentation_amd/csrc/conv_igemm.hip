@@ -307,6 +307,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     int nkg = kgEnd - kg0;
     if (nkg > KGS) nkg = KGS;
     if (p.dbg == 1) {
+    } else if constexpr (FIXG) {  // compile-time geometry is always the 27-tap form: no runtime tap-count dispatch, so the
+      // accumulators are not shuffled between register sets around a switch
+      stage_taps<27, MS, NS, FUSE2, FIXG>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc, acc2);
     } else if constexpr (KGS == 1) {
       switch (ntaps) {
         case 27: stage_taps<27, MS, NS, FUSE2, FIXG>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc, acc2); break;
