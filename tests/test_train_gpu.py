@@ -1,0 +1,77 @@
+"""-m gpu: the training-loop shell on the real engine: `fit` runs epochs of train_step / eval_step, logs the
+reference's CSV, checkpoints on validation improvement -- and a run resumed from the container continues BIT-EXACTLY
+(weights, Adam moments, step count, LR schedule position and the dropout / reparameterisation RNG counters all persist)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import torch_ref as R  # noqa: E402
+
+KW = dict(base_filters=8, groups=2, reduction=2, depth=3)
+CROP = (16, 16, 16)
+
+
+def _setup(seed=0):
+    import bts_amd  # noqa: F401
+    from bts_amd.model import Model
+    from bts_amd.util import DiceCoefficient, DiceVAELoss, ScheduledOptim
+    torch.manual_seed(seed)
+    m = Model(**KW)
+    m.build((1,) + CROP + (2,))
+    g = torch.Generator().manual_seed(11)
+    for p in m.trainable_variables:   # same deterministic start for every model of this test module
+        if p.t.dim() > 1:
+            p.t.copy_((torch.randn(p.t.shape, generator=g) * 0.05).to(p.t.device))
+    from bts_amd.tape import bump_weights_epoch
+    bump_weights_epoch()
+    return m, ScheduledOptim(1e-3, n_epochs=4), DiceVAELoss(), DiceCoefficient()
+
+
+def _data(n, seed):
+    dev = torch.device('cuda', 0)
+    latent = KW['base_filters'] * 2 ** (KW['depth'] - 2)
+    out = []
+    for i in range(n):
+        x, y, _, _ = R.synthetic_batch(1, CROP, latent=latent, seed=seed + i)
+        out.append((x.to(dev), y.to(dev)))
+    return out
+
+
+def test_fit_logs_and_checkpoints(tmp_path):
+    from bts_amd import train as T
+    m, opt, lf, df = _setup()
+    hist = T.fit(m, opt, lf, df, _data(3, 100), _data(2, 200), n_epochs=2, patience=5, save_folder=str(tmp_path),
+                 log=lambda s: None)
+    assert len(hist) == 2 and all(torch.isfinite(torch.tensor(float(h['train_loss']))) for h in hist)
+    assert float(hist[1]['train_loss']) < float(hist[0]['train_loss'])      # it learns something on 3 fixed volumes
+    lines = open(os.path.join(str(tmp_path), 'train.log')).read().strip().split('\n')
+    assert lines[0] == T.LOG_HEADER and len(lines) == 3 and lines[1].startswith('0,0.001,')
+    assert os.path.exists(os.path.join(str(tmp_path), T.CHECKPOINT_NAME))
+    assert opt.iterations == 6
+
+
+def test_resume_is_bit_exact(tmp_path):
+    from bts_amd import train as T
+    train, val = _data(3, 100), _data(1, 200)
+    # run A: epochs 0 and 1 back to back, snapshot after epoch 0
+    mA, oA, lf, df = _setup()
+    T.fit(mA, oA, lf, df, train, val, n_epochs=1, patience=5, log=lambda s: None)
+    mA.epoch.assign(1)
+    T.save_checkpoint(str(tmp_path), mA, oA)
+    T.fit(mA, oA, lf, df, train, val, n_epochs=2, patience=5, log=lambda s: None)
+    # run B: fresh process state, restored from the snapshot, then epoch 1
+    mB, oB, lf2, df2 = _setup(seed=123)
+    for p in mB.trainable_variables:
+        p.t.zero_()
+    meta = T.load_checkpoint(str(tmp_path), mB, oB)
+    assert meta['epoch'] == 1 and oB.iterations == 3
+    histB = T.fit(mB, oB, lf2, df2, train, val, n_epochs=2, patience=5, log=lambda s: None)
+    assert [h['epoch'] for h in histB] == [1]
+    torch.cuda.synchronize()
+    assert torch.equal(mA.flat_params, mB.flat_params), 'resumed run diverged: max |d| %.3e' % float(
+        (mA.flat_params - mB.flat_params).abs().max())
+    sA, sB = oA._state[id(mA.flat_params)], oB._state[id(mB.flat_params)]
+    assert torch.equal(sA[0], sB[0]) and torch.equal(sA[1], sB[1]) and oA.iterations == oB.iterations == 6
