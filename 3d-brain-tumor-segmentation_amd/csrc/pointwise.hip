@@ -170,3 +170,74 @@ extern "C" int bts_sigmoid_bwd(const float* y, const float* dy, float* dx, long 
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
+
+// ---- full-volume inference helpers (test.py:95-151) ----------------------------------------------------
+// dst[n,d,h,w,c] (+)= scale * t(src[n, fd(d), fh(h), fw(w), c]) with t(v) = (v - mean[c]) / std[c] when mean != NULL
+// (input normalisation, test.py:111), identity otherwise; flip bits: 4 = D, 2 = H, 1 = W (tf.reverse on those axes,
+// test.py:139,142).  One float4 per thread when C % 4 == 0, dense NDHWC tensors.
+__global__ void flip_affine_kernel(const float* __restrict__ src, float* dst, const float* __restrict__ mean,
+                                   const float* __restrict__ stdv, long nvox, int D, int H, int W, int C, int flip, float scale,
+                                   int accum) {
+  const long total = nvox * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long v = i / C;
+    const int w = (int)(v % W); v /= W;
+    const int h = (int)(v % H); v /= H;
+    const int d = (int)(v % D);
+    const long n = v / D;
+    const int sd = (flip & 4) ? D - 1 - d : d, sh = (flip & 2) ? H - 1 - h : h, sw = (flip & 1) ? W - 1 - w : w;
+    float val = src[(((n * D + sd) * H + sh) * W + sw) * C + c];
+    if (mean) val = (val - mean[c]) / stdv[c];
+    val *= scale;
+    dst[i] = accum ? dst[i] + val : val;
+  }
+}
+
+extern "C" int bts_flip_affine(const float* src, float* dst, const float* mean, const float* stdv, int N, int D, int H, int W,
+                               int C, int flip_mask, float scale, int accumulate, hipStream_t stream) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || (flip_mask & ~7)) return BTS_ERR_SHAPE;
+  if ((mean == nullptr) != (stdv == nullptr)) return BTS_ERR_SHAPE;
+  if (src == dst && flip_mask != 0) return BTS_ERR_UNSUPPORTED;  // an in-place flip would read overwritten voxels
+  const long total = (long)N * D * H * W * C;
+  long blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  (void)hipGetLastError(); hipLaunchKernelGGL(flip_affine_kernel, dim3((int)blocks), dim3(256), 0, stream, src, dst, mean, stdv,
+                     (long)N * D * H * W, D, H, W, C, flip_mask, scale, accumulate);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+// y = prob * bmask (test.py:154-155) and the label map the script intends (its argmax is commented out, :157-158):
+// label = argmax_c + 1, values >= 3 become 4 (test.py:259-261), 0 where the voxel is masked out or no class reaches
+// `threshold`.  First maximum wins ties (tf.argmax / np.argmax convention).
+__global__ void tta_finish_kernel(const float* __restrict__ prob, const float* __restrict__ bmask, float* y, uint8_t* labels,
+                                  long nvox, int C, float threshold) {
+  for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < nvox; v += (long)gridDim.x * blockDim.x) {
+    const float m = bmask[v];
+    float best = -1.f;
+    int arg = 0;
+    for (int c = 0; c < C; ++c) {
+      const float pv = prob[v * C + c] * m;
+      if (y) y[v * C + c] = pv;
+      if (pv > best) { best = pv; arg = c; }
+    }
+    if (labels) {
+      int lbl = arg + 1;
+      if (lbl >= 3) lbl = 4;
+      if (m == 0.f || best < threshold) lbl = 0;
+      labels[v] = (uint8_t)lbl;
+    }
+  }
+}
+
+extern "C" int bts_tta_finish(const float* prob, const float* bmask, float* y, uint8_t* labels, long nvox, int C,
+                              float threshold, hipStream_t stream) {
+  if (nvox <= 0 || C <= 0 || C > 250) return BTS_ERR_SHAPE;
+  long blocks = (nvox + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  (void)hipGetLastError(); hipLaunchKernelGGL(tta_finish_kernel, dim3((int)blocks), dim3(256), 0, stream, prob, bmask, y, labels, nvox, C,
+                     threshold);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}

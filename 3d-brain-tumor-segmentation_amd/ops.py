@@ -458,3 +458,29 @@ def l2_reg_bwd(params_flat, grads_flat, ranges, gscale=None):
 def adam_tf_step(p, g, m, v, lr_t, beta1, beta2, eps, gmul=1.0):
     lib().call('bts_adam_tf_step', _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr_t), float(beta1), float(beta2),
                float(eps), float(gmul), _stream())
+
+
+# ---- full-volume inference helpers ----
+def flip_affine(src, flip_mask=0, mean=None, std=None, scale=1.0, out=None, accumulate=False):
+    """out (+)= scale * t(flip(src)); flip_mask bits 4|2|1 = reverse D|H|W; t = (v - mean[c]) / std[c] when given"""
+    _check(src, 'src')
+    if not src.is_contiguous():
+        raise ValueError('flip_affine: src must be a dense NDHWC tensor')
+    n, d, h, w, c = src.shape
+    if out is None:
+        if accumulate:
+            raise ValueError('flip_affine: accumulate needs an output tensor')
+        out = torch.empty_like(src)
+    lib().call('bts_flip_affine', _p(src), _p(out), _p(mean), _p(std), n, d, h, w, c, int(flip_mask), float(scale),
+               1 if accumulate else 0, _stream())
+    return out
+
+
+def tta_finish(prob, bmask, threshold=0.5, want_probabilities=True, want_labels=True):
+    """-> (prob * bmask, uint8 label map): argmax + 1, >= 3 -> 4, 0 where masked out / below threshold"""
+    n, d, h, w, c = prob.shape
+    y = torch.empty_like(prob) if want_probabilities else None
+    labels = torch.empty((n, d, h, w), dtype=torch.uint8, device=prob.device) if want_labels else None
+    lib().call('bts_tta_finish', _p(prob.contiguous()), _p(bmask.contiguous()), _p(y), _p(labels), n * d * h * w, c,
+               float(threshold), _stream())
+    return y, labels

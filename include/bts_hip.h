@@ -157,6 +157,17 @@ int bts_l2_reg_bwd(const float* params, float* grads, const long* off, const lon
 int bts_adam_tf_step(float* p, const float* g, float* m, float* v, long n, float lr_t, float beta1, float beta2, float eps,
                      float gmul, bts_stream_t stream);
 
+/* ===== full-volume inference helpers (test.py:95-151,259-261) ===== */
+/* dst (+)= scale * t(flip(src)) on dense NDHWC tensors; flip_mask bits 4|2|1 reverse D|H|W (tf.reverse, test.py:139,142);
+ * mean/stdv (C floats, both or neither): t(v) = (v - mean[c]) / std[c] (test.py:111), identity when NULL. src != dst
+ * unless flip_mask == 0. */
+int bts_flip_affine(const float* src, float* dst, const float* mean, const float* stdv, int N, int D, int H, int W, int C,
+                    int flip_mask, float scale, int accumulate, bts_stream_t stream);
+/* y = prob * bmask (test.py:154-155; bmask one float per voxel) and/or the label map the script intends: argmax_c + 1,
+ * values >= 3 -> 4 (test.py:259-261), 0 where masked out or below `threshold`.  y and labels may each be NULL. */
+int bts_tta_finish(const float* prob, const float* bmask, float* y, uint8_t* labels, long nvox, int C, float threshold,
+                   bts_stream_t stream);
+
 /* library identification */
 const char* bts_version(void);
 

@@ -451,3 +451,49 @@ def synthetic_batch(n, crop, in_ch=2, out_ch=3, seed=1234, dropout_rate=0.2, lat
     eps = rng.standard_normal((n, latent)).astype(np.float32)
     tt = lambda a: torch.from_numpy(a).to(dtype)
     return tt(x), tt(y), tt(mask), tt(eps)
+
+
+# ---- full-volume inference wrapper (test.py:78-178,259-261) -------------------------------------------
+def pad_to_spatial_res(res, x, mask):
+    """test.py:164-178: append `res - (size % res)` zeros per spatial axis (a full block when already a multiple)"""
+    shape = list(x.shape[:-1])
+    pad = [res - (s % res) for s in shape]
+    xp = torch.nn.functional.pad(x, (0, 0, 0, pad[2], 0, pad[1], 0, pad[0]))
+    mp = torch.nn.functional.pad(mask, (0, 0, 0, pad[2], 0, pad[1], 0, pad[0]))
+    return xp, mp, shape
+
+
+def tta_augment_axes(spatial_tta=True):
+    """test.py:95-103 verbatim (channels_last: spatial axes 1,2,3 of the batched tensor)"""
+    spatial_axes = [1, 2, 3]
+    if not spatial_tta:
+        return [[]]
+    out = [list(spatial_axes), []]
+    for axis in spatial_axes:
+        pairs = list(spatial_axes)
+        pairs.remove(axis)
+        out.append([axis])
+        out.append(pairs)
+    return out
+
+
+def tta_predict(x, bmask, P, cfg, mean, std, spatial_tta=True):
+    """test.py:109-155 without channel TTA: normalise, for every flip set run the model (training=False,
+    inference=True), un-flip, average, multiply by the brain mask.  x: (D,H,W,C), bmask: (D,H,W,1) -> (D,H,W,out_ch)"""
+    xn = ((x - mean) / std).unsqueeze(0)
+    ys = []
+    for flip in tta_augment_axes(spatial_tta):
+        aug = torch.flip(xn, dims=flip) if flip else xn
+        y = model(aug, P, cfg, training=False, inference=True)[0]
+        ys.append(torch.flip(y, dims=flip) if flip else y)
+    y = torch.cat(ys, dim=0).mean(dim=0, keepdim=True)
+    return (y * bmask.unsqueeze(0))[0]
+
+
+def tta_labels(y, bmask, threshold=0.5):
+    """the label map test.py:157-158,259-261 intends: argmax + 1, values >= 3 -> 4, 0 where masked / below threshold"""
+    best, arg = y.max(dim=-1)
+    lab = arg + 1
+    lab = torch.where(lab >= 3, torch.full_like(lab, 4), lab)
+    lab = torch.where((bmask[..., 0] == 0) | (best < threshold), torch.zeros_like(lab), lab)
+    return lab.to(torch.uint8)

@@ -1,0 +1,95 @@
+"""-m gpu: full-volume inference wrapper -- the flip / normalise / accumulate and mask / label kernels
+against torch, and the whole pad -> 8-way flip TTA -> mean -> mask -> labels pipeline against the fp64 oracle."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import torch_ref as R  # noqa: E402
+
+
+def dev():
+    return torch.device('cuda', 0)
+
+
+def randomised_params(cfg, crop, seed):
+    """oracle ParamSet with every gamma/beta/bias randomised (gamma_2 = 0 at init would hide the conv branch: F6)"""
+    P = R.build_params(cfg, crop, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    for k in P:
+        if k.endswith('_b'):
+            P[k] = torch.randn(P[k].shape, generator=g, dtype=torch.float64) * 0.1
+        if k.endswith('_g'):
+            P[k] = 1.0 + torch.randn(P[k].shape, generator=g, dtype=torch.float64) * 0.3
+    for k in P:  # fp32-representable values so both sides see identical inputs
+        P[k] = P[k].float().double()
+    return P
+
+
+@pytest.mark.parametrize('shape', [(1, 4, 6, 8, 4), (2, 3, 5, 7, 3), (1, 1, 2, 9, 2)])
+def test_flip_affine_all_masks(shape):
+    import bts_amd  # noqa: F401
+    from bts_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(shape, generator=g)
+    mean, std = torch.randn(shape[-1], generator=g), torch.rand(shape[-1], generator=g) + 0.5
+    xg = x.to(dev())
+    for flip in range(8):
+        dims = [a for a, b in ((1, 4), (2, 2), (3, 1)) if flip & b]
+        ref = torch.flip(x, dims) if dims else x
+        out = ops.flip_affine(xg, flip)
+        assert torch.equal(out.cpu(), ref), 'plain flip %d' % flip
+        outn = ops.flip_affine(xg, flip, mean.to(dev()), std.to(dev()))
+        assert torch.allclose(outn.cpu(), (ref - mean) / std, rtol=1e-6, atol=1e-6)
+        acc = torch.full(shape, 0.5, device=dev())
+        ops.flip_affine(xg, flip, scale=0.125, out=acc, accumulate=True)
+        assert torch.allclose(acc.cpu(), 0.5 + 0.125 * ref, rtol=1e-6, atol=1e-7)
+    with pytest.raises(RuntimeError):
+        ops.flip_affine(xg, 1, out=xg)        # in-place flip is refused
+
+
+def test_tta_finish_labels_bit_exact():
+    import bts_amd  # noqa: F401
+    from bts_amd import ops
+    g = torch.Generator().manual_seed(4)
+    p = torch.rand((2, 5, 6, 7, 3), generator=g)
+    p[0, 0, 0, 0] = torch.tensor([0.6, 0.6, 0.1])      # tie: first maximum wins
+    bm = (torch.rand((2, 5, 6, 7, 1), generator=g) > 0.3).float()
+    y, lab = ops.tta_finish(p.to(dev()), bm.to(dev()), 0.5)
+    assert torch.equal(y.cpu(), p * bm)
+    assert torch.equal(lab.cpu(), R.tta_labels(p * bm, bm, 0.5))
+    assert int(lab[0, 0, 0, 0]) == (1 if bm[0, 0, 0, 0, 0] else 0)
+
+
+@pytest.mark.parametrize('kw,vol,res', [(dict(base_filters=4, groups=2, reduction=2, depth=2), (5, 6, 7), 8),
+                                        (dict(base_filters=8, groups=2, reduction=2, depth=3), (13, 9, 16), 8)])
+def test_segment_volume_matches_oracle(kw, vol, res):
+    import bts_amd  # noqa: F401
+    from bts_amd import infer
+    from bts_amd.model import Model
+    cfg = R.default_config(**kw)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(vol + (2,), generator=g) * 40.0 + 100.0
+    mask = (torch.rand(vol + (1,), generator=g) > 0.15).float()
+    x = x * mask
+    mean, std = torch.tensor([95.0, 110.0]), torch.tensor([35.0, 45.0])
+    xp, mp, orig = R.pad_to_spatial_res(res, x.double(), mask.double())
+    P = randomised_params(cfg, tuple(xp.shape[:3]), seed=5)
+    y_ref = R.tta_predict(xp, mp, P, cfg, mean.double(), std.double())[:orig[0], :orig[1], :orig[2]]
+    lab_ref = R.tta_labels(y_ref, mask.double(), 0.5)
+
+    m = Model(**kw)
+    m.build((1,) + tuple(xp.shape[:3]) + (2,))
+    m.set_weights_from(P)
+    y, lab = infer.segment_volume(m, x.to(dev()), mask.to(dev()), mean, std, res)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == vol + (3,) and tuple(lab.shape) == vol and lab.dtype == torch.uint8
+    err = float((y.double().cpu() - y_ref).abs().max())
+    assert err <= 1e-4, 'TTA probabilities: max abs err %.3e' % err
+    # labels bit-exact wherever the decision is not within rounding of a tie / the threshold
+    best = y_ref.max(dim=-1).values
+    top2 = torch.topk(y_ref, 2, dim=-1).values
+    amb = ((best - 0.5).abs() < 1e-4) | ((top2[..., 0] - top2[..., 1]) < 1e-4)
+    bad = (lab.cpu() != lab_ref) & ~amb
+    assert int(bad.sum()) == 0, '%d label mismatches outside the ambiguous set (%d ambiguous)' % (int(bad.sum()), int(amb.sum()))
+    assert set(lab.cpu().unique().tolist()) <= {0, 1, 2, 4}
