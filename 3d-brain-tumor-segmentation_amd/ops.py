@@ -484,3 +484,32 @@ def tta_finish(prob, bmask, threshold=0.5, want_probabilities=True, want_labels=
     lib().call('bts_tta_finish', _p(prob.contiguous()), _p(bmask.contiguous()), _p(y), _p(labels), n * d * h * w, c,
                float(threshold), _stream())
     return y, labels
+
+
+# ---- training-time augmentation on the device ----
+def channel_moments(x):
+    """per-channel (mean, population variance) over all voxels of a dense (..., C) tensor, C <= 16 -> two (C,) tensors"""
+    _check(x, 'x')
+    c = x.shape[-1]
+    nvox = x.numel() // c
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    var = torch.empty(c, dtype=torch.float32, device=x.device)
+    nb = lib().query('bts_channel_moments_workspace', c)
+    ws = workspace(nb, x.device)
+    lib().call('bts_channel_moments', _p(x.contiguous()), _p(mean), _p(var), _p(ws), nb, nvox, c, c, _stream())
+    return mean, var
+
+
+def augment_crop(x, y, var, crop, offsets, flip_mask, shift, scale, out_ch):
+    """x: (S0,S1,S2,C), y: (S0,S1,S2) or (S0,S1,S2,1) float labels, var: (C,) device tensor; shift/scale: C python floats
+    -> (x_out (T0,T1,T2,C), y_out (T0,T1,T2,out_ch))"""
+    s0, s1, s2, c = x.shape
+    t0, t1, t2 = crop
+    xo = torch.empty((t0, t1, t2, c), dtype=torch.float32, device=x.device)
+    yo = torch.empty((t0, t1, t2, out_ch), dtype=torch.float32, device=x.device)
+    sh = (ctypes.c_float * c)(*[float(v) for v in shift])
+    sc = (ctypes.c_float * c)(*[float(v) for v in scale])
+    lib().call('bts_augment_crop', _p(x.contiguous()), _p(y.contiguous()), _p(var), _p(xo), _p(yo), s0, s1, s2, c, t0, t1, t2,
+               int(offsets[0]), int(offsets[1]), int(offsets[2]), int(flip_mask), ctypes.cast(sh, ctypes.c_void_p),
+               ctypes.cast(sc, ctypes.c_void_p), int(out_ch), _stream())
+    return xo, yo

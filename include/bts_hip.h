@@ -168,6 +168,19 @@ int bts_flip_affine(const float* src, float* dst, const float* mean, const float
 int bts_tta_finish(const float* prob, const float* bmask, float* y, uint8_t* labels, long nvox, int C, float threshold,
                    bts_stream_t stream);
 
+/* ===== training-time augmentation on the device (train.py:14-49) ===== */
+/* per-channel mean / population variance of a (nvox, C) tensor with voxel stride ld (tf.nn.moments, train.py:18);
+ * C <= 16; mean may be NULL; fp64 partials, fixed-order combine */
+long bts_channel_moments_workspace(int C);
+int bts_channel_moments(const float* x, float* mean, float* var, void* workspace, long workspace_bytes, long nvox, int C,
+                        int ld, bts_stream_t stream);
+/* xo = crop+flip of (x + shift[c]*sqrt(var[c])) * scale[c] (train.py:19-34), yo = one-hot of the cropped+flipped labels
+ * without the background channel (train.py:38-41).  x: (S0,S1,S2,C), y: (S0,S1,S2) float labels, var: C device floats,
+ * shift/scale: C HOST floats (the caller's random draws), window origin (o0,o1,o2), flip_mask bits 4|2|1 = axes 0|1|2. */
+int bts_augment_crop(const float* x, const float* y, const float* var, float* xo, float* yo, int S0, int S1, int S2, int C,
+                     int T0, int T1, int T2, int o0, int o1, int o2, int flip_mask, const float* shift, const float* scale,
+                     int out_ch, bts_stream_t stream);
+
 /* library identification */
 const char* bts_version(void);
 

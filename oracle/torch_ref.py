@@ -497,3 +497,22 @@ def tta_labels(y, bmask, threshold=0.5):
     lab = torch.where(lab >= 3, torch.full_like(lab, 4), lab)
     lab = torch.where((bmask[..., 0] == 0) | (best < threshold), torch.zeros_like(lab), lab)
     return lab.to(torch.uint8)
+
+
+# ---- training-time augmentation (train.py:14-49) ------------------------------------------------------
+def augment_example(x, y, crop_size, out_ch, shift, scale, offsets, flips):
+    """`parse_example` after the proto parse, with the random draws as arguments.  x: (h,w,d,c), y: (h,w,d,1)."""
+    c = x.shape[-1]
+    var = x.var(dim=(0, 1, 2), unbiased=False, keepdim=True)                       # tf.nn.moments (:18)
+    x = x + torch.as_tensor(shift, dtype=x.dtype).reshape(1, 1, 1, c) * torch.sqrt(var)   # :21
+    x = x * torch.as_tensor(scale, dtype=x.dtype).reshape(1, 1, 1, c)                     # :22
+    xy = torch.cat([x, y.to(x.dtype)], dim=-1)                                      # :25
+    o = offsets
+    xy = xy[o[0]:o[0] + crop_size[0], o[1]:o[1] + crop_size[1], o[2]:o[2] + crop_size[2]]   # :26
+    for axis in (0, 1, 2):                                                          # :29-33
+        if flips[axis]:
+            xy = torch.flip(xy, dims=[axis])
+    x, y = xy[..., :c], xy[..., c:]
+    lab = y[..., 0].to(torch.int64)                                                 # :38 (cast truncates)
+    onehot = torch.nn.functional.one_hot(lab.clamp(0, out_ch), out_ch + 1).to(x.dtype)   # :39
+    return x, onehot[..., 1:]                                                       # :40
