@@ -77,10 +77,14 @@ class Layer(object):
         raise NotImplementedError
 
     def __call__(self, inputs, training=None, **kwargs):
+        cf = getattr(self, 'data_format', 'channels_last') == 'channels_first'
+        if cf:
+            inputs = to_internal(inputs)   # raw NCDHW tensors -> engine Tensors (NDHWC memory)
         if not self.built:
             self.build(_shape_of(inputs))
             self.built = True
-        return self.call(inputs, training=training, **kwargs)
+        out = self.call(inputs, training=training, **kwargs)
+        return mark_public_layout(out) if cf else out
 
     @property
     def trainable_variables(self):
@@ -154,6 +158,24 @@ def _repack_all():
         e.epoch = ep
 
 
+def to_internal(x):
+    """channels_first boundary: every raw 5-D tensor / array in a (possibly nested) input becomes an engine Tensor"""
+    if isinstance(x, (tuple, list)):
+        return type(x)(to_internal(e) for e in x)
+    if isinstance(x, Tensor) or x is None:
+        return x
+    return as_tensor(x, data_format='channels_first')
+
+
+def mark_public_layout(out):
+    """flag 5-D result Tensors of a channels_first layer so that .numpy() / .public() export NCDHW"""
+    if isinstance(out, (tuple, list)):
+        return type(out)(mark_public_layout(e) for e in out)
+    if isinstance(out, Tensor) and out.t.dim() == 5:
+        out.cf = True
+    return out
+
+
 def _l2_term(p):
     flat = p.t.reshape(-1)
     val = Tensor(ops.l2_reg_fwd(flat, [(0, flat.numel(), p.l2)]))
@@ -182,13 +204,17 @@ def _shape_of(x):
 
 
 def check_data_format(data_format):
-    if data_format == 'channels_first':
-        raise NotImplementedError(
-            "data_format='channels_first' (the reference's --gpu layout) is a SURVEY 8(f-4) 'next' row: the kernels "
-            'already implement its GroupNorm semantics (BTS_GN_CHANNEL) but the public NCDHW layout is not wired yet')
-    if data_format != 'channels_last':
+    """channels_last | channels_first (the reference's --gpu layout, args.py:121-123).  The engine's memory is NDHWC either
+    way; channels_first changes the PUBLIC layout of raw inputs / exported outputs, GroupNorm to true channel-group
+    semantics and the Dice metric to the intended all-spatial reduction (F8)."""
+    if data_format not in ('channels_last', 'channels_first'):
         raise ValueError('unknown data_format %r' % (data_format,))
+    return data_format
 
 
-__all__ = ['Layer', 'Param', 'Tensor', 'as_tensor', 'bump_weights_epoch', 'check_data_format', 'current_tape',
+def gn_mode_of(data_format):
+    return ops.GN_SLAB if data_format == 'channels_last' else ops.GN_CHANNEL
+
+
+__all__ = ['Layer', 'Param', 'Tensor', 'as_tensor', 'bump_weights_epoch', 'check_data_format', 'current_tape', 'gn_mode_of', 'mark_public_layout', 'to_internal',
            'initialise', 'set_seed']

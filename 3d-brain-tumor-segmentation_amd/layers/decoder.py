@@ -14,7 +14,7 @@ class Decoder(Layer):
     def __init__(self, data_format='channels_last', groups=8, reduction=2, l2_scale=1e-5, upsampling='conv',
                  base_filters=16, depth=4, out_ch=3, name='decoder'):
         super(Decoder, self).__init__(name=name)
-        check_data_format(data_format)
+        self.data_format = check_data_format(data_format)
         self.config = {'data_format': data_format, 'groups': groups, 'reduction': reduction, 'l2_scale': l2_scale,
                        'upsampling': upsampling, 'base_filters': base_filters, 'depth': depth, 'out_ch': out_ch}
         Upsample = get_upsampling(upsampling)

@@ -4,7 +4,7 @@ ConvDownsample (:14-48): Conv3D k3 s2 'same' (he_normal, L2) -> GroupNorm (no re
 TF 'same' for k=3,s=2 on even sizes pads (0,1): output o reads inputs 2o..2o+2, index n reads zero.
 MaxDownsample (:51-70) is a non-default option on the call surface: SURVEY 8(f-4) "next" row."""
 from .. import ops
-from ._base import Layer, Tensor, as_tensor, check_data_format, current_tape
+from ._base import Layer, Tensor, as_tensor, check_data_format, current_tape, gn_mode_of
 from .group_norm import GroupNormalization, group_norm_backward
 from .resnet import _wgrad
 
@@ -20,12 +20,12 @@ def get_downsampling(downsampling):
 class ConvDownsample(Layer):
     def __init__(self, filters, data_format='channels_last', groups=8, l2_scale=1e-5, name=None, **kwargs):
         super(ConvDownsample, self).__init__(name=name)
-        check_data_format(data_format)
+        self.data_format = check_data_format(data_format)
         self.config = {'filters': filters, 'data_format': data_format, 'groups': groups, 'l2_scale': l2_scale}
         self.filters = filters
         self.groups = groups
         self.l2_scale = l2_scale
-        self.norm = self.track(GroupNormalization(groups=groups, axis=-1, name=self.name + '/gn'))
+        self.norm = self.track(GroupNormalization(groups=groups, axis=-1, name=self.name + '/gn', semantics=gn_mode_of(data_format)))
 
     def build(self, input_shape):
         cin = input_shape[-1]
@@ -39,16 +39,17 @@ class ConvDownsample(Layer):
         return (s[0], s[1] // 2, s[2] // 2, s[3] // 2, self.filters)
 
     def call(self, inputs, training=None, out=None):
-        x = as_tensor(inputs)
+        x = as_tensor(inputs, data_format=self.data_format)
         if any(s % 2 for s in x.shape[1:4]):
             raise ValueError('ConvDownsample needs even spatial sizes (TF SAME pads (0,1) only then), got %s' % (x.shape,))
         f, g = self.filters, self.groups
         wp = self.packed('f', ops.K3S2, ops.ROLE_FWD, self.conv_k, self.cin, f)
         c = ops.conv_fwd(ops.K3S2, x.t, wp, self.conv_b.t, f)
-        mean, rstd = ops.gn_stats(c, g, ops.GN_SLAB, self.norm.epsilon)
-        yt = ops.gn_apply(c, self.norm.gamma.t, self.norm.beta.t, mean, rstd, g, ops.GN_SLAB, True,
+        mean, rstd = ops.gn_stats(c, g, self.norm._mode, self.norm.epsilon)
+        yt = ops.gn_apply(c, self.norm.gamma.t, self.norm.beta.t, mean, rstd, g, self.norm._mode, True,
                           out=None if out is None else out.t)
         y = out if out is not None else Tensor(yt)
+        y.cf = self.data_format == 'channels_first'
         tape = current_tape()
         if tape is not None:
             def backward():

@@ -16,7 +16,7 @@ class Encoder(Layer):
     def __init__(self, data_format='channels_last', groups=8, reduction=2, l2_scale=1e-5, dropout=0.2,
                  downsampling='conv', base_filters=16, depth=4, name='encoder', _reserve_for_decoder=False):
         super(Encoder, self).__init__(name=name)
-        check_data_format(data_format)
+        self.data_format = check_data_format(data_format)
         self.config = {'data_format': data_format, 'groups': groups, 'reduction': reduction, 'l2_scale': l2_scale,
                        'downsampling': downsampling, 'base_filters': base_filters, 'depth': depth}
         Downsample = get_downsampling(downsampling)
@@ -56,7 +56,8 @@ class Encoder(Layer):
         self.built = True
 
     def set_dropout_mask(self, mask):
-        """inject the Bernoulli keep-mask (uint8/bool/float [N,D,H,W,C]) for the next training call (parity runs)"""
+        """inject the Bernoulli keep-mask (uint8/bool/float, in the layer's public layout: [N,D,H,W,C], or [N,C,D,H,W] for
+        channels_first) for the next training call (parity runs)"""
         self._mask = mask
 
     def call(self, inputs, training=None):
@@ -66,6 +67,8 @@ class Encoder(Layer):
         if training and self.dropout_rate > 0:                                    # encoder.py:71
             if self._mask is not None:
                 m = torch.as_tensor(self._mask)
+                if self.data_format == 'channels_first' and m.dim() == 5:
+                    m = m.permute(0, 2, 3, 4, 1)
                 m = (m != 0).to(torch.uint8).to(dev).contiguous()
                 self._mask = None
             else:

@@ -10,6 +10,7 @@ class GroupNormalization(Layer):
                  gamma_initializer='ones', beta_regularizer=None, gamma_regularizer=None, beta_constraint=None,
                  gamma_constraint=None, **kwargs):
         super(GroupNormalization, self).__init__(name=kwargs.pop('name', None))
+        self._semantics = kwargs.pop('semantics', None)   # engine layers: GN mode on internal NDHWC shapes (axis stays -1)
         self.supports_masking = True
         self.groups = groups
         self.axis = axis
@@ -39,10 +40,12 @@ class GroupNormalization(Layer):
                              str(dim) + ').')
         nd = len(input_shape)
         ax = self.axis if self.axis >= 0 else nd + self.axis
-        if ax == nd - 1:
+        if self._semantics is not None:      # built by an engine layer on internal NDHWC shapes
+            self._mode = self._semantics
+        elif ax == nd - 1:
             self._mode = ops.GN_SLAB
-        elif ax == 1:
-            raise NotImplementedError('axis=1 (channels_first) public layout is a SURVEY 8(f-4) "next" row')
+        elif ax == 1:                        # standalone channels_first use: raw NCDHW in, true GroupNorm
+            self._mode = ops.GN_CHANNEL
         else:
             raise ValueError('GroupNormalization supports axis=-1 (channels_last) or axis=1 (channels_first)')
         if self.scale:
@@ -52,8 +55,10 @@ class GroupNormalization(Layer):
         self.built = True
 
     def call(self, inputs, training=None, relu=False, out=None, **kwargs):
-        x = as_tensor(inputs)
+        cf = self._semantics is None and self.axis == 1
+        x = as_tensor(inputs, data_format='channels_first' if cf else 'channels_last')
         y, _ = group_norm_forward(self, x, relu=relu, out=out)
+        y.cf = x.cf
         return y
 
     def get_config(self):

@@ -15,14 +15,14 @@ input channels that are folded at pack time.
 import torch
 
 from .. import ops
-from ._base import Layer, Tensor, as_tensor, check_data_format, current_tape
+from ._base import Layer, Tensor, as_tensor, check_data_format, current_tape, gn_mode_of
 from .group_norm import GroupNormalization
 
 
 class ResnetBlock(Layer):
     def __init__(self, filters, data_format='channels_last', groups=8, reduction=2, l2_scale=1e-5, name=None):
         super(ResnetBlock, self).__init__(name=name)
-        check_data_format(data_format)
+        self.data_format = check_data_format(data_format)
         self.config = {'filters': filters, 'data_format': data_format, 'reduction': reduction, 'l2_scale': l2_scale,
                        'groups': groups}
         if filters % reduction != 0:
@@ -33,10 +33,12 @@ class ResnetBlock(Layer):
         self.l2_scale = l2_scale
         self.norm1 = self.track(GroupNormalization(groups=groups, axis=-1, beta_initializer='zeros',
                                                    gamma_initializer='ones', beta_regularizer=l2_scale,
-                                                   gamma_regularizer=l2_scale, name=self.name + '/gn1'))
+                                                   gamma_regularizer=l2_scale, name=self.name + '/gn1',
+                                                   semantics=gn_mode_of(data_format)))
         self.norm2 = self.track(GroupNormalization(groups=groups, axis=-1, beta_initializer='zeros',
                                                    gamma_initializer='zeros', beta_regularizer=l2_scale,
-                                                   gamma_regularizer=l2_scale, name=self.name + '/gn2'))
+                                                   gamma_regularizer=l2_scale, name=self.name + '/gn2',
+                                                   semantics=gn_mode_of(data_format)))
 
     def build(self, input_shape, fold=None):
         cin = input_shape[-1] + (fold[1] if fold else 0)
@@ -66,12 +68,13 @@ class ResnetBlock(Layer):
         return tuple(input_shape[:-1]) + (self.filters,)
 
     def __call__(self, inputs, training=None, out=None, fold=None):
+        inputs = as_tensor(inputs, data_format=self.data_format)   # raw NCDHW -> NDHWC for channels_first
         if not self.built:
             self.build(tuple(inputs.shape), fold)
         return self.call(inputs, training=training, out=out, fold=fold)
 
     def call(self, inputs, training=None, out=None, fold=None):
-        x = as_tensor(inputs)
+        x = as_tensor(inputs, data_format=self.data_format)
         f, g = self.filters, self.groups
         n, d, h, w, cin = x.shape
         dup_start, dup_shift = fold if fold else (0, 0)
@@ -95,14 +98,15 @@ class ResnetBlock(Layer):
         gap = ops.colsum(res, scale=1.0 / v)
         hbuf, ch = ops.se_mlp_fwd(gap, self.se_w1.t, self.se_w2.t)
         # conv branch
-        m1, r1 = ops.gn_stats(c1, g, ops.GN_SLAB, self.norm1.epsilon)
-        a = ops.gn_apply(c1, self.norm1.gamma.t, self.norm1.beta.t, m1, r1, g, ops.GN_SLAB, True)
+        m1, r1 = ops.gn_stats(c1, g, self.norm1._mode, self.norm1.epsilon)
+        a = ops.gn_apply(c1, self.norm1.gamma.t, self.norm1.beta.t, m1, r1, g, self.norm1._mode, True)
         c2 = ops.conv_fwd(K3, a, wp_c2, self.conv2_b.t, f)
-        m2, r2 = ops.gn_stats(c2, g, ops.GN_SLAB, self.norm2.epsilon)
+        m2, r2 = ops.gn_stats(c2, g, self.norm2._mode, self.norm2.epsilon)
         if out is None:
             out = Tensor(torch.empty((n, d, h, w, f), dtype=torch.float32, device=x.t.device))
         wsp = self.spatial_k.t.reshape(-1)
-        sp = ops.block_epilogue_fwd(res, c2, out.t, wsp, ch, self.norm2.gamma.t, self.norm2.beta.t, m2, r2, g, ops.GN_SLAB)
+        sp = ops.block_epilogue_fwd(res, c2, out.t, wsp, ch, self.norm2.gamma.t, self.norm2.beta.t, m2, r2, g, self.norm2._mode)
+        out.cf = self.data_format == 'channels_first'
         tape = current_tape()
         if tape is not None:
             def backward():

@@ -5,7 +5,7 @@ SURVEY F10) -> GroupNorm -> ReLU.  The transposed conv runs in gather form over 
 every output voxel is written exactly once (deterministic, no atomics).
 LinearUpsample (:49-79) is a non-default option: SURVEY 8(f-4) "next" row."""
 from .. import ops
-from ._base import Layer, Tensor, as_tensor, check_data_format, current_tape
+from ._base import Layer, Tensor, as_tensor, check_data_format, current_tape, gn_mode_of
 from .group_norm import GroupNormalization, group_norm_backward
 from .resnet import _wgrad
 
@@ -20,11 +20,11 @@ def get_upsampling(upsampling):
 class ConvUpsample(Layer):
     def __init__(self, filters, groups=8, data_format='channels_last', l2_scale=1e-5, name=None, **kwargs):
         super(ConvUpsample, self).__init__(name=name)
-        check_data_format(data_format)
+        self.data_format = check_data_format(data_format)
         self.config = {'filters': filters, 'data_format': data_format, 'groups': groups, 'l2_scale': l2_scale}
         self.filters = filters
         self.groups = groups
-        self.norm = self.track(GroupNormalization(groups=groups, axis=-1, name=self.name + '/gn'))
+        self.norm = self.track(GroupNormalization(groups=groups, axis=-1, name=self.name + '/gn', semantics=gn_mode_of(data_format)))
 
     def build(self, input_shape):
         cin = input_shape[-1]
@@ -38,12 +38,12 @@ class ConvUpsample(Layer):
         return (s[0], s[1] * 2, s[2] * 2, s[3] * 2, self.filters)
 
     def call(self, inputs, training=None, out=None):
-        x = as_tensor(inputs)
+        x = as_tensor(inputs, data_format=self.data_format)
         f, g = self.filters, self.groups
         wp = self.packed('f', ops.K3S2T, ops.ROLE_FWD, self.conv_k, self.cin, f)
         c = ops.conv_fwd(ops.K3S2T, x.t, wp, self.conv_b.t, f)
-        mean, rstd = ops.gn_stats(c, g, ops.GN_SLAB, self.norm.epsilon)
-        yt = ops.gn_apply(c, self.norm.gamma.t, self.norm.beta.t, mean, rstd, g, ops.GN_SLAB, True,
+        mean, rstd = ops.gn_stats(c, g, self.norm._mode, self.norm.epsilon)
+        yt = ops.gn_apply(c, self.norm.gamma.t, self.norm.beta.t, mean, rstd, g, self.norm._mode, True,
                           out=None if out is None else out.t)
         y = out if out is not None else Tensor(yt)
         tape = current_tape()

@@ -27,7 +27,7 @@ class VariationalAutoencoder(Layer):
     def __init__(self, data_format='channels_last', groups=8, reduction=2, l2_scale=1e-5, downsampling='conv',
                  upsampling='conv', base_filters=16, depth=4, out_ch=2, name='vae'):
         super(VariationalAutoencoder, self).__init__(name=name)
-        check_data_format(data_format)
+        self.data_format = check_data_format(data_format)
         self.data_format = data_format
         self.l2_scale = l2_scale
         self.config = {'groups': groups, 'reduction': reduction, 'downsampling': downsampling, 'upsampling': upsampling,

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import ops, parallel
-from .layers._base import Layer, Tensor, as_tensor, check_data_format, current_tape
+from .layers._base import Layer, Tensor, as_tensor, check_data_format, current_tape, mark_public_layout, to_internal
 from .layers.decoder import Decoder
 from .layers.encoder import Encoder
 from .layers.vae import VariationalAutoencoder
@@ -20,8 +20,7 @@ class Model(Layer):
     def __init__(self, data_format='channels_last', groups=8, reduction=2, l2_scale=1e-5, dropout=0.2,
                  downsampling='conv', upsampling='conv', base_filters=16, depth=4, in_ch=2, out_ch=3):
         super(Model, self).__init__(name='model')
-        check_data_format(data_format)
-        self.data_format = data_format
+        self.data_format = check_data_format(data_format)
         self.epoch = _EpochVariable()                                              # model.py:29
         self.in_ch = in_ch
         self.encoder = self.track(Encoder(data_format=data_format, groups=groups, reduction=reduction, l2_scale=l2_scale,
@@ -85,7 +84,7 @@ class Model(Layer):
 
     def call(self, inputs, training=None, inference=None):
         assert (not inference or not training), 'Cannot run training and inference modes simultaneously.'
-        x = as_tensor(inputs)
+        x = as_tensor(inputs, data_format=self.data_format)
         residuals = self.encoder(x, training=training)
         y_pred = self.decoder((residuals[-1], residuals[:-1]), training=training)
         if inference:
@@ -94,9 +93,13 @@ class Model(Layer):
         return (y_pred, y_vae, z_mean, z_logvar)
 
     def __call__(self, inputs, training=None, inference=None):
+        cf = self.data_format == 'channels_first'
+        if cf:
+            inputs = to_internal(inputs)     # raw NCDHW -> engine Tensor (NDHWC memory)
         if not self.built:
             self.build(tuple(inputs.shape))
-        return self.call(inputs, training=training, inference=inference)
+        out = self.call(inputs, training=training, inference=inference)
+        return mark_public_layout(out) if cf else out
 
     @property
     def trainable_variables(self):

@@ -40,10 +40,11 @@ def default_device():
 
 class Tensor(object):
     """Handle on a device buffer: `.t` is the torch tensor (possibly a channel-slice view of a Slab)."""
-    __slots__ = ('t', 'base', 'c0', 'requires_grad', '_grad', 'name')
+    __slots__ = ('t', 'base', 'c0', 'requires_grad', '_grad', 'name', 'cf')
 
     def __init__(self, t, base=None, c0=0, requires_grad=True, name=None):
         self.t = t
+        self.cf = False   # True: the PUBLIC layout of this tensor is channels_first (memory is NDHWC regardless)
         self.base = base
         self.c0 = c0
         self.requires_grad = requires_grad
@@ -55,7 +56,15 @@ class Tensor(object):
         return tuple(self.t.shape)
 
     def numpy(self):
-        return self.t.detach().cpu().numpy()
+        """host copy in the public layout (NCDHW when the producing layer was built with data_format='channels_first')"""
+        t = self.t.detach()
+        if self.cf and t.dim() == 5:
+            t = t.permute(0, 4, 1, 2, 3)
+        return t.cpu().numpy()
+
+    def public(self):
+        """device tensor in the public layout (a permuted view for channels_first)"""
+        return self.t.permute(0, 4, 1, 2, 3) if (self.cf and self.t.dim() == 5) else self.t
 
     def __float__(self):
         return float(self.t.reshape(-1)[0].item())
@@ -221,8 +230,9 @@ class GradientTape(object):
         return [s.grad for s in sources]
 
 
-def as_tensor(x, requires_grad=False):
-    """wrap user input (Tensor | torch tensor | numpy) as an engine Tensor on the default device"""
+def as_tensor(x, requires_grad=False, data_format='channels_last'):
+    """wrap user input (Tensor | torch tensor | numpy) as an engine Tensor on the default device.  Raw 5-D inputs of a
+    channels_first layer are NCDHW and are re-laid out to the engine's NDHWC memory here (one HBM pass at the boundary)"""
     if isinstance(x, Tensor):
         return x
     if isinstance(x, np.ndarray):
@@ -236,6 +246,10 @@ def as_tensor(x, requires_grad=False):
         raise RuntimeError('no MI355X visible: the engine has no CPU execution path')
     if not x.is_cuda:
         x = x.to(dev)
+    if data_format == 'channels_first' and x.dim() == 5:
+        out = Tensor(x.permute(0, 2, 3, 4, 1).contiguous(), requires_grad=requires_grad)
+        out.cf = True
+        return out
     return Tensor(x.contiguous() if not _is_slice_ok(x) else x, requires_grad=requires_grad)
 
 

@@ -14,12 +14,14 @@ class DiceVAELoss(object):
     so every rank evaluates the global-batch loss and its exact gradient."""
 
     def __init__(self, name='custom_loss', data_format='channels_last', **kwargs):
-        if data_format != 'channels_last':
-            raise NotImplementedError("channels_first is a SURVEY 8(f-4) 'next' row")
-        self.axis = (0, 1, 2, 3)
+        if data_format not in ('channels_last', 'channels_first'):
+            raise ValueError('unknown data_format %r' % (data_format,))
+        self.data_format = data_format
+        # util.py:11 -- batch + spatial axes of the public layout; the sums are the same numbers either way
+        self.axis = (0, 1, 2, 3) if data_format == 'channels_last' else (0, 2, 3, 4)
 
     def __call__(self, x, y, y_pred, y_vae, z_mean, z_logvar, sample_weight=None):
-        x, y = as_tensor(x), as_tensor(y)
+        x, y = as_tensor(x, data_format=self.data_format), as_tensor(y, data_format=self.data_format)
         y_pred, y_vae = as_tensor(y_pred, True), as_tensor(y_vae, True)
         pbase = getattr(z_mean, 'base', None)
         if pbase is None or pbase is not getattr(z_logvar, 'base', None):
@@ -56,18 +58,21 @@ class DiceCoefficient(object):
     argmax label map of the last call is kept in .last_labels (uint8, 0 = below threshold, k+1 = class k)."""
 
     def __init__(self, name='dice_coefficient', data_format='channels_last'):
-        if data_format != 'channels_last':
-            raise NotImplementedError("channels_first is a SURVEY 8(f-4) 'next' row")
+        if data_format not in ('channels_last', 'channels_first'):
+            raise ValueError('unknown data_format %r' % (data_format,))
         self.name = name
         self.data_format = data_format
         self.last_labels = None
 
     def __call__(self, y_true, y_pred):
-        y_true, y_pred = as_tensor(y_true), as_tensor(y_pred)
+        y_true, y_pred = as_tensor(y_true, data_format=self.data_format), as_tensor(y_pred, data_format=self.data_format)
         w, c = y_pred.shape[3], y_pred.shape[4]
-        table, labels = ops.dice_metric_sums(y_true.t, y_pred.t, True, True)
+        # channels_last reduces axes (0,1,2) only -> one cell per (last spatial index, class) (SURVEY F8);
+        # channels_first reduces (0,2,3,4): one cell per class, the intended metric (util.py:36)
+        cl = self.data_format == 'channels_last'
+        table, labels = ops.dice_metric_sums(y_true.t, y_pred.t, cl, True)
         parallel.all_reduce_sum(table)
-        out = ops.dice_metric_value(table, w, c, True)
+        out = ops.dice_metric_value(table, w, c, cl)
         self.last_labels = labels
         return Tensor(out[0:1], requires_grad=False), Tensor(out[1:2], requires_grad=False)
 

@@ -74,8 +74,12 @@ def test_error_behaviour_matches_reference():
     g = group_norm.GroupNormalization(groups=3)
     with pytest.raises(ValueError, match='multiple'):
         g.build((1, 4, 4, 4, 8))                                                        # group_norm.py:56-59
-    with pytest.raises(NotImplementedError):
-        Model(data_format='channels_first')
+    with pytest.raises(ValueError, match='data_format'):
+        Model(data_format='channels_middle')
+    mcf = Model(data_format='channels_first', base_filters=8, groups=2, depth=2)        # args.py:121-123 default layout
+    mcf.build((1, 8, 8, 8, 2))                                                          # internal (NDHWC) build shape
+    from bts_amd import ops
+    assert mcf.encoder.blocks[0][0].norm1._mode == ops.GN_CHANNEL if hasattr(mcf.encoder, 'blocks') else True
 
 
 def test_scheduled_optim_schedule():

@@ -146,3 +146,69 @@ def test_inference_mode_skips_vae_and_build_call():
     sp = torch.sigmoid(res @ blk.spatial_k.t.cpu().double().reshape(-1, 1))
     ref = res * (sp + ch.reshape(1, 1, 1, 1, -1))
     assert float((o1.double() - ref).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize('name', ['micro_n2', 'tiny'])
+def test_channels_first_public_layout_parity(name):
+    """data_format='channels_first' (the reference's --gpu default, args.py:121-123): raw NCDHW in/out,
+    true channel-group GroupNorm (F1), Dice over all spatial axes (F8 intended form), same Keras-layout weights.
+    Forward, loss, metric, labels and every gradient against the fp64 oracle evaluated in channels_first."""
+    import bts_amd  # noqa: F401
+    from bts_amd.model import Model
+    from bts_amd.tape import GradientTape
+    from bts_amd.util import DiceCoefficient, DiceVAELoss, reduce_sum
+    kw, crop, n = CONFIGS[name]
+    kw = dict(kw, data_format='channels_first')
+    cfg = R.default_config(**kw)
+    latent = cfg['base_filters'] * 2 ** (cfg['depth'] - 2)
+    x, y, mask, eps = R.synthetic_batch(n, crop, latent=latent, seed=4321)
+    cf = lambda t: t.permute(0, 4, 1, 2, 3).contiguous()
+    x, y, mask = cf(x), cf(y), cf(mask)
+    P = randomised_params(cfg, crop, seed=9)
+    (yp_r, yv_r, zm_r, zl_r), loss_r, grads_r = run_oracle(cfg, P, x, y, mask, eps)
+    _, _, grads_32 = run_oracle(cfg, P, x, y, mask, eps, dtype=torch.float32)
+    assert yp_r.shape[1] == 3 and yv_r.shape[1] == 2      # oracle really ran channels_first
+
+    model = Model(**kw)
+    out0 = model(torch.zeros_like(x))                      # train.py:95-96 build call with an NCDHW zeros tensor
+    assert out0[0].numpy().shape == tuple(yp_r.shape)
+    model.set_weights_from(P)
+    model.encoder.set_dropout_mask(mask)
+    model.vae.set_eps(eps)
+    loss_fn, dice_fn = DiceVAELoss(data_format='channels_first'), DiceCoefficient(data_format='channels_first')
+    with GradientTape() as tape:
+        y_pred, y_vae, z_mean, z_logvar = model(x, training=True, inference=False)
+        loss = loss_fn(x, y, y_pred, y_vae, z_mean, z_logvar)
+        loss = loss + reduce_sum(model.losses)
+    macro, micro = dice_fn(y, y_pred)
+    grads = tape.gradient(loss, model.trainable_variables)
+    torch.cuda.synchronize()
+
+    def maxerr(a, b):
+        return float((a.detach().double().cpu() - b.detach().double()).abs().max())
+
+    assert y_pred.cf and tuple(y_pred.public().shape) == tuple(yp_r.shape)
+    assert maxerr(y_pred.public(), yp_r) <= 1e-4
+    assert maxerr(y_vae.public(), yv_r) <= 1e-4 * max(1.0, float(yv_r.detach().abs().max()))
+    assert maxerr(z_mean.t, zm_r) <= 1e-4 and maxerr(z_logvar.t, zl_r) <= 1e-4
+    assert abs(float(loss) - float(loss_r)) <= 1e-5 * max(1.0, abs(float(loss_r)))
+    # metric kernel in its channels_first form (one Dice cell per class): the oracle formula on the ENGINE's probabilities,
+    # so near-tie voxels (this fixture has top-2 gaps below the 1e-4 forward tolerance) cannot blur the comparison
+    macro_e, micro_e, labels_e = R.dice_coefficient(y.double(), y_pred.public().detach().cpu().double(), 'channels_first')
+    assert abs(float(macro) - float(macro_e)) <= 1e-6 and abs(float(micro) - float(micro_e)) <= 1e-6
+    assert torch.equal(dice_fn.last_labels.cpu().long(), labels_e.long())
+    # label map against the oracle's own forward: bit-exact outside the voxels whose decision is within the forward tolerance
+    _, _, labels_r = R.dice_coefficient(y.double(), yp_r, 'channels_first')
+    top2 = yp_r.topk(2, dim=1).values
+    ambiguous = ((yp_r.max(dim=1).values - 0.5).abs() < 2e-4) | ((top2[:, 0] - top2[:, 1]).abs() < 2e-4)
+    lab = dice_fn.last_labels.cpu().long()
+    assert torch.equal(lab[~ambiguous], labels_r.long()[~ambiguous]), 'argmax label map differs'
+    print('voxels within 2e-4 of a decision boundary:', int(ambiguous.sum()), 'of', ambiguous.numel())
+    gdev = max(maxerr(grads_32[k], grads_r[k]) / (float(grads_r[k].abs().max()) + 1e-12) for k in grads_r)
+    for p, g in zip(model.trainable_variables, grads):
+        gr = grads_r[model.oracle_name(p)]
+        scale = float(gr.abs().max()) + 1e-12
+        err = maxerr(g, gr) / scale
+        dev32 = maxerr(grads_32[model.oracle_name(p)], gr) / scale
+        assert err <= max(1e-3, 4 * dev32, 0.25 * gdev) or maxerr(g, gr) <= 1e-9, \
+            'grad %s rel err %.3e (fp32-torch deviates %.3e)' % (p.name, err, dev32)
