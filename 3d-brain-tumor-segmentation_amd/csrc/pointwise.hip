@@ -241,3 +241,127 @@ extern "C" int bts_tta_finish(const float* prob, const float* bmask, float* y, u
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
+
+// ---- non-default samplers (downsample.py:51-70 MaxPooling3D 2/2; upsample.py:49-79 UpSampling3D 2 = nearest) ----------
+// x: (N,D,H,W,C) stride ldx (D,H,W even), y: (N,D/2,H/2,W/2,C) stride ldy; idx: window position 0..7 (dz*4+dy*2+dx) of the
+// FIRST maximum (strict > in window order), one byte per output element, dense.
+__global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* y, uint8_t* idx, long nout, int Do, int Ho, int Wo, int C,
+                                    int ldx, int ldy) {
+  const long total = nout * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long v = i / C;
+    const int wo = (int)(v % Wo); v /= Wo;
+    const int ho = (int)(v % Ho); v /= Ho;
+    const int dz = (int)(v % Do);
+    const long n = v / Do;
+    float best = 0.f;
+    int arg = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const long src = (((n * (2 * Do) + 2 * dz + (k >> 2)) * (2 * Ho) + 2 * ho + ((k >> 1) & 1)) * (2 * Wo) + 2 * wo + (k & 1));
+      const float val = x[src * ldx + c];
+      if (k == 0 || val > best) { best = val; arg = k; }
+    }
+    y[(i / C) * ldy + c] = best;
+    idx[i] = (uint8_t)arg;
+  }
+}
+// dx[n, 2d+a, 2h+b, 2w+e, c] (+)= dy[n,d,h,w,c] if idx == a*4+b*2+e else 0  (every input voxel belongs to one window)
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx, float* dx, long nin, int D, int H,
+                                    int W, int C, int lddy, int lddx, int accum) {
+  const long total = nin * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long v = i / C;
+    const int w = (int)(v % W); v /= W;
+    const int h = (int)(v % H); v /= H;
+    const int d = (int)(v % D);
+    const long n = v / D;
+    const long o = ((n * (D / 2) + d / 2) * (H / 2) + h / 2) * (W / 2) + w / 2;
+    const int pos = (d & 1) * 4 + (h & 1) * 2 + (w & 1);
+    const float g = (idx[o * C + c] == pos) ? dy[o * lddy + c] : 0.f;
+    float* dst = dx + (i / C) * lddx + c;
+    *dst = accum ? *dst + g : g;
+  }
+}
+extern "C" int bts_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int N, int D, int H, int W, int C, int ldx, int ldy,
+                                hipStream_t stream) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || ((D | H | W) & 1) || ldx < C || ldy < C) return BTS_ERR_SHAPE;
+  const long nout = (long)N * (D / 2) * (H / 2) * (W / 2);
+  long blocks = (nout * C + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  (void)hipGetLastError(); hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3((int)blocks), dim3(256), 0, stream, x, y, idx, nout, D / 2, H / 2, W / 2, C,
+                     ldx, ldy);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+extern "C" int bts_maxpool2_bwd(const float* dy, const uint8_t* idx, float* dx, int N, int D, int H, int W, int C, int lddy,
+                                int lddx, int accumulate, hipStream_t stream) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || ((D | H | W) & 1) || lddx < C || lddy < C) return BTS_ERR_SHAPE;
+  const long nin = (long)N * D * H * W;
+  long blocks = (nin * C + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  (void)hipGetLastError(); hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3((int)blocks), dim3(256), 0, stream, dy, idx, dx, nin, D, H, W, C, lddy, lddx,
+                     accumulate);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+// nearest-neighbour x2: y[n,2d+a,2h+b,2w+e,c] = x[n,d,h,w,c]; backward sums the 8 children
+__global__ void upsample2_fwd_kernel(const float* __restrict__ x, float* y, long nfine, int D2, int H2, int W2, int C, int ldx,
+                                     int ldy) {
+  const long total = nfine * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long v = i / C;
+    const int w = (int)(v % W2); v /= W2;
+    const int h = (int)(v % H2); v /= H2;
+    const int d = (int)(v % D2);
+    const long n = v / D2;
+    const long src = ((n * (D2 / 2) + d / 2) * (H2 / 2) + h / 2) * (W2 / 2) + w / 2;
+    y[(i / C) * ldy + c] = x[src * ldx + c];
+  }
+}
+__global__ void upsample2_bwd_kernel(const float* __restrict__ dy, float* dx, long ncoarse, int D, int H, int W, int C, int lddy,
+                                     int lddx, int accum) {
+  const long total = ncoarse * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long v = i / C;
+    const int w = (int)(v % W); v /= W;
+    const int h = (int)(v % H); v /= H;
+    const int d = (int)(v % D);
+    const long n = v / D;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {  // fixed order
+      const long f = ((n * (2 * D) + 2 * d + (k >> 2)) * (2 * H) + 2 * h + ((k >> 1) & 1)) * (2 * W) + 2 * w + (k & 1);
+      s += dy[f * lddy + c];
+    }
+    float* dst = dx + (i / C) * lddx + c;
+    *dst = accum ? *dst + s : s;
+  }
+}
+extern "C" int bts_upsample2_fwd(const float* x, float* y, int N, int D, int H, int W, int C, int ldx, int ldy,
+                                 hipStream_t stream) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || ldx < C || ldy < C) return BTS_ERR_SHAPE;
+  const long nfine = (long)N * D * H * W * 8;
+  long blocks = (nfine * C + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  (void)hipGetLastError(); hipLaunchKernelGGL(upsample2_fwd_kernel, dim3((int)blocks), dim3(256), 0, stream, x, y, nfine, 2 * D, 2 * H, 2 * W, C, ldx,
+                     ldy);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+extern "C" int bts_upsample2_bwd(const float* dy, float* dx, int N, int D, int H, int W, int C, int lddy, int lddx, int accumulate,
+                                 hipStream_t stream) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || lddx < C || lddy < C) return BTS_ERR_SHAPE;
+  const long nc = (long)N * D * H * W;
+  long blocks = (nc * C + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  (void)hipGetLastError(); hipLaunchKernelGGL(upsample2_bwd_kernel, dim3((int)blocks), dim3(256), 0, stream, dy, dx, nc, D, H, W, C, lddy, lddx,
+                     accumulate);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}

@@ -2,7 +2,7 @@
 
 ConvDownsample (:14-48): Conv3D k3 s2 'same' (he_normal, L2) -> GroupNorm (no regulariser) -> ReLU.
 TF 'same' for k=3,s=2 on even sizes pads (0,1): output o reads inputs 2o..2o+2, index n reads zero.
-MaxDownsample (:51-70) is a non-default option on the call surface: SURVEY 8(f-4) "next" row."""
+MaxDownsample (:51-70): MaxPooling3D 2/2, the non-default `--downsampling max` option."""
 from .. import ops
 from ._base import Layer, Tensor, as_tensor, check_data_format, current_tape, gn_mode_of
 from .group_norm import GroupNormalization, group_norm_backward
@@ -70,13 +70,33 @@ class ConvDownsample(Layer):
 
 
 class MaxDownsample(Layer):
-    def __init__(self, data_format='channels_last', **kwargs):
-        super(MaxDownsample, self).__init__()
+    """MaxPooling3D(pool_size=2, strides=2, padding='same') (downsample.py:51-70); extra constructor arguments of the
+    conv variant are accepted and ignored like the reference's **kwargs.  The channel count is unchanged."""
+
+    def __init__(self, data_format='channels_last', name=None, **kwargs):
+        super(MaxDownsample, self).__init__(name=name)
+        self.data_format = check_data_format(data_format)
         self.config = {'data_format': data_format}
 
+    def compute_output_shape(self, s):
+        return (s[0], s[1] // 2, s[2] // 2, s[3] // 2, s[4])
+
     def call(self, inputs, training=None):
-        raise NotImplementedError("downsampling='max' (MaxPooling3D 2/2) is a non-default option of the reference "
-                                  '(args.py:136-138); SURVEY 8(f-4) "next" row, not built in this round')
+        x = as_tensor(inputs, data_format=self.data_format)
+        if any(s % 2 for s in x.shape[1:4]):
+            raise ValueError('MaxDownsample needs even spatial sizes, got %s' % (x.shape,))
+        yt, idx = ops.maxpool2_fwd(x.t)
+        y = Tensor(yt)
+        tape = current_tape()
+        if tape is not None and x.requires_grad:
+            def backward():
+                dy = y.grad
+                if dy is None:
+                    return
+                dx, acc = x.grad_slot()
+                ops.maxpool2_bwd(dy, idx, dx, acc)
+            tape.record(backward)
+        return y
 
     def get_config(self):
         return self.config

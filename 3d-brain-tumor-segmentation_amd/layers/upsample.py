@@ -66,13 +66,47 @@ class ConvUpsample(Layer):
 
 
 class LinearUpsample(Layer):
-    def __init__(self, filters, data_format='channels_last', l2_scale=1e-5, **kwargs):
-        super(LinearUpsample, self).__init__()
-        self.config = {'filters': filters, 'data_format': data_format, 'l2_scale': l2_scale}
+    """Conv3D 1x1x1 (he_normal, L2) followed by UpSampling3D(size=2), i.e. nearest-neighbour repetition -- "linear" is the
+    reference's name for it (upsample.py:49-79); the non-default `--upsampling linear` option."""
 
-    def call(self, inputs, training=None):
-        raise NotImplementedError("upsampling='linear' (1x1x1 conv + nearest UpSampling3D) is a non-default option of the "
-                                  'reference (args.py:139-141); SURVEY 8(f-4) "next" row, not built in this round')
+    def __init__(self, filters, data_format='channels_last', l2_scale=1e-5, name=None, **kwargs):
+        super(LinearUpsample, self).__init__(name=name)
+        self.data_format = check_data_format(data_format)
+        self.config = {'filters': filters, 'data_format': data_format, 'l2_scale': l2_scale}
+        self.filters = filters
+        self.l2_scale = l2_scale
+
+    def build(self, input_shape):
+        cin = input_shape[-1]
+        self.cin = cin
+        self.ptwise_k = self.add_weight('ptwise_k', (1, 1, 1, cin, self.filters), 'he_normal', self.l2_scale)
+        self.ptwise_b = self.add_weight('ptwise_b', (self.filters,), 'zeros')
+        self.built = True
+
+    def compute_output_shape(self, s):
+        return (s[0], s[1] * 2, s[2] * 2, s[3] * 2, self.filters)
+
+    def call(self, inputs, training=None, out=None):
+        x = as_tensor(inputs, data_format=self.data_format)
+        f = self.filters
+        wp = self.packed('f', ops.K1, ops.ROLE_FWD, self.ptwise_k, self.cin, f)
+        c = ops.conv_fwd(ops.K1, x.t, wp, self.ptwise_b.t, f)
+        yt = ops.upsample2_fwd(c, out=None if out is None else out.t)
+        y = out if out is not None else Tensor(yt)
+        tape = current_tape()
+        if tape is not None:
+            def backward():
+                dy = y.grad
+                if dy is None:
+                    return
+                dc = ops.upsample2_bwd(dy)
+                if x.requires_grad:
+                    dx, acc = x.grad_slot()
+                    wpb = self.packed('b', ops.K1, ops.ROLE_BWD, self.ptwise_k, self.cin, f)
+                    ops.conv_bwd_data(ops.K1, dc, wpb, dx, acc)
+                _wgrad(ops.K1, x.t, dc, self.ptwise_k, self.ptwise_b)
+            tape.record(backward)
+        return y
 
     def get_config(self):
         return self.config

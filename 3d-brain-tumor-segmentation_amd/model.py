@@ -46,7 +46,7 @@ class Model(Layer):
             s = s[:4] + (f * (i + 1),)
             res_shapes.append(s)
             if i < self.encoder.depth - 1:
-                s = (s[0], s[1] // 2, s[2] // 2, s[3] // 2, f)
+                s = tuple(self.encoder.levels[i][1].compute_output_shape(s))   # conv: f channels; max pooling keeps them all
         self.decoder.build((res_shapes[-1], res_shapes[:-1]))
         self.vae.build(res_shapes[-1])
         self.built = True

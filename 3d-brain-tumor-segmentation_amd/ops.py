@@ -513,3 +513,36 @@ def augment_crop(x, y, var, crop, offsets, flip_mask, shift, scale, out_ch):
                int(offsets[0]), int(offsets[1]), int(offsets[2]), int(flip_mask), ctypes.cast(sh, ctypes.c_void_p),
                ctypes.cast(sc, ctypes.c_void_p), int(out_ch), _stream())
     return xo, yo
+
+
+# ---- non-default samplers ----
+def maxpool2_fwd(x):
+    n, d, h, w, c = x.shape
+    y = torch.empty((n, d // 2, h // 2, w // 2, c), dtype=torch.float32, device=x.device)
+    idx = torch.empty((n, d // 2, h // 2, w // 2, c), dtype=torch.uint8, device=x.device)
+    lib().call('bts_maxpool2_fwd', _p(x), _p(y), _p(idx), n, d, h, w, c, ld_of(x), c, _stream())
+    return y, idx
+
+
+def maxpool2_bwd(dy, idx, dx, accumulate):
+    """dx: [N,D,H,W,C] view of the input's gradient (may be a slab slice)"""
+    n, d, h, w, c = dx.shape
+    lib().call('bts_maxpool2_bwd', _p(dy), _p(idx), _p(dx), n, d, h, w, c, ld_of(dy), ld_of(dx), 1 if accumulate else 0, _stream())
+    return dx
+
+
+def upsample2_fwd(x, out=None):
+    n, d, h, w, c = x.shape
+    if out is None:
+        out = torch.empty((n, 2 * d, 2 * h, 2 * w, c), dtype=torch.float32, device=x.device)
+    lib().call('bts_upsample2_fwd', _p(x), _p(out), n, d, h, w, c, ld_of(x), ld_of(out), _stream())
+    return out
+
+
+def upsample2_bwd(dy, dx=None, accumulate=False):
+    n, d2, h2, w2, c = dy.shape
+    if dx is None:
+        dx = torch.empty((n, d2 // 2, h2 // 2, w2 // 2, c), dtype=torch.float32, device=dy.device)
+    lib().call('bts_upsample2_bwd', _p(dy), _p(dx), n, d2 // 2, h2 // 2, w2 // 2, c, ld_of(dy), ld_of(dx),
+               1 if accumulate else 0, _stream())
+    return dx

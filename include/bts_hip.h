@@ -157,6 +157,19 @@ int bts_l2_reg_bwd(const float* params, float* grads, const long* off, const lon
 int bts_adam_tf_step(float* p, const float* g, float* m, float* v, long n, float lr_t, float beta1, float beta2, float eps,
                      float gmul, bts_stream_t stream);
 
+/* ===== non-default samplers (downsample.py:51-70, upsample.py:49-79) ===== */
+/* MaxPooling3D(pool 2, stride 2) on even (D,H,W): y (N,D/2,H/2,W/2,C); idx (dense, one byte per output element) records the
+ * window position dz*4+dy*2+dx of the first maximum and routes the gradient in bts_maxpool2_bwd (D,H,W = INPUT dims). */
+int bts_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int N, int D, int H, int W, int C, int ldx, int ldy,
+                     bts_stream_t stream);
+int bts_maxpool2_bwd(const float* dy, const uint8_t* idx, float* dx, int N, int D, int H, int W, int C, int lddy, int lddx,
+                     int accumulate, bts_stream_t stream);
+/* UpSampling3D(size 2) = nearest-neighbour repeat: y (N,2D,2H,2W,C) from x (N,D,H,W,C); backward sums the 8 children
+ * (D,H,W = COARSE dims in both calls). */
+int bts_upsample2_fwd(const float* x, float* y, int N, int D, int H, int W, int C, int ldx, int ldy, bts_stream_t stream);
+int bts_upsample2_bwd(const float* dy, float* dx, int N, int D, int H, int W, int C, int lddy, int lddx, int accumulate,
+                      bts_stream_t stream);
+
 /* ===== full-volume inference helpers (test.py:95-151,259-261) ===== */
 /* dst (+)= scale * t(flip(src)) on dense NDHWC tensors; flip_mask bits 4|2|1 reverse D|H|W (tf.reverse, test.py:139,142);
  * mean/stdv (C floats, both or neither): t(v) = (v - mean[c]) / std[c] (test.py:111), identity when NULL. src != dst

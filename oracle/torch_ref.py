@@ -175,6 +175,11 @@ def _add_up(P, gen, pre, cin, f):
     _add(P, gen, pre + 'gn_b', (f,), 'zeros', 0)
 
 
+def _add_lin_up(P, gen, pre, cin, f, l2):
+    _add(P, gen, pre + 'ptwise_k', (1, 1, 1, cin, f), 'he_normal', l2)   # upsample.py:62-69 (LinearUpsample)
+    _add(P, gen, pre + 'ptwise_b', (f,), 'zeros', 0)
+
+
 def default_config(**kw):
     cfg = dict(data_format='channels_last', groups=8, reduction=2, l2_scale=1e-5, dropout=0.2, downsampling='conv',
                upsampling='conv', base_filters=16, depth=4, in_ch=2, out_ch=3)  # model.py:9-20
@@ -197,12 +202,17 @@ def build_params(cfg, crop, seed=0):
         cout = f if i == 0 else (i + 1) * f
         level_out.append(cout)
         if i < depth - 1:
-            _add_down(P, gen, 'encoder/L%d/down/' % i, cout, f, l2)
-            cin = f
+            if cfg['downsampling'] == 'max':     # MaxPooling3D has no variables and keeps every channel (downsample.py:51-70)
+                cin = cout
+            else:
+                _add_down(P, gen, 'encoder/L%d/down/' % i, cout, f, l2)
+                cin = f
+    linear = cfg['upsampling'] == 'linear'
+    add_up = (lambda pre, ci, fo: _add_lin_up(P, gen, pre, ci, fo, l2)) if linear else (lambda pre, ci, fo: _add_up(P, gen, pre, ci, fo))
     c = level_out[-1]
     for i in range(depth - 2, -1, -1):           # decoder.py:38-53
         f = bf * 2 ** i
-        _add_up(P, gen, 'decoder/L%d/up/' % i, c, f)
+        add_up('decoder/L%d/up/' % i, c, f)
         _add_resblock(P, gen, 'decoder/L%d/res/' % i, level_out[i] + f, f, red, l2)
         c = f
     _add(P, gen, 'decoder/out_k', (1, 1, 1, c, cfg['out_ch']), 'glorot_normal', l2)  # decoder.py:55-63
@@ -219,11 +229,11 @@ def build_params(cfg, crop, seed=0):
     un = sp[0] * sp[1] * sp[2] // 8
     _add(P, gen, 'vae/unproj_k', (latent, un), 'he_normal', l2)
     _add(P, gen, 'vae/unproj_b', (un,), 'zeros', 0)
-    _add_up(P, gen, 'vae/up/', 1, units)
+    add_up('vae/up/', 1, units)
     c = units
     for i in range(depth - 2, -1, -1):
         f = bf * 2 ** i
-        _add_up(P, gen, 'vae/L%d/up/' % i, c, f)
+        add_up('vae/L%d/up/' % i, c, f)
         _add_resblock(P, gen, 'vae/L%d/res/' % i, f, f, red, l2)
         c = f
     _add(P, gen, 'vae/out_k', (3, 3, 3, c, cfg['in_ch']), 'he_normal', l2)
@@ -272,6 +282,24 @@ def conv_upsample(x, P, pre, cfg):
     return torch.relu(group_norm(h, P[pre + 'gn_g'], P[pre + 'gn_b'], cfg['groups'], _caxis(df)))
 
 
+def max_downsample(x, cfg):
+    """MaxDownsample.__call__, downsample.py:51-70: MaxPooling3D(pool 2, stride 2, 'same') -- even sizes, no padding"""
+    df = cfg['data_format']
+    return _from_ncdhw(F.max_pool3d(_to_ncdhw(x, df), 2, 2), df)
+
+
+def linear_upsample(x, P, pre, cfg):
+    """LinearUpsample.__call__, upsample.py:76-79: 1x1x1 conv then UpSampling3D(size 2) = nearest-neighbour repeat"""
+    df = cfg['data_format']
+    h = _to_ncdhw(conv3d(x, P[pre + 'ptwise_k'], P[pre + 'ptwise_b'], 1, df), df)
+    h = h.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3).repeat_interleave(2, dim=4)
+    return _from_ncdhw(h, df)
+
+
+def upsample(x, P, pre, cfg):
+    return linear_upsample(x, P, pre, cfg) if cfg['upsampling'] == 'linear' else conv_upsample(x, P, pre, cfg)
+
+
 def encoder(x, P, cfg, training, mask):
     """Encoder.call, encoder.py:69-101."""
     ax = _caxis(cfg['data_format'])
@@ -290,7 +318,10 @@ def encoder(x, P, cfg, training, mask):
             inputs = torch.cat(cache, dim=ax)                    # :90-91
         residuals.append(inputs)
         if i < cfg['depth'] - 1:
-            inputs = conv_downsample(inputs, P, 'encoder/L%d/down/' % i, cfg)  # :97-98
+            if cfg['downsampling'] == 'max':
+                inputs = max_downsample(inputs, cfg)
+            else:
+                inputs = conv_downsample(inputs, P, 'encoder/L%d/down/' % i, cfg)  # :97-98
     return residuals
 
 
@@ -300,7 +331,7 @@ def decoder(x, residuals, P, cfg):
     ax = _caxis(df)
     lv = list(range(cfg['depth'] - 2, -1, -1))
     for i, residual in zip(lv, residuals[::-1]):
-        x = conv_upsample(x, P, 'decoder/L%d/up/' % i, cfg)
+        x = upsample(x, P, 'decoder/L%d/up/' % i, cfg)
         x = torch.cat([residual, x], dim=ax)                     # :75
         x = resnet_block(x, P, 'decoder/L%d/res/' % i, cfg)
     return torch.sigmoid(conv3d(x, P['decoder/out_k'], P['decoder/out_b'], 1, df))  # :55-63,80
@@ -326,9 +357,9 @@ def vae(x, P, cfg, eps):
         u = u.reshape(n, sd[0] // 2, sd[1] // 2, sd[2] // 2, 1)  # :110-111,129
     else:
         u = u.reshape(n, 1, sd[0] // 2, sd[1] // 2, sd[2] // 2)
-    u = conv_upsample(u, P, 'vae/up/', cfg)                      # :132
+    u = upsample(u, P, 'vae/up/', cfg)                           # :132
     for i in range(cfg['depth'] - 2, -1, -1):                    # :135-138
-        u = conv_upsample(u, P, 'vae/L%d/up/' % i, cfg)
+        u = upsample(u, P, 'vae/L%d/up/' % i, cfg)
         u = resnet_block(u, P, 'vae/L%d/res/' % i, cfg)
     y = conv3d(u, P['vae/out_k'], P['vae/out_b'], 1, df)         # :141
     return y, z_mean, z_logvar

@@ -432,3 +432,39 @@ def test_loss_metric_l2_adam():
     check_close(p, pr, 'adam p', rtol=1e-6, atol=1e-7)
     check_close(m, mr, 'adam m', rtol=1e-5, atol=1e-8)
     check_close(v, vr, 'adam v', rtol=5e-5, atol=1e-9)  # (1-beta_2) is inexact in fp32
+
+
+@pytest.mark.parametrize('n,dims,c,pad', [(1, (4, 6, 8), 5, 0), (2, (2, 2, 2), 16, 3), (1, (8, 4, 10), 32, 8)])
+def test_maxpool_and_nearest_upsample(n, dims, c, pad):
+    """MaxPooling3D 2/2 (downsample.py:51-70) and UpSampling3D 2 (upsample.py:70-72) forward / backward against torch,
+    on dense tensors and on channel slices of a wider slab (ld > C), with and without accumulation."""
+    from bts_amd import ops
+    d, h, w = dims
+    g = torch.Generator().manual_seed(13)
+    slab = torch.randn((n, d, h, w, c + pad), generator=g)
+    xg = slab.to(dev())[..., pad:]
+    xd = slab[..., pad:].double().permute(0, 4, 1, 2, 3).requires_grad_(True)
+    # max pool
+    y, idx = ops.maxpool2_fwd(xg)
+    ref = torch.nn.functional.max_pool3d(xd, 2, 2)
+    assert torch.equal(y.cpu().double(), ref.detach().permute(0, 2, 3, 4, 1))
+    dy = torch.randn(tuple(y.shape), generator=g)
+    ref.backward(dy.double().permute(0, 4, 1, 2, 3))
+    gslab = torch.full((n, d, h, w, c + pad), 7.0, device=dev())
+    ops.maxpool2_bwd(dy.to(dev()), idx, gslab[..., pad:], False)
+    assert torch.equal(gslab[..., pad:].cpu().double(), xd.grad.permute(0, 2, 3, 4, 1))
+    assert pad == 0 or float((gslab[..., :pad] - 7.0).abs().max()) == 0.0
+    ops.maxpool2_bwd(dy.to(dev()), idx, gslab[..., pad:], True)
+    assert torch.allclose(gslab[..., pad:].cpu().double(), 2 * xd.grad.permute(0, 2, 3, 4, 1))
+    # nearest upsample
+    up = ops.upsample2_fwd(xg)
+    xr = slab[..., pad:].double().permute(0, 4, 1, 2, 3).clone().requires_grad_(True)
+    uref = xr.repeat_interleave(2, 2).repeat_interleave(2, 3).repeat_interleave(2, 4)
+    assert torch.equal(up.cpu().double(), uref.detach().permute(0, 2, 3, 4, 1))
+    out_slab = torch.zeros((n, 2 * d, 2 * h, 2 * w, c + pad), device=dev())
+    ops.upsample2_fwd(xg, out=out_slab[..., pad:])
+    assert torch.equal(out_slab[..., pad:], up) and (pad == 0 or float(out_slab[..., :pad].abs().max()) == 0.0)
+    du = torch.randn(tuple(up.shape), generator=g)
+    uref.backward(du.double().permute(0, 4, 1, 2, 3))
+    dx = ops.upsample2_bwd(du.to(dev()))
+    assert torch.allclose(dx.cpu().double(), xr.grad.permute(0, 2, 3, 4, 1), rtol=1e-6, atol=1e-6)

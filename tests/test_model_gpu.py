@@ -212,3 +212,50 @@ def test_channels_first_public_layout_parity(name):
         dev32 = maxerr(grads_32[model.oracle_name(p)], gr) / scale
         assert err <= max(1e-3, 4 * dev32, 0.25 * gdev) or maxerr(g, gr) <= 1e-9, \
             'grad %s rel err %.3e (fp32-torch deviates %.3e)' % (p.name, err, dev32)
+
+
+@pytest.mark.parametrize('samplers', [dict(downsampling='max'), dict(upsampling='linear'), dict(downsampling='max', upsampling='linear')])
+def test_non_default_samplers_parity(samplers):
+    """--downsampling max (MaxPooling3D 2/2, keeps every channel) and --upsampling linear (1x1x1 conv +
+    nearest repeat) end to end: forward, loss and every gradient against the fp64 oracle."""
+    import bts_amd  # noqa: F401
+    from bts_amd.model import Model
+    from bts_amd.tape import GradientTape
+    from bts_amd.util import DiceVAELoss, reduce_sum
+    kw = dict(base_filters=8, groups=2, reduction=2, depth=3, **samplers)
+    crop, n = (16, 16, 16), 1
+    cfg = R.default_config(**kw)
+    latent = cfg['base_filters'] * 2 ** (cfg['depth'] - 2)
+    x, y, mask, eps = R.synthetic_batch(n, crop, latent=latent, seed=77)
+    P = randomised_params(cfg, crop, seed=3)
+    (yp_r, yv_r, zm_r, zl_r), loss_r, grads_r = run_oracle(cfg, P, x, y, mask, eps)
+    _, _, grads_32 = run_oracle(cfg, P, x, y, mask, eps, dtype=torch.float32)
+    model = Model(**kw)
+    model.build((n,) + crop + (2,))
+    assert model.n_params == sum(t.numel() for t in P.values())
+    assert sorted(model.oracle_name(p) for p in model.trainable_variables) == sorted(P.keys())
+    model.set_weights_from(P)
+    model.encoder.set_dropout_mask(mask)
+    model.vae.set_eps(eps)
+    loss_fn = DiceVAELoss()
+    with GradientTape() as tape:
+        y_pred, y_vae, z_mean, z_logvar = model(x, training=True, inference=False)
+        loss = loss_fn(x, y, y_pred, y_vae, z_mean, z_logvar)
+        loss = loss + reduce_sum(model.losses)
+    grads = tape.gradient(loss, model.trainable_variables)
+    torch.cuda.synchronize()
+
+    def maxerr(a, b):
+        return float((a.detach().double().cpu() - b.detach().double()).abs().max())
+
+    assert maxerr(y_pred.t, yp_r) <= 1e-4
+    assert maxerr(y_vae.t, yv_r) <= 1e-4 * max(1.0, float(yv_r.detach().abs().max()))
+    assert abs(float(loss) - float(loss_r)) <= 1e-5 * max(1.0, abs(float(loss_r)))
+    gdev = max(maxerr(grads_32[k], grads_r[k]) / (float(grads_r[k].abs().max()) + 1e-12) for k in grads_r)
+    for p, g in zip(model.trainable_variables, grads):
+        gr = grads_r[model.oracle_name(p)]
+        scale = float(gr.abs().max()) + 1e-12
+        err = maxerr(g, gr) / scale
+        dev32 = maxerr(grads_32[model.oracle_name(p)], gr) / scale
+        assert err <= max(1e-3, 4 * dev32, 0.25 * gdev) or maxerr(g, gr) <= 1e-9, \
+            'grad %s rel err %.3e (fp32-torch deviates %.3e)' % (p.name, err, dev32)
