@@ -446,6 +446,17 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams 
   for (int i = 0; i < WG_MAXT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  // fixed-geometry kernels: partial accumulators of the three left-over row-tiles 24..26 (this wave's slice of K)
+  f32x16 accx[WG_MAXT];
+  int rowoffx[3] = {0, 0, 0};
+  if constexpr (FIXG != 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accx[i][r] = 0.f;
+      rowoffx[i] = (p.tap_vox[24 + i] << p.lgSP) + l32;
+    }
+  }
   double bsum = 0.0;  // bias column sum: thread (c = tid&31, part = tid>>5)
 
   const int sub0 = blockIdx.x * p.sub_per_wg;
@@ -507,9 +518,21 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams 
       for (int i = 0; i < WG_MAXT; ++i) vp[i] = bpb + 4u * (unsigned)(rowoff[i] + ((h * p.s) << 5));
       if (p.dbg == 1) {
         if (dofetch) fetch_fast(sub + 1, lds + (cur ^ 1) * bufDw);
-      } else if (ntw == 4 && p.dbg != 4) {
-        wgrad_sweep_fixed<4, G>(vp, vq, acc, stage);
       } else {
+        // 27 row-tiles over 8 waves: every wave owns tiles w, w+8, w+16 for the whole sub-tile and 1/8 of the voxel pairs
+        // of the three left-over tiles 24..26 (its own x-row for stride 1, half a row for stride 2) in a second, short
+        // sweep -> 216 MFMAs per wave and sub-tile on every wave instead of 256 / 192 (the barrier waits for the slowest)
+        using GX = typename std::conditional<FIXG == 1, WgGeo<1, 16, 1, 1>, WgGeo<2, 4, 1, 1>>::type;   // NS = 8 / 2 steps
+        static_assert(GX::NS * WG_WAVES == G::NS, "the left-over tiles' steps must split evenly over the waves");
+        const int k0 = wave * GX::NS;                       // first step of this wave's slice (wave-uniform)
+        const int r0 = k0 / G::JR, j0 = k0 % G::JR;         // its x-row (z-major) and position inside the row
+        const int pb0 = (((r0 >> 2) * p.s * p.IY + (r0 & 3) * p.s) * p.IX + 2 * j0 * p.s) * 128;   // = G::p_b(k0), TY = 4
+        unsigned vpx[WG_MAXT];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) vpx[i] = bpb + 4u * (unsigned)(rowoffx[i] + ((h * p.s) << 5)) + (unsigned)pb0;
+        vpx[3] = vpx[2];
+        auto nostage = [](auto) {};
+        wgrad_sweep_fixed<3, GX>(vpx, vq + (unsigned)(k0 * 256), accx, nostage);
         wgrad_sweep_fixed<3, G>(vp, vq, acc, stage);
       }
     } else {
@@ -532,7 +555,28 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams 
 
   // ---- write partials ----
   const long tileBase = ((((long)blockIdx.x * gridDim.y + pct) * gridDim.z + qct) * p.ntiles) * 1024;
-  if (!ksplit) {
+  if constexpr (FIXG != 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {   // the wave's own tiles w, w+8, w+16
+      float* dst = p.partial + tileBase + (long)(wave + WG_WAVES * i) * 1024;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l32] = acc[i][r];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {   // tiles 24..26: fixed-order sum of the 8 waves' K-slices through LDS
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lds[wave * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l32] = accx[i][r];
+      __syncthreads();
+      float* dst = p.partial + tileBase + (long)(24 + i) * 1024;
+      for (int e = tid; e < 1024; e += WG_THREADS) {
+        float s = lds[e];
+#pragma unroll
+        for (int w = 1; w < WG_WAVES; ++w) s += lds[w * 1024 + e];
+        dst[e] = s;
+      }
+    }
+  } else if (!ksplit) {
 #pragma unroll
     for (int i = 0; i < WG_MAXT; ++i) {
       const int tile = wave + WG_WAVES * i;
