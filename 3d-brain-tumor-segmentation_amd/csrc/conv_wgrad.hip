@@ -410,8 +410,11 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams 
       if (f_tmask == 0 || ((faceP[i >> 2] >> (8 * (i & 3))) & f_tmask) == 0)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(f_pbase + relP[i]),
                                          (__attribute__((address_space(3))) void*)(f_buf + e0 * 4), 16, 0, 0);
-      else
-        *reinterpret_cast<f32x4*>(f_buf + (e0 + lane) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      else {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));  // keep the 8 per-slot zero-fill addresses out of the sub-tile loop's live registers
+        *reinterpret_cast<f32x4*>(f_buf + (e0 + ln) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   };
   auto fast_slot_q = [&](auto ic) {
