@@ -158,12 +158,15 @@ __device__ __forceinline__ void stage_taps(const IgemmParams& p, const int* tlp,
   }
 }
 
+// TRI: three resident workgroups per CU instead of two (single-buffered halo tile, <= 168 VGPRs): whenever one
+// workgroup is in its prologue / refill / epilogue the SIMD still holds two MFMA-issuing waves.
+#define IG_TRI(MS, NS, KGS, FUSE2, FIXG) ((MS) == 2 && (NS) == 1 && (KGS) == 1 && !(FUSE2) && (FIXG))
 template <int MS, int NS, int WM, int WN, int KGS, bool FUSE2 = false, bool FIXG = false>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(256, IG_TRI(MS, NS, KGS, FUSE2, FIXG) ? 3 : 2) void igemm_kernel(const IgemmParams p) {
   // MS == 4 (512-voxel tile, 16 MFMAs per tap for 32-cout layers): its 59 KB halo tile is single-buffered so that two
   // workgroups still fit a CU; the partner workgroup covers the (short) LDS refill between stages
   constexpr int NSLOT = (MS == 4) ? 10 : MAXSLOT;
-  constexpr bool SINGLE = (MS == 4);
+  constexpr bool SINGLE = (MS == 4) || IG_TRI(MS, NS, KGS, FUSE2, FIXG);
   constexpr int S = KGS * 8 + 4;  // dwords per staged voxel (pad 4: 16B-odd stride)
   constexpr int QPV = KGS * 2;    // float4 slots per voxel
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1043,7 +1046,7 @@ static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   // a single stage (all channels fit one staging pass, e.g. the 1x1x1 convs with Cin <= 32) needs no second buffer:
   // half the LDS -> twice the resident workgroups to hide the (then un-overlapped) staging latency
   const int nstages_all = (p.KG + KGS - 1) / KGS;
-  const size_t shmem = (size_t)((nstages_all > 1 && MS != 4) ? 2 : 1) * tileVox * S * sizeof(float);
+  const size_t shmem = (size_t)((nstages_all > 1 && MS != 4 && !IG_TRI(MS, NS, KGS, FUSE2, FIXG)) ? 2 : 1) * tileVox * S * sizeof(float);
   auto kern = igemm_kernel<MS, NS, WM, WN, KGS, FUSE2, FIXG>;
   static bool attr_done = false;
   if (!attr_done && !p.plan_only) {
