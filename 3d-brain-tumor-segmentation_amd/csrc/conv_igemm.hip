@@ -161,7 +161,7 @@ __device__ __forceinline__ void stage_taps(const IgemmParams& p, const int* tlp,
 // TRI: three resident workgroups per CU instead of two (single-buffered halo tile, <= 168 VGPRs): whenever one
 // workgroup is in its prologue / refill / epilogue the SIMD still holds two MFMA-issuing waves.
 #define IG_TRI(MS, NS, KGS, FUSE2, FIXG) ((MS) == 2 && (NS) == 1 && (KGS) == 1 && !(FUSE2) && (FIXG))
-template <int MS, int NS, int WM, int WN, int KGS, bool FUSE2 = false, bool FIXG = false>
+template <int MS, int NS, int WM, int WN, int KGS, bool FUSE2 = false, bool FIXG = false, bool T27 = false>
 __global__ __launch_bounds__(256, IG_TRI(MS, NS, KGS, FUSE2, FIXG) ? 3 : 2) void igemm_kernel(const IgemmParams p) {
   // MS == 4 (512-voxel tile, 16 MFMAs per tap for 32-cout layers): its 59 KB halo tile is single-buffered so that two
   // workgroups still fit a CU; the partner workgroup covers the (short) LDS refill between stages
@@ -310,8 +310,9 @@ __global__ __launch_bounds__(256, IG_TRI(MS, NS, KGS, FUSE2, FIXG) ? 3 : 2) void
     int nkg = kgEnd - kg0;
     if (nkg > KGS) nkg = KGS;
     if (p.dbg == 1) {
-    } else if constexpr (FIXG) {  // compile-time geometry is always the 27-tap form: no runtime tap-count dispatch, so the
-      // accumulators are not shuffled between register sets around a switch
+    } else if constexpr (FIXG || T27 || FUSE2) {  // 27-tap form known at compile time (fixed geometry, the fused pair, or
+      // the launcher's T27 instantiation for k3s1 / stride-2 convs): no runtime tap-count dispatch, so the accumulators
+      // are not shuffled between register sets around a switch
       stage_taps<27, MS, NS, FUSE2, FIXG>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc, acc2);
     } else if constexpr (KGS == 1) {
       switch (ntaps) {
@@ -1038,7 +1039,7 @@ static int launch_dsc(const float* x, const float* wp, const float* bias, float*
 // ---------------------------------------------------------------------------------------------
 enum Geo { GEO_K1 = 0, GEO_S1 = 1, GEO_DOWN = 2, GEO_UP = 3 };
 
-template <int MS, int NS, int WM, int WN, int KGS, bool FUSE2 = false, bool FIXG = false>
+template <int MS, int NS, int WM, int WN, int KGS, bool FUSE2 = false, bool FIXG = false, bool T27 = false>
 static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   constexpr int S = KGS * 8 + 4;
   const int tileVox = p.IZ * p.IY * p.IX;
@@ -1047,7 +1048,7 @@ static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   // half the LDS -> twice the resident workgroups to hide the (then un-overlapped) staging latency
   const int nstages_all = (p.KG + KGS - 1) / KGS;
   const size_t shmem = (size_t)((nstages_all > 1 && MS != 4 && !IG_TRI(MS, NS, KGS, FUSE2, FIXG)) ? 2 : 1) * tileVox * S * sizeof(float);
-  auto kern = igemm_kernel<MS, NS, WM, WN, KGS, FUSE2, FIXG>;
+  auto kern = igemm_kernel<MS, NS, WM, WN, KGS, FUSE2, FIXG, T27>;
   static bool attr_done = false;
   if (!attr_done && !p.plan_only) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1291,6 +1292,15 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
       case 3: rc = launch_cfg<1, 1, 2, 2, 1, true>(p, stream); break;
       case 4: rc = launch_cfg<1, 1, 4, 1, 1, true>(p, stream); break;
       default: rc = BTS_ERR_UNSUPPORTED; break;
+    }
+  } else if (p.ntaps == 27 && p.ncls <= 1) {
+    switch (cfg) {
+      case 0: rc = launch_cfg<2, 1, 4, 1, 1, false, false, true>(p, stream); break;
+      case 5: rc = BTS_ERR_UNSUPPORTED; break;
+      case 1: rc = launch_cfg<2, 2, 4, 1, 1, false, false, true>(p, stream); break;
+      case 2: rc = launch_cfg<1, 2, 2, 2, 1, false, false, true>(p, stream); break;
+      case 3: rc = launch_cfg<1, 1, 2, 2, 1, false, false, true>(p, stream); break;
+      default: rc = launch_cfg<1, 1, 4, 1, 1, false, false, true>(p, stream); break;
     }
   } else {
     switch (cfg) {
