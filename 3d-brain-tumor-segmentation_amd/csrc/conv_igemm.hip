@@ -600,6 +600,8 @@ struct UpmParams {
   int lgTX, lgTY, TZ, ntx, nty, ntz;
   int IX, IY, IZ;  // halo tile = coarse tile + 1 on the low side of every axis
   int flags;
+  float* part;     // split-K partials [ksplit][fine voxel][Npad] (igemm_reduce_kernel finishes them)
+  int ksplit, kg_per;
 };
 __host__ __device__ constexpr int upm_cls(int t) { return ((t / 9 == 1) ? 4 : 0) | (((t / 3) % 3 == 1) ? 2 : 0) | ((t % 3 == 1) ? 1 : 0); }
 // halo coordinate of the input voxel per axis: k=2 reads c-1 (index 0), k=0/1 read c (index 1)
@@ -674,12 +676,18 @@ __global__ __launch_bounds__(256, 2) void upm_kernel(const UpmParams p) {
       if (e < nslots) *reinterpret_cast<f32x4*>(buf + (e >> 1) * S + (e & 1) * 4) = pre[i];
     }
   };
-  fetch(0);
+  int kgBeg = 0, kgEnd = p.KG;
+  if (p.ksplit > 1) {
+    kgBeg = blockIdx.z * p.kg_per;
+    kgEnd = kgBeg + p.kg_per;
+    if (kgEnd > p.KG) kgEnd = p.KG;
+  }
+  fetch(kgBeg);
   commit(lds);
   __syncthreads();
-  for (int st = 0; st < p.KG; ++st) {
-    const float* cur = lds + (st & 1) * bufDw;
-    const bool more = (st + 1) < p.KG;
+  for (int st = kgBeg; st < kgEnd; ++st) {
+    const float* cur = lds + ((st - kgBeg) & 1) * bufDw;
+    const bool more = (st + 1) < kgEnd;
     if (more) fetch(st + 1);
     const float* wk = p.wp + st * wstepKG;  // wave-uniform
     constexpr int AD = 2;
@@ -697,7 +705,7 @@ __global__ __launch_bounds__(256, 2) void upm_kernel(const UpmParams p) {
         acc[upm_cls(t)] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t % (AD + 1)][j], bf[upm_off(t)][j], acc[upm_cls(t)], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) commit(lds + ((st + 1) & 1) * bufDw);
+    if (more) commit(lds + ((st + 1 - kgBeg) & 1) * bufDw);
     __syncthreads();
   }
 
@@ -708,7 +716,17 @@ __global__ __launch_bounds__(256, 2) void upm_kernel(const UpmParams p) {
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const int oz = 2 * cz + ((c >> 2) & 1), oy = 2 * cy + ((c >> 1) & 1), ox = 2 * cx + (c & 1);
-    float* yrow = p.y + ((((long)n * (2 * p.Di) + oz) * (2 * p.Hi) + oy) * (2 * p.Wi) + ox) * (long)p.ldy;
+    const long vfine = (((long)n * (2 * p.Di) + oz) * (2 * p.Hi) + oy) * (2 * p.Wi) + ox;
+    if (p.ksplit > 1) {  // raw partial, finished (bias / activation / accumulate) by igemm_reduce_kernel in a fixed order
+      float* row = p.part + ((long)blockIdx.z * ((long)p.N * 8 * p.Di * p.Hi * p.Wi) + vfine) * p.Npad;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v4 = {acc[c][4 * g + 0], acc[c][4 * g + 1], acc[c][4 * g + 2], acc[c][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(row + nb + 8 * g + 4 * h) = v4;
+      }
+      continue;
+    }
+    float* yrow = p.y + vfine * (long)p.ldy;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int co = nb + 8 * g + 4 * h;
@@ -726,17 +744,13 @@ __global__ __launch_bounds__(256, 2) void upm_kernel(const UpmParams p) {
   }
 }
 
-// returns BTS_OK when the merged-class kernel took the launch, 1 when the shape is left to the per-class path
-static int launch_upm(const float* x, const float* wp, const float* bias, float* y, int N, int Di, int Hi, int Wi, int Cin,
-                      int ldx, int Cout, int ldy, int flags, hipStream_t stream) {
-  if (getenv("BTS_IGEMM_NOUPM") != nullptr) return 1;
-  if ((Cin & 7) || (Cout & 3) || (ldx & 3) || (ldy & 3) || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 15)) return 1;
-  if ((flags & IG_FLAG_BIAS) && (((uintptr_t)bias) & 15)) return 1;
-  if (Wi < 8 || Hi < 4 || Di < 2) return 1;
-  UpmParams p;
-  p.x = x; p.wp = wp; p.bias = bias; p.y = y;
-  p.N = N; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.ldy = ldy;
-  p.Npad = npad32(Cout); p.KG = Cin / 8; p.flags = flags;
+// Shape-only part of the decision (shared by the workspace query): tile geometry and split-K factor.
+// returns 0 when the merged-class kernel does not fit the shape.
+static int plan_upm(UpmParams& p, int N, int Di, int Hi, int Wi, int Cin, int Cout, long* need) {
+  *need = 0;
+  if ((Cin & 7) || (Cout & 3) || Wi < 8 || Hi < 4 || Di < 2) return 0;
+  p.N = N; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Cout = Cout;
+  p.Npad = npad32(Cout); p.KG = Cin / 8;
   int TX = 32;
   while (TX > 8 && TX / 2 >= Wi) TX /= 2;
   int TY = (TX == 32) ? 2 : 4;
@@ -744,18 +758,54 @@ static int launch_upm(const float* x, const float* wp, const float* bias, float*
   p.lgTX = ilog2(TX); p.lgTY = ilog2(TY); p.TZ = TZ;
   p.ntx = (Wi + TX - 1) / TX; p.nty = (Hi + TY - 1) / TY; p.ntz = (Di + TZ - 1) / TZ;
   p.IX = TX + 1; p.IY = TY + 1; p.IZ = TZ + 1;
+  if (p.IZ * p.IY * p.IX * 2 > 256 * UPM_NSLOT) return 0;
+  const long wgs = (long)N * p.ntz * p.nty * p.ntx * (p.Npad / 32);
+  const long min_wgs = getenv("BTS_IGEMM_UPM_MIN") ? atol(getenv("BTS_IGEMM_UPM_MIN")) : 256;  // (tests force 1)
+  p.ksplit = 1; p.kg_per = p.KG;
+  if (wgs < min_wgs) {
+    // too few workgroups to fill the chip: split the contraction (deterministic two-stage reduction) when it is long
+    if (p.KG < 8 || getenv("BTS_IGEMM_UPM_NOSPLIT") != nullptr) return 0;
+    int ks = (int)((512 + wgs - 1) / wgs);
+    if (ks > p.KG / 4) ks = p.KG / 4;
+    if (ks > 16) ks = 16;
+    if (ks < 2) return 0;
+    p.kg_per = (p.KG + ks - 1) / ks;
+    p.ksplit = (p.KG + p.kg_per - 1) / p.kg_per;
+    if (p.ksplit < 2 || wgs * p.ksplit < min_wgs / 2) return 0;
+    *need = (long)p.ksplit * N * 8 * Di * Hi * Wi * p.Npad * 4;
+  }
+  return 1;
+}
+
+// returns BTS_OK when the merged-class kernel took the launch, 1 when the shape is left to the per-class path
+static int launch_upm(const float* x, const float* wp, const float* bias, float* y, int N, int Di, int Hi, int Wi, int Cin,
+                      int ldx, int Cout, int ldy, int flags, void* ws, long ws_bytes, hipStream_t stream) {
+  if (getenv("BTS_IGEMM_NOUPM") != nullptr) return 1;
+  if ((ldx & 3) || (ldy & 3) || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 15)) return 1;
+  if ((flags & IG_FLAG_BIAS) && (((uintptr_t)bias) & 15)) return 1;
+  UpmParams p;
+  long need = 0;
+  if (!plan_upm(p, N, Di, Hi, Wi, Cin, Cout, &need)) return 1;
+  if (need > 0 && (ws == nullptr || ws_bytes < need)) return 1;
+  p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.ldx = ldx; p.ldy = ldy; p.flags = flags;
+  p.part = reinterpret_cast<float*>(ws);
   const long tiles = (long)N * p.ntz * p.nty * p.ntx;
   const int ny = p.Npad / 32;
-  const long min_wgs = getenv("BTS_IGEMM_UPM_MIN") ? atol(getenv("BTS_IGEMM_UPM_MIN")) : 256;  // (tests force 1)
-  if (tiles * ny < min_wgs) return 1;  // too few workgroups to fill the chip: the per-class path has 8x the grid
   const int tileVox = p.IZ * p.IY * p.IX;
-  if (tileVox * 2 > 256 * UPM_NSLOT) return 1;
   const size_t shmem = (size_t)2 * tileVox * 12 * sizeof(float);
   const bool prof = bts_prof_on();
   if (prof) bts_prof_begin(20, 2.0 * 27.0 * Cin * Cout * (double)N * Di * Hi * Wi, stream);
-  (void)hipGetLastError(); hipLaunchKernelGGL(upm_kernel, dim3((unsigned)tiles, ny), dim3(256), shmem, stream, p);
+  (void)hipGetLastError(); hipLaunchKernelGGL(upm_kernel, dim3((unsigned)tiles, ny, p.ksplit), dim3(256), shmem, stream, p);
   if (prof) bts_prof_end(stream);
   BTS_LAUNCH_CHECK();
+  if (p.ksplit > 1) {
+    const long nvox = (long)N * 8 * Di * Hi * Wi;
+    long blocks = (nvox * Cout + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    (void)hipGetLastError(); hipLaunchKernelGGL(igemm_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, p.part, bias, y, nvox, Cout, p.Npad, ldy,
+                       p.ksplit, flags);
+    BTS_LAUNCH_CHECK();
+  }
   return BTS_OK;
 }
 
@@ -1149,10 +1199,13 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
   if (geo == GEO_UP && pz < 0 && wp2 == nullptr && !(flags & ~(IG_FLAG_BIAS | IG_FLAG_ACCUM | IG_FLAG_SIGMOID | IG_FLAG_VECIN | IG_FLAG_VECOUT))) {
     // merged parity classes (no workspace needed); shapes it declines fall through to the per-class launch
     if (need_out != nullptr) {
-      // planning call: the merged kernel needs no workspace, but whether it takes the launch depends on pointers we do
-      // not have here -> report the per-class path's requirement (an upper bound)
+      // planning call: whether the merged kernel takes the launch also depends on pointer alignment we do not have here,
+      // so report its split-K requirement as an upper bound (the per-class path needs none)
+      UpmParams pp;
+      long need = 0;
+      if (plan_upm(pp, N, Di, Hi, Wi, Cin, Cout, &need) && need > 0) { *need_out = need; return BTS_OK; }
     } else {
-      const int r = launch_upm(x, wp, bias, y, N, Di, Hi, Wi, Cin, ldx, Cout, ldy, flags, stream);
+      const int r = launch_upm(x, wp, bias, y, N, Di, Hi, Wi, Cin, ldx, Cout, ldy, flags, ws, ws_bytes, stream);
       if (r != 1) return r;
     }
   }

@@ -153,6 +153,14 @@ def test_conv_small_cout_direct(monkeypatch, n, dims, cin, cout):
     assert float(out[..., :4].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('kind,n,dims,cin,cout', [(3, 2, (8, 8, 8), 64, 32), (3, 1, (4, 8, 16), 128, 40), (2, 1, (16, 16, 16), 32, 64)])
+def test_conv_up_merged_classes_split_k(monkeypatch, kind, n, dims, cin, cout):
+    """upm_kernel with the contraction split over workgroups (grids too small to fill the chip): raw partials + the
+    fixed-order igemm_reduce_kernel, incl. bias and accumulate; BTS_IGEMM_UPM_MIN=64 makes these small grids take it."""
+    monkeypatch.setenv('BTS_IGEMM_UPM_MIN', '64')
+    test_conv_fwd_bwd(kind, n, dims, cin, cout)
+
+
 def test_conv_strided_views_and_sigmoid():
     """channel slices of a slab as conv input and output (virtual Concatenate), fused sigmoid"""
     from bts_amd import ops
