@@ -79,7 +79,9 @@ def test_error_behaviour_matches_reference():
     mcf = Model(data_format='channels_first', base_filters=8, groups=2, depth=2)        # args.py:121-123 default layout
     mcf.build((1, 8, 8, 8, 2))                                                          # internal (NDHWC) build shape
     from bts_amd import ops
-    assert mcf.encoder.blocks[0][0].norm1._mode == ops.GN_CHANNEL if hasattr(mcf.encoder, 'blocks') else True
+    blk = mcf.encoder.levels[0][0][0]
+    assert blk.norm1._mode == ops.GN_CHANNEL and blk.norm2._mode == ops.GN_CHANNEL          # true GroupNorm
+    assert Model(base_filters=8, groups=2, depth=2).encoder.levels[0][0][0].norm1._semantics == ops.GN_SLAB
 
 
 def test_scheduled_optim_schedule():
