@@ -61,6 +61,11 @@ struct IgemmParams {
   long ws_bytes, ws_need;  // host-side planning only
   int plan_only;
   int dbg;  // profiling aid (BTS_IGEMM_DBG): 1 = skip the MFMA sweep, 2 = skip re-staging after the first stage
+  // fused GroupNorm statistics of the output (slab semantics: group = z-slab of D/G planes, whole tiles per group):
+  // every workgroup writes (sum, sum of squares) of its tile to gnp[((n*G+g)*gn_B + b)*2], b = tile index inside the group
+  double* gnp;
+  int gn_G, gn_zt;  // groups; z-tiles per group
+  int gn_gridy;     // host side: grid.y of the launch (partials per group = gn_zt*nty*ntx*gn_gridy)
   // merged launch of the 8 output-parity classes of the UP geometry (blockIdx.z = class)
   int ncls;
   int cls_nt[8];
@@ -356,6 +361,7 @@ __global__ __launch_bounds__(256, IG_TRI(MS, NS, KGS, FUSE2, FIXG) ? 3 : 2) void
 
   // ---- epilogue: D rows = couts (4 consecutive per register quad), cols = voxels ----
   const bool vecout = (p.flags & IG_FLAG_VECOUT) != 0;
+  float gn_s = 0.f, gn_q = 0.f;  // this lane's share of the tile's GroupNorm sums (<= 64 values)
 #pragma unroll
   for (int ms = 0; ms < MS; ++ms) {
     const int m = (wm * MS + ms) * 32 + l32;
@@ -378,6 +384,11 @@ __global__ __launch_bounds__(256, IG_TRI(MS, NS, KGS, FUSE2, FIXG) ? 3 : 2) void
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             if (co + j < p.Cout) v[j] += p.bias[co + j];
+        }
+        if (p.gnp) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (co + j < p.Cout) { gn_s += v[j]; gn_q = fmaf(v[j], v[j], gn_q); }
         }
         if (p.flags & IG_FLAG_SIGMOID) {
 #pragma unroll
@@ -414,6 +425,20 @@ __global__ __launch_bounds__(256, IG_TRI(MS, NS, KGS, FUSE2, FIXG) ? 3 : 2) void
           }
         }
       }
+    }
+  }
+  if (p.gnp) {  // fixed-order combine: lanes (shuffle tree) -> 4 waves (LDS) -> one (sum, sumsq) pair per workgroup
+    double ds = wave_sum_f64((double)gn_s), dq = wave_sum_f64((double)gn_q);
+    double* sh = reinterpret_cast<double*>(lds);  // the staging buffers are idle (last barrier passed)
+    if (lane == 0) { sh[wave * 2] = ds; sh[wave * 2 + 1] = dq; }
+    __syncthreads();
+    if (tid == 0) {
+      const int g = tz / p.gn_zt;
+      const long B = (long)p.gn_zt * p.nty * p.ntx * gridDim.y;
+      const long b_ = (((long)(tz - g * p.gn_zt) * p.nty + ty) * p.ntx + tx) * gridDim.y + blockIdx.y;
+      double* o = p.gnp + (((long)n * p.gn_G + g) * B + b_) * 2;
+      o[0] = sh[0] + sh[2] + sh[4] + sh[6];
+      o[1] = sh[1] + sh[3] + sh[5] + sh[7];
     }
   }
 }
@@ -1134,6 +1159,8 @@ static int launch_cfg(IgemmParams& p, hipStream_t stream) {
       }
     }
   }
+  if (p.ksplit > 1) p.gnp = nullptr;  // split-K tiles are finished by the reduce kernel: no fused statistics
+  p.gn_gridy = (int)grid.y;
   if (p.plan_only) return BTS_OK;
   const bool prof = bts_prof_on();
   if (prof) {
@@ -1187,7 +1214,8 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
                         int Wi, int Cin, int ldx, int Do, int Ho, int Wo, int Cout, int ldy, int ODa, int OHa, int OWa,
                         int pz, int py, int px, int flags, hipStream_t stream, void* ws = nullptr, long ws_bytes = 0,
                         long* need_out = nullptr, const float* wp2 = nullptr, const float* bias2 = nullptr,
-                        float* y2 = nullptr, int ldy2 = 0) {
+                        float* y2 = nullptr, int ldy2 = 0, double* gnp = nullptr, int gnG = 0, long* gn_B = nullptr) {
+  if (gn_B) *gn_B = 0;  // stays 0 unless the tiled kernel took the launch and emitted the GroupNorm partials
   if (geo == GEO_S1 && wp2 == nullptr && need_out == nullptr && Cout <= 4) {
     const int r = launch_dsc(x, wp, bias, y, N, Di, Hi, Wi, Cin, ldx, Cout, ldy, flags, stream);
     if (r != 1) return r;
@@ -1285,6 +1313,10 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
   while (TZ > 1 && TZ / 2 >= Do && TY * 2 <= 64) { TZ /= 2; TY *= 2; }
   p.lgTX = ilog2(TX); p.lgTY = ilog2(TY); p.TZ = TZ;
   p.ntx = (Wo + TX - 1) / TX; p.nty = (Ho + TY - 1) / TY; p.ntz = (Do + TZ - 1) / TZ;
+  p.gnp = nullptr; p.gn_G = 0; p.gn_zt = 1; p.gn_gridy = 1;
+  if (gnp != nullptr && gnG > 0 && geo != GEO_UP && Do % gnG == 0 && (Do / gnG) % TZ == 0 && getenv("BTS_IGEMM_NOGNFUSE") == nullptr) {
+    p.gnp = gnp; p.gn_G = gnG; p.gn_zt = (Do / gnG) / TZ;   // whole tiles per z-slab group
+  }
   p.IX = (TX - 1) * p.s + (hi[2] - lo[2] + 1);
   p.IY = (TY - 1) * p.s + (hi[1] - lo[1] + 1);
   p.IZ = (TZ - 1) * p.s + (hi[0] - lo[0] + 1);
@@ -1366,6 +1398,7 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
     }
   }
   if (need_out) *need_out = p.ws_need;
+  if (gn_B && rc == BTS_OK && p.gnp != nullptr) *gn_B = (long)p.gn_zt * p.nty * p.ntx * p.gn_gridy;
   return rc;
 }
 
@@ -1463,6 +1496,78 @@ extern "C" int bts_conv3d_fwd_fused2(const float* x, const float* wp_fwd, const 
   if (!wp2 || !y2) return BTS_ERR_SHAPE;
   return launch_igemm(GEO_S1, x, wp_fwd, bias, y, N, D, H, W, Cin, ldx, D, H, W, Cout, ldy, D, H, W, 0, 0, 0,
                       bias ? IG_FLAG_BIAS : 0, stream, nullptr, 0, nullptr, wp2, bias2, y2, ldy2);
+}
+
+// ---- convolution + GroupNorm statistics of its output (resnet.py:80-93, downsample.py:41-43: conv -> GroupNormalization) ----
+extern "C" long bts_gn_workspace(int N, long V, int C, int G, int mode);
+extern "C" int bts_gn_stats(const float* x, float* mean, float* rstd, void* workspace, long workspace_bytes, int N, long V, int C,
+                            int G, int mode, float eps, hipStream_t stream);
+static long gnfuse_partial_bytes(int N, int Do, int Ho, int Wo, int Cout) {
+  // upper bound of N*G*B*2 doubles: one pair per 64-voxel tile and 32-cout tile
+  const long tiles = (long)N * ((Do + 0) ) * ((Ho + 3) / 4) * ((Wo + 7) / 8);
+  return tiles * ((npad32(Cout) + 31) / 32) * 2 * (long)sizeof(double) + 64;
+}
+extern "C" long bts_conv3d_fwd_gn_workspace(int kind, int N, int D, int H, int W, int Cin, int Cout, int G) {
+  const long cw = bts_conv3d_fwd_workspace(kind, N, D, H, W, Cin, Cout);
+  if (cw < 0) return -1;
+  int Do = D, Ho = H, Wo = W;
+  if (kind == BTS_CONV_K3S2) { Do = D / 2; Ho = H / 2; Wo = W / 2; }
+  if (kind == BTS_CONV_K3S2T) { Do = 2 * D; Ho = 2 * H; Wo = 2 * W; }
+  const long gw = bts_gn_workspace(N, (long)Do * Ho * Wo, Cout, G, BTS_GN_SLAB);
+  if (gw < 0) return -1;
+  const long fused = ((cw + 63) & ~63L) + gnfuse_partial_bytes(N, Do, Ho, Wo, Cout);
+  return fused > gw ? fused : gw;
+}
+// y = conv(x) + bias (y dense: ldy == Cout) and (mean, rstd) = slab-mode GroupNorm statistics of y.  The statistics come out
+// of the conv epilogue when the tiled kernel takes the launch without split-K and the z-slab groups hold whole tiles;
+// otherwise bts_gn_stats runs on y afterwards (same result up to the summation order, both deterministic).
+static int conv_fwd_gn_impl(int kind, const float* x, const float* wp, const float* bias, float* y, const float* wp2,
+                            const float* bias2, float* y2, int ldy2, void* ws, long ws_bytes, int N, int D, int H, int W, int Cin,
+                            int ldx, int Cout, int G, float eps, float* mean, float* rstd, hipStream_t stream) {
+  if (G <= 0 || Cout % G != 0) return BTS_ERR_SHAPE;
+  if (ws == nullptr || ws_bytes < bts_conv3d_fwd_gn_workspace(kind, N, D, H, W, Cin, Cout, G)) return BTS_ERR_WORKSPACE;
+  int Do = D, Ho = H, Wo = W;
+  if (kind == BTS_CONV_K3S2) { Do = D / 2; Ho = H / 2; Wo = W / 2; }
+  if (kind == BTS_CONV_K3S2T) { Do = 2 * D; Ho = 2 * H; Wo = 2 * W; }
+  const long cw = (bts_conv3d_fwd_workspace(kind, N, D, H, W, Cin, Cout) + 63) & ~63L;
+  double* gnp = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + cw);
+  long gnB = 0;
+  int r;
+  if (wp2 != nullptr) {
+    r = launch_igemm(GEO_S1, x, wp, bias, y, N, D, H, W, Cin, ldx, D, H, W, Cout, Cout, D, H, W, 0, 0, 0, bias ? IG_FLAG_BIAS : 0,
+                     stream, nullptr, 0, nullptr, wp2, bias2, y2, ldy2, gnp, G, &gnB);
+  } else {
+    const int geo = geo_of_kind_fwd(kind);
+    const int f = bias ? IG_FLAG_BIAS : 0;
+    if (geo == GEO_K1 || geo == GEO_S1)
+      r = launch_igemm(geo, x, wp, bias, y, N, D, H, W, Cin, ldx, D, H, W, Cout, Cout, D, H, W, 0, 0, 0, f, stream, ws, cw, nullptr,
+                       nullptr, nullptr, nullptr, 0, gnp, G, &gnB);
+    else if (geo == GEO_DOWN) {
+      if ((D | H | W) & 1) return BTS_ERR_SHAPE;
+      r = launch_igemm(geo, x, wp, bias, y, N, D, H, W, Cin, ldx, Do, Ho, Wo, Cout, Cout, Do, Ho, Wo, 0, 0, 0, f, stream, ws, cw,
+                       nullptr, nullptr, nullptr, nullptr, 0, gnp, G, &gnB);
+    } else
+      r = launch_igemm(GEO_UP, x, wp, bias, y, N, D, H, W, Cin, ldx, D, H, W, Cout, Cout, Do, Ho, Wo, -1, -1, -1, f, stream, ws, cw);
+  }
+  if (r != BTS_OK) return r;
+  const long V = (long)Do * Ho * Wo;
+  if (gnB > 0) return bts_gn_finalize_partials_(gnp, mean, rstd, N * G, gnB, (double)V * Cout / G, eps, stream);
+  return bts_gn_stats(y, mean, rstd, ws, ws_bytes, N, V, Cout, G, BTS_GN_SLAB, eps, stream);
+}
+extern "C" int bts_conv3d_fwd_gn(int kind, const float* x, const float* wp_fwd, const float* bias, float* y, void* workspace,
+                                 long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int G, float eps,
+                                 float* mean, float* rstd, hipStream_t stream) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin) return BTS_ERR_SHAPE;
+  return conv_fwd_gn_impl(kind, x, wp_fwd, bias, y, nullptr, nullptr, nullptr, 0, workspace, workspace_bytes, N, D, H, W, Cin, ldx,
+                          Cout, G, eps, mean, rstd, stream);
+}
+extern "C" int bts_conv3d_fwd_fused2_gn(const float* x, const float* wp_fwd, const float* bias, float* y, const float* wp2,
+                                        const float* bias2, float* y2, void* workspace, long workspace_bytes, int N, int D, int H,
+                                        int W, int Cin, int ldx, int Cout, int ldy2, int G, float eps, float* mean, float* rstd,
+                                        hipStream_t stream) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldy2 < Cout || !wp2 || !y2) return BTS_ERR_SHAPE;
+  return conv_fwd_gn_impl(BTS_CONV_K3S1, x, wp_fwd, bias, y, wp2, bias2, y2, ldy2, workspace, workspace_bytes, N, D, H, W, Cin, ldx,
+                          Cout, G, eps, mean, rstd, stream);
 }
 
 // Which igemm_kernel<...> instantiation a call resolves to: returns cfg + 8*(KGS==4); cfg ids as in choose_cfg.

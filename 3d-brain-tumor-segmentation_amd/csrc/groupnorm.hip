@@ -266,6 +266,15 @@ extern "C" int bts_gn_stats(const float* x, float* mean, float* rstd, void* work
   return BTS_OK;
 }
 
+int bts_gn_finalize_partials_(const double* partial, float* mean, float* rstd, int NG, long B, double count, float eps,
+                              hipStream_t stream) {
+  if (NG <= 0 || B <= 0 || B > 0x7fffffffL) return BTS_ERR_SHAPE;
+  (void)hipGetLastError(); hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3((NG + 3) / 4), dim3(256), 0, stream, partial, mean, rstd, NG, (int)B, 0,
+                     1, BTS_GN_SLAB, count, eps);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward apply (+ReLU), y may be strided
 // ---------------------------------------------------------------------------------------------

@@ -44,8 +44,11 @@ class ConvDownsample(Layer):
             raise ValueError('ConvDownsample needs even spatial sizes (TF SAME pads (0,1) only then), got %s' % (x.shape,))
         f, g = self.filters, self.groups
         wp = self.packed('f', ops.K3S2, ops.ROLE_FWD, self.conv_k, self.cin, f)
-        c = ops.conv_fwd(ops.K3S2, x.t, wp, self.conv_b.t, f)
-        mean, rstd = ops.gn_stats(c, g, self.norm._mode, self.norm.epsilon)
+        if self.norm._mode == ops.GN_SLAB:
+            c, mean, rstd = ops.conv_fwd_gn(ops.K3S2, x.t, wp, self.conv_b.t, f, g, self.norm.epsilon)
+        else:
+            c = ops.conv_fwd(ops.K3S2, x.t, wp, self.conv_b.t, f)
+            mean, rstd = ops.gn_stats(c, g, self.norm._mode, self.norm.epsilon)
         yt = ops.gn_apply(c, self.norm.gamma.t, self.norm.beta.t, mean, rstd, g, self.norm._mode, True,
                           out=None if out is None else out.t)
         y = out if out is not None else Tensor(yt)

@@ -88,20 +88,35 @@ class ResnetBlock(Layer):
         wp_c1 = pk('c1_f', K3, ops.ROLE_FWD, self.conv1_k, self.cin_ref, f, True)
         wp_c2 = pk('c2_f', K3, ops.ROLE_FWD, self.conv2_k, f, f, False)
         # shortcut conv + conv1 share the input tile: one fused pass where the tiling has the registers for it
-        fused = ops.conv_fwd_fused2(x.t, wp_c1, self.conv1_b.t, wp_pt, self.ptwise_b.t, f)
-        if fused is not None:
-            c1, res = fused
+        # channels_last GroupNorm statistics (z-slab groups) come out of the producing conv's epilogue where possible
+        slab = self.norm1._mode == ops.GN_SLAB
+        m1 = r1 = None
+        if slab:
+            fused = ops.conv_fwd_fused2_gn(x.t, wp_c1, self.conv1_b.t, wp_pt, self.ptwise_b.t, f, g, self.norm1.epsilon)
+            if fused is not None:
+                c1, res, m1, r1 = fused
+            else:
+                res = ops.conv_fwd(K1, x.t, wp_pt, self.ptwise_b.t, f)
+                c1, m1, r1 = ops.conv_fwd_gn(K3, x.t, wp_c1, self.conv1_b.t, f, g, self.norm1.epsilon)
         else:
-            res = ops.conv_fwd(K1, x.t, wp_pt, self.ptwise_b.t, f)
-            c1 = ops.conv_fwd(K3, x.t, wp_c1, self.conv1_b.t, f)
+            fused = ops.conv_fwd_fused2(x.t, wp_c1, self.conv1_b.t, wp_pt, self.ptwise_b.t, f)
+            if fused is not None:
+                c1, res = fused
+            else:
+                res = ops.conv_fwd(K1, x.t, wp_pt, self.ptwise_b.t, f)
+                c1 = ops.conv_fwd(K3, x.t, wp_c1, self.conv1_b.t, f)
         # gates
         gap = ops.colsum(res, scale=1.0 / v)
         hbuf, ch = ops.se_mlp_fwd(gap, self.se_w1.t, self.se_w2.t)
         # conv branch
-        m1, r1 = ops.gn_stats(c1, g, self.norm1._mode, self.norm1.epsilon)
+        if m1 is None:
+            m1, r1 = ops.gn_stats(c1, g, self.norm1._mode, self.norm1.epsilon)
         a = ops.gn_apply(c1, self.norm1.gamma.t, self.norm1.beta.t, m1, r1, g, self.norm1._mode, True)
-        c2 = ops.conv_fwd(K3, a, wp_c2, self.conv2_b.t, f)
-        m2, r2 = ops.gn_stats(c2, g, self.norm2._mode, self.norm2.epsilon)
+        if slab:
+            c2, m2, r2 = ops.conv_fwd_gn(K3, a, wp_c2, self.conv2_b.t, f, g, self.norm2.epsilon)
+        else:
+            c2 = ops.conv_fwd(K3, a, wp_c2, self.conv2_b.t, f)
+            m2, r2 = ops.gn_stats(c2, g, self.norm2._mode, self.norm2.epsilon)
         if out is None:
             out = Tensor(torch.empty((n, d, h, w, f), dtype=torch.float32, device=x.t.device))
         wsp = self.spatial_k.t.reshape(-1)

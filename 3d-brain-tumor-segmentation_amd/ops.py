@@ -192,6 +192,36 @@ def conv_fwd_fused2(x, wp3, bias3, wp1, bias1, cout):
     return c1, res
 
 
+def conv_fwd_gn(kind, x, wp, bias, cout, groups, eps):
+    """(y, mean, rstd): y = conv(x) + bias (dense) and the slab-mode GroupNorm statistics of y, in one pass where the
+    tiled kernel can emit them from its epilogue (the library falls back to bts_gn_stats otherwise)"""
+    n, d, h, w, cin = x.shape
+    y = torch.empty(conv_out_shape(kind, x.shape, cout), dtype=torch.float32, device=x.device)
+    mean = torch.empty(n * groups, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(n * groups, dtype=torch.float32, device=x.device)
+    nb = lib().query('bts_conv3d_fwd_gn_workspace', kind, n, d, h, w, cin, cout, groups)
+    ws = workspace(nb, x.device)
+    lib().call('bts_conv3d_fwd_gn', kind, _p(x), _p(wp), _p(bias), _p(y), _p(ws), nb, n, d, h, w, cin, ld_of(x), cout, groups,
+               float(eps), _p(mean), _p(rstd), _stream())
+    return y, mean, rstd
+
+
+def conv_fwd_fused2_gn(x, wp3, bias3, wp1, bias1, cout, groups, eps):
+    """conv_fwd_fused2 with the GroupNorm statistics of its 3x3x3 output: (c1, res, mean, rstd) or None"""
+    n, d, h, w, cin = x.shape
+    if not lib()._bts_conv3d_fwd_can_fuse(n, d, h, w, cin, cout):
+        return None
+    c1 = torch.empty((n, d, h, w, cout), dtype=torch.float32, device=x.device)
+    res = torch.empty_like(c1)
+    mean = torch.empty(n * groups, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(n * groups, dtype=torch.float32, device=x.device)
+    nb = lib().query('bts_conv3d_fwd_gn_workspace', K3S1, n, d, h, w, cin, cout, groups)
+    ws = workspace(nb, x.device)
+    lib().call('bts_conv3d_fwd_fused2_gn', _p(x), _p(wp3), _p(bias3), _p(c1), _p(wp1), _p(bias1), _p(res), _p(ws), nb, n, d, h, w,
+               cin, ld_of(x), cout, cout, groups, float(eps), _p(mean), _p(rstd), _stream())
+    return c1, res, mean, rstd
+
+
 def conv_bwd_data(kind, dy, wp_bwd, dx, accumulate):
     """dx: [N,D,H,W,Cin] view of the forward input's gradient"""
     n, d, h, w, cin = dx.shape

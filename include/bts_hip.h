@@ -157,6 +157,20 @@ int bts_l2_reg_bwd(const float* params, float* grads, const long* off, const lon
 int bts_adam_tf_step(float* p, const float* g, float* m, float* v, long n, float lr_t, float beta1, float beta2, float eps,
                      float gmul, bts_stream_t stream);
 
+/* ===== convolution + GroupNorm statistics of its output in one pass (resnet.py:80-93: conv -> GroupNormalization) ===== */
+/* y = conv(x) + bias, y DENSE (voxel stride Cout), and (mean, rstd)[N*G] = BTS_GN_SLAB statistics of y.  The sums come out of
+ * the conv epilogue when the tiled kernel takes the launch (no split-K, whole tiles per z-slab group); otherwise the library
+ * runs bts_gn_stats on y itself.  Workspace (required) from bts_conv3d_fwd_gn_workspace. */
+long bts_conv3d_fwd_gn_workspace(int kind, int N, int D, int H, int W, int Cin, int Cout, int G);
+int bts_conv3d_fwd_gn(int kind, const float* x, const float* wp_fwd, const float* bias, float* y, void* workspace,
+                      long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int G, float eps, float* mean,
+                      float* rstd, bts_stream_t stream);
+/* the fused shortcut pair (bts_conv3d_fwd_fused2) with the statistics of its 3x3x3 output y */
+int bts_conv3d_fwd_fused2_gn(const float* x, const float* wp_fwd, const float* bias, float* y, const float* wp2,
+                             const float* bias2, float* y2, void* workspace, long workspace_bytes, int N, int D, int H, int W,
+                             int Cin, int ldx, int Cout, int ldy2, int G, float eps, float* mean, float* rstd,
+                             bts_stream_t stream);
+
 /* ===== non-default samplers (downsample.py:51-70, upsample.py:49-79) ===== */
 /* MaxPooling3D(pool 2, stride 2) on even (D,H,W): y (N,D/2,H/2,W/2,C); idx (dense, one byte per output element) records the
  * window position dz*4+dy*2+dx of the first maximum and routes the gradient in bts_maxpool2_bwd (D,H,W = INPUT dims). */

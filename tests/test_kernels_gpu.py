@@ -161,6 +161,51 @@ def test_conv_up_merged_classes_split_k(monkeypatch, kind, n, dims, cin, cout):
     test_conv_fwd_bwd(kind, n, dims, cin, cout)
 
 
+@pytest.mark.parametrize('kind,n,dims,cin,cout,g', [(1, 1, (16, 16, 32), 32, 32, 8), (1, 2, (32, 16, 32), 16, 64, 8), (1, 1, (8, 8, 8), 8, 16, 8),
+                                                    (2, 1, (32, 32, 32), 32, 32, 8), (1, 1, (6, 10, 14), 12, 20, 2), (3, 1, (4, 4, 8), 16, 32, 4)])
+def test_conv_with_fused_groupnorm_statistics(monkeypatch, kind, n, dims, cin, cout, g):
+    """bts_conv3d_fwd_gn: the conv output and its slab-mode GroupNorm statistics from one call -- epilogue partials where
+    the z-slab groups hold whole tiles, the library's own bts_gn_stats fallback elsewhere (and with the fusion disabled);
+    both against the fp64 reference (group = contiguous 1/G chunk of each sample's flattened (D,H,W,C) memory)."""
+    from bts_amd import ops
+    d, h, w = dims
+    x = rnd((n, d, h, w, cin), 61)
+    wt = rnd(wshape(kind, cin, cout), 62, 0.2)
+    b = rnd((cout,), 63)
+    ref = ref_conv(kind, x.double(), wt.double(), b.double())
+    flat = ref.reshape(n, g, -1)
+    mean_r = flat.mean(dim=2).reshape(-1)
+    rstd_r = 1.0 / torch.sqrt(flat.var(dim=2, unbiased=False) + 1e-5).reshape(-1)
+    wp = ops.conv_pack(kind, ops.ROLE_FWD, wt.to(dev()), cin, cout)
+    for fuse in (True, False):
+        if not fuse:
+            monkeypatch.setenv('BTS_IGEMM_NOGNFUSE', '1')
+        y, mean, rstd = ops.conv_fwd_gn(kind, x.to(dev()), wp, b.to(dev()), cout, g, 1e-5)
+        check_contraction(y, ref, ref_conv(kind, x.double().abs(), wt.double().abs(), b.double().abs()), 'conv_fwd_gn y')
+        check_close(mean, mean_r, 'fused GN mean', rtol=2e-5, atol=2e-5)
+        check_close(rstd, rstd_r, 'fused GN rstd', rtol=2e-5, atol=2e-5)
+
+
+def test_conv_fused_pair_with_groupnorm_statistics():
+    from bts_amd import ops
+    n, (d, h, w), cin, cout, g = 1, (16, 16, 32), 32, 32, 8
+    x = rnd((n, d, h, w, cin), 71)
+    w3, b3 = rnd((3, 3, 3, cin, cout), 72, 0.2), rnd((cout,), 73)
+    w1, b1 = rnd((1, 1, 1, cin, cout), 74, 0.2), rnd((cout,), 75)
+    wp3 = ops.conv_pack(1, ops.ROLE_FWD, w3.to(dev()), cin, cout)
+    wp1 = ops.conv_pack(0, ops.ROLE_FWD, w1.to(dev()), cin, cout)
+    out = ops.conv_fwd_fused2_gn(x.to(dev()), wp3, b3.to(dev()), wp1, b1.to(dev()), cout, g, 1e-5)
+    assert out is not None
+    c1, res, mean, rstd = out
+    r3 = R.conv3d(x.double(), w3.double(), b3.double())
+    r1 = R.conv3d(x.double(), w1.double(), b1.double())
+    check_contraction(c1, r3, R.conv3d(x.double().abs(), w3.double().abs(), b3.double().abs()), 'fused_gn conv3')
+    check_contraction(res, r1, R.conv3d(x.double().abs(), w1.double().abs(), b1.double().abs()), 'fused_gn conv1')
+    flat = r3.reshape(n, g, -1)
+    check_close(mean, flat.mean(dim=2).reshape(-1), 'fused2 GN mean', rtol=2e-5, atol=2e-5)
+    check_close(rstd, (1.0 / torch.sqrt(flat.var(dim=2, unbiased=False) + 1e-5)).reshape(-1), 'fused2 GN rstd', rtol=2e-5, atol=2e-5)
+
+
 def test_conv_strided_views_and_sigmoid():
     """channel slices of a slab as conv input and output (virtual Concatenate), fused sigmoid"""
     from bts_amd import ops
