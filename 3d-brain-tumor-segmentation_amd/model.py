@@ -115,10 +115,16 @@ class Model(Layer):
         if tape is not None:
             gen = tape.gen
 
+            self._l2_val, self._l2_val_gen = val, tape.gen
+
             def backward():
                 g = val.grad
                 if g is None:
                     return
+                from .tape import current_or_replaying_tape
+                tp = current_or_replaying_tape()
+                if tp is not None and tp.grad_sync is not None:
+                    return  # the gradient-sync hook applies the regulariser per bucket before each all-reduce
                 # every parameter's gradient has been written by its layer by now (this node replays last)
                 for p in self.trainable_variables:
                     if p._gen != gen:

@@ -96,3 +96,104 @@ def broadcast_parameters(model, src=0):
         torch.distributed.broadcast(model.flat_params, src=src)
         from .tape import bump_weights_epoch
         bump_weights_epoch()
+
+
+class GradSync(object):
+    """C1 overlapped with the backward pass: the flat gradient buffer is cut into buckets (BUCKET_BYTES, sized for xGMI's
+    per-link-bound rings); the tape reports which parameters each node wrote, and as soon as every parameter of a bucket is
+    final the bucket gets its share of the (rank-identical, pre-divided) L2 term and is all-reduced asynchronously on
+    RCCL's stream while the remaining backward kernels keep the compute stream busy.  Parameters never written (unused in
+    this step) are zero-filled at the end, exactly like the non-overlapped path.  Results are bit-identical to
+    all_reduce_gradients() after a plain backward (same kernels on the same values, only earlier)."""
+
+    def __init__(self, model, bucket_bytes=BUCKET_BYTES):
+        self.model = model
+        ps = model.trainable_variables
+        base = model.flat_grads.data_ptr()
+        self.spans = {}
+        for p_ in ps:
+            off = (p_._gview.data_ptr() - base) // 4
+            self.spans[id(p_)] = (off, p_._gview.numel())
+        self.buckets = []   # (start, length, [param ids])
+        n = model.flat_grads.numel()
+        for off, ln in bucket_ranges(n, 4, bucket_bytes):
+            members = [id(p_) for p_ in ps if self.spans[id(p_)][0] < off + ln and self.spans[id(p_)][0] + self.spans[id(p_)][1] > off]
+            self.buckets.append((off, ln, members))
+        self.by_param = {}
+        for bi, (_, _, members) in enumerate(self.buckets):
+            for pid in members:
+                self.by_param.setdefault(pid, []).append(bi)
+        self.params = {id(p_): p_ for p_ in ps}
+
+    def begin(self, tape):
+        self.tape = tape
+        self.done = set()
+        self.pending = [len(m) for _, _, m in self.buckets]
+        self.launched = [False] * len(self.buckets)
+        self.handles = []
+
+    def params_written(self, params):
+        seen = set()
+        for p_ in params:
+            pid = id(p_)
+            if pid in seen or pid not in self.by_param:
+                continue
+            seen.add(pid)
+            if pid in self.done:
+                # a second tape node wrote a gradient whose bucket may already be in flight: the overlap contract (one
+                # writer node per parameter, true for every layer of this model) is broken -- refuse rather than corrupt
+                raise RuntimeError('parameter %s received gradient contributions from two tape nodes; run with '
+                                   'BTS_DP_NO_OVERLAP=1' % p_.name)
+            self.done.add(pid)
+            for bi in self.by_param[pid]:
+                self.pending[bi] -= 1
+                if self.pending[bi] == 0:
+                    self._launch(bi)
+
+    def _launch(self, bi):
+        from . import ops
+        off, ln, _ = self.buckets[bi]
+        m = self.model
+        fresh = getattr(m, '_l2_val', None) is not None and getattr(m, '_l2_val_gen', None) == self.tape.gen
+        g = m._l2_val.grad if fresh else None   # (no regulariser term was added to this step's loss otherwise)
+        if g is not None and m._l2_ranges:
+            k = l2_grad_scale()
+            rg = []
+            for o, l, c in m._l2_ranges:        # regulariser ranges clipped to this bucket
+                a, b = max(o, off), min(o + l, off + ln)
+                if a < b:
+                    rg.append((a, b - a, c * k))
+            if rg:
+                ops.l2_reg_bwd(m.flat_params, m.flat_grads, rg, g)
+        self.launched[bi] = True
+        if active():
+            self.handles.append(torch.distributed.all_reduce(m.flat_grads[off:off + ln], op=torch.distributed.ReduceOp.SUM,
+                                                             async_op=True))
+
+    def finish(self):
+        from . import ops
+        gen = self.tape.gen
+        for pid, p_ in self.params.items():
+            if pid not in self.done:
+                if p_._gen != gen:              # never written this step: its gradient is exactly the regulariser's
+                    ops.fill(p_._gview, 0.0)
+                    p_._gen = gen
+                self.done.discard(pid)
+                self.params_written([p_])
+        for bi in range(len(self.buckets)):    # (pad-only tail buckets have no members)
+            if not self.launched[bi]:
+                self._launch(bi)
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+
+
+def grad_sync(model):
+    """a GradSync for `model` when a process group exists (and BTS_DP_NO_OVERLAP is unset), else None"""
+    if not active() or os.environ.get('BTS_DP_NO_OVERLAP') or model.flat_grads is None:
+        return None
+    gs = getattr(model, '_grad_sync', None)
+    if gs is None or gs.model.flat_grads.data_ptr() != model.flat_grads.data_ptr():
+        gs = GradSync(model)
+        model._grad_sync = gs
+    return gs

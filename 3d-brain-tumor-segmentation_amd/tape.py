@@ -161,6 +161,8 @@ class Param(Tensor):
         if self._gview is None:
             self._gview = torch.empty(self.t.shape, dtype=torch.float32, device=self.t.device)
         gen = tape.gen if tape is not None else -2
+        if tape is not None and tape._touched is not None:
+            tape._touched.append(self)   # the replay loop reports these to the gradient-sync hook after the node
         if self._gen != gen:
             self._gen = gen
             return self._gview, False
@@ -192,6 +194,8 @@ class GradientTape(object):
         self.persistent = persistent
         self.gen = None
         self._prev = None
+        self._touched = None   # list while a gradient-sync hook is attached to the replay
+        self.grad_sync = None
 
     def __enter__(self):
         global _current, _generation
@@ -209,22 +213,35 @@ class GradientTape(object):
     def record(self, fn):
         self.nodes.append(fn)
 
-    def gradient(self, target, sources):
+    def gradient(self, target, sources, grad_sync=None):
+        """grad_sync (parallel.GradSync, optional): told after every node which parameters' gradients that node wrote, so
+        that finished buckets of the flat gradient buffer are all-reduced while the rest of the backward still runs"""
         global _replaying, _last_gen
         if not isinstance(target, Tensor) or target.t.numel() != 1:
             raise ValueError('target must be a 1-element Tensor (the loss)')
         target.seed_grad(1.0)
         _replaying = self
         _last_gen = self.gen
+        self.grad_sync = grad_sync
+        self._touched = [] if grad_sync is not None else None
         try:
+            if grad_sync is not None:
+                grad_sync.begin(self)
             nodes = self.nodes if self.persistent else None
             seq = self.nodes
             for i in range(len(seq) - 1, -1, -1):
                 seq[i]()
                 if nodes is None:
                     seq[i] = None  # release saved activations as soon as they are consumed
+                if self._touched:
+                    grad_sync.params_written(self._touched)
+                    self._touched = []
+            if grad_sync is not None:
+                grad_sync.finish()
         finally:
             _replaying = None
+            self._touched = None
+            self.grad_sync = None
         if not self.persistent:
             self.nodes = []
         return [s.grad for s in sources]

@@ -142,7 +142,8 @@ def train_step(model, optimizer, loss_fn, dice_fn, x, y):
         loss = loss_fn(x, y, y_pred, y_vae, z_mean, z_logvar)                          # :145
         loss = loss + reduce_sum(model.losses)                                        # :146
     macro_dice, micro_dice = dice_fn(y, y_pred)                                        # :148
-    grads = tape.gradient(loss, model.trainable_variables)                             # :151
-    scale = parallel.all_reduce_gradients(model)                                       # C1 (no-op on one rank)
+    sync = parallel.grad_sync(model)                 # data parallel: all-reduce finished gradient buckets during the backward
+    grads = tape.gradient(loss, model.trainable_variables, grad_sync=sync)             # :151
+    scale = 1.0 if sync is not None else parallel.all_reduce_gradients(model)          # C1 (no-op on one rank)
     optimizer.apply_gradients(zip(grads, model.trainable_variables), model=model, grad_scale=scale)  # :152
     return loss, macro_dice, micro_dice

@@ -110,3 +110,25 @@ def test_bucket_ranges_cover_flat_buffer():
     r = parallel.bucket_ranges(n, 4, 64 << 20)
     assert r[0] == (0, 16777216) and sum(l for _, l in r) == n and all(a + l == b for (a, l), (b, _) in zip(r, r[1:]))
     assert parallel.world() == 1 and parallel.l2_grad_scale() == 1.0
+
+
+def test_grad_sync_bucket_bookkeeping():
+    """parallel.GradSync (SURVEY 8e, C1 overlapped with the backward): buckets tile the flat gradient buffer, every
+    parameter sits in the bucket(s) its span overlaps, and a bucket's pending count is its member count."""
+    m = Model(base_filters=8, groups=2, depth=3)
+    m.build((1, 16, 16, 16, 2))
+    gs = parallel.GradSync(m, bucket_bytes=1 << 14)
+    n = m.flat_grads.numel()
+    covered = 0
+    for off, ln, members in gs.buckets:
+        assert off == covered
+        covered += ln
+        for pid in members:
+            o, l = gs.spans[pid]
+            assert o < off + ln and o + l > off
+    assert covered == n and len(gs.buckets) > 8
+    for p in m.trainable_variables:
+        o, l = gs.spans[id(p)]
+        nb = len(gs.by_param[id(p)])
+        assert nb >= 1 and nb == len([1 for off, ln, _ in gs.buckets if o < off + ln and o + l > off])
+    assert sum(l for _, l in gs.spans.values()) == m.n_params

@@ -75,3 +75,41 @@ def test_resume_is_bit_exact(tmp_path):
         (mA.flat_params - mB.flat_params).abs().max())
     sA, sB = oA._state[id(mA.flat_params)], oB._state[id(mB.flat_params)]
     assert torch.equal(sA[0], sB[0]) and torch.equal(sA[1], sB[1]) and oA.iterations == oB.iterations == 6
+
+
+def test_overlapped_gradient_sync_is_bit_identical(monkeypatch):
+    """parallel.GradSync (bucketed all-reduce issued from inside the backward pass, L2 term applied per bucket) against
+    the plain path (backward, then all_reduce_gradients) on a 1-rank RCCL group: identical parameters after 3 steps."""
+    import bts_amd  # noqa: F401
+    from bts_amd import parallel
+    from bts_amd.util import train_step
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip('a process group already exists in this process')
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29617', rank=0, world_size=1)
+    try:
+        train = _data(3, 300)
+        results = []
+        for overlap in (True, False):
+            if overlap:
+                monkeypatch.delenv('BTS_DP_NO_OVERLAP', raising=False)
+            else:
+                monkeypatch.setenv('BTS_DP_NO_OVERLAP', '1')
+            m, opt, lf, df = _setup()
+            opt(epoch=0)
+            if overlap:
+                gs = parallel.grad_sync(m)
+                assert gs is not None and len(gs.buckets) >= 1
+                parallel_buckets = parallel.GradSync(m, bucket_bytes=1 << 16)   # many small buckets: exercises the bookkeeping
+                m._grad_sync = parallel_buckets
+                assert len(parallel_buckets.buckets) > 4
+            else:
+                assert parallel.grad_sync(m) is None
+            for x, y in train:
+                loss, _, _ = train_step(m, opt, lf, df, x, y)
+            torch.cuda.synchronize()
+            results.append((m.flat_params.clone(), float(loss)))
+        assert results[0][1] == results[1][1]
+        assert torch.equal(results[0][0], results[1][0]), 'max |d| %.3e' % float((results[0][0] - results[1][0]).abs().max())
+    finally:
+        dist.destroy_process_group()
