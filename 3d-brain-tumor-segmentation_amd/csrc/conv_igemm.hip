@@ -55,6 +55,11 @@ struct IgemmParams {
   const float* bias2;
   float* y2;
   int ldy2;
+  // fused second INPUT (27-tap kernels, never together with FUSE2): out += 1x1x1 conv of x2 with wp2 (K1 packing), evaluated at
+  // the centre tap -- the ResNet block's data gradient dx = bwd(conv1)(dc1) + bwd(shortcut)(dres) in one pass
+  // (resnet.py:118,134); the x2 fragment is a 16-byte global load of the voxel's own row (no halo, no LDS)
+  const float* x2;
+  int ldx2;
   // split-K: blockIdx.z handles k-groups [z*kg_per, ...); raw partials go to part[z][voxel][Npad] (no bias/act)
   int ksplit, kg_per;
   float* part;
@@ -83,7 +88,8 @@ struct IgemmParams {
 template <int NT, int MS, int NS, bool F2 = false, bool FIXG = false>
 __device__ __forceinline__ void stage_taps(const IgemmParams& p, const int* tlp, const int* twp, const float* cur,
                                            const int (&bbase)[MS], const int (&lane_woff)[NS], int kg0, int nkg,
-                                           f32x16 (&acc)[MS][NS], f32x16 (*acc2)[NS] = nullptr) {
+                                           f32x16 (&acc)[MS][NS], f32x16 (*acc2)[NS], const float* const (&x2row)[MS],
+                                           bool have_x2) {
   const int wstepKG = 2 * p.Npad * 4;       // floats between consecutive k-groups of one tap
   const int wstepTap = p.KG * wstepKG;      // floats between consecutive taps
   // 27-tap geometries (k3s1, DOWN): LDS offset and weight tap index are arithmetic in the compile-time tap number, so
@@ -111,6 +117,12 @@ __device__ __forceinline__ void stage_taps(const IgemmParams& p, const int* tlp,
     constexpr int AD = 2, BD = 1;  // deeper (3/2) measured neutral on MI355X and costs registers
     f32x4 a[AD + 1][NS], b[BD + 1][MS];
     f32x4 a2s[NS];
+    f32x4 b2in[MS];
+    const bool fin = (NT == 27) && !F2 && have_x2;
+    if (fin) {  // second input: this voxel's 8 channels of the k-group, requested a whole stage ahead of their use
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms) b2in[ms] = *reinterpret_cast<const f32x4*>(x2row[ms] + (kg0 + kgl) * 8);
+    }
 #pragma unroll
     for (int q = 0; q < AD; ++q)
       if (q < NT) {
@@ -141,6 +153,12 @@ __device__ __forceinline__ void stage_taps(const IgemmParams& p, const int* tlp,
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) a2s[ns] = *reinterpret_cast<const f32x4*>((p.wp2 + wk) + lane_woff[ns]);
       }
+      if (!F2 && NT == 27 && t == 11) {
+        if (fin) {
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns) a2s[ns] = *reinterpret_cast<const f32x4*>((p.wp2 + wk) + lane_woff[ns]);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);  // prefetches are issued before this tap's MFMAs, not sunk behind them
       if (F2 && NT == 27 && t == 13) {
 #pragma unroll
@@ -150,6 +168,17 @@ __device__ __forceinline__ void stage_taps(const IgemmParams& p, const int* tlp,
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns)
               acc2[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2s[ns][j], b[t % (BD + 1)][ms][j], acc2[ms][ns], 0, 0, 0);
+      }
+      if (!F2 && NT == 27 && t == 13) {
+        if (fin) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+              for (int ns = 0; ns < NS; ++ns)
+                acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2s[ns][j], b2in[ms][j], acc[ms][ns], 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -243,6 +272,20 @@ __global__ __launch_bounds__(256, IG_TRI(MS, NS, KGS, FUSE2, FIXG) ? 3 : 2) void
     lane_woff[ns] = (h * p.Npad + ncol) * 4;
   }
 
+  const float* x2row[MS];
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms) {
+    x2row[ms] = nullptr;
+    if (p.x2) {
+      const int m = (wm * MS + ms) * 32 + l32;
+      int oz = oz0 + (m >> (p.lgTX + p.lgTY)), oy = oy0 + ((m >> p.lgTX) & (TY - 1)), ox = ox0 + (m & (TX - 1));
+      if (oz >= p.Do) oz = p.Do - 1;   // voxels past the edge are computed and discarded: keep their loads in bounds
+      if (oy >= p.Ho) oy = p.Ho - 1;
+      if (ox >= p.Wo) ox = p.Wo - 1;
+      x2row[ms] = p.x2 + ((((long)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * (long)p.ldx2 + h * 4;
+    }
+  }
+  const bool have_x2 = p.x2 != nullptr;
   f32x16 acc[MS][NS];
 #pragma unroll
   for (int ms = 0; ms < MS; ++ms)
@@ -318,17 +361,17 @@ __global__ __launch_bounds__(256, IG_TRI(MS, NS, KGS, FUSE2, FIXG) ? 3 : 2) void
     } else if constexpr (FIXG || T27 || FUSE2) {  // 27-tap form known at compile time (fixed geometry, the fused pair, or
       // the launcher's T27 instantiation for k3s1 / stride-2 convs): no runtime tap-count dispatch, so the accumulators
       // are not shuffled between register sets around a switch
-      stage_taps<27, MS, NS, FUSE2, FIXG>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc, acc2);
+      stage_taps<27, MS, NS, FUSE2, FIXG>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc, acc2, x2row, have_x2);
     } else if constexpr (KGS == 1) {
       switch (ntaps) {
-        case 27: stage_taps<27, MS, NS, FUSE2, FIXG>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc, acc2); break;
-        case 8: stage_taps<8, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc); break;
-        case 4: stage_taps<4, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc); break;
-        case 2: stage_taps<2, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc); break;
-        default: stage_taps<1, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc); break;
+        case 27: stage_taps<27, MS, NS, FUSE2, FIXG>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc, acc2, x2row, have_x2); break;
+        case 8: stage_taps<8, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc, nullptr, x2row, false); break;
+        case 4: stage_taps<4, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc, nullptr, x2row, false); break;
+        case 2: stage_taps<2, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc, nullptr, x2row, false); break;
+        default: stage_taps<1, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc, nullptr, x2row, false); break;
       }
     } else {  // the 4-k-group staging variant only serves the 1x1x1 convolutions
-      stage_taps<1, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc);
+      stage_taps<1, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc, nullptr, x2row, false);
     }
     if (SINGLE) __syncthreads();  // every wave has finished reading the tile before it is overwritten
     if (more && p.dbg != 2) commit(nxt);
@@ -1214,7 +1257,8 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
                         int Wi, int Cin, int ldx, int Do, int Ho, int Wo, int Cout, int ldy, int ODa, int OHa, int OWa,
                         int pz, int py, int px, int flags, hipStream_t stream, void* ws = nullptr, long ws_bytes = 0,
                         long* need_out = nullptr, const float* wp2 = nullptr, const float* bias2 = nullptr,
-                        float* y2 = nullptr, int ldy2 = 0, double* gnp = nullptr, int gnG = 0, long* gn_B = nullptr) {
+                        float* y2 = nullptr, int ldy2 = 0, double* gnp = nullptr, int gnG = 0, long* gn_B = nullptr,
+                        const float* x2 = nullptr, int ldx2 = 0) {
   if (gn_B) *gn_B = 0;  // stays 0 unless the tiled kernel took the launch and emitted the GroupNorm partials
   if (geo == GEO_S1 && wp2 == nullptr && need_out == nullptr && Cout <= 4) {
     const int r = launch_dsc(x, wp, bias, y, N, Di, Hi, Wi, Cin, ldx, Cout, ldy, flags, stream);
@@ -1239,6 +1283,7 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
   }
   IgemmParams p;
   p.wp2 = wp2; p.bias2 = bias2; p.y2 = y2; p.ldy2 = ldy2;
+  p.x2 = x2; p.ldx2 = ldx2;   // second input (x2 + wp2 without y2): see IgemmParams
   p.part = reinterpret_cast<float*>(ws);
   p.ws_bytes = ws_bytes;
   p.plan_only = need_out != nullptr;
@@ -1299,7 +1344,7 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
   const int k1 = (geo == GEO_K1);
   int M;  // voxels per workgroup tile
   int cfg = choose_cfg(geo, (geo == GEO_UP && pz < 0) ? 8 * N : N, Do, Ho, Wo, p.Npad, &M);
-  if (p.wp2 != nullptr && cfg == 5) { cfg = 0; M = 256; }  // the fused pair needs the registers of the 256-voxel tiling
+  if (p.y2 != nullptr && cfg == 5) { cfg = 0; M = 256; }  // the fused pair needs the registers of the 256-voxel tiling
   // tile dims (powers of two in x,y)
   int TX = 32;
   while (TX > 4 && TX / 2 >= Wo) TX /= 2;  // smallest pow2 >= Wo, capped at 32
@@ -1353,7 +1398,7 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
   int rc;
   const bool fixg = (geo == GEO_S1) && p.IX == 34 && p.IY == 6;
   if (fixg && !k1 && (cfg == 0 || cfg == 1 || cfg == 5)) {
-    if (p.wp2 != nullptr) {
+    if (p.y2 != nullptr) {
       if (cfg == 0) rc = launch_cfg<2, 1, 4, 1, 1, true, true>(p, stream);
       else rc = BTS_ERR_UNSUPPORTED;
     } else {
@@ -1369,7 +1414,7 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
       case 3: rc = launch_cfg<1, 1, 2, 2, 4>(p, stream); break;
       default: rc = launch_cfg<1, 1, 4, 1, 4>(p, stream); break;
     }
-  } else if (p.wp2 != nullptr) {  // fused shortcut conv: every tiling but the 64-accumulator one has the registers
+  } else if (p.y2 != nullptr) {  // fused shortcut conv: every tiling but the 64-accumulator one has the registers
     switch (cfg) {
       case 0: rc = launch_cfg<2, 1, 4, 1, 1, true>(p, stream); break;
       case 5: rc = BTS_ERR_UNSUPPORTED; break;  // M=512 tiling exists only with the compile-time halo geometry
@@ -1568,6 +1613,36 @@ extern "C" int bts_conv3d_fwd_fused2_gn(const float* x, const float* wp_fwd, con
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldy2 < Cout || !wp2 || !y2) return BTS_ERR_SHAPE;
   return conv_fwd_gn_impl(BTS_CONV_K3S1, x, wp_fwd, bias, y, wp2, bias2, y2, ldy2, workspace, workspace_bytes, N, D, H, W, Cin, ldx,
                           Cout, G, eps, mean, rstd, stream);
+}
+
+// dx (+)= data gradient of a 3x3x3 stride-1 conv (dy, wp_bwd) + data gradient of a 1x1x1 conv of the SAME input (dy2, wp2_bwd):
+// the two gradient paths of a ResNet block's input (resnet.py:118,134) in one pass over dx.  Falls back to two launches when
+// the tiled kernel would split the contraction or dy2 cannot be read with 16-byte loads.
+extern "C" long bts_conv3d_bwd_data_pair_workspace(int N, int D, int H, int W, int Cin, int Cout) {
+  const long a = bts_conv3d_bwd_data_workspace(BTS_CONV_K3S1, N, D, H, W, Cin, Cout);
+  const long b = bts_conv3d_bwd_data_workspace(BTS_CONV_K1, N, D, H, W, Cin, Cout);
+  if (a < 0 || b < 0) return -1;
+  return a > b ? a : b;
+}
+extern "C" int bts_conv3d_bwd_data_pair(const float* dy, const float* wp_bwd, const float* dy2, const float* wp2_bwd, float* dx,
+                                        void* workspace, long workspace_bytes, int N, int D, int H, int W, int Cin, int lddx,
+                                        int Cout, int lddy, int lddy2, int flags, hipStream_t stream) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || lddx < Cin || lddy < Cout || lddy2 < Cout) return BTS_ERR_SHAPE;
+  long need = 0;
+  int r = conv_bwd_impl(BTS_CONV_K3S1, nullptr, nullptr, nullptr, nullptr, 0, &need, N, D, H, W, Cin, Cin, Cout, Cout, 0, nullptr);
+  if (r != BTS_OK) return r;
+  const bool fuse = need == 0 && (Cout % 8 == 0) && (lddy2 % 4 == 0) && ((((uintptr_t)dy2) & 15) == 0) && Cin > 4 &&
+                    getenv("BTS_IGEMM_NOPAIR") == nullptr;
+  if (fuse) {
+    int f = 0;
+    if (flags & BTS_CONV_FLAG_ACCUM) f |= IG_FLAG_ACCUM;
+    return launch_igemm(GEO_S1, dy, wp_bwd, nullptr, dx, N, D, H, W, Cout, lddy, D, H, W, Cin, lddx, D, H, W, 0, 0, 0, f, stream,
+                        workspace, workspace_bytes, nullptr, wp2_bwd, nullptr, nullptr, 0, nullptr, 0, nullptr, dy2, lddy2);
+  }
+  r = conv_bwd_impl(BTS_CONV_K3S1, dy, wp_bwd, dx, workspace, workspace_bytes, nullptr, N, D, H, W, Cin, lddx, Cout, lddy, flags, stream);
+  if (r != BTS_OK) return r;
+  return conv_bwd_impl(BTS_CONV_K1, dy2, wp2_bwd, dx, workspace, workspace_bytes, nullptr, N, D, H, W, Cin, lddx, Cout, lddy2,
+                       flags | BTS_CONV_FLAG_ACCUM, stream);
 }
 
 // Which igemm_kernel<...> instantiation a call resolves to: returns cfg + 8*(KGS==4); cfg ids as in choose_cfg.

@@ -148,13 +148,7 @@ class ResnetBlock(Layer):
         dc1 = group_norm_backward(n1, c1, da, n1.gamma.t, n1.beta.t, m1, r1, True)
         del da
         need_dx = x.requires_grad
-        if need_dx:
-            dx, acc = x.grad_slot()
-            wpb1 = self.packed('c1_b', K3, ops.ROLE_BWD, self.conv1_k, self.cin_ref, f, cin, dup_start, dup_shift)
-            ops.conv_bwd_data(K3, dc1, wpb1, dx, acc)
-        _wgrad(K3, x.t, dc1, self.conv1_k, self.conv1_b, dup_start, dup_shift)
-        del dc1
-        # ---- gate branch
+        # ---- gate branch (independent of the conv branch; evaluated first so that both gradients into x leave in one pass)
         gw1, a1 = self.se_w1.grad_slot()
         gw2, a2 = self.se_w2.grad_slot()
         gws, a3 = self.spatial_k.grad_slot()
@@ -165,10 +159,13 @@ class ResnetBlock(Layer):
             a1 = True
         dres = ops.se_bwd(dout, res, sp, gap, hbuf, ch, self.se_w1.t, self.se_w2.t, self.spatial_k.t.reshape(-1), gw1, gw2,
                           gws.reshape(-1), accumulate_params=a1)
-        if need_dx:
+        if need_dx:   # dx (+)= conv1^T dc1 + shortcut^T dres: the 1x1x1 term rides on the centre tap of the 3x3x3 sweep
             dx, acc = x.grad_slot()
+            wpb1 = self.packed('c1_b', K3, ops.ROLE_BWD, self.conv1_k, self.cin_ref, f, cin, dup_start, dup_shift)
             wpbp = self.packed('pt_b', K1, ops.ROLE_BWD, self.ptwise_k, self.cin_ref, f, cin, dup_start, dup_shift)
-            ops.conv_bwd_data(K1, dres, wpbp, dx, acc)
+            ops.conv_bwd_data_pair(dc1, wpb1, dres, wpbp, dx, acc)
+        _wgrad(K3, x.t, dc1, self.conv1_k, self.conv1_b, dup_start, dup_shift)
+        del dc1
         _wgrad(K1, x.t, dres, self.ptwise_k, self.ptwise_b, dup_start, dup_shift)
 
     def get_config(self):

@@ -50,6 +50,17 @@ def profile_records():
     return out
 
 
+def conv_bwd_data_pair(dy, wp_bwd, dy2, wp2_bwd, dx, accumulate):
+    """dx (+)= bwd_data(3x3x3)(dy) + bwd_data(1x1x1)(dy2): both gradient paths into a ResNet block's input in one pass"""
+    n, d, h, w, cin = dx.shape
+    cout = dy.shape[4]
+    nb = lib().query('bts_conv3d_bwd_data_pair_workspace', n, d, h, w, cin, cout)
+    ws = workspace(nb, dy.device) if nb > 0 else None
+    lib().call('bts_conv3d_bwd_data_pair', _p(dy), _p(wp_bwd), _p(dy2), _p(wp2_bwd), _p(dx), _p(ws), nb, n, d, h, w, cin,
+               ld_of(dx), cout, ld_of(dy), ld_of(dy2), FLAG_ACCUM if accumulate else 0, _stream())
+    return dx
+
+
 def conv_flops(kind, n, d, h, w, cin, cout):
     """algorithmic FLOPs of one conv call, SURVEY 8(d) convention (MAC = 2; (d,h,w) = forward INPUT dims)"""
     v = n * d * h * w

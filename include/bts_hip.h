@@ -157,6 +157,16 @@ int bts_l2_reg_bwd(const float* params, float* grads, const long* off, const lon
 int bts_adam_tf_step(float* p, const float* g, float* m, float* v, long n, float lr_t, float beta1, float beta2, float eps,
                      float gmul, bts_stream_t stream);
 
+/* ===== the two data-gradient paths into a ResNet block's input in one pass (resnet.py:118,134: x feeds conv1 and the
+ * 1x1x1 shortcut) ===== */
+/* dx (+)= bwd_data(3x3x3 s1)(dy, wp_bwd) + bwd_data(1x1x1)(dy2, wp2_bwd); both weight images in BTS_ROLE_BWD_DATA packing.
+ * The 1x1x1 term is evaluated at the centre tap of the 3x3x3 sweep; the library falls back to two launches where that is
+ * not possible (split-K grids, unaligned dy2). */
+long bts_conv3d_bwd_data_pair_workspace(int N, int D, int H, int W, int Cin, int Cout);
+int bts_conv3d_bwd_data_pair(const float* dy, const float* wp_bwd, const float* dy2, const float* wp2_bwd, float* dx,
+                             void* workspace, long workspace_bytes, int N, int D, int H, int W, int Cin, int lddx, int Cout,
+                             int lddy, int lddy2, int flags, bts_stream_t stream);
+
 /* ===== convolution + GroupNorm statistics of its output in one pass (resnet.py:80-93: conv -> GroupNormalization) ===== */
 /* y = conv(x) + bias, y DENSE (voxel stride Cout), and (mean, rstd)[N*G] = BTS_GN_SLAB statistics of y.  The sums come out of
  * the conv epilogue when the tiled kernel takes the launch (no split-K, whole tiles per z-slab group); otherwise the library

@@ -206,6 +206,39 @@ def test_conv_fused_pair_with_groupnorm_statistics():
     check_close(rstd, (1.0 / torch.sqrt(flat.var(dim=2, unbiased=False) + 1e-5)).reshape(-1), 'fused2 GN rstd', rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize('n,dims,cin,cout,pad', [(1, (16, 16, 32), 32, 32, 0), (2, (8, 8, 8), 24, 16, 8), (1, (4, 4, 4), 64, 128, 0),
+                                                 (1, (32, 32, 32), 48, 64, 16), (1, (6, 10, 14), 12, 8, 0)])
+def test_conv_bwd_data_pair(monkeypatch, n, dims, cin, cout, pad):
+    """bts_conv3d_bwd_data_pair: dx (+)= bwd(3x3x3)(dy) + bwd(1x1x1)(dy2) in one pass (centre-tap fusion), into a slab slice,
+    with accumulation, and with the fusion disabled (two launches) -- all against the fp64 reference."""
+    from bts_amd import ops
+    d, h, w = dims
+    x = rnd((n, d, h, w, cin), 81).double().requires_grad_(True)
+    w3 = rnd((3, 3, 3, cin, cout), 82, 0.2)
+    w1 = rnd((1, 1, 1, cin, cout), 83, 0.3)
+    dy, dy2 = rnd((n, d, h, w, cout), 84), rnd((n, d, h, w, cout), 85)
+    y = R.conv3d(x, w3.double(), None)
+    y2 = R.conv3d(x, w1.double(), None)
+    (y * dy.double()).sum().backward(retain_graph=True)
+    (y2 * dy2.double()).sum().backward()
+    ref = x.grad
+    xa = x.detach().abs().requires_grad_(True)
+    ((R.conv3d(xa, w3.double().abs(), None) * dy.double().abs()).sum() + (R.conv3d(xa, w1.double().abs(), None) * dy2.double().abs()).sum()).backward()
+    bound = xa.grad
+    wpb3 = ops.conv_pack(1, ops.ROLE_BWD, w3.to(dev()), cin, cout)
+    wpb1 = ops.conv_pack(0, ops.ROLE_BWD, w1.to(dev()), cin, cout)
+    for fuse in (True, False):
+        if not fuse:
+            monkeypatch.setenv('BTS_IGEMM_NOPAIR', '1')
+        slab = torch.full((n, d, h, w, cin + pad), 3.0, device=dev())
+        dx = slab[..., pad:]
+        ops.conv_bwd_data_pair(dy.to(dev()), wpb3, dy2.to(dev()), wpb1, dx, False)
+        check_contraction(dx, ref, bound, 'bwd_data_pair fuse=%s' % fuse)
+        assert pad == 0 or float((slab[..., :pad] - 3.0).abs().max()) == 0.0
+        ops.conv_bwd_data_pair(dy.to(dev()), wpb3, dy2.to(dev()), wpb1, dx, True)
+        check_contraction(dx, 2 * ref, 2 * bound, 'bwd_data_pair accumulate fuse=%s' % fuse)
+
+
 def test_conv_strided_views_and_sigmoid():
     """channel slices of a slab as conv input and output (virtual Concatenate), fused sigmoid"""
     from bts_amd import ops
