@@ -800,7 +800,10 @@ __global__ __launch_bounds__(256, 2) void upm_kernel(const UpmParams p) {
       const int co = nb + 8 * g + 4 * h;
       if (co >= p.Cout) continue;
       f32x4 v = {acc[c][4 * g + 0], acc[c][4 * g + 1], acc[c][4 * g + 2], acc[c][4 * g + 3]};
-      if (p.flags & IG_FLAG_BIAS) v += *reinterpret_cast<const f32x4*>(p.bias + co);
+      if (p.flags & IG_FLAG_BIAS) {   // element loads: the bias is a view into the flat parameter buffer, 4-byte aligned only
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += p.bias[co + j];
+      }
       if (p.flags & IG_FLAG_SIGMOID) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = sigmoidf_(v[j]);
@@ -850,7 +853,6 @@ static int launch_upm(const float* x, const float* wp, const float* bias, float*
                       int ldx, int Cout, int ldy, int flags, void* ws, long ws_bytes, hipStream_t stream) {
   if (getenv("BTS_IGEMM_NOUPM") != nullptr) return 1;
   if ((ldx & 3) || (ldy & 3) || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 15)) return 1;
-  if ((flags & IG_FLAG_BIAS) && (((uintptr_t)bias) & 15)) return 1;
   UpmParams p;
   long need = 0;
   if (!plan_upm(p, N, Di, Hi, Wi, Cin, Cout, &need)) return 1;
