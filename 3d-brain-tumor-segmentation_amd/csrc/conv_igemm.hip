@@ -21,6 +21,12 @@
 // input halo tile for KGS*8 channels staged global->regs->LDS, double buffered (one barrier per stage);
 // weight fragments come straight from L2/L1 (shared by the 4 waves), input fragments from LDS via
 // ds_read_b128 with a 16B-odd voxel stride (S = KGS*8+4 dwords) so 16-lane groups hit distinct slots.
+//
+// Also in this translation unit (they share the packed-weight layout, the flag bits and the split-K reduce kernel):
+//   upm_kernel  -- UP form with all 8 output-parity classes per workgroup (Conv3DTranspose forward, stride-2 data gradient)
+//   k1s_kernel  -- LDS-free streaming 1x1x1 conv for big grids
+//   dsc_kernel  -- vector-ALU direct 3x3x3 conv for <= 4 output channels
+// and the fused entry points: shortcut pair (FUSE2), GroupNorm statistics in the epilogue, data-gradient pair (second input).
 #include <stdlib.h>
 #include "common.h"
 #include "bts_internal.h"

@@ -9,9 +9,12 @@
 // N = 32 Q-channels, K = voxels (v_mfma_f32_32x32x2_f32 consumes 2 voxels per instruction).
 // A 512-thread workgroup (8 waves) walks a run of spatial sub-tiles; the waves split the row-tiles (27 taps) or, when
 // there are at most 4 row-tiles, the voxel pairs.  P halo tile and Q tile live in LDS as [voxel][channels] so both
-// fragment reads are conflict-free ds_read_b32; the next sub-tile is prefetched global->registers while the current
-// one is multiplied (double-buffered LDS, one barrier per sub-tile).  Per-workgroup partials go to a workspace and are
-// combined in a fixed order by the finalize kernel (bitwise reproducible; no float atomics).
+// fragment reads are conflict-free ds_read_b32; the next sub-tile is staged by direct global->LDS DMA
+// (global_load_lds_dwordx4) while the current one is multiplied (double-buffered LDS, one barrier per sub-tile).
+// Kernel variants <MODE, FIXG>: <2,1>/<2,2> straight-line fixed-geometry sweeps with interleaved staging for every big
+// 3x3x3 layer (stride 1 / 2), <1,0> general LDS-DMA staging, <0,0> register staging for odd strides / channel counts.
+// Per-workgroup partials go to a workspace and are combined in a fixed order by the finalize kernel (bitwise
+// reproducible; no float atomics).
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
