@@ -5,3 +5,7 @@
 // groupnorm.hip: mean / rstd from per-block (sum, sumsq) partials laid out [N*G][B][2] (slab semantics), fixed order
 int bts_gn_finalize_partials_(const double* partial, float* mean, float* rstd, int NG, long B, double count, float eps,
                               hipStream_t stream);
+
+// conv_wino.hip: 3x3x3 stride-1 conv in Winograd F(2x2,3x3) x direct form; BTS_OK = taken, 1 = declined (run the implicit GEMM)
+int bts_wino_launch_(const float* x, const float* up, const float* bias, float* y, int N, int D, int H, int W, int Cin, int ldx,
+                     int Cout, int ldy, int accum, double* gnp, int gnG, long* gn_B, hipStream_t stream);

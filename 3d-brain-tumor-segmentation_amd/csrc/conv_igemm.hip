@@ -524,37 +524,72 @@ struct PackParams {
   int flip;         // tap t reads source tap ntaps-1-t
   int cin_is_k;     // 1: the (possibly folded) input-channel axis is k, 0: it is n, -1: no fold
   int shift, dup_start;
+  long wino_off;    // K3S1 images: element index where the Winograd part starts; otherwise beyond the image
+  long total;       // floats of the whole image
 };
 
+// source value of packed position (tap t, contraction index k, column n), with the tap flip of the data-gradient role and
+// the encoder's duplicated input slice folded in
+__device__ __forceinline__ float pack_src(const PackParams& q, int t, int k, int n) {
+  if (k >= q.K || n >= q.N) return 0.f;
+  const int ts = q.flip ? (q.ntaps - 1 - t) : t;
+  int kk = k, nn = n, k2 = -1, n2 = -1;
+  if (q.cin_is_k == 1) {
+    if (k >= q.dup_start) k2 = k - q.dup_start;
+    kk = k + q.shift;
+    n2 = n;
+  } else if (q.cin_is_k == 0) {
+    if (n >= q.dup_start) n2 = n - q.dup_start;
+    nn = n + q.shift;
+    k2 = k;
+  }
+  float v = q.w[ts * q.sT + kk * q.sK + nn * q.sN];
+  if (q.shift > 0 && k2 >= 0 && n2 >= 0) v += q.w[ts * q.sT + k2 * q.sK + n2 * q.sN];
+  return v;
+}
+
 __device__ __forceinline__ float pack_elem(const PackParams& q, long i) {
+  if (i >= q.wino_off) {
+    // Winograd part of a K3S1 image (conv_wino.hip): U = G g G^T over the (z, y) taps, per x tap;
+    // layout [cout block of 32][k-group][x tap][xi_z*4 + xi_y][half][32][4]
+    long r = i - q.wino_off;
+    const int j = (int)(r & 3);
+    const int n32 = (int)((r >> 2) & 31);
+    const int hh = (int)((r >> 7) & 1);
+    const int xi = (int)((r >> 8) & 15);
+    r >>= 12;
+    const int dx = (int)(r % 3); r /= 3;
+    const int kg = (int)(r % q.KG);
+    const int cb = (int)(r / q.KG);
+    const int k = kg * 8 + hh * 4 + j, n = cb * 32 + n32;
+    const int xz = xi >> 2, xy = xi & 3;
+    // rows of G: (1 0 0) (.5 .5 .5) (.5 -.5 .5) (0 0 1)
+    float u = 0.f;
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) {
+      const float gz = (xz == 0) ? (kz == 0 ? 1.f : 0.f) : (xz == 3) ? (kz == 2 ? 1.f : 0.f) : ((xz == 2 && kz == 1) ? -0.5f : 0.5f);
+      if (gz == 0.f) continue;
+      float s = 0.f;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const float gy = (xy == 0) ? (ky == 0 ? 1.f : 0.f) : (xy == 3) ? (ky == 2 ? 1.f : 0.f) : ((xy == 2 && ky == 1) ? -0.5f : 0.5f);
+        if (gy != 0.f) s = fmaf(gy, pack_src(q, (kz * 3 + ky) * 3 + dx, k, n), s);
+      }
+      u = fmaf(gz, s, u);
+    }
+    return u;
+  }
   const int j = (int)(i & 3);
   long r = i >> 2;
   const int n = (int)(r % q.Npad); r /= q.Npad;
   const int hh = (int)(r & 1); r >>= 1;
   const int kg = (int)(r % q.KG);
   const int t = (int)(r / q.KG);
-  const int k = kg * 8 + hh * 4 + j;
-  float v = 0.f;
-  if (k < q.K && n < q.N) {
-    const int ts = q.flip ? (q.ntaps - 1 - t) : t;
-    int kk = k, nn = n, k2 = -1, n2 = -1;
-    if (q.cin_is_k == 1) {
-      if (k >= q.dup_start) k2 = k - q.dup_start;
-      kk = k + q.shift;
-      n2 = n;
-    } else if (q.cin_is_k == 0) {
-      if (n >= q.dup_start) n2 = n - q.dup_start;
-      nn = n + q.shift;
-      k2 = k;
-    }
-    v = q.w[ts * q.sT + kk * q.sK + nn * q.sN];
-    if (q.shift > 0 && k2 >= 0 && n2 >= 0) v += q.w[ts * q.sT + k2 * q.sK + n2 * q.sN];
-  }
-  return v;
+  return pack_src(q, t, kg * 8 + hh * 4 + j, n);
 }
 
 __global__ void pack_kernel(const PackParams q) {
-  const long total = (long)q.ntaps * q.KG * 2 * q.Npad * 4;
+  const long total = q.total;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
     q.wp[i] = pack_elem(q, i);
 }
@@ -588,7 +623,8 @@ extern "C" long bts_conv_packed_floats(int kind, int role, int Cin, int Cout) {
   const int ntaps = (kind == BTS_CONV_K1) ? 1 : 27;
   const int K = (role == BTS_ROLE_FWD) ? Cin : Cout;
   const int N = (role == BTS_ROLE_FWD) ? Cout : Cin;
-  return (long)ntaps * ((K + 7) / 8) * 2 * npad32(N) * 4;
+  // K3S1 images carry a second, Winograd-domain copy (16 transform points x 3 x taps) for conv_wino.hip
+  return (long)(ntaps + (kind == BTS_CONV_K3S1 ? 48 : 0)) * ((K + 7) / 8) * 2 * npad32(N) * 4;
 }
 
 static int pack_params(PackParams& q, int kind, int role, const float* w, float* wp, int Cin_ref, int Cout, int Cin_slab,
@@ -613,6 +649,9 @@ static int pack_params(PackParams& q, int kind, int role, const float* w, float*
   }
   q.KG = (q.K + 7) / 8;
   q.Npad = npad32(q.N);
+  const long ig = (long)q.ntaps * q.KG * 2 * q.Npad * 4;
+  q.wino_off = (kind == BTS_CONV_K3S1) ? ig : (1L << 62);
+  q.total = ig + ((kind == BTS_CONV_K3S1) ? 48L * q.KG * 2 * q.Npad * 4 : 0L);
   return BTS_OK;
 }
 
@@ -621,7 +660,7 @@ extern "C" int bts_conv_pack(int kind, int role, const float* w, float* wp, int 
   PackParams q;
   const int r = pack_params(q, kind, role, w, wp, Cin_ref, Cout, Cin_slab, dup_start, dup_shift);
   if (r != BTS_OK) return r;
-  const long total = (long)q.ntaps * q.KG * 2 * q.Npad * 4;
+  const long total = q.total;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   (void)hipGetLastError(); hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, stream, q);
@@ -638,7 +677,7 @@ extern "C" long bts_conv_pack_desc(void* host_table, int index, long first_block
   PackDesc d;
   const int r = pack_params(d.q, kind, role, w, wp, Cin_ref, Cout, Cin_slab, dup_start, dup_shift);
   if (r != BTS_OK) return r;
-  d.total = (long)d.q.ntaps * d.q.KG * 2 * d.q.Npad * 4;
+  d.total = d.q.total;
   d.first_block = first_block;
   reinterpret_cast<PackDesc*>(host_table)[index] = d;
   return (d.total + PACK_BLOCK_ELEMS - 1) / PACK_BLOCK_ELEMS;
@@ -1270,6 +1309,23 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
   if (gn_B) *gn_B = 0;  // stays 0 unless the tiled kernel took the launch and emitted the GroupNorm partials
   if (geo == GEO_S1 && wp2 == nullptr && need_out == nullptr && Cout <= 4) {
     const int r = launch_dsc(x, wp, bias, y, N, Di, Hi, Wi, Cin, ldx, Cout, ldy, flags, stream);
+    if (r != 1) return r;
+  }
+  if (geo == GEO_S1 && need_out == nullptr && !(flags & IG_FLAG_SIGMOID)) {
+    // Winograd form (conv_wino.hip) on the second part of the K3S1 image; the fused shortcut output / second input of the
+    // pair entry points then run as their own 1x1x1 launches
+    const float* up = wp + 27L * ((Cin + 7) / 8) * 2 * npad32(Cout) * 4;
+    const int r = bts_wino_launch_(x, up, (flags & IG_FLAG_BIAS) ? bias : nullptr, y, N, Di, Hi, Wi, Cin, ldx, Cout, ldy,
+                                   (flags & IG_FLAG_ACCUM) ? 1 : 0, gnp, gnG, gn_B, stream);
+    if (r == BTS_OK) {
+      if (y2 != nullptr)
+        return launch_igemm(GEO_K1, x, wp2, bias2, y2, N, Di, Hi, Wi, Cin, ldx, Di, Hi, Wi, Cout, ldy2, Di, Hi, Wi, 0, 0, 0,
+                            bias2 ? IG_FLAG_BIAS : 0, stream);
+      if (x2 != nullptr)
+        return launch_igemm(GEO_K1, x2, wp2, nullptr, y, N, Di, Hi, Wi, Cin, ldx2, Di, Hi, Wi, Cout, ldy, Di, Hi, Wi, 0, 0, 0,
+                            IG_FLAG_ACCUM, stream);
+      return BTS_OK;
+    }
     if (r != 1) return r;
   }
   if (geo == GEO_K1 && wp2 == nullptr && need_out == nullptr) {

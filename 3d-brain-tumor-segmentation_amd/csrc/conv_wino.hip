@@ -1,0 +1,368 @@
+// 3x3x3 stride-1 'same' convolution with the (z, y) plane in Winograd F(2x2, 3x3) form and the x axis direct, on the
+// exact-fp32 matrix pipe of gfx950 (v_mfma_f32_32x32x2_f32).  Serves the same call sites as the 27-tap implicit GEMM
+// (reference: layers/resnet.py:30-37,80-87,96-103  layers/decoder.py:55-63  layers/vae.py:92-99, and their data
+// gradients = the same form on flipped, transposed weights): 12 matrix instructions per output voxel and channel pair
+// instead of 27.
+//
+//   Y = A^T [ (G g G^T) o (B^T d B) ] A   per 2x2 (z, y) output patch, summed over the three x taps and the input channels
+//   B^T = (1 0 -1 0 | 0 1 1 0 | 0 -1 1 0 | 0 1 0 -1)   G = (1 0 0 | .5 .5 .5 | .5 -.5 .5 | 0 0 1)   A^T = (1 1 1 0 | 0 1 -1 -1)
+//
+// U = G g G^T is formed at weight-packing time (conv_igemm.hip: second part of the K3S1 image, layout
+// [cout block of 32][k-group of 8 cin][x tap][xi = xi_z*4 + xi_y][half h][32 couts][4 cin]).
+//
+// Work decomposition: 256 threads = 4 waves; workgroup tile = 32 (x) x 4 (y) x 4 (z) output voxels x 32 couts; each wave
+// owns one 2x2 (z, y) patch row of 32 x positions and ALL 16 transform points: 16 accumulators of 32 voxels x 32 couts =
+// 256 accumulation registers, one wave per SIMD.  The 34 x 6 x 6 halo tile of 8 input channels is staged
+// global -> registers -> LDS (double buffered, voxel stride 12 dwords: conflict-free ds_read_b128, as the implicit GEMM).
+// Lane (h, x) reads the 4 x 4 patch of its x position for channels h*4..h*4+3, forms the transform with packed fp32 adds
+// one group (one xi_z, four xi_y) AHEAD of the matrix instructions that consume it, and the U fragments stream from L2
+// two groups ahead.  Out-of-image halo voxels are fetched with an out-of-range buffer offset (the load returns zeros).
+//
+// Rounding: the transforms add fp32 values before the multiply, so results differ from the direct form in the last bits
+// (measured max |err| 5e-6 at |y| ~ 3, K = 864); the summation order is fixed (deterministic).
+#include <stdlib.h>
+#include "common.h"
+#include "bts_internal.h"
+
+int bts_prof_on();
+void bts_prof_begin(int sym, double flops, hipStream_t stream);
+void bts_prof_end(hipStream_t stream);
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct WinoParams {
+  const float* x;
+  const float* up;
+  const float* bias;
+  float* y;
+  int N, D, H, W, ldx, Cout, ldy, KG;
+  int ntz, nty, ntx;
+  int accum;
+  double* gnp;  // fused GroupNorm partial sums (slab semantics), layout as igemm_kernel's
+  int gn_G, gn_zt;
+};
+
+#define WS 12
+#define WIX 34
+#define WIY 6
+#define WIZ 6
+#define WVOX (WIX * WIY * WIZ)
+#define WBUF (WVOX * WS)
+#define WNSLOT 10
+#define LDSOFF(i, j, dx) ((((i) * WIY + (j)) * WIX + (dx)) * WS)
+
+__device__ __forceinline__ f32x4 bufload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+// packed fp32 add / subtract (the compiler selects scalar v_sub_f32 for vector subtraction; every vector-ALU instruction
+// issued next to the matrix pipe costs ~9 cycles of a single-wave SIMD, so halving their number is worth the asm)
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x4 add4(f32x4 a, f32x4 b) {
+  const f32x2 lo = pk_add(a.xy, b.xy), hi = pk_add(a.zw, b.zw);
+  return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
+__device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {
+  const f32x2 lo = pk_sub(a.xy, b.xy), hi = pk_sub(a.zw, b.zw);
+  return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
+// y transform of one z-combined row set
+__device__ __forceinline__ void wino_yt(const f32x4 (&c)[4], f32x4 (&v)[4]) {
+  v[0] = sub4(c[0], c[2]);
+  v[1] = add4(c[1], c[2]);
+  v[2] = sub4(c[2], c[1]);
+  v[3] = sub4(c[1], c[3]);
+}
+// one group: xi_z fixed, 4 xi_y values, 4 channel pairs -> 16 MFMAs (A = U rows = couts, B = transformed input columns = x)
+__device__ __forceinline__ void wino_mfma16(const f32x4 (&v)[4], const f32x4 (&a)[4], f32x16 (&acc)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e][j], v[e][j], acc[e], 0, 0, 0);
+}
+// after every MFMA: room for two vector-ALU operations and one memory request of the group
+#define WINO_SCHED_GROUP()                                 \
+  _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     \
+    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);     \
+    __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);     \
+  }
+
+__global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l32 = lane & 31;
+  int b = blockIdx.x;
+  const int tx = b % p.ntx; b /= p.ntx;
+  const int ty = b % p.nty; b /= p.nty;
+  const int tz = b % p.ntz;
+  const int n = b / p.ntz;
+  const int oz0 = tz * 4, oy0 = ty * 4, ox0 = tx * 32;
+  const int iz0 = oz0 - 1, iy0 = oy0 - 1, ix0 = ox0 - 1;
+
+  // halo origin of this tile; slots outside the image get a 2 GB offset = outside the descriptor -> the load returns zeros
+  const float* xorg = p.x + ((((long)n * p.D + iz0) * p.H + iy0) * p.W + ix0) * (long)p.ldx;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xorg, 0, 0x7fffffff, 0x00020000);
+  // U of this cout block: [k-group][x tap][xi][h][32][4] = 1 KB per (x tap, xi) image
+  const __amdgpu_buffer_rsrc_t wr =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.up + (long)blockIdx.y * p.KG * (3 * 16 * 256)), 0, 0x7fffffff, 0x00020000);
+  unsigned goff[WNSLOT];
+#pragma unroll
+  for (int i = 0; i < WNSLOT; ++i) {
+    const int e = tid + i * 256;
+    goff[i] = 0x80000000u;
+    if (e < WVOX * 2) {
+      const int vox = e >> 1, q = e & 1;
+      const int vz = vox / (WIY * WIX);
+      const int r = vox - vz * (WIY * WIX);
+      const int vy = r / WIX;
+      const int vx = r - vy * WIX;
+      if ((unsigned)(iz0 + vz) < (unsigned)p.D && (unsigned)(iy0 + vy) < (unsigned)p.H && (unsigned)(ix0 + vx) < (unsigned)p.W)
+        goff[i] = (unsigned)(((vz * p.H + vy) * p.W + vx) * p.ldx + q * 4) * 4u;
+    }
+  }
+  const int tz2 = wave >> 1, ty2 = wave & 1;
+  const int bbase = ((2 * tz2 * WIY + 2 * ty2) * WIX + l32) * WS + h * 4;
+  const unsigned wlane = (unsigned)((h * 32 + l32) * 16);
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+  f32x4 pre[WNSLOT];
+  auto fetch = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < WNSLOT; ++i) pre[i] = bufload(xr, goff[i], (unsigned)st * 32u);
+  };
+  auto commit = [&](float* buf) {
+#pragma unroll
+    for (int i = 0; i < WNSLOT; ++i) {
+      const int e = tid + i * 256;
+      if (e < WVOX * 2) *reinterpret_cast<f32x4*>(buf + (e >> 1) * WS + (e & 1) * 4) = pre[i];
+    }
+  };
+
+  fetch(0);
+  // U fragments of group G = st*12 + g live in aw[G % 3]; two groups are always in flight
+  f32x4 aw[3][4];
+  constexpr int zorder[4] = {1, 2, 0, 3};
+  auto wload = [&](f32x4 (&dst)[4], int st, int g) {
+    const int dx = g >> 2, xz = zorder[g & 3];
+    const unsigned so = (unsigned)(((st * 3 + dx) * 16 + xz * 4) * 1024);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dst[e] = bufload(wr, wlane + e * 1024, so);
+  };
+  wload(aw[0], 0, 0);
+  wload(aw[1], 0, 1);
+  commit(lds);
+  __syncthreads();
+
+  const int nst = p.KG;
+  for (int st = 0; st < nst; ++st) {
+    const float* cur = lds + (st & 1) * WBUF;
+    float* nxt = lds + ((st + 1) & 1) * WBUF;
+    const bool more = (st + 1) < nst;
+    if (more) fetch(st + 1);
+    const float* lb = cur + bbase;
+    const int stn = more ? st + 1 : st;  // the last stage re-requests its own first groups instead of running past the image
+    {
+      // Software pipeline: while the 16 MFMAs of group G run on v[G&1], the vector ALU forms v[(G+1)&1] -- a matrix
+      // instruction never waits for an operand written just before it.
+      f32x4 r1[4], r2[4], rt[4], c[4], v[2][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        r1[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(1, j, 0));
+        r2[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(2, j, 0));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c[j] = add4(r1[j], r2[j]);
+      wino_yt(c, v[0]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        {  // MFMA xi_z = 1 ; form xi_z = 2 : d2 - d1 ; request row 0
+          const int G = dx * 4 + 0;
+          wload(aw[(G + 2) % 3], (G + 2 < 12) ? st : stn, (G + 2) % 12);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) rt[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(0, j, dx));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) c[j] = sub4(r2[j], r1[j]);
+          wino_yt(c, v[1]);
+          wino_mfma16(v[0], aw[G % 3], acc[1]);
+          WINO_SCHED_GROUP();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        {  // MFMA xi_z = 2 ; form xi_z = 0 : d0 - d2 ; then request row 3
+          const int G = dx * 4 + 1;
+          wload(aw[(G + 2) % 3], (G + 2 < 12) ? st : stn, (G + 2) % 12);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) c[j] = sub4(rt[j], r2[j]);
+          wino_yt(c, v[0]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) rt[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(3, j, dx));
+          wino_mfma16(v[1], aw[G % 3], acc[2]);
+          WINO_SCHED_GROUP();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        {  // MFMA xi_z = 0 ; form xi_z = 3 : d1 - d3 ; then request rows 1, 2 of the next x tap
+          const int G = dx * 4 + 2;
+          wload(aw[(G + 2) % 3], (G + 2 < 12) ? st : stn, (G + 2) % 12);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) c[j] = sub4(r1[j], rt[j]);
+          wino_yt(c, v[1]);
+          if (dx < 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              r1[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(1, j, dx + 1));
+              r2[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(2, j, dx + 1));
+            }
+          }
+          wino_mfma16(v[0], aw[G % 3], acc[0]);
+          WINO_SCHED_GROUP();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        {  // MFMA xi_z = 3 ; form xi_z = 1 of the next x tap : d1 + d2
+          const int G = dx * 4 + 3;
+          wload(aw[(G + 2) % 3], (G + 2 < 12) ? st : stn, (G + 2) % 12);
+          if (dx < 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = add4(r1[j], r2[j]);
+            wino_yt(c, v[0]);
+          }
+          wino_mfma16(v[1], aw[G % 3], acc[3]);
+          WINO_SCHED_GROUP();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    if (more) commit(nxt);
+    __syncthreads();
+  }
+
+  // ---- output transform (A^T . A over (z, y)), bias, optional accumulate, store; D rows = couts (4 per register quad) ----
+  f32x4 bq[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    bq[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+      const int co = blockIdx.y * 32 + 8 * g + 4 * h;
+      if (co < p.Cout) bq[g] = f32x4{p.bias[co], p.bias[co + 1], p.bias[co + 2], p.bias[co + 3]};  // 4-byte aligned views are common
+    }
+  }
+  const int oxx = ox0 + l32;
+  const int zb = oz0 + 2 * tz2, yb = oy0 + 2 * ty2;
+  float* ybase = p.y + ((((long)n * p.D + zb) * p.H + yb) * p.W + oxx) * (long)p.ldy + blockIdx.y * 32 + 4 * h;
+  const long ysY = (long)p.W * p.ldy, ysZ = (long)p.H * p.W * p.ldy;
+  const bool inx = oxx < p.W;
+  float gn_s = 0.f, gn_q = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {  // one register quad (4 couts) of all 16 accumulators at a time
+    f32x4 tq[4][2];
+#pragma unroll
+    for (int xz = 0; xz < 4; ++xz) {
+      f32x4 q[4];
+#pragma unroll
+      for (int xy = 0; xy < 4; ++xy)
+        q[xy] = f32x4{acc[xz][xy][4 * g], acc[xz][xy][4 * g + 1], acc[xz][xy][4 * g + 2], acc[xz][xy][4 * g + 3]};
+      tq[xz][0] = q[0] + q[1] + q[2];
+      tq[xz][1] = q[1] - q[2] - q[3];
+    }
+    const bool cok = inx && (blockIdx.y * 32 + 8 * g + 4 * h < p.Cout);
+#pragma unroll
+    for (int oy = 0; oy < 2; ++oy) {
+      f32x4 o[2];
+      o[0] = tq[0][oy] + tq[1][oy] + tq[2][oy] + bq[g];
+      o[1] = tq[1][oy] - tq[2][oy] - tq[3][oy] + bq[g];
+      if (cok && yb + oy < p.H) {
+#pragma unroll
+        for (int oz = 0; oz < 2; ++oz) {
+          if (zb + oz < p.D) {
+            if (p.gnp) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { gn_s += o[oz][j]; gn_q = fmaf(o[oz][j], o[oz][j], gn_q); }
+            }
+            f32x4* dst = reinterpret_cast<f32x4*>(ybase + oz * ysZ + oy * ysY + 8 * g);
+            f32x4 v = o[oz];
+            if (p.accum) v += *dst;
+            *dst = v;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (p.gnp) {  // fixed-order combine: lanes (shuffle tree) -> 4 waves (LDS) -> one (sum, sumsq) pair per workgroup
+    const double ds = wave_sum_f64((double)gn_s), dq = wave_sum_f64((double)gn_q);
+    double* sh = reinterpret_cast<double*>(lds);  // the staging buffers are idle (last barrier passed)
+    if (lane == 0) { sh[wave * 2] = ds; sh[wave * 2 + 1] = dq; }
+    __syncthreads();
+    if (tid == 0) {
+      const int g = tz / p.gn_zt;
+      const long B = (long)p.gn_zt * p.nty * p.ntx * gridDim.y;
+      const long b_ = (((long)(tz - g * p.gn_zt) * p.nty + ty) * p.ntx + tx) * gridDim.y + blockIdx.y;
+      double* o = p.gnp + (((long)n * p.gn_G + g) * B + b_) * 2;
+      o[0] = sh[0] + sh[2] + sh[4] + sh[6];
+      o[1] = sh[1] + sh[3] + sh[5] + sh[7];
+    }
+  }
+}
+
+static int wino_enabled() {  // BTS_WINO=0: every 3x3x3 conv on the implicit GEMM (read per call: tests and A/B runs toggle it)
+  const char* e = getenv("BTS_WINO");
+  return e ? atoi(e) : 1;
+}
+
+// Returns BTS_OK when the launch was taken, 1 when declined (the caller runs the implicit GEMM), another code on error.
+// up: the Winograd part of the K3S1 packed image.  gn_B: as launch_igemm's.
+int bts_wino_launch_(const float* x, const float* up, const float* bias, float* y, int N, int D, int H, int W, int Cin, int ldx,
+                     int Cout, int ldy, int accum, double* gnp, int gnG, long* gn_B, hipStream_t stream) {
+  if (!wino_enabled()) return 1;
+  if (Cin % 8 != 0 || Cout % 4 != 0 || Cout < 16 || ldx % 4 != 0 || ldy % 4 != 0) return 1;
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)y) & 15)) return 1;
+  if (W < 32 || H < 4 || D < 4) return 1;  // a narrower grid leaves most of the 32 x columns of a wave empty
+  if (((long)(D + 2) * H * W + 64) * (long)ldx * 4 >= 0x7fffffffL) return 1;  // 31-bit byte offsets inside one volume
+  WinoParams p;
+  p.x = x; p.up = up; p.bias = bias; p.y = y;
+  p.N = N; p.D = D; p.H = H; p.W = W; p.ldx = ldx; p.Cout = Cout; p.ldy = ldy; p.KG = Cin / 8;
+  p.ntz = (D + 3) / 4; p.nty = (H + 3) / 4; p.ntx = (W + 31) / 32;
+  p.accum = accum;
+  const int nb = (Cout + 31) / 32;
+  const long wgs = (long)N * p.ntz * p.nty * p.ntx * nb;
+  int min_wgs = 192;
+  { const char* e = getenv("BTS_WINO_MIN_WGS"); if (e) min_wgs = atoi(e); }
+  if (wgs < min_wgs || wgs > 0x7fffffffL / nb) return 1;  // one workgroup per CU at a time: too few tiles leave CUs idle
+  p.gnp = nullptr; p.gn_G = 0; p.gn_zt = 1;
+  if (gnp != nullptr && gnG > 0 && D % gnG == 0 && (D / gnG) % 4 == 0 && getenv("BTS_IGEMM_NOGNFUSE") == nullptr) {
+    p.gnp = gnp; p.gn_G = gnG; p.gn_zt = (D / gnG) / 4;
+  }
+  static bool attr_done = false;
+  const size_t shmem = 2 * WBUF * sizeof(float);
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  const bool prof = bts_prof_on();
+  if (prof) bts_prof_begin(23, 2.0 * 27 * Cin * Cout * (double)N * D * H * W, stream);
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(wino_kernel, dim3((unsigned)(N * p.ntz * p.nty * p.ntx), nb), dim3(256), shmem, stream, p);
+  if (prof) bts_prof_end(stream);
+  BTS_LAUNCH_CHECK();
+  if (gn_B && p.gnp != nullptr) *gn_B = (long)p.gn_zt * p.nty * p.ntx * nb;
+  return BTS_OK;
+}
