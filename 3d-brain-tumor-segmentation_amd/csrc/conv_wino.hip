@@ -89,6 +89,13 @@ __device__ __forceinline__ void wino_mfma16(const f32x4 (&v)[4], const f32x4 (&a
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e][j], v[e][j], acc[e], 0, 0, 0);
 }
+// accumulator element -> vector register, pinned in program order (volatile): the compiler otherwise reads all 256
+// accumulation registers at the loop exit and spills what does not fit
+__device__ __forceinline__ float acc_rd(float a) {
+  float v;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+  return v;
+}
 // after every MFMA: room for two vector-ALU operations and one memory request of the group
 #define WINO_SCHED_GROUP()                                 \
   _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {      \
@@ -255,6 +262,9 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
   }
 
   // ---- output transform (A^T . A over (z, y)), bias, optional accumulate, store; D rows = couts (4 per register quad) ----
+  // the accumulators are read with hand-written v_accvgpr_read (acc_rd): the compiler's hazard tracking does not see them,
+  // so the 16-pass latency of the last matrix instructions is covered explicitly (18 wait states required, 80 given)
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
   f32x4 bq[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -278,7 +288,7 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
       f32x4 q[4];
 #pragma unroll
       for (int xy = 0; xy < 4; ++xy)
-        q[xy] = f32x4{acc[xz][xy][4 * g], acc[xz][xy][4 * g + 1], acc[xz][xy][4 * g + 2], acc[xz][xy][4 * g + 3]};
+        q[xy] = f32x4{acc_rd(acc[xz][xy][4 * g]), acc_rd(acc[xz][xy][4 * g + 1]), acc_rd(acc[xz][xy][4 * g + 2]), acc_rd(acc[xz][xy][4 * g + 3])};
       tq[xz][0] = q[0] + q[1] + q[2];
       tq[xz][1] = q[1] - q[2] - q[3];
     }

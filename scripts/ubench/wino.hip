@@ -342,7 +342,7 @@ int main(int argc, char** argv) {
   hipMemcpy(dup, hup.data(), hup.size() * 4, hipMemcpyHostToDevice);
   hipMemset(dy, 0, nvox * K * 4);
   WinoParams p{};
-  p.x = dx_; p.up = dup; p.bias = db; p.y = dy; p.N = 1; p.D = D; p.H = H; p.W = W; p.Cin = C; p.ldx = C; p.Cout = K; p.ldy = K;
+  p.x = dx_; p.up = dup; p.bias = getenv("NOBIAS") ? nullptr : db; p.y = dy; p.N = 1; p.D = D; p.H = H; p.W = W; p.Cin = C; p.ldx = C; p.Cout = K; p.ldy = K;
   p.Npad = Npad; p.KG = KG; p.ntz = (D + 3) / 4; p.nty = (H + 3) / 4; p.ntx = (W + 31) / 32; p.dbg = dbg;
   p.tpw = argc > 5 ? atoi(argv[5]) : 8; p.nzc = (p.ntz + p.tpw - 1) / p.tpw;
   const int ldsb = 2 * WBUF * 4;
