@@ -8,4 +8,8 @@ int bts_gn_finalize_partials_(const double* partial, float* mean, float* rstd, i
 
 // conv_wino.hip: 3x3x3 stride-1 conv in Winograd F(2x2,3x3) x direct form; BTS_OK = taken, 1 = declined (run the implicit GEMM)
 int bts_wino_launch_(const float* x, const float* up, const float* bias, float* y, int N, int D, int H, int W, int Cin, int ldx,
-                     int Cout, int ldy, int accum, double* gnp, int gnG, long* gn_B, hipStream_t stream);
+                     int Cout, int ldy, int accum, double* gnp, int gnG, long* gn_B, void* ws, long ws_bytes, hipStream_t stream);
+long bts_wino_workspace_(int N, int D, int H, int W, int Cin, int Cout);
+// conv_igemm.hip: y (+)= bias + sum_z part[z][voxel][Npad]  (finish of a split-K launch, fixed summation order)
+int bts_igemm_reduce_(const float* part, const float* bias, float* y, long nvox, int Cout, int Npad, int ldy, int ksplit,
+                      int with_bias, int accum, hipStream_t stream);

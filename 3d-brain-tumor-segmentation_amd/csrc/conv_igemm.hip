@@ -509,6 +509,17 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const float* __restri
   }
 }
 
+int bts_igemm_reduce_(const float* part, const float* bias, float* y, long nvox, int Cout, int Npad, int ldy, int ksplit,
+                      int with_bias, int accum, hipStream_t stream) {
+  long blocks = (nvox * Cout + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(igemm_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, part, bias, y, nvox, Cout, Npad, ldy, ksplit,
+                     (with_bias ? IG_FLAG_BIAS : 0) | (accum ? IG_FLAG_ACCUM : 0));
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Weight packing (role = forward or data-gradient). Source layouts are the reference's Keras layouts:
 // Conv3D (kd,kh,kw,Cin,Cout) -- resnet.py:30-37,80-87; Conv3DTranspose (kd,kh,kw,Cout,Cin) -- upsample.py:28-33.
@@ -1316,7 +1327,7 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
     // pair entry points then run as their own 1x1x1 launches
     const float* up = wp + 27L * ((Cin + 7) / 8) * 2 * npad32(Cout) * 4;
     const int r = bts_wino_launch_(x, up, (flags & IG_FLAG_BIAS) ? bias : nullptr, y, N, Di, Hi, Wi, Cin, ldx, Cout, ldy,
-                                   (flags & IG_FLAG_ACCUM) ? 1 : 0, gnp, gnG, gn_B, stream);
+                                   (flags & IG_FLAG_ACCUM) ? 1 : 0, gnp, gnG, gn_B, ws, ws_bytes, stream);
     if (r == BTS_OK) {
       if (y2 != nullptr)
         return launch_igemm(GEO_K1, x, wp2, bias2, y2, N, Di, Hi, Wi, Cin, ldx, Di, Hi, Wi, Cout, ldy2, Di, Hi, Wi, 0, 0, 0,
@@ -1506,7 +1517,13 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
       default: rc = launch_cfg<1, 1, 4, 1, 1>(p, stream); break;
     }
   }
-  if (need_out) *need_out = p.ws_need;
+  if (need_out) {
+    *need_out = p.ws_need;
+    if (geo == GEO_S1) {  // the Winograd form may split the contraction where the implicit GEMM does not (and vice versa)
+      const long wn = bts_wino_workspace_(N, Di, Hi, Wi, Cin, Cout);
+      if (wn > *need_out) *need_out = wn;
+    }
+  }
   if (gn_B && rc == BTS_OK && p.gnp != nullptr) *gn_B = (long)p.gn_zt * p.nty * p.ntx * p.gn_gridy;
   return rc;
 }

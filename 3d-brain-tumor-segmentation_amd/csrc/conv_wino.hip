@@ -20,6 +20,7 @@
 //
 // Rounding: the transforms add fp32 values before the multiply, so results differ from the direct form in the last bits
 // (measured max |err| 5e-6 at |y| ~ 3, K = 864); the summation order is fixed (deterministic).
+#include <stdio.h>
 #include <stdlib.h>
 #include "common.h"
 #include "bts_internal.h"
@@ -41,16 +42,29 @@ struct WinoParams {
   int accum;
   double* gnp;  // fused GroupNorm partial sums (slab semantics), layout as igemm_kernel's
   int gn_G, gn_zt;
+  // split-K: blockIdx.z handles k-groups [z*kg_per, ...); raw partial outputs go to part[z][voxel][Npad] and are finished
+  // (bias, accumulate) by the implicit GEMM's reduce kernel
+  int ksplit, kg_per, Npad;
+  float* part;
 };
 
-#define WS 12
-#define WIX 34
-#define WIY 6
-#define WIZ 6
-#define WVOX (WIX * WIY * WIZ)
-#define WBUF (WVOX * WS)
-#define WNSLOT 10
-#define LDSOFF(i, j, dx) ((((i) * WIY + (j)) * WIX + (dx)) * WS)
+#define WS 12      // dwords per staged voxel: 8 channels + 4 pad (16-byte-odd stride, conflict-free ds_read_b128)
+#define WNSLOT 10  // staging slots (16 bytes) per thread and stage
+// Tile geometry.  XW = 32: a wave's 32 matrix columns are 32 x positions of one 2x2 (z, y) patch row; tile 32 x 4 x 4.
+// XW = 16 (grids narrower than 32): the columns are 16 x positions of TWO y patches; tile 16 x 8 x 4.  The LDS row
+// stride LX is padded to 24 voxels there: two patch rows are then a multiple of 64 dwords apart and the two halves of a
+// ds_read_b128 lane group fall on complementary banks.
+template <int XW>
+struct WinoGeo {
+  static constexpr int SX = XW + 2;                 // staged halo columns
+  static constexpr int LX = (XW == 32) ? 34 : 24;   // LDS row stride (voxels)
+  static constexpr int IY = (XW == 32) ? 6 : 10, IZ = 6;
+  static constexpr int TY = (XW == 32) ? 4 : 8;     // output rows per tile
+  static constexpr int NSTAGE = SX * IY * IZ;       // staged voxels (1224 / 1080)
+  static constexpr int BUF = LX * IY * IZ * WS;     // dwords per LDS buffer
+  static constexpr int off(int i, int j, int dx) { return ((i * IY + j) * LX + dx) * WS; }
+};
+#define LDSOFF(i, j, dx) (G_::off(i, j, dx))
 
 __device__ __forceinline__ f32x4 bufload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
@@ -104,7 +118,9 @@ __device__ __forceinline__ float acc_rd(float a) {
     __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);     \
   }
 
+template <int XW>
 __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
+  typedef WinoGeo<XW> G_;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -115,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
   const int ty = b % p.nty; b /= p.nty;
   const int tz = b % p.ntz;
   const int n = b / p.ntz;
-  const int oz0 = tz * 4, oy0 = ty * 4, ox0 = tx * 32;
+  const int oz0 = tz * 4, oy0 = ty * G_::TY, ox0 = tx * XW;
   const int iz0 = oz0 - 1, iy0 = oy0 - 1, ix0 = ox0 - 1;
 
   // halo origin of this tile; slots outside the image get a 2 GB offset = outside the descriptor -> the load returns zeros
@@ -129,18 +145,20 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
   for (int i = 0; i < WNSLOT; ++i) {
     const int e = tid + i * 256;
     goff[i] = 0x80000000u;
-    if (e < WVOX * 2) {
+    if (e < G_::NSTAGE * 2) {
       const int vox = e >> 1, q = e & 1;
-      const int vz = vox / (WIY * WIX);
-      const int r = vox - vz * (WIY * WIX);
-      const int vy = r / WIX;
-      const int vx = r - vy * WIX;
+      const int vz = vox / (G_::IY * G_::SX);
+      const int r = vox - vz * (G_::IY * G_::SX);
+      const int vy = r / G_::SX;
+      const int vx = r - vy * G_::SX;
       if ((unsigned)(iz0 + vz) < (unsigned)p.D && (unsigned)(iy0 + vy) < (unsigned)p.H && (unsigned)(ix0 + vx) < (unsigned)p.W)
         goff[i] = (unsigned)(((vz * p.H + vy) * p.W + vx) * p.ldx + q * 4) * 4u;
     }
   }
-  const int tz2 = wave >> 1, ty2 = wave & 1;
-  const int bbase = ((2 * tz2 * WIY + 2 * ty2) * WIX + l32) * WS + h * 4;
+  const int tz2 = wave >> 1;
+  const int ty2 = (XW == 32) ? (wave & 1) : ((wave & 1) * 2 + (l32 >> 4));  // y patch of this lane
+  const int xl = (XW == 32) ? l32 : (l32 & 15);                              // x position inside the tile
+  const int bbase = ((2 * tz2 * G_::IY + 2 * ty2) * G_::LX + xl) * WS + h * 4;
   const unsigned wlane = (unsigned)((h * 32 + l32) * 16);
 
   f32x16 acc[4][4];
@@ -160,11 +178,22 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
 #pragma unroll
     for (int i = 0; i < WNSLOT; ++i) {
       const int e = tid + i * 256;
-      if (e < WVOX * 2) *reinterpret_cast<f32x4*>(buf + (e >> 1) * WS + (e & 1) * 4) = pre[i];
+      if (e < G_::NSTAGE * 2) {
+        const int vox = e >> 1;
+        const int row = vox / G_::SX;   // (vz*IY + vy); SX == LX for the 32-wide tile
+        const int lo = (G_::SX == G_::LX) ? vox * WS : (row * G_::LX + (vox - row * G_::SX)) * WS;
+        *reinterpret_cast<f32x4*>(buf + lo + (e & 1) * 4) = pre[i];
+      }
     }
   };
 
-  fetch(0);
+  int st0 = 0, st1 = p.KG;
+  if (p.ksplit > 1) {
+    st0 = blockIdx.z * p.kg_per;
+    st1 = st0 + p.kg_per;
+    if (st1 > p.KG) st1 = p.KG;
+  }
+  fetch(st0);
   // U fragments of group G = st*12 + g live in aw[G % 3]; two groups are always in flight
   f32x4 aw[3][4];
   constexpr int zorder[4] = {1, 2, 0, 3};
@@ -174,16 +203,15 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) dst[e] = bufload(wr, wlane + e * 1024, so);
   };
-  wload(aw[0], 0, 0);
-  wload(aw[1], 0, 1);
+  wload(aw[0], st0, 0);
+  wload(aw[1], st0, 1);
   commit(lds);
   __syncthreads();
 
-  const int nst = p.KG;
-  for (int st = 0; st < nst; ++st) {
-    const float* cur = lds + (st & 1) * WBUF;
-    float* nxt = lds + ((st + 1) & 1) * WBUF;
-    const bool more = (st + 1) < nst;
+  for (int st = st0; st < st1; ++st) {
+    const float* cur = lds + ((st - st0) & 1) * G_::BUF;
+    float* nxt = lds + ((st - st0 + 1) & 1) * G_::BUF;
+    const bool more = (st + 1) < st1;
     if (more) fetch(st + 1);
     const float* lb = cur + bbase;
     const int stn = more ? st + 1 : st;  // the last stage re-requests its own first groups instead of running past the image
@@ -269,16 +297,19 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     bq[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
+    if (p.bias && p.ksplit <= 1) {
       const int co = blockIdx.y * 32 + 8 * g + 4 * h;
       if (co < p.Cout) bq[g] = f32x4{p.bias[co], p.bias[co + 1], p.bias[co + 2], p.bias[co + 3]};  // 4-byte aligned views are common
     }
   }
-  const int oxx = ox0 + l32;
+  const int oxx = ox0 + xl;
   const int zb = oz0 + 2 * tz2, yb = oy0 + 2 * ty2;
   float* ybase = p.y + ((((long)n * p.D + zb) * p.H + yb) * p.W + oxx) * (long)p.ldy + blockIdx.y * 32 + 4 * h;
   const long ysY = (long)p.W * p.ldy, ysZ = (long)p.H * p.W * p.ldy;
   const bool inx = oxx < p.W;
+  const bool raw = p.ksplit > 1;
+  float* pbase = nullptr;
+  if (raw) pbase = p.part + (((long)blockIdx.z * p.N + n) * p.D * p.H * p.W + ((long)zb * p.H + yb) * p.W + oxx) * p.Npad + blockIdx.y * 32 + 4 * h;
   float gn_s = 0.f, gn_q = 0.f;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {  // one register quad (4 couts) of all 16 accumulators at a time
@@ -292,7 +323,7 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
       tq[xz][0] = q[0] + q[1] + q[2];
       tq[xz][1] = q[1] - q[2] - q[3];
     }
-    const bool cok = inx && (blockIdx.y * 32 + 8 * g + 4 * h < p.Cout);
+    const bool cok = inx && (blockIdx.y * 32 + 8 * g + 4 * h < (raw ? p.Npad : p.Cout));
 #pragma unroll
     for (int oy = 0; oy < 2; ++oy) {
       f32x4 o[2];
@@ -306,10 +337,14 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) { gn_s += o[oz][j]; gn_q = fmaf(o[oz][j], o[oz][j], gn_q); }
             }
-            f32x4* dst = reinterpret_cast<f32x4*>(ybase + oz * ysZ + oy * ysY + 8 * g);
-            f32x4 v = o[oz];
-            if (p.accum) v += *dst;
-            *dst = v;
+            if (raw) {
+              *reinterpret_cast<f32x4*>(pbase + ((long)oz * p.H + oy) * p.W * p.Npad + 8 * g) = o[oz];
+            } else {
+              f32x4* dst = reinterpret_cast<f32x4*>(ybase + oz * ysZ + oy * ysY + 8 * g);
+              f32x4 v = o[oz];
+              if (p.accum) v += *dst;
+              *dst = v;
+            }
           }
         }
       }
@@ -337,42 +372,102 @@ static int wino_enabled() {  // BTS_WINO=0: every 3x3x3 conv on the implicit GEM
   return e ? atoi(e) : 1;
 }
 
-// Returns BTS_OK when the launch was taken, 1 when declined (the caller runs the implicit GEMM), another code on error.
-// up: the Winograd part of the K3S1 packed image.  gn_B: as launch_igemm's.
-int bts_wino_launch_(const float* x, const float* up, const float* bias, float* y, int N, int D, int H, int W, int Cin, int ldx,
-                     int Cout, int ldy, int accum, double* gnp, int gnG, long* gn_B, hipStream_t stream) {
-  if (!wino_enabled()) return 1;
-  if (Cin % 8 != 0 || Cout % 4 != 0 || Cout < 16 || ldx % 4 != 0 || ldy % 4 != 0) return 1;
-  if ((((uintptr_t)x) & 15) || (((uintptr_t)y) & 15)) return 1;
-  if (W < 32 || H < 4 || D < 4) return 1;  // a narrower grid leaves most of the 32 x columns of a wave empty
-  if (((long)(D + 2) * H * W + 64) * (long)ldx * 4 >= 0x7fffffffL) return 1;  // 31-bit byte offsets inside one volume
-  WinoParams p;
-  p.x = x; p.up = up; p.bias = bias; p.y = y;
-  p.N = N; p.D = D; p.H = H; p.W = W; p.ldx = ldx; p.Cout = Cout; p.ldy = ldy; p.KG = Cin / 8;
-  p.ntz = (D + 3) / 4; p.nty = (H + 3) / 4; p.ntx = (W + 31) / 32;
-  p.accum = accum;
-  const int nb = (Cout + 31) / 32;
-  const long wgs = (long)N * p.ntz * p.nty * p.ntx * nb;
-  int min_wgs = 192;
-  { const char* e = getenv("BTS_WINO_MIN_WGS"); if (e) min_wgs = atoi(e); }
-  if (wgs < min_wgs || wgs > 0x7fffffffL / nb) return 1;  // one workgroup per CU at a time: too few tiles leave CUs idle
-  p.gnp = nullptr; p.gn_G = 0; p.gn_zt = 1;
-  if (gnp != nullptr && gnG > 0 && D % gnG == 0 && (D / gnG) % 4 == 0 && getenv("BTS_IGEMM_NOGNFUSE") == nullptr) {
-    p.gnp = gnp; p.gn_G = gnG; p.gn_zt = (D / gnG) / 4;
+struct WinoPlan {
+  int xw, ntz, nty, ntx, nb, ksplit, kg_per;
+  long wgs, need;
+};
+// tile geometry and k-split of one call; false = not a Winograd shape
+static bool wino_plan(WinoPlan& q, int N, int D, int H, int W, int Cin, int Cout) {
+  if (Cin % 8 != 0 || Cout % 4 != 0 || Cout < 16) return false;
+  if (W < 12 || H < 4 || D < 4) return false;  // a narrower grid leaves most matrix columns of a wave empty
+  // 16-wide tiles when they waste fewer columns (W <= 16, or W = 33..48 etc.)
+  const int pad32 = (W + 31) / 32 * 32, pad16 = (W + 15) / 16 * 16;
+  q.xw = (pad16 < pad32) ? 16 : 32;
+  q.ntz = (D + 3) / 4;
+  q.nty = (q.xw == 32) ? (H + 3) / 4 : (H + 7) / 8;
+  q.ntx = (W + q.xw - 1) / q.xw;
+  q.nb = (Cout + 31) / 32;
+  q.wgs = (long)N * q.ntz * q.nty * q.ntx * q.nb;
+  if (q.wgs > 0x7fffffffL / q.nb) return false;
+  // one workgroup per CU at a time: a grid below ~one wave of workgroups is split along the input channels
+  const int KG = Cin / 8;
+  q.ksplit = 1;
+  q.kg_per = KG;
+  q.need = 0;
+  if (q.wgs < 192 && KG >= 8) {
+    int ks = (int)((256 + q.wgs - 1) / q.wgs);
+    if (ks > KG / 4) ks = KG / 4;   // at least 4 stages per workgroup
+    if (ks > 16) ks = 16;
+    if (ks > 1) {
+      const int per = (KG + ks - 1) / ks;
+      ks = (KG + per - 1) / per;
+      if (ks > 1) {
+        q.ksplit = ks;
+        q.kg_per = per;
+        q.need = (long)ks * N * D * H * W * (q.nb * 32) * 4;
+      }
+    }
   }
+  return true;
+}
+// workspace the Winograd form wants for a call (0 = none / not taken): lets the planner size the buffer for both forms
+long bts_wino_workspace_(int N, int D, int H, int W, int Cin, int Cout) {
+  WinoPlan q;
+  if (!wino_enabled() || !wino_plan(q, N, D, H, W, Cin, Cout)) return 0;
+  return q.need;
+}
+
+template <int XW>
+static int wino_launch_cfg(const WinoParams& p, const WinoPlan& q, double flops, hipStream_t stream) {
+  auto kern = wino_kernel<XW>;
   static bool attr_done = false;
-  const size_t shmem = 2 * WBUF * sizeof(float);
+  const size_t shmem = 2 * WinoGeo<XW>::BUF * sizeof(float);
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
   const bool prof = bts_prof_on();
-  if (prof) bts_prof_begin(23, 2.0 * 27 * Cin * Cout * (double)N * D * H * W, stream);
+  if (prof) bts_prof_begin(23, flops, stream);
   (void)hipGetLastError();
-  hipLaunchKernelGGL(wino_kernel, dim3((unsigned)(N * p.ntz * p.nty * p.ntx), nb), dim3(256), shmem, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.N * q.ntz * q.nty * q.ntx), q.nb, q.ksplit), dim3(256), shmem, stream, p);
   if (prof) bts_prof_end(stream);
   BTS_LAUNCH_CHECK();
-  if (gn_B && p.gnp != nullptr) *gn_B = (long)p.gn_zt * p.nty * p.ntx * nb;
+  return BTS_OK;
+}
+
+// Returns BTS_OK when the launch was taken, 1 when declined (the caller runs the implicit GEMM), another code on error.
+// up: the Winograd part of the K3S1 packed image.  gn_B: as launch_igemm's.  ws: split-K workspace (may be NULL).
+int bts_wino_launch_(const float* x, const float* up, const float* bias, float* y, int N, int D, int H, int W, int Cin, int ldx,
+                     int Cout, int ldy, int accum, double* gnp, int gnG, long* gn_B, void* ws, long ws_bytes, hipStream_t stream) {
+  if (!wino_enabled()) return 1;
+  if (getenv("BTS_WINO_LOG")) fprintf(stderr, "wino? N=%d D=%d H=%d W=%d Cin=%d Cout=%d ldx=%d ldy=%d accum=%d gn=%d\n", N, D, H, W, Cin, Cout, ldx, ldy, accum, gnp != nullptr);
+  if (ldx % 4 != 0 || ldy % 4 != 0) return 1;
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)y) & 15)) return 1;
+  if (((long)(D + 2) * H * W + 64) * (long)ldx * 4 >= 0x7fffffffL) return 1;  // 31-bit byte offsets inside one volume
+  WinoPlan q;
+  if (!wino_plan(q, N, D, H, W, Cin, Cout)) return 1;
+  if (q.ksplit > 1 && (ws == nullptr || ws_bytes < q.need || (((uintptr_t)ws) & 15))) { q.ksplit = 1; q.kg_per = Cin / 8; }
+  int min_wgs = 192;
+  { const char* e = getenv("BTS_WINO_MIN_WGS"); if (e) min_wgs = atoi(e); }
+  if (q.wgs * q.ksplit < min_wgs) return 1;
+  WinoParams p;
+  p.x = x; p.up = up; p.bias = bias; p.y = y;
+  p.N = N; p.D = D; p.H = H; p.W = W; p.ldx = ldx; p.Cout = Cout; p.ldy = ldy; p.KG = Cin / 8;
+  p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx;
+  p.accum = accum;
+  p.ksplit = q.ksplit; p.kg_per = q.kg_per; p.Npad = q.nb * 32; p.part = reinterpret_cast<float*>(ws);
+  p.gnp = nullptr; p.gn_G = 0; p.gn_zt = 1;
+  if (q.ksplit == 1 && gnp != nullptr && gnG > 0 && D % gnG == 0 && (D / gnG) % 4 == 0 && getenv("BTS_IGEMM_NOGNFUSE") == nullptr) {
+    p.gnp = gnp; p.gn_G = gnG; p.gn_zt = (D / gnG) / 4;
+  }
+  const double flops = 2.0 * 27 * Cin * Cout * (double)N * D * H * W;
+  const int r = (q.xw == 32) ? wino_launch_cfg<32>(p, q, flops, stream) : wino_launch_cfg<16>(p, q, flops, stream);
+  if (r != BTS_OK) return r;
+  if (q.ksplit > 1) {
+    const int rr = bts_igemm_reduce_(p.part, bias, y, (long)N * D * H * W, Cout, p.Npad, ldy, q.ksplit, bias != nullptr, accum, stream);
+    if (rr != BTS_OK) return rr;
+  }
+  if (gn_B && p.gnp != nullptr) *gn_B = (long)p.gn_zt * q.nty * q.ntx * q.nb;
   return BTS_OK;
 }

@@ -68,6 +68,8 @@ CASES = [
     # N, (D,H,W), Cin, Cout  -- aligned, ragged in every axis (D=6, H=10, W=40), several cout blocks, cout < 32, deep cin
     (1, (8, 8, 32), 16, 32), (2, (6, 10, 40), 8, 48), (1, (16, 16, 64), 64, 64), (1, (4, 4, 32), 24, 16),
     (1, (5, 7, 33), 32, 20), (1, (8, 4, 96), 128, 32),
+    # 16-wide tiles (two y patches per wave), ragged; long contractions on small grids (split along the input channels)
+    (1, (8, 8, 16), 32, 32), (1, (5, 9, 13), 64, 32), (1, (16, 16, 16), 256, 64), (1, (8, 16, 48), 128, 48),
 ]
 
 
@@ -114,7 +116,7 @@ def test_wino_fwd_and_data_gradient(n, dims, cin, cout):
 def test_wino_declines_what_it_cannot_do(monkeypatch):
     """narrow grids, odd channel counts and the sigmoid epilogue stay on the implicit GEMM; BTS_WINO=0 turns the form off"""
     from bts_amd import ops
-    for (dims, cin, cout, sig, env) in [((8, 8, 16), 16, 32, False, None), ((8, 8, 32), 12, 32, False, None),
+    for (dims, cin, cout, sig, env) in [((8, 8, 8), 16, 32, False, None), ((8, 8, 32), 12, 32, False, None),
                                         ((8, 8, 32), 16, 32, True, None), ((8, 8, 32), 16, 32, False, '0')]:
         if env is not None:
             monkeypatch.setenv('BTS_WINO', env)
@@ -134,7 +136,8 @@ def test_wino_declines_what_it_cannot_do(monkeypatch):
         check_close(y, ref, 'declined case', rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize('n,dims,cin,cout,g', [(1, (16, 16, 32), 32, 32, 4), (2, (32, 8, 64), 16, 64, 8), (1, (6, 10, 40), 8, 16, 2)])
+@pytest.mark.parametrize('n,dims,cin,cout,g', [(1, (16, 16, 32), 32, 32, 4), (2, (32, 8, 64), 16, 64, 8), (1, (6, 10, 40), 8, 16, 2),
+                                               (1, (16, 16, 16), 32, 32, 4), (1, (16, 16, 16), 128, 32, 2)])
 def test_wino_fused_groupnorm_statistics(n, dims, cin, cout, g):
     """conv + slab-mode GroupNorm statistics from the Winograd epilogue (groups of whole 4-plane tiles) or, for the ragged
     case, from the library's own statistics pass over the Winograd output"""
