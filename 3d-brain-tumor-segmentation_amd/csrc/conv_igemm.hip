@@ -537,6 +537,7 @@ struct PackParams {
   int shift, dup_start;
   long wino_off;    // K3S1 images: element index where the Winograd part starts; otherwise beyond the image
   long total;       // floats of the whole image
+  long items;       // work items (pack_item): implicit-GEMM floats + Winograd positions (16 floats each)
 };
 
 // source value of packed position (tap t, contraction index k, column n), with the tap flip of the data-gradient role and
@@ -559,36 +560,42 @@ __device__ __forceinline__ float pack_src(const PackParams& q, int t, int k, int
   return v;
 }
 
-__device__ __forceinline__ float pack_elem(const PackParams& q, long i) {
+// One work item of an image: index i < wino_off writes one float of the implicit-GEMM part; an index above it writes the
+// 16 transform points of one (cout block, k-group, x tap, half, cout, cin) position of the Winograd part (conv_wino.hip):
+// U = G g G^T over the (z, y) taps, layout [cout block of 32][k-group][x tap][xi_z*4 + xi_y][half][32][4]; the 9 source
+// taps are read once.  rows of G: (1 0 0) (.5 .5 .5) (.5 -.5 .5) (0 0 1)
+__device__ __forceinline__ void pack_item(const PackParams& q, long i) {
   if (i >= q.wino_off) {
-    // Winograd part of a K3S1 image (conv_wino.hip): U = G g G^T over the (z, y) taps, per x tap;
-    // layout [cout block of 32][k-group][x tap][xi_z*4 + xi_y][half][32][4]
     long r = i - q.wino_off;
     const int j = (int)(r & 3);
     const int n32 = (int)((r >> 2) & 31);
     const int hh = (int)((r >> 7) & 1);
-    const int xi = (int)((r >> 8) & 15);
-    r >>= 12;
+    r >>= 8;
     const int dx = (int)(r % 3); r /= 3;
     const int kg = (int)(r % q.KG);
     const int cb = (int)(r / q.KG);
     const int k = kg * 8 + hh * 4 + j, n = cb * 32 + n32;
-    const int xz = xi >> 2, xy = xi & 3;
-    // rows of G: (1 0 0) (.5 .5 .5) (.5 -.5 .5) (0 0 1)
-    float u = 0.f;
+    float g[3][3], t[4][3];
 #pragma unroll
-    for (int kz = 0; kz < 3; ++kz) {
-      const float gz = (xz == 0) ? (kz == 0 ? 1.f : 0.f) : (xz == 3) ? (kz == 2 ? 1.f : 0.f) : ((xz == 2 && kz == 1) ? -0.5f : 0.5f);
-      if (gz == 0.f) continue;
-      float s = 0.f;
+    for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const float gy = (xy == 0) ? (ky == 0 ? 1.f : 0.f) : (xy == 3) ? (ky == 2 ? 1.f : 0.f) : ((xy == 2 && ky == 1) ? -0.5f : 0.5f);
-        if (gy != 0.f) s = fmaf(gy, pack_src(q, (kz * 3 + ky) * 3 + dx, k, n), s);
-      }
-      u = fmaf(gz, s, u);
+      for (int ky = 0; ky < 3; ++ky) g[kz][ky] = pack_src(q, (kz * 3 + ky) * 3 + dx, k, n);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {  // G along z
+      t[0][ky] = g[0][ky];
+      t[1][ky] = fmaf(0.5f, g[2][ky], fmaf(0.5f, g[1][ky], 0.5f * g[0][ky]));
+      t[2][ky] = fmaf(0.5f, g[2][ky], fmaf(-0.5f, g[1][ky], 0.5f * g[0][ky]));
+      t[3][ky] = g[2][ky];
     }
-    return u;
+    float* o = q.wp + q.wino_off + ((((long)cb * q.KG + kg) * 3 + dx) * 16) * 256 + hh * 128 + n32 * 4 + j;
+#pragma unroll
+    for (int xz = 0; xz < 4; ++xz) {  // G along y
+      o[(xz * 4 + 0) * 256] = t[xz][0];
+      o[(xz * 4 + 1) * 256] = fmaf(0.5f, t[xz][2], fmaf(0.5f, t[xz][1], 0.5f * t[xz][0]));
+      o[(xz * 4 + 2) * 256] = fmaf(0.5f, t[xz][2], fmaf(-0.5f, t[xz][1], 0.5f * t[xz][0]));
+      o[(xz * 4 + 3) * 256] = t[xz][2];
+    }
+    return;
   }
   const int j = (int)(i & 3);
   long r = i >> 2;
@@ -596,13 +603,13 @@ __device__ __forceinline__ float pack_elem(const PackParams& q, long i) {
   const int hh = (int)(r & 1); r >>= 1;
   const int kg = (int)(r % q.KG);
   const int t = (int)(r / q.KG);
-  return pack_src(q, t, kg * 8 + hh * 4 + j, n);
+  q.wp[i] = pack_src(q, t, kg * 8 + hh * 4 + j, n);
 }
 
 __global__ void pack_kernel(const PackParams q) {
-  const long total = q.total;
+  const long total = q.items;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
-    q.wp[i] = pack_elem(q, i);
+    pack_item(q, i);
 }
 
 // All layers' weight images in one launch (the optimiser step invalidates every image at once; 120 separate 5 us
@@ -624,7 +631,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restr
 #pragma unroll
   for (int u = 0; u < PACK_BLOCK_ELEMS / 256; ++u) {
     const long i = i0 + threadIdx.x + u * 256;
-    if (i < d.total) d.q.wp[i] = pack_elem(d.q, i);
+    if (i < d.total) pack_item(d.q, i);
   }
 }
 
@@ -663,6 +670,7 @@ static int pack_params(PackParams& q, int kind, int role, const float* w, float*
   const long ig = (long)q.ntaps * q.KG * 2 * q.Npad * 4;
   q.wino_off = (kind == BTS_CONV_K3S1) ? ig : (1L << 62);
   q.total = ig + ((kind == BTS_CONV_K3S1) ? 48L * q.KG * 2 * q.Npad * 4 : 0L);
+  q.items = ig + ((kind == BTS_CONV_K3S1) ? 3L * q.KG * 2 * q.Npad * 4 : 0L);
   return BTS_OK;
 }
 
@@ -671,7 +679,7 @@ extern "C" int bts_conv_pack(int kind, int role, const float* w, float* wp, int 
   PackParams q;
   const int r = pack_params(q, kind, role, w, wp, Cin_ref, Cout, Cin_slab, dup_start, dup_shift);
   if (r != BTS_OK) return r;
-  const long total = q.total;
+  const long total = q.items;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   (void)hipGetLastError(); hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, stream, q);
@@ -688,7 +696,7 @@ extern "C" long bts_conv_pack_desc(void* host_table, int index, long first_block
   PackDesc d;
   const int r = pack_params(d.q, kind, role, w, wp, Cin_ref, Cout, Cin_slab, dup_start, dup_shift);
   if (r != BTS_OK) return r;
-  d.total = d.q.total;
+  d.total = d.q.items;
   d.first_block = first_block;
   reinterpret_cast<PackDesc*>(host_table)[index] = d;
   return (d.total + PACK_BLOCK_ELEMS - 1) / PACK_BLOCK_ELEMS;
