@@ -41,7 +41,8 @@ typedef struct ihipStream_t* bts_stream_t; /* == hipStream_t */
 /* ---- declarations are appended below, grouped by reference call site ---- */
 
 /* ===== convolutions (layers/resnet.py:30-37,80-87,96-103; downsample.py:28-35; upsample.py:28-33; decoder.py:55-63; vae.py:92-99) ===== */
-/* number of floats of the packed weight image for (kind, role); Cin is the slab (folded) input-channel count */
+/* number of floats of the packed weight image for (kind, role); Cin is the slab (folded) input-channel count.
+   K3S1 images hold two parts: the implicit-GEMM layout (27 taps) and the Winograd-domain layout (3 x taps x 16 points) */
 long bts_conv_packed_floats(int kind, int role, int Cin, int Cout);
 /* w: reference Keras layout ((kd,kh,kw,Cin_ref,Cout) or, for K3S2T, (kd,kh,kw,Cout,Cin_ref)); wp: packed image.
  * Cin_slab + dup_shift == Cin_ref. dup_shift>0 folds the encoder's duplicated dense-connection slice
