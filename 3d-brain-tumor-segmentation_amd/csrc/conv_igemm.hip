@@ -1668,8 +1668,9 @@ static int conv_fwd_gn_impl(int kind, const float* x, const float* wp, const flo
   long gnB = 0;
   int r;
   if (wp2 != nullptr) {
+    // the workspace serves the Winograd form's split-K on small grids (the fused implicit-GEMM pair never splits)
     r = launch_igemm(GEO_S1, x, wp, bias, y, N, D, H, W, Cin, ldx, D, H, W, Cout, Cout, D, H, W, 0, 0, 0, bias ? IG_FLAG_BIAS : 0,
-                     stream, nullptr, 0, nullptr, wp2, bias2, y2, ldy2, gnp, G, &gnB);
+                     stream, ws, cw, nullptr, wp2, bias2, y2, ldy2, gnp, G, &gnB);
   } else {
     const int geo = geo_of_kind_fwd(kind);
     const int f = bias ? IG_FLAG_BIAS : 0;
