@@ -441,7 +441,6 @@ static int wino_launch_cfg(const WinoParams& p, const WinoPlan& q, double flops,
 int bts_wino_launch_(const float* x, const float* up, const float* bias, float* y, int N, int D, int H, int W, int Cin, int ldx,
                      int Cout, int ldy, int accum, double* gnp, int gnG, long* gn_B, void* ws, long ws_bytes, hipStream_t stream) {
   if (!wino_enabled()) return 1;
-  if (getenv("BTS_WINO_LOG")) fprintf(stderr, "wino? N=%d D=%d H=%d W=%d Cin=%d Cout=%d ldx=%d ldy=%d accum=%d gn=%d\n", N, D, H, W, Cin, Cout, ldx, ldy, accum, gnp != nullptr);
   if (ldx % 4 != 0 || ldy % 4 != 0) return 1;
   if ((((uintptr_t)x) & 15) || (((uintptr_t)y) & 15)) return 1;
   if (((long)(D + 2) * H * W + 64) * (long)ldx * 4 >= 0x7fffffffL) return 1;  // 31-bit byte offsets inside one volume
@@ -450,6 +449,10 @@ int bts_wino_launch_(const float* x, const float* up, const float* bias, float* 
   if (q.ksplit > 1 && (ws == nullptr || ws_bytes < q.need || (((uintptr_t)ws) & 15))) { q.ksplit = 1; q.kg_per = Cin / 8; }
   int min_wgs = 192;
   { const char* e = getenv("BTS_WINO_MIN_WGS"); if (e) min_wgs = atoi(e); }
+  if (getenv("BTS_WINO_LOG"))
+    fprintf(stderr, "wino %s N=%d D=%d H=%d W=%d Cin=%d Cout=%d ldx=%d ldy=%d accum=%d gn=%d xw=%d wgs=%ld ksplit=%d ws=%ld\n",
+            q.wgs * q.ksplit < min_wgs ? "declined" : "taken", N, D, H, W, Cin, Cout, ldx, ldy, accum, gnp != nullptr, q.xw, q.wgs,
+            q.ksplit, ws_bytes);
   if (q.wgs * q.ksplit < min_wgs) return 1;
   WinoParams p;
   p.x = x; p.up = up; p.bias = bias; p.y = y;

@@ -69,7 +69,7 @@ CASES = [
     (1, (8, 8, 32), 16, 32), (2, (6, 10, 40), 8, 48), (1, (16, 16, 64), 64, 64), (1, (4, 4, 32), 24, 16),
     (1, (5, 7, 33), 32, 20), (1, (8, 4, 96), 128, 32),
     # 16-wide tiles (two y patches per wave), ragged; long contractions on small grids (split along the input channels)
-    (1, (8, 8, 16), 32, 32), (1, (5, 9, 13), 64, 32), (1, (16, 16, 16), 256, 64), (1, (8, 16, 48), 128, 48),
+    (1, (8, 8, 16), 32, 32), (1, (5, 9, 13), 64, 32), (1, (16, 16, 16), 256, 64), (1, (8, 16, 48), 128, 48), (2, (8, 8, 16), 128, 32),
 ]
 
 
