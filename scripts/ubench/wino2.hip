@@ -34,7 +34,6 @@ struct WinoParams {
 
 #define LDSOFF(i, j, dx) ((((i) * WIY + (j)) * WIX + (dx)) * WS)
 
-// y transform of one z-combined row set: B^T rows (1,0,-1,0) (0,1,1,0) (0,-1,1,0) (0,1,0,-1)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
   f32x2 d;
@@ -46,6 +45,11 @@ __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
   asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 __device__ __forceinline__ f32x4 add4(f32x4 a, f32x4 b) {
   const f32x2 lo = pk_add(a.xy, b.xy), hi = pk_add(a.zw, b.zw);
   return f32x4{lo.x, lo.y, hi.x, hi.y};
@@ -54,59 +58,68 @@ __device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {
   const f32x2 lo = pk_sub(a.xy, b.xy), hi = pk_sub(a.zw, b.zw);
   return f32x4{lo.x, lo.y, hi.x, hi.y};
 }
+__device__ __forceinline__ f32x4 fma4(f32x4 a, f32x2 s, f32x4 c) {  // a*s + c
+  const f32x2 lo = pk_fma(a.xy, s, c.xy), hi = pk_fma(a.zw, s, c.zw);
+  return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
 __device__ __forceinline__ void wino_yt(const f32x4 (&c)[4], f32x4 (&v)[4]) {
   v[0] = sub4(c[0], c[2]);
   v[1] = add4(c[1], c[2]);
   v[2] = sub4(c[2], c[1]);
   v[3] = sub4(c[1], c[3]);
 }
-// one group: xi_z fixed, 4 xi_y values, 4 channel pairs -> 16 MFMAs
 __device__ __forceinline__ void wino_mfma16(const f32x4 (&v)[4], const f32x4 (&a)[4], f32x16 (&acc)[4]) {
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e][j], v[e][j], acc[e], 0, 0, 0);
 }
-// interleave: after every MFMA two vector-ALU operations (the NEXT group's transform) and the group's memory requests
-#define WINO_SCHED_GROUP()                                 \
-  _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {      \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     \
-    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);     \
-    __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);     \
-  }
+__device__ __forceinline__ float acc_rd(float a) {
+  float v;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+  return v;
+}
 
-// DBG: 0 normal, 1 no sweep, 2 no re-staging; clock64 stamps (start / first barrier / loop end / exit) always written
+// Two waves per SIMD: 512 threads, the 16 transform points of a 2x2 patch split over a wave PAIR:
+//   wave A (even): xi_z = 0 (d0 - d2), 1 (d1 + d2)      wave B (odd): xi_z = 3 (d1 - d3), 2 (d2 - d1)
+// 8 accumulators = 128 registers per wave.  Both waves run the same code on rows (X, Y, Z) = (0, 2, 1) / (3, 1, 2):
+//   group 0: c = X - Y   (B: the negative of xi_z = 3, undone in the output transform)     group 1: c = Z + s*Y, s = +1 / -1
+// LDS tile as two channel-quad planes [h][voxel][4] filled by global->LDS DMA (no staging registers, no padding).
+#define W2IZ 4
+#define W2VOX (WIX * WIY * W2IZ)   /* 816 */
+#define W2PLANE (W2VOX * 4)
+#define W2BUF (28 * 256)   /* dwords: 2 planes (6528) rounded up to the 7 x 4 DMA chunks of 1 KB */
+#define W2SLOT 7
+#define CELL(j, dx) (((j) * WIX + (dx)) * 4)
+
 template <int DBG>
-__global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
+__global__ __launch_bounds__(256, 2) void wino2_kernel(const WinoParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l32 = lane & 31;
-  long long ts0 = 0, ts1 = 0, ts2 = 0;
-  ts0 = clock64();
+  long long ts0 = clock64(), ts1 = 0, ts2 = 0;
   const long long wc0 = wall_clock64();
   int b = blockIdx.x;
   const int tx = b % p.ntx; b /= p.ntx;
   const int ty = b % p.nty; b /= p.nty;
   const int tz = b % p.ntz;
   const int n = b / p.ntz;
-  const int oz0 = tz * 4, oy0 = ty * 4, ox0 = tx * 32;
+  const int oz0 = tz * 2, oy0 = ty * 4, ox0 = tx * 32;
   const int iz0 = oz0 - 1, iy0 = oy0 - 1, ix0 = ox0 - 1;
-
-  // halo origin of this tile; slots outside the image get a 2 GB offset = outside the descriptor -> the load returns zeros
   const float* xorg = p.x + ((((long)n * p.D + iz0) * p.H + iy0) * p.W + ix0) * (long)p.ldx;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xorg, 0, 0x7fffffff, 0x00020000);
-  // weights of this cout block: [k-group][dx][xi][h][32][4] = 1 KB per (dx, xi) image
   const __amdgpu_buffer_rsrc_t wr =
       __builtin_amdgcn_make_buffer_rsrc((void*)(p.up + (long)blockIdx.y * p.KG * (3 * 16 * 256)), 0, 0x7fffffff, 0x00020000);
-  unsigned goff[WNSLOT];
+  unsigned goff[W2SLOT];
 #pragma unroll
-  for (int i = 0; i < WNSLOT; ++i) {
-    const int e = tid + i * 256;
+  for (int i = 0; i < W2SLOT; ++i) {
+    const int e = (i * 4 + wave) * 64 + lane;
     goff[i] = 0x80000000u;
-    if (e < WVOX * 2) {
-      const int vox = e >> 1, q = e & 1;
+    if (e < W2VOX * 2) {
+      const int q = e >= W2VOX ? 1 : 0;
+      const int vox = e - q * W2VOX;
       const int vz = vox / (WIY * WIX);
       const int r = vox - vz * (WIY * WIX);
       const int vy = r / WIX;
@@ -115,166 +128,139 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
         goff[i] = (unsigned)(((vz * p.H + vy) * p.W + vx) * p.ldx + q * 4) * 4u;
     }
   }
-  const int tz2 = wave >> 1, ty2 = wave & 1;
-  const int bbase = ((2 * tz2 * WIY + 2 * ty2) * WIX + l32) * WS + h * 4;
+  auto fetch = [&](int st, float* buf) {
+#pragma unroll
+    for (int i = 0; i < W2SLOT; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(buf + (i * 4 + wave) * 256), 16, goff[i],
+                                               (unsigned)st * 32u, 0, 0);
+  };
+  const int pair = wave >> 1, wb = wave & 1;
+  const int tz2 = 0, ty2 = pair;
+  const int pb = h * W2PLANE + (((2 * tz2) * WIY + 2 * ty2) * WIX + l32) * 4;
+  const int offX = pb + (wb ? 3 : 0) * (WIY * WIX * 4), offY = pb + (wb ? 1 : 2) * (WIY * WIX * 4), offZ = pb + (wb ? 2 : 1) * (WIY * WIX * 4);
+  const int xz0 = wb ? 3 : 0, xz1 = wb ? 2 : 1;
+  const float sgn = wb ? -1.f : 1.f;
+  const f32x2 s2 = {sgn, sgn};
   const unsigned wlane = (unsigned)((h * 32 + l32) * 16);
 
-  f32x16 acc[4][4];
+  f32x16 acc[2][4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
-  f32x4 pre[WNSLOT];
-  auto fetch = [&](int st) {
-#pragma unroll
-    for (int i = 0; i < WNSLOT; ++i) pre[i] = bufload(xr, goff[i], (unsigned)st * 32u);
-  };
-  auto commit = [&](float* buf) {
-#pragma unroll
-    for (int i = 0; i < WNSLOT; ++i) {
-      const int e = tid + i * 256;
-      if (e < WVOX * 2) *reinterpret_cast<f32x4*>(buf + (e >> 1) * WS + (e & 1) * 4) = pre[i];
-    }
-  };
-
-  fetch(0);
-  // weight fragments of group G = st*12 + g live in aw[G % 3]; two groups are always in flight
-  f32x4 aw[3][4];
-  constexpr int zorder[4] = {1, 2, 0, 3};
-  auto wload = [&](f32x4 (&dst)[4], int st, int g) {
-    const int dx = g >> 2, xz = zorder[g & 3];
+  fetch(0, lds);
+  f32x4 aw[2][4];
+  auto wload = [&](f32x4 (&dst)[4], int st, int dx, int xz) {
     const unsigned so = (unsigned)(((st * 3 + dx) * 16 + xz * 4) * 1024);
 #pragma unroll
     for (int e = 0; e < 4; ++e) dst[e] = bufload(wr, wlane + e * 1024, so);
   };
-  wload(aw[0], 0, 0);
-  wload(aw[1], 0, 1);
-  commit(lds);
-  __syncthreads();
+  wload(aw[0], 0, 0, xz0);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the tile's DMA was issued before the 4 weight loads
+  __builtin_amdgcn_s_barrier();
   ts1 = clock64();
 
   const int nst = p.KG;
   for (int st = 0; st < nst; ++st) {
-    const float* cur = lds + (DBG == 2 ? 0 : (st & 1) * WBUF);
-    float* nxt = lds + ((st + 1) & 1) * WBUF;
+    const float* cur = lds + (st & 1) * W2BUF;
+    float* nxt = lds + ((st + 1) & 1) * W2BUF;
     const bool more = (st + 1) < nst;
-    if (more && DBG != 2) fetch(st + 1);
-    const float* lb = cur + bbase;
-    const int stn = more ? st + 1 : st;  // the last stage re-requests its own first groups instead of running past the image
+    if (more && DBG != 2) fetch(st + 1, nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    const int stn = more ? st + 1 : st;
+    const float* lX = cur + offX;
+    const float* lY = cur + offY;
+    const float* lZ = cur + offZ;
     if (DBG != 1) {
-      // Software pipeline: while the 16 MFMAs of group G run on v[G&1], the vector ALU forms v[(G+1)&1] -- a matrix
-      // instruction never waits for an operand written just before it.
-      f32x4 r1[4], r2[4], rt[4], c[4], v[2][4];
+      f32x4 rx[4], ry[4], v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        r1[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(1, j, 0));
-        r2[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(2, j, 0));
+        ry[j] = *reinterpret_cast<const f32x4*>(lY + CELL(j, 0));
+        rx[j] = *reinterpret_cast<const f32x4*>(lX + CELL(j, 0));
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) c[j] = add4(r1[j], r2[j]);
-      wino_yt(c, v[0]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
-        {  // MFMA xi_z = 1 ; form xi_z = 2 : d2 - d1 ; request row 0
-          const int G = dx * 4 + 0;
-          wload(aw[(G + 2) % 3], (G + 2 < 12) ? st : stn, (G + 2) % 12);
+        {  // group 0: c = X - Y (in place), then Z requested into X's registers
+          wload(aw[1], st, dx, xz1);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) rt[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(0, j, dx));
+          for (int j = 0; j < 4; ++j) rx[j] = sub4(rx[j], ry[j]);
+          wino_yt(rx, v);
+          asm volatile("s_nop 3" ::: "memory");  // hand-written VALU -> MFMA operand: the compiler's hazard tracking does not see it
 #pragma unroll
-          for (int j = 0; j < 4; ++j) c[j] = sub4(r2[j], r1[j]);
-          wino_yt(c, v[1]);
-          wino_mfma16(v[0], aw[G % 3], acc[1]);
-          WINO_SCHED_GROUP();
+          for (int j = 0; j < 4; ++j) rx[j] = *reinterpret_cast<const f32x4*>(lZ + CELL(j, dx));
+          wino_mfma16(v, aw[0], acc[0]);
           __builtin_amdgcn_sched_barrier(0);
         }
-        {  // MFMA xi_z = 2 ; form xi_z = 0 : d0 - d2 ; then request row 3
-          const int G = dx * 4 + 1;
-          wload(aw[(G + 2) % 3], (G + 2 < 12) ? st : stn, (G + 2) % 12);
+        {  // group 1: c = Z + s*Y (in place), then the next x tap's Y, X requested
+          if (dx < 2) wload(aw[0], st, dx + 1, xz0); else wload(aw[0], stn, 0, xz0);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) c[j] = sub4(rt[j], r2[j]);
-          wino_yt(c, v[0]);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) rt[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(3, j, dx));
-          wino_mfma16(v[1], aw[G % 3], acc[2]);
-          WINO_SCHED_GROUP();
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        {  // MFMA xi_z = 0 ; form xi_z = 3 : d1 - d3 ; then request rows 1, 2 of the next x tap
-          const int G = dx * 4 + 2;
-          wload(aw[(G + 2) % 3], (G + 2 < 12) ? st : stn, (G + 2) % 12);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) c[j] = sub4(r1[j], rt[j]);
-          wino_yt(c, v[1]);
+          for (int j = 0; j < 4; ++j) rx[j] = fma4(ry[j], s2, rx[j]);
+          wino_yt(rx, v);
+          asm volatile("s_nop 3" ::: "memory");  // hand-written VALU -> MFMA operand: the compiler's hazard tracking does not see it
           if (dx < 2) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              r1[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(1, j, dx + 1));
-              r2[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(2, j, dx + 1));
+              ry[j] = *reinterpret_cast<const f32x4*>(lY + CELL(j, dx + 1));
+              rx[j] = *reinterpret_cast<const f32x4*>(lX + CELL(j, dx + 1));
             }
           }
-          wino_mfma16(v[0], aw[G % 3], acc[0]);
-          WINO_SCHED_GROUP();
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        {  // MFMA xi_z = 3 ; form xi_z = 1 of the next x tap : d1 + d2
-          const int G = dx * 4 + 3;
-          wload(aw[(G + 2) % 3], (G + 2 < 12) ? st : stn, (G + 2) % 12);
-          if (dx < 2) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) c[j] = add4(r1[j], r2[j]);
-            wino_yt(c, v[0]);
-          }
-          wino_mfma16(v[1], aw[G % 3], acc[3]);
-          WINO_SCHED_GROUP();
+          wino_mfma16(v, aw[1], acc[1]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
-    if (more && DBG != 2) commit(nxt);
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile landed (and the one prefetched weight group)
+    __builtin_amdgcn_s_barrier();
   }
   ts2 = clock64();
 
-  // ---- output transform (A^T . A over (z,y)) and store; the bias quads are requested first and arrive under the adds ----
-  // bias of this lane's 16 couts (4 quads), 4 quads
-  f32x4 bq[4];
+  // ---- output transform; the pair exchanges one partial through LDS: A finishes plane oz = 0, B plane oz = 1 ----
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  float* xbuf = lds;  // staging buffers are idle
+  f32x4 keep[4][2];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    bq[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bq[g] = *reinterpret_cast<const f32x4*>(p.bias + blockIdx.y * 32 + 8 * g + 4 * h);
-  }
-  const int oxx = ox0 + l32;
-  const int zb = oz0 + 2 * tz2, yb = oy0 + 2 * ty2;
-  float* ybase = p.y + ((((long)n * p.D + zb) * p.H + yb) * p.W + oxx) * (long)p.ldy + blockIdx.y * 32 + 4 * h;
-  const long ysY = (long)p.W * p.ldy, ysZ = (long)p.H * p.W * p.ldy;
-  const bool inx = oxx < p.W;
-  // one register quad (4 couts) of all 16 accumulators at a time: 64 + 32 live values
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    f32x4 tq[4][2];
-#pragma unroll
-    for (int xz = 0; xz < 4; ++xz) {
+    f32x4 t0[2], t1[2];
+    {
       f32x4 q[4];
 #pragma unroll
-      for (int xy = 0; xy < 4; ++xy) q[xy] = f32x4{acc[xz][xy][4 * g], acc[xz][xy][4 * g + 1], acc[xz][xy][4 * g + 2], acc[xz][xy][4 * g + 3]};
-      tq[xz][0] = q[0] + q[1] + q[2];
-      tq[xz][1] = q[1] - q[2] - q[3];
+      for (int xy = 0; xy < 4; ++xy)
+        q[xy] = f32x4{acc_rd(acc[0][xy][4 * g]), acc_rd(acc[0][xy][4 * g + 1]), acc_rd(acc[0][xy][4 * g + 2]), acc_rd(acc[0][xy][4 * g + 3])};
+      t0[0] = q[0] + q[1] + q[2];
+      t0[1] = q[1] - q[2] - q[3];
+#pragma unroll
+      for (int xy = 0; xy < 4; ++xy)
+        q[xy] = f32x4{acc_rd(acc[1][xy][4 * g]), acc_rd(acc[1][xy][4 * g + 1]), acc_rd(acc[1][xy][4 * g + 2]), acc_rd(acc[1][xy][4 * g + 3])};
+      t1[0] = q[0] + q[1] + q[2];
+      t1[1] = q[1] - q[2] - q[3];
     }
-    const bool cok = inx && (blockIdx.y * 32 + 8 * g + 4 * h < p.Cout);
+    // A: t0 = T0, t1 = T1 -> keep T0 + T1 (plane 0), send T1.   B: t0 = -T3, t1 = T2 -> keep -T3 - T2 (plane 1), send T2
 #pragma unroll
     for (int oy = 0; oy < 2; ++oy) {
-      const f32x4 o0 = tq[0][oy] + tq[1][oy] + tq[2][oy] + bq[g];
-      const f32x4 o1 = tq[1][oy] - tq[2][oy] - tq[3][oy] + bq[g];
-      if (cok && yb + oy < p.H) {
-        if (zb < p.D) *reinterpret_cast<f32x4*>(ybase + oy * ysY + 8 * g) = o0;
-        if (zb + 1 < p.D) *reinterpret_cast<f32x4*>(ybase + ysZ + oy * ysY + 8 * g) = o1;
-      }
+      keep[g][oy] = wb ? (t0[oy] - t1[oy]) : (t0[oy] + t1[oy]);
+      *reinterpret_cast<f32x4*>(xbuf + ((wave * 8 + g * 2 + oy) * 64 + lane) * 4) = t1[oy];
     }
-    __builtin_amdgcn_sched_barrier(0);
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+  __builtin_amdgcn_s_barrier();
+  const int oxx = ox0 + l32;
+  const int zb = oz0 + 2 * tz2 + wb, yb = oy0 + 2 * ty2;
+  float* ybase = p.y + ((((long)n * p.D + zb) * p.H + yb) * p.W + oxx) * (long)p.ldy + blockIdx.y * 32 + 4 * h;
+  const long ysY = (long)p.W * p.ldy;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int co = blockIdx.y * 32 + 8 * g + 4 * h;
+    f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && co < p.Cout) bq = f32x4{p.bias[co], p.bias[co + 1], p.bias[co + 2], p.bias[co + 3]};
+#pragma unroll
+    for (int oy = 0; oy < 2; ++oy) {
+      const f32x4 other = *reinterpret_cast<const f32x4*>(xbuf + (((wave ^ 1) * 8 + g * 2 + oy) * 64 + lane) * 4);
+      const f32x4 o = keep[g][oy] + other + bq;   // A: T0+T1+T2   B: -T3-T2+T1
+      if (oxx < p.W && yb + oy < p.H && zb < p.D && co < p.Cout) *reinterpret_cast<f32x4*>(ybase + oy * ysY + 8 * g) = o;
+    }
   }
   if (tid == 0) {
     const long long ts3 = clock64();
@@ -345,10 +331,10 @@ int main(int argc, char** argv) {
   hipMemset(dy, 0, nvox * K * 4);
   WinoParams p{};
   p.x = dx_; p.up = dup; p.bias = getenv("NOBIAS") ? nullptr : db; p.y = dy; p.N = 1; p.D = D; p.H = H; p.W = W; p.Cin = C; p.ldx = C; p.Cout = K; p.ldy = K;
-  p.Npad = Npad; p.KG = KG; p.ntz = (D + 3) / 4; p.nty = (H + 3) / 4; p.ntx = (W + 31) / 32; p.dbg = dbg;
+  p.Npad = Npad; p.KG = KG; p.ntz = (D + 1) / 2; p.nty = (H + 3) / 4; p.ntx = (W + 31) / 32; p.dbg = dbg;
   p.tpw = argc > 5 ? atoi(argv[5]) : 8; p.nzc = (p.ntz + p.tpw - 1) / p.tpw;
-  const int ldsb = 2 * WBUF * 4;
-  void (*kern)(const WinoParams) = dbg == 1 ? wino_kernel<1> : dbg == 2 ? wino_kernel<2> : wino_kernel<0>;
+  const int ldsb = 2 * W2BUF * 4;
+  void (*kern)(const WinoParams) = dbg == 1 ? wino2_kernel<1> : dbg == 2 ? wino2_kernel<2> : wino2_kernel<0>;
   hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
   dim3 grid(p.ntz * p.nty * p.ntx, Npad / 32);
   hipMalloc(&p.stamps, ((long)grid.x * 4 + 2) * 8);
