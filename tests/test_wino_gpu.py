@@ -237,3 +237,34 @@ def test_wino_is_deterministic():
         a = ops.conv_fwd(ops.K3S1, x, wp, None, 32).clone()
         b = ops.conv_fwd(ops.K3S1, x, wp, None, 32)
     assert torch.equal(a, b)
+
+
+def test_wino_full_size_agrees_with_direct_form():
+    """BASELINE size (32 -> 32 channels on 128^3, the layer the metric is dominated by): too big for the fp64 oracle, so the
+    Winograd form is held against the engine's own direct-form kernel (itself oracle-checked at small sizes) with the sum of
+    both bounds, the bound sum|a_i b_i| being evaluated by the direct kernel on |x|, |w|; plus linearity in x."""
+    import os
+    from bts_amd import ops
+    x = rnd((1, 128, 128, 128, 32), 21).to(dev())
+    x2 = rnd((1, 128, 128, 128, 32), 22).to(dev())
+    wt = rnd((3, 3, 3, 32, 32), 23, 0.1).to(dev())
+    b = rnd((32,), 24).to(dev())
+    wp = ops.conv_pack(ops.K3S1, ops.ROLE_FWD, wt, 32, 32)
+    wpa = ops.conv_pack(ops.K3S1, ops.ROLE_FWD, wt.abs(), 32, 32)
+    with ran_wino(3):
+        y = ops.conv_fwd(ops.K3S1, x, wp, b, 32)
+        ya = ops.conv_fwd(ops.K3S1, x2, wp, None, 32)
+        ys = ops.conv_fwd(ops.K3S1, x + x2, wp, b, 32)
+    os.environ['BTS_WINO'] = '0'
+    try:
+        y0 = ops.conv_fwd(ops.K3S1, x, wp, b, 32)
+        bound = ops.conv_fwd(ops.K3S1, x.abs(), wpa, b.abs(), 32)
+        bound2 = ops.conv_fwd(ops.K3S1, x2.abs(), wpa, None, 32)
+    finally:
+        del os.environ['BTS_WINO']
+    tol = 40 * EPS32 * bound + 1e-7
+    err = (y - y0).abs()
+    assert not bool((err > tol).any()), 'max err %.3e' % float(err.max())
+    lin = (ys - (y + ya)).abs()
+    tol2 = 3 * 32 * EPS32 * (bound + bound2) + 1e-6      # three Winograd evaluations + the fp32 sums x + x2, y + ya
+    assert not bool((lin > tol2).any()), 'linearity: max err %.3e' % float(lin.max())
