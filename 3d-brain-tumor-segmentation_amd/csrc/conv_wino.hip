@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
       for (int j = 0; j < 4; ++j) c[j] = add4(r1[j], r2[j]);
       wino_yt(c, v[0]);
       __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 3" ::: "memory");
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         {  // MFMA xi_z = 1 ; form xi_z = 2 : d2 - d1 ; request row 0
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
           wino_mfma16(v[0], aw[G % 3], acc[1]);
           WINO_SCHED_GROUP();
           __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_nop 1" ::: "memory");  // hand-written transform VALU -> next group's MFMA operand: hazard not tracked by the compiler
         }
         {  // MFMA xi_z = 2 ; form xi_z = 0 : d0 - d2 ; then request row 3
           const int G = dx * 4 + 1;
@@ -253,6 +255,7 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
           wino_mfma16(v[1], aw[G % 3], acc[2]);
           WINO_SCHED_GROUP();
           __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_nop 1" ::: "memory");  // hand-written transform VALU -> next group's MFMA operand: hazard not tracked by the compiler
         }
         {  // MFMA xi_z = 0 ; form xi_z = 3 : d1 - d3 ; then request rows 1, 2 of the next x tap
           const int G = dx * 4 + 2;
@@ -270,6 +273,7 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
           wino_mfma16(v[0], aw[G % 3], acc[0]);
           WINO_SCHED_GROUP();
           __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_nop 1" ::: "memory");  // hand-written transform VALU -> next group's MFMA operand: hazard not tracked by the compiler
         }
         {  // MFMA xi_z = 3 ; form xi_z = 1 of the next x tap : d1 + d2
           const int G = dx * 4 + 3;
@@ -282,6 +286,7 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
           wino_mfma16(v[1], aw[G % 3], acc[3]);
           WINO_SCHED_GROUP();
           __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_nop 1" ::: "memory");  // hand-written transform VALU -> next group's MFMA operand: hazard not tracked by the compiler
         }
       }
     }
