@@ -861,6 +861,236 @@ static int plan_wgrad(WgradPlan& pl, int ntaps, int s, int neg, int N, int Dp, i
   return BTS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the 3x3x3 stride-1 convolution in Winograd form (F(2x2,3x3) over (z,y), x direct) -- the counterpart of
+// conv_wino.hip for  dW[kz,ky,kx,c,k] = sum_v P[v + (kz-1,ky-1,kx-1)][c] * Q[v][k]:
+//   dU[dx][xi] = sum over 2x2 (z,y) patches and x' of  V[xi](c; x') * T[xi](k; x' - dx + 1),
+//   V = B^T d B (the forward's input transform, of P),  T = A dY A^T (of Q),  dg[.,.,dx] = G^T dU[dx] G.
+// 48 accumulator tiles (3 x taps x 16 transform points) instead of 27, each fed a quarter as often: 12/27 of the matrix
+// instructions.  The contraction runs over voxels, so channels sit on the lanes; for packed transforms every lane handles 4
+// consecutive x of its channel: the LDS tiles are x-fastest ([row][channel][x], transposed while staging; the P rows have
+// their 16-byte cells XOR-swizzled by (c >> 2) & 3 instead of padding).  Lanes 0-31 / 32-63 take two neighbouring x quads =
+// the two voxels of an MFMA's K = 2, so one ds_read_b128 feeds four matrix instructions per (x tap, point).  The x tap only
+// selects WHICH register of a 12-wide T window is the B operand (window value 5 + j - dx): V is formed once for all three taps.
+// 4 waves = the 4 xi_z, each 3 taps x 4 xi_y = 12 accumulators (192 registers), one wave per SIMD; sub-tile 16 x 4 x 2 as
+// the direct kernel's, so plan, partial layout ([27 taps][32][32] per workgroup, written after an in-LDS combine of the
+// waves) and finalize kernels are shared.  Bias partials: wave 1 holds all four Q rows of a patch anyway.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ wg_f32x2 wgw_pk_add(wg_f32x2 a, wg_f32x2 b) { wg_f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ wg_f32x2 wgw_pk_sub(wg_f32x2 a, wg_f32x2 b) { wg_f32x2 d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ wg_f32x2 wgw_pk_fma(wg_f32x2 a, wg_f32x2 b, wg_f32x2 c) { wg_f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ f32x4 wgw_add4(f32x4 a, f32x4 b) { const wg_f32x2 lo = wgw_pk_add(a.xy, b.xy), hi = wgw_pk_add(a.zw, b.zw); return f32x4{lo.x, lo.y, hi.x, hi.y}; }
+__device__ __forceinline__ f32x4 wgw_sub4(f32x4 a, f32x4 b) { const wg_f32x2 lo = wgw_pk_sub(a.xy, b.xy), hi = wgw_pk_sub(a.zw, b.zw); return f32x4{lo.x, lo.y, hi.x, hi.y}; }
+__device__ __forceinline__ f32x4 wgw_fma4(f32x4 a, wg_f32x2 s, f32x4 c) { const wg_f32x2 lo = wgw_pk_fma(a.xy, s, c.xy), hi = wgw_pk_fma(a.zw, s, c.zw); return f32x4{lo.x, lo.y, hi.x, hi.y}; }
+__device__ __forceinline__ float wgw_acc_rd(float a) { float v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; }
+
+#define WGW_QSTR 28                          /* floats per (row, channel) of the Q tile: x = -1..16 at entries 3..20 */
+#define WGW_PTILE (24 * 32 * 16)             /* 4 z-rows x 6 y-rows */
+#define WGW_QTILE (8 * 32 * WGW_QSTR)        /* 2 z-rows x 4 y-rows */
+#define WGW_BUF (WGW_PTILE + WGW_QTILE)      /* 19456 floats = 76 KB, double buffered */
+#define WGW_NPS 12
+#define WGW_NQS 5
+#define WGW_THREADS 256
+
+__global__ __launch_bounds__(WGW_THREADS, 1) void wgw_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = xi_z
+  const int ch = lane & 31, hh = lane >> 5;
+  const int pct = blockIdx.y, qct = blockIdx.z;
+  const float* pP = p.p + pct * 32;
+  const float* pQ = p.q + qct * 32;
+
+  // ---- staging maps: slot id = tid + 256*i ; P: x = id & 15, channel quad = (id >> 4) & 7, row = id >> 7 = (tid >> 7) + 2i ----
+  const int sxx = tid & 15, scq = (tid >> 4) & 7, srow0 = tid >> 7;
+  const int p_lds0 = (srow0 * 32 + scq * 4) * 16 + ((((sxx >> 2) ^ (scq & 3)) << 2) | (sxx & 3));
+  const int p_g0 = sxx * p.ldp + scq * 4;
+  int q_lds[WGW_NQS], q_goff[WGW_NQS], q_row[WGW_NQS], q_x[WGW_NQS];
+#pragma unroll
+  for (int i = 0; i < WGW_NQS; ++i) {
+    const int id = tid + WGW_THREADS * i;
+    q_row[i] = -1; q_lds[i] = 0; q_goff[i] = 0; q_x[i] = 0;
+    if (id < 1152) {
+      const int xx = id % 18, kq = (id / 18) & 7, row = id / 144;
+      q_row[i] = row;
+      q_x[i] = xx - 1;
+      q_lds[i] = WGW_PTILE + (row * 32 + kq * 4) * WGW_QSTR + xx + 3;
+      q_goff[i] = (xx - 1) * p.ldq + kq * 4;
+    }
+  }
+  f32x4 pre[WGW_NPS + WGW_NQS];
+  auto fetch = [&](int sub) {
+    int t = sub;
+    const int tx = t % p.ntx; t /= p.ntx;
+    const int ty = t % p.nty; t /= p.nty;
+    const int tz = t % p.ntz;
+    const int n = t / p.ntz;
+    const int z0 = 2 * tz, y0 = 4 * ty, x0 = 16 * tx;
+    const float* pb = pP + ((((long)n * p.Dp + z0 - 1) * p.Hp + y0 - 1) * p.Wp + x0) * p.ldp + p_g0;
+#pragma unroll
+    for (int i = 0; i < WGW_NPS; ++i) {
+      const int row = srow0 + 2 * i;
+      const int zr = row / 6, yr = row - zr * 6;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)(z0 - 1 + zr) < (unsigned)p.Dp && (unsigned)(y0 - 1 + yr) < (unsigned)p.Hp)
+        v = *reinterpret_cast<const f32x4*>(pb + ((long)zr * p.Hp + yr) * p.Wp * p.ldp);
+      pre[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < WGW_NQS; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (q_row[i] >= 0) {
+        const int z = z0 + (q_row[i] >> 2), y = y0 + (q_row[i] & 3), x = x0 + q_x[i];
+        if ((unsigned)x < (unsigned)p.Wq)
+          v = *reinterpret_cast<const f32x4*>(pQ + ((((long)n * p.Dq + z) * p.Hq + y) * p.Wq + x0) * p.ldq + q_goff[i]);
+      }
+      pre[WGW_NPS + i] = v;
+    }
+  };
+  auto commit = [&](float* buf) {
+#pragma unroll
+    for (int i = 0; i < WGW_NPS; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) buf[p_lds0 + i * (2 * 32 * 16) + e * 16] = pre[i][e];
+    }
+#pragma unroll
+    for (int i = 0; i < WGW_NQS; ++i) {
+      if (q_row[i] >= 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) buf[q_lds[i] + e * WGW_QSTR] = pre[WGW_NPS + i][e];
+      }
+    }
+  };
+
+  // ---- wave roles: xi_z: 0: d0 - d2 | 1: d1 + d2 | 2: d2 - d1 | 3: d1 - d3 ;  c = P[ra] + s * P[rb] ----
+  const int ra = (wave == 0) ? 0 : (wave == 2) ? 2 : 1;
+  const int rb = (wave == 0) ? 2 : (wave == 1) ? 2 : (wave == 2) ? 1 : 3;
+  const float sp = (wave == 1) ? 1.f : -1.f;
+  const wg_f32x2 sp2 = {sp, sp};
+  // T z-part: 0: q0 | 1: q0 + q1 | 2: q0 - q1 | 3: +q1 (the true -q1 is undone in the tap combine)
+  const float sq = (wave == 2) ? -1.f : 1.f;
+  const wg_f32x2 sq2 = {sq, sq};
+  const int pswz = (ch >> 2) & 3;
+  const int pA = (ra * 6 * 32 + ch) * 16, pB = (rb * 6 * 32 + ch) * 16;
+  const bool bias = p.want_bias && pct == 0 && wave == 1;
+  double bsum = 0.0;
+
+  f32x16 acc[3][4];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+  const int t0 = blockIdx.x * p.sub_per_wg;
+  int t1 = t0 + p.sub_per_wg;
+  if (t1 > p.nsub) t1 = p.nsub;
+  if (t0 < t1) {
+    fetch(t0);
+    commit(lds);
+  }
+  __syncthreads();
+  for (int t = t0; t < t1; ++t) {
+    const float* cur = lds + ((t - t0) & 1) * WGW_BUF;
+    float* nxt = lds + ((t - t0 + 1) & 1) * WGW_BUF;
+    const bool more = (t + 1) < t1;
+    if (more) fetch(t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int py2 = 0; py2 < 2; ++py2)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int xq = 2 * s + hh;               // logical x quad of this lane
+        const int xo = 4 * xq;
+        const int pq = (xq ^ pswz) << 2;          // physical cell inside the 16-float row
+        // ---- V: z-combine of two rows, then the y transform ----
+        f32x4 c[4], v[4];
+#pragma unroll
+        for (int yr = 0; yr < 4; ++yr) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(cur + pA + (2 * py2 + yr) * 512 + pq);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(cur + pB + (2 * py2 + yr) * 512 + pq);
+          c[yr] = wgw_fma4(b, sp2, a);
+        }
+        v[0] = wgw_sub4(c[0], c[2]);
+        v[1] = wgw_add4(c[1], c[2]);
+        v[2] = wgw_sub4(c[2], c[1]);
+        v[3] = wgw_sub4(c[1], c[3]);
+        // ---- T: window of 12 x values (entries xo .. xo+11 of the Q rows), z part then y part ----
+        f32x4 a0[3], a1[3], u1[3], u2[3];
+        const float* qb = cur + WGW_PTILE + ((2 * py2) * 32 + ch) * WGW_QSTR + xo;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          const f32x4 q00 = *reinterpret_cast<const f32x4*>(qb + (0 * 32) * WGW_QSTR + 4 * w);   // (oz 0, oy 0)
+          const f32x4 q01 = *reinterpret_cast<const f32x4*>(qb + (1 * 32) * WGW_QSTR + 4 * w);   // (oz 0, oy 1)
+          const f32x4 q10 = *reinterpret_cast<const f32x4*>(qb + (4 * 32) * WGW_QSTR + 4 * w);   // (oz 1, oy 0)
+          const f32x4 q11 = *reinterpret_cast<const f32x4*>(qb + (5 * 32) * WGW_QSTR + 4 * w);   // (oz 1, oy 1)
+          if (wave == 0) { a0[w] = q00; a1[w] = q01; }
+          else if (wave == 3) { a0[w] = q10; a1[w] = q11; }
+          else { a0[w] = wgw_fma4(q10, sq2, q00); a1[w] = wgw_fma4(q11, sq2, q01); }
+          u1[w] = wgw_add4(a0[w], a1[w]);
+          u2[w] = wgw_sub4(a0[w], a1[w]);
+          if (w == 1 && bias) {   // wave 1: a0 + a1 of the middle quad = the four Q rows of this lane's own 4 x
+            const f32x4 sm = u1[1];
+            bsum += (double)((sm[0] + sm[1]) + (sm[2] + sm[3]));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the hand-written VALU must not sink between the matrix instructions:
+        asm volatile("s_nop 3" ::: "memory");  // the compiler does not track their write -> MFMA-read hazard
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int w = 5 + j - dx;
+            acc[dx][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[0][j], a0[w >> 2][w & 3], acc[dx][0], 0, 0, 0);
+            acc[dx][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[1][j], u1[w >> 2][w & 3], acc[dx][1], 0, 0, 0);
+            acc[dx][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[2][j], u2[w >> 2][w & 3], acc[dx][2], 0, 0, 0);
+            acc[dx][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[3][j], a1[w >> 2][w & 3], acc[dx][3], 0, 0, 0);   // true t3 = -a1
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    if (more) commit(nxt);
+    __syncthreads();
+  }
+
+  // ---- G^T dU G: y part in the wave (u3 carries the opposite sign) -> LDS [xi_z][dx*3+ky][c][k]; z part across the waves ----
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  float* xl = lds + wave * 9 * 1024;
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float u0 = wgw_acc_rd(acc[dx][0][r]), u1 = wgw_acc_rd(acc[dx][1][r]), u2 = wgw_acc_rd(acc[dx][2][r]),
+                  u3 = wgw_acc_rd(acc[dx][3][r]);
+      const float hs = 0.5f * (u1 + u2), hd = 0.5f * (u1 - u2);
+      const int crow = 8 * (r >> 2) + 4 * hh + (r & 3);
+      float* o = xl + (dx * 3) * 1024 + crow * 32 + ch;
+      o[0] = u0 + hs;
+      o[1024] = hd;
+      o[2048] = hs - u3;
+    }
+  __syncthreads();
+  // taps (kz, ky, dx): kz 0: L0 + .5 L1 + .5 L2 | kz 1: .5 L1 - .5 L2 | kz 2: .5 L1 + .5 L2 - L3   (L3 accumulated with +q1)
+  float* out = p.partial + ((((long)blockIdx.x * gridDim.y + pct) * gridDim.z + qct) * 27) * 1024;
+  for (int e = tid; e < 9 * 1024; e += WGW_THREADS) {
+    const int g = e >> 10, ck = e & 1023;       // g = dx*3 + ky
+    const int dx = g / 3, ky = g - dx * 3;
+    const float l0 = lds[(0 * 9 + g) * 1024 + ck], l1 = lds[(1 * 9 + g) * 1024 + ck], l2 = lds[(2 * 9 + g) * 1024 + ck],
+                l3 = lds[(3 * 9 + g) * 1024 + ck];
+    const float hs = 0.5f * (l1 + l2), hd = 0.5f * (l1 - l2);
+    out[((0 * 3 + ky) * 3 + dx) * 1024 + ck] = l0 + hs;
+    out[((1 * 3 + ky) * 3 + dx) * 1024 + ck] = hd;
+    out[((2 * 3 + ky) * 3 + dx) * 1024 + ck] = hs - l3;
+  }
+  if (bias) {
+    const double o = __shfl_xor(bsum, 32, 64);   // the two x-quad halves of the wave
+    if (lane < 32) p.partial_b[((long)blockIdx.x * gridDim.z + qct) * 32 + ch] = bsum + o;
+  }
+}
+
 struct WgradRoles {
   int ntaps, s, neg, swapped, transposed;
   int Dp, Hp, Wp, Cp, Dq, Hq, Wq, Cq;
@@ -945,11 +1175,31 @@ extern "C" int bts_conv3d_bwd_weight(int kind, const float* x, const float* dy, 
     if (e != hipSuccess) return (int)e;
   }
   const int kidx = !glds ? 0 : (p.fastf ? 1 + p.fixg : 1);
+  // stride-1 whole-tile layers: Winograd form (BTS_WGW=0: the direct fixed-geometry kernel)
+  bool use_wgw = false;
+  if (kidx == 2 && ro.ntaps == 27 && ro.s == 1) {
+    const char* e = getenv("BTS_WGW");
+    use_wgw = !(e && atoi(e) == 0);
+  }
+  if (use_wgw) {
+    static bool wattr = false;
+    if (!wattr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+      wattr = true;
+    }
+    if (prof) bts_prof_begin(24, 2.0 * ro.ntaps * (double)ro.Cp * ro.Cq * (double)N * ro.Dq * ro.Hq * ro.Wq, stream);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(wgw_kernel, dim3(pl.nsp, pl.npct, pl.nqct), dim3(WGW_THREADS), (size_t)2 * WGW_BUF * sizeof(float), stream, p);
+    if (prof) bts_prof_end(stream);
+    BTS_LAUNCH_CHECK();
+  } else {
   static const int ksym[4] = {100, 104, 109, 110};  // 100 + (MODE << 2 | FIXG)
   if (prof) bts_prof_begin(ksym[kidx], 2.0 * ro.ntaps * (double)ro.Cp * ro.Cq * (double)N * ro.Dq * ro.Hq * ro.Wq, stream);
   (void)hipGetLastError(); hipLaunchKernelGGL(kernels[kidx], dim3(pl.nsp, pl.npct, pl.nqct), dim3(WG_THREADS), pl.shmem, stream, p);
   if (prof) bts_prof_end(stream);
   BTS_LAUNCH_CHECK();
+  }
   WfinParams f;
   f.partial = p.partial; f.partial_b = p.partial_b; f.dw = dw; f.db = p.want_bias ? db : nullptr;
   f.nsp = pl.nsp; f.npct = pl.npct; f.nqct = pl.nqct; f.ntaps = ro.ntaps; f.ntiles = p.ntiles; f.cpad = p.cpad;

@@ -22,11 +22,12 @@ struct WgwParams {
   long long* stamps;
 };
 
-#define PSTR 20                        /* floats per (row, channel) of the P tile: 16 x + pad (conflict-free b128) */
 #define QSTR 28                        /* floats per (row, channel) of the Q tile: x = -1..16 at entries 3..20 */
-#define PTILE (16 * 32 * PSTR)         /* 4 z-rows x 4 y-rows */
-#define QTILE (4 * 32 * QSTR)
-#define WBUF (PTILE + QTILE)           /* 13824 floats = 55 KB */
+#define PTILE (24 * 32 * 16)           /* 4 z-rows x 6 y-rows, 16 x per (row, channel), quads XOR-swizzled by (c >> 2) & 3 */
+#define QTILE (8 * 32 * QSTR)          /* 2 z-rows x 4 y-rows */
+#define WBUF (PTILE + QTILE)           /* 19456 floats = 76 KB */
+#define NPS 12
+#define NQS 5
 
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
@@ -36,6 +37,7 @@ __device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) { const f32x2 lo = pk_su
 __device__ __forceinline__ f32x4 fma4(f32x4 a, f32x2 s, f32x4 c) { const f32x2 lo = pk_fma(a.xy, s, c.xy), hi = pk_fma(a.zw, s, c.zw); return f32x4{lo.x, lo.y, hi.x, hi.y}; }
 __device__ __forceinline__ float acc_rd(float a) { float v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; }
 
+// tile = 16 x * 4 y * 2 z of Q (two 2x2 (z,y) patches side by side in y); part: [wg][27 taps][32 c][32 k]
 __global__ __launch_bounds__(256, 1) void wgw_kernel(const WgwParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -44,22 +46,16 @@ __global__ __launch_bounds__(256, 1) void wgw_kernel(const WgwParams p) {
   const int ch = lane & 31, hh = lane >> 5;
   const long long ts0 = clock64();
 
-  // ---- staging maps (fixed per thread): P 8 quads, Q 3 quads of 4 channels; x fastest over the lanes ----
-  int p_row[8], p_lds[8], p_goff[8];   // row = zr*4+yr ; LDS float offset of (channel quad, x) ; global float offset inside a row
-  int q_lds[3], q_goff[3], q_row[3], q_x[3];
+  // ---- staging maps: slot id = tid + 256*i ; P: x = id&15, channel quad = (id>>4)&7, row = id>>7 = (tid>>7) + 2i ----
+  const int sxx = tid & 15, scq = (tid >> 4) & 7, srow0 = tid >> 7;
+  const int p_lds0 = (srow0 * 32 + scq * 4) * 16 + ((((sxx >> 2) ^ (scq & 3)) << 2) | (sxx & 3));
+  const int p_g0 = sxx * p.ldp + scq * 4;
+  int q_lds[NQS], q_goff[NQS], q_row[NQS], q_x[NQS];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int id = tid + 256 * i;
-    const int xx = id & 15, cq = (id >> 4) & 7, row = id >> 7;
-    p_row[i] = row;
-    p_lds[i] = (row * 32 + cq * 4) * PSTR + xx;
-    p_goff[i] = xx * p.ldp + cq * 4;
-  }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < NQS; ++i) {
     const int id = tid + 256 * i;
     q_row[i] = -1; q_lds[i] = 0; q_goff[i] = 0; q_x[i] = 0;
-    if (id < 576) {
+    if (id < 1152) {
       const int xx = id % 18, kq = (id / 18) & 7, row = id / 144;
       q_row[i] = row;
       q_x[i] = xx - 1;
@@ -67,57 +63,60 @@ __global__ __launch_bounds__(256, 1) void wgw_kernel(const WgwParams p) {
       q_goff[i] = (xx - 1) * p.ldq + kq * 4;
     }
   }
-  f32x4 pre[11];
+  f32x4 pre[NPS + NQS];
   auto fetch = [&](int tile) {
     int t = tile;
     const int tx = t % p.ntx; t /= p.ntx;
     const int py = t % p.npy; t /= p.npy;
     const int pz = t % p.npz;
     const int n = t / p.npz;
-    const int z0 = 2 * pz, y0 = 2 * py, x0 = 16 * tx;
+    const int z0 = 2 * pz, y0 = 4 * py, x0 = 16 * tx;
+    const float* pb = p.p + ((((long)n * p.D + z0 - 1) * p.H + y0 - 1) * p.W + x0) * p.ldp + p_g0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int z = z0 - 1 + (p_row[i] >> 2), y = y0 - 1 + (p_row[i] & 3);
+    for (int i = 0; i < NPS; ++i) {
+      const int row = srow0 + 2 * i;
+      const int zr = row / 6, yr = row - zr * 6;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H)
-        v = *reinterpret_cast<const f32x4*>(p.p + ((((long)n * p.D + z) * p.H + y) * p.W + x0) * p.ldp + p_goff[i]);
+      if ((unsigned)(z0 - 1 + zr) < (unsigned)p.D && (unsigned)(y0 - 1 + yr) < (unsigned)p.H)
+        v = *reinterpret_cast<const f32x4*>(pb + ((long)zr * p.H + yr) * p.W * p.ldp);
       pre[i] = v;
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NQS; ++i) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (q_row[i] >= 0) {
-        const int z = z0 + (q_row[i] >> 1), y = y0 + (q_row[i] & 1), x = x0 + q_x[i];
+        const int z = z0 + (q_row[i] >> 2), y = y0 + (q_row[i] & 3), x = x0 + q_x[i];
         if ((unsigned)x < (unsigned)p.W)
           v = *reinterpret_cast<const f32x4*>(p.q + ((((long)n * p.D + z) * p.H + y) * p.W + x0) * p.ldq + q_goff[i]);
       }
-      pre[8 + i] = v;
+      pre[NPS + i] = v;
     }
   };
   auto commit = [&](float* buf) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NPS; ++i) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) buf[p_lds[i] + e * PSTR] = pre[i][e];
+      for (int e = 0; e < 4; ++e) buf[p_lds0 + i * (2 * 32 * 16) + e * 16] = pre[i][e];
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NQS; ++i) {
       if (q_row[i] >= 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) buf[q_lds[i] + e * QSTR] = pre[8 + i][e];
+        for (int e = 0; e < 4; ++e) buf[q_lds[i] + e * QSTR] = pre[NPS + i][e];
       }
     }
   };
 
-  // ---- wave roles ----
-  // xi_z: 0: d0 - d2 | 1: d1 + d2 | 2: d2 - d1 | 3: d1 - d3     rows (ra, rb), c = P[ra] + s * P[rb]
+  // ---- wave roles: xi_z: 0: d0 - d2 | 1: d1 + d2 | 2: d2 - d1 | 3: d1 - d3 ;  c = P[ra] + s * P[rb] ----
   const int ra = (wave == 0) ? 0 : (wave == 2) ? 2 : 1;
   const int rb = (wave == 0) ? 2 : (wave == 1) ? 2 : (wave == 2) ? 1 : 3;
   const float sp = (wave == 1) ? 1.f : -1.f;
   const f32x2 sp2 = {sp, sp};
-  // T z-part: 0: q0 | 1: q0 + q1 | 2: q0 - q1 | 3: +q1 (the true -q1 is undone in the finalize)
+  // T z-part: 0: q0 | 1: q0 + q1 | 2: q0 - q1 | 3: +q1 (the true -q1 is undone in the tap combine)
   const float sq = (wave == 2) ? -1.f : 1.f;
   const f32x2 sq2 = {sq, sq};
+  const int pswz = (ch >> 2) & 3;
+  const int pA = (ra * 6 * 32 + ch) * 16, pB = (rb * 6 * 32 + ch) * 16;
 
   f32x16 acc[3][4];
 #pragma unroll
@@ -143,59 +142,62 @@ __global__ __launch_bounds__(256, 1) void wgw_kernel(const WgwParams p) {
     if (more) fetch(t + 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int xo = 8 * s + 4 * hh;
-      // ---- V: z-combine of two rows, then the y transform ----
-      f32x4 c[4], v[4];
+    for (int py2 = 0; py2 < 2; ++py2)
 #pragma unroll
-      for (int yr = 0; yr < 4; ++yr) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(cur + ((ra * 4 + yr) * 32 + ch) * PSTR + xo);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(cur + ((rb * 4 + yr) * 32 + ch) * PSTR + xo);
-        c[yr] = fma4(b, sp2, a);
-      }
-      v[0] = sub4(c[0], c[2]);
-      v[1] = add4(c[1], c[2]);
-      v[2] = sub4(c[2], c[1]);
-      v[3] = sub4(c[1], c[3]);
-      // ---- T: window of 12 x values (entries xo .. xo+11 of the Q rows), z part then y part ----
-      f32x4 a0[3], a1[3], u1[3], u2[3];
-      const float* qb = cur + PTILE + ch * QSTR + xo;
+      for (int s = 0; s < 2; ++s) {
+        const int xq = 2 * s + hh;               // logical x quad of this lane
+        const int xo = 4 * xq;
+        const int pq = (xq ^ pswz) << 2;          // physical quad offset inside the 16-float row
+        // ---- V: z-combine of two rows, then the y transform ----
+        f32x4 c[4], v[4];
 #pragma unroll
-      for (int w = 0; w < 3; ++w) {
-        const f32x4 q00 = *reinterpret_cast<const f32x4*>(qb + (0 * 32) * QSTR + 4 * w);   // (oz 0, oy 0)
-        const f32x4 q01 = *reinterpret_cast<const f32x4*>(qb + (1 * 32) * QSTR + 4 * w);   // (oz 0, oy 1)
-        const f32x4 q10 = *reinterpret_cast<const f32x4*>(qb + (2 * 32) * QSTR + 4 * w);   // (oz 1, oy 0)
-        const f32x4 q11 = *reinterpret_cast<const f32x4*>(qb + (3 * 32) * QSTR + 4 * w);   // (oz 1, oy 1)
-        if (wave == 0) { a0[w] = q00; a1[w] = q01; }
-        else if (wave == 3) { a0[w] = q10; a1[w] = q11; }
-        else { a0[w] = fma4(q10, sq2, q00); a1[w] = fma4(q11, sq2, q01); }
-        u1[w] = add4(a0[w], a1[w]);
-        u2[w] = sub4(a0[w], a1[w]);
-      }
-      __builtin_amdgcn_sched_barrier(0);   // the hand-written VALU must not sink between the matrix instructions:
-      asm volatile("s_nop 3" ::: "memory");  // the compiler does not track their write -> MFMA-read hazard
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- 48 MFMAs: (x tap, xi_y, j) ; B operand = window value 5 + j - dx ----
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int w = 5 + j - dx;
-          acc[dx][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[0][j], a0[w >> 2][w & 3], acc[dx][0], 0, 0, 0);
-          acc[dx][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[1][j], u1[w >> 2][w & 3], acc[dx][1], 0, 0, 0);
-          acc[dx][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[2][j], u2[w >> 2][w & 3], acc[dx][2], 0, 0, 0);
-          acc[dx][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[3][j], a1[w >> 2][w & 3], acc[dx][3], 0, 0, 0);   // true t3 = -a1
+        for (int yr = 0; yr < 4; ++yr) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(cur + pA + (2 * py2 + yr) * 512 + pq);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(cur + pB + (2 * py2 + yr) * 512 + pq);
+          c[yr] = fma4(b, sp2, a);
         }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+        v[0] = sub4(c[0], c[2]);
+        v[1] = add4(c[1], c[2]);
+        v[2] = sub4(c[2], c[1]);
+        v[3] = sub4(c[1], c[3]);
+        // ---- T: window of 12 x values (entries xo .. xo+11 of the Q rows), z part then y part ----
+        f32x4 a0[3], a1[3], u1[3], u2[3];
+        const float* qb = cur + PTILE + ((2 * py2) * 32 + ch) * QSTR + xo;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          const f32x4 q00 = *reinterpret_cast<const f32x4*>(qb + (0 * 32) * QSTR + 4 * w);   // (oz 0, oy 0)
+          const f32x4 q01 = *reinterpret_cast<const f32x4*>(qb + (1 * 32) * QSTR + 4 * w);   // (oz 0, oy 1)
+          const f32x4 q10 = *reinterpret_cast<const f32x4*>(qb + (4 * 32) * QSTR + 4 * w);   // (oz 1, oy 0)
+          const f32x4 q11 = *reinterpret_cast<const f32x4*>(qb + (5 * 32) * QSTR + 4 * w);   // (oz 1, oy 1)
+          if (wave == 0) { a0[w] = q00; a1[w] = q01; }
+          else if (wave == 3) { a0[w] = q10; a1[w] = q11; }
+          else { a0[w] = fma4(q10, sq2, q00); a1[w] = fma4(q11, sq2, q01); }
+          u1[w] = add4(a0[w], a1[w]);
+          u2[w] = sub4(a0[w], a1[w]);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the hand-written VALU must not sink between the matrix instructions:
+        asm volatile("s_nop 3" ::: "memory");  // the compiler does not track their write -> MFMA-read hazard
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int w = 5 + j - dx;
+            acc[dx][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[0][j], a0[w >> 2][w & 3], acc[dx][0], 0, 0, 0);
+            acc[dx][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[1][j], u1[w >> 2][w & 3], acc[dx][1], 0, 0, 0);
+            acc[dx][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[2][j], u2[w >> 2][w & 3], acc[dx][2], 0, 0, 0);
+            acc[dx][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[3][j], a1[w >> 2][w & 3], acc[dx][3], 0, 0, 0);   // true t3 = -a1
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     if (more) commit(nxt);
     __syncthreads();
   }
   const long long ts2 = clock64();
 
-  // ---- y part of G^T dU G in the wave (u3 carries the opposite sign), partial tiles to global ----
+  // ---- G^T dU G: y part in the wave (u3 carries the opposite sign) -> LDS [xi_z][dx*3+ky][c][k]; z part across the waves ----
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-  float* out = p.part + ((long)blockIdx.x * 4 + wave) * 9 * 1024;
+  float* xl = lds + wave * 9 * 1024;
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
@@ -203,31 +205,37 @@ __global__ __launch_bounds__(256, 1) void wgw_kernel(const WgwParams p) {
       const float u0 = acc_rd(acc[dx][0][r]), u1 = acc_rd(acc[dx][1][r]), u2 = acc_rd(acc[dx][2][r]), u3 = acc_rd(acc[dx][3][r]);
       const float hs = 0.5f * (u1 + u2), hd = 0.5f * (u1 - u2);
       const int crow = 8 * (r >> 2) + 4 * hh + (r & 3);
-      float* o = out + (long)(dx * 3) * 1024 + crow * 32 + ch;
+      float* o = xl + (dx * 3) * 1024 + crow * 32 + ch;
       o[0] = u0 + hs;
       o[1024] = hd;
       o[2048] = hs - u3;
     }
+  __syncthreads();
+  // taps (kz, ky, dx): kz 0: L0 + .5 L1 + .5 L2 | kz 1: .5 L1 - .5 L2 | kz 2: .5 L1 + .5 L2 - L3   (L3 accumulated with +q1)
+  float* out = p.part + (long)blockIdx.x * 27 * 1024;
+  for (int e = tid; e < 9 * 1024; e += 256) {
+    const int g = e >> 10, ck = e & 1023;       // g = dx*3 + ky
+    const int dx = g / 3, ky = g - dx * 3;
+    const float l0 = lds[(0 * 9 + g) * 1024 + ck], l1 = lds[(1 * 9 + g) * 1024 + ck], l2 = lds[(2 * 9 + g) * 1024 + ck],
+                l3 = lds[(3 * 9 + g) * 1024 + ck];
+    const float hs = 0.5f * (l1 + l2), hd = 0.5f * (l1 - l2);
+    out[((0 * 3 + ky) * 3 + dx) * 1024 + ck] = l0 + hs;
+    out[((1 * 3 + ky) * 3 + dx) * 1024 + ck] = hd;
+    out[((2 * 3 + ky) * 3 + dx) * 1024 + ck] = hs - l3;
+  }
   if (tid == 0) {
     long long* o = p.stamps + (long)blockIdx.x * 4;
     o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = clock64();
   }
 }
 
-// dW[(kz*3+ky)*3+dx][c][k] = sum_wg sum_xiz G[xiz][kz] * sign(xiz) * part[wg][xiz][dx][ky][c][k]
+// dW[tap][c][k] = sum_wg part[wg][tap][c][k]
 __global__ void wgw_finalize(const float* part, float* dw, int nwg) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 27 * 1024
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 27 * 1024) return;
-  const int ck = i & 1023, t = i >> 10;
-  const int dx = t % 3, ky = (t / 3) % 3, kz = t / 9;
-  const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, -1.f}};  // last row: sign of xi_z = 3
   double s = 0.0;
-  for (int w = 0; w < nwg; ++w)
-    for (int xz = 0; xz < 4; ++xz) {
-      const float g = G[xz][kz];
-      if (g != 0.f) s += (double)g * part[(((long)w * 4 + xz) * 9 + dx * 3 + ky) * 1024 + ck];
-    }
-  dw[(long)t * 1024 + ck] = (float)s;
+  for (int w = 0; w < nwg; ++w) s += part[(long)w * 27 * 1024 + i];
+  dw[i] = (float)s;
 }
 
 __global__ void ref_wgrad(const float* p, const float* q, double* dw, int D, int H, int W) {
@@ -271,11 +279,11 @@ int main(int argc, char** argv) {
   hipMemcpy(dq, hq.data(), hq.size() * 4, hipMemcpyHostToDevice);
   WgwParams p{};
   p.p = dp; p.q = dq; p.N = 1; p.D = D; p.H = H; p.W = W; p.ldp = 32; p.ldq = 32;
-  p.npz = D / 2; p.npy = H / 2; p.ntx = W / 16; p.ntiles = p.npz * p.npy * p.ntx;
+  p.npz = D / 2; p.npy = H / 4; p.ntx = W / 16; p.ntiles = p.npz * p.npy * p.ntx;
   if (nwg > p.ntiles) nwg = p.ntiles;
   p.per = (p.ntiles + nwg - 1) / nwg;
   nwg = (p.ntiles + p.per - 1) / p.per;
-  hipMalloc(&dpart, (long)nwg * 4 * 9 * 1024 * 4); hipMalloc(&ddw, 27 * 1024 * 4); hipMalloc(&dref, 27 * 1024 * 8);
+  hipMalloc(&dpart, (long)nwg * 27 * 1024 * 4); hipMalloc(&ddw, 27 * 1024 * 4); hipMalloc(&dref, 27 * 1024 * 8);
   hipMalloc(&p.stamps, (long)nwg * 4 * 8);
   p.part = dpart;
   const int ldsb = 2 * WBUF * 4;
@@ -319,6 +327,6 @@ int main(int argc, char** argv) {
   hipMemcpy(st.data(), p.stamps, st.size() * 8, hipMemcpyDeviceToHost);
   double a = 0, b = 0, c = 0;
   for (int i = 0; i < nwg; ++i) { a += st[i * 4 + 1] - st[i * 4]; b += st[i * 4 + 2] - st[i * 4 + 1]; c += st[i * 4 + 3] - st[i * 4 + 2]; }
-  printf("clock64 ticks per WG: prologue %.0f  loop %.0f (%.0f per tile, %d MFMA cycles)  epilogue %.0f\n", a / nwg, b / nwg, b / nwg / p.per, 96 * 64, c / nwg);
+  printf("clock64 ticks per WG: prologue %.0f  loop %.0f (%.0f per tile, %d MFMA cycles)  epilogue %.0f\n", a / nwg, b / nwg, b / nwg / p.per, 192 * 64, c / nwg);
   return 0;
 }
