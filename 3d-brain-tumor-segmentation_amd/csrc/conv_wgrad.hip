@@ -903,65 +903,90 @@ __global__ __launch_bounds__(WGW_THREADS, 1) void wgw_kernel(const WgradParams p
   const float* pP = p.p + pct * 32;
   const float* pQ = p.q + qct * 32;
 
-  // ---- staging maps: slot id = tid + 256*i ; P: x = id & 15, channel quad = (id >> 4) & 7, row = id >> 7 = (tid >> 7) + 2i ----
+  // ---- staging maps: slot id = tid + 256*i ; P: x = id & 15, channel quad = (id >> 4) & 7, row = id >> 7 = (tid >> 7) + 2i.
+  //      Byte offsets relative to the tile origin are computed once; a slot outside the image gets a 2 GB offset = outside
+  //      the buffer descriptor, the load returns zeros (border tiles only: 4 flag bits per slot against 4 per tile) ----
   const int sxx = tid & 15, scq = (tid >> 4) & 7, srow0 = tid >> 7;
   const int p_lds0 = (srow0 * 32 + scq * 4) * 16 + ((((sxx >> 2) ^ (scq & 3)) << 2) | (sxx & 3));
-  const int p_g0 = sxx * p.ldp + scq * 4;
-  int q_lds[WGW_NQS], q_goff[WGW_NQS], q_row[WGW_NQS], q_x[WGW_NQS];
+  unsigned poff[WGW_NPS], pfl0 = 0, pfl1 = 0;
+#pragma unroll
+  for (int i = 0; i < WGW_NPS; ++i) {
+    const int row = srow0 + 2 * i;
+    const int zr = row / 6, yr = row - zr * 6;
+    poff[i] = (unsigned)(((zr * p.Hp + yr) * p.Wp + sxx) * p.ldp + scq * 4) * 4u;
+    const unsigned fl = (zr == 0 ? 1u : 0u) | (zr == 3 ? 2u : 0u) | (yr == 0 ? 4u : 0u) | (yr == 5 ? 8u : 0u);
+    if (i < 8) pfl0 |= fl << (4 * i); else pfl1 |= fl << (4 * (i - 8));
+  }
+  int q_lds[WGW_NQS];
+  unsigned qoff[WGW_NQS], qfl = 0;
 #pragma unroll
   for (int i = 0; i < WGW_NQS; ++i) {
     const int id = tid + WGW_THREADS * i;
-    q_row[i] = -1; q_lds[i] = 0; q_goff[i] = 0; q_x[i] = 0;
+    q_lds[i] = -1; qoff[i] = 0x80000000u;
     if (id < 1152) {
-      const int xx = id % 18, kq = (id / 18) & 7, row = id / 144;
-      q_row[i] = row;
-      q_x[i] = xx - 1;
+      const int xx = id % 18, kq = (id / 18) & 7, row = id / 144;   // x = x0 - 1 + xx ; row = oz*4 + oy
       q_lds[i] = WGW_PTILE + (row * 32 + kq * 4) * WGW_QSTR + xx + 3;
-      q_goff[i] = (xx - 1) * p.ldq + kq * 4;
+      qoff[i] = (unsigned)((((row >> 2) * p.Hq + (row & 3)) * p.Wq + xx) * p.ldq + kq * 4) * 4u;
+      qfl |= ((xx == 0 ? 1u : 0u) | (xx == 17 ? 2u : 0u)) << (2 * i);
     }
   }
+  // coordinates of the NEXT sub-tile to fetch (sub-tiles of a workgroup are consecutive: incremental, no division in the loop)
+  int ftx, fty, ftz, fn;
+  {
+    int t = blockIdx.x * p.sub_per_wg;
+    ftx = t % p.ntx; t /= p.ntx;
+    fty = t % p.nty; t /= p.nty;
+    ftz = t % p.ntz;
+    fn = t / p.ntz;
+  }
+  // The 17 slots of the next sub-tile are fetched in four quarters (P 0-2 + Q 0-1 | P 3-5 + Q 2 | P 6-8 + Q 3 | P 9-11 + Q 4),
+  // quarter k issued at step k of the current sub-tile and written to the OTHER LDS buffer one step later: the staging
+  // registers of a quarter live for one step only and the ds_writes spread over the matrix instructions.
   f32x4 pre[WGW_NPS + WGW_NQS];
-  auto fetch = [&](int sub) {
-    int t = sub;
-    const int tx = t % p.ntx; t /= p.ntx;
-    const int ty = t % p.nty; t /= p.nty;
-    const int tz = t % p.ntz;
-    const int n = t / p.ntz;
-    const int z0 = 2 * tz, y0 = 4 * ty, x0 = 16 * tx;
-    const float* pb = pP + ((((long)n * p.Dp + z0 - 1) * p.Hp + y0 - 1) * p.Wp + x0) * p.ldp + p_g0;
+  __amdgpu_buffer_rsrc_t f_pr, f_qr;
+  unsigned f_tm = 0, f_qm = 0;
+  auto fetch_begin = [&]() {
+    const int z0 = 2 * ftz, y0 = 4 * fty, x0 = 16 * ftx;
+    const float* pb = pP + ((((long)fn * p.Dp + z0 - 1) * p.Hp + y0 - 1) * p.Wp + x0) * p.ldp;
+    const float* qb = pQ + ((((long)fn * p.Dq + z0) * p.Hq + y0) * p.Wq + x0 - 1) * p.ldq;
+    f_pr = __builtin_amdgcn_make_buffer_rsrc((void*)pb, 0, 0x7fffffff, 0x00020000);
+    f_qr = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, 0x7fffffff, 0x00020000);
+    f_tm = (ftz == 0 ? 1u : 0u) | (ftz == p.ntz - 1 ? 2u : 0u) | (fty == 0 ? 4u : 0u) | (fty == p.nty - 1 ? 8u : 0u);
+    f_qm = (ftx == 0 ? 1u : 0u) | (ftx == p.ntx - 1 ? 2u : 0u);
+    if (++ftx == p.ntx) { ftx = 0; if (++fty == p.nty) { fty = 0; if (++ftz == p.ntz) { ftz = 0; ++fn; } } }
+  };
+  auto fetch_p = [&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int sh = 4 * (i & 7);
+    const unsigned fl = (((i < 8 ? pfl0 : pfl1) >> sh) & 15u) & f_tm;
+    pre[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(f_pr, fl ? 0x80000000u : poff[i], 0, 0));
+  };
+  auto fetch_q = [&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    const unsigned fl = ((qfl >> (2 * i)) & 3u) & f_qm;
+    pre[WGW_NPS + i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(f_qr, fl ? 0x80000000u : qoff[i], 0, 0));
+  };
+  auto commit_p = [&](float* buf, auto ic) {
+    constexpr int i = decltype(ic)::value;
 #pragma unroll
-    for (int i = 0; i < WGW_NPS; ++i) {
-      const int row = srow0 + 2 * i;
-      const int zr = row / 6, yr = row - zr * 6;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)(z0 - 1 + zr) < (unsigned)p.Dp && (unsigned)(y0 - 1 + yr) < (unsigned)p.Hp)
-        v = *reinterpret_cast<const f32x4*>(pb + ((long)zr * p.Hp + yr) * p.Wp * p.ldp);
-      pre[i] = v;
-    }
+    for (int e = 0; e < 4; ++e) buf[p_lds0 + i * (2 * 32 * 16) + e * 16] = pre[i][e];
+  };
+  auto commit_q = [&](float* buf, auto ic) {
+    constexpr int i = decltype(ic)::value;
+    if (q_lds[i] >= 0) {
 #pragma unroll
-    for (int i = 0; i < WGW_NQS; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (q_row[i] >= 0) {
-        const int z = z0 + (q_row[i] >> 2), y = y0 + (q_row[i] & 3), x = x0 + q_x[i];
-        if ((unsigned)x < (unsigned)p.Wq)
-          v = *reinterpret_cast<const f32x4*>(pQ + ((((long)n * p.Dq + z) * p.Hq + y) * p.Wq + x0) * p.ldq + q_goff[i]);
-      }
-      pre[WGW_NPS + i] = v;
+      for (int e = 0; e < 4; ++e) buf[q_lds[i] + e * WGW_QSTR] = pre[WGW_NPS + i][e];
     }
   };
-  auto commit = [&](float* buf) {
-#pragma unroll
-    for (int i = 0; i < WGW_NPS; ++i) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) buf[p_lds0 + i * (2 * 32 * 16) + e * 16] = pre[i][e];
-    }
-#pragma unroll
-    for (int i = 0; i < WGW_NQS; ++i) {
-      if (q_row[i] >= 0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) buf[q_lds[i] + e * WGW_QSTR] = pre[WGW_NPS + i][e];
-      }
-    }
+  auto fetch_quarter = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    fetch_p(IC<3 * k>{}); fetch_p(IC<3 * k + 1>{}); fetch_p(IC<3 * k + 2>{});
+    if constexpr (k == 0) { fetch_q(IC<0>{}); fetch_q(IC<1>{}); } else fetch_q(IC<k + 1>{});
+  };
+  auto commit_quarter = [&](float* buf, auto kc) {
+    constexpr int k = decltype(kc)::value;
+    commit_p(buf, IC<3 * k>{}); commit_p(buf, IC<3 * k + 1>{}); commit_p(buf, IC<3 * k + 2>{});
+    if constexpr (k == 0) { commit_q(buf, IC<0>{}); commit_q(buf, IC<1>{}); } else commit_q(buf, IC<k + 1>{});
   };
 
   // ---- wave roles: xi_z: 0: d0 - d2 | 1: d1 + d2 | 2: d2 - d1 | 3: d1 - d3 ;  c = P[ra] + s * P[rb] ----
@@ -969,9 +994,11 @@ __global__ __launch_bounds__(WGW_THREADS, 1) void wgw_kernel(const WgradParams p
   const int rb = (wave == 0) ? 2 : (wave == 1) ? 2 : (wave == 2) ? 1 : 3;
   const float sp = (wave == 1) ? 1.f : -1.f;
   const wg_f32x2 sp2 = {sp, sp};
-  // T z-part: 0: q0 | 1: q0 + q1 | 2: q0 - q1 | 3: +q1 (the true -q1 is undone in the tap combine)
-  const float sq = (wave == 2) ? -1.f : 1.f;
+  // T z-part: a = X + sq * Y over the two z-rows of Q:  0: q0 | 1: q0 + q1 | 2: q0 - q1 | 3: +q1 (the true -q1 is undone in the
+  // tap combine) -- X = row oz 0 (wave 3: oz 1), Y = row oz 1, sq = 0 / +1 / -1 / 0: the same instructions for every wave
+  const float sq = (wave == 1) ? 1.f : (wave == 2) ? -1.f : 0.f;
   const wg_f32x2 sq2 = {sq, sq};
+  const int qX = (wave == 3) ? 4 * 32 * WGW_QSTR : 0;
   const int pswz = (ch >> 2) & 3;
   const int pA = (ra * 6 * 32 + ch) * 16, pB = (rb * 6 * 32 + ch) * 16;
   const bool bias = p.want_bias && pct == 0 && wave == 1;
@@ -985,74 +1012,123 @@ __global__ __launch_bounds__(WGW_THREADS, 1) void wgw_kernel(const WgradParams p
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
+  // operands of one step (patch py2, x-quad pair s): V = 4 quads (A operand), T = the middle quad of the 12-wide window in
+  // full (window 4..7) and its two neighbours (window 3 and 8) as scalars
+  struct WgwOps {
+    f32x4 v[4];
+    f32x4 a0, a1, u1, u2;
+    float a0s[2], a1s[2], u1s[2], u2s[2];
+  };
+  auto form = [&](const float* cur, auto stc, WgwOps& o) {
+    constexpr int st = decltype(stc)::value;
+    constexpr int py2 = st >> 1, sx = st & 1;
+    const int xq = 2 * sx + hh;               // logical x quad of this lane
+    const int xo = 4 * xq;
+    const int pq = (xq ^ pswz) << 2;          // physical cell inside the 16-float row
+    f32x4 c[4];
+#pragma unroll
+    for (int yr = 0; yr < 4; ++yr) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(cur + pA + (2 * py2 + yr) * 512 + pq);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(cur + pB + (2 * py2 + yr) * 512 + pq);
+      c[yr] = wgw_fma4(b, sp2, a);
+    }
+    o.v[0] = wgw_sub4(c[0], c[2]);
+    o.v[1] = wgw_add4(c[1], c[2]);
+    o.v[2] = wgw_sub4(c[2], c[1]);
+    o.v[3] = wgw_sub4(c[1], c[3]);
+    const float* qb = cur + WGW_PTILE + ((2 * py2) * 32 + ch) * WGW_QSTR + xo;
+    {  // middle quad, packed
+      const f32x4 x0q = *reinterpret_cast<const f32x4*>(qb + qX + 4);
+      const f32x4 x1q = *reinterpret_cast<const f32x4*>(qb + qX + 32 * WGW_QSTR + 4);
+      const f32x4 y0q = *reinterpret_cast<const f32x4*>(qb + (4 * 32) * WGW_QSTR + 4);
+      const f32x4 y1q = *reinterpret_cast<const f32x4*>(qb + (5 * 32) * WGW_QSTR + 4);
+      o.a0 = wgw_fma4(y0q, sq2, x0q);
+      o.a1 = wgw_fma4(y1q, sq2, x1q);
+      o.u1 = wgw_add4(o.a0, o.a1);
+      o.u2 = wgw_sub4(o.a0, o.a1);
+      if (bias) bsum += (double)((o.u1[0] + o.u1[1]) + (o.u1[2] + o.u1[3]));   // wave 1: the four Q rows of this lane's own 4 x
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {  // window 3 and 8 (the x neighbours of the quad)
+      const int off = e == 0 ? 3 : 8;
+      const float x0s = qb[qX + off], x1s = qb[qX + 32 * WGW_QSTR + off];
+      const float y0s = qb[(4 * 32) * WGW_QSTR + off], y1s = qb[(5 * 32) * WGW_QSTR + off];
+      o.a0s[e] = fmaf(y0s, sq, x0s);
+      o.a1s[e] = fmaf(y1s, sq, x1s);
+      o.u1s[e] = o.a0s[e] + o.a1s[e];
+      o.u2s[e] = o.a0s[e] - o.a1s[e];
+    }
+  };
+  auto mfma48 = [&](const WgwOps& o) {
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int w = 5 + j - dx;   // window value paired with this lane's x quad element j
+        const float b0 = w == 3 ? o.a0s[0] : w == 8 ? o.a0s[1] : o.a0[(w - 4) & 3];
+        const float b1 = w == 3 ? o.u1s[0] : w == 8 ? o.u1s[1] : o.u1[(w - 4) & 3];
+        const float b2 = w == 3 ? o.u2s[0] : w == 8 ? o.u2s[1] : o.u2[(w - 4) & 3];
+        const float b3 = w == 3 ? o.a1s[0] : w == 8 ? o.a1s[1] : o.a1[(w - 4) & 3];   // true t3 = -a1
+        acc[dx][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.v[0][j], b0, acc[dx][0], 0, 0, 0);
+        acc[dx][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.v[1][j], b1, acc[dx][1], 0, 0, 0);
+        acc[dx][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.v[2][j], b2, acc[dx][2], 0, 0, 0);
+        acc[dx][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.v[3][j], b3, acc[dx][3], 0, 0, 0);
+      }
+  };
+  // one slot of the schedule per matrix instruction: the MFMA, then up to two vector-ALU operations and one memory operation
+  // of the work that shares the step (next step's operands, the staging quarter)
+#define WGW_SCHED_STEP()                                   \
+  _Pragma("unroll") for (int q_ = 0; q_ < 48; ++q_) {      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     \
+    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);     \
+    __builtin_amdgcn_sched_group_barrier(0x320, 1, 0);     \
+  }
+
   const int t0 = blockIdx.x * p.sub_per_wg;
   int t1 = t0 + p.sub_per_wg;
   if (t1 > p.nsub) t1 = p.nsub;
   if (t0 < t1) {
-    fetch(t0);
-    commit(lds);
+    fetch_begin();
+    fetch_quarter(IC<0>{}); fetch_quarter(IC<1>{}); fetch_quarter(IC<2>{}); fetch_quarter(IC<3>{});
+    commit_quarter(lds, IC<0>{}); commit_quarter(lds, IC<1>{}); commit_quarter(lds, IC<2>{}); commit_quarter(lds, IC<3>{});
   }
   __syncthreads();
+  WgwOps opA, opB;
   for (int t = t0; t < t1; ++t) {
     const float* cur = lds + ((t - t0) & 1) * WGW_BUF;
     float* nxt = lds + ((t - t0 + 1) & 1) * WGW_BUF;
     const bool more = (t + 1) < t1;
-    if (more) fetch(t + 1);
+    form(cur, IC<0>{}, opA);
+    if (more) fetch_begin();
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int py2 = 0; py2 < 2; ++py2)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int xq = 2 * s + hh;               // logical x quad of this lane
-        const int xo = 4 * xq;
-        const int pq = (xq ^ pswz) << 2;          // physical cell inside the 16-float row
-        // ---- V: z-combine of two rows, then the y transform ----
-        f32x4 c[4], v[4];
-#pragma unroll
-        for (int yr = 0; yr < 4; ++yr) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(cur + pA + (2 * py2 + yr) * 512 + pq);
-          const f32x4 b = *reinterpret_cast<const f32x4*>(cur + pB + (2 * py2 + yr) * 512 + pq);
-          c[yr] = wgw_fma4(b, sp2, a);
-        }
-        v[0] = wgw_sub4(c[0], c[2]);
-        v[1] = wgw_add4(c[1], c[2]);
-        v[2] = wgw_sub4(c[2], c[1]);
-        v[3] = wgw_sub4(c[1], c[3]);
-        // ---- T: window of 12 x values (entries xo .. xo+11 of the Q rows), z part then y part ----
-        f32x4 a0[3], a1[3], u1[3], u2[3];
-        const float* qb = cur + WGW_PTILE + ((2 * py2) * 32 + ch) * WGW_QSTR + xo;
-#pragma unroll
-        for (int w = 0; w < 3; ++w) {
-          const f32x4 q00 = *reinterpret_cast<const f32x4*>(qb + (0 * 32) * WGW_QSTR + 4 * w);   // (oz 0, oy 0)
-          const f32x4 q01 = *reinterpret_cast<const f32x4*>(qb + (1 * 32) * WGW_QSTR + 4 * w);   // (oz 0, oy 1)
-          const f32x4 q10 = *reinterpret_cast<const f32x4*>(qb + (4 * 32) * WGW_QSTR + 4 * w);   // (oz 1, oy 0)
-          const f32x4 q11 = *reinterpret_cast<const f32x4*>(qb + (5 * 32) * WGW_QSTR + 4 * w);   // (oz 1, oy 1)
-          if (wave == 0) { a0[w] = q00; a1[w] = q01; }
-          else if (wave == 3) { a0[w] = q10; a1[w] = q11; }
-          else { a0[w] = wgw_fma4(q10, sq2, q00); a1[w] = wgw_fma4(q11, sq2, q01); }
-          u1[w] = wgw_add4(a0[w], a1[w]);
-          u2[w] = wgw_sub4(a0[w], a1[w]);
-          if (w == 1 && bias) {   // wave 1: a0 + a1 of the middle quad = the four Q rows of this lane's own 4 x
-            const f32x4 sm = u1[1];
-            bsum += (double)((sm[0] + sm[1]) + (sm[2] + sm[3]));
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);   // the hand-written VALU must not sink between the matrix instructions:
-        asm volatile("s_nop 3" ::: "memory");  // the compiler does not track their write -> MFMA-read hazard
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int w = 5 + j - dx;
-            acc[dx][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[0][j], a0[w >> 2][w & 3], acc[dx][0], 0, 0, 0);
-            acc[dx][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[1][j], u1[w >> 2][w & 3], acc[dx][1], 0, 0, 0);
-            acc[dx][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[2][j], u2[w >> 2][w & 3], acc[dx][2], 0, 0, 0);
-            acc[dx][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[3][j], a1[w >> 2][w & 3], acc[dx][3], 0, 0, 0);   // true t3 = -a1
-          }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    if (more) commit(nxt);
+    asm volatile("s_nop 3" ::: "memory");   // hand-written VALU -> MFMA operand: the compiler does not track that hazard
+    // step 0: MFMA(opA) | form step 1 | fetch quarter 0
+    if (more) fetch_quarter(IC<0>{});
+    form(cur, IC<1>{}, opB);
+    mfma48(opA);
+    WGW_SCHED_STEP();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1" ::: "memory");
+    // step 1: MFMA(opB) | form step 2 | commit quarter 0, fetch quarter 1
+    if (more) { commit_quarter(nxt, IC<0>{}); fetch_quarter(IC<1>{}); }
+    form(cur, IC<2>{}, opA);
+    mfma48(opB);
+    WGW_SCHED_STEP();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1" ::: "memory");
+    // step 2: MFMA(opA) | form step 3 | commit quarter 1, fetch quarter 2
+    if (more) { commit_quarter(nxt, IC<1>{}); fetch_quarter(IC<2>{}); }
+    form(cur, IC<3>{}, opB);
+    mfma48(opA);
+    WGW_SCHED_STEP();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1" ::: "memory");
+    // step 3: MFMA(opB) | commit quarter 2, fetch quarter 3
+    if (more) { commit_quarter(nxt, IC<2>{}); fetch_quarter(IC<3>{}); }
+    mfma48(opB);
+    WGW_SCHED_STEP();
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) commit_quarter(nxt, IC<3>{});
     __syncthreads();
   }
 
@@ -1179,7 +1255,7 @@ extern "C" int bts_conv3d_bwd_weight(int kind, const float* x, const float* dy, 
   bool use_wgw = false;
   if (kidx == 2 && ro.ntaps == 27 && ro.s == 1) {
     const char* e = getenv("BTS_WGW");
-    use_wgw = !(e && atoi(e) == 0);
+    use_wgw = !(e && atoi(e) == 0) && 5.0 * p.Hp * p.Wp * p.ldp * 4.0 < 2.0e9 && 3.0 * p.Hq * p.Wq * p.ldq * 4.0 < 2.0e9;  // 31-bit tile offsets
   }
   if (use_wgw) {
     static bool wattr = false;
