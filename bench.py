@@ -193,7 +193,7 @@ def main():
             'algorithmic_gflop_per_launch': fl / nl / 1e9,
             'time_share_of_step': tsec / dt,
         }
-        if sym == 'wino_kernel':
+        if sym in ('wino_kernel', 'wgw_kernel'):
             # the Winograd form issues 12 matrix instructions where the direct form needs 27: `achieved` follows the
             # contract (ALGORITHMIC direct-conv FLOPs / time) and can exceed the pipe's peak; the rate the matrix pipe
             # really executes, and its fraction of the peak, are reported next to it
