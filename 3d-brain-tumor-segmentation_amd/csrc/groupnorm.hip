@@ -8,6 +8,7 @@
 // (short fp32 runs per lane, fp64 across lanes/blocks) and combined in a fixed order, so results are
 // reproducible run to run; no float atomics.
 // x is always a dense NDHWC tensor (ld == C: the raw conv output); y / dy may be channel slices (ld >= C).
+#include <stdlib.h>
 #include "common.h"
 #include "bts_internal.h"
 
@@ -314,6 +315,59 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   }
 }
 
+// Slab mode, dense rows (ld == C), L % 1024 == 0: a block owns `cpb` consecutive 1024-element chunks of ONE (n, group) unit, so
+// the statistics are block constants and a thread's channel phase (4*tid mod C, 1024 % C == 0) and affine parameters never
+// change: the loop is loads, four fused multiply-adds and a store -- no index arithmetic, two chunks in flight.
+__global__ __launch_bounds__(256) void gn_apply_slab_stream_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                   long chunks_per_unit, int cpb, int C, int cg, int G, int relu) {
+  const long chunk0 = (long)blockIdx.x * cpb;
+  const long unit = chunk0 / chunks_per_unit;          // n*G + g
+  const int g = (int)(unit % G);
+  const float m = mean[unit], rs = rstd[unit];
+  const int c = (threadIdx.x * 4) % C;
+  float sc[4], sh[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = g * cg + ((c + e) % cg);
+    sc[e] = rs * gamma[idx];
+    sh[e] = beta[idx] - m * sc[e];
+  }
+  const float* xp = x + chunk0 * 1024 + threadIdx.x * 4;
+  float* yp = y + chunk0 * 1024 + threadIdx.x * 4;
+  int k = 0;
+  for (; k + 1 < cpb; k += 2) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(xp + (long)k * 1024);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(xp + (long)(k + 1) * 1024);
+    f32x4 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o0[e] = fmaf(v0[e], sc[e], sh[e]);
+      o1[e] = fmaf(v1[e], sc[e], sh[e]);
+      if (relu) { o0[e] = fmaxf(o0[e], 0.f); o1[e] = fmaxf(o1[e], 0.f); }
+    }
+    *reinterpret_cast<f32x4*>(yp + (long)k * 1024) = o0;
+    *reinterpret_cast<f32x4*>(yp + (long)(k + 1) * 1024) = o1;
+  }
+  for (; k < cpb; ++k) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(xp + (long)k * 1024);
+    f32x4 o0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o0[e] = fmaf(v0[e], sc[e], sh[e]);
+      if (relu) o0[e] = fmaxf(o0[e], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(yp + (long)k * 1024) = o0;
+  }
+}
+// chunks per block for the streaming kernels: the largest power of two <= 8 dividing the chunks of a unit
+static int gn_stream_cpb(long chunks_per_unit) {
+  int cpb = 8;
+  while (cpb > 1 && chunks_per_unit % cpb != 0) cpb >>= 1;
+  return cpb;
+}
+
 extern "C" int bts_gn_apply(const float* x, float* y, const float* gamma, const float* beta, const float* mean,
                             const float* rstd, int N, long V, int C, int ldy, int G, int mode, int relu,
                             hipStream_t stream) {
@@ -331,6 +385,19 @@ extern "C" int bts_gn_apply(const float* x, float* y, const float* gamma, const 
     return BTS_OK;
   }
   if (ldy < C || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 15)) return BTS_ERR_ALIGN;
+  if (mode == BTS_GN_SLAB && ldy == C && g.L % 1024 == 0 && 1024 % C == 0 && getenv("BTS_GN_NOSTREAM") == nullptr) {
+    // NOTE: slab-mode results differ from gn_apply_kernel in the last bit ((x - m) * rs * gamma + beta is evaluated as
+    // fma(x, rs*gamma, beta - m*rs*gamma)); both are within the element-wise tolerance of the oracle
+    const long cpu = g.L / 1024;
+    const int cpb = gn_stream_cpb(cpu);
+    const long nblk = (long)N * G * cpu / cpb;
+    if (nblk <= 0x7fffffffL) {
+      (void)hipGetLastError(); hipLaunchKernelGGL(gn_apply_slab_stream_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, x, y, gamma, beta, mean,
+                         rstd, cpu, cpb, C, g.cg, G, relu);
+      BTS_LAUNCH_CHECK();
+      return BTS_OK;
+    }
+  }
   const long total4 = (long)N * g.E / 4;
   int blocks = (int)((total4 + 255) / 256);
   if (blocks > 8192) blocks = 8192;
@@ -373,11 +440,12 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
     gam[e] = gamma[idx];
     bet[e] = beta[idx];
   }
+  const float m_s = mean[n * G + gs], rs_s = rstd[n * G + gs];  // slab mode: the unit's statistics (block constants)
   auto body = [&](const f32x4 v, const f32x4 d, int c) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int g = slab ? gs : (c + e) / cg;
-      const float xh = (v[e] - mean[n * G + g]) * rstd[n * G + g];
+      const float xh = slab ? (v[e] - m_s) * rs_s : (v[e] - mean[n * G + g]) * rstd[n * G + g];
       float de = d[e];
       if (relu && !(xh * gam[e] + bet[e] > 0.f)) de = 0.f;
       a[e] += (double)(de * xh);
@@ -385,6 +453,23 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
     }
   };
   long i = lo + threadIdx.x * 4;
+  if (lddy == C) {  // dense dy: it is indexed like x, no division in the loop
+    const float* xb = x + (long)n * E + unitBase;
+    const float* db = dy + (long)n * E + unitBase;
+    for (; i + 1024 < hi; i += 2048) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(xb + i);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(xb + i + 1024);
+      const f32x4 d0 = *reinterpret_cast<const f32x4*>(db + i);
+      const f32x4 d1 = *reinterpret_cast<const f32x4*>(db + i + 1024);
+      body(v0, d0, cph);
+      body(v1, d1, cph);
+    }
+    for (; i < hi; i += 1024) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xb + i);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(db + i);
+      body(v, d, cph);
+    }
+  }
   for (; i + 1024 < hi; i += 2048) {  // two independent 16-B loads per stream in flight
     const long r0 = unitBase + i, r1 = r0 + 1024;
     const int c0 = (int)(r0 % C), c1 = (int)(r1 % C);
@@ -509,6 +594,54 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// streaming form of gn_bwd_apply_kernel for slab mode with dense dy (see gn_apply_slab_stream_kernel); same arithmetic, element
+// for element, as the general kernel
+__global__ __launch_bounds__(256) void gn_bwd_apply_slab_stream_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                       float* __restrict__ dx, const float* __restrict__ gamma,
+                                                                       const float* __restrict__ beta, const float* __restrict__ mean,
+                                                                       const float* __restrict__ rstd, const float* __restrict__ c1,
+                                                                       const float* __restrict__ c2, long chunks_per_unit, int cpb,
+                                                                       int C, int cg, int G, int relu) {
+  const long chunk0 = (long)blockIdx.x * cpb;
+  const long unit = chunk0 / chunks_per_unit;
+  const int g = (int)(unit % G);
+  const float m = mean[unit], rs = rstd[unit], k1 = c1[unit], k2 = c2[unit];
+  const int c = (threadIdx.x * 4) % C;
+  float ga[4], be[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = g * cg + ((c + e) % cg);
+    ga[e] = gamma[idx];
+    be[e] = beta[idx];
+  }
+  const long off = chunk0 * 1024 + threadIdx.x * 4;
+  auto one = [&](const f32x4 v, const f32x4 d) {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (v[e] - m) * rs;
+      float de = d[e];
+      if (relu && !(xh * ga[e] + be[e] > 0.f)) de = 0.f;
+      o[e] = (de * ga[e] - k1 - xh * k2) * rs;
+    }
+    return o;
+  };
+  int k = 0;
+  for (; k + 1 < cpb; k += 2) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + off + (long)k * 1024);
+    const f32x4 d0 = *reinterpret_cast<const f32x4*>(dy + off + (long)k * 1024);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(x + off + (long)(k + 1) * 1024);
+    const f32x4 d1 = *reinterpret_cast<const f32x4*>(dy + off + (long)(k + 1) * 1024);
+    *reinterpret_cast<f32x4*>(dx + off + (long)k * 1024) = one(v0, d0);
+    *reinterpret_cast<f32x4*>(dx + off + (long)(k + 1) * 1024) = one(v1, d1);
+  }
+  for (; k < cpb; ++k) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + off + (long)k * 1024);
+    const f32x4 d0 = *reinterpret_cast<const f32x4*>(dy + off + (long)k * 1024);
+    *reinterpret_cast<f32x4*>(dx + off + (long)k * 1024) = one(v0, d0);
+  }
+}
+
 // gn backward: dx dense (ld == C). small_ws: >= (N*G*2 floats + N*C*2 doubles) scratch inside workspace tail.
 extern "C" int bts_gn_bwd(const float* x, const float* dy, float* dx, const float* gamma, const float* beta,
                           const float* mean, const float* rstd, float* dgamma, float* dbeta, void* workspace,
@@ -553,6 +686,17 @@ extern "C" int bts_gn_bwd(const float* x, const float* dy, float* dx, const floa
   (void)hipGetLastError(); hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), 0, stream, gamma, dgamma, dbeta, c1, c2, scratch, N, C, G,
                      (double)g.L, accumulate_params);
   BTS_LAUNCH_CHECK();
+  if (slab && lddy == C && g.L % 1024 == 0 && 1024 % C == 0 && getenv("BTS_GN_NOSTREAM") == nullptr) {
+    const long cpu = g.L / 1024;
+    const int cpb = gn_stream_cpb(cpu);
+    const long nblk = (long)N * G * cpu / cpb;
+    if (nblk <= 0x7fffffffL) {
+      (void)hipGetLastError(); hipLaunchKernelGGL(gn_bwd_apply_slab_stream_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, x, dy, dx, gamma, beta,
+                         mean, rstd, c1, c2, cpu, cpb, C, g.cg, G, relu);
+      BTS_LAUNCH_CHECK();
+      return BTS_OK;
+    }
+  }
   const long total4 = (long)N * g.E / 4;
   int blocks = (int)((total4 + 255) / 256);
   if (blocks > 8192) blocks = 8192;
