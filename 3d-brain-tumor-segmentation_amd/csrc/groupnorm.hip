@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void gn_apply_slab_stream_kernel(const float* 
   for (int e = 0; e < 4; ++e) {
     const int idx = g * cg + ((c + e) % cg);
     sc[e] = rs * gamma[idx];
-    sh[e] = beta[idx] - m * sc[e];
+    sh[e] = beta[idx];
   }
   const float* xp = x + chunk0 * 1024 + threadIdx.x * 4;
   float* yp = y + chunk0 * 1024 + threadIdx.x * 4;
@@ -343,8 +343,8 @@ __global__ __launch_bounds__(256) void gn_apply_slab_stream_kernel(const float* 
     f32x4 o0, o1;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      o0[e] = fmaf(v0[e], sc[e], sh[e]);
-      o1[e] = fmaf(v1[e], sc[e], sh[e]);
+      o0[e] = fmaf(v0[e] - m, sc[e], sh[e]);   // centred first: no cancellation when |mean| >> std
+      o1[e] = fmaf(v1[e] - m, sc[e], sh[e]);
       if (relu) { o0[e] = fmaxf(o0[e], 0.f); o1[e] = fmaxf(o1[e], 0.f); }
     }
     *reinterpret_cast<f32x4*>(yp + (long)k * 1024) = o0;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void gn_apply_slab_stream_kernel(const float* 
     f32x4 o0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      o0[e] = fmaf(v0[e], sc[e], sh[e]);
+      o0[e] = fmaf(v0[e] - m, sc[e], sh[e]);
       if (relu) o0[e] = fmaxf(o0[e], 0.f);
     }
     *reinterpret_cast<f32x4*>(yp + (long)k * 1024) = o0;
@@ -386,8 +386,8 @@ extern "C" int bts_gn_apply(const float* x, float* y, const float* gamma, const 
   }
   if (ldy < C || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 15)) return BTS_ERR_ALIGN;
   if (mode == BTS_GN_SLAB && ldy == C && g.L % 1024 == 0 && 1024 % C == 0 && getenv("BTS_GN_NOSTREAM") == nullptr) {
-    // NOTE: slab-mode results differ from gn_apply_kernel in the last bit ((x - m) * rs * gamma + beta is evaluated as
-    // fma(x, rs*gamma, beta - m*rs*gamma)); both are within the element-wise tolerance of the oracle
+    // NOTE: results differ from gn_apply_kernel in the last bit ((x - m) * rs * gamma + beta is evaluated as
+    // fma(x - m, rs*gamma, beta)); both are within the element-wise tolerance of the oracle
     const long cpu = g.L / 1024;
     const int cpb = gn_stream_cpb(cpu);
     const long nblk = (long)N * G * cpu / cpb;
