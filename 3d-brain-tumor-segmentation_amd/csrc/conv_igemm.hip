@@ -1219,6 +1219,169 @@ static int launch_dsc(const float* x, const float* wp, const float* bias, float*
 }
 
 // ---------------------------------------------------------------------------------------------
+// 3x3x3 stride-1 conv of a TWO-channel input (the network's first convolutions, model.py / resnet.py:30-37 on the 2ch x 128^3
+// volume) into <= 32 output channels.  The tiled kernel pads the 2 channels to a k-group of 8 and runs at a quarter of the
+// useful rate; here the contraction index of the MFMA (K = 2) IS the channel pair: one matrix instruction per tap, its B
+// operand a single ds_read_b32 of the planar LDS halo tile [channel][z][y][x] (lane = (channel, x)), its A operand the
+// tap's 2 x 32 weights held in a register for the whole workgroup.  A wave owns one z plane of the 32 x 4 x 4 tile: the
+// 18 input fragments of a kz slab feed the 36 matrix instructions of its four output rows.  Optional second output
+// (the 1x1x1 shortcut conv of the same input: one more instruction on the centre fragment), bias, GroupNorm partials.
+// ---------------------------------------------------------------------------------------------
+struct C2Params {
+  const float* x;
+  const float* wp;    // K3S1 forward image (KG = 1): W[t][c][n] = wp[(t*2*Npad + n)*4 + c]
+  const float* bias;
+  float* y;
+  const float* wp2;   // K1 forward image of the shortcut (or null): W2[c][n] = wp2[n*4 + c]
+  const float* bias2;
+  float* y2;
+  int N, D, H, W, ldx, Cout, ldy, ldy2, Npad;
+  int ntz, nty, ntx;
+  double* gnp;
+  int gn_G, gn_zt;
+};
+
+template <bool F2>
+__global__ __launch_bounds__(256, 2) void c2_kernel(const C2Params p) {
+  __shared__ float lds[2 * 6 * 6 * 34 + 16];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l32 = lane & 31;
+  int b = blockIdx.x;
+  const int tx = b % p.ntx; b /= p.ntx;
+  const int ty = b % p.nty; b /= p.nty;
+  const int tz = b % p.ntz;
+  const int n = b / p.ntz;
+  const int oz0 = tz * 4, oy0 = ty * 4, ox0 = tx * 32;
+  // ---- halo tile (34 x 6 x 6 voxels x 2 channels) -> planar LDS ----
+  for (int e = tid; e < 6 * 6 * 34; e += 256) {
+    const int vz = e / (6 * 34), r = e - vz * (6 * 34);
+    const int vy = r / 34, vx = r - vy * 34;
+    const int z = oz0 - 1 + vz, yy = oy0 - 1 + vy, xx = ox0 - 1 + vx;
+    float v0 = 0.f, v1 = 0.f;
+    if ((unsigned)z < (unsigned)p.D && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
+      const float* s = p.x + ((((long)n * p.D + z) * p.H + yy) * p.W + xx) * (long)p.ldx;
+      v0 = s[0]; v1 = s[1];
+    }
+    lds[e] = v0;
+    lds[6 * 6 * 34 + e] = v1;
+  }
+  // ---- weights: lane (channel h, cout l32) ----
+  float wt[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) wt[t] = p.wp[((long)t * 2 * p.Npad + l32) * 4 + h];
+  float w2 = 0.f;
+  if (F2) w2 = p.wp2[l32 * 4 + h];
+  __syncthreads();
+  f32x16 acc[4], acc2[F2 ? 4 : 1];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; if (F2) acc2[F2 ? i : 0][r] = 0.f; }
+  const float* lb = lds + h * (6 * 6 * 34) + (wave * 6) * 34 + l32;   // (channel h, z = wave + kz, y, x = l32 + kx)
+#pragma unroll
+  for (int kz = 0; kz < 3; ++kz) {
+    float f[6][3];
+#pragma unroll
+    for (int yr = 0; yr < 6; ++yr)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) f[yr][kx] = lb[(kz * 6 + yr) * 34 + kx];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int oy = 0; oy < 4; ++oy)
+          acc[oy] = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[(kz * 3 + ky) * 3 + kx], f[oy + ky][kx], acc[oy], 0, 0, 0);
+    if (F2 && kz == 1) {
+#pragma unroll
+      for (int oy = 0; oy < 4; ++oy) acc2[F2 ? oy : 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2, f[oy + 1][1], acc2[F2 ? oy : 0], 0, 0, 0);
+    }
+  }
+  // ---- epilogue: D rows = couts (4 per register quad), cols = x ----
+  const int oz = oz0 + wave, ox = ox0 + l32;
+  float gn_s = 0.f, gn_q = 0.f;
+  if (oz < p.D && ox < p.W) {
+#pragma unroll
+    for (int oy = 0; oy < 4; ++oy) {
+      const int y = oy0 + oy;
+      if (y >= p.H) continue;
+      const long pix = (((long)n * p.D + oz) * p.H + y) * p.W + ox;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = 8 * g + 4 * h;
+        if (co >= p.Cout) continue;
+        f32x4 v = {acc[oy][4 * g], acc[oy][4 * g + 1], acc[oy][4 * g + 2], acc[oy][4 * g + 3]};
+        if (p.bias) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += p.bias[co + j];
+        }
+        if (p.gnp) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { gn_s += v[j]; gn_q = fmaf(v[j], v[j], gn_q); }
+        }
+        *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + co) = v;
+        if (F2) {
+          f32x4 v2 = {acc2[F2 ? oy : 0][4 * g], acc2[F2 ? oy : 0][4 * g + 1], acc2[F2 ? oy : 0][4 * g + 2], acc2[F2 ? oy : 0][4 * g + 3]};
+          if (p.bias2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v2[j] += p.bias2[co + j];
+          }
+          *reinterpret_cast<f32x4*>(p.y2 + pix * p.ldy2 + co) = v2;
+        }
+      }
+    }
+  }
+  if (p.gnp) {  // fixed-order combine, layout as igemm_kernel's
+    const double ds = wave_sum_f64((double)gn_s), dq = wave_sum_f64((double)gn_q);
+    __syncthreads();
+    double* sh = reinterpret_cast<double*>(lds);
+    if (lane == 0) { sh[wave * 2] = ds; sh[wave * 2 + 1] = dq; }
+    __syncthreads();
+    if (tid == 0) {
+      const int g = tz / p.gn_zt;
+      const long B = (long)p.gn_zt * p.nty * p.ntx;
+      const long b_ = ((long)(tz - g * p.gn_zt) * p.nty + ty) * p.ntx + tx;
+      double* o = p.gnp + (((long)n * p.gn_G + g) * B + b_) * 2;
+      o[0] = sh[0] + sh[2] + sh[4] + sh[6];
+      o[1] = sh[1] + sh[3] + sh[5] + sh[7];
+    }
+  }
+}
+
+// returns BTS_OK when taken, 1 when the shape is left to the tiled kernel
+static int launch_c2(const float* x, const float* wp, const float* bias, float* y, int N, int D, int H, int W, int Cin, int ldx,
+                     int Cout, int ldy, int flags, const float* wp2, const float* bias2, float* y2, int ldy2, double* gnp, int gnG,
+                     long* gn_B, hipStream_t stream) {
+  if (getenv("BTS_IGEMM_NOC2") != nullptr) return 1;
+  if (Cin != 2 || Cout > 32 || Cout % 4 != 0 || ldy % 4 != 0 || (((uintptr_t)y) & 15)) return 1;
+  if (flags & (IG_FLAG_ACCUM | IG_FLAG_SIGMOID)) return 1;
+  if (y2 != nullptr && (ldy2 % 4 != 0 || (((uintptr_t)y2) & 15))) return 1;
+  C2Params p;
+  p.x = x; p.wp = wp; p.bias = (flags & IG_FLAG_BIAS) ? bias : nullptr; p.y = y;
+  p.wp2 = wp2; p.bias2 = bias2; p.y2 = y2;
+  p.N = N; p.D = D; p.H = H; p.W = W; p.ldx = ldx; p.Cout = Cout; p.ldy = ldy; p.ldy2 = ldy2; p.Npad = npad32(Cout);
+  p.ntz = (D + 3) / 4; p.nty = (H + 3) / 4; p.ntx = (W + 31) / 32;
+  const long tiles = (long)N * p.ntz * p.nty * p.ntx;
+  const long min_tiles = getenv("BTS_IGEMM_C2_MIN") ? atol(getenv("BTS_IGEMM_C2_MIN")) : 512;  // (tests force 1)
+  if (tiles < min_tiles || tiles > 0x7fffffffL) return 1;
+  p.gnp = nullptr; p.gn_G = 0; p.gn_zt = 1;
+  if (gnp != nullptr && gnG > 0 && D % gnG == 0 && (D / gnG) % 4 == 0 && getenv("BTS_IGEMM_NOGNFUSE") == nullptr) {
+    p.gnp = gnp; p.gn_G = gnG; p.gn_zt = (D / gnG) / 4;
+  }
+  const bool prof = bts_prof_on();
+  if (prof) bts_prof_begin(25, 2.0 * (27.0 + (y2 ? 1.0 : 0.0)) * Cin * (double)Cout * (double)N * D * H * W, stream);
+  (void)hipGetLastError();
+  if (y2 != nullptr) hipLaunchKernelGGL(c2_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(c2_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, stream, p);
+  if (prof) bts_prof_end(stream);
+  BTS_LAUNCH_CHECK();
+  if (gn_B && p.gnp != nullptr) *gn_B = (long)p.gn_zt * p.nty * p.ntx;
+  return BTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Launch logic
 // ---------------------------------------------------------------------------------------------
 enum Geo { GEO_K1 = 0, GEO_S1 = 1, GEO_DOWN = 2, GEO_UP = 3 };
@@ -1328,6 +1491,10 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
   if (gn_B) *gn_B = 0;  // stays 0 unless the tiled kernel took the launch and emitted the GroupNorm partials
   if (geo == GEO_S1 && wp2 == nullptr && need_out == nullptr && Cout <= 4) {
     const int r = launch_dsc(x, wp, bias, y, N, Di, Hi, Wi, Cin, ldx, Cout, ldy, flags, stream);
+    if (r != 1) return r;
+  }
+  if (geo == GEO_S1 && need_out == nullptr && Cin == 2 && x2 == nullptr && (wp2 == nullptr) == (y2 == nullptr)) {
+    const int r = launch_c2(x, wp, bias, y, N, Di, Hi, Wi, Cin, ldx, Cout, ldy, flags, wp2, bias2, y2, ldy2, gnp, gnG, gn_B, stream);
     if (r != 1) return r;
   }
   if (geo == GEO_S1 && need_out == nullptr && !(flags & IG_FLAG_SIGMOID)) {

@@ -554,3 +554,39 @@ def test_maxpool_and_nearest_upsample(n, dims, c, pad):
     uref.backward(du.double().permute(0, 4, 1, 2, 3))
     dx = ops.upsample2_bwd(du.to(dev()))
     assert torch.allclose(dx.cpu().double(), xr.grad.permute(0, 2, 3, 4, 1), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('n,dims,cout', [(1, (8, 8, 32), 32), (2, (5, 6, 40), 16), (1, (16, 8, 64), 32)])
+def test_conv_two_channel_input(monkeypatch, n, dims, cout):
+    """c2_kernel: the network's first convolutions (2 input channels) with the channel pair as the MFMA's K -- plain, with the
+    fused 1x1x1 shortcut output, and with GroupNorm statistics from the epilogue; all through the usual entry points"""
+    from bts_amd import ops
+    monkeypatch.setenv('BTS_IGEMM_C2_MIN', '1')
+    d, h, w = dims
+    x = rnd((n, d, h, w, 2), 91)
+    w3, b3 = rnd((3, 3, 3, 2, cout), 92, 0.3), rnd((cout,), 93)
+    w1, b1 = rnd((1, 1, 1, 2, cout), 94, 0.3), rnd((cout,), 95)
+    r3 = R.conv3d(x.double(), w3.double(), b3.double())
+    r1 = R.conv3d(x.double(), w1.double(), b1.double())
+    b3d = R.conv3d(x.double().abs(), w3.double().abs(), b3.double().abs())
+    b1d = R.conv3d(x.double().abs(), w1.double().abs(), b1.double().abs())
+    xg = x.to(dev())
+    wp3 = ops.conv_pack(ops.K3S1, ops.ROLE_FWD, w3.to(dev()), 2, cout)
+    wp1 = ops.conv_pack(ops.K1, ops.ROLE_FWD, w1.to(dev()), 2, cout)
+    ops.profile_enable(True)
+    y = ops.conv_fwd(ops.K3S1, xg, wp3, b3.to(dev()), cout)
+    pair = ops.conv_fwd_fused2(xg, wp3, b3.to(dev()), wp1, b1.to(dev()), cout)
+    g = 4 if d % 16 == 0 else 2 if d % 8 == 0 else 1
+    yg, mean, rstd = ops.conv_fwd_gn(ops.K3S1, xg, wp3, b3.to(dev()), cout, g, 1e-5)
+    torch.cuda.synchronize()
+    names = [r[0] for r in ops.profile_records()]
+    ops.profile_enable(False)
+    assert names.count('c2_kernel') >= 2, names
+    check_contraction(y, r3, b3d, 'c2 conv')
+    check_contraction(yg, r3, b3d, 'c2 conv + gn')
+    if pair is not None:
+        check_contraction(pair[0], r3, b3d, 'c2 fused conv3')
+        check_contraction(pair[1], r1, b1d, 'c2 fused conv1')
+    flat = r3.reshape(n, g, -1)
+    check_close(mean, flat.mean(dim=2).reshape(-1), 'c2 GN mean', rtol=2e-5, atol=2e-5)
+    check_close(rstd, (1.0 / torch.sqrt(flat.var(dim=2, unbiased=False) + 1e-5)).reshape(-1), 'c2 GN rstd', rtol=2e-5, atol=2e-5)
