@@ -26,6 +26,8 @@
 //   upm_kernel  -- UP form with all 8 output-parity classes per workgroup (Conv3DTranspose forward, stride-2 data gradient)
 //   k1s_kernel  -- LDS-free streaming 1x1x1 conv for big grids
 //   dsc_kernel  -- vector-ALU direct 3x3x3 conv for <= 4 output channels
+//   c2_kernel   -- 3x3x3 conv of a 2-channel input (the MFMA's K = 2 is the channel pair)
+// The K3S1 weight image carries a second, Winograd-domain part; stride-1 3x3x3 launches are offered to conv_wino.hip first.
 // and the fused entry points: shortcut pair (FUSE2), GroupNorm statistics in the epilogue, data-gradient pair (second input).
 #include <stdlib.h>
 #include "common.h"
