@@ -113,3 +113,32 @@ def test_wgw_is_deterministic_and_declines_ragged_shapes():
         xs, ds = rnd(shp + (cin,), 13).to(dev()), rnd(shp + (cout,), 14).to(dev())
         dw = torch.empty((3, 3, 3, cin, cout), device=dev())
         assert 'wgw_kernel' not in kernels_of(lambda: ops.conv_bwd_weight(ops.K3S1, xs, ds, dw, None))
+
+
+def test_wgw_full_size_agrees_with_direct_form():
+    """BASELINE size (32 -> 32 channels on 128^3): too big for the fp64 oracle, so the Winograd weight gradient is held against
+    the engine's own direct kernel (oracle-checked at small sizes) within the sum of both bounds; the bound sum|a_i b_i| is
+    the direct kernel's result on |x|, |dy|.  Plus linearity in dy."""
+    from bts_amd import ops
+    x = rnd((1, 128, 128, 128, 32), 31).to(dev())
+    dy = rnd((1, 128, 128, 128, 32), 32).to(dev())
+    dy2 = rnd((1, 128, 128, 128, 32), 33).to(dev())
+    shape = (3, 3, 3, 32, 32)
+    dw, dwb, dws = (torch.empty(shape, device=dev()) for _ in range(3))
+    db = torch.empty((32,), device=dev())
+    names = kernels_of(lambda: (ops.conv_bwd_weight(ops.K3S1, x, dy, dw, db), ops.conv_bwd_weight(ops.K3S1, x, dy2, dwb, None),
+                                ops.conv_bwd_weight(ops.K3S1, x, dy + dy2, dws, None)))
+    assert names.count('wgw_kernel') == 3, names
+    os.environ['BTS_WGW'] = '0'
+    try:
+        dw0, bound, bound2 = (torch.empty(shape, device=dev()) for _ in range(3))
+        ops.conv_bwd_weight(ops.K3S1, x, dy, dw0, None)
+        ops.conv_bwd_weight(ops.K3S1, x.abs(), dy.abs(), bound, None)
+        ops.conv_bwd_weight(ops.K3S1, x.abs(), dy2.abs(), bound2, None)
+    finally:
+        del os.environ['BTS_WGW']
+    err = (dw - dw0).abs()
+    assert not bool((err > 16 * EPS32 * bound + 1e-6).any()), 'max err %.3e' % float(err.max())
+    lin = (dws - (dw + dwb)).abs()
+    assert not bool((lin > 32 * EPS32 * (bound + bound2) + 1e-5).any()), 'linearity: max err %.3e' % float(lin.max())
+    check(db, dy.double().cpu().sum(dim=(0, 1, 2, 3)), dy.double().cpu().abs().sum(dim=(0, 1, 2, 3)), 'full-size bias gradient')
