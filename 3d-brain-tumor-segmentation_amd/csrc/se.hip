@@ -212,13 +212,9 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float* __restr
   long v1 = v0 + vspan;
   if (v1 > V) v1 = V;
   double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
-  for (long vv = v0 + vl; vv < v1; vv += vpb) {
-    const long v = n * V + vv;
-    const f32x4 r = *reinterpret_cast<const f32x4*>(res + v * F + c);
-    const f32x4 d = *reinterpret_cast<const f32x4*>(dout + v * lddo + c);
+  auto one = [&](long v, const f32x4 r, const f32x4 d, float s) {
     float t = (d[0] * r[0] + d[1] * r[1]) + (d[2] * r[2] + d[3] * r[3]);
     for (int o = F4 >> 1; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-    const float s = sp[v];
     const float ds = t * s * (1.f - s);
     if (lg == 0) ds_out[v] = ds;
 #pragma unroll
@@ -226,6 +222,26 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float* __restr
       a[e] += (double)(d[e] * r[e]);
       b[e] += (double)(ds * r[e]);
     }
+  };
+  long vv = v0 + vl;
+  for (; vv + 3L * vpb < v1; vv += 4L * vpb) {  // four voxels per thread in flight: the shuffle chain of one hides the loads of the next
+    f32x4 r[4], d[4];
+    float s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long v = n * V + vv + (long)u * vpb;
+      r[u] = *reinterpret_cast<const f32x4*>(res + v * F + c);
+      d[u] = *reinterpret_cast<const f32x4*>(dout + v * lddo + c);
+      s[u] = sp[v];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(n * V + vv + (long)u * vpb, r[u], d[u], s[u]);
+  }
+  for (; vv < v1; vv += vpb) {
+    const long v = n * V + vv;
+    const f32x4 r = *reinterpret_cast<const f32x4*>(res + v * F + c);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dout + v * lddo + c);
+    one(v, r, d, sp[v]);
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) { sh[threadIdx.x * 8 + e] = a[e]; sh[threadIdx.x * 8 + 4 + e] = b[e]; }
