@@ -29,7 +29,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     const int c = (cb + tx) * 4;
     double s[4] = {0, 0, 0, 0};
     if (ty < TR && c < C) {
-      for (long r = r0 + ty; r < r1; r += TR) {
+      long r = r0 + ty;
+      if (vec) {  // four rows in flight; the sums are still taken in row order
+        for (; r + 3L * TR < r1; r += 4L * TR) {
+          f32x4 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(base + (r + (long)u * TR) * ld + c);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { s[0] += v[u][0]; s[1] += v[u][1]; s[2] += v[u][2]; s[3] += v[u][3]; }
+        }
+      }
+      for (; r < r1; r += TR) {
         const float* src = base + r * ld + c;
         if (vec) {
           const f32x4 v = *reinterpret_cast<const f32x4*>(src);
