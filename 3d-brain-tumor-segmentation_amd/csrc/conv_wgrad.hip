@@ -1167,6 +1167,82 @@ __global__ __launch_bounds__(WGW_THREADS, 1) void wgw_kernel(const WgradParams p
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the 1x1x1 convs (the ResNet blocks' shortcut convs, resnet.py:96-103, and the decoder / VAE projections):
+// dW[c][k] = sum_v P[v][c] * Q[v][k] -- a 32x32 tile per (P, Q) channel-group pair with K = all voxels: 2 FLOP per loaded
+// byte, HBM-bound.  The staged kernel (LDS DMA, a barrier per 256-voxel sub-tile, 8 matrix instructions between barriers) ran
+// these at ~2 TB/s.  Here nothing is staged: the MFMA operand layout (lane = channel, register = voxel of the K pair) is
+// exactly a coalesced 128-byte row read, so each lane streams its channel of consecutive voxels with 16 independent 4-byte
+// loads in flight and feeds them to the matrix pipe directly; 8 waves per workgroup split the workgroup's voxel range and
+// are summed in LDS in fixed order.  Bias partials (column sums of Q) fall out of the B operands.
+// ---------------------------------------------------------------------------------------------------------------------
+#define K1W_THREADS 512
+#define K1W_U 8
+__global__ __launch_bounds__(K1W_THREADS, 2) void k1w_kernel(const WgradParams p, long NV, long chunk) {
+  __shared__ float lds[8 * 1024];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ch = lane & 31, hh = lane >> 5;
+  const int pct = blockIdx.y, qct = blockIdx.z;
+  const int pc = pct * 32 + ch, qc = qct * 32 + ch;
+  const bool pok = pc < p.Cp, qok = qc < p.Cq;
+  const long w0 = (long)blockIdx.x * chunk;
+  long w1 = w0 + chunk;
+  if (w1 > NV) w1 = NV;
+  // this wave's part of the workgroup range, whole K pairs
+  long per = ((w1 - w0 + 7) / 8 + 1) & ~1L;
+  long v = w0 + wave * per;
+  long ve = v + per;
+  if (ve > w1) ve = w1;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  double bsum = 0.0;
+  const bool bias = p.want_bias && pct == 0;
+  const float* pp = p.p + pc;
+  const float* qq = p.q + qc;
+  for (; v < ve; v += 2 * K1W_U) {
+    float a[K1W_U], b[K1W_U];
+#pragma unroll
+    for (int u = 0; u < K1W_U; ++u) {
+      const long vv = v + 2 * u + hh;
+      const bool in = vv < ve;
+      a[u] = (in && pok) ? pp[vv * p.ldp] : 0.f;
+      b[u] = (in && qok) ? qq[vv * p.ldq] : 0.f;
+    }
+    float bs = 0.f;
+#pragma unroll
+    for (int u = 0; u < K1W_U; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+      bs += b[u];
+    }
+    if (bias) bsum += (double)bs;
+  }
+  // fixed-order sum of the 8 waves' tiles
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lds[wave * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + ch] = acc[r];
+  __syncthreads();
+  float* dst = p.partial + ((((long)blockIdx.x * gridDim.y + pct) * gridDim.z + qct) * p.ntiles) * 1024;
+  for (int e = tid; e < 1024; e += K1W_THREADS) {
+    float sacc = lds[e];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) sacc += lds[w * 1024 + e];
+    dst[e] = sacc;
+  }
+  if (bias) {
+    __syncthreads();
+    double* shd = reinterpret_cast<double*>(lds);
+    shd[tid] = bsum;   // [wave][hh][ch]
+    __syncthreads();
+    if (tid < 32) {
+      double t = 0.0;
+      for (int k = 0; k < 16; ++k) t += shd[k * 32 + tid];
+      p.partial_b[((long)blockIdx.x * gridDim.z + qct) * 32 + tid] = t;
+    }
+  }
+}
+
 struct WgradRoles {
   int ntaps, s, neg, swapped, transposed;
   int Dp, Hp, Wp, Cp, Dq, Hq, Wq, Cq;
@@ -1257,7 +1333,21 @@ extern "C" int bts_conv3d_bwd_weight(int kind, const float* x, const float* dy, 
     const char* e = getenv("BTS_WGW");
     use_wgw = !(e && atoi(e) == 0) && 5.0 * p.Hp * p.Wp * p.ldp * 4.0 < 2.0e9 && 3.0 * p.Hq * p.Wq * p.ldq * 4.0 < 2.0e9;  // 31-bit tile offsets
   }
-  if (use_wgw) {
+  // 1x1x1 convs on big grids: streaming kernel (BTS_K1W=0: the staged kernel)
+  bool use_k1w = false;
+  const long NVall = (long)N * ro.Dq * ro.Hq * ro.Wq;
+  if (ro.ntaps == 1 && !pIsDy && p.ntiles == 1 && NVall >= 32768) {
+    const char* e = getenv("BTS_K1W");
+    use_k1w = !(e && atoi(e) == 0);
+  }
+  if (use_k1w) {
+    const long chunk = (((NVall + pl.nsp - 1) / pl.nsp) + 15) & ~15L;
+    if (prof) bts_prof_begin(26, 2.0 * (double)ro.Cp * ro.Cq * (double)NVall, stream);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k1w_kernel, dim3(pl.nsp, pl.npct, pl.nqct), dim3(K1W_THREADS), 0, stream, p, NVall, chunk);
+    if (prof) bts_prof_end(stream);
+    BTS_LAUNCH_CHECK();
+  } else if (use_wgw) {
     static bool wattr = false;
     if (!wattr) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -142,3 +142,32 @@ def test_wgw_full_size_agrees_with_direct_form():
     lin = (dws - (dw + dwb)).abs()
     assert not bool((lin > 32 * EPS32 * (bound + bound2) + 1e-5).any()), 'linearity: max err %.3e' % float(lin.max())
     check(db, dy.double().cpu().sum(dim=(0, 1, 2, 3)), dy.double().cpu().abs().sum(dim=(0, 1, 2, 3)), 'full-size bias gradient')
+
+
+@pytest.mark.parametrize('n,dims,cin,cout', [(1, (32, 32, 32), 32, 32), (2, (16, 32, 32), 48, 80), (1, (33, 31, 35), 64, 24)])
+def test_k1w_streaming_pointwise_weight_gradient(n, dims, cin, cout):
+    """k1w_kernel: weight and bias gradient of the 1x1x1 convs on big grids, operands streamed from global memory (no LDS
+    staging); channel counts that are not multiples of 32, odd voxel counts, channel slices of wider slabs"""
+    from bts_amd import ops
+    d, h, w = dims
+    xs = rnd((n, d, h, w, cin + 8), 41)
+    ds = rnd((n, d, h, w, cout + 4), 42)
+    x, dy = xs[..., 8:], ds[..., :cout]
+    wd = torch.zeros((1, 1, 1, cin, cout), dtype=torch.float64, requires_grad=True)
+    bd = torch.zeros((cout,), dtype=torch.float64, requires_grad=True)
+    (R.conv3d(x.double(), wd, bd) * dy.double()).sum().backward()
+    bound = torch.einsum('ndhwc,ndhwk->ck', x.double().abs(), dy.double().abs()).reshape(1, 1, 1, cin, cout)
+    xg, dg = xs.to(dev())[..., 8:], ds.to(dev())[..., :cout]
+    dw = torch.empty((1, 1, 1, cin, cout), device=dev())
+    db = torch.empty((cout,), device=dev())
+    names = kernels_of(lambda: ops.conv_bwd_weight(ops.K1, xg, dg, dw, db))
+    assert 'k1w_kernel' in names, names
+    check(dw, wd.grad, bound, 'k1w dW')
+    check(db, bd.grad, dy.double().abs().sum(dim=(0, 1, 2, 3)), 'k1w db')
+    os.environ['BTS_K1W'] = '0'
+    try:
+        dw0 = torch.empty_like(dw)
+        assert 'k1w_kernel' not in kernels_of(lambda: ops.conv_bwd_weight(ops.K1, xg, dg, dw0, None))
+    finally:
+        del os.environ['BTS_K1W']
+    check(dw0, wd.grad, bound, 'staged dW')
