@@ -456,6 +456,16 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
   if (lddy == C) {  // dense dy: it is indexed like x, no division in the loop
     const float* xb = x + (long)n * E + unitBase;
     const float* db = dy + (long)n * E + unitBase;
+    for (; i + 3072 < hi; i += 4096) {  // four chunks of both streams in flight
+      f32x4 v[4], d[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = *reinterpret_cast<const f32x4*>(xb + i + 1024 * u);
+        d[u] = *reinterpret_cast<const f32x4*>(db + i + 1024 * u);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) body(v[u], d[u], cph);
+    }
     for (; i + 1024 < hi; i += 2048) {
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(xb + i);
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(xb + i + 1024);
