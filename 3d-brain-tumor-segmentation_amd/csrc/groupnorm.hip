@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void gn_apply_slab_stream_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                   long chunks_per_unit, int cpb, int C, int cg, int G, int relu) {
+                                                                   long chunks_per_unit, int cpb, int C, int cg, int G, int relu, int ldy) {
   const long chunk0 = (long)blockIdx.x * cpb;
   const long unit = chunk0 / chunks_per_unit;          // n*G + g
   const int g = (int)(unit % G);
@@ -335,7 +335,9 @@ __global__ __launch_bounds__(256) void gn_apply_slab_stream_kernel(const float* 
     sh[e] = beta[idx];
   }
   const float* xp = x + chunk0 * 1024 + threadIdx.x * 4;
-  float* yp = y + chunk0 * 1024 + threadIdx.x * 4;
+  const long vpc = 1024 / C;   // y may be a channel slice of a wider slab (row stride ldy >= C)
+  float* yp = y + (chunk0 * vpc + (threadIdx.x * 4) / C) * ldy + c;
+  const long ystep = vpc * ldy;
   int k = 0;
   for (; k + 1 < cpb; k += 2) {
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(xp + (long)k * 1024);
@@ -347,8 +349,8 @@ __global__ __launch_bounds__(256) void gn_apply_slab_stream_kernel(const float* 
       o1[e] = fmaf(v1[e] - m, sc[e], sh[e]);
       if (relu) { o0[e] = fmaxf(o0[e], 0.f); o1[e] = fmaxf(o1[e], 0.f); }
     }
-    *reinterpret_cast<f32x4*>(yp + (long)k * 1024) = o0;
-    *reinterpret_cast<f32x4*>(yp + (long)(k + 1) * 1024) = o1;
+    *reinterpret_cast<f32x4*>(yp + (long)k * ystep) = o0;
+    *reinterpret_cast<f32x4*>(yp + (long)(k + 1) * ystep) = o1;
   }
   for (; k < cpb; ++k) {
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(xp + (long)k * 1024);
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(256) void gn_apply_slab_stream_kernel(const float* 
       o0[e] = fmaf(v0[e] - m, sc[e], sh[e]);
       if (relu) o0[e] = fmaxf(o0[e], 0.f);
     }
-    *reinterpret_cast<f32x4*>(yp + (long)k * 1024) = o0;
+    *reinterpret_cast<f32x4*>(yp + (long)k * ystep) = o0;
   }
 }
 // chunks per block for the streaming kernels: the largest power of two <= 8 dividing the chunks of a unit
@@ -385,7 +387,7 @@ extern "C" int bts_gn_apply(const float* x, float* y, const float* gamma, const 
     return BTS_OK;
   }
   if (ldy < C || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 15)) return BTS_ERR_ALIGN;
-  if (mode == BTS_GN_SLAB && ldy == C && g.L % 1024 == 0 && 1024 % C == 0 && getenv("BTS_GN_NOSTREAM") == nullptr) {
+  if (mode == BTS_GN_SLAB && g.L % 1024 == 0 && 1024 % C == 0 && getenv("BTS_GN_NOSTREAM") == nullptr) {
     // NOTE: results differ from gn_apply_kernel in the last bit ((x - m) * rs * gamma + beta is evaluated as
     // fma(x - m, rs*gamma, beta)); both are within the element-wise tolerance of the oracle
     const long cpu = g.L / 1024;
@@ -393,7 +395,7 @@ extern "C" int bts_gn_apply(const float* x, float* y, const float* gamma, const 
     const long nblk = (long)N * G * cpu / cpb;
     if (nblk <= 0x7fffffffL) {
       (void)hipGetLastError(); hipLaunchKernelGGL(gn_apply_slab_stream_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, x, y, gamma, beta, mean,
-                         rstd, cpu, cpb, C, g.cg, G, relu);
+                         rstd, cpu, cpb, C, g.cg, G, relu, ldy);
       BTS_LAUNCH_CHECK();
       return BTS_OK;
     }
@@ -611,7 +613,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_slab_stream_kernel(const flo
                                                                        const float* __restrict__ beta, const float* __restrict__ mean,
                                                                        const float* __restrict__ rstd, const float* __restrict__ c1,
                                                                        const float* __restrict__ c2, long chunks_per_unit, int cpb,
-                                                                       int C, int cg, int G, int relu) {
+                                                                       int C, int cg, int G, int relu, int lddy) {
   const long chunk0 = (long)blockIdx.x * cpb;
   const long unit = chunk0 / chunks_per_unit;
   const int g = (int)(unit % G);
@@ -625,6 +627,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_slab_stream_kernel(const flo
     be[e] = beta[idx];
   }
   const long off = chunk0 * 1024 + threadIdx.x * 4;
+  // dy may be a channel slice of a wider slab (row stride lddy >= C): its rows advance by 1024 / C voxels per chunk
+  const long vpc = 1024 / C;
+  const long doff = (chunk0 * vpc + (threadIdx.x * 4) / C) * lddy + c;
+  const long dstep = vpc * lddy;
   auto one = [&](const f32x4 v, const f32x4 d) {
     f32x4 o;
 #pragma unroll
@@ -639,15 +645,15 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_slab_stream_kernel(const flo
   int k = 0;
   for (; k + 1 < cpb; k += 2) {
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + off + (long)k * 1024);
-    const f32x4 d0 = *reinterpret_cast<const f32x4*>(dy + off + (long)k * 1024);
+    const f32x4 d0 = *reinterpret_cast<const f32x4*>(dy + doff + (long)k * dstep);
     const f32x4 v1 = *reinterpret_cast<const f32x4*>(x + off + (long)(k + 1) * 1024);
-    const f32x4 d1 = *reinterpret_cast<const f32x4*>(dy + off + (long)(k + 1) * 1024);
+    const f32x4 d1 = *reinterpret_cast<const f32x4*>(dy + doff + (long)(k + 1) * dstep);
     *reinterpret_cast<f32x4*>(dx + off + (long)k * 1024) = one(v0, d0);
     *reinterpret_cast<f32x4*>(dx + off + (long)(k + 1) * 1024) = one(v1, d1);
   }
   for (; k < cpb; ++k) {
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + off + (long)k * 1024);
-    const f32x4 d0 = *reinterpret_cast<const f32x4*>(dy + off + (long)k * 1024);
+    const f32x4 d0 = *reinterpret_cast<const f32x4*>(dy + doff + (long)k * dstep);
     *reinterpret_cast<f32x4*>(dx + off + (long)k * 1024) = one(v0, d0);
   }
 }
@@ -696,13 +702,13 @@ extern "C" int bts_gn_bwd(const float* x, const float* dy, float* dx, const floa
   (void)hipGetLastError(); hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), 0, stream, gamma, dgamma, dbeta, c1, c2, scratch, N, C, G,
                      (double)g.L, accumulate_params);
   BTS_LAUNCH_CHECK();
-  if (slab && lddy == C && g.L % 1024 == 0 && 1024 % C == 0 && getenv("BTS_GN_NOSTREAM") == nullptr) {
+  if (slab && g.L % 1024 == 0 && 1024 % C == 0 && getenv("BTS_GN_NOSTREAM") == nullptr) {
     const long cpu = g.L / 1024;
     const int cpb = gn_stream_cpb(cpu);
     const long nblk = (long)N * G * cpu / cpb;
     if (nblk <= 0x7fffffffL) {
       (void)hipGetLastError(); hipLaunchKernelGGL(gn_bwd_apply_slab_stream_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, x, dy, dx, gamma, beta,
-                         mean, rstd, c1, c2, cpu, cpb, C, g.cg, G, relu);
+                         mean, rstd, c1, c2, cpu, cpb, C, g.cg, G, relu, lddy);
       BTS_LAUNCH_CHECK();
       return BTS_OK;
     }
