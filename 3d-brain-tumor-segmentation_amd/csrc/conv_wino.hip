@@ -46,6 +46,7 @@ struct WinoParams {
   // (bias, accumulate) by the implicit GEMM's reduce kernel
   int ksplit, kg_per, Npad;
   float* part;
+  int nb, ntiles;   // cout blocks of 32; tiles = N * ntz * nty * ntx
 };
 
 #define WS 12      // dwords per staged voxel: 8 channels + 4 pad (16-byte-odd stride, conflict-free ds_read_b128)
@@ -126,7 +127,13 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l32 = lane & 31;
-  int b = blockIdx.x;
+  // 1-D grid over (tile, cout block): the cout blocks of one tile are 8 workgroup ids apart -- same XCD (ids are dealt
+  // round-robin to the 8 XCDs), dispatched within the same wave of workgroups: the second block finds the halo tile in L2
+  const int nb_ = p.nb;
+  const int grp_ = blockIdx.x / (8 * nb_), rem_ = blockIdx.x - grp_ * (8 * nb_);
+  const int cb = rem_ >> 3;
+  int b = grp_ * 8 + (rem_ & 7);
+  if (b >= p.ntiles) return;   // tail of the last group of 8 tiles (before any barrier: whole workgroups leave)
   const int tx = b % p.ntx; b /= p.ntx;
   const int ty = b % p.nty; b /= p.nty;
   const int tz = b % p.ntz;
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xorg, 0, 0x7fffffff, 0x00020000);
   // U of this cout block: [k-group][x tap][xi][h][32][4] = 1 KB per (x tap, xi) image
   const __amdgpu_buffer_rsrc_t wr =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(p.up + (long)blockIdx.y * p.KG * (3 * 16 * 256)), 0, 0x7fffffff, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.up + (long)cb * p.KG * (3 * 16 * 256)), 0, 0x7fffffff, 0x00020000);
   unsigned goff[WNSLOT];
 #pragma unroll
   for (int i = 0; i < WNSLOT; ++i) {
@@ -303,18 +310,18 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
   for (int g = 0; g < 4; ++g) {
     bq[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.bias && p.ksplit <= 1) {
-      const int co = blockIdx.y * 32 + 8 * g + 4 * h;
+      const int co = cb * 32 + 8 * g + 4 * h;
       if (co < p.Cout) bq[g] = f32x4{p.bias[co], p.bias[co + 1], p.bias[co + 2], p.bias[co + 3]};  // 4-byte aligned views are common
     }
   }
   const int oxx = ox0 + xl;
   const int zb = oz0 + 2 * tz2, yb = oy0 + 2 * ty2;
-  float* ybase = p.y + ((((long)n * p.D + zb) * p.H + yb) * p.W + oxx) * (long)p.ldy + blockIdx.y * 32 + 4 * h;
+  float* ybase = p.y + ((((long)n * p.D + zb) * p.H + yb) * p.W + oxx) * (long)p.ldy + cb * 32 + 4 * h;
   const long ysY = (long)p.W * p.ldy, ysZ = (long)p.H * p.W * p.ldy;
   const bool inx = oxx < p.W;
   const bool raw = p.ksplit > 1;
   float* pbase = nullptr;
-  if (raw) pbase = p.part + (((long)blockIdx.z * p.N + n) * p.D * p.H * p.W + ((long)zb * p.H + yb) * p.W + oxx) * p.Npad + blockIdx.y * 32 + 4 * h;
+  if (raw) pbase = p.part + (((long)blockIdx.z * p.N + n) * p.D * p.H * p.W + ((long)zb * p.H + yb) * p.W + oxx) * p.Npad + cb * 32 + 4 * h;
   float gn_s = 0.f, gn_q = 0.f;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {  // one register quad (4 couts) of all 16 accumulators at a time
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
       tq[xz][0] = q[0] + q[1] + q[2];
       tq[xz][1] = q[1] - q[2] - q[3];
     }
-    const bool cok = inx && (blockIdx.y * 32 + 8 * g + 4 * h < (raw ? p.Npad : p.Cout));
+    const bool cok = inx && (cb * 32 + 8 * g + 4 * h < (raw ? p.Npad : p.Cout));
 #pragma unroll
     for (int oy = 0; oy < 2; ++oy) {
       f32x4 o[2];
@@ -363,8 +370,8 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
     __syncthreads();
     if (tid == 0) {
       const int g = tz / p.gn_zt;
-      const long B = (long)p.gn_zt * p.nty * p.ntx * gridDim.y;
-      const long b_ = (((long)(tz - g * p.gn_zt) * p.nty + ty) * p.ntx + tx) * gridDim.y + blockIdx.y;
+      const long B = (long)p.gn_zt * p.nty * p.ntx * nb_;
+      const long b_ = (((long)(tz - g * p.gn_zt) * p.nty + ty) * p.ntx + tx) * nb_ + cb;
       double* o = p.gnp + (((long)n * p.gn_G + g) * B + b_) * 2;
       o[0] = sh[0] + sh[2] + sh[4] + sh[6];
       o[1] = sh[1] + sh[3] + sh[5] + sh[7];
@@ -435,7 +442,8 @@ static int wino_launch_cfg(const WinoParams& p, const WinoPlan& q, double flops,
   const bool prof = bts_prof_on();
   if (prof) bts_prof_begin(23, flops, stream);
   (void)hipGetLastError();
-  hipLaunchKernelGGL(kern, dim3((unsigned)(p.N * q.ntz * q.nty * q.ntx), q.nb, q.ksplit), dim3(256), shmem, stream, p);
+  const long tiles = (long)p.N * q.ntz * q.nty * q.ntx;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(((tiles + 7) / 8) * 8 * q.nb), 1, q.ksplit), dim3(256), shmem, stream, p);
   if (prof) bts_prof_end(stream);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
@@ -465,6 +473,7 @@ int bts_wino_launch_(const float* x, const float* up, const float* bias, float* 
   p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx;
   p.accum = accum;
   p.ksplit = q.ksplit; p.kg_per = q.kg_per; p.Npad = q.nb * 32; p.part = reinterpret_cast<float*>(ws);
+  p.nb = q.nb; p.ntiles = N * q.ntz * q.nty * q.ntx;
   p.gnp = nullptr; p.gn_G = 0; p.gn_zt = 1;
   if (q.ksplit == 1 && gnp != nullptr && gnG > 0 && D % gnG == 0 && (D / gnG) % 4 == 0 && getenv("BTS_IGEMM_NOGNFUSE") == nullptr) {
     p.gnp = gnp; p.gn_G = gnG; p.gn_zt = (D / gnG) / 4;
