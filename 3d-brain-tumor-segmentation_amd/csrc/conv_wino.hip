@@ -46,7 +46,7 @@ struct WinoParams {
   // (bias, accumulate) by the implicit GEMM's reduce kernel
   int ksplit, kg_per, Npad;
   float* part;
-  int nb, ntiles;   // cout blocks of 32; tiles = N * ntz * nty * ntx
+  int nb, ntiles, tiles_per_xcd;   // cout blocks of 32; tiles = N * ntz * nty * ntx
 };
 
 #define WS 12      // dwords per staged voxel: 8 channels + 4 pad (16-byte-odd stride, conflict-free ds_read_b128)
@@ -127,13 +127,14 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l32 = lane & 31;
-  // 1-D grid over (tile, cout block): the cout blocks of one tile are 8 workgroup ids apart -- same XCD (ids are dealt
-  // round-robin to the 8 XCDs), dispatched within the same wave of workgroups: the second block finds the halo tile in L2
+  // 1-D grid over (tile, cout block).  Workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2): XCD k walks
+  // its own contiguous eighth of the tiles, the cout blocks of a tile back to back -- x / y / z neighbours (a third of every
+  // halo tile each) and the second cout block find their data in the XCD's L2 instead of behind the fabric
   const int nb_ = p.nb;
-  const int grp_ = blockIdx.x / (8 * nb_), rem_ = blockIdx.x - grp_ * (8 * nb_);
-  const int cb = rem_ >> 3;
-  int b = grp_ * 8 + (rem_ & 7);
-  if (b >= p.ntiles) return;   // tail of the last group of 8 tiles (before any barrier: whole workgroups leave)
+  const int xcd_ = blockIdx.x & 7, seq_ = blockIdx.x >> 3;
+  const int cb = seq_ % nb_;
+  int b = xcd_ * p.tiles_per_xcd + seq_ / nb_;
+  if (seq_ / nb_ >= p.tiles_per_xcd || b >= p.ntiles) return;   // (before any barrier: whole workgroups leave)
   const int tx = b % p.ntx; b /= p.ntx;
   const int ty = b % p.nty; b /= p.nty;
   const int tz = b % p.ntz;
@@ -442,8 +443,7 @@ static int wino_launch_cfg(const WinoParams& p, const WinoPlan& q, double flops,
   const bool prof = bts_prof_on();
   if (prof) bts_prof_begin(23, flops, stream);
   (void)hipGetLastError();
-  const long tiles = (long)p.N * q.ntz * q.nty * q.ntx;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(((tiles + 7) / 8) * 8 * q.nb), 1, q.ksplit), dim3(256), shmem, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(8L * p.tiles_per_xcd * q.nb), 1, q.ksplit), dim3(256), shmem, stream, p);
   if (prof) bts_prof_end(stream);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
@@ -473,7 +473,7 @@ int bts_wino_launch_(const float* x, const float* up, const float* bias, float* 
   p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx;
   p.accum = accum;
   p.ksplit = q.ksplit; p.kg_per = q.kg_per; p.Npad = q.nb * 32; p.part = reinterpret_cast<float*>(ws);
-  p.nb = q.nb; p.ntiles = N * q.ntz * q.nty * q.ntx;
+  p.nb = q.nb; p.ntiles = N * q.ntz * q.nty * q.ntx; p.tiles_per_xcd = (p.ntiles + 7) / 8;
   p.gnp = nullptr; p.gn_G = 0; p.gn_zt = 1;
   if (q.ksplit == 1 && gnp != nullptr && gnG > 0 && D % gnG == 0 && (D / gnG) % 4 == 0 && getenv("BTS_IGEMM_NOGNFUSE") == nullptr) {
     p.gnp = gnp; p.gn_G = gnG; p.gn_zt = (D / gnG) / 4;
