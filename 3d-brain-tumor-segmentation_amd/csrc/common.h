@@ -14,6 +14,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define BTS_ERR_UNSUPPORTED (-3)
 #define BTS_ERR_WORKSPACE (-4)
 
+// Timing experiments that skip parts of a kernel (results are WRONG by design) exist only in builds made with
+// -DBTS_TIMING_EXPERIMENTS; in the product library the switch is the literal 0 and the branches fold away.
+#ifdef BTS_TIMING_EXPERIMENTS
+#define BTS_DBG(p) ((p).dbg)
+#else
+#define BTS_DBG(p) 0
+#endif
+
 #define BTS_LAUNCH_CHECK()                         \
   do {                                             \
     hipError_t e__ = hipGetLastError();            \

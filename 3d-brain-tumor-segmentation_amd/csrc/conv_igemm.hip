@@ -358,14 +358,14 @@ __global__ __launch_bounds__(256, IG_TRI(MS, NS, KGS, FUSE2, FIXG) ? 3 : 2) void
     const float* cur = SINGLE ? lds : lds + (st & 1) * bufDw;
     float* nxt = SINGLE ? lds : lds + ((st + 1) & 1) * bufDw;
     const bool more = (st + 1) < nstages;
-    if (more && p.dbg != 2) fetch(st + 1);
+    if (more && BTS_DBG(p) != 2) fetch(st + 1);
 
     // k-groups of this stage x taps: fully unrolled tap sequence (tables hoisted to SGPRs), weight fragments
     // prefetched two taps ahead and input fragments one tap ahead so their latencies sit under the MFMAs
     const int kg0 = (stBeg + st) * KGS;
     int nkg = kgEnd - kg0;
     if (nkg > KGS) nkg = KGS;
-    if (p.dbg == 1) {
+    if (BTS_DBG(p) == 1) {
     } else if constexpr (FIXG || T27 || FUSE2) {  // 27-tap form known at compile time (fixed geometry, the fused pair, or
       // the launcher's T27 instantiation for k3s1 / stride-2 convs): no runtime tap-count dispatch, so the accumulators
       // are not shuffled between register sets around a switch
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256, IG_TRI(MS, NS, KGS, FUSE2, FIXG) ? 3 : 2) void
       stage_taps<1, MS, NS>(p, tlp, twp, cur, bbase, lane_woff, kg0, nkg, acc, nullptr, x2row, false);
     }
     if (SINGLE) __syncthreads();  // every wave has finished reading the tile before it is overwritten
-    if (more && p.dbg != 2) commit(nxt);
+    if (more && BTS_DBG(p) != 2) commit(nxt);
     __syncthreads();
   }
 
@@ -1539,7 +1539,11 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
   p.part = reinterpret_cast<float*>(ws);
   p.ws_bytes = ws_bytes;
   p.plan_only = need_out != nullptr;
+#ifdef BTS_TIMING_EXPERIMENTS
   { const char* e = getenv("BTS_IGEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
+#else
+  p.dbg = 0;
+#endif
   p.ws_need = 0;
   p.x = x; p.wp = wp; p.bias = bias; p.y = y;
   p.N = N; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.ldx = ldx;

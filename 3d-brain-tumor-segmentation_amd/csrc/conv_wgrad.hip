@@ -488,7 +488,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams 
     const bool more = (sub + 1) < sub1;
     // BTS_WGRAD_DBG (timing only, results are wrong): 1 skip the sweep, 2 no re-staging, 3 = 2 + no barriers,
     // 4 = 2 + at most 3 row-tiles per wave, 5 stage but keep reading buffer 0, 7 = always stage the first sub-tile
-    const bool dofetch = more && (p.dbg < 2 || p.dbg >= 5);
+    const bool dofetch = more && (BTS_DBG(p) < 2 || BTS_DBG(p) >= 5);
     if constexpr (FIXG == 0) {
       if (dofetch) {
         if constexpr (GLDS) fetch_glds(sub + 1, lds + (cur ^ 1) * bufDw);
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams 
       auto stage = [&](auto kc) {
         constexpr int K = decltype(kc)::value;
         if constexpr (K == 0) {
-          if (dofetch) fast_prep(p.dbg == 7 ? sub0 : sub + 1, lds + (cur ^ 1) * bufDw);
+          if (dofetch) fast_prep(BTS_DBG(p) == 7 ? sub0 : sub + 1, lds + (cur ^ 1) * bufDw);
         } else if constexpr (K >= P0 && K < Q0 && (K - P0) % PD == 0) {
           if (dofetch) fast_slot_p(IC<(K - P0) / PD>{});
         } else if constexpr (K >= Q0 && K <= Q0 + 3 * QD && (K - Q0) % QD == 0) {
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams 
       unsigned vp[WG_MAXT];
 #pragma unroll
       for (int i = 0; i < WG_MAXT; ++i) vp[i] = bpb + 4u * (unsigned)(rowoff[i] + ((h * p.s) << 5));
-      if (p.dbg == 1) {
+      if (BTS_DBG(p) == 1) {
         if (dofetch) fetch_fast(sub + 1, lds + (cur ^ 1) * bufDw);
       } else {
         // 27 row-tiles over 8 waves: every wave owns tiles w, w+8, w+16 for the whole sub-tile and 1/8 of the voxel pairs
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams 
       }
     } else {
       const int st0 = ksplit ? wave : 0, stinc = ksplit ? WG_WAVES : 1;
-      if (p.dbg != 1) switch ((p.dbg == 4 && ntw > 3) ? 3 : ntw) {  // wave-uniform: row-tiles this wave owns -> branch-free MFMA bodies
+      if (BTS_DBG(p) != 1) switch ((BTS_DBG(p) == 4 && ntw > 3) ? 3 : ntw) {  // wave-uniform: row-tiles this wave owns -> branch-free MFMA bodies
         case 4: wgrad_steps<4>(p, bp, bq, rowoff, acc, st0, stinc, nsteps, h, l32); break;
         case 3: wgrad_steps<3>(p, bp, bq, rowoff, acc, st0, stinc, nsteps, h, l32); break;
         case 2: wgrad_steps<2>(p, bp, bq, rowoff, acc, st0, stinc, nsteps, h, l32); break;
@@ -555,8 +555,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const WgradParams 
       if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else commit(lds + (cur ^ 1) * bufDw);
     }
-    if (p.dbg != 3) __syncthreads();
-    if (p.dbg < 2) cur ^= 1;
+    if (BTS_DBG(p) != 3) __syncthreads();
+    if (BTS_DBG(p) < 2) cur ^= 1;
   }
 
   // ---- write partials ----
@@ -1303,7 +1303,11 @@ extern "C" int bts_conv3d_bwd_weight(int kind, const float* x, const float* dy, 
   p.partial_b = reinterpret_cast<double*>(pb);
   // bias gradient = column sums of dy: dy is Q in the plain form only
   p.want_bias = (db != nullptr && !pIsDy) ? 1 : 0;
+#ifdef BTS_TIMING_EXPERIMENTS
   { const char* e = getenv("BTS_WGRAD_DBG"); p.dbg = e ? atoi(e) : 0; }
+#else
+  p.dbg = 0;
+#endif
   typedef void (*WgKernel)(const WgradParams);
   static const WgKernel kernels[4] = {wgrad_kernel<0, 0>, wgrad_kernel<1, 0>, wgrad_kernel<2, 1>, wgrad_kernel<2, 2>};
   static bool attr_done = false;

@@ -54,10 +54,32 @@ def init_from_env(backend=None):
     torch.distributed.init_process_group(backend=backend, rank=int(os.environ.get('RANK', '0')), world_size=ws)
 
 
+class _Done(object):
+    """handle of an exchange that already completed"""
+
+    def wait(self):
+        return True
+
+
+def _sum_over_ranks(t, async_op=False):
+    """in-place sum of `t` over the group.  RCCL reduces device buffers directly (the production path, one GPU per rank).
+    A gloo group given a device buffer -- ranks sharing ONE GPU, which RCCL refuses: tests/test_dp_gpu.py and
+    `bench.py --share-gpu` -- is served through a host bounce buffer after the producing stream has drained."""
+    d = torch.distributed
+    if t.is_cuda and d.get_backend() == 'gloo':
+        torch.cuda.current_stream(t.device).synchronize()
+        h = t.detach().to('cpu')
+        d.all_reduce(h, op=d.ReduceOp.SUM)
+        t.copy_(h)
+        return _Done()
+    h = d.all_reduce(t, op=d.ReduceOp.SUM, async_op=async_op)
+    return h if async_op else _Done()
+
+
 def all_reduce_sum(t):
     """in-place sum over ranks (C3); no-op on one rank"""
     if active():
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+        _sum_over_ranks(t)
     return t
 
 
@@ -72,7 +94,7 @@ def all_reduce_flat(flat, bucket_bytes=BUCKET_BYTES):
         return flat
     handles = []
     for off, ln in bucket_ranges(flat.numel(), flat.element_size(), bucket_bytes):
-        handles.append(torch.distributed.all_reduce(flat[off:off + ln], op=torch.distributed.ReduceOp.SUM, async_op=True))
+        handles.append(_sum_over_ranks(flat[off:off + ln], async_op=True))
     for h in handles:
         h.wait()
     return flat
@@ -93,9 +115,28 @@ def all_reduce_gradients(model):
 def broadcast_parameters(model, src=0):
     """C2"""
     if active():
-        torch.distributed.broadcast(model.flat_params, src=src)
+        fp = model.flat_params
+        if fp.is_cuda and torch.distributed.get_backend() == 'gloo':    # ranks sharing one GPU (see _sum_over_ranks)
+            h = fp.detach().to('cpu')
+            torch.distributed.broadcast(h, src=src)
+            fp.copy_(h)
+        else:
+            torch.distributed.broadcast(fp, src=src)
         from .tape import bump_weights_epoch
         bump_weights_epoch()
+        decorrelate_rng(model)
+
+
+def decorrelate_rng(model):
+    """Weights are replicated, random draws are not: move each rank's dropout / reparameterisation counters
+    (encoder.py:39, vae.py:12 draw fresh numbers per example) to its own stream, once per model."""
+    if getattr(model, '_rng_rank', None) == rank():
+        return
+    for name in ('encoder', 'vae'):
+        lay = getattr(model, name, None)
+        if lay is not None and hasattr(lay, '_seed'):
+            lay._seed = (int(lay._seed) + rank() * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
+    model._rng_rank = rank()
 
 
 class GradSync(object):
@@ -167,8 +208,7 @@ class GradSync(object):
                 ops.l2_reg_bwd(m.flat_params, m.flat_grads, rg, g)
         self.launched[bi] = True
         if active():
-            self.handles.append(torch.distributed.all_reduce(m.flat_grads[off:off + ln], op=torch.distributed.ReduceOp.SUM,
-                                                             async_op=True))
+            self.handles.append(_sum_over_ranks(m.flat_grads[off:off + ln], async_op=True))
 
     def finish(self):
         from . import ops

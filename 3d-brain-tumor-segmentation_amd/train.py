@@ -118,11 +118,26 @@ def _rng_layers(model):
     return out
 
 
-def save_checkpoint(folder, model, optimizer=None):
-    """weights by variable name + `epoch`; with an optimizer also Adam m / v (flat order) and its step count"""
+def save_checkpoint(folder, model, optimizer=None, completed=False, tracker=None, datasets=None):
+    """weights by variable name + `epoch`; with an optimizer also Adam m / v (flat order) and its step count.
+
+    completed=True (what fit() passes: it saves AFTER the epoch's last step): the container also records
+    `next_epoch = epoch + 1`, and a resumed fit() starts there -- the reference restarts at the saved epoch
+    (train.py:133-135) but carries no optimizer state; with Adam moments, step count and RNG counters persisted, repeating
+    that epoch would apply it twice.  tracker: the PatienceTracker (best / patience persist, so the first resumed epoch cannot
+    overwrite a better checkpoint).  datasets: {'train': ds, 'val': ds}; objects with state_dict() (data._Dataset: shuffle
+    and augmentation generators) are persisted."""
     tensors = {'var/' + p.name: p.t for p in model.trainable_variables}
     meta = {'format': FORMAT_VERSION, 'epoch': int(model.epoch.value().numpy()), 'n_params': int(model.n_params),
             'rng': {k: int(v._seed) for k, v in _rng_layers(model).items()}}
+    if completed:
+        meta['next_epoch'] = meta['epoch'] + 1
+    if tracker is not None:
+        meta['tracker'] = {'best': float(tracker.best), 'patience': int(tracker.patience)}
+    for key, ds in (datasets or {}).items():
+        if hasattr(ds, 'state_dict'):
+            for k, v in ds.state_dict().items():
+                tensors['data/%s/%s' % (key, k)] = v
     if optimizer is not None:
         meta['optimizer'] = {'iterations': int(optimizer.iterations), 'learning_rate': float(optimizer.learning_rate),
                              'init_lr': float(optimizer.init_lr), 'n_epochs': float(optimizer.n_epochs)}
@@ -149,7 +164,10 @@ def load_checkpoint(folder, model, optimizer=None):
         if tuple(src.shape) != tuple(p.t.shape):
             raise ValueError('shape mismatch for %s: %s vs %s' % (p.name, tuple(src.shape), tuple(p.t.shape)))
         p.t.copy_(src.to(p.t.device))
-    model.epoch.assign(int(meta.get('epoch', 0)))
+    model.epoch.assign(int(meta.get('next_epoch', meta.get('epoch', 0))))
+    # consumed by the next fit(): PatienceTracker state and the datasets' generator states
+    model._resume = {'tracker': meta.get('tracker'),
+                     'data': {k[len('data/'):]: v for k, v in tensors.items() if k.startswith('data/')}}
     for k, lay in _rng_layers(model).items():
         if k in meta.get('rng', {}):
             lay._seed = int(meta['rng'][k])
@@ -205,6 +223,15 @@ def fit(model, optimizer, loss_fn, dice_fn, train_data, val_data, n_epochs, pati
         with open(os.path.join(save_folder, 'train.log'), 'w') as f:
             f.write(LOG_HEADER + '\n')
     tracker = PatienceTracker(patience)
+    resume = getattr(model, '_resume', None)       # left by load_checkpoint
+    if resume is not None:
+        model._resume = None
+        if resume.get('tracker'):
+            tracker.best, tracker.patience = float(resume['tracker']['best']), int(resume['tracker']['patience'])
+        for key, ds in (('train', train_data), ('val', val_data)):
+            st = {k[len(key) + 1:]: v for k, v in resume.get('data', {}).items() if k.startswith(key + '/')}
+            if st and hasattr(ds, 'load_state_dict'):
+                ds.load_state_dict(st)
     history = []
     for epoch in range(int(model.epoch.value().numpy()), int(n_epochs)):
         log('Epoch {}.'.format(epoch))
@@ -233,7 +260,8 @@ def fit(model, optimizer, loss_fn, dice_fn, train_data, val_data, n_epochs, pati
         action = tracker.update(float(row['val_macro_dice']))
         if action == 'save':
             if writer:
-                save_checkpoint(save_folder, model, optimizer)
+                save_checkpoint(save_folder, model, optimizer, completed=True, tracker=tracker,
+                                datasets={'train': train_data, 'val': val_data})
             log('Saved model weights.')
         elif action == 'stop':
             log('Validation dice has not improved in {} epochs. Stopped training.'.format(patience))

@@ -4,16 +4,25 @@
 One "step" = one pass of the hot path over one resident batch: forward (training=True), Dice+0.1*MSE+0.1*KL+L2 loss,
 Dice metric, full backward, TF-form Adam (train.py:140-152 of the reference), CLI-default model (base_filters=32,
 reduction=8, depth=4, groups=8; args.py:121-143), fp32.  N=1: BASELINE.json configs[1] (batch 1 per GPU).
-N>1 (torchrun): one process per GPU, one sample per rank (weak scaling), RCCL all-reduce of the 13 loss sums and of the
-flat 168.7 MB gradient buffer.
+
+N>1: one process per GPU, one sample per rank (weak scaling), RCCL all-reduce of the 13 loss sums and of the flat
+168.7 MB gradient buffer.  Two ways in:
+  * `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (the driver's form): this process IS a rank
+    (RANK / LOCAL_RANK / WORLD_SIZE in the environment); --gpus must equal WORLD_SIZE or the run is refused;
+  * `python bench.py --gpus N` with no WORLD_SIZE: this process only LAUNCHES -- it starts N fresh rank processes before
+    anything here touches the GPU (never re-executing a GPU-initialised process), relays rank 0's JSON line and exits with
+    the worst child status.  `--share-gpu` lets the ranks share devices when the box has fewer than N (gloo instead of
+    RCCL, which refuses two ranks on one device): a functional check of the N>1 path, not a scaling number.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  "roofline":     dominant kernel (by summed time in the timed region), algorithmic FLOPs / measured HIP-event time
-  "cpu_baseline": the oracle's identical step on the host cores, bounded sample (rank 0, N=1 only)
+  "roofline":     dominant kernel (by summed time in the timed region), measured live with HIP events on the launch stream
+  "cpu_baseline": the oracle's identical 128^3 step on the host cores (rank 0, N=1 only)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,16 +30,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
+PEAK_HBM_TBS = 8.0             # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
+WINOGRAD_EXECUTED = 12.0 / 27.0   # F(2x2,3x3) over (z,y), x direct: matrix instructions issued per algorithmic MAC
 
 
-def pmc_traffic_bytes(symbol):
-    """HBM bytes per launch of `symbol` from the committed rocprofv3 PMC passes (scripts/pmc_traffic.sh ->
-    profiles/rNN_pmc_traffic.json): (2*FETCH_SIZE + WRITE_SIZE) KiB -- on gfx950 FETCH_SIZE reports half of the bytes of
-    wide (16 B/lane) coalesced reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is taken as is.  None if absent."""
+def pmc_traffic(symbol):
+    """HBM bytes per launch of `symbol` from the newest COMMITTED rocprofv3 PMC capture (scripts/pmc_traffic.sh ->
+    profiles/rNN*_pmc_traffic.json; two separate --pmc passes, FETCH_SIZE and WRITE_SIZE).  Corrected as
+    MI355X_MICROARCH.md's HBM section prescribes for gfx950: FETCH_SIZE tallies the 128-byte requests of wide (16 B/lane)
+    coalesced reads at 64 bytes, so it is doubled; WRITE_SIZE is taken as is.  The raw counter values and the file they
+    come from are reported next to the corrected figure -- it belongs to that capture, not to this run."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), key=os.path.getmtime)
     if not files:
-        return None, None
+        return None
     tab = json.load(open(files[-1]))
     norm = lambda n: n.replace('void ', '').replace(' ', '')
     key = norm(symbol)
@@ -42,24 +55,37 @@ def pmc_traffic_bytes(symbol):
             if best is None or v['launches'] > best['launches']:
                 best = v
     if best is None:
-        return None, None
-    return (2.0 * best['FETCH_SIZE_KiB_mean'] + best['WRITE_SIZE_KiB_mean']) * 1024.0, os.path.basename(files[-1])
+        return None
+    return {'bytes': (2.0 * best['FETCH_SIZE_KiB_mean'] + best['WRITE_SIZE_KiB_mean']) * 1024.0,
+            'fetch_size_kib_raw': best['FETCH_SIZE_KiB_mean'], 'write_size_kib_raw': best['WRITE_SIZE_KiB_mean'],
+            'correction': '2*FETCH_SIZE + WRITE_SIZE (gfx950 wide-read undercount)',
+            'source': 'committed capture profiles/' + os.path.basename(files[-1])}
 
 
 CPU_BASELINE_THREADS = 16   # torch-CPU conv3d stops scaling (and thrashes badly) far below the GPU box's 256 hardware threads
 
 
-def _cpu_baseline_worker():
-    """child process: oracle (torch-CPU restatement) train step on a bounded sample; prints one JSON line"""
+def _cpu_model():
+    try:
+        for line in subprocess.run(['lscpu'], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            if line.lower().startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return None
+
+
+def _cpu_baseline_worker(crop):
+    """child process: oracle (torch-CPU restatement) train step on the host cores; prints one JSON line"""
     import torch
     from oracle import torch_ref as R
     threads = min(os.cpu_count() or 1, CPU_BASELINE_THREADS)
     torch.set_num_threads(threads)
     cfg = R.default_config(base_filters=32, reduction=8)
 
-    def one(crop):
-        x, y, mask, eps = R.synthetic_batch(1, crop, latent=128, seed=1234)
-        P = R.build_params(cfg, crop, seed=0)
+    def one(c):
+        x, y, mask, eps = R.synthetic_batch(1, c, latent=128, seed=1234)
+        P = R.build_params(cfg, c, seed=0)
         for k in P:
             P[k] = P[k].float()
         t0 = time.time()
@@ -67,27 +93,72 @@ def _cpu_baseline_worker():
         return time.time() - t0
 
     one((16, 16, 16))                      # warm-up: thread pool, oneDNN primitive caches
-    t = one((64, 64, 64))
-    print(json.dumps({'value': (64 ** 3 / float(128 ** 3)) / t, 'unit': 'volumes/s', 'cores': threads, 'kind': 'port',
-                      'sample': '1 fwd+bwd+Adam step, fp32, CLI-default model, one 2ch x 64^3 crop (= 1/8 of a 128^3 volume) '
-                                'after a 16^3 warm-up step; value scaled to 128^3 volumes', 'seconds': round(t, 3)}))
+    t = one((crop,) * 3)
+    print(json.dumps({'value': (crop ** 3 / float(128 ** 3)) / t, 'unit': 'volumes/s', 'cores': threads, 'kind': 'port',
+                      'host_cpus': os.cpu_count(), 'cpu_model': _cpu_model(),
+                      'sample': ('1 full train step (fwd+bwd+Dice metric+Adam), fp32, CLI-default model, one 2ch x %d^3 '
+                                 'volume, after a 16^3 warm-up step; oracle/torch_ref.py on %d torch threads' % (crop, threads))
+                                + ('' if crop == 128 else '; value scaled to 128^3 volumes'),
+                      'seconds': round(t, 3)}))
 
 
-def cpu_baseline(timeout_s=150):
+def cpu_baseline(crop=128, timeout_s=240):
     """oracle train step timed on the host cores in a child process; kind 'port' (the reference needs TensorFlow, which
-    cannot be installed here, so the restatement is what can be timed)"""
-    import subprocess
+    cannot be installed here, so the restatement is what can be timed).  A 128^3 step is ~20-30 s on 16 threads."""
+    fail = {'value': None, 'unit': 'volumes/s', 'cores': min(os.cpu_count() or 1, CPU_BASELINE_THREADS), 'kind': 'port',
+            'host_cpus': os.cpu_count(), 'cpu_model': _cpu_model()}
     try:
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker'], capture_output=True,
-                             text=True, timeout=timeout_s, cwd=ROOT)
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--crop', str(crop)],
+                             capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
         for line in reversed(out.stdout.strip().splitlines()):
             if line.startswith('{'):
                 return json.loads(line)
-        return {'value': None, 'unit': 'volumes/s', 'cores': CPU_BASELINE_THREADS, 'kind': 'port',
-                'sample': 'worker failed: ' + out.stderr[-200:]}
+        fail['sample'] = 'worker failed: ' + out.stderr[-200:]
     except subprocess.TimeoutExpired:
-        return {'value': None, 'unit': 'volumes/s', 'cores': CPU_BASELINE_THREADS, 'kind': 'port',
-                'sample': 'bounded sample (64^3 crop step) did not finish within %d s' % timeout_s}
+        fail['sample'] = 'one %d^3 oracle step did not finish within %d s' % (crop, timeout_s)
+    return fail
+
+
+def active_overrides():
+    """every BTS_* variable in the environment (A/B and test aids; the defaults are the product)"""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith('BTS_') and not k.startswith('BTS_BENCH_')}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """Start args.gpus fresh rank processes (this process has not touched the GPU and never will) and relay rank 0's line."""
+    import torch
+    ndev = torch.cuda.device_count()        # counts devices without initialising the runtime
+    n = args.gpus
+    if ndev < n and not args.share_gpu:
+        raise SystemExit('bench.py --gpus %d: only %d GPU(s) visible (pass --share-gpu for a functional run of the N>1 '
+                         'path with ranks sharing devices over gloo)' % (n, ndev))
+    if ndev < 1:
+        raise SystemExit('bench.py needs an MI355X (no CPU execution path exists for the product)')
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r % ndev), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        if ndev < n:
+            env['BTS_BENCH_SHARED_DEVICES'] = str(ndev)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [c for c in codes if c != 0]
+    if bad:
+        raise SystemExit('rank exit codes %s' % codes)
 
 
 def main():
@@ -97,29 +168,45 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--crop', type=int, default=128)
     ap.add_argument('--batch', type=int, default=1, help='samples per GPU')
+    ap.add_argument('--share-gpu', action='store_true', help='let ranks share devices (gloo); functional check only')
+    ap.add_argument('--allow-overrides', action='store_true', help='run although BTS_* A/B switches are set')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-crop', type=int, default=128)
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
-        _cpu_baseline_worker()
+        _cpu_baseline_worker(args.crop)
         return
+    overrides = active_overrides()
+    if overrides and not args.allow_overrides:
+        raise SystemExit('bench.py measures the product defaults; unset %s or pass --allow-overrides (they are then listed '
+                         'in the JSON line)' % ', '.join(overrides))
+
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is None and args.gpus > 1:
+        launch_ranks(args, sys.argv[1:])
+        return
+    world = int(env_world) if env_world is not None else 1
+    if world != args.gpus:
+        raise SystemExit('bench.py --gpus %d but WORLD_SIZE=%d: refusing to report a %d-rank run as %d GPUs'
+                         % (args.gpus, world, world, args.gpus))
 
     import torch
     import bts_amd  # noqa: F401
     from bts_amd import ops, parallel
+    from bts_amd.data import synthetic_batch
     from bts_amd.model import Model
     from bts_amd.util import DiceCoefficient, DiceVAELoss, ScheduledOptim, train_step
-    from oracle import torch_ref as R   # synthetic input generator only
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU execution path exists for the product)')
-    world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    shared = os.environ.get('BTS_BENCH_SHARED_DEVICES')
     torch.cuda.set_device(local)
     if world > 1 or os.environ.get('BTS_FORCE_PG'):   # BTS_FORCE_PG=1: 1-rank RCCL group, smoke-tests the N>1 code path
-        parallel.init_from_env('nccl')
+        parallel.init_from_env('gloo' if shared else 'nccl')
     dev = torch.device('cuda', local)
 
     crop = (args.crop,) * 3
@@ -128,7 +215,7 @@ def main():
     model = Model(**kw)
     model.build((nb,) + crop + (2,))
     parallel.broadcast_parameters(model)
-    x, y, _, _ = R.synthetic_batch(nb, crop, latent=128, seed=1234 + rank)
+    x, y, _, _ = synthetic_batch(nb, crop, latent=128, seed=1234 + rank)
     x, y = x.to(dev), y.to(dev)
     opt = ScheduledOptim(1e-4)
     opt(epoch=0)
@@ -142,7 +229,7 @@ def main():
     torch.cuda.synchronize()
     do_prof = (not args.no_profile)
     if do_prof:
-        ops.profile_enable(True)   # HIP events on the launch stream around every igemm_kernel / wgrad_kernel launch
+        ops.profile_enable(True)   # HIP events on the launch stream around every conv / weight-gradient launch
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, macro, micro = train_step(model, opt, loss_fn, dice_fn, x, y)
@@ -151,10 +238,16 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    ranks_seen = 1
     if parallel.active():
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64)
+        one = torch.ones(1, dtype=torch.float64)
+        if torch.distributed.get_backend() != 'gloo':
+            tt, one = tt.to(dev), one.to(dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(one, op=torch.distributed.ReduceOp.SUM)
         dt = float(tt.item())
+        ranks_seen = int(round(float(one.item())))
     prof = None
     if do_prof:
         ops.profile_enable(False)
@@ -164,10 +257,12 @@ def main():
         if parallel.active():
             torch.distributed.destroy_process_group()
         return
-    volumes = world * nb * args.steps
+    volumes = ranks_seen * nb * args.steps
+    n_gpus = min(world, int(shared)) if shared else world
     out = {
         'metric': 'training volumes/sec (2ch x %d^3)' % args.crop, 'value': volumes / dt, 'unit': 'volumes/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+        'n_gpus': n_gpus, 'ranks_seen': ranks_seen, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * dt / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[1]: 2ch x %d^3, batch %d per GPU, fp32, full fwd+bwd with '
                                'Dice+KL+L2 VAE loss + Dice metric + TF-form Adam; CLI-default model '
@@ -175,6 +270,10 @@ def main():
                    'parallelism': 'dp%d' % world, 'global_batch': world * nb},
         'loss': float(loss), 'macro_dice': float(macro),
     }
+    if shared:
+        out['config']['note'] = '%d ranks sharing %s device(s) over gloo: functional check of the N>1 path' % (world, shared)
+    if overrides:
+        out['overrides'] = overrides
     if do_prof and prof:
         agg = {}
         for sym, flops, ms in prof:
@@ -184,27 +283,32 @@ def main():
             a[2] += 1
         dom = max(agg.items(), key=lambda kv: kv[1][0])
         sym, (tsec, fl, nl) = dom
-        ach = fl / tsec / 1e12
-        traffic, tsrc = pmc_traffic_bytes(sym)
+        alg = fl / tsec / 1e12                     # ALGORITHMIC (direct-form) FLOP rate
+        wino = sym in ('wino_kernel', 'wgw_kernel')
+        ach = alg * (WINOGRAD_EXECUTED if wino else 1.0)   # what the matrix pipe executes
+        traffic = pmc_traffic(sym)
+        t_launch = tsec / nl
+        # which roofline bounds it: time the executed FLOPs need at the matrix peak vs time the measured HBM traffic needs
+        t_mfma = (fl / nl) * (WINOGRAD_EXECUTED if wino else 1.0) / (PEAK_F32_MFMA_TFLOPS * 1e12)
+        t_hbm = (traffic['bytes'] / (PEAK_HBM_TBS * 1e12)) if traffic else 0.0
         out['roofline'] = {
-            'kernel': sym, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': tsrc,
-            'launches_per_step': nl / args.steps, 'avg_launch_ms': 1e3 * tsec / nl,
+            'kernel': sym, 'bound': 'mfma' if t_mfma >= t_hbm else 'hbm',
+            'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
+            'achieved_algorithmic': alg, 'frac_algorithmic': alg / PEAK_F32_MFMA_TFLOPS,
+            'traffic': traffic['bytes'] if traffic else None, 'traffic_detail': traffic,
+            'hbm_frac_of_launch': (t_hbm / t_launch) if traffic else None,
+            'launches_per_step': nl / args.steps, 'avg_launch_ms': 1e3 * t_launch,
             'algorithmic_gflop_per_launch': fl / nl / 1e9,
             'time_share_of_step': tsec / dt,
         }
-        if sym in ('wino_kernel', 'wgw_kernel'):
-            # the Winograd form issues 12 matrix instructions where the direct form needs 27: `achieved` follows the
-            # contract (ALGORITHMIC direct-conv FLOPs / time) and can exceed the pipe's peak; the rate the matrix pipe
-            # really executes, and its fraction of the peak, are reported next to it
-            out['roofline']['executed'] = ach * 12.0 / 27.0
-            out['roofline']['executed_frac'] = ach * 12.0 / 27.0 / PEAK_F32_MFMA_TFLOPS
-            out['roofline']['note'] = ('Winograd F(2x2,3x3) x direct: 12/27 of the algorithmic MACs are executed; '
-                                       'frac > 1 means faster than any direct-form kernel could be')
+        if wino:
+            out['roofline']['note'] = ('Winograd F(2x2,3x3) x direct issues 12 matrix instructions per 27 algorithmic MACs: '
+                                       '`achieved`/`frac` are the EXECUTED rate (what is left to gain); *_algorithmic is '
+                                       'direct-form FLOPs / time and may exceed the peak')
         out['kernel_breakdown'] = {k: {'ms_per_step': 1e3 * v[0] / args.steps, 'tflops': v[1] / v[0] / 1e12,
                                        'launches_per_step': v[2] / args.steps} for k, v in sorted(agg.items())}
     if world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline()
+        out['cpu_baseline'] = cpu_baseline(args.cpu_baseline_crop)
     print(json.dumps(out), flush=True)
     if parallel.active():
         torch.distributed.destroy_process_group()

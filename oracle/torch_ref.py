@@ -456,6 +456,47 @@ def train_step(P, cfg, x, y, mask, eps, state, lr, step):
     return loss.detach(), macro, micro, gd, (y_pred.detach(), y_vae.detach(), z_mean.detach(), z_logvar.detach())
 
 
+def eval_step(P, cfg, x, y, eps):
+    """One validation iteration, train.py:166-173: forward with training=False (the input Dropout is the identity,
+    encoder.py:71; the VAE still draws eps, vae.py:9-13,127), loss incl. the regularisers, Dice.  No gradient."""
+    with torch.no_grad():
+        y_pred, y_vae, z_mean, z_logvar = model(x, P, cfg, training=False, inference=False, mask=None, eps=eps)
+        loss = dice_vae_loss(x, y, y_pred, y_vae, z_mean, z_logvar, cfg['data_format']) + l2_regularisation(P)
+        macro, micro, _ = dice_coefficient(y, y_pred, cfg['data_format'])
+    return loss, macro, micro
+
+
+def fit(P, cfg, train, val, n_epochs, init_lr, schedule_epochs=300, start_epoch=0, state=None, step=0):
+    """The epoch loop of train.py:133-181 on explicit draws.  train: list of (x, y, mask, eps); val: list of (x, y, eps).
+    Per epoch: lr = scheduled_lr(init_lr, epoch) (train.py:136, util.py:82-84; n_epochs=300 is ScheduledOptim's default
+    because train.py:105 does not pass it), one train_step per training batch, one eval_step per validation batch; the
+    six metrics are tf.keras.metrics.Mean = float32 running total / count (train.py:109-114,155-157,174-176).
+    Returns (rows, state, step): rows = [{epoch, lr, train_loss, train_macro_dice, ..., val_micro_dice}]."""
+    import numpy as np
+    state = {} if state is None else state
+    rows = []
+    for epoch in range(start_epoch, n_epochs):
+        lr = scheduled_lr(init_lr, epoch, schedule_epochs)
+        acc = {k: [np.float32(0.0), 0] for k in ('train_loss', 'train_macro_dice', 'train_micro_dice', 'val_loss',
+                                                 'val_macro_dice', 'val_micro_dice')}
+
+        def upd(key, v):
+            acc[key][0] = np.float32(acc[key][0] + np.float32(float(v)))
+            acc[key][1] += 1
+
+        for x, y, mask, eps in train:
+            step += 1
+            loss, macro, micro, _, _ = train_step(P, cfg, x, y, mask, eps, state, lr, step)
+            upd('train_loss', loss), upd('train_macro_dice', macro), upd('train_micro_dice', micro)
+        for x, y, eps in val:
+            loss, macro, micro = eval_step(P, cfg, x, y, eps)
+            upd('val_loss', loss), upd('val_macro_dice', macro), upd('val_micro_dice', micro)
+        row = {'epoch': epoch, 'lr': np.float32(lr)}
+        row.update({k: np.float32(t / np.float32(max(n, 1))) for k, (t, n) in acc.items()})
+        rows.append(row)
+    return rows, state, step
+
+
 # --------------------------------------------------------------------------------------------------
 # synthetic data of SURVEY 8(d)
 # --------------------------------------------------------------------------------------------------

@@ -1,6 +1,7 @@
 """CPU: host-side mirror of the reference's call surface (model.py / layers.* / util.py): constructor kwargs and
 defaults, lazy build, variable inventory, error behaviour, and that the product fails loudly without a GPU."""
 import inspect
+import os
 import math
 
 import pytest
@@ -132,3 +133,38 @@ def test_grad_sync_bucket_bookkeeping():
         nb = len(gs.by_param[id(p)])
         assert nb >= 1 and nb == len([1 for off, ln, _ in gs.buckets if o < off + ln and o + l > off])
     assert sum(l for _, l in gs.spans.values()) == m.n_params
+
+
+def test_package_synthetic_batch_is_the_oracles():
+    """bench.py draws its volumes from the package (bts_amd.data.synthetic_batch); the parity tests draw theirs from the
+    oracle's generator: same seeds must give the same tensors"""
+    from bts_amd.data import synthetic_batch
+    from oracle import torch_ref as R
+    for n, crop, latent, seed in ((1, (16, 16, 16), 128, 1234), (2, (8, 16, 8), 4, 77)):
+        a = synthetic_batch(n, crop, latent=latent, seed=seed)
+        b = R.synthetic_batch(n, crop, latent=latent, seed=seed)
+        assert all(torch.equal(u, v) for u, v in zip(a, b))
+
+
+def _bench(args, env_extra, drop=()):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if not k.startswith('BTS_') and k not in drop}
+    env.update(env_extra)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + args, env=env, cwd=root, capture_output=True,
+                          text=True, timeout=300)
+
+
+def test_bench_refuses_world_size_mismatch_and_overrides():
+    """`--gpus N` used to be ignored.  As a rank (WORLD_SIZE set) a mismatch is refused; A/B switches in the
+    environment are refused unless explicitly allowed; as a launcher with no GPU it fails loudly instead of falling back"""
+    r = _bench(['--gpus', '2'], {'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in r.stderr
+    r = _bench(['--gpus', '1'], {'WORLD_SIZE': '4', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert r.returncode != 0 and 'WORLD_SIZE=4' in r.stderr
+    r = _bench([], {'BTS_WINO': '0'}, drop=('WORLD_SIZE',))
+    assert r.returncode != 0 and 'BTS_WINO' in r.stderr and '--allow-overrides' in r.stderr
+    if not torch.cuda.is_available():
+        r = _bench(['--gpus', '2'], {}, drop=('WORLD_SIZE', 'RANK', 'LOCAL_RANK'))
+        assert r.returncode != 0 and 'GPU' in r.stderr

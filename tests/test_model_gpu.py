@@ -14,6 +14,9 @@ CONFIGS = {
     'tiny': (dict(base_filters=16, groups=8, reduction=2, depth=3), (32, 32, 32), 1),
     'cli_small': (dict(base_filters=32, groups=8, reduction=8, depth=4), (16, 16, 16), 1),
     'cli_32': (dict(base_filters=32, groups=8, reduction=8, depth=4), (32, 32, 32), 1),
+    # the largest grid the fp64 oracle finishes in test time (~1 min of host CPU for its fp64 + fp32 evaluations): at 64^3 the
+    # dispatcher already picks the big-grid conv forms for the top two levels
+    'cli_64': (dict(base_filters=32, groups=8, reduction=8, depth=4), (64, 64, 64), 1),
 }
 
 

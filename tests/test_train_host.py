@@ -96,7 +96,7 @@ def test_fit_with_stub_steps_writes_reference_log_and_stops(tmp_path):
             return super().__iter__()
 
     orig = T.save_checkpoint
-    T.save_checkpoint = lambda folder, m, o=None: saved.append(int(m.epoch.value().numpy()))
+    T.save_checkpoint = lambda folder, m, o=None, **kw: saved.append(int(m.epoch.value().numpy()))
     try:
         hist = T.fit(model, opt, None, None, [(1.0, 0), (3.0, 0)], Data([(0, 0), (0, 0)]), n_epochs=10, patience=2,
                      save_folder=str(tmp_path), train_step_fn=tstep, eval_step_fn=estep, log=lambda s: None)
@@ -152,6 +152,66 @@ def test_checkpoint_container_round_trip(tmp_path):
     m3.build((1, 8, 8, 8, 2))
     with pytest.raises((KeyError, ValueError)):
         T.load_checkpoint(str(tmp_path), m3)
+
+
+def test_checkpoint_of_a_finished_epoch_resumes_at_the_next_one(tmp_path):
+    """fit() saves after the epoch's last step: the container says next_epoch = epoch + 1, carries the patience tracker
+    and the datasets' generator states, and the resumed fit() starts there with all three restored"""
+    from bts_amd import data as D
+    m = Model(base_filters=8, reduction=2, depth=2, groups=2)
+    m.build((1, 8, 8, 8, 2))
+    m.epoch.assign(4)
+    tr = T.PatienceTracker(5)
+    tr.best, tr.patience = 0.625, 3
+    ds = D._Dataset(['a', 'b', 'c'], 1, (8, 8, 8, 2), (8, 8, 8), 3, True, seed=3, device='cpu')
+    torch.randperm(3, generator=ds.order_gen)                    # advance both generators past their seeds
+    torch.rand(5, generator=ds.gen)
+    want = (torch.randperm(3, generator=torch.Generator().set_state(ds.order_gen.get_state())).tolist(),
+            torch.rand(4, generator=torch.Generator().set_state(ds.gen.get_state())).tolist())
+    meta = T.save_checkpoint(str(tmp_path), m, None, completed=True, tracker=tr, datasets={'train': ds, 'val': [1, 2]})
+    assert meta['epoch'] == 4 and meta['next_epoch'] == 5 and meta['tracker'] == {'best': 0.625, 'patience': 3}
+
+    m2 = Model(base_filters=8, reduction=2, depth=2, groups=2)
+    m2.build((1, 8, 8, 8, 2))
+    T.load_checkpoint(str(tmp_path), m2)
+    assert int(m2.epoch.value().numpy()) == 5
+    ds2 = D._Dataset(['a', 'b', 'c'], 1, (8, 8, 8, 2), (8, 8, 8), 3, True, seed=999, device='cpu')
+    seen = {}
+
+    def estep(x, y):
+        return torch.tensor([1.0]), torch.tensor([0.5]), torch.tensor([0.5])    # 0.5 < restored best 0.625 -> no save
+
+    class Probe(list):
+        def load_state_dict(self, st):
+            seen['loaded'] = True
+            ds2.load_state_dict(st)
+
+    orig = T.save_checkpoint
+    saves = []
+    T.save_checkpoint = lambda *a, **k: saves.append(1)
+    try:
+        hist = T.fit(m2, ScheduledOptim(1e-4, n_epochs=8), None, None, Probe([(0, 0)]), [(0, 0)], n_epochs=6, patience=5,
+                     save_folder=str(tmp_path / 'out'), train_step_fn=estep, eval_step_fn=estep, log=lambda s: None)
+    finally:
+        T.save_checkpoint = orig
+    assert [h['epoch'] for h in hist] == [5] and saves == [] and seen.get('loaded')
+    assert torch.randperm(3, generator=ds2.order_gen).tolist() == want[0]
+    assert torch.rand(4, generator=ds2.gen).tolist() == want[1]
+
+
+def test_dataset_shards_by_rank_with_equal_lengths():
+    from bts_amd import data as D
+    files = ['f%d' % i for i in range(7)]
+    shards = []
+    for r in range(2):
+        ds = D._Dataset(files, 2, (8, 8, 8, 2), (8, 8, 8), 3, True, seed=5, device='cpu', rank=r, world=2)
+        assert len(ds) == 2                                     # 7 // 2 = 3 examples per rank -> 2 batches of <= 2
+        order = torch.randperm(7, generator=ds.order_gen).tolist()
+        shards.append(order[r::2][:3])
+    assert len(shards[0]) == len(shards[1]) == 3 and not set(shards[0]) & set(shards[1])
+    g0 = D._Dataset(files, 2, (8, 8, 8, 2), (8, 8, 8), 3, True, seed=5, device='cpu', rank=0, world=2).gen
+    g1 = D._Dataset(files, 2, (8, 8, 8, 2), (8, 8, 8), 3, True, seed=5, device='cpu', rank=1, world=2).gen
+    assert torch.rand(4, generator=g0).tolist() != torch.rand(4, generator=g1).tolist()   # per-rank augmentation draws
 
 
 def test_train_args_round_trip(tmp_path):
