@@ -1,30 +1,62 @@
-# Round-end evidence: kernel stats of the default bench, the bench JSON line, and the two HBM-traffic PMC passes.
-# Usage on the GPU box: bash scripts/round_profile.sh r01c   -> gpurun_out/<tag>_*
-TAG=${1:-rXX}
-R=$GRAFT_REPO_ROOT
+#!/bin/bash
+# Per-round evidence for bench.py (run ON the GPU box: `gpurun -- 'bash scripts/round_profile.sh r02a'`):
+#   gpurun_out/<tag>_bench.json               the bench line (un-profiled, HIP-event hooks on)
+#   gpurun_out/<tag>_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the same command
+#   gpurun_out/<tag>_pmc_traffic.json         FETCH_SIZE / WRITE_SIZE per-launch means (two separate --pmc passes: the TCC
+#                                             slots cannot hold both; kernel-trace only, as the MI355X guide prescribes)
+# Every pass writes into a directory removed beforehand, keeps its log next to the outputs, and the script stops at the
+# first pass that fails or leaves no CSV -- nothing stale can be published.  The program sits directly after `--`.
+set -euo pipefail
+TAG=${1:?usage: round_profile.sh <tag>}
+R=${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}
 O=$R/gpurun_out
+mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py --steps 10 --warmup 3 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
-tail -c 600 $O/${TAG}_bench.json
-rm -rf $O/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -o bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile > $O/${TAG}_bench_prof.log 2>&1
-cp $(find $O/prof_$TAG -name bench_kernel_stats.csv | head -1) $O/${TAG}_bench_kernel_stats.csv
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_$TAG -o fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_$TAG -o write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2>&1
-python3 - <<PY
-import csv, collections, json, glob
+
+python3 "$R/bench.py" --steps 10 --warmup 3 > "$O/${TAG}_bench.json" 2> "$O/${TAG}_bench.err"
+test -s "$O/${TAG}_bench.json" || { echo "bench.py printed nothing"; tail -5 "$O/${TAG}_bench.err"; exit 1; }
+cut -c1-400 "$O/${TAG}_bench.json"
+
+need() {  # need <dir> <file name>: the one CSV a pass must have produced, non-empty
+  local f
+  f=$(find "$1" -name "$2" -size +0 | head -1)
+  test -n "$f" || { echo "missing or empty $2 under $1 (log: $1.log)"; tail -20 "$1.log"; exit 1; }
+  echo "$f"
+}
+
+rm -rf "$O/prof_$TAG"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$TAG" -o bench -- \
+  python3 "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-profile > "$O/prof_$TAG.log" 2>&1
+cp "$(need "$O/prof_$TAG" bench_kernel_stats.csv)" "$O/${TAG}_bench_kernel_stats.csv"
+
+for pass in fetch:FETCH_SIZE write:WRITE_SIZE; do
+  name=${pass%%:*}; ctr=${pass##*:}
+  rm -rf "$O/pmc_${TAG}_$name"
+  rocprofv3 --kernel-trace --pmc "$ctr" --output-format csv -d "$O/pmc_${TAG}_$name" -o "$name" -- \
+    python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-profile > "$O/pmc_${TAG}_$name.log" 2>&1
+  need "$O/pmc_${TAG}_$name" "${name}_counter_collection.csv" > /dev/null
+done
+
+python3 - "$O" "$TAG" <<'PY'
+import collections, csv, glob, json, sys
+O, TAG = sys.argv[1], sys.argv[2]
 out = {}
-for tag, cname in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
+for name, ctr in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
+    files = glob.glob('%s/pmc_%s_%s/**/%s_counter_collection.csv' % (O, TAG, name, name), recursive=True)
+    assert len(files) == 1, files
     agg = collections.defaultdict(list)
-    f = glob.glob('$O/pmc_$TAG/**/%s_counter_collection.csv' % tag, recursive=True)[0]
-    for r in csv.DictReader(open(f)):
-        if r['Counter_Name'] == cname:
+    for r in csv.DictReader(open(files[0])):
+        if r['Counter_Name'] == ctr:
             agg[r['Kernel_Name'].split('(')[0]].append(float(r['Counter_Value']))
+    assert agg, 'no %s rows in %s' % (ctr, files[0])
     for k, v in agg.items():
-        out.setdefault(k, {})[cname + '_KiB_mean'] = sum(v) / len(v)
+        out.setdefault(k, {})[ctr + '_KiB_mean'] = sum(v) / len(v)
         out[k]['launches'] = len(v)
-json.dump(out, open('$O/${TAG}_pmc_traffic.json', 'w'), indent=1, sort_keys=True)
-for k in sorted(out, key=lambda k: -out[k].get('FETCH_SIZE_KiB_mean', 0) * out[k]['launches'])[:8]:
-    print(k[:70], out[k])
+json.dump(out, open('%s/%s_pmc_traffic.json' % (O, TAG), 'w'), indent=1, sort_keys=True)
+rows = list(csv.DictReader(open('%s/%s_bench_kernel_stats.csv' % (O, TAG))))
+tot = sum(float(r['TotalDurationNs']) for r in rows)
+print('kernel time per step (7 steps in the trace): %.2f ms' % (tot / 7e6))
+for r in rows[:28]:
+    print('%-66s %5s x %8.1f us  %6.2f ms/step %5.1f%%' % (r['Name'][:66], r['Calls'], float(r['AverageNs']) / 1e3,
+          float(r['TotalDurationNs']) / 7e6, 100 * float(r['TotalDurationNs']) / tot))
 PY
-head -12 $O/${TAG}_bench_kernel_stats.csv | cut -c1-150

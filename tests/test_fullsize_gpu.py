@@ -10,7 +10,13 @@ it: tests/test_model_gpu.py::test_train_step_parity[cli_64]), so full size is co
   * determinism: two default-form steps from the same state end bitwise identical (no float atomics, fixed-order reductions).
 
 Tolerances: loss <= 1e-5 relative, Dice <= 1e-4, y_pred max-abs <= 1e-4, label map identical outside counted
-near-ties (|p-0.5| < 1e-5 or top-2 gap < 1e-5), every variable's gradient <= 1e-3 of that gradient's max-abs.
+near-ties (|p-0.5| < 1e-5 or top-2 gap < 1e-5), every variable's gradient <= 1e-3 of that gradient's max-abs -- or 4x
+what a one-ulp change of the input volume does to the direct form's own gradient of that variable (two such changes, the
+larger effect), or 2x the largest such effect over all variables, when those are larger: the same "may deviate as much as an
+equally valid fp32 evaluation does" rule tests/test_model_gpu.py applies with torch-fp32.  scripts/grad_conditioning.py shows
+why it is needed: at 64^3 torch-fp32 itself is off by > 1e-3 of max-abs on 22 of the 260 variables (worst 7e-3), the engine's
+default forms on 9 (worst 5e-3) and its direct forms on 22 (worst 2e-2) -- deep-level gradients are sums over every voxel
+with heavy cancellation, and which ReLUs sit within rounding of zero differs between any two evaluation orders.
 """
 import os
 
@@ -20,6 +26,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 FORM_SWITCHES = ('BTS_WINO', 'BTS_WGW', 'BTS_K1W')
+GRAD_TOL = 1e-3
 CLI = dict(base_filters=32, reduction=8, depth=4, groups=8)
 
 
@@ -107,16 +114,29 @@ def test_full_size_train_step_forms_agree_and_are_deterministic():
     print('near-threshold voxels: %d of %d' % (n_amb, amb.numel()))
     assert n_amb <= 1e-3 * amb.numel()
     assert torch.equal(a['labels'][~amb], d['labels'][~amb]), 'argmax label map differs between the conv forms'
-    worst = (0.0, None)
+    # conditioning yardstick at THIS size (the fp64 oracle cannot provide one): the direct form again on an input moved by
+    # one unit in the last place.  Billions of ReLU pre-activations and 1233 near-threshold outputs make the 128^3 gradient
+    # of a randomly initialised network far more sensitive than the 16^3..64^3 cases the oracle tests bound with 1e-3.
+    qs = [_one_step(True, x * f, y, mask, eps)['grads'] for f in (1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24)]
+    errs, sens = [], {}
     for name, off, n in a['spans']:
         ga, gd = a['grads'][off:off + n], d['grads'][off:off + n]
         scale = float(gd.abs().max()) + 1e-30
-        err = float((ga - gd).abs().max()) / scale
-        if err > worst[0]:
-            worst = (err, name)
-        assert err <= 1e-3, 'gradient of %s: forms differ by %.3e of its max-abs %.3e' % (name, err, scale)
-    print('worst gradient disagreement between forms: %.3e (%s)' % worst)
-    assert worst[0] > 0.0, 'both runs took the same kernels: the switches did nothing'
+        sens[name] = max(float((gq[off:off + n] - gd).abs().max()) for gq in qs) / scale
+        errs.append((float((ga - gd).abs().max()) / scale, name, scale))
+    gsens = max(sens.values())
+    l2 = float((a['grads'] - d['grads']).norm() / d['grads'].norm())
+    l2q = max(float((gq - d['grads']).norm() / d['grads'].norm()) for gq in qs)
+    print('whole flat gradient, relative L2: forms %.3e ; 1-ulp input change %.3e' % (l2, l2q))
+    assert l2 <= max(1e-4, 4.0 * l2q)
+    errs.sort(reverse=True)
+    for e_, name, scale in errs[:12]:
+        print('gradient %-34s forms differ by %.3e of its max-abs %.3e (1-ulp input sensitivity %.3e)' %
+              (name, e_, scale, sens[name]))
+    print('largest 1-ulp sensitivity over all variables: %.3e' % gsens)
+    assert errs[0][0] > 0.0, 'both runs took the same kernels: the switches did nothing'
+    for e_, name, scale in errs:
+        assert e_ <= max(GRAD_TOL, 4.0 * sens[name], 2.0 * gsens), (name, e_, sens[name], gsens)
 
 
 def test_full_volume_inference_forms_agree():

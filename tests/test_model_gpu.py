@@ -98,7 +98,10 @@ def test_train_step_parity(name):
     assert abs(float(macro) - float(macro_r)) <= 1e-4 and abs(float(micro) - float(micro_r)) <= 1e-4
     # gradients
     worst = (0.0, None)
-    # global conditioning of this configuration: worst fp32-vs-fp64 deviation of torch itself over all variables
+    # global conditioning of this configuration: worst fp32-vs-fp64 deviation of torch itself over all variables.  A variable
+    # may deviate as much as torch-fp32 does on ITS worst variable: at the CLI model's 64^3 case torch-fp32 is off by > 1e-3 on
+    # 22 of 260 variables (worst 7e-3), the engine on 9 (worst 5e-3, a GroupNorm beta of a 16^3 level: 4096 terms per channel,
+    # one ReLU within rounding of zero moves it by a whole term) -- scripts/grad_conditioning.py prints the table
     gdev = max(maxerr(grads_32[k], grads_r[k]) / (float(grads_r[k].abs().max()) + 1e-12) for k in grads_r)
     for p, g in zip(model.trainable_variables, grads):
         assert g is not None, p.name
@@ -108,9 +111,16 @@ def test_train_step_parity(name):
         if err > worst[0]:
             worst = (err, p.name)
         dev32 = maxerr(grads_32[model.oracle_name(p)], gr) / scale
-        assert err <= max(1e-3, 4 * dev32, 0.25 * gdev) or maxerr(g, gr) <= 1e-9, \
+        assert err <= max(1e-3, 4 * dev32, gdev) or maxerr(g, gr) <= 1e-9, \
             'grad %s rel err %.3e (fp32-torch deviates %.3e; scale %.3e)' % (p.name, err, dev32, scale)
     print('worst grad rel err', worst)
+    # aggregate bound, insensitive to WHICH pre-activations sit within rounding of zero: the whole gradient in relative L2
+    num = sum(float((g.detach().double().cpu() - grads_r[model.oracle_name(p)]).pow(2).sum())
+              for p, g in zip(model.trainable_variables, grads)) ** 0.5
+    num32 = sum(float((grads_32[k].double() - grads_r[k]).pow(2).sum()) for k in grads_r) ** 0.5
+    den = sum(float(grads_r[k].pow(2).sum()) for k in grads_r) ** 0.5
+    print('whole-gradient relative L2 error: engine %.3e, torch-fp32 %.3e' % (num / den, num32 / den))
+    assert num / den <= max(1e-4, 2.0 * num32 / den)
     # one Adam step (TF form)
     opt = ScheduledOptim(learning_rate=1e-4)
     opt(epoch=0)
@@ -213,7 +223,7 @@ def test_channels_first_public_layout_parity(name):
         scale = float(gr.abs().max()) + 1e-12
         err = maxerr(g, gr) / scale
         dev32 = maxerr(grads_32[model.oracle_name(p)], gr) / scale
-        assert err <= max(1e-3, 4 * dev32, 0.25 * gdev) or maxerr(g, gr) <= 1e-9, \
+        assert err <= max(1e-3, 4 * dev32, gdev) or maxerr(g, gr) <= 1e-9, \
             'grad %s rel err %.3e (fp32-torch deviates %.3e)' % (p.name, err, dev32)
 
 
@@ -260,5 +270,5 @@ def test_non_default_samplers_parity(samplers):
         scale = float(gr.abs().max()) + 1e-12
         err = maxerr(g, gr) / scale
         dev32 = maxerr(grads_32[model.oracle_name(p)], gr) / scale
-        assert err <= max(1e-3, 4 * dev32, 0.25 * gdev) or maxerr(g, gr) <= 1e-9, \
+        assert err <= max(1e-3, 4 * dev32, gdev) or maxerr(g, gr) <= 1e-9, \
             'grad %s rel err %.3e (fp32-torch deviates %.3e)' % (p.name, err, dev32)
