@@ -22,12 +22,26 @@
 // (measured max |err| 5e-6 at |y| ~ 3, K = 864); the summation order is fixed (deterministic).
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "bts_internal.h"
 
 int bts_prof_on();
 void bts_prof_begin(int sym, double flops, hipStream_t stream);
 void bts_prof_end(hipStream_t stream);
+
+#ifdef BTS_WINO_STAMPS   // experiment builds only (scripts/wino_timeline.py): per-item clock stamps of wave 0
+__device__ long long g_wino_stamps[1 << 20];
+extern "C" int bts_wino_stamps_copy_(long long* dst, long n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wino_stamps), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
+}
+#define WSTAMP(slot)                                                                              \
+  do {                                                                                            \
+    if (tid == 0) g_wino_stamps[((long)blockIdx.x * p.T + it) * 16 + (slot)] = wall_clock64();    \
+  } while (0)
+#else
+#define WSTAMP(slot) do { } while (0)
+#endif
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -47,10 +61,14 @@ struct WinoParams {
   int ksplit, kg_per, Npad;
   float* part;
   int nb, ntiles, tiles_per_xcd;   // cout blocks of 32; tiles = N * ntz * nty * ntx
+  int T;                           // (tile, cout block) items one workgroup walks back to back
 };
 
 #define WS 12      // dwords per staged voxel: 8 channels + 4 pad (16-byte-odd stride, conflict-free ds_read_b128)
 #define WNSLOT 10  // staging slots (16 bytes) per thread and stage
+#ifndef WPF
+#define WPF 2      // groups of 16 matrix instructions a U fragment is requested ahead of its use
+#endif
 // Tile geometry.  XW = 32: a wave's 32 matrix columns are 32 x positions of one 2x2 (z, y) patch row; tile 32 x 4 x 4.
 // XW = 16 (grids narrower than 32): the columns are 16 x positions of TWO y patches; tile 16 x 8 x 4.  The LDS row
 // stride LX is padded to 24 voxels there: two patch rows are then a multiple of 64 dwords apart and the two halves of a
@@ -98,11 +116,21 @@ __device__ __forceinline__ void wino_yt(const f32x4 (&c)[4], f32x4 (&v)[4]) {
   v[3] = sub4(c[1], c[3]);
 }
 // one group: xi_z fixed, 4 xi_y values, 4 channel pairs -> 16 MFMAs (A = U rows = couts, B = transformed input columns = x)
+// ZERO: the accumulators are not read by their first matrix instruction (C = literal 0) -- the first group of each xi_z in an
+// item's first stage starts the sums this way, so the 256 accumulation registers are never cleared by separate writes
+template <bool ZERO>
 __device__ __forceinline__ void wino_mfma16(const f32x4 (&v)[4], const f32x4 (&a)[4], f32x16 (&acc)[4]) {
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e][j], v[e][j], acc[e], 0, 0, 0);
+    for (int e = 0; e < 4; ++e) {
+      if (ZERO && j == 0) {
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e][j], v[e][j], z, 0, 0, 0);
+      } else {
+        acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e][j], v[e][j], acc[e], 0, 0, 0);
+      }
+    }
 }
 // accumulator element -> vector register, pinned in program order (volatile): the compiler otherwise reads all 256
 // accumulation registers at the loop exit and spills what does not fit
@@ -127,40 +155,32 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l32 = lane & 31;
-  // 1-D grid over (tile, cout block).  Workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2): XCD k walks
-  // its own contiguous eighth of the tiles, the cout blocks of a tile back to back -- x / y / z neighbours (a third of every
-  // halo tile each) and the second cout block find their data in the XCD's L2 instead of behind the fabric
+  // 1-D grid over (tile, cout block) ITEMS.  Workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2): XCD k
+  // walks its own contiguous eighth of the tiles, the cout blocks of a tile back to back -- x / y / z neighbours (a third of
+  // every halo tile each) and the second cout block find their data in the XCD's L2 instead of behind the fabric.  One
+  // workgroup takes p.T consecutive items of its XCD's sequence: the first halo tile and weight fragments of item i+1 are
+  // requested BEFORE the output transform / stores of item i, so only a workgroup's first item pays the fetch latency with
+  // the matrix pipe idle (one wave per SIMD: nothing else on the CU could hide it).
   const int nb_ = p.nb;
-  const int xcd_ = blockIdx.x & 7, seq_ = blockIdx.x >> 3;
-  const int cb = seq_ % nb_;
-  int b = xcd_ * p.tiles_per_xcd + seq_ / nb_;
-  if (seq_ / nb_ >= p.tiles_per_xcd || b >= p.ntiles) return;   // (before any barrier: whole workgroups leave)
-  const int tx = b % p.ntx; b /= p.ntx;
-  const int ty = b % p.nty; b /= p.nty;
-  const int tz = b % p.ntz;
-  const int n = b / p.ntz;
-  const int oz0 = tz * 4, oy0 = ty * G_::TY, ox0 = tx * XW;
-  const int iz0 = oz0 - 1, iy0 = oy0 - 1, ix0 = ox0 - 1;
+  const int xcd_ = blockIdx.x & 7;
+  const int seq0 = (blockIdx.x >> 3) * p.T;
 
-  // halo origin of this tile; slots outside the image get a 2 GB offset = outside the descriptor -> the load returns zeros
-  const float* xorg = p.x + ((((long)n * p.D + iz0) * p.H + iy0) * p.W + ix0) * (long)p.ldx;
-  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xorg, 0, 0x7fffffff, 0x00020000);
-  // U of this cout block: [k-group][x tap][xi][h][32][4] = 1 KB per (x tap, xi) image
-  const __amdgpu_buffer_rsrc_t wr =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(p.up + (long)cb * p.KG * (3 * 16 * 256)), 0, 0x7fffffff, 0x00020000);
-  unsigned goff[WNSLOT];
+  // per-slot constants of the staging pattern (tile independent): voxel coordinates inside the halo tile and the byte
+  // offset from the tile's halo origin
+  unsigned gbase[WNSLOT], gpos[WNSLOT];
 #pragma unroll
   for (int i = 0; i < WNSLOT; ++i) {
     const int e = tid + i * 256;
-    goff[i] = 0x80000000u;
+    gbase[i] = 0x80000000u;
+    gpos[i] = 0x00ffffffu;   // (255, 255, 255): never inside an image
     if (e < G_::NSTAGE * 2) {
       const int vox = e >> 1, q = e & 1;
       const int vz = vox / (G_::IY * G_::SX);
       const int r = vox - vz * (G_::IY * G_::SX);
       const int vy = r / G_::SX;
       const int vx = r - vy * G_::SX;
-      if ((unsigned)(iz0 + vz) < (unsigned)p.D && (unsigned)(iy0 + vy) < (unsigned)p.H && (unsigned)(ix0 + vx) < (unsigned)p.W)
-        goff[i] = (unsigned)(((vz * p.H + vy) * p.W + vx) * p.ldx + q * 4) * 4u;
+      gbase[i] = (unsigned)(((vz * p.H + vy) * p.W + vx) * p.ldx + q * 4) * 4u;
+      gpos[i] = (unsigned)((vz << 16) | (vy << 8) | vx);
     }
   }
   const int tz2 = wave >> 1;
@@ -169,18 +189,69 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
   const int bbase = ((2 * tz2 * G_::IY + 2 * ty2) * G_::LX + xl) * WS + h * 4;
   const unsigned wlane = (unsigned)((h * 32 + l32) * 16);
 
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+  int st0 = 0, st1 = p.KG;
+  if (p.ksplit > 1) {
+    st0 = blockIdx.z * p.kg_per;
+    st1 = st0 + p.kg_per;
+    if (st1 > p.KG) st1 = p.KG;
+  }
 
-  f32x4 pre[WNSLOT];
-  auto fetch = [&](int st) {
+  // item coordinates (wave-uniform)
+  struct Item { int n, tz, ty, tx, cb; };
+  auto decode = [&](int seq) {
+    Item it;
+    it.cb = seq % nb_;
+    int b = xcd_ * p.tiles_per_xcd + seq / nb_;
+    it.tx = b % p.ntx; b /= p.ntx;
+    it.ty = b % p.nty; b /= p.nty;
+    it.tz = b % p.ntz;
+    it.n = b / p.ntz;
+    return it;
+  };
+  // the item after `it` in this XCD's sequence (no divisions: cout block, then x, y, z, sample); false past the last one
+  int tiles_left = p.ntiles - xcd_ * p.tiles_per_xcd;          // tiles of this XCD's eighth that exist
+  if (tiles_left > p.tiles_per_xcd) tiles_left = p.tiles_per_xcd;
+  const int items_here = tiles_left * nb_;
+  if (seq0 >= items_here) return;   // (before any barrier: whole workgroups leave)
+  auto advance = [&](Item& it) {
+    if (++it.cb < nb_) return;
+    it.cb = 0;
+    if (++it.tx < p.ntx) return;
+    it.tx = 0;
+    if (++it.ty < p.nty) return;
+    it.ty = 0;
+    if (++it.tz < p.ntz) return;
+    it.tz = 0;
+    ++it.n;
+  };
+
+  __amdgpu_buffer_rsrc_t xr, wr, wr_n;
+  unsigned goff[WNSLOT];
+  // input descriptor + per-slot offsets of an item; slots outside the image get a 2 GB offset = outside the descriptor -> zeros
+  auto setup_x = [&](const Item& it) {
+    const int iz0 = it.tz * 4 - 1, iy0 = it.ty * G_::TY - 1, ix0 = it.tx * XW - 1;
+    const float* xorg = p.x + ((((long)it.n * p.D + iz0) * p.H + iy0) * p.W + ix0) * (long)p.ldx;
+    xr = __builtin_amdgcn_make_buffer_rsrc((void*)xorg, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < WNSLOT; ++i) pre[i] = bufload(xr, goff[i], (unsigned)st * 32u);
+    for (int i = 0; i < WNSLOT; ++i) {
+      const int vz = (int)(gpos[i] >> 16), vy = (int)((gpos[i] >> 8) & 255), vx = (int)(gpos[i] & 255);
+      const bool in = (unsigned)(iz0 + vz) < (unsigned)p.D && (unsigned)(iy0 + vy) < (unsigned)p.H && (unsigned)(ix0 + vx) < (unsigned)p.W;
+      goff[i] = in ? gbase[i] : 0x80000000u;
+    }
+  };
+  // U of an item's cout block: [k-group][x tap][xi][h][32][4] = 1 KB per (x tap, xi) image
+  auto wdesc = [&](const Item& it) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(p.up + (long)it.cb * p.KG * (3 * 16 * 256)), 0, 0x7fffffff, 0x00020000);
+  };
+
+  f32x16 acc[4][4];
+  f32x4 pre[WNSLOT];
+  // soff = 0x80000000: nothing left to fetch -- every slot is then out of range (zeros, no traffic).  The requests are issued
+  // all the same: with one request count on every path the compiler's vmcnt waits stay exact, and a wait for a weight
+  // fragment never drains the stores of the previous item's output (vector memory returns in order)
+  auto fetch = [&](unsigned soff) {
+#pragma unroll
+    for (int i = 0; i < WNSLOT; ++i) pre[i] = bufload(xr, goff[i], soff);
   };
   auto commit = [&](float* buf) {
 #pragma unroll
@@ -194,189 +265,258 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WinoParams p) {
       }
     }
   };
-
-  int st0 = 0, st1 = p.KG;
-  if (p.ksplit > 1) {
-    st0 = blockIdx.z * p.kg_per;
-    st1 = st0 + p.kg_per;
-    if (st1 > p.KG) st1 = p.KG;
-  }
-  fetch(st0);
-  // U fragments of group G = st*12 + g live in aw[G % 3]; two groups are always in flight
-  f32x4 aw[3][4];
+  // U fragments of group G = st*12 + g live in aw[G % (WPF + 1)]; two groups are always in flight
+  f32x4 aw[WPF + 1][4];
   constexpr int zorder[4] = {1, 2, 0, 3};
-  auto wload = [&](f32x4 (&dst)[4], int st, int g) {
+  auto wload = [&](f32x4 (&dst)[4], const __amdgpu_buffer_rsrc_t d, int st, int g) {
     const int dx = g >> 2, xz = zorder[g & 3];
     const unsigned so = (unsigned)(((st * 3 + dx) * 16 + xz * 4) * 1024);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) dst[e] = bufload(wr, wlane + e * 1024, so);
+    for (int e = 0; e < 4; ++e) dst[e] = bufload(d, wlane + e * 1024, so);
   };
-  wload(aw[0], st0, 0);
-  wload(aw[1], st0, 1);
-  commit(lds);
-  __syncthreads();
+  double* const gsh = reinterpret_cast<double*>(lds + 2 * G_::BUF);   // GroupNorm partial exchange: past the staging buffers
+  float* const bsh = lds + 2 * G_::BUF + 16;                           // 32 bias values of the current / next item
+  float bias_v = 0.f;
+  auto bias_of = [&](const Item& it) {
+    const int co = it.cb * 32 + tid;
+    return (p.bias && p.ksplit <= 1 && tid < 32 && co < p.Cout) ? p.bias[co] : 0.f;
+  };
 
-  for (int st = st0; st < st1; ++st) {
-    const float* cur = lds + ((st - st0) & 1) * G_::BUF;
-    float* nxt = lds + ((st - st0 + 1) & 1) * G_::BUF;
-    const bool more = (st + 1) < st1;
-    if (more) fetch(st + 1);
-    const float* lb = cur + bbase;
-    const int stn = more ? st + 1 : st;  // the last stage re-requests its own first groups instead of running past the image
-    {
-      // Software pipeline: while the 16 MFMAs of group G run on v[G&1], the vector ALU forms v[(G+1)&1] -- a matrix
-      // instruction never waits for an operand written just before it.
-      f32x4 r1[4], r2[4], rt[4], c[4], v[2][4];
+  // One k-group stage: 12 groups of 16 matrix instructions on LDS buffer `par`.  FIRST: the item's first stage (accumulators
+  // start from zero).  more: the item has another stage -- its halo tile is fetched now and committed to the other buffer at
+  // the end.  chain (last stage of an item that has a successor in this workgroup; xr / goff / wr_n / bias_v already belong to
+  // the successor): the successor's FIRST halo tile and weight fragments take the place of the next stage's, so an item
+  // boundary costs what a stage boundary costs and the output transform below runs with everything it needs next in LDS.
+  auto stage = [&](auto first_tag, int st, int par, bool more, bool chain, int bias_slot) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    fetch(more ? (unsigned)(st + 1) * 32u : (chain ? (unsigned)st0 * 32u : 0x80000000u));
+    const float* lb = lds + par * G_::BUF + bbase;
+    const int stn = more ? st + 1 : st0;              // (neither more nor chain: a harmless re-request of this cout block's U)
+    const __amdgpu_buffer_rsrc_t wt = chain ? wr_n : wr;
+    // Software pipeline: while the 16 MFMAs of group G run on v[G&1], the vector ALU forms v[(G+1)&1] -- a matrix
+    // instruction never waits for an operand written just before it.
+    f32x4 r1[4], r2[4], rt[4], c[4], v[2][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        r1[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(1, j, 0));
-        r2[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(2, j, 0));
+    for (int j = 0; j < 4; ++j) {
+      r1[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(1, j, 0));
+      r2[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(2, j, 0));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = add4(r1[j], r2[j]);
+    wino_yt(c, v[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 3" ::: "memory");
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      {  // MFMA xi_z = 1 ; form xi_z = 2 : d2 - d1 ; request row 0
+        const int G = dx * 4 + 0;
+        wload(aw[(G + WPF) % (WPF + 1)], (G + WPF < 12) ? wr : wt, (G + WPF < 12) ? st : stn, (G + WPF) % 12);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rt[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(0, j, dx));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = sub4(r2[j], r1[j]);
+        wino_yt(c, v[1]);
+        if (FIRST && dx == 0) wino_mfma16<true>(v[0], aw[G % (WPF + 1)], acc[1]); else wino_mfma16<false>(v[0], aw[G % (WPF + 1)], acc[1]);
+        WINO_SCHED_GROUP();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1" ::: "memory");  // hand-written transform VALU -> next group's MFMA operand: hazard not tracked by the compiler
       }
+      {  // MFMA xi_z = 2 ; form xi_z = 0 : d0 - d2 ; then request row 3
+        const int G = dx * 4 + 1;
+        wload(aw[(G + WPF) % (WPF + 1)], (G + WPF < 12) ? wr : wt, (G + WPF < 12) ? st : stn, (G + WPF) % 12);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) c[j] = add4(r1[j], r2[j]);
-      wino_yt(c, v[0]);
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_nop 3" ::: "memory");
+        for (int j = 0; j < 4; ++j) c[j] = sub4(rt[j], r2[j]);
+        wino_yt(c, v[0]);
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        {  // MFMA xi_z = 1 ; form xi_z = 2 : d2 - d1 ; request row 0
-          const int G = dx * 4 + 0;
-          wload(aw[(G + 2) % 3], (G + 2 < 12) ? st : stn, (G + 2) % 12);
+        for (int j = 0; j < 4; ++j) rt[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(3, j, dx));
+        if (FIRST && dx == 0) wino_mfma16<true>(v[1], aw[G % (WPF + 1)], acc[2]); else wino_mfma16<false>(v[1], aw[G % (WPF + 1)], acc[2]);
+        WINO_SCHED_GROUP();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1" ::: "memory");
+      }
+      {  // MFMA xi_z = 0 ; form xi_z = 3 : d1 - d3 ; then request rows 1, 2 of the next x tap
+        const int G = dx * 4 + 2;
+        wload(aw[(G + WPF) % (WPF + 1)], (G + WPF < 12) ? wr : wt, (G + WPF < 12) ? st : stn, (G + WPF) % 12);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) rt[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(0, j, dx));
+        for (int j = 0; j < 4; ++j) c[j] = sub4(r1[j], rt[j]);
+        wino_yt(c, v[1]);
+        if (dx < 2) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) c[j] = sub4(r2[j], r1[j]);
-          wino_yt(c, v[1]);
-          wino_mfma16(v[0], aw[G % 3], acc[1]);
-          WINO_SCHED_GROUP();
-          __builtin_amdgcn_sched_barrier(0);
-          asm volatile("s_nop 1" ::: "memory");  // hand-written transform VALU -> next group's MFMA operand: hazard not tracked by the compiler
+          for (int j = 0; j < 4; ++j) {
+            r1[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(1, j, dx + 1));
+            r2[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(2, j, dx + 1));
+          }
         }
-        {  // MFMA xi_z = 2 ; form xi_z = 0 : d0 - d2 ; then request row 3
-          const int G = dx * 4 + 1;
-          wload(aw[(G + 2) % 3], (G + 2 < 12) ? st : stn, (G + 2) % 12);
+        if (FIRST && dx == 0) wino_mfma16<true>(v[0], aw[G % (WPF + 1)], acc[0]); else wino_mfma16<false>(v[0], aw[G % (WPF + 1)], acc[0]);
+        WINO_SCHED_GROUP();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1" ::: "memory");
+      }
+      {  // MFMA xi_z = 3 ; form xi_z = 1 of the next x tap : d1 + d2
+        const int G = dx * 4 + 3;
+        wload(aw[(G + WPF) % (WPF + 1)], (G + WPF < 12) ? wr : wt, (G + WPF < 12) ? st : stn, (G + WPF) % 12);
+        if (dx < 2) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) c[j] = sub4(rt[j], r2[j]);
+          for (int j = 0; j < 4; ++j) c[j] = add4(r1[j], r2[j]);
           wino_yt(c, v[0]);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) rt[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(3, j, dx));
-          wino_mfma16(v[1], aw[G % 3], acc[2]);
-          WINO_SCHED_GROUP();
-          __builtin_amdgcn_sched_barrier(0);
-          asm volatile("s_nop 1" ::: "memory");  // hand-written transform VALU -> next group's MFMA operand: hazard not tracked by the compiler
         }
-        {  // MFMA xi_z = 0 ; form xi_z = 3 : d1 - d3 ; then request rows 1, 2 of the next x tap
-          const int G = dx * 4 + 2;
-          wload(aw[(G + 2) % 3], (G + 2 < 12) ? st : stn, (G + 2) % 12);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) c[j] = sub4(r1[j], rt[j]);
-          wino_yt(c, v[1]);
-          if (dx < 2) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              r1[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(1, j, dx + 1));
-              r2[j] = *reinterpret_cast<const f32x4*>(lb + LDSOFF(2, j, dx + 1));
-            }
-          }
-          wino_mfma16(v[0], aw[G % 3], acc[0]);
-          WINO_SCHED_GROUP();
-          __builtin_amdgcn_sched_barrier(0);
-          asm volatile("s_nop 1" ::: "memory");  // hand-written transform VALU -> next group's MFMA operand: hazard not tracked by the compiler
-        }
-        {  // MFMA xi_z = 3 ; form xi_z = 1 of the next x tap : d1 + d2
-          const int G = dx * 4 + 3;
-          wload(aw[(G + 2) % 3], (G + 2 < 12) ? st : stn, (G + 2) % 12);
-          if (dx < 2) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) c[j] = add4(r1[j], r2[j]);
-            wino_yt(c, v[0]);
-          }
-          wino_mfma16(v[1], aw[G % 3], acc[3]);
-          WINO_SCHED_GROUP();
-          __builtin_amdgcn_sched_barrier(0);
-          asm volatile("s_nop 1" ::: "memory");  // hand-written transform VALU -> next group's MFMA operand: hazard not tracked by the compiler
-        }
+        if (FIRST && dx == 0) wino_mfma16<true>(v[1], aw[G % (WPF + 1)], acc[3]); else wino_mfma16<false>(v[1], aw[G % (WPF + 1)], acc[3]);
+        WINO_SCHED_GROUP();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1" ::: "memory");
       }
     }
-    if (more) commit(nxt);
+    if (more || chain) commit(lds + (par ^ 1) * G_::BUF);
+    if (chain && tid < 32) bsh[bias_slot * 32 + tid] = bias_v;
     __syncthreads();
-  }
+  };
+
+  // output side: buffer stores with an out-of-range offset for masked lanes -- the store count is the same on every path
+  // (see fetch) and there are no branches around the stores
+  auto store4 = [&](const __amdgpu_buffer_rsrc_t d, unsigned voff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), d, voff, 0, 0);
+  };
 
   // ---- output transform (A^T . A over (z, y)), bias, optional accumulate, store; D rows = couts (4 per register quad) ----
-  // the accumulators are read with hand-written v_accvgpr_read (acc_rd): the compiler's hazard tracking does not see them,
-  // so the 16-pass latency of the last matrix instructions is covered explicitly (18 wait states required, 80 given)
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-  f32x4 bq[4];
+  auto finish = [&](const Item& o, int slot) {
+    const bool raw = p.ksplit > 1;
+    const int oxx = o.tx * XW + xl;
+    const int zb = o.tz * 4 + 2 * tz2, yb = o.ty * G_::TY + 2 * ty2;
+    const int ld = raw ? p.Npad : p.ldy;
+    const float* obase = raw ? p.part + ((long)blockIdx.z * p.N + o.n) * p.D * p.H * p.W * (long)p.Npad
+                             : p.y + (long)o.n * p.D * p.H * p.W * (long)p.ldy;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, 0x7fffffff, 0x00020000);
+    const int clim = raw ? p.Npad : p.Cout;
+    unsigned yo[2][2];   // [oz][oy] byte offsets of this lane's first cout quad; masked positions out of range
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    bq[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias && p.ksplit <= 1) {
-      const int co = cb * 32 + 8 * g + 4 * h;
-      if (co < p.Cout) bq[g] = f32x4{p.bias[co], p.bias[co + 1], p.bias[co + 2], p.bias[co + 3]};  // 4-byte aligned views are common
-    }
-  }
-  const int oxx = ox0 + xl;
-  const int zb = oz0 + 2 * tz2, yb = oy0 + 2 * ty2;
-  float* ybase = p.y + ((((long)n * p.D + zb) * p.H + yb) * p.W + oxx) * (long)p.ldy + cb * 32 + 4 * h;
-  const long ysY = (long)p.W * p.ldy, ysZ = (long)p.H * p.W * p.ldy;
-  const bool inx = oxx < p.W;
-  const bool raw = p.ksplit > 1;
-  float* pbase = nullptr;
-  if (raw) pbase = p.part + (((long)blockIdx.z * p.N + n) * p.D * p.H * p.W + ((long)zb * p.H + yb) * p.W + oxx) * p.Npad + cb * 32 + 4 * h;
-  float gn_s = 0.f, gn_q = 0.f;
+    for (int oz = 0; oz < 2; ++oz)
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {  // one register quad (4 couts) of all 16 accumulators at a time
-    f32x4 tq[4][2];
+      for (int oy = 0; oy < 2; ++oy) {
+        const bool ok = oxx < p.W && (yb + oy) < p.H && (zb + oz) < p.D;
+        yo[oz][oy] = ok ? (unsigned)(((((zb + oz) * p.H + (yb + oy)) * p.W + oxx) * ld + o.cb * 32 + 4 * h) * 4) : 0x80000000u;
+      }
+    f32x4 bq[4];
 #pragma unroll
-    for (int xz = 0; xz < 4; ++xz) {
-      f32x4 q[4];
+    for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const f32x4*>(bsh + slot * 32 + 8 * g + 4 * h);
+    // the accumulators are read with hand-written v_accvgpr_read (acc_rd): the compiler's hazard tracking does not see
+    // them, so the 16-pass latency of the last matrix instructions is covered explicitly (18 wait states required, 80 given)
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    float gn_s = 0.f, gn_q = 0.f;
 #pragma unroll
-      for (int xy = 0; xy < 4; ++xy)
-        q[xy] = f32x4{acc_rd(acc[xz][xy][4 * g]), acc_rd(acc[xz][xy][4 * g + 1]), acc_rd(acc[xz][xy][4 * g + 2]), acc_rd(acc[xz][xy][4 * g + 3])};
-      tq[xz][0] = q[0] + q[1] + q[2];
-      tq[xz][1] = q[1] - q[2] - q[3];
-    }
-    const bool cok = inx && (cb * 32 + 8 * g + 4 * h < (raw ? p.Npad : p.Cout));
+    for (int g = 0; g < 4; ++g) {  // one register quad (4 couts) of all 16 accumulators at a time
+      f32x4 tq[4][2];
 #pragma unroll
-    for (int oy = 0; oy < 2; ++oy) {
-      f32x4 o[2];
-      o[0] = tq[0][oy] + tq[1][oy] + tq[2][oy] + bq[g];
-      o[1] = tq[1][oy] - tq[2][oy] - tq[3][oy] + bq[g];
-      if (cok && yb + oy < p.H) {
+      for (int xz = 0; xz < 4; ++xz) {
+        f32x4 q[4];
+#pragma unroll
+        for (int xy = 0; xy < 4; ++xy)
+          q[xy] = f32x4{acc_rd(acc[xz][xy][4 * g]), acc_rd(acc[xz][xy][4 * g + 1]), acc_rd(acc[xz][xy][4 * g + 2]), acc_rd(acc[xz][xy][4 * g + 3])};
+        tq[xz][0] = q[0] + q[1] + q[2];
+        tq[xz][1] = q[1] - q[2] - q[3];
+      }
+      const bool cok = o.cb * 32 + 8 * g + 4 * h < clim;
+#pragma unroll
+      for (int oy = 0; oy < 2; ++oy) {
+        f32x4 ov[2];
+        ov[0] = tq[0][oy] + tq[1][oy] + tq[2][oy] + bq[g];
+        ov[1] = tq[1][oy] - tq[2][oy] - tq[3][oy] + bq[g];
 #pragma unroll
         for (int oz = 0; oz < 2; ++oz) {
-          if (zb + oz < p.D) {
-            if (p.gnp) {
+          const unsigned off = cok ? yo[oz][oy] : 0x80000000u;
+          const bool live = off != 0x80000000u;
+          f32x4 v = ov[oz];
 #pragma unroll
-              for (int j = 0; j < 4; ++j) { gn_s += o[oz][j]; gn_q = fmaf(o[oz][j], o[oz][j], gn_q); }
-            }
-            if (raw) {
-              *reinterpret_cast<f32x4*>(pbase + ((long)oz * p.H + oy) * p.W * p.Npad + 8 * g) = o[oz];
-            } else {
-              f32x4* dst = reinterpret_cast<f32x4*>(ybase + oz * ysZ + oy * ysY + 8 * g);
-              f32x4 v = o[oz];
-              if (p.accum) v += *dst;
-              *dst = v;
-            }
+          for (int j = 0; j < 4; ++j) {   // masked positions contribute nothing to the GroupNorm sums
+            const float t = live ? v[j] : 0.f;
+            gn_s += t;
+            gn_q = fmaf(t, t, gn_q);
           }
+          if (p.accum && !raw) v += bufload(yr, off + 32u * g, 0);
+          store4(yr, off + 32u * g, v);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (p.gnp) {  // fixed-order combine: lanes (shuffle tree) -> 4 waves (LDS) -> one (sum, sumsq) pair per workgroup
-    const double ds = wave_sum_f64((double)gn_s), dq = wave_sum_f64((double)gn_q);
-    double* sh = reinterpret_cast<double*>(lds);  // the staging buffers are idle (last barrier passed)
-    if (lane == 0) { sh[wave * 2] = ds; sh[wave * 2 + 1] = dq; }
-    __syncthreads();
-    if (tid == 0) {
-      const int g = tz / p.gn_zt;
+    // GroupNorm partials: fixed-order combine, lanes (shuffle tree) -> 4 waves (LDS) -> one (sum, sumsq) pair per item.  The
+    // exchange runs (and thread 0 stores, out of range when there is no consumer) whether or not p.gnp is set: same request
+    // count on every path
+    {
+      const double ds = wave_sum_f64((double)gn_s), dq = wave_sum_f64((double)gn_q);
+      if (lane == 0) { gsh[wave * 2] = ds; gsh[wave * 2 + 1] = dq; }
+      __syncthreads();
+      const int gn_g = o.tz / p.gn_zt;
       const long B = (long)p.gn_zt * p.nty * p.ntx * nb_;
-      const long b_ = (((long)(tz - g * p.gn_zt) * p.nty + ty) * p.ntx + tx) * nb_ + cb;
-      double* o = p.gnp + (((long)n * p.gn_G + g) * B + b_) * 2;
-      o[0] = sh[0] + sh[2] + sh[4] + sh[6];
-      o[1] = sh[1] + sh[3] + sh[5] + sh[7];
+      const long gn_slot = (((long)(o.tz - gn_g * p.gn_zt) * p.nty + o.ty) * p.ntx + o.tx) * nb_ + o.cb;
+      const double* dst = p.gnp ? p.gnp + (((long)o.n * p.gn_G + gn_g) * B + gn_slot) * 2 : nullptr;
+      const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, p.gnp ? 16 : 0, 0x00020000);
+      const double s0 = gsh[0] + gsh[2] + gsh[4] + gsh[6], s1 = gsh[1] + gsh[3] + gsh[5] + gsh[7];
+      struct D2 { double a, b; } d2{s0, s1};
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d2), gr, tid == 0 ? 0u : 0x80000000u, 0, 0);
+      // (gsh is rewritten only after the next item's stage barriers)
     }
+  };
+
+  Item cur = decode(seq0);
+  setup_x(cur);
+  wr = wdesc(cur);
+  wr_n = wr;
+  bias_v = bias_of(cur);
+  fetch((unsigned)st0 * 32u);
+#pragma unroll
+  for (int g = 0; g < WPF; ++g) wload(aw[g], wr, st0, g);
+  commit(lds);
+  if (tid < 32) bsh[tid] = bias_v;
+  __syncthreads();
+  {  // as many (dropped) stores as an item's output side issues: the first item's waits then match the later items'
+    const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 17; ++i) store4(none, 0x80000000u + 16u * i, f32x4{0.f, 0.f, 0.f, 0.f});   // (distinct: not dead stores)
+  }
+
+  int par = 0;
+  for (int it = 0; it < p.T; ++it) {
+    const bool have_next = (it + 1 < p.T) && (seq0 + it + 1 < items_here);
+    const Item out = cur;
+    WSTAMP(0);
+#ifdef BTS_WINO_STAMPS
+    if (tid == 0) {
+      unsigned hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      g_wino_stamps[((long)blockIdx.x * p.T + it) * 16 + 6] = ((long long)xcc << 32) | hwid;
+      g_wino_stamps[((long)blockIdx.x * p.T + it) * 16 + 7] = clock64();
+    }
+#endif
+    WSTAMP(1);
+    // from an item's last stage on, the input-side state is the successor's (the item's own last halo tile is in LDS by then)
+    auto enter = [&](int st) {
+      const bool chain = (st + 1 == st1) && have_next;
+      if (chain) {
+        advance(cur);
+        setup_x(cur);
+        wr_n = wdesc(cur);
+        bias_v = bias_of(cur);
+      }
+      return chain;
+    };
+    {
+      const bool chain = enter(st0);
+      stage(std::true_type{}, st0, par, st0 + 1 < st1, chain, (it + 1) & 1);
+      par ^= 1;
+    }
+    WSTAMP(2);
+    for (int st = st0 + 1; st < st1; ++st) {
+      const bool chain = enter(st);
+      stage(std::false_type{}, st, par, st + 1 < st1, chain, (it + 1) & 1);
+      par ^= 1;
+    }
+    WSTAMP(3);
+    if (have_next) wr = wr_n;
+    WSTAMP(4);
+    finish(out, it & 1);
+    WSTAMP(5);
+    if (!have_next) break;
   }
 }
 
@@ -434,7 +574,7 @@ template <int XW>
 static int wino_launch_cfg(const WinoParams& p, const WinoPlan& q, double flops, hipStream_t stream) {
   auto kern = wino_kernel<XW>;
   static bool attr_done = false;
-  const size_t shmem = 2 * WinoGeo<XW>::BUF * sizeof(float);
+  const size_t shmem = 2 * WinoGeo<XW>::BUF * sizeof(float) + 64 + 256;   // + GroupNorm partial exchange (8 doubles) + 2 x 32 bias values
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
@@ -443,7 +583,8 @@ static int wino_launch_cfg(const WinoParams& p, const WinoPlan& q, double flops,
   const bool prof = bts_prof_on();
   if (prof) bts_prof_begin(23, flops, stream);
   (void)hipGetLastError();
-  hipLaunchKernelGGL(kern, dim3((unsigned)(8L * p.tiles_per_xcd * q.nb), 1, q.ksplit), dim3(256), shmem, stream, p);
+  const long wgs_per_xcd = ((long)p.tiles_per_xcd * q.nb + p.T - 1) / p.T;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(8L * wgs_per_xcd), 1, q.ksplit), dim3(256), shmem, stream, p);
   if (prof) bts_prof_end(stream);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
@@ -474,6 +615,13 @@ int bts_wino_launch_(const float* x, const float* up, const float* bias, float* 
   p.accum = accum;
   p.ksplit = q.ksplit; p.kg_per = q.kg_per; p.Npad = q.nb * 32; p.part = reinterpret_cast<float*>(ws);
   p.nb = q.nb; p.ntiles = N * q.ntz * q.nty * q.ntx; p.tiles_per_xcd = (p.ntiles + 7) / 8;
+  // items per workgroup: as many as leave every CU (32 per XCD, one workgroup each at a time) at least two workgroups
+  {
+    const long per_cu = ((long)p.tiles_per_xcd * q.nb) / 32;
+    p.T = q.ksplit > 1 ? 1 : (per_cu >= 8 ? 4 : per_cu >= 4 ? 2 : 1);
+    const char* e = getenv("BTS_WINO_T");   // A/B aid
+    if (e && q.ksplit == 1) p.T = atoi(e) > 0 ? atoi(e) : 1;
+  }
   p.gnp = nullptr; p.gn_G = 0; p.gn_zt = 1;
   if (q.ksplit == 1 && gnp != nullptr && gnG > 0 && D % gnG == 0 && (D / gnG) % 4 == 0 && getenv("BTS_IGEMM_NOGNFUSE") == nullptr) {
     p.gnp = gnp; p.gn_G = gnG; p.gn_zt = (D / gnG) / 4;
