@@ -1,0 +1,978 @@
+// Reduced-precision STORAGE path of the forward pass (BASELINE configs[4]: full-volume inference in fp16, VAE off; also the
+// forward half of configs[2], bf16): activations and packed weights are 16-bit (fp16 or bf16), every sum is fp32 -- conv
+// contractions on v_mfma_f32_32x32x16_{f16,bf16}, GroupNorm statistics / SE gates / sigmoid in fp32 from the stored values.
+// The fp32 engine (conv_igemm / conv_wino / groupnorm / se) is the parity reference of this path; the reference itself has
+// no reduced-precision mode.  Call sites replaced: the same as the fp32 kernels' (layers/resnet.py:116-138,
+// group_norm.py:83-124, downsample.py:28-45, upsample.py:28-43, decoder.py:55-63,65-83, encoder.py:69-101, model.py:58-68).
+//
+// Matrix instruction layout (32x32x16, K = 16 channels): A = weights (row = cout, lane>>5 selects k 0..7 / 8..15: one 16-byte
+// load of 8 consecutive input channels), B = activations (column = voxel, same k split: one 16-byte read of 8 consecutive
+// channels of the voxel -- NDHWC memory IS the operand layout), D: lane holds voxel lane&31 and couts 8*(r>>2) + 4*(lane>>5)
+// + (r&3): four consecutive couts per register quad = one 8-byte store.
+//
+// Two conv kernels:
+//   lp_conv_s1_kernel      3x3x3 stride-1 'same' (90 % of the FLOPs): halo tile of 16 channels staged global -> registers ->
+//                          LDS (voxel stride 48 bytes: conflict-free 16-byte reads), wave = 32 x-columns x VB rows of one z
+//                          plane x CB cout blocks, weights straight from L2 (one fragment feeds VB matrix instructions)
+//   lp_conv_gather_kernel  1x1x1, stride-2 and transposed convs (gather form out[o*os+oo] = sum_t in[o*s+off_t] W[t], the
+//                          transposed conv as 8 output-parity classes): operands straight from global memory -- every input
+//                          voxel is needed by at most 8 outputs, an LDS tile would buy nothing
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include "common.h"
+#include "bts_internal.h"
+
+int bts_prof_on();
+void bts_prof_begin(int sym, double flops, hipStream_t stream);
+void bts_prof_end(hipStream_t stream);
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+
+#define LP_F16 1
+#define LP_BF16 2
+
+// ---- storage-type traits: conversions are explicit, sums never happen in 16 bits ----
+struct TF16 {
+  typedef h16x8 frag;
+  static __device__ __forceinline__ float ld(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+  static __device__ __forceinline__ unsigned short st(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }   // RNE
+  static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  }
+};
+struct TBF16 {
+  typedef b16x8 frag;
+  static __device__ __forceinline__ float ld(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+  static __device__ __forceinline__ unsigned short st(float f) {   // round to nearest even (NaN stays NaN)
+    unsigned u = __builtin_bit_cast(unsigned, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+  }
+  static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b16x8, a), __builtin_bit_cast(b16x8, b), c, 0, 0, 0);
+  }
+};
+template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b) {
+  return (unsigned)T::st(a) | ((unsigned)T::st(b) << 16);
+}
+template <typename T> __device__ __forceinline__ void unpack8(u32x4 v, float (&o)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { o[2 * i] = T::ld((unsigned short)(v[i] & 0xffffu)); o[2 * i + 1] = T::ld((unsigned short)(v[i] >> 16)); }
+}
+template <typename T> __device__ __forceinline__ u32x4 pack8(const float (&o)[8]) {
+  return u32x4{pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7])};
+}
+__device__ __forceinline__ u32x4 bload16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+}
+
+// =====================================================================================================================
+// weight packing: Keras layout fp32 -> [tap][k-step of 16 cin][cout block of 32][h][32 couts][8 cin] 16-bit
+// =====================================================================================================================
+struct LpPackParams {
+  const float* w;
+  unsigned short* wp;
+  int ntaps, Cin_ref, Cout, Cin_slab, dup_start, dup_shift, transposed, KS, NB;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void lp_pack_kernel(const LpPackParams p) {
+  const long total = (long)p.ntaps * p.KS * p.NB * 512;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int e = (int)(i & 7), r = (int)((i >> 3) & 31), h = (int)((i >> 8) & 1);
+    long q = i >> 9;
+    const int cb = (int)(q % p.NB); q /= p.NB;
+    const int ks = (int)(q % p.KS);
+    const int t = (int)(q / p.KS);
+    const int c = ks * 16 + h * 8 + e, k = cb * 32 + r;
+    float v = 0.f;
+    if (c < p.Cin_slab && k < p.Cout) {
+      // slab channel c is reference channel c + dup_shift; inside [dup_start, dup_start + dup_shift) it is ALSO reference
+      // channel c - dup_start (encoder.py:83-87: [o_{j-1}, o_0 .. o_{j-1}] read once from the slab [o_0 .. o_{j-1}])
+      auto at = [&](int cr) {
+        return p.transposed ? p.w[((long)t * p.Cout + k) * p.Cin_ref + cr] : p.w[((long)t * p.Cin_ref + cr) * p.Cout + k];
+      };
+      v = at(c + p.dup_shift);
+      if (p.dup_shift > 0 && c >= p.dup_start && c < p.dup_start + p.dup_shift) v += at(c - p.dup_start);
+    }
+    p.wp[i] = T::st(v);
+  }
+}
+
+static int lp_ntaps(int kind) { return kind == BTS_CONV_K1 ? 1 : 27; }
+
+extern "C" long bts_lp_packed_bytes(int kind, int Cin_slab, int Cout) {
+  if (kind < 0 || kind > 3 || Cin_slab <= 0 || Cout <= 0) return -1;
+  return (long)lp_ntaps(kind) * ((Cin_slab + 15) / 16) * ((Cout + 31) / 32) * 512 * 2;
+}
+extern "C" int bts_lp_pack(int kind, int dtype, const float* w, void* wp, int Cin_ref, int Cout, int Cin_slab, int dup_start,
+                           int dup_shift, hipStream_t stream) {
+  if (kind < 0 || kind > 3 || (dtype != LP_F16 && dtype != LP_BF16)) return BTS_ERR_UNSUPPORTED;
+  if (Cin_slab + dup_shift != Cin_ref || dup_shift < 0 || dup_start < 0 || dup_start + dup_shift > Cin_slab) return BTS_ERR_SHAPE;
+  LpPackParams p;
+  p.w = w; p.wp = reinterpret_cast<unsigned short*>(wp);
+  p.ntaps = lp_ntaps(kind); p.Cin_ref = Cin_ref; p.Cout = Cout; p.Cin_slab = Cin_slab; p.dup_start = dup_start; p.dup_shift = dup_shift;
+  p.transposed = kind == BTS_CONV_K3S2T; p.KS = (Cin_slab + 15) / 16; p.NB = (Cout + 31) / 32;
+  const long total = (long)p.ntaps * p.KS * p.NB * 512;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  (void)hipGetLastError();
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_pack_kernel<TF16>, dim3(blocks), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(lp_pack_kernel<TBF16>, dim3(blocks), dim3(256), 0, stream, p);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+// =====================================================================================================================
+// 3x3x3 stride-1 convolution
+// =====================================================================================================================
+struct LpS1Params {
+  const unsigned short* x;
+  const unsigned short* wp;
+  const float* bias;
+  unsigned short* y;
+  int N, D, H, W, ldx, ldy, Cout, KS, NB;   // KS = k-steps of 16 input channels, NB = cout blocks of 32
+  int ntx, nty, ntz, ncg;                    // tiles per axis, cout groups of CB blocks
+  int ksplit, ks_per;                        // split-K over blockIdx.y (small grids)
+  long ntiles;
+  float* part;
+};
+#define LPS 24   // halves per staged voxel: 16 channels + 8 pad (48-byte stride: conflict-free 16-byte reads)
+
+template <typename T, int VB, int CB, int TXL>
+__global__ __launch_bounds__(256, 2) void lp_conv_s1_kernel(const LpS1Params p) {
+  constexpr int TX = 1 << TXL, R = 32 / TX, TY = VB * R, TZ = 4;
+  constexpr int SX = TX + 2, SY = TY + 2, SZ = TZ + 2;
+  constexpr int NVOX = SX * SY * SZ;
+  constexpr int NSLOT = (NVOX * 2 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l32 = lane & 31;
+  const int lx = l32 & (TX - 1), ly = l32 >> TXL;
+  // persistent over tiles: a launch has a few workgroups per CU, each walking tiles blockIdx.x, + gridDim.x, ... (with one short
+  // tile per workgroup the dispatcher, not the CUs, set the pace: 0.5 resident waves per SIMD on the 160x192x160 layers)
+  for (long tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+  long b = tile;
+  const int cg = (int)(b % p.ncg); b /= p.ncg;
+  const int tx = (int)(b % p.ntx); b /= p.ntx;
+  const int ty = (int)(b % p.nty); b /= p.nty;
+  const int tz = (int)(b % p.ntz);
+  const int n = (int)(b / p.ntz);
+  const int ox0 = tx * TX, oy0 = ty * TY, oz0 = tz * TZ;
+  // halo origin; slots outside the image get an offset outside the descriptor -> the load returns zeros (the 'same' padding)
+  const unsigned short* xorg = p.x + ((((long)n * p.D + (oz0 - 1)) * p.H + (oy0 - 1)) * p.W + (ox0 - 1)) * (long)p.ldx;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xorg, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7fffffff, 0x00020000);
+  unsigned goff[NSLOT];
+#pragma unroll
+  for (int i = 0; i < NSLOT; ++i) {
+    const int e = tid + i * 256;
+    goff[i] = 0x80000000u;
+    if (e < NVOX * 2) {
+      const int vox = e >> 1, q = e & 1;
+      const int vz = vox / (SY * SX);
+      const int r = vox - vz * (SY * SX);
+      const int vy = r / SX, vx = r - vy * SX;
+      if ((unsigned)(oz0 - 1 + vz) < (unsigned)p.D && (unsigned)(oy0 - 1 + vy) < (unsigned)p.H && (unsigned)(ox0 - 1 + vx) < (unsigned)p.W)
+        goff[i] = (unsigned)(((vz * p.H + vy) * p.W + vx) * p.ldx + q * 8) * 2u;
+    }
+  }
+  u32x4 pre[NSLOT];
+  auto fetch = [&](int ks) {
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) pre[i] = bload16(xr, goff[i], (unsigned)ks * 32u);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+      const int e = tid + i * 256;
+      if (e < NVOX * 2) *reinterpret_cast<u32x4*>(lds + (e >> 1) * LPS + (e & 1) * 8) = pre[i];
+    }
+  };
+  f32x16 acc[VB][CB];
+#pragma unroll
+  for (int v = 0; v < VB; ++v)
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[v][c][r] = 0.f;
+
+  // this lane's B-operand base inside the tile: voxel (z = wave, y = ly, x = lx), channel half h
+  const int bbase = ((wave * SY + ly) * SX + lx) * LPS + h * 8;
+  const unsigned wlane = (unsigned)((h * 32 + l32) * 16);
+  // k-steps of this workgroup (split-K: blockIdx.y takes k-steps [ks0, ks1))
+  int ks0 = 0, ks1 = p.KS;
+  if (p.ksplit > 1) {
+    ks0 = blockIdx.y * p.ks_per;
+    ks1 = ks0 + p.ks_per;
+    if (ks1 > p.KS) ks1 = p.KS;
+  }
+  auto wfrag = [&](int t, int ks, int c) {
+    const int cb = cg * CB + c;
+    return bload16(wr, wlane, (unsigned)((((t * p.KS + ks) * p.NB) + (cb < p.NB ? cb : 0)) * 1024));
+  };
+  if constexpr (R == 1) {
+    // 32-wide tiles: a wave's VB voxel blocks are VB consecutive y rows of its z plane, so for a fixed (dz, dx) the VB + 2 input
+    // rows it needs serve all three dy taps: (VB + 2) LDS reads feed 3 * VB * CB matrix instructions (one read per instruction
+    // otherwise -- with 32 couts the LDS port, not the matrix pipe, was the limit).  Taps run in (dz, dx) groups of three dy; the
+    // weights of group g live in a[g % 3] and are requested one group ahead.
+    u32x4 a[3][3][CB];
+    auto wgroup = [&](u32x4 (&dst)[3][CB], int g, int ks) {
+      const int dz = g / 3, dx = g % 3;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) dst[dy][c] = wfrag((dz * 3 + dy) * 3 + dx, ks, c);
+    };
+    fetch(ks0);
+    wgroup(a[0], 0, ks0);
+    for (int ks = ks0; ks < ks1; ++ks) {
+      __syncthreads();        // every wave is done reading the previous k-step's tile
+      commit();
+      __syncthreads();
+      const bool more = ks + 1 < ks1;
+      if (more) fetch(ks + 1);
+      const int ksn = more ? ks + 1 : ks;   // (the last step re-requests its own first group: same request count on every path)
+#pragma unroll
+      for (int g = 0; g < 9; ++g) {
+        const int dz = g / 3, dx = g % 3;
+        wgroup(a[(g + 1) % 3], (g + 1) % 9, (g + 1 < 9) ? ks : ksn);
+        u32x4 bj[VB + 2];
+#pragma unroll
+        for (int j = 0; j < VB + 2; ++j) bj[j] = *reinterpret_cast<const u32x4*>(lds + bbase + ((dz * SY + j) * SX + dx) * LPS);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int v = 0; v < VB; ++v)
+#pragma unroll
+            for (int c = 0; c < CB; ++c) acc[v][c] = T::mfma(a[g % 3][dy][c], bj[v + dy], acc[v][c]);
+      }
+    }
+  } else {
+    // narrower tiles (small grids): weight fragments of tap t live in a[t % 3], two taps are always in flight (an L2 round
+    // trip is ~10x the 4-8 matrix instructions one tap feeds)
+    u32x4 a[3][CB];
+    auto wload = [&](u32x4 (&dst)[CB], int t, int ks) {
+#pragma unroll
+      for (int c = 0; c < CB; ++c) dst[c] = wfrag(t, ks, c);
+    };
+    fetch(ks0);
+    wload(a[0], 0, ks0);
+    wload(a[1], 1, ks0);
+    for (int ks = ks0; ks < ks1; ++ks) {
+      __syncthreads();        // every wave is done reading the previous k-step's tile
+      commit();
+      __syncthreads();
+      const bool more = ks + 1 < ks1;
+      if (more) fetch(ks + 1);
+      const int ksn = more ? ks + 1 : ks;   // (the last step re-requests its own first taps: same request count on every path)
+#pragma unroll
+      for (int t = 0; t < 27; ++t) {
+        const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+        wload(a[(t + 2) % 3], (t + 2) % 27, (t + 2 < 27) ? ks : ksn);
+#pragma unroll
+        for (int v = 0; v < VB; ++v) {
+          const u32x4 bv = *reinterpret_cast<const u32x4*>(lds + bbase + ((dz * SY + (v * R + dy)) * SX + dx) * LPS);
+#pragma unroll
+          for (int c = 0; c < CB; ++c) acc[v][c] = T::mfma(a[t % 3][c], bv, acc[v][c]);
+        }
+      }
+    }
+  }
+  if (p.ksplit > 1) {   // raw fp32 partial sums [split][voxel][NB*32]; bias / rounding happen in the reduce kernel
+    const int oz = oz0 + wave, ox = ox0 + lx;
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+      const int cb = cg * CB + c;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int v = 0; v < VB; ++v) {
+          const int oy = oy0 + v * R + ly;
+          if (cb < p.NB && oz < p.D && oy < p.H && ox < p.W) {
+            float* dst = p.part + ((((long)blockIdx.y * p.N + n) * p.D + oz) * p.H + oy) * (long)p.W * (p.NB * 32) +
+                         (long)ox * (p.NB * 32) + cb * 32 + 8 * q + 4 * h;
+            *reinterpret_cast<f32x4*>(dst) = f32x4{acc[v][c][4 * q], acc[v][c][4 * q + 1], acc[v][c][4 * q + 2], acc[v][c][4 * q + 3]};
+          }
+        }
+      }
+    }
+    continue;
+  }
+  // epilogue: bias, convert, one 8-byte store per register quad
+  const int oz = oz0 + wave, ox = ox0 + lx;
+#pragma unroll
+  for (int c = 0; c < CB; ++c) {
+    const int cb = cg * CB + c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = cb * 32 + 8 * q + 4 * h;
+      float bq[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && cb < p.NB) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (co + j < p.Cout) bq[j] = p.bias[co + j];
+      }
+#pragma unroll
+      for (int v = 0; v < VB; ++v) {
+        const int oy = oy0 + v * R + ly;
+        if (cb < p.NB && oz < p.D && oy < p.H && ox < p.W && co < p.Cout) {
+          unsigned short* dst = p.y + ((((long)n * p.D + oz) * p.H + oy) * p.W + ox) * (long)p.ldy + co;
+          const float o0 = acc[v][c][4 * q] + bq[0], o1 = acc[v][c][4 * q + 1] + bq[1], o2 = acc[v][c][4 * q + 2] + bq[2],
+                      o3 = acc[v][c][4 * q + 3] + bq[3];
+          if (co + 3 < p.Cout) {
+            *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<T>(o0, o1), pack2<T>(o2, o3)};
+          } else {
+            dst[0] = T::st(o0);
+            if (co + 1 < p.Cout) dst[1] = T::st(o1);
+            if (co + 2 < p.Cout) dst[2] = T::st(o2);
+          }
+        }
+      }
+    }
+  }
+  }   // tile loop
+}
+
+// finish of a split-K launch: y = round(bias + sum_z part[z]) in fixed order
+template <typename T>
+__global__ __launch_bounds__(256) void lp_splitk_reduce_kernel(const float* part, const float* bias, unsigned short* y, long nvox, int Cout,
+                                                               int Npad, int ldy, int ksplit) {
+  const int q4 = Npad / 4;
+  const long total = nvox * q4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long v = i / q4;
+    const int c = (int)(i - v * q4) * 4;
+    if (c >= Cout) continue;
+    f32x4 s = *reinterpret_cast<const f32x4*>(part + v * Npad + c);
+    for (int z = 1; z < ksplit; ++z) s += *reinterpret_cast<const f32x4*>(part + ((long)z * nvox + v) * Npad + c);
+    if (bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (c + j < Cout) s[j] += bias[c + j];
+    }
+    unsigned short* dst = y + v * ldy + c;
+    if (c + 3 < Cout) {
+      *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<T>(s[0], s[1]), pack2<T>(s[2], s[3])};
+    } else {
+      for (int j = 0; j < 4 && c + j < Cout; ++j) dst[j] = T::st(s[j]);
+    }
+  }
+}
+
+// split-K plan of the stride-1 kernel: grids that cannot give every CU a workgroup split the input channels
+static int lp_s1_ksplit(long wgs, int KS) {
+  if (wgs >= 192 || KS < 8) return 1;
+  int ks = (int)((384 + wgs - 1) / wgs);
+  if (ks > KS / 4) ks = KS / 4;    // at least 4 k-steps per workgroup
+  if (ks > 16) ks = 16;
+  return ks < 1 ? 1 : ks;
+}
+
+template <typename T, int VB, int CB, int TXL>
+static int lp_s1_launch(LpS1Params p, void* ws, long ws_bytes, hipStream_t stream) {
+  constexpr int TX = 1 << TXL, R = 32 / TX, TY = VB * R, TZ = 4;
+  p.ntx = (p.W + TX - 1) / TX; p.nty = (p.H + TY - 1) / TY; p.ntz = (p.D + TZ - 1) / TZ;
+  p.ncg = (p.NB + CB - 1) / CB;
+  const long wgs = (long)p.N * p.ntz * p.nty * p.ntx * p.ncg;
+  if (wgs > 0x7fffffffL) return BTS_ERR_SHAPE;
+  p.ksplit = lp_s1_ksplit(wgs, p.KS);
+  p.ks_per = p.KS;
+  p.part = reinterpret_cast<float*>(ws);
+  const long nvox = (long)p.N * p.D * p.H * p.W;
+  if (p.ksplit > 1) {
+    p.ks_per = (p.KS + p.ksplit - 1) / p.ksplit;
+    p.ksplit = (p.KS + p.ks_per - 1) / p.ks_per;
+    if (ws == nullptr || ws_bytes < (long)p.ksplit * nvox * p.NB * 32 * 4 || (((uintptr_t)ws) & 15)) { p.ksplit = 1; p.ks_per = p.KS; }
+  }
+  const size_t shmem = (size_t)(TX + 2) * (TY + 2) * (TZ + 2) * LPS * 2;
+  auto kern = lp_conv_s1_kernel<T, VB, CB, TXL>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  (void)hipGetLastError();
+  p.ntiles = wgs;
+  const long grid = wgs < 1024 ? wgs : 1024;   // <= 4 workgroups per CU in flight or queued
+  const bool prof = bts_prof_on();
+  if (prof) bts_prof_begin(30, 2.0 * 27.0 * 16.0 * p.KS * p.Cout * (double)nvox, stream);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid, p.ksplit), dim3(256), shmem, stream, p);
+  if (prof) bts_prof_end(stream);
+  BTS_LAUNCH_CHECK();
+  if (p.ksplit > 1) {
+    long blocks = (nvox * (p.NB * 8) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(lp_splitk_reduce_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p.part, p.bias, p.y, nvox, p.Cout, p.NB * 32,
+                       p.ldy, p.ksplit);
+    BTS_LAUNCH_CHECK();
+  }
+  return BTS_OK;
+}
+
+// (VB, CB, TXL) of a stride-1 call; shared by the launcher and the workspace query
+static void lp_s1_shape(int N, int D, int H, int W, int NB, int& vb, int& cb, int& txl) {
+  // x extent of a wave's 32 columns: the widest power of two that wastes no more columns than a narrower one would
+  txl = (W >= 24) ? 5 : (W >= 12 ? 4 : 3);
+  // rows per wave (VB) and cout blocks per wave (CB): 4 x 1 for 32-cout layers (one weight fragment feeds 4 matrix
+  // instructions), 4 x 2 from 64 couts on.  Small grids keep the 4 rows (weight reuse) and split the input channels instead
+  cb = NB >= 2 ? 2 : 1;
+  const long vox = (long)N * D * H * W;
+  vb = vox >= 4096 ? 4 : (vox >= 1024 ? 2 : 1);
+}
+static long lp_s1_wgs(int N, int D, int H, int W, int NB, int vb, int cb, int txl) {
+  const int TX = 1 << txl, TY = vb * (32 / TX);
+  return (long)N * ((D + 3) / 4) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX) * ((NB + cb - 1) / cb);
+}
+
+template <typename T>
+static int lp_s1_dispatch(const LpS1Params& p, void* ws, long ws_bytes, hipStream_t stream) {
+  int vb, cb, txl;
+  lp_s1_shape(p.N, p.D, p.H, p.W, p.NB, vb, cb, txl);
+#define LP_S1_CASE(VB_, CB_, TXL_) if (vb == VB_ && cb == CB_ && txl == TXL_) return lp_s1_launch<T, VB_, CB_, TXL_>(p, ws, ws_bytes, stream);
+  LP_S1_CASE(4, 1, 5) LP_S1_CASE(4, 2, 5) LP_S1_CASE(2, 1, 5) LP_S1_CASE(2, 2, 5) LP_S1_CASE(1, 1, 5) LP_S1_CASE(1, 2, 5)
+  LP_S1_CASE(4, 1, 4) LP_S1_CASE(4, 2, 4) LP_S1_CASE(2, 1, 4) LP_S1_CASE(2, 2, 4) LP_S1_CASE(1, 1, 4) LP_S1_CASE(1, 2, 4)
+  LP_S1_CASE(4, 1, 3) LP_S1_CASE(4, 2, 3) LP_S1_CASE(2, 1, 3) LP_S1_CASE(2, 2, 3) LP_S1_CASE(1, 1, 3) LP_S1_CASE(1, 2, 3)
+#undef LP_S1_CASE
+  return BTS_ERR_UNSUPPORTED;
+}
+
+// =====================================================================================================================
+// gather-form convolution (1x1x1, stride 2, transposed): operands straight from global memory
+// =====================================================================================================================
+struct LpTap { short dz, dy, dx, w; };   // input offset of the tap, index of its weight slab
+struct LpGatherParams {
+  const unsigned short* x;
+  const unsigned short* wp;
+  const float* bias;
+  unsigned short* y;
+  int N, Di, Hi, Wi, ldx;           // input grid
+  int Dg, Hg, Wg;                   // grid of this launch (output positions of one class)
+  int Do, Ho, Wo, ldy, Cout;        // output tensor
+  int s, os, ooz, ooy, oox;         // in = g*s + off_t ; out = g*os + oo
+  int KS, NB, ncg, ntaps;
+  long npos;                        // N*Dg*Hg*Wg
+  LpTap taps[27];
+};
+
+template <typename T, int VB, int CB>
+__global__ __launch_bounds__(256, 2) void lp_conv_gather_kernel(const LpGatherParams p) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = tid >> 6;
+  const int h = lane >> 5, l32 = lane & 31;
+  const int cg = blockIdx.x % p.ncg;
+  const long blk = blockIdx.x / p.ncg;
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7fffffff, 0x00020000);
+  const unsigned wlane = (unsigned)((h * 32 + l32) * 16);
+  // this lane's VB grid positions
+  int gz[VB], gy[VB], gx[VB], gn[VB];
+  bool live[VB];
+#pragma unroll
+  for (int v = 0; v < VB; ++v) {
+    long pos = ((blk * 4 + wave) * VB + v) * 32 + l32;
+    live[v] = pos < p.npos;
+    if (!live[v]) pos = 0;
+    gx[v] = (int)(pos % p.Wg); pos /= p.Wg;
+    gy[v] = (int)(pos % p.Hg); pos /= p.Hg;
+    gz[v] = (int)(pos % p.Dg);
+    gn[v] = (int)(pos / p.Dg);
+  }
+  f32x16 acc[VB][CB];
+#pragma unroll
+  for (int v = 0; v < VB; ++v)
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[v][c][r] = 0.f;
+  // Software pipeline over the flattened (tap, k-step) sequence: the operands of step i+1 are requested before the matrix
+  // instructions of step i run (both operands come straight from global memory: a step without its successor in flight
+  // would wait a full memory round trip for every 4-8 matrix instructions)
+  const unsigned short* src[VB];   // of the tap being REQUESTED
+  bool ok[VB];
+  int wtap = 0;
+  auto tap_setup = [&](int t) {
+    const LpTap tp = p.taps[t];
+    wtap = tp.w;
+#pragma unroll
+    for (int v = 0; v < VB; ++v) {
+      const int iz = gz[v] * p.s + tp.dz, iy = gy[v] * p.s + tp.dy, ix = gx[v] * p.s + tp.dx;
+      ok[v] = live[v] && (unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      src[v] = p.x + ((((long)gn[v] * p.Di + iz) * p.Hi + iy) * p.Wi + ix) * (long)p.ldx + h * 8;
+    }
+  };
+  auto request = [&](int ks, u32x4 (&a)[CB], u32x4 (&b)[VB]) {
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+      const int cb = cg * CB + c;
+      a[c] = bload16(wr, wlane, (unsigned)((((wtap * p.KS + ks) * p.NB) + (cb < p.NB ? cb : 0)) * 1024));
+    }
+#pragma unroll
+    for (int v = 0; v < VB; ++v) {
+      b[v] = u32x4{0u, 0u, 0u, 0u};
+      if (ok[v]) b[v] = *reinterpret_cast<const u32x4*>(src[v] + ks * 16);
+    }
+  };
+  u32x4 a_cur[CB], b_cur[VB], a_nxt[CB], b_nxt[VB];
+  tap_setup(0);
+  request(0, a_cur, b_cur);
+  const int total = p.ntaps * p.KS;
+  int rt = 0, rks = 0;
+  for (int i = 0; i < total; ++i) {
+    const bool has = i + 1 < total;
+    if (has) {
+      if (++rks == p.KS) { rks = 0; tap_setup(++rt); }
+      request(rks, a_nxt, b_nxt);
+    }
+#pragma unroll
+    for (int v = 0; v < VB; ++v)
+#pragma unroll
+      for (int c = 0; c < CB; ++c) acc[v][c] = T::mfma(a_cur[c], b_cur[v], acc[v][c]);
+    if (has) {
+#pragma unroll
+      for (int c = 0; c < CB; ++c) a_cur[c] = a_nxt[c];
+#pragma unroll
+      for (int v = 0; v < VB; ++v) b_cur[v] = b_nxt[v];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CB; ++c) {
+    const int cb = cg * CB + c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = cb * 32 + 8 * q + 4 * h;
+      float bq[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && cb < p.NB) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (co + j < p.Cout) bq[j] = p.bias[co + j];
+      }
+#pragma unroll
+      for (int v = 0; v < VB; ++v) {
+        if (live[v] && cb < p.NB && co < p.Cout) {
+          const int oz = gz[v] * p.os + p.ooz, oy = gy[v] * p.os + p.ooy, ox = gx[v] * p.os + p.oox;
+          if (oz < p.Do && oy < p.Ho && ox < p.Wo) {
+            unsigned short* dst = p.y + ((((long)gn[v] * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * (long)p.ldy + co;
+            const float o0 = acc[v][c][4 * q] + bq[0], o1 = acc[v][c][4 * q + 1] + bq[1], o2 = acc[v][c][4 * q + 2] + bq[2],
+                        o3 = acc[v][c][4 * q + 3] + bq[3];
+            if (co + 3 < p.Cout) {
+              *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<T>(o0, o1), pack2<T>(o2, o3)};
+            } else {
+              dst[0] = T::st(o0);
+              if (co + 1 < p.Cout) dst[1] = T::st(o1);
+              if (co + 2 < p.Cout) dst[2] = T::st(o2);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+static int lp_gather_launch(LpGatherParams p, hipStream_t stream) {
+  p.npos = (long)p.N * p.Dg * p.Hg * p.Wg;
+  const int cb = p.NB >= 2 ? 2 : 1;
+  p.ncg = (p.NB + cb - 1) / cb;
+  const long wg4 = ((p.npos + 511) / 512) * p.ncg;
+  const int vb = wg4 >= 512 ? 4 : (wg4 >= 128 ? 2 : 1);
+  const long blocks = ((p.npos + 128L * vb - 1) / (128L * vb)) * p.ncg;
+  if (blocks > 0x7fffffffL) return BTS_ERR_SHAPE;
+  const bool prof = bts_prof_on();
+  if (prof) bts_prof_begin(31, 2.0 * p.ntaps * 16.0 * p.KS * p.Cout * (double)p.npos, stream);
+  (void)hipGetLastError();
+#define LP_G_CASE(VB_, CB_) if (vb == VB_ && cb == CB_) hipLaunchKernelGGL((lp_conv_gather_kernel<T, VB_, CB_>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+  LP_G_CASE(4, 1) LP_G_CASE(4, 2) LP_G_CASE(2, 1) LP_G_CASE(2, 2) LP_G_CASE(1, 1) LP_G_CASE(1, 2)
+#undef LP_G_CASE
+  if (prof) bts_prof_end(stream);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+// y = conv(x) + bias in the storage type.  x (N,D,H,W,Cin) stride ldx (elements); y (N,D',H',W',Cout) stride ldy; D' = D | D/2
+// (TF 'same', stride 2) | 2D (transposed).  Cin must be a multiple of 16 and ldx / ldy / the views' first channel multiples of 8.
+extern "C" long bts_lp_conv3d_workspace(int kind, int N, int D, int H, int W, int Cin, int Cout) {
+  if (kind != BTS_CONV_K3S1 || Cin % 16 != 0) return 0;
+  const int NB = (Cout + 31) / 32;
+  int vb, cb, txl;
+  lp_s1_shape(N, D, H, W, NB, vb, cb, txl);
+  const int ks = lp_s1_ksplit(lp_s1_wgs(N, D, H, W, NB, vb, cb, txl), Cin / 16);
+  return ks > 1 ? (long)ks * N * D * H * W * NB * 32 * 4 : 0;
+}
+extern "C" int bts_lp_conv3d_fwd(int kind, int dtype, const void* x, const void* wp, const float* bias, void* y, void* workspace,
+                                 long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, hipStream_t stream) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return BTS_ERR_SHAPE;
+  if (Cin % 16 != 0 || ldx % 8 != 0 || ldy % 4 != 0 || ldx < Cin || ldy < Cout) return BTS_ERR_ALIGN;
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)y) & 7) || (((uintptr_t)wp) & 15)) return BTS_ERR_ALIGN;
+  const int KS = Cin / 16, NB = (Cout + 31) / 32;
+  if (kind == BTS_CONV_K3S1) {
+    if (((long)(D + 2) * H * W + 64) * (long)ldx * 2 >= 0x7fffffffL) return BTS_ERR_SHAPE;   // 31-bit offsets inside one volume
+    LpS1Params p;
+    p.x = (const unsigned short*)x; p.wp = (const unsigned short*)wp; p.bias = bias; p.y = (unsigned short*)y;
+    p.N = N; p.D = D; p.H = H; p.W = W; p.ldx = ldx; p.ldy = ldy; p.Cout = Cout; p.KS = KS; p.NB = NB;
+    return dtype == LP_F16 ? lp_s1_dispatch<TF16>(p, workspace, workspace_bytes, stream) : lp_s1_dispatch<TBF16>(p, workspace, workspace_bytes, stream);
+  }
+  LpGatherParams g;
+  g.x = (const unsigned short*)x; g.wp = (const unsigned short*)wp; g.bias = bias; g.y = (unsigned short*)y;
+  g.N = N; g.Di = D; g.Hi = H; g.Wi = W; g.ldx = ldx; g.ldy = ldy; g.Cout = Cout; g.KS = KS; g.NB = NB;
+  auto run = [&](const LpGatherParams& q) { return dtype == LP_F16 ? lp_gather_launch<TF16>(q, stream) : lp_gather_launch<TBF16>(q, stream); };
+  if (kind == BTS_CONV_K1) {
+    g.Dg = g.Do = D; g.Hg = g.Ho = H; g.Wg = g.Wo = W; g.s = 1; g.os = 1; g.ooz = g.ooy = g.oox = 0; g.ntaps = 1;
+    g.taps[0] = LpTap{0, 0, 0, 0};
+    return run(g);
+  }
+  if (kind == BTS_CONV_K3S2) {   // TF 'same', stride 2: out = ceil(in/2), pad_before = max((out-1)*2+3-in, 0) / 2
+    g.Do = (D + 1) / 2; g.Ho = (H + 1) / 2; g.Wo = (W + 1) / 2;
+    g.Dg = g.Do; g.Hg = g.Ho; g.Wg = g.Wo; g.s = 2; g.os = 1; g.ooz = g.ooy = g.oox = 0; g.ntaps = 27;
+    auto padb = [](int in, int out) { const int t = (out - 1) * 2 + 3 - in; return t > 0 ? t / 2 : 0; };
+    const int pz = padb(D, g.Do), py = padb(H, g.Ho), px = padb(W, g.Wo);
+    for (int t = 0; t < 27; ++t) g.taps[t] = LpTap{(short)(t / 9 - pz), (short)((t / 3) % 3 - py), (short)(t % 3 - px), (short)t};
+    return run(g);
+  }
+  if (kind == BTS_CONV_K3S2T) {  // y[2i+k] += x[i] w[k], cropped to [0, 2n): 8 output-parity classes, every output written once
+    g.Do = 2 * D; g.Ho = 2 * H; g.Wo = 2 * W; g.Dg = D; g.Hg = H; g.Wg = W; g.s = 1; g.os = 2;
+    for (int cls = 0; cls < 8; ++cls) {
+      const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+      // per axis: even outputs (j = 2i) take (i, k=0) and (i-1, k=2); odd outputs (j = 2i+1) take (i, k=1)
+      int noz = 0, noy = 0, nox = 0;
+      int ozs[2], kzs[2], oys[2], kys[2], oxs[2], kxs[2];
+      auto fill = [](int par, int* off, int* k) { if (par) { off[0] = 0; k[0] = 1; return 1; } off[0] = 0; k[0] = 0; off[1] = -1; k[1] = 2; return 2; };
+      noz = fill(pz, ozs, kzs); noy = fill(py, oys, kys); nox = fill(px, oxs, kxs);
+      int nt = 0;
+      for (int a = 0; a < noz; ++a)
+        for (int b2 = 0; b2 < noy; ++b2)
+          for (int c = 0; c < nox; ++c)
+            g.taps[nt++] = LpTap{(short)ozs[a], (short)oys[b2], (short)oxs[c], (short)((kzs[a] * 3 + kys[b2]) * 3 + kxs[c])};
+      g.ntaps = nt; g.ooz = pz; g.ooy = py; g.oox = px;
+      const int r = run(g);
+      if (r != BTS_OK) return r;
+    }
+    return BTS_OK;
+  }
+  return BTS_ERR_UNSUPPORTED;
+}
+
+// =====================================================================================================================
+// element-wise passes of the forward (16-bit in / out, fp32 arithmetic)
+// =====================================================================================================================
+// fp32 -> storage type, rows of C elements with row strides (elements)
+template <typename T>
+__global__ __launch_bounds__(256) void lp_cast_kernel(const float* src, long lds_, unsigned short* dst, long ldd, long rows, int C) {
+  const long total = rows * C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    dst[r * ldd + c] = T::st(src[r * lds_ + c]);
+  }
+}
+extern "C" int bts_lp_cast(int dtype, const float* src, long ld_src, void* dst, long ld_dst, long rows, int C, hipStream_t stream) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  if (rows <= 0 || C <= 0) return BTS_ERR_SHAPE;
+  long blocks = (rows * C + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  (void)hipGetLastError();
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_cast_kernel<TF16>, dim3((unsigned)blocks), dim3(256), 0, stream, src, ld_src, (unsigned short*)dst, ld_dst, rows, C);
+  else hipLaunchKernelGGL(lp_cast_kernel<TBF16>, dim3((unsigned)blocks), dim3(256), 0, stream, src, ld_src, (unsigned short*)dst, ld_dst, rows, C);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void lp_uncast_kernel(const unsigned short* src, long lds_, float* dst, long ldd, long rows, int C) {
+  const long total = rows * C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    dst[r * ldd + c] = T::ld(src[r * lds_ + c]);
+  }
+}
+extern "C" int bts_lp_uncast(int dtype, const void* src, long ld_src, float* dst, long ld_dst, long rows, int C, hipStream_t stream) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  if (rows <= 0 || C <= 0) return BTS_ERR_SHAPE;
+  long blocks = (rows * C + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  (void)hipGetLastError();
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_uncast_kernel<TF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)src, ld_src, dst, ld_dst, rows, C);
+  else hipLaunchKernelGGL(lp_uncast_kernel<TBF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)src, ld_src, dst, ld_dst, rows, C);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+// ---- GroupNormalization statistics (group_norm.py:100-107): per (n, group) sum and sum of squares from the STORED values,
+// fp64 partials per block, fixed-order combine (bts_gn_finalize_partials_).  Dense tensors (ld == C).
+//   slab mode: group g of sample n = elements [g*L, (g+1)*L) of the sample's flattened (D,H,W,C) memory
+//   channel mode: group g = channels [g*cg, (g+1)*cg)
+template <typename T>
+__global__ __launch_bounds__(256) void lp_gn_stats_kernel(const unsigned short* x, double* partial, long E, long L, int C, int G, int cg,
+                                                          int mode, int B) {
+  __shared__ double sh[8];
+  const int unit = blockIdx.y;          // n*G + g
+  const int n = unit / G, g = unit % G;
+  const unsigned short* base = x + (long)n * E;
+  double s = 0.0, q = 0.0;
+  if (mode == BTS_GN_SLAB) {
+    const long lo = (long)g * L;
+    const long per = ((L / 8 + B - 1) / B) * 8;
+    const long a = lo + (long)blockIdx.x * per, bnd = (a + per < lo + L) ? a + per : lo + L;
+    float fs = 0.f, fq = 0.f;
+    long cnt = 0;
+    for (long i = a + threadIdx.x * 8L; i < bnd; i += 256 * 8) {
+      float v[8];
+      unpack8<T>(*reinterpret_cast<const u32x4*>(base + i), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { fs += v[e]; fq = fmaf(v[e], v[e], fq); }
+      if (++cnt == 64) { s += fs; q += fq; fs = fq = 0.f; cnt = 0; }   // bounded fp32 run lengths (512 values per lane)
+    }
+    s += fs; q += fq;
+  } else {
+    const long V = E / C;
+    const long per = (V + B - 1) / B;
+    const long a = (long)blockIdx.x * per, bnd = (a + per < V) ? a + per : V;
+    const int c0 = g * cg;
+    for (long v = a + threadIdx.x; v < bnd; v += 256) {
+      float fs = 0.f, fq = 0.f;
+      for (int c = 0; c < cg; ++c) { const float t = T::ld(base[v * C + c0 + c]); fs += t; fq = fmaf(t, t, fq); }
+      s += fs; q += fq;
+    }
+  }
+  s = block_sum_f64(s, sh);
+  q = block_sum_f64(q, sh + 4);
+  if (threadIdx.x == 0) {
+    double* o = partial + ((long)unit * B + blockIdx.x) * 2;
+    o[0] = s; o[1] = q;
+  }
+}
+static int lp_gn_blocks(long L) {
+  long b = L / (256 * 8 * 8);
+  if (b < 1) b = 1;
+  if (b > 256) b = 256;
+  return (int)b;
+}
+extern "C" long bts_lp_gn_workspace(int N, long V, int C, int G) {
+  if (N <= 0 || V <= 0 || C <= 0 || G <= 0 || C % G != 0) return -1;
+  return (long)N * G * lp_gn_blocks(V * C / G) * 2 * 8 + 64;
+}
+extern "C" int bts_lp_gn_stats(int dtype, const void* x, float* mean, float* rstd, void* workspace, long workspace_bytes, int N, long V,
+                               int C, int G, int mode, float eps, hipStream_t stream) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  if (N <= 0 || V <= 0 || C < G || C % G != 0) return BTS_ERR_SHAPE;
+  const long E = V * C, L = E / G;
+  if (mode == BTS_GN_SLAB && (E % G != 0 || L % 8 != 0)) return BTS_ERR_UNSUPPORTED;
+  if (((uintptr_t)x) & 15) return BTS_ERR_ALIGN;
+  const int B = lp_gn_blocks(L);
+  if (workspace_bytes < bts_lp_gn_workspace(N, V, C, G)) return BTS_ERR_WORKSPACE;
+  double* partial = reinterpret_cast<double*>(workspace);
+  (void)hipGetLastError();
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_gn_stats_kernel<TF16>, dim3(B, N * G), dim3(256), 0, stream, (const unsigned short*)x, partial, E, L, C, G, C / G, mode, B);
+  else hipLaunchKernelGGL(lp_gn_stats_kernel<TBF16>, dim3(B, N * G), dim3(256), 0, stream, (const unsigned short*)x, partial, E, L, C, G, C / G, mode, B);
+  BTS_LAUNCH_CHECK();
+  return bts_gn_finalize_partials_(partial, mean, rstd, N * G, B, (double)L, eps, stream);
+}
+
+// ---- y = [relu]((x - mean) * rstd * gamma[idx] + beta[idx])  (group_norm.py:110-122); x dense, y rows of stride ldy
+template <typename T>
+__global__ __launch_bounds__(256) void lp_gn_apply_kernel(const unsigned short* x, unsigned short* y, const float* gamma, const float* beta,
+                                                          const float* mean, const float* rstd, long total8, long E, long L, int C, int G,
+                                                          int cg, int ldy, int mode, int relu) {
+  for (long f = blockIdx.x * 256L + threadIdx.x; f < total8; f += (long)gridDim.x * 256) {
+    const long i = f * 8;
+    const long n = i / E;
+    const long r = i - n * E;
+    const int c = (int)(r % C);
+    const long pix = i / C;
+    float v[8], o[8];
+    unpack8<T>(*reinterpret_cast<const u32x4*>(x + i), v);
+    const int gsl = (int)(r / L);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (mode == BTS_GN_SLAB) ? gsl : (c + e) / cg;
+      const int idx = (mode == BTS_GN_SLAB) ? g * cg + ((c + e) % cg) : (c + e);
+      float t = (v[e] - mean[n * G + g]) * rstd[n * G + g] * gamma[idx] + beta[idx];
+      if (relu) t = fmaxf(t, 0.f);
+      o[e] = t;
+    }
+    *reinterpret_cast<u32x4*>(y + pix * ldy + c) = pack8<T>(o);
+  }
+}
+extern "C" int bts_lp_gn_apply(int dtype, const void* x, void* y, const float* gamma, const float* beta, const float* mean,
+                               const float* rstd, int N, long V, int C, int ldy, int G, int mode, int relu, hipStream_t stream) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  if (N <= 0 || V <= 0 || C < G || C % G != 0 || C % 8 != 0 || ldy % 8 != 0 || ldy < C) return BTS_ERR_SHAPE;
+  const long E = V * C, L = E / G;
+  if (mode == BTS_GN_SLAB && L % 8 != 0) return BTS_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)y) & 15)) return BTS_ERR_ALIGN;
+  const long total8 = (long)N * E / 8;
+  long blocks = (total8 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  (void)hipGetLastError();
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_gn_apply_kernel<TF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)x, (unsigned short*)y, gamma, beta, mean, rstd, total8, E, L, C, G, C / G, ldy, mode, relu);
+  else hipLaunchKernelGGL(lp_gn_apply_kernel<TBF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)x, (unsigned short*)y, gamma, beta, mean, rstd, total8, E, L, C, G, C / G, ldy, mode, relu);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+// ---- global average pool of the shortcut (resnet.py:45-46,121): per (n, channel) mean over the voxels, fp64 partials
+template <typename T>
+__global__ __launch_bounds__(256) void lp_colsum_kernel(const unsigned short* x, double* partial, long V, int C, int B) {
+  // block (b, n): voxels [b*per, ...) ; thread t handles channel octet (t % (C/8)) of every (256 / (C/8))-th voxel
+  const int n = blockIdx.y;
+  const int oct = C / 8;
+  const int co = threadIdx.x % oct, vr = threadIdx.x / oct, vstep = 256 / oct;
+  const long per = (V + B - 1) / B;
+  const long a = (long)blockIdx.x * per, bnd = (a + per < V) ? a + per : V;
+  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float fs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int cnt = 0;
+  if (vr < vstep) {
+    for (long v = a + vr; v < bnd; v += vstep) {
+      float t[8];
+      unpack8<T>(*reinterpret_cast<const u32x4*>(x + ((long)n * V + v) * C + co * 8), t);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) fs[e] += t[e];
+      if (++cnt == 256) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += fs[e]; fs[e] = 0.f; }
+        cnt = 0;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] += fs[e];
+  // combine the vstep voxel-rows through LDS in fixed order
+  __shared__ double sh[256 * 8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sh[threadIdx.x * 8 + e] = (vr < vstep) ? s[e] : 0.0;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    const int c = threadIdx.x, o = c / 8, e = c % 8;
+    double tot = 0.0;
+    for (int r = 0; r < vstep; ++r) tot += sh[(r * oct + o) * 8 + e];
+    partial[((long)n * B + blockIdx.x) * C + c] = tot;
+  }
+}
+__global__ __launch_bounds__(256) void lp_colsum_finalize_kernel(const double* partial, float* out, int N, int C, int B, double scale) {
+  // one wave per (n, c): lanes split the blocks, fixed-order shuffle tree
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= N * C) return;
+  const int n = i / C, c = i % C;
+  double s = 0.0;
+  for (int b = lane; b < B; b += 64) s += partial[((long)n * B + b) * C + c];
+  s = wave_sum_f64(s);
+  if (lane == 0) out[i] = (float)(s * scale);
+}
+static int lp_colsum_blocks(long V) {
+  long b = V / 2048;
+  if (b < 1) b = 1;
+  if (b > 512) b = 512;
+  return (int)b;
+}
+extern "C" long bts_lp_colsum_workspace(int N, long V, int C) {
+  if (N <= 0 || V <= 0 || C <= 0) return -1;
+  return (long)N * lp_colsum_blocks(V) * C * 8 + 64;
+}
+extern "C" int bts_lp_colsum(int dtype, const void* x, float* out, void* workspace, long workspace_bytes, int N, long V, int C, float scale,
+                             hipStream_t stream) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  if (N <= 0 || V <= 0 || C % 8 != 0 || C > 256 || 256 % (C / 8) != 0) return BTS_ERR_SHAPE;
+  if (((uintptr_t)x) & 15) return BTS_ERR_ALIGN;
+  const int B = lp_colsum_blocks(V);
+  if (workspace_bytes < bts_lp_colsum_workspace(N, V, C)) return BTS_ERR_WORKSPACE;
+  double* partial = reinterpret_cast<double*>(workspace);
+  (void)hipGetLastError();
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_colsum_kernel<TF16>, dim3(B, N), dim3(256), 0, stream, (const unsigned short*)x, partial, V, C, B);
+  else hipLaunchKernelGGL(lp_colsum_kernel<TBF16>, dim3(B, N), dim3(256), 0, stream, (const unsigned short*)x, partial, V, C, B);
+  BTS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(lp_colsum_finalize_kernel, dim3((N * C + 3) / 4), dim3(256), 0, stream, partial, out, N, C, B, (double)scale);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+// ---- ResNet block epilogue (resnet.py:127-137): out = res * (sigmoid(res . w_sp) + ch[n]) + relu(GN2(c2))
+// one voxel per group of C/8 lanes: the spatial dot product is reduced across those lanes with xor shuffles
+template <typename T>
+__global__ __launch_bounds__(256) void lp_block_epilogue_kernel(const unsigned short* res, const unsigned short* c2, unsigned short* out,
+                                                                const float* wsp, const float* ch, const float* gamma, const float* beta,
+                                                                const float* mean, const float* rstd, long total8, long E, long L, int C,
+                                                                int G, int cg, int ldo, int mode) {
+  const int oct = C / 8;
+  for (long f = blockIdx.x * 256L + threadIdx.x; f < total8; f += (long)gridDim.x * 256) {
+    const long i = f * 8;
+    const long n = i / E;
+    const long r = i - n * E;
+    const int c = (int)(r % C);
+    const long pix = i / C;
+    float a[8], b[8], o[8];
+    unpack8<T>(*reinterpret_cast<const u32x4*>(res + i), a);
+    unpack8<T>(*reinterpret_cast<const u32x4*>(c2 + i), b);
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dot = fmaf(a[e], wsp[c + e], dot);
+    for (int m = 1; m < oct; m <<= 1) dot += __shfl_xor(dot, m, 64);   // (oct is a power of two <= 32; lanes of a voxel are adjacent)
+    const float sp = 1.f / (1.f + __expf(-dot));
+    const int gsl = (int)(r / L);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (mode == BTS_GN_SLAB) ? gsl : (c + e) / cg;
+      const int idx = (mode == BTS_GN_SLAB) ? g * cg + ((c + e) % cg) : (c + e);
+      const float t = fmaxf((b[e] - mean[n * G + g]) * rstd[n * G + g] * gamma[idx] + beta[idx], 0.f);
+      o[e] = fmaf(a[e], sp + ch[n * C + c + e], t);
+    }
+    *reinterpret_cast<u32x4*>(out + pix * ldo + c) = pack8<T>(o);
+  }
+}
+extern "C" int bts_lp_block_epilogue(int dtype, const void* res, const void* c2, void* out, const float* wsp, const float* ch,
+                                     const float* gamma, const float* beta, const float* mean, const float* rstd, int N, long V, int C,
+                                     int ldo, int G, int mode, hipStream_t stream) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  if (N <= 0 || V <= 0 || C % 8 != 0 || C > 256 || ((C / 8) & (C / 8 - 1)) != 0 || C % G != 0 || ldo % 8 != 0 || ldo < C) return BTS_ERR_SHAPE;
+  const long E = V * C, L = E / G;
+  if (mode == BTS_GN_SLAB && L % 8 != 0) return BTS_ERR_UNSUPPORTED;
+  if ((((uintptr_t)res) & 15) || (((uintptr_t)c2) & 15) || (((uintptr_t)out) & 15)) return BTS_ERR_ALIGN;
+  const long total8 = (long)N * E / 8;
+  // (the C/8 lanes of a voxel are adjacent and aligned inside a wave, so they enter and leave the loop together)
+  long blocks = (total8 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  (void)hipGetLastError();
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_block_epilogue_kernel<TF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)res, (const unsigned short*)c2, (unsigned short*)out, wsp, ch, gamma, beta, mean, rstd, total8, E, L, C, G, C / G, ldo, mode);
+  else hipLaunchKernelGGL(lp_block_epilogue_kernel<TBF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)res, (const unsigned short*)c2, (unsigned short*)out, wsp, ch, gamma, beta, mean, rstd, total8, E, L, C, G, C / G, ldo, mode);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+// ---- output head (decoder.py:55-63): y = sigmoid(x . W + b), 1x1x1 conv to out_ch <= 4 channels, fp32 result (the label map
+// is taken from it, so it is never rounded to 16 bits).  One voxel per lane, weights in registers via scalar loads.
+template <typename T>
+__global__ __launch_bounds__(256) void lp_head_kernel(const unsigned short* x, const float* w, const float* bias, float* y, long nvox, int C,
+                                                      int ldx, int K, int sigmoid) {
+  for (long v = blockIdx.x * 256L + threadIdx.x; v < nvox; v += (long)gridDim.x * 256) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < C; c0 += 8) {
+      float t[8];
+      unpack8<T>(*reinterpret_cast<const u32x4*>(x + v * ldx + c0), t);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < K) acc[k] = fmaf(t[e], w[(c0 + e) * K + k], acc[k]);
+    }
+    for (int k = 0; k < K; ++k) {
+      float o = acc[k] + (bias ? bias[k] : 0.f);
+      if (sigmoid) o = 1.f / (1.f + __expf(-o));
+      y[v * K + k] = o;
+    }
+  }
+}
+extern "C" int bts_lp_head(int dtype, const void* x, const float* w, const float* bias, float* y, long nvox, int C, int ldx, int K, int sigmoid,
+                           hipStream_t stream) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  if (nvox <= 0 || C % 8 != 0 || K < 1 || K > 4 || ldx % 8 != 0) return BTS_ERR_SHAPE;
+  if (((uintptr_t)x) & 15) return BTS_ERR_ALIGN;
+  long blocks = (nvox + 255) / 256;
+  if (blocks > 32768) blocks = 32768;
+  (void)hipGetLastError();
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_head_kernel<TF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)x, w, bias, y, nvox, C, ldx, K, sigmoid);
+  else hipLaunchKernelGGL(lp_head_kernel<TBF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)x, w, bias, y, nvox, C, ldx, K, sigmoid);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}

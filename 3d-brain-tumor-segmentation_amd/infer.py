@@ -48,10 +48,17 @@ class TestTimeAugmentor(object):
     __test__ = False  # not a pytest class
 
     def __init__(self, mean, std, model, model_data_format='channels_last', spatial_tta=True, channel_tta=0, threshold=0.5,
-                 seed=0):
+                 seed=0, compute_dtype='float32'):
+        """compute_dtype: 'float32' (the engine's parity path) | 'float16' | 'bfloat16' -- 16-bit STORAGE of activations and
+        weight images with fp32 sums (bts_amd.lowp; BASELINE configs[4] runs the forwards in fp16)"""
         if model_data_format != 'channels_last':
             raise NotImplementedError('channels_first public layout is SURVEY 8 f-4 (not built)')
         self.model = model
+        if compute_dtype in ('float32', 'fp32', 'f32'):
+            self._forward = lambda aug: self.model(aug, training=False, inference=True)[0]
+        else:
+            from .lowp import LowPrecisionForward
+            self._forward = LowPrecisionForward(model, compute_dtype)
         self.mean, self.std = mean, std
         self.model_data_format = model_data_format
         self.channel_tta = int(channel_tta)
@@ -71,7 +78,8 @@ class TestTimeAugmentor(object):
         sig = None
         if self.channel_tta:
             xn = ops.flip_affine(xs, 0, mean, std)
-            sig = xn.reshape(-1, xn.shape[-1]).std(dim=0, unbiased=False)          # tf.nn.moments over the spatial axes
+            _, var = ops.channel_moments(xn[0])                                     # tf.nn.moments over the spatial axes
+            sig = torch.sqrt(var)
         for flip in self.flips:
             variants = [(None, None)]
             for _ in range(self.channel_tta):
@@ -84,7 +92,7 @@ class TestTimeAugmentor(object):
                     aug = ops.flip_affine(xs, flip, mean, std)                       # normalise + tf.reverse in one pass
                 else:  # (x_norm + shift*sigma)*scale == (x - (mean - shift*sigma*std)) / (std / scale)
                     aug = ops.flip_affine(xs, flip, (mean - shift * std).contiguous(), (std / scale).contiguous())
-                y = self.model(aug, training=False, inference=True)[0]
+                y = self._forward(aug)
                 yt = y.t if isinstance(y, Tensor) else y
                 if acc is None:
                     acc = ops.flip_affine(yt.contiguous(), flip, scale=1.0 / count)  # un-flip, start the mean
@@ -101,11 +109,12 @@ class TestTimeAugmentor(object):
         return lab[0]
 
 
-def segment_volume(model, x, mask, mean, std, spatial_res, spatial_tta=True, threshold=0.5):
+def segment_volume(model, x, mask, mean, std, spatial_res, spatial_tta=True, threshold=0.5, compute_dtype='float32'):
     """test.py:246-261 for one volume: pad to the model's spatial resolution, TTA inference, crop back.
     -> (probabilities (D,H,W,out_ch), uint8 labels (D,H,W))"""
     xp, mp, orig = pad_to_spatial_res(spatial_res, x, mask)
-    tta = TestTimeAugmentor(mean, std, model, 'channels_last', spatial_tta=spatial_tta, threshold=threshold)
+    tta = TestTimeAugmentor(mean, std, model, 'channels_last', spatial_tta=spatial_tta, threshold=threshold,
+                            compute_dtype=compute_dtype)
     y = tta(xp, mp)
     lab = tta.labels()
     return y[:orig[0], :orig[1], :orig[2]], lab[:orig[0], :orig[1], :orig[2]]

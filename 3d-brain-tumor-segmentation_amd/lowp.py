@@ -1,0 +1,256 @@
+"""Reduced-precision STORAGE forward of the model (BASELINE configs[4]: full-volume fp16 inference with the VAE branch off,
+model.py:67-68 / test.py:128-134; the same kernels in bf16 are the forward half of configs[2]).
+
+Activations and packed weights are 16-bit, every sum is fp32: convolutions on v_mfma_f32_32x32x16_{f16,bf16}, GroupNorm
+statistics, SE gates and the sigmoid head in fp32 from the stored values (csrc/lowp.hip).  The master weights stay the
+model's fp32 variables; 16-bit weight images are re-packed when the weights epoch changes.  The reference has no reduced
+precision mode, so the parity reference of this path is the fp32 engine (tests/test_lowp_gpu.py).
+
+The graph walked here is the fp32 layers' own (encoder.py:69-101 incl. the folded duplicated dense connections F4,
+resnet.py:116-138, downsample.py:41-45, upsample.py:39-43, decoder.py:65-83) with the same virtual concatenation through
+level slabs.  The first block reads the 2-channel input volume: a 16-channel matrix step is the 16-bit instructions' floor,
+so that block's two convolutions run on the fp32 kernels and their outputs are rounded once.
+"""
+import ctypes
+
+import torch
+
+from . import ops
+from ._lib import lib
+from .tape import weights_epoch
+
+DTYPES = {'float16': (1, torch.float16), 'bfloat16': (2, torch.bfloat16), 'fp16': (1, torch.float16),
+          'bf16': (2, torch.bfloat16), 'f16': (1, torch.float16)}
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ld(t):
+    """voxel stride in elements of a [N,D,H,W,C] tensor or channel-slice view"""
+    if t.stride(-1) != 1:
+        raise RuntimeError('channel stride must be 1')
+    ld = t.stride(-2)
+    n, d, h, w, _ = t.shape
+    if (w > 1 and t.stride(3) != ld) or (h > 1 and t.stride(2) != ld * w) or (d > 1 and t.stride(1) != ld * w * h) or \
+            (n > 1 and t.stride(0) != ld * w * h * d):
+        raise RuntimeError('tensor is not a channel slice of a dense NDHWC buffer')
+    return ld
+
+
+# ---- C-ABI wrappers ----------------------------------------------------------------------------------------------------
+def pack(kind, code, w, cin_ref, cout, cin_slab=None, dup_start=0, dup_shift=0):
+    cin_slab = cin_ref if cin_slab is None else cin_slab
+    nbytes = lib().query('bts_lp_packed_bytes', kind, cin_slab, cout)
+    wp = torch.empty(nbytes // 2, dtype=torch.int16, device=w.device)
+    lib().call('bts_lp_pack', kind, code, _p(w), _p(wp), cin_ref, cout, cin_slab, dup_start, dup_shift, _stream())
+    return wp
+
+
+def conv(kind, code, tdt, x, wp, bias, cout, out=None):
+    n, d, h, w, cin = x.shape
+    do, ho, wo = (d, h, w) if kind in (ops.K1, ops.K3S1) else ((d + 1) // 2, (h + 1) // 2, (w + 1) // 2) if kind == ops.K3S2 \
+        else (2 * d, 2 * h, 2 * w)
+    if out is None:
+        out = torch.empty((n, do, ho, wo, cout), dtype=tdt, device=x.device)
+    elif tuple(out.shape) != (n, do, ho, wo, cout):
+        raise RuntimeError('conv output view has shape %s, expected %s' % (tuple(out.shape), (n, do, ho, wo, cout)))
+    nb = lib().query('bts_lp_conv3d_workspace', kind, n, d, h, w, cin, cout)
+    ws = ops.workspace(nb, x.device) if nb > 0 else None
+    lib().call('bts_lp_conv3d_fwd', kind, code, _p(x), _p(wp), _p(bias) if bias is not None else None, _p(out),
+               _p(ws) if ws is not None else None, nb, n, d, h, w, cin, _ld(x), cout, _ld(out), _stream())
+    return out
+
+
+def cast(code, tdt, src, out=None):
+    c = src.shape[-1]
+    rows = src.numel() // c
+    if out is None:
+        out = torch.empty(src.shape, dtype=tdt, device=src.device)
+    lib().call('bts_lp_cast', code, _p(src), src.stride(-2), _p(out), out.stride(-2), rows, c, _stream())
+    return out
+
+
+def uncast(code, src):
+    c = src.shape[-1]
+    rows = src.numel() // c
+    out = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    lib().call('bts_lp_uncast', code, _p(src), src.stride(-2), _p(out), out.stride(-2), rows, c, _stream())
+    return out
+
+
+def gn_stats(code, x, groups, mode, eps):
+    n, c = x.shape[0], x.shape[4]
+    v = x.shape[1] * x.shape[2] * x.shape[3]
+    if not x.is_contiguous():
+        raise RuntimeError('GroupNormalization statistics need a dense tensor')
+    nb = lib().query('bts_lp_gn_workspace', n, v, c, groups)
+    ws = ops.workspace(nb, x.device)
+    mean = torch.empty(n * groups, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    lib().call('bts_lp_gn_stats', code, _p(x), _p(mean), _p(rstd), _p(ws), nb, n, v, c, groups, mode, float(eps), _stream())
+    return mean, rstd
+
+
+def gn_apply(code, x, gamma, beta, mean, rstd, groups, mode, relu, out=None):
+    n, c = x.shape[0], x.shape[4]
+    v = x.shape[1] * x.shape[2] * x.shape[3]
+    if out is None:
+        out = torch.empty_like(x)
+    lib().call('bts_lp_gn_apply', code, _p(x), _p(out), _p(gamma), _p(beta), _p(mean), _p(rstd), n, v, c, _ld(out), groups, mode,
+               1 if relu else 0, _stream())
+    return out
+
+
+def colsum(code, x, scale):
+    n, c = x.shape[0], x.shape[4]
+    v = x.shape[1] * x.shape[2] * x.shape[3]
+    nb = lib().query('bts_lp_colsum_workspace', n, v, c)
+    ws = ops.workspace(nb, x.device)
+    out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    lib().call('bts_lp_colsum', code, _p(x), _p(out), _p(ws), nb, n, v, c, float(scale), _stream())
+    return out
+
+
+def block_epilogue(code, res, c2, out, wsp, ch, gamma, beta, mean, rstd, groups, mode):
+    n, f = res.shape[0], res.shape[4]
+    v = res.shape[1] * res.shape[2] * res.shape[3]
+    lib().call('bts_lp_block_epilogue', code, _p(res), _p(c2), _p(out), _p(wsp), _p(ch), _p(gamma), _p(beta), _p(mean), _p(rstd), n, v,
+               f, _ld(out), groups, mode, _stream())
+    return out
+
+
+def head(code, x, w, bias, sigmoid=True):
+    n, d, h, wd, c = x.shape
+    k = w.shape[-1]
+    y = torch.empty((n, d, h, wd, k), dtype=torch.float32, device=x.device)
+    lib().call('bts_lp_head', code, _p(x), _p(w), _p(bias) if bias is not None else None, _p(y), n * d * h * wd, c, _ld(x), k,
+               1 if sigmoid else 0, _stream())
+    return y
+
+
+# ---- the forward graph -------------------------------------------------------------------------------------------------
+class LowPrecisionForward(object):
+    """model(x, training=False, inference=True) with 16-bit storage: `LowPrecisionForward(model, 'float16')(x)` -> y_pred fp32
+    [N,D,H,W,out_ch] (model.py:63-68).  Default samplers (conv down / up-sampling) and channels_last public layout only."""
+
+    def __init__(self, model, dtype='float16'):
+        if dtype not in DTYPES:
+            raise ValueError('dtype must be one of %s' % sorted(DTYPES))
+        self.model = model
+        self.code, self.tdt = DTYPES[dtype]
+        self._packs = {}
+        from .layers.downsample import ConvDownsample
+        from .layers.upsample import ConvUpsample
+        for convs, down in model.encoder.levels:
+            if down is not None and not isinstance(down, ConvDownsample):
+                raise NotImplementedError('the 16-bit forward covers the default conv down-sampling only')
+        for up, _ in model.decoder.levels:
+            if not isinstance(up, ConvUpsample):
+                raise NotImplementedError('the 16-bit forward covers the default conv up-sampling only')
+        if model.data_format != 'channels_last':
+            raise NotImplementedError('the 16-bit forward takes channels_last volumes')
+
+    def _packed(self, key, kind, param, cin_ref, cout, cin_slab=None, dup_start=0, dup_shift=0):
+        ent = self._packs.get(key)
+        sig = (kind, cin_ref, cout, cin_slab, dup_start, dup_shift, id(param))
+        if ent is None or ent[0] != weights_epoch() or ent[1] != sig:
+            ent = (weights_epoch(), sig, pack(kind, self.code, param.t, cin_ref, cout, cin_slab, dup_start, dup_shift))
+            self._packs[key] = ent
+        return ent[2]
+
+    def _gn(self, norm, c, relu, out=None):
+        m, r = gn_stats(self.code, c, norm.groups, norm._mode, norm.epsilon)
+        return gn_apply(self.code, c, norm.gamma.t, norm.beta.t, m, r, norm.groups, norm._mode, relu, out=out)
+
+    def _block(self, blk, x, out, fold=None):
+        """ResnetBlock.call (resnet.py:116-138); x: 16-bit view (or the fp32 2-channel input volume), out: 16-bit view or None"""
+        code, tdt = self.code, self.tdt
+        f, g = blk.filters, blk.groups
+        n, d, h, w, cin = x.shape
+        dup_start, dup_shift = fold if fold else (0, 0)
+        v = d * h * w
+        if x.dtype == torch.float32:      # the 2-channel input block: fp32 kernels, outputs rounded once
+            wp_pt = blk.packed('pt_f', ops.K1, ops.ROLE_FWD, blk.ptwise_k, blk.cin_ref, f)
+            wp_c1 = blk.packed('c1_f', ops.K3S1, ops.ROLE_FWD, blk.conv1_k, blk.cin_ref, f)
+            fused = ops.conv_fwd_fused2(x, wp_c1, blk.conv1_b.t, wp_pt, blk.ptwise_b.t, f)
+            if fused is not None:
+                c1f, resf = fused
+            else:
+                resf = ops.conv_fwd(ops.K1, x, wp_pt, blk.ptwise_b.t, f)
+                c1f = ops.conv_fwd(ops.K3S1, x, wp_c1, blk.conv1_b.t, f)
+            res, c1 = cast(code, tdt, resf), cast(code, tdt, c1f)
+            del resf, c1f
+        else:
+            key = id(blk)
+            wp_pt = self._packed((key, 'pt'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin, dup_start, dup_shift)
+            wp_c1 = self._packed((key, 'c1'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin, dup_start, dup_shift)
+            res = conv(ops.K1, code, tdt, x, wp_pt, blk.ptwise_b.t, f)
+            c1 = conv(ops.K3S1, code, tdt, x, wp_c1, blk.conv1_b.t, f)
+        gap = colsum(code, res, 1.0 / v)
+        _, ch = ops.se_mlp_fwd(gap, blk.se_w1.t, blk.se_w2.t)
+        a = self._gn(blk.norm1, c1, True)
+        del c1
+        wp_c2 = self._packed((id(blk), 'c2'), ops.K3S1, blk.conv2_k, f, f)
+        c2 = conv(ops.K3S1, code, tdt, a, wp_c2, blk.conv2_b.t, f)
+        del a
+        m2, r2 = gn_stats(code, c2, g, blk.norm2._mode, blk.norm2.epsilon)
+        if out is None:
+            out = torch.empty((n, d, h, w, f), dtype=tdt, device=res.device)
+        return block_epilogue(code, res, c2, out, blk.spatial_k.t.reshape(-1), ch, blk.norm2.gamma.t, blk.norm2.beta.t, m2, r2, g,
+                              blk.norm2._mode)
+
+    def _down(self, lay, x):
+        wp = self._packed((id(lay), 'f'), ops.K3S2, lay.conv_k, lay.cin, lay.filters)
+        c = conv(ops.K3S2, self.code, self.tdt, x, wp, lay.conv_b.t, lay.filters)
+        return self._gn(lay.norm, c, True)
+
+    def _up(self, lay, x, out):
+        wp = self._packed((id(lay), 'f'), ops.K3S2T, lay.conv_k, lay.cin, lay.filters)
+        c = conv(ops.K3S2T, self.code, self.tdt, x, wp, lay.conv_b.t, lay.filters)
+        return self._gn(lay.norm, c, True, out=out)
+
+    def __call__(self, x):
+        m = self.model
+        if not m.built:
+            raise RuntimeError('build the model first (its weights belong to a training crop)')
+        if not torch.is_tensor(x):
+            x = torch.as_tensor(x)
+        if not x.is_cuda:
+            if not torch.cuda.is_available():
+                raise RuntimeError('no MI355X visible: the engine has no CPU execution path')
+            x = x.cuda()
+        x = x.float().contiguous()
+        if any(s % (2 ** (m.encoder.depth - 1)) for s in x.shape[1:4]):
+            raise ValueError('spatial sizes must be multiples of %d (test.py:164-178 pads to that)' % 2 ** (m.encoder.depth - 1))
+        enc, dec = m.encoder, m.decoder
+        n = x.shape[0]
+        residuals = []
+        cur = x
+        for i, (convs, down) in enumerate(enc.levels):
+            d, h, w = cur.shape[1:4]
+            f = enc.base_filters * 2 ** i
+            nb = len(convs)
+            spare = f if i < enc.depth - 1 else 0
+            slab = torch.empty((n, d, h, w, nb * f + spare), dtype=self.tdt, device=x.device)
+            for j, blk in enumerate(convs):
+                out = slab[..., j * f:(j + 1) * f]
+                if j == 0:
+                    self._block(blk, cur, out)
+                else:
+                    self._block(blk, slab[..., :j * f], out, fold=((j - 1) * f, f))       # encoder.py:83-87
+            residuals.append((slab, nb * f))
+            if down is not None:
+                cur = self._down(down, slab[..., :nb * f])                                # encoder.py:97-98
+        slab, used = residuals[-1]
+        y = slab[..., :used]
+        for (up, blk), (slab, cres) in zip(dec.levels, residuals[-2::-1]):
+            f = up.filters
+            self._up(up, y, slab[..., cres:cres + f])                                     # decoder.py:72
+            y = self._block(blk, slab[..., :cres + f], None)                              # decoder.py:75-78
+        return head(self.code, y, dec.out_k.t.reshape(dec.out_k.t.shape[-2], dec.out_k.t.shape[-1]), dec.out_b.t, True)

@@ -161,6 +161,103 @@ def launch_ranks(args, argv):
         raise SystemExit('rank exit codes %s' % codes)
 
 
+PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak (v_mfma_f32_32x32x16_*)
+INFER_ALGORITHMIC_GFLOP = 3984.7   # 160x192x160 forward without the VAE branch
+INFER_ALGORITHMIC_GB = {'f16': 8.7, 'bf16': 8.7, 'f32': 17.25}   # 8.55 GB of 16-bit activations + 149 MB weights
+
+
+def run_infer(args, world, rank, dev, overrides):
+    """BASELINE configs[4]: 2ch x 155x190x147 zero-padded to 160x192x160 (test.py:164-178), inference=True (VAE skipped,
+    model.py:67-68), CLI-default model, batch 1 per GPU.  A step = one forward.  N > 1: independent replicas (the path has no
+    exchange step)."""
+    import torch
+    from bts_amd import lowp, ops, parallel
+    from bts_amd.model import Model
+    dt = {'f32': 'f32', 'fp32': 'f32', 'float32': 'f32', None: 'f16', 'f16': 'f16', 'fp16': 'f16', 'float16': 'f16',
+          'bf16': 'bf16', 'bfloat16': 'bf16'}[args.dtype]
+    model = Model(base_filters=32, reduction=8, depth=4, groups=8)
+    model.build((1, 128, 128, 128, 2))     # the weights belong to the training crop (the VAE is tied to it, vae.py:101-111)
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randn((1, 160, 192, 160, 2), generator=g)
+    x[:, 155:] = 0
+    x[:, :, 190:] = 0
+    x[:, :, :, 147:] = 0
+    x = x.to(dev)
+    if dt == 'f32':
+        fwd = lambda: model(x, training=False, inference=True)[0].t
+    else:
+        run = lowp.LowPrecisionForward(model, {'f16': 'float16', 'bf16': 'bfloat16'}[dt])
+        fwd = lambda: run(x)
+    for _ in range(args.warmup):
+        y = fwd()
+    torch.cuda.synchronize()
+    if parallel.active():
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    do_prof = not args.no_profile
+    if do_prof:
+        ops.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = fwd()
+    torch.cuda.synchronize()
+    if parallel.active():
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dts = time.perf_counter() - t0
+    ranks_seen = 1
+    if parallel.active():
+        tt, one = torch.tensor([dts], dtype=torch.float64), torch.ones(1, dtype=torch.float64)
+        if torch.distributed.get_backend() != 'gloo':
+            tt, one = tt.to(dev), one.to(dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(one, op=torch.distributed.ReduceOp.SUM)
+        dts, ranks_seen = float(tt.item()), int(round(float(one.item())))
+    prof = None
+    if do_prof:
+        ops.profile_enable(False)
+        prof = ops.profile_records()
+    if parallel.active():
+        torch.distributed.destroy_process_group()
+    if rank != 0:
+        return
+    sec = dts / args.steps
+    out = {
+        'metric': 'inference volumes/sec (2ch x 155x190x147 padded to 160x192x160, VAE off)', 'value': ranks_seen / sec,
+        'unit': 'volumes/s', 'n_gpus': world, 'ranks_seen': ranks_seen, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * sec, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dt, 'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[4]: full-volume inference, 2ch x 155x190x147 zero-padded to 160x192x160, inference=True '
+                               '(decoder path, VAE off), batch 1 per GPU, CLI-default model; storage %s, fp32 sums' % dt,
+                   'parallelism': 'replicas%d' % world},
+        'y_pred_mean': float(y.mean()),
+        # whole-forward rooflines (SURVEY 8d figures): both terms, the larger one bounds the forward
+        'forward_rooflines': {
+            'algorithmic_gflop': INFER_ALGORITHMIC_GFLOP, 'algorithmic_gb': INFER_ALGORITHMIC_GB[dt],
+            'mfma_frac': INFER_ALGORITHMIC_GFLOP / 1e3 / sec / (PEAK_F32_MFMA_TFLOPS if dt == 'f32' else PEAK_F16_MFMA_TFLOPS),
+            'hbm_frac': INFER_ALGORITHMIC_GB[dt] / 1e3 / sec / PEAK_HBM_TBS},
+    }
+    if overrides:
+        out['overrides'] = overrides
+    if prof:
+        agg = {}
+        for sym, flops, ms in prof:
+            a = agg.setdefault(sym, [0.0, 0.0, 0])
+            a[0] += ms * 1e-3
+            a[1] += flops
+            a[2] += 1
+        sym, (tsec, fl, nl) = max(agg.items(), key=lambda kv: kv[1][0])
+        lowp_kernel = sym.startswith('lp_')
+        wino = sym in ('wino_kernel', 'wgw_kernel')
+        peak = PEAK_F16_MFMA_TFLOPS if lowp_kernel else PEAK_F32_MFMA_TFLOPS
+        ach = fl / tsec / 1e12 * (WINOGRAD_EXECUTED if wino else 1.0)
+        out['roofline'] = {'kernel': sym, 'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+                           'traffic': None, 'launches_per_step': nl / args.steps, 'avg_launch_ms': 1e3 * tsec / nl,
+                           'algorithmic_gflop_per_launch': fl / nl / 1e9, 'time_share_of_step': tsec / dts}
+        out['kernel_breakdown'] = {k: {'ms_per_step': 1e3 * v[0] / args.steps, 'tflops': v[1] / v[0] / 1e12,
+                                       'launches_per_step': v[2] / args.steps} for k, v in sorted(agg.items())}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -173,6 +270,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-crop', type=int, default=128)
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--infer', action='store_true', help='BASELINE configs[4]: full-volume inference (VAE off) instead of the train step')
+    ap.add_argument('--dtype', default=None, help="storage type of the --infer forward: f32 | f16 (default) | bf16")
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -209,6 +308,9 @@ def main():
         parallel.init_from_env('gloo' if shared else 'nccl')
     dev = torch.device('cuda', local)
 
+    if args.infer:
+        run_infer(args, world, rank, dev, overrides)
+        return
     crop = (args.crop,) * 3
     nb = args.batch
     kw = dict(base_filters=32, reduction=8, depth=4, groups=8)

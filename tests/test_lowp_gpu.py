@@ -1,0 +1,248 @@
+"""-m gpu: the reduced-precision STORAGE forward (csrc/lowp.hip, bts_amd/lowp.py; BASELINE configs[4] fp16 inference, the forward
+half of configs[2] in bf16).  The reference has no such mode; what is checked:
+
+  * every kernel against the oracle's op on the SAME 16-bit-rounded operands, evaluated in fp64: the only differences left are
+    the fp32 summation order and the final rounding of the result to the storage type.  Stated tolerance:
+        |err| <= 8 * 2^-24 * sum|a_i b_i|  +  u * |ref|  (+ u * |ref| again where a second rounding is part of the op),
+    u = 2^-11 (fp16) or 2^-8 (bf16), the storage type's unit round-off;
+  * the whole 16-bit forward against the fp32 engine on the same weights and volume: probabilities, label map, Dice -- reported,
+    and bounded by the tolerances stated at the test (fp16: |dp| <= 2e-2, <= 0.2 % label changes; bf16 8x the fp16 bounds).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import torch_ref as R  # noqa: E402
+
+DEV = torch.device('cuda', 0)
+U = {'float16': 2.0 ** -11, 'bfloat16': 2.0 ** -8}
+
+
+def _round(t, tdt):
+    return t.to(tdt).to(torch.float64)
+
+
+def _ref_conv(kind, x, w, b):
+    from bts_amd import ops
+    if kind == ops.K3S2T:
+        return R.conv3d_transpose(x, w, b)
+    return R.conv3d(x, w, b, stride=2 if kind == ops.K3S2 else 1)
+
+
+def _abs_conv(kind, x, w):
+    """sum |a_i b_i| per output: the same op on absolute values"""
+    return _ref_conv(kind, x.abs(), w.abs(), None)
+
+
+CONV_CASES = [
+    # kind, (D,H,W), Cin, Cout, slab_in (ld > Cin), slab_out
+    ('K3S1', (8, 8, 32), 32, 32, False, False),
+    ('K3S1', (10, 12, 10), 32, 64, True, True),       # level-3 grid of the 160x192x160 volume: ragged tiles on every axis
+    ('K3S1', (4, 8, 16), 64, 128, False, True),
+    ('K3S1', (4, 4, 36), 16, 32, True, False),        # two x tiles, the second one ragged
+    ('K1', (6, 5, 7), 48, 32, True, True),
+    ('K1', (8, 8, 8), 16, 96, False, False),
+    ('K3S2', (8, 12, 16), 32, 32, True, False),
+    ('K3S2', (4, 4, 4), 64, 64, False, True),
+    ('K3S2T', (4, 6, 5), 32, 32, False, True),
+    ('K3S2T', (3, 3, 3), 64, 64, True, False),
+]
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: '%s-%dx%dx%d-%d-%d' % (c[0], *c[1], c[2], c[3]))
+def test_conv_kernels(case, dtype):
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    name, (d, h, w), cin, cout, slab_in, slab_out = case
+    kind = getattr(ops, name)
+    code, tdt = lowp.DTYPES[dtype]
+    g = torch.Generator().manual_seed(hash((name, d, h, w, cin, cout)) % 10000)
+    n = 2
+    x = torch.randn((n, d, h, w, cin), generator=g)
+    k = 1 if kind == ops.K1 else 3
+    wshape = (k, k, k, cout, cin) if kind == ops.K3S2T else (k, k, k, cin, cout)
+    wt = torch.randn(wshape, generator=g) * (2.0 / (k ** 3 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.3
+    xr, wr = _round(x, tdt), _round(wt, tdt)
+    ref = _ref_conv(kind, xr, wr, b.double())
+    bound = 8 * 2.0 ** -24 * _abs_conv(kind, xr, wr) + U[dtype] * ref.abs() + 1e-30
+    ldx = cin + 16 if slab_in else cin
+    xin = torch.zeros((n, d, h, w, ldx), dtype=tdt, device=DEV)
+    c0 = 16 if slab_in else 0
+    xin[..., c0:c0 + cin] = x.to(tdt).to(DEV)
+    wp = lowp.pack(kind, code, wt.to(DEV), cin, cout)
+    out = None
+    if slab_out:
+        buf = torch.full(tuple(ref.shape[:4]) + (cout + 24,), 7.0, dtype=tdt, device=DEV)
+        out = buf[..., 8:8 + cout]
+    y = lowp.conv(kind, code, tdt, xin[..., c0:c0 + cin], wp, b.to(DEV), cout, out=out)
+    torch.cuda.synchronize()
+    err = (y.double().cpu() - ref).abs()
+    worst = float((err / bound).max())
+    assert worst <= 1.0, '%s %s: error %.3e is %.2fx the stated bound' % (name, dtype, float(err.max()), worst)
+    if slab_out:      # neighbours of the output slice untouched
+        assert bool((buf[..., :8] == 7.0).all()) and bool((buf[..., 8 + cout:] == 7.0).all())
+
+
+def test_folded_duplicate_slice_pack():
+    """encoder.py:83-87: block j reads [o_{j-1}, o_0 .. o_{j-1}]; the engine reads the slab [o_0 .. o_{j-1}] once with the duplicated
+    slice folded into the weights"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    code, tdt = lowp.DTYPES['float16']
+    g = torch.Generator().manual_seed(3)
+    f, j = 16, 2
+    slab = torch.randn((1, 4, 4, 8, j * f), generator=g)
+    wt = torch.randn((3, 3, 3, (j + 1) * f, 32), generator=g) * 0.05
+    sr = _round(slab, tdt)
+    full = torch.cat([sr[..., (j - 1) * f:], sr], dim=-1)                 # what the reference's Concatenate would build
+    ref = R.conv3d(full, wt.double(), None)
+    wp = lowp.pack(ops.K3S1, code, wt.to(DEV), (j + 1) * f, 32, j * f, (j - 1) * f, f)
+    y = lowp.conv(ops.K3S1, code, tdt, slab.to(tdt).to(DEV), wp, None, 32)
+    torch.cuda.synchronize()
+    # the folded weight W[first copy] + W[second copy] is rounded once more than either copy: 2 u on top of the conv bound
+    bound = (8 * 2.0 ** -24 + 2 * U['float16']) * R.conv3d(full.abs(), wt.double().abs(), None) + U['float16'] * ref.abs()
+    assert float(((y.double().cpu() - ref).abs() / bound).max()) <= 1.0
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('mode', ['slab', 'channel'])
+def test_groupnorm_colsum_epilogue_head(dtype, mode):
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    code, tdt = lowp.DTYPES[dtype]
+    u = U[dtype]
+    gmode = ops.GN_SLAB if mode == 'slab' else ops.GN_CHANNEL
+    g = torch.Generator().manual_seed(11)
+    n, d, h, w, c, G = 2, 8, 6, 8, 32, 8
+    x = torch.randn((n, d, h, w, c), generator=g) * 1.7 + 0.4
+    gamma, beta = 1 + 0.3 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g)
+    xr = _round(x, tdt)
+    axis = -1 if mode == 'slab' else 1
+    xx = xr if mode == 'slab' else xr.permute(0, 4, 1, 2, 3)
+    ref = R.group_norm(xx, gamma.double(), beta.double(), G, axis)
+    ref = torch.relu(ref if mode == 'slab' else ref.permute(0, 2, 3, 4, 1))
+    xd = x.to(tdt).to(DEV)
+    mean, rstd = lowp.gn_stats(code, xd, G, gmode, 1e-5)
+    y = lowp.gn_apply(code, xd, gamma.to(DEV), beta.to(DEV), mean, rstd, G, gmode, True)
+    torch.cuda.synchronize()
+    err = (y.double().cpu() - ref).abs()
+    assert float((err / (1e-5 * (1 + ref.abs()) + u * ref.abs() + 1e-30)).max()) <= 1.0
+    # global average pool
+    gap = lowp.colsum(code, xd, 1.0 / (d * h * w))
+    torch.cuda.synchronize()
+    assert float((gap.double().cpu() - xr.mean(dim=(1, 2, 3))).abs().max()) <= 1e-6
+    # block epilogue: out = res * (sigmoid(res . wsp) + ch) + relu(GN2(c2))
+    res = torch.randn((n, d, h, w, c), generator=g)
+    wsp = torch.randn(c, generator=g) * 0.3
+    ch = torch.rand((n, c), generator=g)
+    rr = _round(res, tdt)
+    sp = torch.sigmoid((rr * wsp.double()).sum(-1, keepdim=True))
+    ref2 = rr * (sp + ch.double().reshape(n, 1, 1, 1, c)) + ref
+    buf = torch.zeros((n, d, h, w, c + 16), dtype=tdt, device=DEV)
+    out = lowp.block_epilogue(code, res.to(tdt).to(DEV), xd, buf[..., 8:8 + c], wsp.to(DEV), ch.to(DEV), gamma.to(DEV), beta.to(DEV),
+                              mean, rstd, G, gmode)
+    torch.cuda.synchronize()
+    err = (out.double().cpu() - ref2).abs()
+    assert float((err / (2e-5 * (1 + ref2.abs()) + u * ref2.abs() + 1e-30)).max()) <= 1.0
+    # head: sigmoid(x . W + b) in fp32
+    wk, bk = torch.randn((c, 3), generator=g) * 0.2, torch.randn(3, generator=g) * 0.1
+    yh = lowp.head(code, xd, wk.to(DEV), bk.to(DEV), True)
+    torch.cuda.synchronize()
+    refh = torch.sigmoid(xr @ wk.double() + bk.double())
+    assert yh.dtype == torch.float32 and float((yh.double().cpu() - refh).abs().max()) <= 2e-6
+
+
+def _model(kw, crop, seed):
+    from bts_amd.layers import _base
+    from bts_amd.model import Model
+    from bts_amd.tape import bump_weights_epoch
+    _base.set_seed(seed)
+    m = Model(**kw)
+    m.build((1,) + crop + (2,))
+    g = torch.Generator().manual_seed(seed + 1)
+    for p in m.trainable_variables:           # gamma_2 = 0 at init would hide the conv branch
+        if p.name.endswith('gamma'):
+            p.t.copy_((1.0 + 0.3 * torch.randn(p.t.shape, generator=g)).to(p.t.device))
+        elif p.name.endswith('beta') or p.t.dim() == 1:
+            p.t.copy_((0.1 * torch.randn(p.t.shape, generator=g)).to(p.t.device))
+    bump_weights_epoch()
+    return m
+
+
+def _compare(y_lp, y_32, tag):
+    d = (y_lp - y_32).abs()
+    lab = lambda y: torch.where(y.max(-1).values > 0.5, y.argmax(-1) + 1, torch.zeros_like(y.argmax(-1)))
+    l1, l2 = lab(y_lp), lab(y_32)
+    mism = float((l1 != l2).float().mean())
+    inter = [(float(((l1 == k) & (l2 == k)).sum()), float((l1 == k).sum() + (l2 == k).sum())) for k in (1, 2, 3)]
+    dice = [2 * a / b if b > 0 else 1.0 for a, b in inter]
+    print('%s: |dp| max %.3e mean %.3e ; label changes %.4f %% ; label-map Dice vs fp32 %s' %
+          (tag, float(d.max()), float(d.mean()), 100 * mism, ' '.join('%.4f' % v for v in dice)))
+    return float(d.max()), float(d.mean()), mism
+
+
+@pytest.mark.parametrize('dtype,scale', [('float16', 1.0), ('bfloat16', 8.0)])
+def test_forward_against_fp32_engine_and_oracle(dtype, scale):
+    """tiny config at 32^3: 16-bit forward vs the fp32 engine AND vs the fp64 oracle (both on the fp32 master weights)"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp
+    kw = dict(base_filters=16, groups=8, reduction=2, depth=3)
+    crop = (32, 32, 32)
+    m = _model(kw, crop, 5)
+    x = torch.randn((1,) + crop + (2,), generator=torch.Generator().manual_seed(9))
+    y32 = m(x, training=False, inference=True)[0].t
+    ylp = lowp.LowPrecisionForward(m, dtype)(x)
+    torch.cuda.synchronize()
+    assert ylp.dtype == torch.float32 and ylp.shape == y32.shape
+    mx, mean, mism = _compare(ylp, y32, dtype + ' vs fp32 engine')
+    assert mx <= 2e-2 * scale and mean <= 1e-3 * scale and mism <= 2e-3 * scale
+    cfg = R.default_config(**kw)
+    P = R.ParamSet()
+    for p in m.trainable_variables:
+        P[m.oracle_name(p)] = p.t.detach().cpu().double()
+    yo = R.model(x.double(), P, cfg, training=False, inference=True)[0]
+    mx, mean, mism = _compare(ylp.cpu().double(), yo, dtype + ' vs fp64 oracle')
+    assert mx <= 2e-2 * scale and mean <= 1e-3 * scale and mism <= 2e-3 * scale
+
+
+def test_full_volume_fp16_inference_against_fp32_engine():
+    """BASELINE configs[4]: 155x190x147 padded to 160x192x160 (test.py:164-178), CLI-default model, VAE off, fp16 storage"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp
+    m = _model(dict(base_filters=32, reduction=8, depth=4, groups=8), (128, 128, 128), 77)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((1, 160, 192, 160, 2), generator=g)
+    x[:, 155:] = 0
+    x[:, :, 190:] = 0
+    x[:, :, :, 147:] = 0
+    x = x.to(DEV)
+    y32 = m(x, training=False, inference=True)[0].t
+    ylp = lowp.LowPrecisionForward(m, 'float16')(x)
+    torch.cuda.synchronize()
+    mx, mean, mism = _compare(ylp, y32, 'fp16 160x192x160 vs fp32 engine')
+    assert mx <= 5e-2 and mean <= 2e-3 and mism <= 5e-3
+
+
+def test_segment_volume_in_fp16_against_the_fp32_pipeline():
+    """infer.segment_volume(..., compute_dtype='float16'): pad, 8 flip-TTA forwards in 16-bit storage, un-flip + mean + mask + labels"""
+    import bts_amd  # noqa: F401
+    from bts_amd import infer
+    m = _model(dict(base_filters=16, groups=8, reduction=2, depth=3), (16, 16, 24), 3)
+    g = torch.Generator().manual_seed(21)
+    vol = (13, 9, 20)
+    x = torch.randn(vol + (2,), generator=g) * 40.0 + 100.0
+    mask = (torch.rand(vol + (1,), generator=g) > 0.15).float()
+    x = x * mask
+    mean, std = torch.tensor([95.0, 110.0]), torch.tensor([35.0, 45.0])
+    y32, l32 = infer.segment_volume(m, x.to(DEV), mask.to(DEV), mean, std, 4)
+    y16, l16 = infer.segment_volume(m, x.to(DEV), mask.to(DEV), mean, std, 4, compute_dtype='float16')
+    torch.cuda.synchronize()
+    assert y16.shape == y32.shape and l16.dtype == torch.uint8
+    d = (y16 - y32).abs()
+    mism = float((l16 != l32).float().mean())
+    print('TTA pipeline fp16 vs fp32: |dp| max %.3e mean %.3e, label changes %.3f %%' % (float(d.max()), float(d.mean()), 100 * mism))
+    assert float(d.max()) <= 2e-2 and float(d.mean()) <= 1e-3 and mism <= 5e-3
+    assert set(l16.cpu().unique().tolist()) <= {0, 1, 2, 4}
