@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "common.h"
 #include "bts_internal.h"
 
@@ -516,26 +517,31 @@ __global__ __launch_bounds__(256, 2) void lp_conv_gather_kernel(const LpGatherPa
       if (ok[v]) b[v] = *reinterpret_cast<const u32x4*>(src[v] + ks * 16);
     }
   };
-  u32x4 a_cur[CB], b_cur[VB], a_nxt[CB], b_nxt[VB];
-  tap_setup(0);
-  request(0, a_cur, b_cur);
+  // ring of GD + 1 operand sets: step i computes on set i % (GD + 1) while the requests of steps i+1 .. i+GD are in flight
+  constexpr int GD = (VB + CB >= 6) ? 2 : 3;   // (4 x 2 tiles: a third set in flight would spill)
+  u32x4 ar[GD + 1][CB], br[GD + 1][VB];
   const int total = p.ntaps * p.KS;
-  int rt = 0, rks = 0;
-  for (int i = 0; i < total; ++i) {
-    const bool has = i + 1 < total;
-    if (has) {
-      if (++rks == p.KS) { rks = 0; tap_setup(++rt); }
-      request(rks, a_nxt, b_nxt);
+  int rt = 0, rks = 0, issued = 0;
+  tap_setup(0);
+  auto issue = [&](u32x4 (&a)[CB], u32x4 (&b)[VB]) {   // request the operands of step `issued` (no-op past the end)
+    if (issued < total) {
+      request(rks, a, b);
+      ++issued;
+      if (++rks == p.KS) { rks = 0; if (++rt < p.ntaps) tap_setup(rt); }
     }
+  };
 #pragma unroll
-    for (int v = 0; v < VB; ++v)
+  for (int j = 0; j < GD; ++j) issue(ar[j], br[j]);
+  for (int i0 = 0; i0 < total; i0 += GD + 1) {
 #pragma unroll
-      for (int c = 0; c < CB; ++c) acc[v][c] = T::mfma(a_cur[c], b_cur[v], acc[v][c]);
-    if (has) {
+    for (int j = 0; j <= GD; ++j) {
+      if (i0 + j < total) {
+        issue(ar[(j + GD) % (GD + 1)], br[(j + GD) % (GD + 1)]);
 #pragma unroll
-      for (int c = 0; c < CB; ++c) a_cur[c] = a_nxt[c];
+        for (int v = 0; v < VB; ++v)
 #pragma unroll
-      for (int v = 0; v < VB; ++v) b_cur[v] = b_nxt[v];
+          for (int c = 0; c < CB; ++c) acc[v][c] = T::mfma(ar[j][c], br[j][v], acc[v][c]);
+      }
     }
   }
 #pragma unroll

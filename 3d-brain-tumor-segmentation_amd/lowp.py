@@ -9,7 +9,7 @@ precision mode, so the parity reference of this path is the fp32 en
 The graph walked here is the fp32 layers' own (encoder.py:69-101 incl. the folded duplicated dense connections F4,
 resnet.py:116-138, downsample.py:41-45, upsample.py:39-43, decoder.py:65-83) with the same virtual concatenation through
 level slabs.  The first block reads the 2-channel input volume: a 16-channel matrix step is the 16-bit instructions' floor,
-so that block's two convolutions run on the fp32 kernels and their outputs are rounded once.
+so the volume is stored zero-padded to 16 channels (the pad multiplies zeros on both sides).
 """
 import ctypes
 
@@ -169,29 +169,22 @@ class LowPrecisionForward(object):
         return gn_apply(self.code, c, norm.gamma.t, norm.beta.t, m, r, norm.groups, norm._mode, relu, out=out)
 
     def _block(self, blk, x, out, fold=None):
-        """ResnetBlock.call (resnet.py:116-138); x: 16-bit view (or the fp32 2-channel input volume), out: 16-bit view or None"""
+        """ResnetBlock.call (resnet.py:116-138); x: 16-bit view, out: 16-bit view or None"""
         code, tdt = self.code, self.tdt
         f, g = blk.filters, blk.groups
         n, d, h, w, cin = x.shape
         dup_start, dup_shift = fold if fold else (0, 0)
         v = d * h * w
-        if x.dtype == torch.float32:      # the 2-channel input block: fp32 kernels, outputs rounded once
-            wp_pt = blk.packed('pt_f', ops.K1, ops.ROLE_FWD, blk.ptwise_k, blk.cin_ref, f)
-            wp_c1 = blk.packed('c1_f', ops.K3S1, ops.ROLE_FWD, blk.conv1_k, blk.cin_ref, f)
-            fused = ops.conv_fwd_fused2(x, wp_c1, blk.conv1_b.t, wp_pt, blk.ptwise_b.t, f)
-            if fused is not None:
-                c1f, resf = fused
-            else:
-                resf = ops.conv_fwd(ops.K1, x, wp_pt, blk.ptwise_b.t, f)
-                c1f = ops.conv_fwd(ops.K3S1, x, wp_c1, blk.conv1_b.t, f)
-            res, c1 = cast(code, tdt, resf), cast(code, tdt, c1f)
-            del resf, c1f
-        else:
-            key = id(blk)
-            wp_pt = self._packed((key, 'pt'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin, dup_start, dup_shift)
-            wp_c1 = self._packed((key, 'c1'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin, dup_start, dup_shift)
-            res = conv(ops.K1, code, tdt, x, wp_pt, blk.ptwise_b.t, f)
-            c1 = conv(ops.K3S1, code, tdt, x, wp_c1, blk.conv1_b.t, f)
+        key = id(blk)
+        if cin % 16 != 0:
+            raise RuntimeError('16-bit convolutions step over 16 input channels; got a %d-channel view' % cin)
+        # (the 2-channel input volume arrives zero-padded to 16 channels, see __call__: blk.cin_ref real channels, the rest
+        # of the k-step multiplies zeros in both operands)
+        cin_slab = min(cin, blk.cin_ref) if fold is None else cin
+        wp_pt = self._packed((key, 'pt'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
+        wp_c1 = self._packed((key, 'c1'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
+        res = conv(ops.K1, code, tdt, x, wp_pt, blk.ptwise_b.t, f)
+        c1 = conv(ops.K3S1, code, tdt, x, wp_c1, blk.conv1_b.t, f)
         gap = colsum(code, res, 1.0 / v)
         _, ch = ops.se_mlp_fwd(gap, blk.se_w1.t, blk.se_w2.t)
         a = self._gn(blk.norm1, c1, True)
@@ -228,6 +221,11 @@ class LowPrecisionForward(object):
         x = x.float().contiguous()
         if any(s % (2 ** (m.encoder.depth - 1)) for s in x.shape[1:4]):
             raise ValueError('spatial sizes must be multiples of %d (test.py:164-178 pads to that)' % 2 ** (m.encoder.depth - 1))
+        # the input volume in the storage type, zero-padded to one 16-channel matrix step (in_ch = 2: model.py:18)
+        cpad = (x.shape[-1] + 15) // 16 * 16
+        xin = torch.zeros(tuple(x.shape[:4]) + (cpad,), dtype=self.tdt, device=x.device)
+        cast(self.code, self.tdt, x, out=xin[..., :x.shape[-1]])
+        x = xin
         enc, dec = m.encoder, m.decoder
         n = x.shape[0]
         residuals = []
