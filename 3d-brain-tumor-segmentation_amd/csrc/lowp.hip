@@ -222,7 +222,10 @@ __global__ __launch_bounds__(256, 2) void lp_conv_s1_kernel(const LpS1Params p) 
     // rows it needs serve all three dy taps: (VB + 2) LDS reads feed 3 * VB * CB matrix instructions (one read per instruction
     // otherwise -- with 32 couts the LDS port, not the matrix pipe, was the limit).  Taps run in (dz, dx) groups of three dy; the
     // weights of group g live in a[g % 3] and are requested one group ahead.
-    u32x4 a[3][3][CB];
+    // weights of group g live in a[g % WR], requested WD groups ahead (2 where the registers allow it: an L2 round trip is
+    // longer than one group's 12 matrix instructions); the input rows of group g+1 are read from LDS while group g computes
+    constexpr int WD = (CB == 1) ? 2 : 1, WR = 3;   // (9 groups per k-step: a ring of 3 keeps the slot of group g the same in every k-step)
+    u32x4 a[WR][3][CB];
     auto wgroup = [&](u32x4 (&dst)[3][CB], int g, int ks) {
       const int dz = g / 3, dx = g % 3;
 #pragma unroll
@@ -230,28 +233,33 @@ __global__ __launch_bounds__(256, 2) void lp_conv_s1_kernel(const LpS1Params p) 
 #pragma unroll
         for (int c = 0; c < CB; ++c) dst[dy][c] = wfrag((dz * 3 + dy) * 3 + dx, ks, c);
     };
+    auto rows = [&](u32x4 (&bj)[VB + 2], int g) {
+      const int dz = g / 3, dx = g % 3;
+#pragma unroll
+      for (int j = 0; j < VB + 2; ++j) bj[j] = *reinterpret_cast<const u32x4*>(lds + bbase + ((dz * SY + j) * SX + dx) * LPS);
+    };
     fetch(ks0);
-    wgroup(a[0], 0, ks0);
+#pragma unroll
+    for (int g = 0; g < WD; ++g) wgroup(a[g], g, ks0);
     for (int ks = ks0; ks < ks1; ++ks) {
       __syncthreads();        // every wave is done reading the previous k-step's tile
       commit();
       __syncthreads();
       const bool more = ks + 1 < ks1;
       if (more) fetch(ks + 1);
-      const int ksn = more ? ks + 1 : ks;   // (the last step re-requests its own first group: same request count on every path)
+      const int ksn = more ? ks + 1 : ks;   // (the last step re-requests its own first groups: same request count on every path)
+      u32x4 bj[2][VB + 2];
+      rows(bj[0], 0);
 #pragma unroll
       for (int g = 0; g < 9; ++g) {
-        const int dz = g / 3, dx = g % 3;
-        wgroup(a[(g + 1) % 3], (g + 1) % 9, (g + 1 < 9) ? ks : ksn);
-        u32x4 bj[VB + 2];
-#pragma unroll
-        for (int j = 0; j < VB + 2; ++j) bj[j] = *reinterpret_cast<const u32x4*>(lds + bbase + ((dz * SY + j) * SX + dx) * LPS);
+        wgroup(a[(g + WD) % WR], (g + WD) % 9, (g + WD < 9) ? ks : ksn);
+        if (g + 1 < 9) rows(bj[(g + 1) & 1], g + 1);
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
           for (int v = 0; v < VB; ++v)
 #pragma unroll
-            for (int c = 0; c < CB; ++c) acc[v][c] = T::mfma(a[g % 3][dy][c], bj[v + dy], acc[v][c]);
+            for (int c = 0; c < CB; ++c) acc[v][c] = T::mfma(a[g % WR][dy][c], bj[g & 1][v + dy], acc[v][c]);
       }
     }
   } else {

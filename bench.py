@@ -178,10 +178,13 @@ def run_infer(args, world, rank, dev, overrides):
     model = Model(base_filters=32, reduction=8, depth=4, groups=8)
     model.build((1, 128, 128, 128, 2))     # the weights belong to the training crop (the VAE is tied to it, vae.py:101-111)
     g = torch.Generator().manual_seed(1234 + rank)
-    x = torch.randn((1, 160, 192, 160, 2), generator=g)
-    x[:, 155:] = 0
-    x[:, :, 190:] = 0
-    x[:, :, :, 147:] = 0
+    shape = tuple(int(v) for v in args.infer_shape.split(','))
+    canonical = shape == (160, 192, 160) and args.batch == 1
+    x = torch.randn((args.batch,) + shape + (2,), generator=g)
+    if canonical:        # the zero padding of test.py:164-178
+        x[:, 155:] = 0
+        x[:, :, 190:] = 0
+        x[:, :, :, 147:] = 0
     x = x.to(dev)
     if dt == 'f32':
         fwd = lambda: model(x, training=False, inference=True)[0].t
@@ -223,19 +226,24 @@ def run_infer(args, world, rank, dev, overrides):
         return
     sec = dts / args.steps
     out = {
-        'metric': 'inference volumes/sec (2ch x 155x190x147 padded to 160x192x160, VAE off)', 'value': ranks_seen / sec,
+        'metric': 'inference volumes/sec (2ch x 155x190x147 padded to 160x192x160, VAE off)' if canonical else
+                  'forward volumes/sec (2ch x %dx%dx%d, batch %d, VAE off)' % (shape + (args.batch,)),
+        'value': ranks_seen * args.batch / sec,
         'unit': 'volumes/s', 'n_gpus': world, 'ranks_seen': ranks_seen, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * sec, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dt, 'data': 'synthetic',
-        'config': {'workload': 'BASELINE configs[4]: full-volume inference, 2ch x 155x190x147 zero-padded to 160x192x160, inference=True '
-                               '(decoder path, VAE off), batch 1 per GPU, CLI-default model; storage %s, fp32 sums' % dt,
+        'config': {'workload': ('BASELINE configs[4]: full-volume inference, 2ch x 155x190x147 zero-padded to 160x192x160, inference=True '
+                                '(decoder path, VAE off), batch 1 per GPU, CLI-default model; storage %s, fp32 sums' % dt) if canonical else
+                               ('NOT a BASELINE line: forward only (VAE off) at 2ch x %dx%dx%d, batch %d per GPU, CLI-default model; storage %s'
+                                % (shape + (args.batch, dt))),
                    'parallelism': 'replicas%d' % world},
         'y_pred_mean': float(y.mean()),
         # whole-forward rooflines (SURVEY 8d figures): both terms, the larger one bounds the forward
-        'forward_rooflines': {
+    }
+    if canonical:
+        out['forward_rooflines'] = {
             'algorithmic_gflop': INFER_ALGORITHMIC_GFLOP, 'algorithmic_gb': INFER_ALGORITHMIC_GB[dt],
             'mfma_frac': INFER_ALGORITHMIC_GFLOP / 1e3 / sec / (PEAK_F32_MFMA_TFLOPS if dt == 'f32' else PEAK_F16_MFMA_TFLOPS),
-            'hbm_frac': INFER_ALGORITHMIC_GB[dt] / 1e3 / sec / PEAK_HBM_TBS},
-    }
+            'hbm_frac': INFER_ALGORITHMIC_GB[dt] / 1e3 / sec / PEAK_HBM_TBS}
     if overrides:
         out['overrides'] = overrides
     if prof:
@@ -271,6 +279,7 @@ def main():
     ap.add_argument('--cpu-baseline-crop', type=int, default=128)
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--infer', action='store_true', help='BASELINE configs[4]: full-volume inference (VAE off) instead of the train step')
+    ap.add_argument('--infer-shape', default='160,192,160', help='D,H,W of the --infer volume (multiples of 8)')
     ap.add_argument('--dtype', default=None, help="storage type of the --infer forward: f32 | f16 (default) | bf16")
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
