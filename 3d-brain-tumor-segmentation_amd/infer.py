@@ -51,11 +51,14 @@ class TestTimeAugmentor(object):
                  seed=0, compute_dtype='float32'):
         """compute_dtype: 'float32' (the engine's parity path) | 'float16' | 'bfloat16' -- 16-bit STORAGE of activations and
         weight images with fp32 sums (bts_amd.lowp; BASELINE configs[4] runs the forwards in fp16)"""
-        if model_data_format != 'channels_last':
-            raise NotImplementedError('channels_first public layout is SURVEY 8 f-4 (not built)')
+        if model_data_format not in ('channels_last', 'channels_first'):
+            raise ValueError('unknown data_format %r' % (model_data_format,))
         self.model = model
+        cf = model_data_format == 'channels_first'
         if compute_dtype in ('float32', 'fp32', 'f32'):
-            self._forward = lambda aug: self.model(aug, training=False, inference=True)[0]
+            # like the reference (test.py:109-117) the volume always ARRIVES channels_last; a channels_first model is fed the
+            # transposed view (the engine's memory is NDHWC either way, so the view costs nothing) and answers in its layout
+            self._forward = lambda aug: self.model(aug.permute(0, 4, 1, 2, 3) if cf else aug, training=False, inference=True)[0]
         else:
             from .lowp import LowPrecisionForward
             self._forward = LowPrecisionForward(model, compute_dtype)
@@ -101,7 +104,7 @@ class TestTimeAugmentor(object):
         self._prob = acc
         self._mask = bmask.unsqueeze(0).to(torch.float32).contiguous()
         y, _ = ops.tta_finish(acc, self._mask, self.threshold, want_probabilities=True, want_labels=False)
-        return y[0]
+        return y[0].permute(3, 0, 1, 2) if self.model_data_format == 'channels_first' else y[0]   # (test.py:112-114: the model's layout)
 
     def labels(self):
         """uint8 label map (D,H,W) of the last call: argmax+1, >=3 -> 4, 0 = background / masked / below threshold"""
@@ -111,10 +114,12 @@ class TestTimeAugmentor(object):
 
 def segment_volume(model, x, mask, mean, std, spatial_res, spatial_tta=True, threshold=0.5, compute_dtype='float32'):
     """test.py:246-261 for one volume: pad to the model's spatial resolution, TTA inference, crop back.
-    -> (probabilities (D,H,W,out_ch), uint8 labels (D,H,W))"""
+    x (D,H,W,C), mask (D,H,W,1) channels_last (test.py:109) -> (probabilities, uint8 labels (D,H,W)); the probabilities are
+    (D,H,W,out_ch), or (out_ch,D,H,W) for a model built with data_format='channels_first'"""
     xp, mp, orig = pad_to_spatial_res(spatial_res, x, mask)
-    tta = TestTimeAugmentor(mean, std, model, 'channels_last', spatial_tta=spatial_tta, threshold=threshold,
-                            compute_dtype=compute_dtype)
+    df = getattr(model, 'data_format', 'channels_last')
+    tta = TestTimeAugmentor(mean, std, model, df, spatial_tta=spatial_tta, threshold=threshold, compute_dtype=compute_dtype)
     y = tta(xp, mp)
     lab = tta.labels()
-    return y[:orig[0], :orig[1], :orig[2]], lab[:orig[0], :orig[1], :orig[2]]
+    y = y[:, :orig[0], :orig[1], :orig[2]] if df == 'channels_first' else y[:orig[0], :orig[1], :orig[2]]
+    return y, lab[:orig[0], :orig[1], :orig[2]]

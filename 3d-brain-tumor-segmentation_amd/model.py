@@ -149,6 +149,38 @@ class Model(Layer):
             self.epoch.assign(int(z['epoch']))
         bump_weights_epoch()
 
+    # ---- Keras-order weight lists (importer keyed by the reference's variable order) ----
+    def get_weights(self):
+        """tf.keras.Model.get_weights(): `model.weights` order = trainable variables in layer-tracking order (model.py:29-56:
+        encoder, decoder, vae; inside a layer its sub-layers in constructor order, kernel before bias, gamma before beta --
+        group_norm.py:63-80; `vae.unproj` last because vae.py:105 creates it in build()), then the non-trainable `epoch`
+        variable (model.py:29).  Arrays keep the Keras layouts ((kd,kh,kw,Cin,Cout), transposed convs (kd,kh,kw,Cout,Cin),
+        Dense (in,out))."""
+        return [p.t.detach().cpu().numpy().copy() for p in self.trainable_variables] + [np.asarray(self.epoch.numpy(), dtype=np.int32)]
+
+    def set_weights(self, weights):
+        """tf.keras.Model.set_weights(): the list get_weights() returns -- e.g. exported from the reference with
+        `np.savez(path, *model.get_weights())` where h5py / Keras HDF5 (train.py:100,201) are available.  The trailing epoch
+        entry is optional.  Shapes are checked one by one: a mismatch names the variable."""
+        ps = self.trainable_variables
+        weights = list(weights)
+        if len(weights) not in (len(ps), len(ps) + 1):
+            raise ValueError('expected %d (or %d with epoch) arrays, got %d' % (len(ps), len(ps) + 1, len(weights)))
+        for p_, w in zip(ps, weights):
+            w = np.asarray(w)
+            if tuple(w.shape) != tuple(p_.t.shape):
+                raise ValueError('weight for %s has shape %s, expected %s' % (p_.name, tuple(w.shape), tuple(p_.t.shape)))
+        for p_, w in zip(ps, weights):
+            p_.t.copy_(torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).to(p_.t.device))
+        if len(weights) == len(ps) + 1:
+            self.epoch.assign(int(np.asarray(weights[-1])))
+        bump_weights_epoch()
+
+    def load_weights_keras_order(self, path):
+        """weights exported as positional arrays (`np.savez(path, *keras_model.get_weights())` -> arr_0, arr_1, ...)"""
+        z = np.load(path)
+        self.set_weights([z['arr_%d' % i] for i in range(len(z.files))])
+
     def set_weights_from(self, named):
         """named: dict name -> array (oracle ParamSet naming, 'encoder/L0/B0/ptwise_k' ...) for parity runs"""
         for p in self.trainable_variables:

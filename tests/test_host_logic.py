@@ -168,3 +168,35 @@ def test_bench_refuses_world_size_mismatch_and_overrides():
     if not torch.cuda.is_available():
         r = _bench(['--gpus', '2'], {}, drop=('WORLD_SIZE', 'RANK', 'LOCAL_RANK'))
         assert r.returncode != 0 and 'GPU' in r.stderr
+
+
+def test_keras_order_weight_list_round_trip(tmp_path):
+    """importer keyed by the reference's variable order -- get_weights()/set_weights() in `model.weights` order
+    (trainable variables in tracking order, `vae.unproj` last, then `epoch`), Keras layouts, shape errors name the variable"""
+    import numpy as np
+    m = Model(base_filters=4, groups=2, reduction=2, depth=2)
+    m.build((1, 8, 8, 8, 2))
+    names = [p.name for p in m.trainable_variables]
+    assert names[0] == 'encoder/L0/B0/ptwise_k' and names[-2:] == ['vae/unproj_k', 'vae/unproj_b']
+    assert names.index('decoder/out_k') < names.index('vae/down/conv_k') < names.index('vae/proj_k') < names.index('vae/out_k')
+    i = names.index('encoder/L0/B0/gn1/gamma')
+    assert names[i + 1] == 'encoder/L0/B0/gn1/beta' and names[i - 2:i] == ['encoder/L0/B0/conv1_k', 'encoder/L0/B0/conv1_b']
+    g = torch.Generator().manual_seed(2)
+    for p in m.trainable_variables:
+        p.t.copy_(torch.randn(p.t.shape, generator=g))
+    m.epoch.assign(17)
+    w = m.get_weights()
+    assert len(w) == len(names) + 1 and int(w[-1]) == 17
+    assert w[names.index('decoder/L0/up/conv_k')].shape == (3, 3, 3, 4, 16)       # transposed conv: (kd,kh,kw,Cout,Cin)
+    np.savez(str(tmp_path / 'keras.npz'), *w)
+    m2 = Model(base_filters=4, groups=2, reduction=2, depth=2)
+    m2.build((1, 8, 8, 8, 2))
+    m2.load_weights_keras_order(str(tmp_path / 'keras.npz'))
+    assert all(torch.equal(a.t, b.t) for a, b in zip(m.trainable_variables, m2.trainable_variables))
+    assert int(m2.epoch.value().numpy()) == 17
+    bad = list(w[:-1])
+    bad[3] = bad[3].T.copy()
+    with pytest.raises(ValueError, match='se_w2'):
+        m2.set_weights(bad)
+    with pytest.raises(ValueError):
+        m2.set_weights(w[:5])

@@ -93,3 +93,36 @@ def test_segment_volume_matches_oracle(kw, vol, res):
     bad = (lab.cpu() != lab_ref) & ~amb
     assert int(bad.sum()) == 0, '%d label mismatches outside the ambiguous set (%d ambiguous)' % (int(bad.sum()), int(amb.sum()))
     assert set(lab.cpu().unique().tolist()) <= {0, 1, 2, 4}
+
+
+def test_segment_volume_channels_first_model_matches_oracle():
+    """a model built with data_format='channels_first' (true GroupNorm): the volume still arrives channels_last
+    (test.py:109), is fed transposed (test.py:112-114) and the probabilities come back in the model's layout"""
+    import bts_amd  # noqa: F401
+    from bts_amd import infer
+    from bts_amd.model import Model
+    kw = dict(base_filters=8, groups=2, reduction=2, depth=3, data_format='channels_first')
+    cfg = R.default_config(**kw)
+    vol, res = (13, 9, 16), 8
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(vol + (2,), generator=g) * 40.0 + 100.0
+    mask = (torch.rand(vol + (1,), generator=g) > 0.15).float()
+    x = x * mask
+    mean, std = torch.tensor([95.0, 110.0]), torch.tensor([35.0, 45.0])
+    xp, mp, orig = R.pad_to_spatial_res(res, x.double(), mask.double())
+    P = randomised_params(cfg, tuple(xp.shape[:3]), seed=5)
+    xn = ((xp - mean.double()) / std.double()).unsqueeze(0)
+    ys = []
+    for flip in R.tta_augment_axes(True):
+        aug = torch.flip(xn, dims=flip) if flip else xn
+        y = R.model(aug.permute(0, 4, 1, 2, 3), P, cfg, training=False, inference=True)[0].permute(0, 2, 3, 4, 1)
+        ys.append(torch.flip(y, dims=flip) if flip else y)
+    y_ref = (torch.cat(ys, 0).mean(0, keepdim=True) * mp.unsqueeze(0))[0][:orig[0], :orig[1], :orig[2]]
+    m = Model(**kw)
+    m(torch.zeros((1, 2) + tuple(xp.shape[:3])))            # train.py:95-96: the build call with an NCDHW zeros tensor
+    m.set_weights_from(P)
+    y, lab = infer.segment_volume(m, x.to(dev()), mask.to(dev()), mean, std, res)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == (3,) + vol and tuple(lab.shape) == vol
+    err = float((y.permute(1, 2, 3, 0).double().cpu() - y_ref).abs().max())
+    assert err <= 1e-4, 'channels_first TTA probabilities: max abs err %.3e' % err
