@@ -173,7 +173,20 @@ class ResnetBlock(Layer):
 
 
 def _wgrad(kind, x, dy, kparam, bparam, dup_start=0, dup_shift=0):
-    """weight + bias gradient into the parameters' grad slots"""
+    """weight + bias gradient into the parameters' grad slots -- enqueued on the side stream (ops.side_stream): nothing in
+    the backward pass reads a parameter gradient, so these launches only have to finish before the regulariser / gradient
+    exchange / optimiser (ops.join_side_stream there)"""
+    side = ops.side_stream()
+    if side is None:
+        return _wgrad_here(kind, x, dy, kparam, bparam, dup_start, dup_shift)
+    side.wait_stream(torch.cuda.current_stream())       # x and dy are complete once the main stream gets here
+    with torch.cuda.stream(side):
+        _wgrad_here(kind, x, dy, kparam, bparam, dup_start, dup_shift)
+    for t in (x, dy):                                   # temporaries the main stream frees: the allocator must not hand
+        t.record_stream(side)                           # their memory out before the side stream has read them
+
+
+def _wgrad_here(kind, x, dy, kparam, bparam, dup_start=0, dup_shift=0):
     dw, aw = kparam.grad_slot()
     db, ab = (None, aw) if bparam is None else bparam.grad_slot()
     if bparam is not None and aw != ab:

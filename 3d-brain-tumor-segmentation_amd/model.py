@@ -126,6 +126,7 @@ class Model(Layer):
                 if tp is not None and tp.grad_sync is not None:
                     return  # the gradient-sync hook applies the regulariser per bucket before each all-reduce
                 # every parameter's gradient has been written by its layer by now (this node replays last)
+                ops.join_side_stream()
                 for p in self.trainable_variables:
                     if p._gen != gen:
                         ops.fill(p._gview, 0.0)

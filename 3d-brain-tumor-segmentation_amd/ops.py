@@ -91,9 +91,35 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_side = {}
+
+
+def side_stream():
+    """Second HIP stream of the backward pass: the weight gradients (a third of the step, needed only by the optimiser) run
+    there while the data-gradient chain -- with its many short normalisation / gate kernels that leave most CUs idle --
+    keeps the main stream.  BTS_WGRAD_STREAM=0 puts everything back on one stream (A/B aid)."""
+    import os
+    if os.environ.get('BTS_WGRAD_STREAM') == '0' or not torch.cuda.is_available():
+        return None
+    dev = torch.cuda.current_device()
+    s = _side.get(dev)
+    if s is None:
+        s = torch.cuda.Stream(device=dev)
+        _side[dev] = s
+    return s
+
+
+def join_side_stream():
+    """the current stream waits for everything enqueued on the side stream so far (before the regulariser / the gradient
+    exchange / the optimiser touch the parameter gradients)"""
+    s = _side.get(torch.cuda.current_device()) if torch.cuda.is_available() else None
+    if s is not None:
+        torch.cuda.current_stream().wait_stream(s)
+
+
 def workspace(nbytes, device):
-    """one grow-only scratch buffer per device; all users are ordered on the same stream"""
-    key = (device.type, device.index)
+    """one grow-only scratch buffer per device AND stream; all users of a buffer are ordered on that stream"""
+    key = (device.type, device.index, torch.cuda.current_stream().cuda_stream if device.type == 'cuda' else 0)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -193,6 +193,7 @@ class GradSync(object):
 
     def _launch(self, bi):
         from . import ops
+        ops.join_side_stream()      # the bucket's weight gradients were enqueued on the side stream
         off, ln, _ = self.buckets[bi]
         m = self.model
         fresh = getattr(m, '_l2_val', None) is not None and getattr(m, '_l2_val_gen', None) == self.tape.gen

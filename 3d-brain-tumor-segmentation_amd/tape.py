@@ -236,6 +236,7 @@ class GradientTape(object):
                 if self._touched:
                     grad_sync.params_written(self._touched)
                     self._touched = []
+            ops.join_side_stream()      # weight gradients enqueued on the side stream (layers/resnet.py:_wgrad)
             if grad_sync is not None:
                 grad_sync.finish()
         finally:
