@@ -91,24 +91,42 @@ class ResnetBlock(Layer):
         # channels_last GroupNorm statistics (z-slab groups) come out of the producing conv's epilogue where possible
         slab = self.norm1._mode == ops.GN_SLAB
         m1 = r1 = None
+        res = None
         if slab:
             fused = ops.conv_fwd_fused2_gn(x.t, wp_c1, self.conv1_b.t, wp_pt, self.ptwise_b.t, f, g, self.norm1.epsilon)
             if fused is not None:
                 c1, res, m1, r1 = fused
-            else:
-                res = ops.conv_fwd(K1, x.t, wp_pt, self.ptwise_b.t, f)
-                c1, m1, r1 = ops.conv_fwd_gn(K3, x.t, wp_c1, self.conv1_b.t, f, g, self.norm1.epsilon)
         else:
             fused = ops.conv_fwd_fused2(x.t, wp_c1, self.conv1_b.t, wp_pt, self.ptwise_b.t, f)
             if fused is not None:
                 c1, res = fused
-            else:
-                res = ops.conv_fwd(K1, x.t, wp_pt, self.ptwise_b.t, f)
-                c1 = ops.conv_fwd(K3, x.t, wp_c1, self.conv1_b.t, f)
-        # gates
-        gap = ops.colsum(res, scale=1.0 / v)
-        hbuf, ch = ops.se_mlp_fwd(gap, self.se_w1.t, self.se_w2.t)
+        # gate branch (resnet.py:118-130): shortcut conv (HBM-bound), global average pool, SE MLP -- on the 'gate' stream next to
+        # the conv branch when the shortcut did not come out of the fused first-block kernel
+        main = torch.cuda.current_stream()
+        gate = ops.side_stream('gate') if res is None else None
+
+        def gate_branch(res_):
+            if res_ is None:
+                res_ = ops.conv_fwd(K1, x.t, wp_pt, self.ptwise_b.t, f)
+            gap_ = ops.colsum(res_, scale=1.0 / v)
+            hbuf_, ch_ = ops.se_mlp_fwd(gap_, self.se_w1.t, self.se_w2.t)
+            return res_, gap_, hbuf_, ch_
+
+        if gate is not None:
+            gate.wait_stream(main)                     # x is complete once the main stream gets here
+            with torch.cuda.stream(gate):
+                res, gap, hbuf, ch = gate_branch(None)
+            x.t.record_stream(gate)
+            for t in (res, gap, hbuf, ch):             # allocated on the gate stream, consumed (and later freed) on the main one
+                t.record_stream(main)
         # conv branch
+        if fused is None:
+            if slab:
+                c1, m1, r1 = ops.conv_fwd_gn(K3, x.t, wp_c1, self.conv1_b.t, f, g, self.norm1.epsilon)
+            else:
+                c1 = ops.conv_fwd(K3, x.t, wp_c1, self.conv1_b.t, f)
+        if gate is None:
+            res, gap, hbuf, ch = gate_branch(res)
         if m1 is None:
             m1, r1 = ops.gn_stats(c1, g, self.norm1._mode, self.norm1.epsilon)
         a = ops.gn_apply(c1, self.norm1.gamma.t, self.norm1.beta.t, m1, r1, g, self.norm1._mode, True)
@@ -117,6 +135,8 @@ class ResnetBlock(Layer):
         else:
             c2 = ops.conv_fwd(K3, a, wp_c2, self.conv2_b.t, f)
             m2, r2 = ops.gn_stats(c2, g, self.norm2._mode, self.norm2.epsilon)
+        if gate is not None:
+            main.wait_stream(gate)                     # the epilogue is where the two branches meet (resnet.py:130,137)
         if out is None:
             out = Tensor(torch.empty((n, d, h, w, f), dtype=torch.float32, device=x.t.device))
         wsp = self.spatial_k.t.reshape(-1)
@@ -138,6 +158,30 @@ class ResnetBlock(Layer):
         K1, K3 = ops.K1, ops.K3S1
         n1, n2 = self.norm1, self.norm2
         from .group_norm import group_norm_backward
+        # ---- gate branch (independent of the conv branch until both gradients meet in dx): on the 'gate' stream
+        gw1, a1 = self.se_w1.grad_slot()
+        gw2, a2 = self.se_w2.grad_slot()
+        gws, a3 = self.spatial_k.grad_slot()
+        main = torch.cuda.current_stream()
+        gate = ops.side_stream('gate')
+
+        def gate_backward():
+            acc_ = a1
+            if not (a1 == a2 == a3):
+                for buf, ac in ((gw1, a1), (gw2, a2), (gws, a3)):
+                    if not ac:
+                        ops.fill(buf, 0.0)
+                acc_ = True
+            return ops.se_bwd(dout, res, sp, gap, hbuf, ch, self.se_w1.t, self.se_w2.t, self.spatial_k.t.reshape(-1), gw1, gw2,
+                              gws.reshape(-1), accumulate_params=acc_)
+
+        if gate is not None:
+            gate.wait_stream(main)                     # dout is complete once the main stream gets here
+            with torch.cuda.stream(gate):
+                dres = gate_backward()
+            for t in (dout, res, sp, gap, hbuf, ch):
+                t.record_stream(gate)
+            dres.record_stream(main)
         # ---- conv branch: GN2 -> conv2 -> GN1 -> conv1
         dc2 = group_norm_backward(n2, c2, dout, n2.gamma.t, n2.beta.t, m2, r2, True)
         wpb2 = self.packed('c2_b', K3, ops.ROLE_BWD, self.conv2_k, f, f)
@@ -148,17 +192,10 @@ class ResnetBlock(Layer):
         dc1 = group_norm_backward(n1, c1, da, n1.gamma.t, n1.beta.t, m1, r1, True)
         del da
         need_dx = x.requires_grad
-        # ---- gate branch (independent of the conv branch; evaluated first so that both gradients into x leave in one pass)
-        gw1, a1 = self.se_w1.grad_slot()
-        gw2, a2 = self.se_w2.grad_slot()
-        gws, a3 = self.spatial_k.grad_slot()
-        if not (a1 == a2 == a3):
-            for buf, acc_ in ((gw1, a1), (gw2, a2), (gws, a3)):
-                if not acc_:
-                    ops.fill(buf, 0.0)
-            a1 = True
-        dres = ops.se_bwd(dout, res, sp, gap, hbuf, ch, self.se_w1.t, self.se_w2.t, self.spatial_k.t.reshape(-1), gw1, gw2,
-                          gws.reshape(-1), accumulate_params=a1)
+        if gate is None:
+            dres = gate_backward()
+        else:
+            main.wait_stream(gate)                     # both gradients into x leave in one pass below
         if need_dx:   # dx (+)= conv1^T dc1 + shortcut^T dres: the 1x1x1 term rides on the centre tap of the 3x3x3 sweep
             dx, acc = x.grad_slot()
             wpb1 = self.packed('c1_b', K3, ops.ROLE_BWD, self.conv1_k, self.cin_ref, f, cin, dup_start, dup_shift)

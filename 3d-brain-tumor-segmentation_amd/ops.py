@@ -94,27 +94,33 @@ def _stream():
 _side = {}
 
 
-def side_stream():
-    """Second HIP stream of the backward pass: the weight gradients (a third of the step, needed only by the optimiser) run
-    there while the data-gradient chain -- with its many short normalisation / gate kernels that leave most CUs idle --
-    keeps the main stream.  BTS_WGRAD_STREAM=0 puts everything back on one stream (A/B aid)."""
+def side_stream(which='wgrad'):
+    """Extra HIP streams of a training step (one process still drives one GPU):
+      'wgrad'  the weight gradients (a third of the step, needed only by the optimiser) run there while the data-gradient
+               chain -- with its many short normalisation / gate kernels that leave most CUs idle -- keeps the main stream;
+      'gate'   a ResNet block's shortcut / squeeze-excitation branch (HBM-bound 1x1x1 conv, pooling, tiny MLP and their
+               gradients: resnet.py:118-130) next to its conv branch (matrix-pipe-bound), joined where the two meet.
+    BTS_WGRAD_STREAM=0 / BTS_GATE_STREAM=0 put the respective work back on the main stream (A/B aids)."""
     import os
-    if os.environ.get('BTS_WGRAD_STREAM') == '0' or not torch.cuda.is_available():
+    if not torch.cuda.is_available() or os.environ.get('BTS_%s_STREAM' % which.upper()) == '0':
         return None
-    dev = torch.cuda.current_device()
-    s = _side.get(dev)
+    key = (torch.cuda.current_device(), which)
+    s = _side.get(key)
     if s is None:
-        s = torch.cuda.Stream(device=dev)
-        _side[dev] = s
+        s = torch.cuda.Stream(device=key[0])
+        _side[key] = s
     return s
 
 
 def join_side_stream():
-    """the current stream waits for everything enqueued on the side stream so far (before the regulariser / the gradient
+    """the current stream waits for everything enqueued on the side streams so far (before the regulariser / the gradient
     exchange / the optimiser touch the parameter gradients)"""
-    s = _side.get(torch.cuda.current_device()) if torch.cuda.is_available() else None
-    if s is not None:
-        torch.cuda.current_stream().wait_stream(s)
+    if not torch.cuda.is_available():
+        return
+    dev = torch.cuda.current_device()
+    for (d, _), s in _side.items():
+        if d == dev:
+            torch.cuda.current_stream().wait_stream(s)
 
 
 def workspace(nbytes, device):
