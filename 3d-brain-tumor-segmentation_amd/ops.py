@@ -92,6 +92,15 @@ def _stream():
 
 
 _side = {}
+_side_enabled = True
+
+
+def enable_side_streams(on):
+    """switch the extra streams off / on at run time (bench.py measures per-kernel launch durations with one stream: a kernel
+    that shares the chip with another stream's kernels has no launch duration of its own)"""
+    global _side_enabled
+    join_side_stream()
+    _side_enabled = bool(on)
 
 
 def side_stream(which='wgrad'):
@@ -102,7 +111,7 @@ def side_stream(which='wgrad'):
                gradients: resnet.py:118-130) next to its conv branch (matrix-pipe-bound), joined where the two meet.
     BTS_WGRAD_STREAM=0 / BTS_GATE_STREAM=0 put the respective work back on the main stream (A/B aids)."""
     import os
-    if not torch.cuda.is_available() or os.environ.get('BTS_%s_STREAM' % which.upper()) == '0':
+    if not _side_enabled or not torch.cuda.is_available() or os.environ.get('BTS_%s_STREAM' % which.upper()) == '0':
         return None
     key = (torch.cuda.current_device(), which)
     s = _side.get(key)

@@ -24,16 +24,23 @@ need() {  # need <dir> <file name>: the one CSV a pass must have produced, non-e
   echo "$f"
 }
 
+# kernel stats on ONE stream (--serial-streams): per-kernel launch durations that mean something; `roofline` in the bench line is
+# measured the same way.  The default (multi-stream) run is captured too: its kernels overlap, so their durations add up to more
+# than the step -- it is the evidence that the streams do overlap, not a per-kernel table.
 rm -rf "$O/prof_$TAG"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$TAG" -o bench -- \
-  python3 "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-profile > "$O/prof_$TAG.log" 2>&1
+  python3 "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-profile --serial-streams > "$O/prof_$TAG.log" 2>&1
 cp "$(need "$O/prof_$TAG" bench_kernel_stats.csv)" "$O/${TAG}_bench_kernel_stats.csv"
+rm -rf "$O/prof_${TAG}_ms"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_${TAG}_ms" -o bench -- \
+  python3 "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-profile > "$O/prof_${TAG}_ms.log" 2>&1
+cp "$(need "$O/prof_${TAG}_ms" bench_kernel_stats.csv)" "$O/${TAG}_bench_multistream_kernel_stats.csv"
 
 for pass in fetch:FETCH_SIZE write:WRITE_SIZE; do
   name=${pass%%:*}; ctr=${pass##*:}
   rm -rf "$O/pmc_${TAG}_$name"
   rocprofv3 --kernel-trace --pmc "$ctr" --output-format csv -d "$O/pmc_${TAG}_$name" -o "$name" -- \
-    python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-profile > "$O/pmc_${TAG}_$name.log" 2>&1
+    python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-profile --serial-streams > "$O/pmc_${TAG}_$name.log" 2>&1
   need "$O/pmc_${TAG}_$name" "${name}_counter_collection.csv" > /dev/null
 done
 
