@@ -78,8 +78,33 @@ __device__ __forceinline__ u32x4 bload16(__amdgpu_buffer_rsrc_t r, unsigned voff
 struct LpPackParams {
   const float* w;
   unsigned short* wp;
-  int ntaps, Cin_ref, Cout, Cin_slab, dup_start, dup_shift, transposed, KS, NB;
+  int ntaps, K, N, KS, NB;
+  long sT, sK, sN;    // source strides of (tap, contraction index k, column n)
+  int flip;           // tap t reads source tap ntaps-1-t (stride-1 data gradient)
+  int cin_is_k;       // 1: the (possibly folded) input-channel axis is k (forward role), 0: it is n (data-gradient role)
+  int shift, dup_start;
 };
+// source value of packed position (tap t, k, n) -- same conventions as the fp32 images (conv_igemm.hip: pack_src)
+__device__ __forceinline__ float lp_pack_src(const LpPackParams& q, int t, int k, int n) {
+  if (k >= q.K || n >= q.N) return 0.f;
+  const int ts = q.flip ? (q.ntaps - 1 - t) : t;
+  int kk = k, nn = n, k2 = -1, n2 = -1;
+  if (q.cin_is_k == 1) {
+    // slab channel c is reference channel c + shift; inside [dup_start, ...) it is ALSO reference channel c - dup_start
+    // (encoder.py:83-87: [o_{j-1}, o_0 .. o_{j-1}] read once from the slab [o_0 .. o_{j-1}])
+    if (k >= q.dup_start) k2 = k - q.dup_start;
+    kk = k + q.shift;
+    n2 = n;
+  } else {
+    if (n >= q.dup_start) n2 = n - q.dup_start;
+    nn = n + q.shift;
+    k2 = k;
+  }
+  float v = q.w[ts * q.sT + kk * q.sK + nn * q.sN];
+  if (q.shift > 0 && k2 >= 0 && n2 >= 0 && k2 < (q.cin_is_k ? q.shift : q.K) && n2 < (q.cin_is_k ? q.N : q.shift))
+    v += q.w[ts * q.sT + k2 * q.sK + n2 * q.sN];
+  return v;
+}
 template <typename T>
 __global__ __launch_bounds__(256) void lp_pack_kernel(const LpPackParams p) {
   const long total = (long)p.ntaps * p.KS * p.NB * 512;
@@ -89,35 +114,37 @@ __global__ __launch_bounds__(256) void lp_pack_kernel(const LpPackParams p) {
     const int cb = (int)(q % p.NB); q /= p.NB;
     const int ks = (int)(q % p.KS);
     const int t = (int)(q / p.KS);
-    const int c = ks * 16 + h * 8 + e, k = cb * 32 + r;
-    float v = 0.f;
-    if (c < p.Cin_slab && k < p.Cout) {
-      // slab channel c is reference channel c + dup_shift; inside [dup_start, dup_start + dup_shift) it is ALSO reference
-      // channel c - dup_start (encoder.py:83-87: [o_{j-1}, o_0 .. o_{j-1}] read once from the slab [o_0 .. o_{j-1}])
-      auto at = [&](int cr) {
-        return p.transposed ? p.w[((long)t * p.Cout + k) * p.Cin_ref + cr] : p.w[((long)t * p.Cin_ref + cr) * p.Cout + k];
-      };
-      v = at(c + p.dup_shift);
-      if (p.dup_shift > 0 && c >= p.dup_start && c < p.dup_start + p.dup_shift) v += at(c - p.dup_start);
-    }
-    p.wp[i] = T::st(v);
+    p.wp[i] = T::st(lp_pack_src(p, t, ks * 16 + h * 8 + e, cb * 32 + r));
   }
 }
 
 static int lp_ntaps(int kind) { return kind == BTS_CONV_K1 ? 1 : 27; }
 
-extern "C" long bts_lp_packed_bytes(int kind, int Cin_slab, int Cout) {
-  if (kind < 0 || kind > 3 || Cin_slab <= 0 || Cout <= 0) return -1;
-  return (long)lp_ntaps(kind) * ((Cin_slab + 15) / 16) * ((Cout + 31) / 32) * 512 * 2;
+extern "C" long bts_lp_packed_bytes(int kind, int role, int Cin_slab, int Cout) {
+  if (kind < 0 || kind > 3 || role < 0 || role > 1 || Cin_slab <= 0 || Cout <= 0) return -1;
+  const int K = role == BTS_ROLE_FWD ? Cin_slab : Cout, N = role == BTS_ROLE_FWD ? Cout : Cin_slab;
+  return (long)lp_ntaps(kind) * ((K + 15) / 16) * ((N + 31) / 32) * 512 * 2;
 }
-extern "C" int bts_lp_pack(int kind, int dtype, const float* w, void* wp, int Cin_ref, int Cout, int Cin_slab, int dup_start,
+extern "C" int bts_lp_pack(int kind, int role, int dtype, const float* w, void* wp, int Cin_ref, int Cout, int Cin_slab, int dup_start,
                            int dup_shift, hipStream_t stream) {
-  if (kind < 0 || kind > 3 || (dtype != LP_F16 && dtype != LP_BF16)) return BTS_ERR_UNSUPPORTED;
+  if (kind < 0 || kind > 3 || role < 0 || role > 1 || (dtype != LP_F16 && dtype != LP_BF16)) return BTS_ERR_UNSUPPORTED;
   if (Cin_slab + dup_shift != Cin_ref || dup_shift < 0 || dup_start < 0 || dup_start + dup_shift > Cin_slab) return BTS_ERR_SHAPE;
   LpPackParams p;
   p.w = w; p.wp = reinterpret_cast<unsigned short*>(wp);
-  p.ntaps = lp_ntaps(kind); p.Cin_ref = Cin_ref; p.Cout = Cout; p.Cin_slab = Cin_slab; p.dup_start = dup_start; p.dup_shift = dup_shift;
-  p.transposed = kind == BTS_CONV_K3S2T; p.KS = (Cin_slab + 15) / 16; p.NB = (Cout + 31) / 32;
+  p.ntaps = lp_ntaps(kind);
+  p.shift = dup_shift;
+  p.dup_start = dup_shift > 0 ? dup_start : (1 << 30);
+  long sCin, sCout;
+  if (kind == BTS_CONV_K3S2T) { sCout = Cin_ref; sCin = 1; }   // (t, Cout, Cin)
+  else { sCin = Cout; sCout = 1; }                             // (t, Cin, Cout)
+  p.sT = (long)Cin_ref * Cout;
+  if (role == BTS_ROLE_FWD) {
+    p.K = Cin_slab; p.N = Cout; p.sK = sCin; p.sN = sCout; p.flip = 0; p.cin_is_k = 1;
+  } else {
+    p.K = Cout; p.N = Cin_slab; p.sK = sCout; p.sN = sCin; p.cin_is_k = 0;
+    p.flip = (kind == BTS_CONV_K3S1) ? 1 : 0;
+  }
+  p.KS = (p.K + 15) / 16; p.NB = (p.N + 31) / 32;
   const long total = (long)p.ntaps * p.KS * p.NB * 512;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
@@ -126,6 +153,22 @@ extern "C" int bts_lp_pack(int kind, int dtype, const float* w, void* wp, int Ci
   else hipLaunchKernelGGL(lp_pack_kernel<TBF16>, dim3(blocks), dim3(256), 0, stream, p);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
+}
+
+// one register quad (4 consecutive couts) of a result: bias added by the caller; optional read-modify-write accumulation
+template <typename T>
+__device__ __forceinline__ void lp_store_quad(unsigned short* dst, float o0, float o1, float o2, float o3, int nleft, int accum) {
+  if (nleft >= 4) {
+    if (accum) {
+      const u32x2 old = *reinterpret_cast<const u32x2*>(dst);
+      o0 += T::ld((unsigned short)(old[0] & 0xffffu)); o1 += T::ld((unsigned short)(old[0] >> 16));
+      o2 += T::ld((unsigned short)(old[1] & 0xffffu)); o3 += T::ld((unsigned short)(old[1] >> 16));
+    }
+    *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<T>(o0, o1), pack2<T>(o2, o3)};
+  } else {
+    const float o[3] = {o0, o1, o2};
+    for (int j = 0; j < nleft; ++j) dst[j] = T::st(accum ? o[j] + T::ld(dst[j]) : o[j]);
+  }
 }
 
 // =====================================================================================================================
@@ -140,6 +183,7 @@ struct LpS1Params {
   int ntx, nty, ntz, ncg;                    // tiles per axis, cout groups of CB blocks
   int ksplit, ks_per;                        // split-K over blockIdx.y (small grids)
   long ntiles;
+  int accum;                                 // y += result (gradient accumulation into a slab), else y = result
   float* part;
 };
 #define LPS 24   // halves per staged voxel: 16 channels + 8 pad (48-byte stride: conflict-free 16-byte reads)
@@ -333,13 +377,7 @@ __global__ __launch_bounds__(256, 2) void lp_conv_s1_kernel(const LpS1Params p) 
           unsigned short* dst = p.y + ((((long)n * p.D + oz) * p.H + oy) * p.W + ox) * (long)p.ldy + co;
           const float o0 = acc[v][c][4 * q] + bq[0], o1 = acc[v][c][4 * q + 1] + bq[1], o2 = acc[v][c][4 * q + 2] + bq[2],
                       o3 = acc[v][c][4 * q + 3] + bq[3];
-          if (co + 3 < p.Cout) {
-            *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<T>(o0, o1), pack2<T>(o2, o3)};
-          } else {
-            dst[0] = T::st(o0);
-            if (co + 1 < p.Cout) dst[1] = T::st(o1);
-            if (co + 2 < p.Cout) dst[2] = T::st(o2);
-          }
+          lp_store_quad<T>(dst, o0, o1, o2, o3, p.Cout - co, p.accum);
         }
       }
     }
@@ -350,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void lp_conv_s1_kernel(const LpS1Params p) 
 // finish of a split-K launch: y = round(bias + sum_z part[z]) in fixed order
 template <typename T>
 __global__ __launch_bounds__(256) void lp_splitk_reduce_kernel(const float* part, const float* bias, unsigned short* y, long nvox, int Cout,
-                                                               int Npad, int ldy, int ksplit) {
+                                                               int Npad, int ldy, int ksplit, int accum) {
   const int q4 = Npad / 4;
   const long total = nvox * q4;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -363,12 +401,7 @@ __global__ __launch_bounds__(256) void lp_splitk_reduce_kernel(const float* part
 #pragma unroll
       for (int j = 0; j < 4; ++j) if (c + j < Cout) s[j] += bias[c + j];
     }
-    unsigned short* dst = y + v * ldy + c;
-    if (c + 3 < Cout) {
-      *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<T>(s[0], s[1]), pack2<T>(s[2], s[3])};
-    } else {
-      for (int j = 0; j < 4 && c + j < Cout; ++j) dst[j] = T::st(s[j]);
-    }
+    lp_store_quad<T>(y + v * ldy + c, s[0], s[1], s[2], s[3], Cout - c, accum);
   }
 }
 
@@ -417,7 +450,7 @@ static int lp_s1_launch(LpS1Params p, void* ws, long ws_bytes, hipStream_t strea
     long blocks = (nvox * (p.NB * 8) + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(lp_splitk_reduce_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p.part, p.bias, p.y, nvox, p.Cout, p.NB * 32,
-                       p.ldy, p.ksplit);
+                       p.ldy, p.ksplit, p.accum);
     BTS_LAUNCH_CHECK();
   }
   return BTS_OK;
@@ -463,7 +496,7 @@ struct LpGatherParams {
   int Dg, Hg, Wg;                   // grid of this launch (output positions of one class)
   int Do, Ho, Wo, ldy, Cout;        // output tensor
   int s, os, ooz, ooy, oox;         // in = g*s + off_t ; out = g*os + oo
-  int KS, NB, ncg, ntaps;
+  int KS, NB, ncg, ntaps, accum;
   long npos;                        // N*Dg*Hg*Wg
   LpTap taps[27];
 };
@@ -571,13 +604,7 @@ __global__ __launch_bounds__(256, 2) void lp_conv_gather_kernel(const LpGatherPa
             unsigned short* dst = p.y + ((((long)gn[v] * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * (long)p.ldy + co;
             const float o0 = acc[v][c][4 * q] + bq[0], o1 = acc[v][c][4 * q + 1] + bq[1], o2 = acc[v][c][4 * q + 2] + bq[2],
                         o3 = acc[v][c][4 * q + 3] + bq[3];
-            if (co + 3 < p.Cout) {
-              *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<T>(o0, o1), pack2<T>(o2, o3)};
-            } else {
-              dst[0] = T::st(o0);
-              if (co + 1 < p.Cout) dst[1] = T::st(o1);
-              if (co + 2 < p.Cout) dst[2] = T::st(o2);
-            }
+            lp_store_quad<T>(dst, o0, o1, o2, o3, p.Cout - co, p.accum);
           }
         }
       }
@@ -605,40 +632,33 @@ static int lp_gather_launch(LpGatherParams p, hipStream_t stream) {
   return BTS_OK;
 }
 
-// y = conv(x) + bias in the storage type.  x (N,D,H,W,Cin) stride ldx (elements); y (N,D',H',W',Cout) stride ldy; D' = D | D/2
-// (TF 'same', stride 2) | 2D (transposed).  Cin must be a multiple of 16 and ldx / ldy / the views' first channel multiples of 8.
-extern "C" long bts_lp_conv3d_workspace(int kind, int N, int D, int H, int W, int Cin, int Cout) {
-  if (kind != BTS_CONV_K3S1 || Cin % 16 != 0) return 0;
-  const int NB = (Cout + 31) / 32;
-  int vb, cb, txl;
-  lp_s1_shape(N, D, H, W, NB, vb, cb, txl);
-  const int ks = lp_s1_ksplit(lp_s1_wgs(N, D, H, W, NB, vb, cb, txl), Cin / 16);
-  return ks > 1 ? (long)ks * N * D * H * W * NB * 32 * 4 : 0;
-}
-extern "C" int bts_lp_conv3d_fwd(int kind, int dtype, const void* x, const void* wp, const float* bias, void* y, void* workspace,
-                                 long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, hipStream_t stream) {
+// geometry-driven core of both entry points below.  geo: 0 = 1x1x1, 1 = 3x3x3 stride 1, 2 = stride-2 gather (out = ceil(in/2),
+// in = 2o + k - pad), 3 = 8 output-parity classes of the transposed form (out = 2 in; even outputs take (i, k=0) and (i-1, k=2),
+// odd ones (i, k=1)).  (D,H,W) are the dims of `x`, the tensor the taps read; Cin its channels (the contraction).
+static int lp_conv_run(int geo, int dtype, const void* x, const void* wp, const float* bias, void* y, void* workspace, long workspace_bytes,
+                       int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, int accum, hipStream_t stream) {
   if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return BTS_ERR_SHAPE;
   if (Cin % 16 != 0 || ldx % 8 != 0 || ldy % 4 != 0 || ldx < Cin || ldy < Cout) return BTS_ERR_ALIGN;
   if ((((uintptr_t)x) & 15) || (((uintptr_t)y) & 7) || (((uintptr_t)wp) & 15)) return BTS_ERR_ALIGN;
   const int KS = Cin / 16, NB = (Cout + 31) / 32;
-  if (kind == BTS_CONV_K3S1) {
+  if (geo == 1) {
     if (((long)(D + 2) * H * W + 64) * (long)ldx * 2 >= 0x7fffffffL) return BTS_ERR_SHAPE;   // 31-bit offsets inside one volume
     LpS1Params p;
     p.x = (const unsigned short*)x; p.wp = (const unsigned short*)wp; p.bias = bias; p.y = (unsigned short*)y;
-    p.N = N; p.D = D; p.H = H; p.W = W; p.ldx = ldx; p.ldy = ldy; p.Cout = Cout; p.KS = KS; p.NB = NB;
+    p.N = N; p.D = D; p.H = H; p.W = W; p.ldx = ldx; p.ldy = ldy; p.Cout = Cout; p.KS = KS; p.NB = NB; p.accum = accum;
     return dtype == LP_F16 ? lp_s1_dispatch<TF16>(p, workspace, workspace_bytes, stream) : lp_s1_dispatch<TBF16>(p, workspace, workspace_bytes, stream);
   }
   LpGatherParams g;
   g.x = (const unsigned short*)x; g.wp = (const unsigned short*)wp; g.bias = bias; g.y = (unsigned short*)y;
-  g.N = N; g.Di = D; g.Hi = H; g.Wi = W; g.ldx = ldx; g.ldy = ldy; g.Cout = Cout; g.KS = KS; g.NB = NB;
+  g.N = N; g.Di = D; g.Hi = H; g.Wi = W; g.ldx = ldx; g.ldy = ldy; g.Cout = Cout; g.KS = KS; g.NB = NB; g.accum = accum;
   auto run = [&](const LpGatherParams& q) { return dtype == LP_F16 ? lp_gather_launch<TF16>(q, stream) : lp_gather_launch<TBF16>(q, stream); };
-  if (kind == BTS_CONV_K1) {
+  if (geo == 0) {
     g.Dg = g.Do = D; g.Hg = g.Ho = H; g.Wg = g.Wo = W; g.s = 1; g.os = 1; g.ooz = g.ooy = g.oox = 0; g.ntaps = 1;
     g.taps[0] = LpTap{0, 0, 0, 0};
     return run(g);
   }
-  if (kind == BTS_CONV_K3S2) {   // TF 'same', stride 2: out = ceil(in/2), pad_before = max((out-1)*2+3-in, 0) / 2
+  if (geo == 2) {   // TF 'same', stride 2: out = ceil(in/2), pad_before = max((out-1)*2+3-in, 0) / 2
     g.Do = (D + 1) / 2; g.Ho = (H + 1) / 2; g.Wo = (W + 1) / 2;
     g.Dg = g.Do; g.Hg = g.Ho; g.Wg = g.Wo; g.s = 2; g.os = 1; g.ooz = g.ooy = g.oox = 0; g.ntaps = 27;
     auto padb = [](int in, int out) { const int t = (out - 1) * 2 + 3 - in; return t > 0 ? t / 2 : 0; };
@@ -646,15 +666,13 @@ extern "C" int bts_lp_conv3d_fwd(int kind, int dtype, const void* x, const void*
     for (int t = 0; t < 27; ++t) g.taps[t] = LpTap{(short)(t / 9 - pz), (short)((t / 3) % 3 - py), (short)(t % 3 - px), (short)t};
     return run(g);
   }
-  if (kind == BTS_CONV_K3S2T) {  // y[2i+k] += x[i] w[k], cropped to [0, 2n): 8 output-parity classes, every output written once
+  if (geo == 3) {  // y[2i+k] += x[i] w[k], cropped to [0, 2n): 8 output-parity classes, every output written once
     g.Do = 2 * D; g.Ho = 2 * H; g.Wo = 2 * W; g.Dg = D; g.Hg = H; g.Wg = W; g.s = 1; g.os = 2;
     for (int cls = 0; cls < 8; ++cls) {
       const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
-      // per axis: even outputs (j = 2i) take (i, k=0) and (i-1, k=2); odd outputs (j = 2i+1) take (i, k=1)
-      int noz = 0, noy = 0, nox = 0;
       int ozs[2], kzs[2], oys[2], kys[2], oxs[2], kxs[2];
       auto fill = [](int par, int* off, int* k) { if (par) { off[0] = 0; k[0] = 1; return 1; } off[0] = 0; k[0] = 0; off[1] = -1; k[1] = 2; return 2; };
-      noz = fill(pz, ozs, kzs); noy = fill(py, oys, kys); nox = fill(px, oxs, kxs);
+      const int noz = fill(pz, ozs, kzs), noy = fill(py, oys, kys), nox = fill(px, oxs, kxs);
       int nt = 0;
       for (int a = 0; a < noz; ++a)
         for (int b2 = 0; b2 < noy; ++b2)
@@ -665,6 +683,47 @@ extern "C" int bts_lp_conv3d_fwd(int kind, int dtype, const void* x, const void*
       if (r != BTS_OK) return r;
     }
     return BTS_OK;
+  }
+  return BTS_ERR_UNSUPPORTED;
+}
+
+static long lp_s1_workspace(int N, int D, int H, int W, int Cin, int Cout) {
+  if (Cin % 16 != 0) return 0;
+  const int NB = (Cout + 31) / 32;
+  int vb, cb, txl;
+  lp_s1_shape(N, D, H, W, NB, vb, cb, txl);
+  const int ks = lp_s1_ksplit(lp_s1_wgs(N, D, H, W, NB, vb, cb, txl), Cin / 16);
+  return ks > 1 ? (long)ks * N * D * H * W * NB * 32 * 4 : 0;
+}
+extern "C" long bts_lp_conv3d_workspace(int kind, int N, int D, int H, int W, int Cin, int Cout) {
+  return kind == BTS_CONV_K3S1 ? lp_s1_workspace(N, D, H, W, Cin, Cout) : 0;
+}
+// y = conv(x) + bias in the storage type.  x (N,D,H,W,Cin) stride ldx (elements); y (N,D',H',W',Cout) stride ldy; D' = D | D/2
+// (TF 'same', stride 2) | 2D (transposed).  Cin must be a multiple of 16 and ldx / ldy / the views' first channel multiples of 8.
+extern "C" int bts_lp_conv3d_fwd(int kind, int dtype, const void* x, const void* wp, const float* bias, void* y, void* workspace,
+                                 long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, hipStream_t stream) {
+  if (kind < 0 || kind > 3) return BTS_ERR_UNSUPPORTED;
+  return lp_conv_run(kind, dtype, x, wp, bias, y, workspace, workspace_bytes, N, D, H, W, Cin, ldx, Cout, ldy, 0, stream);
+}
+// dx (+)= conv^T(dy) (replaces tf.GradientTape for these ops, train.py:142-151).  (D,H,W) are the forward INPUT dims, Cin / Cout
+// the forward channel counts; wp_bwd = bts_lp_pack(kind, BTS_ROLE_BWD_DATA, ...).  The data gradient of each kind is one of the
+// forward geometries on the role-swapped image: stride 1 -> stride 1 with flipped taps, 1x1x1 -> 1x1x1, stride 2 -> the
+// transposed form's parity classes (each input voxel receives from (o, k=i-2o)), transposed -> the stride-2 gather.
+extern "C" long bts_lp_conv3d_bwd_data_workspace(int kind, int N, int D, int H, int W, int Cin, int Cout) {
+  return kind == BTS_CONV_K3S1 ? lp_s1_workspace(N, D, H, W, Cout, Cin) : 0;
+}
+extern "C" int bts_lp_conv3d_bwd_data(int kind, int dtype, const void* dy, const void* wp_bwd, void* dx, void* workspace,
+                                      long workspace_bytes, int N, int D, int H, int W, int Cin, int lddx, int Cout, int lddy, int accum,
+                                      hipStream_t stream) {
+  switch (kind) {
+    case BTS_CONV_K1:
+    case BTS_CONV_K3S1:
+      return lp_conv_run(kind, dtype, dy, wp_bwd, nullptr, dx, workspace, workspace_bytes, N, D, H, W, Cout, lddy, Cin, lddx, accum, stream);
+    case BTS_CONV_K3S2:   // dy lives on the half grid; TF 'same' with even sizes pads (0,1) only, which is what the class tables assume
+      if ((D | H | W) & 1) return BTS_ERR_UNSUPPORTED;
+      return lp_conv_run(3, dtype, dy, wp_bwd, nullptr, dx, workspace, workspace_bytes, N, D / 2, H / 2, W / 2, Cout, lddy, Cin, lddx, accum, stream);
+    case BTS_CONV_K3S2T:  // dy lives on the doubled grid: dx[i] = sum_k dy[2i+k] W[k]
+      return lp_conv_run(2, dtype, dy, wp_bwd, nullptr, dx, workspace, workspace_bytes, N, 2 * D, 2 * H, 2 * W, Cout, lddy, Cin, lddx, accum, stream);
   }
   return BTS_ERR_UNSUPPORTED;
 }
@@ -907,7 +966,7 @@ extern "C" int bts_lp_colsum(int dtype, const void* x, float* out, void* workspa
 // one voxel per group of C/8 lanes: the spatial dot product is reduced across those lanes with xor shuffles
 template <typename T>
 __global__ __launch_bounds__(256) void lp_block_epilogue_kernel(const unsigned short* res, const unsigned short* c2, unsigned short* out,
-                                                                const float* wsp, const float* ch, const float* gamma, const float* beta,
+                                                                float* sp_out, const float* wsp, const float* ch, const float* gamma, const float* beta,
                                                                 const float* mean, const float* rstd, long total8, long E, long L, int C,
                                                                 int G, int cg, int ldo, int mode) {
   const int oct = C / 8;
@@ -925,6 +984,7 @@ __global__ __launch_bounds__(256) void lp_block_epilogue_kernel(const unsigned s
     for (int e = 0; e < 8; ++e) dot = fmaf(a[e], wsp[c + e], dot);
     for (int m = 1; m < oct; m <<= 1) dot += __shfl_xor(dot, m, 64);   // (oct is a power of two <= 32; lanes of a voxel are adjacent)
     const float sp = 1.f / (1.f + __expf(-dot));
+    if (sp_out != nullptr && c == 0) sp_out[pix] = sp;   // the spatial gate, kept for the backward pass (resnet.py:127)
     const int gsl = (int)(r / L);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -936,7 +996,7 @@ __global__ __launch_bounds__(256) void lp_block_epilogue_kernel(const unsigned s
     *reinterpret_cast<u32x4*>(out + pix * ldo + c) = pack8<T>(o);
   }
 }
-extern "C" int bts_lp_block_epilogue(int dtype, const void* res, const void* c2, void* out, const float* wsp, const float* ch,
+extern "C" int bts_lp_block_epilogue(int dtype, const void* res, const void* c2, void* out, float* sp_out, const float* wsp, const float* ch,
                                      const float* gamma, const float* beta, const float* mean, const float* rstd, int N, long V, int C,
                                      int ldo, int G, int mode, hipStream_t stream) {
   if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
@@ -949,8 +1009,8 @@ extern "C" int bts_lp_block_epilogue(int dtype, const void* res, const void* c2,
   long blocks = (total8 + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   (void)hipGetLastError();
-  if (dtype == LP_F16) hipLaunchKernelGGL(lp_block_epilogue_kernel<TF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)res, (const unsigned short*)c2, (unsigned short*)out, wsp, ch, gamma, beta, mean, rstd, total8, E, L, C, G, C / G, ldo, mode);
-  else hipLaunchKernelGGL(lp_block_epilogue_kernel<TBF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)res, (const unsigned short*)c2, (unsigned short*)out, wsp, ch, gamma, beta, mean, rstd, total8, E, L, C, G, C / G, ldo, mode);
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_block_epilogue_kernel<TF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)res, (const unsigned short*)c2, (unsigned short*)out, sp_out, wsp, ch, gamma, beta, mean, rstd, total8, E, L, C, G, C / G, ldo, mode);
+  else hipLaunchKernelGGL(lp_block_epilogue_kernel<TBF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)res, (const unsigned short*)c2, (unsigned short*)out, sp_out, wsp, ch, gamma, beta, mean, rstd, total8, E, L, C, G, C / G, ldo, mode);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }

@@ -44,12 +44,23 @@ def _ld(t):
 
 
 # ---- C-ABI wrappers ----------------------------------------------------------------------------------------------------
-def pack(kind, code, w, cin_ref, cout, cin_slab=None, dup_start=0, dup_shift=0):
+def pack(kind, code, w, cin_ref, cout, cin_slab=None, dup_start=0, dup_shift=0, role=ops.ROLE_FWD):
     cin_slab = cin_ref if cin_slab is None else cin_slab
-    nbytes = lib().query('bts_lp_packed_bytes', kind, cin_slab, cout)
+    nbytes = lib().query('bts_lp_packed_bytes', kind, role, cin_slab, cout)
     wp = torch.empty(nbytes // 2, dtype=torch.int16, device=w.device)
-    lib().call('bts_lp_pack', kind, code, _p(w), _p(wp), cin_ref, cout, cin_slab, dup_start, dup_shift, _stream())
+    lib().call('bts_lp_pack', kind, role, code, _p(w), _p(wp), cin_ref, cout, cin_slab, dup_start, dup_shift, _stream())
     return wp
+
+
+def conv_bwd_data(kind, code, dy, wp_bwd, dx, accumulate):
+    """dx (+)= conv^T(dy); dx: (N,D,H,W,Cin) view of the forward input's gradient, dy: the forward output's"""
+    n, d, h, w, cin = dx.shape
+    cout = dy.shape[-1]
+    nb = lib().query('bts_lp_conv3d_bwd_data_workspace', kind, n, d, h, w, cin, cout)
+    ws = ops.workspace(nb, dx.device) if nb > 0 else None
+    lib().call('bts_lp_conv3d_bwd_data', kind, code, _p(dy), _p(wp_bwd), _p(dx), _p(ws) if ws is not None else None, nb, n, d, h, w,
+               cin, _ld(dx), cout, _ld(dy), 1 if accumulate else 0, _stream())
+    return dx
 
 
 def conv(kind, code, tdt, x, wp, bias, cout, out=None):
@@ -117,10 +128,10 @@ def colsum(code, x, scale):
     return out
 
 
-def block_epilogue(code, res, c2, out, wsp, ch, gamma, beta, mean, rstd, groups, mode):
+def block_epilogue(code, res, c2, out, wsp, ch, gamma, beta, mean, rstd, groups, mode, sp_out=None):
     n, f = res.shape[0], res.shape[4]
     v = res.shape[1] * res.shape[2] * res.shape[3]
-    lib().call('bts_lp_block_epilogue', code, _p(res), _p(c2), _p(out), _p(wsp), _p(ch), _p(gamma), _p(beta), _p(mean), _p(rstd), n, v,
+    lib().call('bts_lp_block_epilogue', code, _p(res), _p(c2), _p(out), _p(sp_out) if sp_out is not None else None, _p(wsp), _p(ch), _p(gamma), _p(beta), _p(mean), _p(rstd), n, v,
                f, _ld(out), groups, mode, _stream())
     return out
 

@@ -237,15 +237,20 @@ int bts_profile_get(int i, int* sym, double* flops, float* ms);
 #define BTS_LP_F16 1
 #define BTS_LP_BF16 2
 /* packed weight image of a conv kind: [tap][16-cin step][32-cout block][k half][32 couts][8 cin]; same folding arguments as bts_conv_pack */
-long bts_lp_packed_bytes(int kind, int Cin_slab, int Cout);
-int bts_lp_pack(int kind, int dtype, const float* w, void* wp, int Cin_ref, int Cout, int Cin_slab, int dup_start, int dup_shift,
-                bts_stream_t stream);
+long bts_lp_packed_bytes(int kind, int role, int Cin_slab, int Cout);
+int bts_lp_pack(int kind, int role, int dtype, const float* w, void* wp, int Cin_ref, int Cout, int Cin_slab, int dup_start,
+                int dup_shift, bts_stream_t stream);
 /* y = conv(x) + bias (resnet.py:30-37,80-87,96-103; downsample.py:28-35; upsample.py:28-33).  Cin % 16 == 0; views' strides % 8 == 0 */
 /* workspace (may be NULL / 0): lets stride-1 grids too small to fill the chip split the input channels over workgroups (fp32 partial
  * sums, fixed-order reduce); size from bts_lp_conv3d_workspace (0 when the shape does not need it) */
 long bts_lp_conv3d_workspace(int kind, int N, int D, int H, int W, int Cin, int Cout);
 int bts_lp_conv3d_fwd(int kind, int dtype, const void* x, const void* wp, const float* bias, void* y, void* workspace, long workspace_bytes,
                       int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, bts_stream_t stream);
+/* dx (+)= conv^T(dy) in the storage type (the data gradients TF autodiff derives, train.py:142-151); (D,H,W) are the forward INPUT
+ * dims, wp_bwd = bts_lp_pack(kind, BTS_ROLE_BWD_DATA, ...); Cout % 16 == 0 */
+long bts_lp_conv3d_bwd_data_workspace(int kind, int N, int D, int H, int W, int Cin, int Cout);
+int bts_lp_conv3d_bwd_data(int kind, int dtype, const void* dy, const void* wp_bwd, void* dx, void* workspace, long workspace_bytes,
+                           int N, int D, int H, int W, int Cin, int lddx, int Cout, int lddy, int accum, bts_stream_t stream);
 /* fp32 <-> storage type, `rows` rows of C elements with row strides (the 2-channel input block runs in fp32: K = 16 is its floor) */
 int bts_lp_cast(int dtype, const float* src, long ld_src, void* dst, long ld_dst, long rows, int C, bts_stream_t stream);
 int bts_lp_uncast(int dtype, const void* src, long ld_src, float* dst, long ld_dst, long rows, int C, bts_stream_t stream);
@@ -260,7 +265,8 @@ long bts_lp_colsum_workspace(int N, long V, int C);
 int bts_lp_colsum(int dtype, const void* x, float* out, void* workspace, long workspace_bytes, int N, long V, int C, float scale,
                   bts_stream_t stream);
 /* out = res * (sigmoid(res . w_sp) + ch[n]) + relu(GN2(c2))   (resnet.py:127-137) */
-int bts_lp_block_epilogue(int dtype, const void* res, const void* c2, void* out, const float* wsp, const float* ch, const float* gamma,
+/* sp_out (may be NULL): the per-voxel spatial gate sigmoid(res . w_sp), fp32 [N*V], kept for the backward pass */
+int bts_lp_block_epilogue(int dtype, const void* res, const void* c2, void* out, float* sp_out, const float* wsp, const float* ch, const float* gamma,
                           const float* beta, const float* mean, const float* rstd, int N, long V, int C, int ldo, int G, int mode,
                           bts_stream_t stream);
 /* output head (decoder.py:55-63): y = sigmoid(x . W + b), W (C, K <= 4) fp32, y fp32 (the label map is taken from it) */

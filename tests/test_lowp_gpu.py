@@ -246,3 +246,51 @@ def test_segment_volume_in_fp16_against_the_fp32_pipeline():
     print('TTA pipeline fp16 vs fp32: |dp| max %.3e mean %.3e, label changes %.3f %%' % (float(d.max()), float(d.mean()), 100 * mism))
     assert float(d.max()) <= 2e-2 and float(d.mean()) <= 1e-3 and mism <= 5e-3
     assert set(l16.cpu().unique().tolist()) <= {0, 1, 2, 4}
+
+
+BWD_CASES = [
+    ('K3S1', (8, 8, 32), 32, 32), ('K3S1', (10, 12, 10), 48, 64), ('K1', (6, 5, 7), 48, 32),
+    ('K3S2', (8, 12, 16), 32, 32), ('K3S2', (4, 4, 4), 48, 64), ('K3S2T', (4, 6, 5), 32, 32), ('K3S2T', (3, 3, 3), 64, 48),
+]
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('accumulate', [False, True])
+@pytest.mark.parametrize('case', BWD_CASES, ids=lambda c: '%s-%dx%dx%d-%d-%d' % (c[0], *c[1], c[2], c[3]))
+def test_conv_data_gradient_kernels(case, accumulate, dtype):
+    """dx (+)= conv^T(dy) on role-swapped 16-bit weight images against torch autograd of the oracle's forward op on the same
+    rounded dy / w (fp64).  (D,H,W) = forward input dims; the gradient lands in a channel slice of a wider slab."""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    name, (d, h, w), cin, cout = case
+    kind = getattr(ops, name)
+    code, tdt = lowp.DTYPES[dtype]
+    u = U[dtype]
+    g = torch.Generator().manual_seed(hash((name, d, h, w, cin, cout, 'b')) % 10000)
+    n = 2
+    k = 1 if kind == ops.K1 else 3
+    wshape = (k, k, k, cout, cin) if kind == ops.K3S2T else (k, k, k, cin, cout)
+    wt = torch.randn(wshape, generator=g) * (2.0 / (k ** 3 * cout)) ** 0.5
+    wr = _round(wt, tdt)
+
+    x0 = torch.zeros((n, d, h, w, cin), dtype=torch.float64, requires_grad=True)
+    yshape = _ref_conv(kind, x0, wr, None).shape
+    dy = torch.randn(tuple(yshape), generator=g)
+    dyr = _round(dy, tdt)
+    ref = torch.autograd.grad(_ref_conv(kind, x0, wr, None), x0, dyr)[0]
+    x1 = torch.zeros((n, d, h, w, cin), dtype=torch.float64, requires_grad=True)
+    mag = torch.autograd.grad(_ref_conv(kind, x1, wr.abs(), None), x1, dyr.abs())[0]
+    old = torch.randn((n, d, h, w, cin), generator=g)
+    oldr = _round(old, tdt)
+    want = ref + (oldr if accumulate else 0.0)
+    bound = 8 * 2.0 ** -24 * mag + u * want.abs() + 1e-30
+    slab = torch.full((n, d, h, w, cin + 16), 5.0, dtype=tdt, device=DEV)
+    dx = slab[..., 8:8 + cin]
+    dx.copy_(old.to(tdt).to(DEV))
+    wpb = lowp.pack(kind, code, wt.to(DEV), cin, cout, role=ops.ROLE_BWD)
+    lowp.conv_bwd_data(kind, code, dy.to(tdt).to(DEV), wpb, dx, accumulate)
+    torch.cuda.synchronize()
+    err = (dx.double().cpu() - want).abs()
+    worst = float((err / bound).max())
+    assert worst <= 1.0, '%s %s: error %.3e is %.2fx the stated bound' % (name, dtype, float(err.max()), worst)
+    assert bool((slab[..., :8] == 5.0).all()) and bool((slab[..., 8 + cin:] == 5.0).all())
