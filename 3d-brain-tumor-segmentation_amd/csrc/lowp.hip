@@ -639,8 +639,10 @@ static int lp_conv_run(int geo, int dtype, const void* x, const void* wp, const 
                        int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, int accum, hipStream_t stream) {
   if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return BTS_ERR_SHAPE;
-  if (Cin % 16 != 0 || ldx % 8 != 0 || ldy % 4 != 0 || ldx < Cin || ldy < Cout) return BTS_ERR_ALIGN;
-  if ((((uintptr_t)x) & 15) || (((uintptr_t)y) & 7) || (((uintptr_t)wp) & 15)) return BTS_ERR_ALIGN;
+  // (results are stored four couts = 8 bytes at a time; a head with fewer than four output channels stores them one by one)
+  const bool vec_out = Cout >= 4;
+  if (Cin % 16 != 0 || ldx % 8 != 0 || (vec_out && ldy % 4 != 0) || ldx < Cin || ldy < Cout) return BTS_ERR_ALIGN;
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)y) & (vec_out ? 7 : 1)) || (((uintptr_t)wp) & 15)) return BTS_ERR_ALIGN;
   const int KS = Cin / 16, NB = (Cout + 31) / 32;
   if (geo == 1) {
     if (((long)(D + 2) * H * W + 64) * (long)ldx * 2 >= 0x7fffffffL) return BTS_ERR_SHAPE;   // 31-bit offsets inside one volume

@@ -1,0 +1,336 @@
+"""One training step with 16-bit STORAGE (BASELINE configs[2]: bf16, batch 8; the step itself is train.py:140-152).
+
+Activations and their gradients live in HBM as bf16 (or fp16), packed weight images too; every sum is fp32 and the master
+weights, their gradients and the Adam moments stay the model's flat fp32 buffers.  Where each piece of the step runs:
+
+  forward convolutions, GroupNorm, pooling, block epilogue            16-bit kernels of csrc/lowp.hip (as bts_amd.lowp)
+  data gradients of every convolution                                  the same kernels on role-swapped weight images
+                                                                       (bts_lp_conv3d_bwd_data), accumulating into slab gradients
+  weight gradients; GroupNorm / squeeze-excitation gradients;          the fp32 engine's kernels on operands widened by a
+  the dense VAE head; loss, metric, regulariser, Adam                  staging pass (bts_lp_uncast) -- exact on the stored values;
+                                                                       their 16-bit forms (the weight gradient needs
+                                                                       voxel-contiguous operand fragments, i.e. an LDS
+                                                                       transpose on the way in) are not built yet
+
+The graph is the fp32 layers' own (same virtual concatenation through level slabs, same folded duplicate slices), written
+out explicitly -- forward saves what the backward needs, the backward walks it in reverse -- so the fp32 engine (the parity
+reference of this path: tests/test_lowp_train_gpu.py) is not touched.  Parameter gradients are accumulated into a zeroed
+flat buffer; slab gradients are zero-initialised and accumulated into (a 16-bit accumulation: every partial sum is rounded
+to the storage type, which is part of what "16-bit storage" means and is bounded by the parity test).
+"""
+import torch
+
+from . import lowp, ops, parallel
+from .lowp import DTYPES, block_epilogue, cast, colsum, conv, conv_bwd_data, gn_apply, gn_stats, head, uncast
+from .tape import Tensor, bump_weights_epoch, weights_epoch
+
+
+class LowPrecisionTrainer(object):
+    def __init__(self, model, dtype='bfloat16'):
+        self.fwd = lowp.LowPrecisionForward(model, dtype)      # checks samplers / layout, owns the forward weight images
+        self.model = model
+        self.code, self.tdt = DTYPES[dtype]
+        self._packs = {}
+        self.last_labels = None
+
+    # ---- weight images ----
+    def _pk(self, key, kind, param, cin_ref, cout, cin_slab=None, dup_start=0, dup_shift=0, role=ops.ROLE_FWD):
+        ent = self._packs.get(key)
+        sig = (kind, role, cin_ref, cout, cin_slab, dup_start, dup_shift, id(param))
+        if ent is None or ent[0] != weights_epoch() or ent[1] != sig:
+            ent = (weights_epoch(), sig, lowp.pack(kind, self.code, param.t, cin_ref, cout, cin_slab, dup_start, dup_shift, role=role))
+            self._packs[key] = ent
+        return ent[2]
+
+    def _f32(self, t):
+        return uncast(self.code, t)
+
+    def _b16(self, t, out=None):
+        return cast(self.code, self.tdt, t, out=out)
+
+    def _b16_k(self, t):
+        """fp32 gradient -> storage type as a matrix-instruction operand: channels zero-padded to a multiple of 16 (the
+        contraction steps over 16 channels; only the VAE's 8- / 16-filter down-sampling conv of small models needs the pad)"""
+        c = t.shape[-1]
+        if c % 16 == 0:
+            return self._b16(t)
+        buf = torch.zeros(tuple(t.shape[:-1]) + ((c + 15) // 16 * 16,), dtype=self.tdt, device=t.device)
+        cast(self.code, self.tdt, t, out=buf[..., :c])
+        return buf
+
+    @staticmethod
+    def _gslot(p):
+        """fp32 gradient view of a parameter inside the model's flat gradient buffer (zeroed at the start of the step)"""
+        return p._gview
+
+    # ================================================================================================================
+    # forward pieces (each returns what its backward needs)
+    # ================================================================================================================
+    def _block_fwd(self, blk, x, out, fold=None):
+        code, tdt = self.code, self.tdt
+        f, g = blk.filters, blk.groups
+        n, d, h, w, cin = x.shape
+        dup_start, dup_shift = fold if fold else (0, 0)
+        v = d * h * w
+        cin_slab = min(cin, blk.cin_ref) if fold is None else cin       # (the zero-padded 2-channel input: cin 16, cin_ref 2)
+        key = id(blk)
+        wp_pt = self._pk((key, 'pt'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
+        wp_c1 = self._pk((key, 'c1'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
+        res = conv(ops.K1, code, tdt, x, wp_pt, blk.ptwise_b.t, f)
+        c1 = conv(ops.K3S1, code, tdt, x, wp_c1, blk.conv1_b.t, f)
+        gap = colsum(code, res, 1.0 / v)
+        hbuf, ch = ops.se_mlp_fwd(gap, blk.se_w1.t, blk.se_w2.t)
+        m1, r1 = gn_stats(code, c1, g, blk.norm1._mode, blk.norm1.epsilon)
+        a = gn_apply(code, c1, blk.norm1.gamma.t, blk.norm1.beta.t, m1, r1, g, blk.norm1._mode, True)
+        wp_c2 = self._pk((key, 'c2'), ops.K3S1, blk.conv2_k, f, f)
+        c2 = conv(ops.K3S1, code, tdt, a, wp_c2, blk.conv2_b.t, f)
+        m2, r2 = gn_stats(code, c2, g, blk.norm2._mode, blk.norm2.epsilon)
+        if out is None:
+            out = torch.empty((n, d, h, w, f), dtype=tdt, device=x.device)
+        sp = torch.empty(n * v, dtype=torch.float32, device=x.device)
+        block_epilogue(code, res, c2, out, blk.spatial_k.t.reshape(-1), ch, blk.norm2.gamma.t, blk.norm2.beta.t, m2, r2, g,
+                       blk.norm2._mode, sp_out=sp)
+        return out, dict(blk=blk, x=x, res=res, c1=c1, m1=m1, r1=r1, a=a, c2=c2, m2=m2, r2=r2, gap=gap, hbuf=hbuf, ch=ch, sp=sp,
+                         fold=(dup_start, dup_shift), cin_slab=cin_slab)
+
+    def _block_bwd(self, s, dout, dx):
+        """dout: 16-bit gradient of the block output (dense or a slab-gradient view); dx: 16-bit gradient view of the block input
+        to ACCUMULATE into, or None (the input volume)"""
+        code = self.code
+        blk = s['blk']
+        f, g = blk.filters, blk.groups
+        n1, n2 = blk.norm1, blk.norm2
+        dup_start, dup_shift = s['fold']
+        key = id(blk)
+        dout32 = self._f32(dout)
+        # conv branch: GN2 (+ReLU) -> conv2 -> GN1 (+ReLU) -> conv1
+        dc2 = ops.gn_bwd(self._f32(s['c2']), dout32, n2.gamma.t, n2.beta.t, s['m2'], s['r2'], self._gslot(n2.gamma), self._gslot(n2.beta),
+                         g, n2._mode, True, accumulate_params=True)
+        a32 = self._f32(s['a'])
+        ops.conv_bwd_weight(ops.K3S1, a32, dc2, self._gslot(blk.conv2_k), self._gslot(blk.conv2_b), accumulate=True)
+        del a32
+        da = torch.empty_like(s['a'])
+        conv_bwd_data(ops.K3S1, code, self._b16(dc2), self._pk((key, 'c2b'), ops.K3S1, blk.conv2_k, f, f, role=ops.ROLE_BWD), da, False)
+        del dc2
+        dc1 = ops.gn_bwd(self._f32(s['c1']), self._f32(da), n1.gamma.t, n1.beta.t, s['m1'], s['r1'], self._gslot(n1.gamma),
+                         self._gslot(n1.beta), g, n1._mode, True, accumulate_params=True)
+        del da
+        # gate branch
+        dres = ops.se_bwd(dout32, self._f32(s['res']), s['sp'], s['gap'], s['hbuf'], s['ch'], blk.se_w1.t, blk.se_w2.t,
+                          blk.spatial_k.t.reshape(-1), self._gslot(blk.se_w1), self._gslot(blk.se_w2),
+                          self._gslot(blk.spatial_k).reshape(-1), accumulate_params=True)
+        del dout32
+        # weight gradients of the two convolutions that read the block input (fp32 kernels on the widened input view)
+        x = s['x']
+        cin_slab = s['cin_slab']
+        x32 = self._f32(x[..., :cin_slab])
+        ops.conv_bwd_weight(ops.K3S1, x32, dc1, self._gslot(blk.conv1_k), self._gslot(blk.conv1_b), dup_start, dup_shift, accumulate=True)
+        ops.conv_bwd_weight(ops.K1, x32, dres, self._gslot(blk.ptwise_k), self._gslot(blk.ptwise_b), dup_start, dup_shift, accumulate=True)
+        del x32
+        if dx is not None:
+            cin = x.shape[-1]
+            wpb1 = self._pk((key, 'c1b'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin, dup_start, dup_shift, role=ops.ROLE_BWD)
+            wpbp = self._pk((key, 'ptb'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin, dup_start, dup_shift, role=ops.ROLE_BWD)
+            conv_bwd_data(ops.K3S1, code, self._b16(dc1), wpb1, dx, True)
+            conv_bwd_data(ops.K1, code, self._b16(dres), wpbp, dx, True)
+
+    def _sampler_fwd(self, lay, kind, x, out=None):
+        wp = self._pk((id(lay), 'f'), kind, lay.conv_k, lay.cin, lay.filters)
+        c = conv(kind, self.code, self.tdt, x, wp, lay.conv_b.t, lay.filters)
+        m, r = gn_stats(self.code, c, lay.norm.groups, lay.norm._mode, lay.norm.epsilon)
+        y = gn_apply(self.code, c, lay.norm.gamma.t, lay.norm.beta.t, m, r, lay.norm.groups, lay.norm._mode, True, out=out)
+        return y, dict(lay=lay, kind=kind, x=x, c=c, m=m, r=r)
+
+    def _sampler_bwd(self, s, dy, dx, accumulate, cin_live=None):
+        """ConvDownsample / ConvUpsample backward (downsample.py:41-45, upsample.py:39-43): GN(+ReLU) gradient, weight gradient,
+        data gradient into dx (None: not needed).  cin_live: real input channels when the input was zero-padded to 16"""
+        lay, kind = s['lay'], s['kind']
+        nrm = lay.norm
+        dc = ops.gn_bwd(self._f32(s['c']), self._f32(dy), nrm.gamma.t, nrm.beta.t, s['m'], s['r'], self._gslot(nrm.gamma),
+                        self._gslot(nrm.beta), nrm.groups, nrm._mode, True, accumulate_params=True)
+        x = s['x'] if cin_live is None else s['x'][..., :cin_live]
+        x32 = self._f32(x)
+        if kind == ops.K3S2T:
+            ops.conv_bwd_weight(kind, x32, dc, self._gslot(lay.conv_k), None, accumulate=True)
+            ops.colsum(dc, sum_over_n=True, out=self._gslot(lay.conv_b), accumulate=True)
+        else:
+            ops.conv_bwd_weight(kind, x32, dc, self._gslot(lay.conv_k), self._gslot(lay.conv_b), accumulate=True)
+        del x32
+        if dx is not None:
+            wpb = self._pk((id(lay), 'b'), kind, lay.conv_k, lay.cin, lay.filters, role=ops.ROLE_BWD)
+            conv_bwd_data(kind, self.code, self._b16_k(dc), wpb, dx, accumulate)
+
+    # ================================================================================================================
+    # the step
+    # ================================================================================================================
+    def step(self, optimizer, dice_fn, x, y):
+        """train.py:140-152 with 16-bit storage -> (loss, macro_dice, micro_dice) as 1-element Tensors"""
+        m = self.model
+        code, tdt = self.code, self.tdt
+        enc, dec, vae = m.encoder, m.decoder, m.vae
+        if not torch.is_tensor(x):
+            x = torch.as_tensor(x)
+        if not torch.is_tensor(y):
+            y = torch.as_tensor(y)
+        dev = torch.device('cuda', torch.cuda.current_device())
+        x = x.to(dev).float().contiguous()
+        y = y.to(dev).float().contiguous()
+        n = x.shape[0]
+        ops.fill(m.flat_grads, 0.0)
+        # ------------------------------------------------ forward ------------------------------------------------
+        xin = x
+        if enc.dropout_rate > 0:                                                      # encoder.py:39,71
+            if enc._mask is not None:
+                msk = (torch.as_tensor(enc._mask) != 0).to(torch.uint8).to(dev).contiguous()
+                enc._mask = None
+            else:
+                enc._seed += 1
+                msk = ops.dropout_mask(x.shape, enc.dropout_rate, enc._seed, dev)
+            xin = ops.dropout_apply(x, msk, enc.dropout_rate)
+        cpad = (x.shape[-1] + 15) // 16 * 16
+        cur = torch.zeros(tuple(x.shape[:4]) + (cpad,), dtype=tdt, device=dev)
+        cast(code, tdt, xin, out=cur[..., :x.shape[-1]])
+        del xin
+        levels = []                     # per encoder level: (slab, used, [block saves], down save or None)
+        for i, (convs, down) in enumerate(enc.levels):
+            d, h, w = cur.shape[1:4]
+            f = enc.base_filters * 2 ** i
+            nb = len(convs)
+            spare = f if i < enc.depth - 1 else 0
+            slab = torch.empty((n, d, h, w, nb * f + spare), dtype=tdt, device=dev)
+            saves = []
+            for j, blk in enumerate(convs):
+                out = slab[..., j * f:(j + 1) * f]
+                if j == 0:
+                    _, sv = self._block_fwd(blk, cur, out)
+                else:
+                    _, sv = self._block_fwd(blk, slab[..., :j * f], out, fold=((j - 1) * f, f))
+                saves.append(sv)
+            dsave = None
+            if down is not None:
+                cur, dsave = self._sampler_fwd(down, ops.K3S2, slab[..., :nb * f])
+            levels.append((slab, nb * f, saves, dsave))
+        top_slab, top_used = levels[-1][0], levels[-1][1]
+        top = top_slab[..., :top_used]
+        # decoder (decoder.py:65-83)
+        yk = top
+        dsaves = []
+        for k, (up, blk) in enumerate(dec.levels):
+            li = len(levels) - 2 - k
+            slab, cres = levels[li][0], levels[li][1]
+            f = up.filters
+            _, us = self._sampler_fwd(up, ops.K3S2T, yk, out=slab[..., cres:cres + f])
+            yk, bs = self._block_fwd(blk, slab[..., :cres + f], None)
+            dsaves.append((us, bs, li, cres, f))
+        y_last = yk
+        y_pred = head(code, y_last, dec.out_k.t.reshape(dec.out_k.t.shape[-2], dec.out_k.t.shape[-1]), dec.out_b.t, True)
+        # VAE branch (vae.py:114-143)
+        hdn, vds = self._sampler_fwd(vae.downsample, ops.K3S2, top)
+        flat = self._f32(hdn).reshape(n, -1)
+        proj = ops.dense_fwd(flat, vae.proj_k.t, vae.proj_b.t, False)
+        L = vae.latent_size
+        if vae._eps is not None:
+            eps = torch.as_tensor(vae._eps, dtype=torch.float32).to(dev).contiguous()
+            vae._eps = None
+        else:
+            vae._seed += 1
+            eps = ops.normal((n, L), vae._seed, dev)
+        z = ops.vae_sample_fwd(proj, eps)
+        u = ops.dense_fwd(z, vae.unproj_k.t, vae.unproj_b.t, True)
+        u5 = u.reshape((n,) + tuple(vae._unflat))
+        u16 = torch.zeros(tuple(u5.shape[:4]) + (16,), dtype=tdt, device=dev)     # 1 channel, zero-padded to a matrix step
+        cast(code, tdt, u5, out=u16[..., :1])
+        yv, vus = self._sampler_fwd(vae.upsample, ops.K3S2T, u16)
+        vsaves = []
+        for up, blk in vae.levels:
+            yv, us = self._sampler_fwd(up, ops.K3S2T, yv)
+            yv, bs = self._block_fwd(blk, yv, None)
+            vsaves.append((us, bs))
+        yv_last = yv
+        wp_vo = self._pk((id(vae), 'out'), ops.K3S1, vae.out_k, yv_last.shape[-1], vae.out_ch)
+        y_vae = self._f32(conv(ops.K3S1, code, tdt, yv_last, wp_vo, vae.out_b.t, vae.out_ch))
+        # ------------------------------------------------ loss, metric (fp32: util.py:13-24,35-57, train.py:145-148) -------------
+        c = y_pred.shape[-1]
+        sums = ops.loss_sums(y_pred, y, x, y_vae, proj)
+        parallel.all_reduce_sum(sums)
+        lt, _ = ops.loss_value(sums, c, True)
+        l2v = ops.l2_reg_fwd(m.flat_params, m._l2_ranges) if m._l2_ranges else None
+        loss_t = ops.scalar_lincomb(lt, l2v, 1.0, 1.0) if l2v is not None else lt
+        macro, micro = dice_fn(y, Tensor(y_pred, requires_grad=False))
+        self.last_labels = dice_fn.last_labels
+        # ------------------------------------------------ backward ------------------------------------------------
+        one = torch.ones(1, dtype=torch.float32, device=dev)
+        dyp = torch.empty_like(y_pred)
+        dyv = torch.empty_like(y_vae)
+        dproj = torch.empty_like(proj)
+        ops.loss_bwd(y_pred, y, x, y_vae, proj, sums, one, dyp, dyv, dproj, through_sigmoid=False)
+        # slab gradients (zero-initialised: every contribution accumulates)
+        gslabs = [torch.zeros_like(slab) for slab, _, _, _ in levels]
+        # decoder head (decoder.py:55-63): sigmoid, 1x1x1 conv to out_ch -- fp32 kernels (3 output channels)
+        dpre = ops.sigmoid_bwd(y_pred, dyp)
+        ylast32 = self._f32(y_last)
+        ops.conv_bwd_weight(ops.K1, ylast32, dpre, self._gslot(dec.out_k), self._gslot(dec.out_b), accumulate=True)
+        dlast32 = torch.empty_like(ylast32)
+        wpb = dec.packed('out_b', ops.K1, ops.ROLE_BWD, dec.out_k, y_last.shape[-1], dec.out_ch)
+        ops.conv_bwd_data(ops.K1, dpre, wpb, dlast32, False)
+        dcur = self._b16(dlast32)
+        del dlast32, ylast32, dpre
+        for idx in range(len(dsaves) - 1, -1, -1):
+            us, bs, li, cres, f = dsaves[idx]
+            gs = gslabs[li]
+            self._block_bwd(bs, dcur, gs[..., :cres + f])        # skip part [0, cres) and the up-sampled part [cres, cres + f)
+            if idx == 0:                                         # the first up layer read the top level's slab view
+                self._sampler_bwd(us, gs[..., cres:cres + f], gslabs[-1][..., :top_used], True)
+            else:                                                # the others read the previous decoder block's output
+                dcur = torch.empty(us['x'].shape, dtype=tdt, device=dev)
+                self._sampler_bwd(us, gs[..., cres:cres + f], dcur, False)
+        # VAE branch backward
+        ylv32 = self._f32(yv_last)
+        ops.conv_bwd_weight(ops.K3S1, ylv32, dyv, self._gslot(vae.out_k), self._gslot(vae.out_b), accumulate=True)
+        dv32 = torch.empty_like(ylv32)
+        wpb = vae.packed('out_b', ops.K3S1, ops.ROLE_BWD, vae.out_k, yv_last.shape[-1], vae.out_ch)
+        ops.conv_bwd_data(ops.K3S1, dyv, wpb, dv32, False)
+        dv = self._b16(dv32)
+        del dv32, ylv32
+        for us, bs in reversed(vsaves):
+            dblk_in = torch.zeros(bs['x'].shape, dtype=tdt, device=dev)
+            self._block_bwd(bs, dv, dblk_in)
+            dv = torch.empty(us['x'].shape, dtype=tdt, device=dev)
+            self._sampler_bwd(us, dblk_in, dv, False)
+        du16 = torch.zeros_like(u16)
+        self._sampler_bwd(vus, dv, du16, False, cin_live=1)
+        du5 = self._f32(du16[..., :1]).reshape(u.shape)
+        gz = ops.relu_bwd(u, du5)
+        dz = torch.empty_like(z)
+        ops.dense_bwd(z, vae.unproj_k.t, gz, dz, self._gslot(vae.unproj_k), self._gslot(vae.unproj_b), accumulate_dx=False,
+                      accumulate_params=True)
+        ops.vae_sample_bwd(proj, eps, dz, dproj)
+        dflat = torch.empty_like(flat)
+        ops.dense_bwd(flat, vae.proj_k.t, dproj, dflat, self._gslot(vae.proj_k), self._gslot(vae.proj_b), accumulate_dx=False,
+                      accumulate_params=True)
+        dhdn = self._b16(dflat.reshape(hdn.shape))
+        self._sampler_bwd(vds, dhdn, gslabs[-1][..., :top_used], True)
+        # encoder backward (encoder.py:69-101 in reverse)
+        for i in range(len(levels) - 1, -1, -1):
+            slab, used, saves, dsave = levels[i]
+            gs = gslabs[i]
+            f = enc.base_filters * 2 ** i
+            for j in range(len(saves) - 1, -1, -1):
+                dout = gs[..., j * f:(j + 1) * f]
+                if j > 0:
+                    self._block_bwd(saves[j], dout, gs[..., :j * f])
+                elif i > 0:
+                    dprev = torch.zeros(saves[0]['x'].shape, dtype=tdt, device=dev)
+                    self._block_bwd(saves[0], dout, dprev)
+                    pslab, pused, _, pds = levels[i - 1]
+                    self._sampler_bwd(pds, dprev, gslabs[i - 1][..., :pused], True)
+                else:
+                    self._block_bwd(saves[0], dout, None)
+        # regulariser (train.py:146), exchange, optimiser (train.py:151-152)
+        if l2v is not None:
+            k = parallel.l2_grad_scale()
+            ops.l2_reg_bwd(m.flat_params, m.flat_grads, [(o, ln, cf * k) for o, ln, cf in m._l2_ranges], one)
+        scale = parallel.all_reduce_gradients(m)
+        grads = [p._gview for p in m.trainable_variables]
+        optimizer.apply_gradients(zip(grads, m.trainable_variables), model=m, grad_scale=scale)
+        return Tensor(loss_t, requires_grad=False), macro, micro
