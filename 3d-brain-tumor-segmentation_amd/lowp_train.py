@@ -59,6 +59,19 @@ class LowPrecisionTrainer(object):
         return buf
 
     @staticmethod
+    def _wg(tensors, fn):
+        """weight-gradient launches go to the side stream (ops.side_stream('wgrad'), as in the fp32 step): nothing in the backward
+        pass reads a parameter gradient; `tensors` are the temporaries the launches read (the main stream frees them)"""
+        side = ops.side_stream('wgrad')
+        if side is None:
+            return fn()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        for t in tensors:
+            t.record_stream(side)
+
+    @staticmethod
     def _gslot(p):
         """fp32 gradient view of a parameter inside the model's flat gradient buffer (zeroed at the start of the step)"""
         return p._gview
@@ -107,8 +120,8 @@ class LowPrecisionTrainer(object):
         dc2 = ops.gn_bwd(self._f32(s['c2']), dout32, n2.gamma.t, n2.beta.t, s['m2'], s['r2'], self._gslot(n2.gamma), self._gslot(n2.beta),
                          g, n2._mode, True, accumulate_params=True)
         a32 = self._f32(s['a'])
-        ops.conv_bwd_weight(ops.K3S1, a32, dc2, self._gslot(blk.conv2_k), self._gslot(blk.conv2_b), accumulate=True)
-        del a32
+        self._wg((a32, dc2), lambda: ops.conv_bwd_weight(ops.K3S1, a32, dc2, self._gslot(blk.conv2_k), self._gslot(blk.conv2_b),
+                                                         accumulate=True))
         da = torch.empty_like(s['a'])
         conv_bwd_data(ops.K3S1, code, self._b16(dc2), self._pk((key, 'c2b'), ops.K3S1, blk.conv2_k, f, f, role=ops.ROLE_BWD), da, False)
         del dc2
@@ -124,9 +137,11 @@ class LowPrecisionTrainer(object):
         x = s['x']
         cin_slab = s['cin_slab']
         x32 = self._f32(x[..., :cin_slab])
-        ops.conv_bwd_weight(ops.K3S1, x32, dc1, self._gslot(blk.conv1_k), self._gslot(blk.conv1_b), dup_start, dup_shift, accumulate=True)
-        ops.conv_bwd_weight(ops.K1, x32, dres, self._gslot(blk.ptwise_k), self._gslot(blk.ptwise_b), dup_start, dup_shift, accumulate=True)
-        del x32
+
+        def wgrads():
+            ops.conv_bwd_weight(ops.K3S1, x32, dc1, self._gslot(blk.conv1_k), self._gslot(blk.conv1_b), dup_start, dup_shift, accumulate=True)
+            ops.conv_bwd_weight(ops.K1, x32, dres, self._gslot(blk.ptwise_k), self._gslot(blk.ptwise_b), dup_start, dup_shift, accumulate=True)
+        self._wg((x32, dc1, dres), wgrads)
         if dx is not None:
             cin = x.shape[-1]
             wpb1 = self._pk((key, 'c1b'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin, dup_start, dup_shift, role=ops.ROLE_BWD)
@@ -150,12 +165,14 @@ class LowPrecisionTrainer(object):
                         self._gslot(nrm.beta), nrm.groups, nrm._mode, True, accumulate_params=True)
         x = s['x'] if cin_live is None else s['x'][..., :cin_live]
         x32 = self._f32(x)
-        if kind == ops.K3S2T:
-            ops.conv_bwd_weight(kind, x32, dc, self._gslot(lay.conv_k), None, accumulate=True)
-            ops.colsum(dc, sum_over_n=True, out=self._gslot(lay.conv_b), accumulate=True)
-        else:
-            ops.conv_bwd_weight(kind, x32, dc, self._gslot(lay.conv_k), self._gslot(lay.conv_b), accumulate=True)
-        del x32
+
+        def wgrads():
+            if kind == ops.K3S2T:
+                ops.conv_bwd_weight(kind, x32, dc, self._gslot(lay.conv_k), None, accumulate=True)
+                ops.colsum(dc, sum_over_n=True, out=self._gslot(lay.conv_b), accumulate=True)
+            else:
+                ops.conv_bwd_weight(kind, x32, dc, self._gslot(lay.conv_k), self._gslot(lay.conv_b), accumulate=True)
+        self._wg((x32, dc), wgrads)
         if dx is not None:
             wpb = self._pk((id(lay), 'b'), kind, lay.conv_k, lay.cin, lay.filters, role=ops.ROLE_BWD)
             conv_bwd_data(kind, self.code, self._b16_k(dc), wpb, dx, accumulate)
@@ -269,7 +286,8 @@ class LowPrecisionTrainer(object):
         # decoder head (decoder.py:55-63): sigmoid, 1x1x1 conv to out_ch -- fp32 kernels (3 output channels)
         dpre = ops.sigmoid_bwd(y_pred, dyp)
         ylast32 = self._f32(y_last)
-        ops.conv_bwd_weight(ops.K1, ylast32, dpre, self._gslot(dec.out_k), self._gslot(dec.out_b), accumulate=True)
+        self._wg((ylast32, dpre), lambda: ops.conv_bwd_weight(ops.K1, ylast32, dpre, self._gslot(dec.out_k), self._gslot(dec.out_b),
+                                                             accumulate=True))
         dlast32 = torch.empty_like(ylast32)
         wpb = dec.packed('out_b', ops.K1, ops.ROLE_BWD, dec.out_k, y_last.shape[-1], dec.out_ch)
         ops.conv_bwd_data(ops.K1, dpre, wpb, dlast32, False)
@@ -286,7 +304,8 @@ class LowPrecisionTrainer(object):
                 self._sampler_bwd(us, gs[..., cres:cres + f], dcur, False)
         # VAE branch backward
         ylv32 = self._f32(yv_last)
-        ops.conv_bwd_weight(ops.K3S1, ylv32, dyv, self._gslot(vae.out_k), self._gslot(vae.out_b), accumulate=True)
+        self._wg((ylv32, dyv), lambda: ops.conv_bwd_weight(ops.K3S1, ylv32, dyv, self._gslot(vae.out_k), self._gslot(vae.out_b),
+                                                           accumulate=True))
         dv32 = torch.empty_like(ylv32)
         wpb = vae.packed('out_b', ops.K3S1, ops.ROLE_BWD, vae.out_k, yv_last.shape[-1], vae.out_ch)
         ops.conv_bwd_data(ops.K3S1, dyv, wpb, dv32, False)
@@ -327,6 +346,7 @@ class LowPrecisionTrainer(object):
                 else:
                     self._block_bwd(saves[0], dout, None)
         # regulariser (train.py:146), exchange, optimiser (train.py:151-152)
+        ops.join_side_stream()
         if l2v is not None:
             k = parallel.l2_grad_scale()
             ops.l2_reg_bwd(m.flat_params, m.flat_grads, [(o, ln, cf * k) for o, ln, cf in m._l2_ranges], one)

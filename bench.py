@@ -333,6 +333,12 @@ def main():
     opt = ScheduledOptim(1e-4)
     opt(epoch=0)
     loss_fn, dice_fn = DiceVAELoss(), DiceCoefficient()
+    tdt = {None: 'f32', 'f32': 'f32', 'fp32': 'f32', 'float32': 'f32', 'bf16': 'bf16', 'bfloat16': 'bf16', 'f16': 'f16', 'fp16': 'f16',
+           'float16': 'f16'}[args.dtype]
+    if tdt != 'f32':      # BASELINE configs[2]: 16-bit storage, fp32 sums / master weights (bts_amd.lowp_train); its own line, never the headline
+        from bts_amd.lowp_train import LowPrecisionTrainer
+        trainer = LowPrecisionTrainer(model, {'bf16': 'bfloat16', 'f16': 'float16'}[tdt])
+        train_step = lambda model_, opt_, loss_fn_, dice_fn_, x_, y_: trainer.step(opt_, dice_fn_, x_, y_)   # noqa: E731
 
     if args.serial_streams:
         ops.enable_side_streams(False)
@@ -395,10 +401,14 @@ def main():
         'metric': 'training volumes/sec (2ch x %d^3)' % args.crop, 'value': volumes / dt, 'unit': 'volumes/s',
         'n_gpus': n_gpus, 'ranks_seen': ranks_seen, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * dt / args.steps,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'BASELINE configs[1]: 2ch x %d^3, batch %d per GPU, fp32, full fwd+bwd with '
-                               'Dice+KL+L2 VAE loss + Dice metric + TF-form Adam; CLI-default model '
-                               '(base_filters=32, depth=4, groups=8, reduction=8; 42,174,773 params)' % (args.crop, nb),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': tdt, 'data': 'synthetic',
+        'config': {'workload': ('BASELINE configs[1]: 2ch x %d^3, batch %d per GPU, fp32, full fwd+bwd with '
+                                'Dice+KL+L2 VAE loss + Dice metric + TF-form Adam; CLI-default model '
+                                '(base_filters=32, depth=4, groups=8, reduction=8; 42,174,773 params)' % (args.crop, nb)) if tdt == 'f32' else
+                               ('BASELINE configs[2] (when batch = 8, bf16): 2ch x %d^3, batch %d per GPU, %s STORAGE of activations / their '
+                                'gradients / weight images, fp32 sums, fp32 master weights and Adam; full train step; forward and data '
+                                'gradients on the 16-bit kernels, weight / GroupNorm / gate gradients on the fp32 kernels over widened '
+                                'operands; CLI-default model' % (args.crop, nb, tdt)),
                    'parallelism': 'dp%d' % world, 'global_batch': world * nb},
         'loss': loss_v, 'macro_dice': macro_v,
         'streams': 'serial (one HIP stream)' if args.serial_streams else 'main + weight-gradient + gate streams',
