@@ -1052,3 +1052,191 @@ extern "C" int bts_lp_head(int dtype, const void* x, const float* w, const float
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
+
+// =====================================================================================================================
+// GroupNormalization backward on 16-bit tensors (channels_last = slab semantics; group_norm.py:83-124 under TF autodiff).
+// With xh = (x - mean) * rstd, y = gamma_i xh + beta_i (i = g*cg + c mod cg), dyE = dy * [y > 0] (fused ReLU):
+//   A_j = sum dyE * xh, B_j = sum dyE per (n, g, j = c mod cg)   ->  dgamma_i (+)= sum_n A_j, dbeta_i (+)= sum_n B_j
+//   c1 = sum_j gamma_j B_j / L,  c2 = sum_j gamma_j A_j / L       ->  dx = (dyE gamma_i - c1 - xh c2) * rstd
+// Sums in fp32 runs flushed to fp64, fixed order; dx is written in the storage type (for the data-gradient convs) AND, when
+// asked, in fp32 (the weight-gradient kernels still run on the fp32 matrix pipe): one pass instead of three.
+// =====================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void lp_gn_bwd_reduce_kernel(const unsigned short* x, const unsigned short* dy, const float* gamma,
+                                                               const float* beta, const float* mean, const float* rstd, double* partial,
+                                                               long E, long L, long span, int C, int G, int cg, int lddy, int relu) {
+  __shared__ double sh[4 * 4 * 16];
+  const int unit = blockIdx.y, n = unit / G, g = unit % G;
+  const long lo = (long)blockIdx.x * span;
+  long hi = lo + span;
+  if (hi > L) hi = L;
+  const long ubase = (long)g * L;
+  const int cph = (int)((ubase + lo + threadIdx.x * 8L) % C);   // constant over the loop: the stride 2048 is a multiple of C
+  float gam[8], bet[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { const int idx = g * cg + ((cph + e) % cg); gam[e] = gamma[idx]; bet[e] = beta[idx]; }
+  const float m = mean[unit], rs = rstd[unit];
+  double a[8], b[8];
+  float fa[8], fb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] = b[e] = 0.0; fa[e] = fb[e] = 0.f; }
+  const unsigned short* xb = x + (long)n * E + ubase;
+  int cnt = 0;
+  for (long i = lo + threadIdx.x * 8L; i < hi; i += 2048) {
+    float v[8], d[8];
+    unpack8<T>(*reinterpret_cast<const u32x4*>(xb + i), v);
+    const long gi = (long)n * E + ubase + i;          // global element index -> voxel, channel of the (possibly strided) dy
+    const long pix = gi / C;
+    unpack8<T>(*reinterpret_cast<const u32x4*>(dy + pix * lddy + (gi - pix * C)), d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = (v[e] - m) * rs;
+      float de = d[e];
+      if (relu && !(xh * gam[e] + bet[e] > 0.f)) de = 0.f;
+      fa[e] = fmaf(de, xh, fa[e]);
+      fb[e] += de;
+    }
+    if (++cnt == 32) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a[e] += fa[e]; b[e] += fb[e]; fa[e] = fb[e] = 0.f; }
+      cnt = 0;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] += fa[e]; b[e] += fb[e]; }
+  // lanes whose 8 channels fall on the same classes: every p-th lane, p = cg / 8 (1 when cg <= 8)
+  const int p = cg > 8 ? cg / 8 : 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int off = 32; off >= p; off >>= 1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] += __shfl_xor(a[e], off, 64); b[e] += __shfl_xor(b[e], off, 64); }
+  }
+  if (lane < p) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sh[((wave * 4 + lane) * 8 + e) * 2] = a[e]; sh[((wave * 4 + lane) * 8 + e) * 2 + 1] = b[e]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < cg) {
+    const int j = threadIdx.x;
+    const int cph0 = (int)((ubase + lo) % C);          // lane q of any wave has channel phase cph0 + 8q (+ wave * 512: a multiple of C)
+    double sa = 0.0, sb = 0.0;
+    for (int w = 0; w < 4; ++w)
+      for (int q = 0; q < p; ++q)
+        for (int e = 0; e < 8; ++e)
+          if (((cph0 + 8 * q + e) % cg) == j) { sa += sh[((w * 4 + q) * 8 + e) * 2]; sb += sh[((w * 4 + q) * 8 + e) * 2 + 1]; }
+    double* o = partial + (((long)unit * gridDim.x + blockIdx.x) * cg + j) * 2;
+    o[0] = sa; o[1] = sb;
+  }
+}
+// one block per group g: for every sample the class sums over the blocks -> c1, c2; the sums over the samples -> dgamma, dbeta
+__global__ __launch_bounds__(256) void lp_gn_bwd_finalize_kernel(const double* partial, const float* gamma, float* dgamma, float* dbeta, float* c1,
+                                                                 float* c2, int N, int G, int B, int cg, double L, int accum) {
+  __shared__ double sh[256 * 2];
+  const int g = blockIdx.x;
+  const int j = threadIdx.x % cg, sl = threadIdx.x / cg, S = 256 / cg;
+  double ga = 0.0, gb = 0.0;     // running dgamma / dbeta of class j (slice 0 holds the result)
+  for (int n = 0; n < N; ++n) {
+    const long unit = (long)n * G + g;
+    double sa = 0.0, sb = 0.0;
+    for (int b = sl; b < B; b += S) {
+      const double* o = partial + ((unit * B + b) * cg + j) * 2;
+      sa += o[0]; sb += o[1];
+    }
+    __syncthreads();
+    sh[threadIdx.x * 2] = sa; sh[threadIdx.x * 2 + 1] = sb;
+    __syncthreads();
+    if (sl == 0) {
+      sa = 0.0; sb = 0.0;
+      for (int s2 = 0; s2 < S; ++s2) { sa += sh[(s2 * cg + j) * 2]; sb += sh[(s2 * cg + j) * 2 + 1]; }
+      ga += sa; gb += sb;
+      sh[j * 2] = (double)gamma[g * cg + j] * sb;       // -> c1
+      sh[j * 2 + 1] = (double)gamma[g * cg + j] * sa;   // -> c2
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int q = 0; q < cg; ++q) { s1 += sh[q * 2]; s2 += sh[q * 2 + 1]; }
+      c1[unit] = (float)(s1 / L);
+      c2[unit] = (float)(s2 / L);
+    }
+  }
+  if (sl == 0) {
+    const int idx = g * cg + j;
+    dgamma[idx] = accum ? dgamma[idx] + (float)ga : (float)ga;
+    dbeta[idx] = accum ? dbeta[idx] + (float)gb : (float)gb;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void lp_gn_bwd_apply_kernel(const unsigned short* x, const unsigned short* dy, unsigned short* dx, float* dx32,
+                                                              const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                                              const float* c1, const float* c2, long total8, long E, long L, int C, int G,
+                                                              int cg, int lddy, int relu) {
+  for (long f = blockIdx.x * 256L + threadIdx.x; f < total8; f += (long)gridDim.x * 256) {
+    const long i = f * 8;
+    const long n = i / E;
+    const long r = i - n * E;
+    const int c = (int)(r % C);
+    const long pix = i / C;
+    const int g = (int)(r / L);
+    const long unit = n * G + g;
+    float v[8], d[8], o[8];
+    unpack8<T>(*reinterpret_cast<const u32x4*>(x + i), v);
+    unpack8<T>(*reinterpret_cast<const u32x4*>(dy + pix * lddy + c), d);
+    const float m = mean[unit], rs = rstd[unit], k1 = c1[unit], k2 = c2[unit];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int idx = g * cg + ((c + e) % cg);
+      const float xh = (v[e] - m) * rs;
+      float de = d[e];
+      const float ga = gamma[idx];
+      if (relu && !(xh * ga + beta[idx] > 0.f)) de = 0.f;
+      o[e] = (de * ga - k1 - xh * k2) * rs;
+    }
+    *reinterpret_cast<u32x4*>(dx + i) = pack8<T>(o);
+    if (dx32 != nullptr) {
+      *reinterpret_cast<f32x4*>(dx32 + i) = f32x4{o[0], o[1], o[2], o[3]};
+      *reinterpret_cast<f32x4*>(dx32 + i + 4) = f32x4{o[4], o[5], o[6], o[7]};
+    }
+  }
+}
+static int lp_gnb_blocks(long L) {
+  long b = L / (2048 * 16);
+  if (b < 1) b = 1;
+  if (b > 256) b = 256;
+  return (int)b;
+}
+extern "C" long bts_lp_gn_bwd_workspace(int N, long V, int C, int G) {
+  if (N <= 0 || V <= 0 || C <= 0 || G <= 0 || C % G != 0) return -1;
+  const long L = V * C / G;
+  return (long)N * G * lp_gnb_blocks(L) * (C / G) * 2 * 8 + (long)N * G * 2 * 4 + 64;
+}
+// x dense (N,V,C) in the storage type; dy rows of stride lddy; dx dense in the storage type, dx32 (may be NULL) the same values in fp32
+extern "C" int bts_lp_gn_bwd(int dtype, const void* x, const void* dy, void* dx, float* dx32, const float* gamma, const float* beta,
+                             const float* mean, const float* rstd, float* dgamma, float* dbeta, void* workspace, long workspace_bytes, int N,
+                             long V, int C, int lddy, int G, int relu, int accumulate_params, hipStream_t stream) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  if (N <= 0 || V <= 0 || C < G || C % G != 0 || C % 8 != 0 || C > 256 || (C & (C - 1)) != 0 || lddy % 8 != 0 || lddy < C) return BTS_ERR_SHAPE;
+  const long E = V * C, L = E / G;
+  const int cg = C / G;
+  if (E % G != 0 || L % 2048 != 0 || cg > 32 || 256 % cg != 0) return BTS_ERR_UNSUPPORTED;   // (the caller falls back to the fp32 kernels)
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)dy) & 15) || (((uintptr_t)dx) & 15) || (dx32 && (((uintptr_t)dx32) & 15))) return BTS_ERR_ALIGN;
+  if (workspace_bytes < bts_lp_gn_bwd_workspace(N, V, C, G)) return BTS_ERR_WORKSPACE;
+  const int B = lp_gnb_blocks(L);
+  const long span = ((L / 2048 + B - 1) / B) * 2048;
+  double* partial = reinterpret_cast<double*>(workspace);
+  float* c1 = reinterpret_cast<float*>(partial + (long)N * G * B * cg * 2);
+  float* c2 = c1 + (long)N * G;
+  (void)hipGetLastError();
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_gn_bwd_reduce_kernel<TF16>, dim3(B, N * G), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)dy, gamma, beta, mean, rstd, partial, E, L, span, C, G, cg, lddy, relu);
+  else hipLaunchKernelGGL(lp_gn_bwd_reduce_kernel<TBF16>, dim3(B, N * G), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)dy, gamma, beta, mean, rstd, partial, E, L, span, C, G, cg, lddy, relu);
+  BTS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(lp_gn_bwd_finalize_kernel, dim3(G), dim3(256), 0, stream, partial, gamma, dgamma, dbeta, c1, c2, N, G, B, cg, (double)L, accumulate_params);
+  BTS_LAUNCH_CHECK();
+  const long total8 = (long)N * E / 8;
+  long blocks = (total8 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_gn_bwd_apply_kernel<TF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)dy, (unsigned short*)dx, dx32, gamma, beta, mean, rstd, c1, c2, total8, E, L, C, G, cg, lddy, relu);
+  else hipLaunchKernelGGL(lp_gn_bwd_apply_kernel<TBF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)dy, (unsigned short*)dx, dx32, gamma, beta, mean, rstd, c1, c2, total8, E, L, C, G, cg, lddy, relu);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}

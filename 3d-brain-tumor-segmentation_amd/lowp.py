@@ -118,6 +118,23 @@ def gn_apply(code, x, gamma, beta, mean, rstd, groups, mode, relu, out=None):
     return out
 
 
+def gn_bwd(code, tdt, x, dy, gamma, beta, mean, rstd, dgamma, dbeta, groups, relu, want_f32=True):
+    """slab-mode GroupNorm backward on 16-bit tensors -> (dx in the storage type, dx in fp32 or None); None if the shape is outside the
+    kernel's tiling (the caller then runs the fp32 kernel on widened copies)"""
+    n, c = x.shape[0], x.shape[4]
+    v = x.shape[1] * x.shape[2] * x.shape[3]
+    L = v * c // groups
+    if (v * c) % groups or L % 2048 or c // groups > 32 or 256 % (c // groups) or c > 256 or c & (c - 1):
+        return None
+    nb = lib().query('bts_lp_gn_bwd_workspace', n, v, c, groups)
+    ws = ops.workspace(nb, x.device)
+    dx = torch.empty_like(x)
+    dx32 = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_f32 else None
+    lib().call('bts_lp_gn_bwd', code, _p(x), _p(dy), _p(dx), _p(dx32) if dx32 is not None else None, _p(gamma), _p(beta), _p(mean), _p(rstd),
+               _p(dgamma), _p(dbeta), _p(ws), nb, n, v, c, _ld(dy), groups, 1 if relu else 0, 1, _stream())
+    return dx, dx32
+
+
 def colsum(code, x, scale):
     n, c = x.shape[0], x.shape[4]
     v = x.shape[1] * x.shape[2] * x.shape[3]

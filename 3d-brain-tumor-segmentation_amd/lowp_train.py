@@ -58,6 +58,21 @@ class LowPrecisionTrainer(object):
         cast(self.code, self.tdt, t, out=buf[..., :c])
         return buf
 
+    def _gn_bwd(self, norm, c, dy, mean, rstd):
+        """GroupNorm (+ReLU) backward -> (dc in the storage type with channels padded to a matrix step, dc in fp32); parameter
+        gradients accumulate.  16-bit kernel where its tiling fits, else the fp32 kernel on widened copies"""
+        r = None
+        if norm._mode == ops.GN_SLAB:
+            r = lowp.gn_bwd(self.code, self.tdt, c, dy, norm.gamma.t, norm.beta.t, mean, rstd, self._gslot(norm.gamma), self._gslot(norm.beta),
+                            norm.groups, True)
+        if r is not None and r[0].shape[-1] % 16 == 0:
+            return r
+        if r is not None:
+            return self._b16_k(r[1]), r[1]
+        dc = ops.gn_bwd(self._f32(c), self._f32(dy), norm.gamma.t, norm.beta.t, mean, rstd, self._gslot(norm.gamma), self._gslot(norm.beta),
+                        norm.groups, norm._mode, True, accumulate_params=True)
+        return self._b16_k(dc), dc
+
     @staticmethod
     def _wg(tensors, fn):
         """weight-gradient launches go to the side stream (ops.side_stream('wgrad'), as in the fp32 step): nothing in the backward
@@ -117,16 +132,14 @@ class LowPrecisionTrainer(object):
         key = id(blk)
         dout32 = self._f32(dout)
         # conv branch: GN2 (+ReLU) -> conv2 -> GN1 (+ReLU) -> conv1
-        dc2 = ops.gn_bwd(self._f32(s['c2']), dout32, n2.gamma.t, n2.beta.t, s['m2'], s['r2'], self._gslot(n2.gamma), self._gslot(n2.beta),
-                         g, n2._mode, True, accumulate_params=True)
+        dc2_16, dc2 = self._gn_bwd(n2, s['c2'], dout, s['m2'], s['r2'])
         a32 = self._f32(s['a'])
         self._wg((a32, dc2), lambda: ops.conv_bwd_weight(ops.K3S1, a32, dc2, self._gslot(blk.conv2_k), self._gslot(blk.conv2_b),
                                                          accumulate=True))
         da = torch.empty_like(s['a'])
-        conv_bwd_data(ops.K3S1, code, self._b16(dc2), self._pk((key, 'c2b'), ops.K3S1, blk.conv2_k, f, f, role=ops.ROLE_BWD), da, False)
-        del dc2
-        dc1 = ops.gn_bwd(self._f32(s['c1']), self._f32(da), n1.gamma.t, n1.beta.t, s['m1'], s['r1'], self._gslot(n1.gamma),
-                         self._gslot(n1.beta), g, n1._mode, True, accumulate_params=True)
+        conv_bwd_data(ops.K3S1, code, dc2_16, self._pk((key, 'c2b'), ops.K3S1, blk.conv2_k, f, f, role=ops.ROLE_BWD), da, False)
+        del dc2, dc2_16
+        dc1_16, dc1 = self._gn_bwd(n1, s['c1'], da, s['m1'], s['r1'])
         del da
         # gate branch
         dres = ops.se_bwd(dout32, self._f32(s['res']), s['sp'], s['gap'], s['hbuf'], s['ch'], blk.se_w1.t, blk.se_w2.t,
@@ -146,7 +159,7 @@ class LowPrecisionTrainer(object):
             cin = x.shape[-1]
             wpb1 = self._pk((key, 'c1b'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin, dup_start, dup_shift, role=ops.ROLE_BWD)
             wpbp = self._pk((key, 'ptb'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin, dup_start, dup_shift, role=ops.ROLE_BWD)
-            conv_bwd_data(ops.K3S1, code, self._b16(dc1), wpb1, dx, True)
+            conv_bwd_data(ops.K3S1, code, dc1_16, wpb1, dx, True)
             conv_bwd_data(ops.K1, code, self._b16(dres), wpbp, dx, True)
 
     def _sampler_fwd(self, lay, kind, x, out=None):
@@ -161,8 +174,7 @@ class LowPrecisionTrainer(object):
         data gradient into dx (None: not needed).  cin_live: real input channels when the input was zero-padded to 16"""
         lay, kind = s['lay'], s['kind']
         nrm = lay.norm
-        dc = ops.gn_bwd(self._f32(s['c']), self._f32(dy), nrm.gamma.t, nrm.beta.t, s['m'], s['r'], self._gslot(nrm.gamma),
-                        self._gslot(nrm.beta), nrm.groups, nrm._mode, True, accumulate_params=True)
+        dc16, dc = self._gn_bwd(nrm, s['c'], dy, s['m'], s['r'])
         x = s['x'] if cin_live is None else s['x'][..., :cin_live]
         x32 = self._f32(x)
 
@@ -175,7 +187,7 @@ class LowPrecisionTrainer(object):
         self._wg((x32, dc), wgrads)
         if dx is not None:
             wpb = self._pk((id(lay), 'b'), kind, lay.conv_k, lay.cin, lay.filters, role=ops.ROLE_BWD)
-            conv_bwd_data(kind, self.code, self._b16_k(dc), wpb, dx, accumulate)
+            conv_bwd_data(kind, self.code, dc16, wpb, dx, accumulate)
 
     # ================================================================================================================
     # the step

@@ -260,6 +260,13 @@ int bts_lp_gn_stats(int dtype, const void* x, float* mean, float* rstd, void* wo
                     int mode, float eps, bts_stream_t stream);
 int bts_lp_gn_apply(int dtype, const void* x, void* y, const float* gamma, const float* beta, const float* mean, const float* rstd, int N,
                     long V, int C, int ldy, int G, int mode, int relu, bts_stream_t stream);
+/* GroupNormalization backward (slab semantics; fused ReLU mask when relu != 0): dx in the storage type and, when dx32 != NULL, the same
+ * values in fp32 (the weight gradients still run on the fp32 matrix pipe); dgamma / dbeta fp32 (+= when accumulate_params).
+ * BTS_ERR_UNSUPPORTED for shapes outside its tiling (group length not a multiple of 2048, C/G > 32): run bts_gn_bwd on widened copies */
+long bts_lp_gn_bwd_workspace(int N, long V, int C, int G);
+int bts_lp_gn_bwd(int dtype, const void* x, const void* dy, void* dx, float* dx32, const float* gamma, const float* beta, const float* mean,
+                  const float* rstd, float* dgamma, float* dbeta, void* workspace, long workspace_bytes, int N, long V, int C, int lddy, int G,
+                  int relu, int accumulate_params, bts_stream_t stream);
 /* GlobalAveragePooling3D of the shortcut (resnet.py:45-46,121): out[n][c] = scale * sum_v x */
 long bts_lp_colsum_workspace(int N, long V, int C);
 int bts_lp_colsum(int dtype, const void* x, float* out, void* workspace, long workspace_bytes, int N, long V, int C, float scale,

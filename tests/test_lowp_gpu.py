@@ -294,3 +294,35 @@ def test_conv_data_gradient_kernels(case, accumulate, dtype):
     worst = float((err / bound).max())
     assert worst <= 1.0, '%s %s: error %.3e is %.2fx the stated bound' % (name, dtype, float(err.max()), worst)
     assert bool((slab[..., :8] == 5.0).all()) and bool((slab[..., 8 + cin:] == 5.0).all())
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('shape', [(2, 8, 16, 16, 32), (1, 16, 16, 16, 64), (2, 8, 8, 16, 256)])
+def test_groupnorm_backward_kernel(shape, dtype):
+    """16-bit GroupNorm(+ReLU) backward against the fp32 engine's kernel (itself pinned to the oracle by tests/test_kernels_gpu.py) on
+    the same rounded x / dy: dx in both precisions, dgamma / dbeta; dy arrives as a channel slice of a wider slab"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    code, tdt = lowp.DTYPES[dtype]
+    n, d, h, w, c = shape
+    G = 8
+    g = torch.Generator().manual_seed(c)
+    x = (torch.randn(shape, generator=g) * 1.5 + 0.3).to(tdt).to(DEV)
+    dyslab = torch.randn((n, d, h, w, c + 16), generator=g).to(tdt).to(DEV)
+    dy = dyslab[..., 8:8 + c]
+    gamma = (1 + 0.3 * torch.randn(c, generator=g)).to(DEV)
+    beta = (0.2 * torch.randn(c, generator=g)).to(DEV)
+    mean, rstd = lowp.gn_stats(code, x, G, ops.GN_SLAB, 1e-5)
+    x32, dy32 = lowp.uncast(code, x), lowp.uncast(code, dy)
+    dg_r, db_r = torch.full((c,), 0.5, device=DEV), torch.full((c,), -0.25, device=DEV)
+    dx_r = ops.gn_bwd(x32, dy32, gamma, beta, mean, rstd, dg_r, db_r, G, ops.GN_SLAB, True, accumulate_params=True)
+    dg, db = torch.full((c,), 0.5, device=DEV), torch.full((c,), -0.25, device=DEV)
+    out = lowp.gn_bwd(code, tdt, x, dy, gamma, beta, mean, rstd, dg, db, G, True)
+    assert out is not None
+    dx16, dx32 = out
+    torch.cuda.synchronize()
+    scale = float(dx_r.abs().max())
+    assert float((dx32 - dx_r).abs().max()) <= 2e-5 * scale + 1e-6
+    assert float((dx16.float() - dx_r).abs().max()) <= U[dtype] * scale * 1.01 + 2e-5 * scale
+    for a, b in ((dg, dg_r), (db, db_r)):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-5
