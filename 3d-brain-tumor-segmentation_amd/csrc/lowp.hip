@@ -1240,3 +1240,283 @@ extern "C" int bts_lp_gn_bwd(int dtype, const void* x, const void* dy, void* dx,
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
+
+// =====================================================================================================================
+// Weight gradient of the stride-1 3x3x3 and 1x1x1 convolutions on 16-bit operands (what TF autodiff derives for the Conv3D
+// kernels of resnet.py:30-37,80-87,96-103; train.py:151):  dW[t][c][k] = sum_v P[v + off_t][c] * Q[v][k],  P = the conv's input,
+// Q = the gradient of its output.  The contraction runs over VOXELS, so both matrix operands want 8 consecutive voxels of one
+// channel per lane (v_mfma_f32_32x32x16: A row = input channel, B column = output channel, K = 16 voxels along x) while memory is
+// channel-fastest: the (halo) tiles are staged voxel-major in LDS as they come and every fragment is gathered with eight
+// 2-byte LDS reads -- taps, which shift the 8-voxel window by single voxels, cost nothing extra that way.  A Q fragment serves all
+// of a wave's taps, a P fragment all of its cout blocks.  8 waves: the 27 taps are dealt round-robin (1x1x1: the 32 x-rows of the
+// tile are), persistent workgroups accumulate over their tiles and leave fp32 partials for a fixed-order finalize that also folds
+// the encoder's duplicated slice back onto both copies of the weight (encoder.py:83-87) and adds into the gradient buffer.
+// =====================================================================================================================
+struct LpWgParams {
+  const unsigned short* p;
+  const unsigned short* q;
+  float* part;
+  int N, D, H, W, Cp, ldp, Cq, ldq, ntaps;
+  int ntx, nty, ntz;
+  long ntiles;
+  int ncp, ncqg;
+};
+#define LPW_TX 16
+#define LPW_TY 8
+#define LPW_TZ 4
+
+template <typename T, int NQ>
+__global__ __launch_bounds__(512, 1) void lp_wgrad_kernel(const LpWgParams p) {
+  constexpr int TX = LPW_TX, TY = LPW_TY, TZ = LPW_TZ;
+  constexpr int PS = 36, QS = 32 * NQ + 4;          // halves per staged voxel (8-byte aligned rows, bank-skewed)
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l32 = lane & 31;
+  const bool k3 = p.ntaps == 27;
+  const int halo = k3 ? 1 : 0;
+  const int SX = TX + 2 * halo, SY = TY + 2 * halo, SZ = TZ + 2 * halo;
+  const int nvp = SX * SY * SZ;
+  unsigned short* ldsP = lds;
+  unsigned short* ldsQ = lds + (TX + 2) * (TY + 2) * (TZ + 2) * PS;
+  const int cpt = blockIdx.y / p.ncqg, cqg = blockIdx.y % p.ncqg;
+  const int cp0 = cpt * 32, cq0 = cqg * 32 * NQ;
+  constexpr int PSLOT = ((TX + 2) * (TY + 2) * (TZ + 2) * 4 + 511) / 512;   // 16-byte chunks of the P tile per thread
+  constexpr int QSLOT = (TX * TY * TZ * 4 * NQ + 511) / 512;
+  u32x4 preP[PSLOT], preQ[QSLOT];
+  f32x16 acc[4][NQ];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int c = 0; c < NQ; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
+
+  auto fetch = [&](long tile) {
+    long b = tile;
+    const int tx = (int)(b % p.ntx); b /= p.ntx;
+    const int ty = (int)(b % p.nty); b /= p.nty;
+    const int tz = (int)(b % p.ntz);
+    const int n = (int)(b / p.ntz);
+    const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
+#pragma unroll
+    for (int i = 0; i < PSLOT; ++i) {
+      const int e = tid + i * 512;
+      preP[i] = u32x4{0u, 0u, 0u, 0u};
+      if (e < nvp * 4) {
+        const int vox = e >> 2, cq = e & 3;
+        const int vz = vox / (SY * SX), r = vox - vz * (SY * SX), vy = r / SX, vx = r - vy * SX;
+        const int gz = z0 - halo + vz, gy = y0 - halo + vy, gx = x0 - halo + vx;
+        if ((unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && cp0 + cq * 8 < p.Cp)
+          preP[i] = *reinterpret_cast<const u32x4*>(p.p + ((((long)n * p.D + gz) * p.H + gy) * p.W + gx) * (long)p.ldp + cp0 + cq * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < QSLOT; ++i) {
+      const int e = tid + i * 512;
+      preQ[i] = u32x4{0u, 0u, 0u, 0u};
+      if (e < TX * TY * TZ * 4 * NQ) {
+        const int vox = e / (4 * NQ), cq = e % (4 * NQ);
+        const int vz = vox / (TY * TX), r = vox - vz * (TY * TX), vy = r / TX, vx = r - vy * TX;
+        const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
+        if (gz < p.D && gy < p.H && gx < p.W && cq0 + cq * 8 < p.Cq)
+          preQ[i] = *reinterpret_cast<const u32x4*>(p.q + ((((long)n * p.D + gz) * p.H + gy) * p.W + gx) * (long)p.ldq + cq0 + cq * 8);
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < PSLOT; ++i) {
+      const int e = tid + i * 512;
+      if (e < nvp * 4) {
+        u32x2* d = reinterpret_cast<u32x2*>(ldsP + (e >> 2) * PS + (e & 3) * 8);
+        d[0] = u32x2{preP[i][0], preP[i][1]};
+        d[1] = u32x2{preP[i][2], preP[i][3]};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < QSLOT; ++i) {
+      const int e = tid + i * 512;
+      if (e < TX * TY * TZ * 4 * NQ) {
+        u32x2* d = reinterpret_cast<u32x2*>(ldsQ + (e / (4 * NQ)) * QS + (e % (4 * NQ)) * 8);
+        d[0] = u32x2{preQ[i][0], preQ[i][1]};
+        d[1] = u32x2{preQ[i][2], preQ[i][3]};
+      }
+    }
+  };
+  // eight 2-byte reads -> one 16-byte matrix operand (K = 8 consecutive voxels along x of one channel)
+  auto gather = [&](const unsigned short* base, int stride) {
+    unsigned v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = base[j * stride];
+    return u32x4{v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
+  };
+
+  long tile = blockIdx.x;
+  if (tile < p.ntiles) fetch(tile);
+  for (; tile < p.ntiles; tile += gridDim.x) {
+    __syncthreads();      // every wave is done with the previous tile
+    commit();
+    __syncthreads();
+    if (tile + gridDim.x < p.ntiles) fetch(tile + gridDim.x);
+    if (k3) {
+      // wave w owns taps w, w+8, w+16 (and w+24 for w < 3) and walks all 32 x-rows of the tile
+#pragma unroll 2
+      for (int kb = 0; kb < TY * TZ; ++kb) {
+        const int z = kb / TY, y = kb % TY;
+        u32x4 bq[NQ];
+#pragma unroll
+        for (int c = 0; c < NQ; ++c) bq[c] = gather(ldsQ + ((z * TY + y) * TX + 8 * h) * QS + c * 32 + l32, QS);
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+          const int t = wave + 8 * ti;
+          if (t < 27) {
+            const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+            const u32x4 a = gather(ldsP + (((z + dz) * SY + (y + dy)) * SX + 8 * h + dx) * PS + l32, PS);
+#pragma unroll
+            for (int c = 0; c < NQ; ++c) acc[ti][c] = T::mfma(a, bq[c], acc[ti][c]);
+          }
+        }
+      }
+    } else {
+      // 1x1x1: wave w takes x-rows w, w+8, w+16, w+24 (one accumulator per wave; the finalize adds the eight)
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        const int kb = wave + 8 * ti;
+        const int z = kb / TY, y = kb % TY;
+        const u32x4 a = gather(ldsP + ((z * SY + y) * SX + 8 * h) * PS + l32, PS);
+#pragma unroll
+        for (int c = 0; c < NQ; ++c) {
+          const u32x4 b = gather(ldsQ + ((z * TY + y) * TX + 8 * h) * QS + c * 32 + l32, QS);
+          acc[0][c] = T::mfma(a, b, acc[0][c]);
+        }
+      }
+    }
+  }
+  // partial sums: part[wg][cp tile][cq group][slot][32 cin][32*NQ cout]; slot = tap (3x3x3) or wave (1x1x1)
+  const int nslot = k3 ? 27 : 8;
+  float* pb = p.part + (((long)blockIdx.x * p.ncp + cpt) * p.ncqg + cqg) * (long)nslot * 32 * (32 * NQ);
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti) {
+    const int slot = k3 ? wave + 8 * ti : wave;
+    if ((k3 && slot < 27) || (!k3 && ti == 0)) {
+#pragma unroll
+      for (int c = 0; c < NQ; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+          pb[((long)slot * 32 + row) * (32 * NQ) + c * 32 + l32] = acc[ti][c][r];
+        }
+    }
+  }
+}
+
+struct LpWfParams {
+  const float* part;
+  float* dw;
+  int nwg, ncp, ncqg, nslot, ntaps, NQ, Cp, Cq, Cin_ref, dup_start, dup_shift, accum;
+};
+// dW[t][c_ref][k] (+)= sum over workgroups (and, for 1x1x1, waves) of the partials, fixed order; a slab channel c is reference
+// channel c + shift and, inside the duplicated slice, ALSO reference channel c - dup_start (both copies get the gradient)
+__global__ __launch_bounds__(256) void lp_wgrad_finalize_kernel(const LpWfParams f) {
+  const long total = (long)f.ntaps * f.Cp * f.Cq;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int k = (int)(i % f.Cq);
+    long r = i / f.Cq;
+    const int c = (int)(r % f.Cp);
+    const int t = (int)(r / f.Cp);
+    const int cpt = c / 32, row = c % 32, cqg = k / (32 * f.NQ), col = k % (32 * f.NQ);
+    const int s0 = f.ntaps == 27 ? t : 0, s1 = f.ntaps == 27 ? t + 1 : 8;
+    double s = 0.0;
+    for (int wg = 0; wg < f.nwg; ++wg) {
+      const float* pb = f.part + (((long)wg * f.ncp + cpt) * f.ncqg + cqg) * (long)f.nslot * 32 * (32 * f.NQ);
+      for (int sl = s0; sl < s1; ++sl) s += pb[((long)sl * 32 + row) * (32 * f.NQ) + col];
+    }
+    const float v = (float)s;
+    float* d0 = f.dw + ((long)t * f.Cin_ref + c + f.dup_shift) * f.Cq + k;
+    *d0 = f.accum ? *d0 + v : v;
+    if (f.dup_shift > 0 && c >= f.dup_start && c < f.dup_start + f.dup_shift) {
+      float* d1 = f.dw + ((long)t * f.Cin_ref + (c - f.dup_start)) * f.Cq + k;
+      *d1 = f.accum ? *d1 + v : v;
+    }
+  }
+}
+// db[k] (+)= sum_n colsum[n][k]
+__global__ void lp_bias_grad_kernel(const float* cs, float* db, int N, int C, int accum) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= C) return;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += cs[n * C + k];
+  db[k] = accum ? db[k] + s : s;
+}
+
+static void lp_wg_plan(int kind, int N, int D, int H, int W, int Cp, int Cq, int& nq, int& nwg, long& ntiles, int& ncp, int& ncqg) {
+  nq = Cq >= 64 ? 2 : 1;
+  ncp = (Cp + 31) / 32;
+  ncqg = (Cq + 32 * nq - 1) / (32 * nq);
+  ntiles = (long)N * ((D + LPW_TZ - 1) / LPW_TZ) * ((H + LPW_TY - 1) / LPW_TY) * ((W + LPW_TX - 1) / LPW_TX);
+  long cap = 512 / ((long)ncp * ncqg);          // ~2 workgroups per CU over the whole launch
+  if (cap < 1) cap = 1;
+  nwg = (int)(ntiles < cap ? ntiles : cap);
+}
+extern "C" long bts_lp_conv3d_bwd_weight_workspace(int kind, int N, int D, int H, int W, int Cin, int Cout) {
+  if (kind != BTS_CONV_K3S1 && kind != BTS_CONV_K1) return -1;
+  int nq, nwg, ncp, ncqg; long ntiles;
+  lp_wg_plan(kind, N, D, H, W, Cin, Cout, nq, nwg, ntiles, ncp, ncqg);
+  const int nslot = kind == BTS_CONV_K3S1 ? 27 : 8;
+  return (long)nwg * ncp * ncqg * nslot * 32 * 32 * nq * 4 + (long)N * ((Cout + 7) / 8 * 8) * 4 + bts_lp_colsum_workspace(N, (long)D * H * W, (Cout + 7) / 8 * 8) + 256;
+}
+// dw (Keras layout (kd,kh,kw,Cin_ref,Cout), fp32) (+)= the weight gradient; db (may be NULL) (+)= sum of dy over voxels and samples.
+// x (N,D,H,W,Cin) stride ldx, dy (N,D,H,W,Cout) DENSE when db is wanted; Cin, Cout multiples of 8.  K3S1 and K1 only (-3 otherwise).
+extern "C" int bts_lp_conv3d_bwd_weight(int kind, int dtype, const void* x, const void* dy, float* dw, float* db, void* workspace,
+                                        long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int lddy, int dup_start,
+                                        int dup_shift, int accumulate, hipStream_t stream) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  if (kind != BTS_CONV_K3S1 && kind != BTS_CONV_K1) return BTS_ERR_UNSUPPORTED;
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin % 8 != 0 || Cout % 8 != 0 || ldx % 8 != 0 || lddy % 8 != 0) return BTS_ERR_SHAPE;
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)dy) & 15) || (((uintptr_t)workspace) & 15)) return BTS_ERR_ALIGN;
+  if (dup_shift < 0 || (dup_shift > 0 && dup_start + dup_shift > Cin)) return BTS_ERR_SHAPE;
+  if (workspace_bytes < bts_lp_conv3d_bwd_weight_workspace(kind, N, D, H, W, Cin, Cout)) return BTS_ERR_WORKSPACE;
+  LpWgParams p;
+  int nq, nwg;
+  lp_wg_plan(kind, N, D, H, W, Cin, Cout, nq, nwg, p.ntiles, p.ncp, p.ncqg);
+  p.p = (const unsigned short*)x; p.q = (const unsigned short*)dy; p.part = reinterpret_cast<float*>(workspace);
+  p.N = N; p.D = D; p.H = H; p.W = W; p.Cp = Cin; p.ldp = ldx; p.Cq = Cout; p.ldq = lddy; p.ntaps = kind == BTS_CONV_K3S1 ? 27 : 1;
+  p.ntx = (W + LPW_TX - 1) / LPW_TX; p.nty = (H + LPW_TY - 1) / LPW_TY; p.ntz = (D + LPW_TZ - 1) / LPW_TZ;
+  const size_t shmem = ((size_t)(LPW_TX + 2) * (LPW_TY + 2) * (LPW_TZ + 2) * 36 + (size_t)LPW_TX * LPW_TY * LPW_TZ * (32 * nq + 4)) * 2;
+  (void)hipGetLastError();
+#define LPW_LAUNCH(TT, NQ_)                                                                                                   \
+  do {                                                                                                                        \
+    auto kern = lp_wgrad_kernel<TT, NQ_>;                                                                                     \
+    static bool done = false;                                                                                                 \
+    if (!done) {                                                                                                              \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      if (e != hipSuccess) return (int)e;                                                                                     \
+      done = true;                                                                                                            \
+    }                                                                                                                         \
+    hipLaunchKernelGGL(kern, dim3(nwg, p.ncp * p.ncqg), dim3(512), shmem, stream, p);                                         \
+  } while (0)
+  if (dtype == LP_F16) { if (nq == 2) LPW_LAUNCH(TF16, 2); else LPW_LAUNCH(TF16, 1); }
+  else { if (nq == 2) LPW_LAUNCH(TBF16, 2); else LPW_LAUNCH(TBF16, 1); }
+#undef LPW_LAUNCH
+  BTS_LAUNCH_CHECK();
+  LpWfParams f;
+  f.part = p.part; f.dw = dw; f.nwg = nwg; f.ncp = p.ncp; f.ncqg = p.ncqg; f.nslot = kind == BTS_CONV_K3S1 ? 27 : 8; f.ntaps = p.ntaps; f.NQ = nq;
+  f.Cp = Cin; f.Cq = Cout; f.Cin_ref = Cin + dup_shift; f.dup_start = dup_start; f.dup_shift = dup_shift; f.accum = accumulate;
+  const long total = (long)p.ntaps * Cin * Cout;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(lp_wgrad_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, f);
+  BTS_LAUNCH_CHECK();
+  if (db != nullptr) {
+    if (lddy != Cout) return BTS_ERR_UNSUPPORTED;
+    char* wsb = reinterpret_cast<char*>(workspace) + (long)nwg * p.ncp * p.ncqg * f.nslot * 32 * 32 * nq * 4;
+    float* cs = reinterpret_cast<float*>(wsb);
+    void* cws = wsb + (((long)N * Cout * 4 + 255) & ~255L);
+    const int r = bts_lp_colsum(dtype, dy, cs, cws, bts_lp_colsum_workspace(N, (long)D * H * W, Cout), N, (long)D * H * W, Cout, 1.0f, stream);
+    if (r != BTS_OK) return r;
+    hipLaunchKernelGGL(lp_bias_grad_kernel, dim3((Cout + 255) / 256), dim3(256), 0, stream, cs, db, N, Cout, accumulate);
+    BTS_LAUNCH_CHECK();
+  }
+  return BTS_OK;
+}

@@ -78,6 +78,26 @@ def conv(kind, code, tdt, x, wp, bias, cout, out=None):
     return out
 
 
+def wgrad_supported(kind, cin, cout):
+    """shapes the 16-bit weight-gradient kernel takes (stride-1 3x3x3 / 1x1x1, channel counts in whole 16-byte chunks)"""
+    return kind in (ops.K3S1, ops.K1) and cin % 8 == 0 and cout % 8 == 0 and cout <= 256 and ((cout // 8) & (cout // 8 - 1)) == 0
+
+
+def conv_bwd_weight(kind, code, x, dy, dw, db, dup_start=0, dup_shift=0, accumulate=True):
+    """16-bit weight gradient of a stride-1 3x3x3 / 1x1x1 conv -> True, or False when the shape is outside the kernel's reach (the
+    caller then runs the fp32 kernel on widened copies)"""
+    n, d, h, w, cin = x.shape
+    cout = dy.shape[-1]
+    if kind not in (ops.K3S1, ops.K1) or cin % 8 or cout % 8 or cout > 256 or (cout // 8) & (cout // 8 - 1) or \
+            (db is not None and not dy.is_contiguous()):
+        return False
+    nb = lib().query('bts_lp_conv3d_bwd_weight_workspace', kind, n, d, h, w, cin, cout)
+    ws = ops.workspace(nb, x.device)
+    lib().call('bts_lp_conv3d_bwd_weight', kind, code, _p(x), _p(dy), _p(dw), _p(db) if db is not None else None, _p(ws), nb, n, d, h, w, cin,
+               _ld(x), cout, _ld(dy), dup_start, dup_shift, 1 if accumulate else 0, _stream())
+    return True
+
+
 def cast(code, tdt, src, out=None):
     c = src.shape[-1]
     rows = src.numel() // c

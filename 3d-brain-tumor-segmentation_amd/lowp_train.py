@@ -6,11 +6,12 @@ weights, their gradients and the Adam moments stay the model's flat fp32 buffers
   forward convolutions, GroupNorm, pooling, block epilogue            16-bit kernels of csrc/lowp.hip (as bts_amd.lowp)
   data gradients of every convolution                                  the same kernels on role-swapped weight images
                                                                        (bts_lp_conv3d_bwd_data), accumulating into slab gradients
-  weight gradients; GroupNorm / squeeze-excitation gradients;          the fp32 engine's kernels on operands widened by a
-  the dense VAE head; loss, metric, regulariser, Adam                  staging pass (bts_lp_uncast) -- exact on the stored values;
-                                                                       their 16-bit forms (the weight gradient needs
-                                                                       voxel-contiguous operand fragments, i.e. an LDS
-                                                                       transpose on the way in) are not built yet
+  weight gradients of the stride-1 3x3x3 / 1x1x1 convolutions,         16-bit kernels too (bts_lp_conv3d_bwd_weight: the contraction
+  GroupNorm gradients                                                  over voxels gathers its operand fragments from LDS;
+                                                                       bts_lp_gn_bwd)
+  weight gradients of the strided / transposed convs and of the       the fp32 engine's kernels on operands widened by a
+  2-channel first block; squeeze-excitation gradients; the dense       staging pass (bts_lp_uncast) -- exact on the stored values
+  VAE head; loss, metric, regulariser, Adam
 
 The graph is the fp32 layers' own (same virtual concatenation through level slabs, same folded duplicate slices), written
 out explicitly -- forward saves what the backward needs, the backward walks it in reverse -- so the fp32 engine (the parity
@@ -58,13 +59,14 @@ class LowPrecisionTrainer(object):
         cast(self.code, self.tdt, t, out=buf[..., :c])
         return buf
 
-    def _gn_bwd(self, norm, c, dy, mean, rstd):
-        """GroupNorm (+ReLU) backward -> (dc in the storage type with channels padded to a matrix step, dc in fp32); parameter
-        gradients accumulate.  16-bit kernel where its tiling fits, else the fp32 kernel on widened copies"""
+    def _gn_bwd(self, norm, c, dy, mean, rstd, want_f32=True):
+        """GroupNorm (+ReLU) backward -> (dc in the storage type with channels padded to a matrix step, dc in fp32 or None);
+        parameter gradients accumulate.  16-bit kernel where its tiling fits, else the fp32 kernel on widened copies"""
         r = None
         if norm._mode == ops.GN_SLAB:
+            pad = c.shape[-1] % 16 != 0
             r = lowp.gn_bwd(self.code, self.tdt, c, dy, norm.gamma.t, norm.beta.t, mean, rstd, self._gslot(norm.gamma), self._gslot(norm.beta),
-                            norm.groups, True)
+                            norm.groups, True, want_f32=want_f32 or pad)
         if r is not None and r[0].shape[-1] % 16 == 0:
             return r
         if r is not None:
@@ -130,37 +132,51 @@ class LowPrecisionTrainer(object):
         n1, n2 = blk.norm1, blk.norm2
         dup_start, dup_shift = s['fold']
         key = id(blk)
+        x = s['x']
+        cin_slab = s['cin_slab']
+        lp2 = lowp.wgrad_supported(ops.K3S1, f, f)                       # conv2's weight gradient on the 16-bit kernel?
+        lp1 = lowp.wgrad_supported(ops.K3S1, cin_slab, f) and cin_slab == x.shape[-1]   # conv1 / shortcut (not the padded 2-channel input)
         dout32 = self._f32(dout)
         # conv branch: GN2 (+ReLU) -> conv2 -> GN1 (+ReLU) -> conv1
-        dc2_16, dc2 = self._gn_bwd(n2, s['c2'], dout, s['m2'], s['r2'])
-        a32 = self._f32(s['a'])
-        self._wg((a32, dc2), lambda: ops.conv_bwd_weight(ops.K3S1, a32, dc2, self._gslot(blk.conv2_k), self._gslot(blk.conv2_b),
-                                                         accumulate=True))
+        dc2_16, dc2 = self._gn_bwd(n2, s['c2'], dout, s['m2'], s['r2'], want_f32=not lp2)
+        if lp2:
+            a16 = s['a']
+            self._wg((a16, dc2_16), lambda: lowp.conv_bwd_weight(ops.K3S1, code, a16, dc2_16, self._gslot(blk.conv2_k),
+                                                                 self._gslot(blk.conv2_b), accumulate=True))
+        else:
+            a32 = self._f32(s['a'])
+            self._wg((a32, dc2), lambda: ops.conv_bwd_weight(ops.K3S1, a32, dc2, self._gslot(blk.conv2_k), self._gslot(blk.conv2_b),
+                                                             accumulate=True))
         da = torch.empty_like(s['a'])
         conv_bwd_data(ops.K3S1, code, dc2_16, self._pk((key, 'c2b'), ops.K3S1, blk.conv2_k, f, f, role=ops.ROLE_BWD), da, False)
         del dc2, dc2_16
-        dc1_16, dc1 = self._gn_bwd(n1, s['c1'], da, s['m1'], s['r1'])
+        dc1_16, dc1 = self._gn_bwd(n1, s['c1'], da, s['m1'], s['r1'], want_f32=not lp1)
         del da
         # gate branch
         dres = ops.se_bwd(dout32, self._f32(s['res']), s['sp'], s['gap'], s['hbuf'], s['ch'], blk.se_w1.t, blk.se_w2.t,
                           blk.spatial_k.t.reshape(-1), self._gslot(blk.se_w1), self._gslot(blk.se_w2),
                           self._gslot(blk.spatial_k).reshape(-1), accumulate_params=True)
         del dout32
-        # weight gradients of the two convolutions that read the block input (fp32 kernels on the widened input view)
-        x = s['x']
-        cin_slab = s['cin_slab']
-        x32 = self._f32(x[..., :cin_slab])
+        dres_16 = self._b16(dres)
+        # weight gradients of the two convolutions that read the block input
+        if lp1:
+            def wgrads():
+                lowp.conv_bwd_weight(ops.K3S1, code, x, dc1_16, self._gslot(blk.conv1_k), self._gslot(blk.conv1_b), dup_start, dup_shift, True)
+                lowp.conv_bwd_weight(ops.K1, code, x, dres_16, self._gslot(blk.ptwise_k), self._gslot(blk.ptwise_b), dup_start, dup_shift, True)
+            self._wg((x, dc1_16, dres_16), wgrads)
+        else:   # fp32 kernels on the widened input view
+            x32 = self._f32(x[..., :cin_slab])
 
-        def wgrads():
-            ops.conv_bwd_weight(ops.K3S1, x32, dc1, self._gslot(blk.conv1_k), self._gslot(blk.conv1_b), dup_start, dup_shift, accumulate=True)
-            ops.conv_bwd_weight(ops.K1, x32, dres, self._gslot(blk.ptwise_k), self._gslot(blk.ptwise_b), dup_start, dup_shift, accumulate=True)
-        self._wg((x32, dc1, dres), wgrads)
+            def wgrads():
+                ops.conv_bwd_weight(ops.K3S1, x32, dc1, self._gslot(blk.conv1_k), self._gslot(blk.conv1_b), dup_start, dup_shift, accumulate=True)
+                ops.conv_bwd_weight(ops.K1, x32, dres, self._gslot(blk.ptwise_k), self._gslot(blk.ptwise_b), dup_start, dup_shift, accumulate=True)
+            self._wg((x32, dc1, dres), wgrads)
         if dx is not None:
             cin = x.shape[-1]
             wpb1 = self._pk((key, 'c1b'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin, dup_start, dup_shift, role=ops.ROLE_BWD)
             wpbp = self._pk((key, 'ptb'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin, dup_start, dup_shift, role=ops.ROLE_BWD)
             conv_bwd_data(ops.K3S1, code, dc1_16, wpb1, dx, True)
-            conv_bwd_data(ops.K1, code, self._b16(dres), wpbp, dx, True)
+            conv_bwd_data(ops.K1, code, dres_16, wpbp, dx, True)
 
     def _sampler_fwd(self, lay, kind, x, out=None):
         wp = self._pk((id(lay), 'f'), kind, lay.conv_k, lay.cin, lay.filters)

@@ -251,6 +251,14 @@ int bts_lp_conv3d_fwd(int kind, int dtype, const void* x, const void* wp, const 
 long bts_lp_conv3d_bwd_data_workspace(int kind, int N, int D, int H, int W, int Cin, int Cout);
 int bts_lp_conv3d_bwd_data(int kind, int dtype, const void* dy, const void* wp_bwd, void* dx, void* workspace, long workspace_bytes,
                            int N, int D, int H, int W, int Cin, int lddx, int Cout, int lddy, int accum, bts_stream_t stream);
+/* dw (fp32, Keras layout (kd,kh,kw,Cin_ref,Cout)) (+)= the weight gradient of a stride-1 3x3x3 / 1x1x1 conv from 16-bit x and dy
+ * (voxel contraction on the 16-bit matrix pipe, fp32 partials, fixed-order finalize); db (may be NULL; dy dense then) (+)= sum dy.
+ * dup_start / dup_shift as bts_conv_pack: Cin + dup_shift == Cin_ref, both copies of the folded slice receive the gradient.
+ * BTS_ERR_UNSUPPORTED for the strided kinds and channel counts that are not multiples of 8: run bts_conv3d_bwd_weight on widened copies */
+long bts_lp_conv3d_bwd_weight_workspace(int kind, int N, int D, int H, int W, int Cin, int Cout);
+int bts_lp_conv3d_bwd_weight(int kind, int dtype, const void* x, const void* dy, float* dw, float* db, void* workspace, long workspace_bytes,
+                             int N, int D, int H, int W, int Cin, int ldx, int Cout, int lddy, int dup_start, int dup_shift, int accumulate,
+                             bts_stream_t stream);
 /* fp32 <-> storage type, `rows` rows of C elements with row strides (the 2-channel input block runs in fp32: K = 16 is its floor) */
 int bts_lp_cast(int dtype, const float* src, long ld_src, void* dst, long ld_dst, long rows, int C, bts_stream_t stream);
 int bts_lp_uncast(int dtype, const void* src, long ld_src, float* dst, long ld_dst, long rows, int C, bts_stream_t stream);

@@ -326,3 +326,53 @@ def test_groupnorm_backward_kernel(shape, dtype):
     assert float((dx16.float() - dx_r).abs().max()) <= U[dtype] * scale * 1.01 + 2e-5 * scale
     for a, b in ((dg, dg_r), (db, db_r)):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-5
+
+
+WG_CASES = [
+    # kind, (N,D,H,W), Cin, Cout, fold (dup_start, dup_shift) or None, x is a slab view
+    ('K3S1', (2, 8, 8, 16), 32, 32, None, False),
+    ('K3S1', (1, 6, 10, 20), 64, 64, None, True),          # ragged tiles, two cout blocks per wave
+    ('K3S1', (2, 4, 8, 16), 32, 16, (16, 16), True),       # folded duplicate slice: both copies of the weight get the gradient
+    ('K1', (2, 8, 8, 16), 48, 32, None, True),
+    ('K1', (1, 4, 8, 16), 32, 128, (16, 16), False),
+]
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('case', WG_CASES, ids=lambda c: '%s-%s-%d-%d-%s' % (c[0], 'x'.join(map(str, c[1])), c[2], c[3], 'fold' if c[4] else 'plain'))
+def test_weight_gradient_kernel(case, dtype):
+    """16-bit weight gradient against torch autograd of the oracle's conv on the same rounded x / dy (fp64), accumulated onto a
+    non-zero buffer; the folded case checks that W[first copy] and W[second copy] both receive the slab slice's gradient"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    name, (n, d, h, w), cin, cout, fold, slab = case
+    kind = getattr(ops, name)
+    code, tdt = lowp.DTYPES[dtype]
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    k = 1 if kind == ops.K1 else 3
+    dup_start, dup_shift = fold if fold else (0, 0)
+    cin_ref = cin + dup_shift
+    x = torch.randn((n, d, h, w, cin), generator=g)
+    dy = torch.randn((n, d, h, w, cout), generator=g)
+    xr, dyr = _round(x, tdt), _round(dy, tdt)
+    # what the reference's block would have seen: [slab[dup_start:dup_start+shift], slab]
+    full = torch.cat([xr[..., dup_start:dup_start + dup_shift], xr], dim=-1) if fold else xr
+    wz = torch.zeros((k, k, k, cin_ref, cout), dtype=torch.float64, requires_grad=True)
+    bz = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    dw_ref, db_ref = torch.autograd.grad(R.conv3d(full, wz, bz), (wz, bz), dyr)
+    wz2 = torch.zeros((k, k, k, cin_ref, cout), dtype=torch.float64, requires_grad=True)
+    mag = torch.autograd.grad(R.conv3d(full.abs(), wz2, None), wz2, dyr.abs())[0]
+    dw0 = torch.randn(dw_ref.shape, generator=g)
+    db0 = torch.randn(cout, generator=g)
+    buf = torch.zeros((n, d, h, w, cin + 16), dtype=tdt, device=DEV)
+    xin = buf[..., 8:8 + cin] if slab else torch.empty((n, d, h, w, cin), dtype=tdt, device=DEV)
+    xin.copy_(x.to(tdt).to(DEV))
+    dw, db = dw0.to(DEV).contiguous(), db0.to(DEV).contiguous()
+    ok = lowp.conv_bwd_weight(kind, code, xin, dy.to(tdt).to(DEV), dw, db, dup_start, dup_shift, accumulate=True)
+    assert ok
+    torch.cuda.synchronize()
+    err = (dw.double().cpu() - (dw_ref + dw0.double())).abs()
+    bound = 8 * 2.0 ** -24 * mag + 2.0 ** -22 * (dw_ref.abs() + dw0.double().abs()) + 1e-9
+    assert float((err / bound).max()) <= 1.0, 'dw: max err %.3e at %.2fx the bound' % (float(err.max()), float((err / bound).max()))
+    eb = (db.double().cpu() - (db_ref + db0.double())).abs()
+    assert float(eb.max()) <= 1e-5 * float(db_ref.abs().max()) + 1e-5
