@@ -1419,25 +1419,40 @@ struct LpWfParams {
 // dW[t][c_ref][k] (+)= sum over workgroups (and, for 1x1x1, waves) of the partials, fixed order; a slab channel c is reference
 // channel c + shift and, inside the duplicated slice, ALSO reference channel c - dup_start (both copies get the gradient)
 __global__ __launch_bounds__(256) void lp_wgrad_finalize_kernel(const LpWfParams f) {
+  // 32 consecutive elements x 8 slices of the workgroup list per block: coalesced partial reads, slices combined in fixed order
+  __shared__ double sh[8][32];
   const long total = (long)f.ntaps * f.Cp * f.Cq;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int k = (int)(i % f.Cq);
-    long r = i / f.Cq;
-    const int c = (int)(r % f.Cp);
-    const int t = (int)(r / f.Cp);
-    const int cpt = c / 32, row = c % 32, cqg = k / (32 * f.NQ), col = k % (32 * f.NQ);
-    const int s0 = f.ntaps == 27 ? t : 0, s1 = f.ntaps == 27 ? t + 1 : 8;
+  const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  for (long i0 = blockIdx.x * 32L; i0 < total; i0 += (long)gridDim.x * 32) {
+    const long i = i0 + el;
     double s = 0.0;
-    for (int wg = 0; wg < f.nwg; ++wg) {
-      const float* pb = f.part + (((long)wg * f.ncp + cpt) * f.ncqg + cqg) * (long)f.nslot * 32 * (32 * f.NQ);
-      for (int sl = s0; sl < s1; ++sl) s += pb[((long)sl * 32 + row) * (32 * f.NQ) + col];
+    int k = 0, c = 0, t = 0;
+    if (i < total) {
+      k = (int)(i % f.Cq);
+      const long r = i / f.Cq;
+      c = (int)(r % f.Cp);
+      t = (int)(r / f.Cp);
+      const int cpt = c / 32, row = c % 32, cqg = k / (32 * f.NQ), col = k % (32 * f.NQ);
+      const int s0 = f.ntaps == 27 ? t : 0, s1 = f.ntaps == 27 ? t + 1 : 8;
+      for (int wg = sl; wg < f.nwg; wg += 8) {
+        const float* pb = f.part + (((long)wg * f.ncp + cpt) * f.ncqg + cqg) * (long)f.nslot * 32 * (32 * f.NQ);
+        for (int q = s0; q < s1; ++q) s += pb[((long)q * 32 + row) * (32 * f.NQ) + col];
+      }
     }
-    const float v = (float)s;
-    float* d0 = f.dw + ((long)t * f.Cin_ref + c + f.dup_shift) * f.Cq + k;
-    *d0 = f.accum ? *d0 + v : v;
-    if (f.dup_shift > 0 && c >= f.dup_start && c < f.dup_start + f.dup_shift) {
-      float* d1 = f.dw + ((long)t * f.Cin_ref + (c - f.dup_start)) * f.Cq + k;
-      *d1 = f.accum ? *d1 + v : v;
+    __syncthreads();
+    sh[sl][el] = s;
+    __syncthreads();
+    if (sl == 0 && i < total) {
+      double tot = 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) tot += sh[q][el];
+      const float v = (float)tot;
+      float* d0 = f.dw + ((long)t * f.Cin_ref + c + f.dup_shift) * f.Cq + k;
+      *d0 = f.accum ? *d0 + v : v;
+      if (f.dup_shift > 0 && c >= f.dup_start && c < f.dup_start + f.dup_shift) {
+        float* d1 = f.dw + ((long)t * f.Cin_ref + (c - f.dup_start)) * f.Cq + k;
+        *d1 = f.accum ? *d1 + v : v;
+      }
     }
   }
 }
@@ -1455,7 +1470,7 @@ static void lp_wg_plan(int kind, int N, int D, int H, int W, int Cp, int Cq, int
   ncp = (Cp + 31) / 32;
   ncqg = (Cq + 32 * nq - 1) / (32 * nq);
   ntiles = (long)N * ((D + LPW_TZ - 1) / LPW_TZ) * ((H + LPW_TY - 1) / LPW_TY) * ((W + LPW_TX - 1) / LPW_TX);
-  long cap = 512 / ((long)ncp * ncqg);          // ~2 workgroups per CU over the whole launch
+  long cap = 256 / ((long)ncp * ncqg);          // one 512-thread workgroup per CU over the whole launch
   if (cap < 1) cap = 1;
   nwg = (int)(ntiles < cap ? ntiles : cap);
 }
@@ -1504,8 +1519,8 @@ extern "C" int bts_lp_conv3d_bwd_weight(int kind, int dtype, const void* x, cons
   f.part = p.part; f.dw = dw; f.nwg = nwg; f.ncp = p.ncp; f.ncqg = p.ncqg; f.nslot = kind == BTS_CONV_K3S1 ? 27 : 8; f.ntaps = p.ntaps; f.NQ = nq;
   f.Cp = Cin; f.Cq = Cout; f.Cin_ref = Cin + dup_shift; f.dup_start = dup_start; f.dup_shift = dup_shift; f.accum = accumulate;
   const long total = (long)p.ntaps * Cin * Cout;
-  long blocks = (total + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  long blocks = (total + 31) / 32;
+  if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(lp_wgrad_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, f);
   BTS_LAUNCH_CHECK();
   if (db != nullptr) {

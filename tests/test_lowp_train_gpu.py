@@ -89,3 +89,34 @@ def test_step_against_the_fp32_engine(dtype, lim):
     assert dl <= lim['loss'] and abs(float(macro16) - float(macro32)) <= 5e-3 and mism <= 1e-2
     assert rel <= lim['l2'] and cos >= lim['cos'] and worst[0] >= lim['var_cos']
     assert dpar <= 2.0 * moved            # Adam's first step is ~lr*sign(g): a flipped sign moves a parameter by 2 lr at most
+
+
+def test_bf16_training_tracks_the_fp32_trajectory():
+    """six optimiser steps on two fixed volumes: the bf16-storage run must learn (loss falls) and stay next to the fp32 run"""
+    from bts_amd.lowp_train import LowPrecisionTrainer
+    from bts_amd.tape import bump_weights_epoch
+    from bts_amd.util import DiceCoefficient, DiceVAELoss, ScheduledOptim, train_step
+    m, x, y, mask, eps = _setup(seed=8)
+    start = m.flat_params.clone()
+    runs = {}
+    for mode in ('fp32', 'bf16'):
+        m.flat_params.copy_(start)
+        bump_weights_epoch()
+        opt = ScheduledOptim(1e-3)
+        opt(epoch=0)
+        tr = LowPrecisionTrainer(m, 'bfloat16') if mode == 'bf16' else None
+        df = DiceCoefficient()
+        losses = []
+        for _ in range(6):
+            m.encoder.set_dropout_mask(mask)
+            m.vae.set_eps(eps)
+            loss = tr.step(opt, df, x, y)[0] if tr else train_step(m, opt, DiceVAELoss(), df, x, y)[0]
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        runs[mode] = losses
+    print('fp32 losses', ['%.5f' % v for v in runs['fp32']])
+    print('bf16 losses', ['%.5f' % v for v in runs['bf16']])
+    assert runs['bf16'][-1] < runs['bf16'][0] - 0.01 and runs['fp32'][-1] < runs['fp32'][0] - 0.01
+    # (lr 1e-3, ten times the default: Adam's early steps are ~lr*sign(g), so rounding noise in small gradients moves the two runs
+    #  apart by up to ~1 % of the loss on the way down; measured: 1.64430/1.64448 ... 1.19224/1.18136 ... 1.02990/1.02862)
+    assert all(abs(a - b) <= 2e-2 * abs(b) for a, b in zip(runs['bf16'], runs['fp32']))
