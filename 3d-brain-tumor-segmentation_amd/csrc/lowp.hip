@@ -188,6 +188,13 @@ struct LpS1Params {
 };
 #define LPS 24   // halves per staged voxel: 16 channels + 8 pad (48-byte stride: conflict-free 16-byte reads)
 
+__device__ __forceinline__ u32x2 bload8(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  return __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
+}
+__device__ __forceinline__ void bstore8(__amdgpu_buffer_rsrc_t r, unsigned voff, u32x2 v) {
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, 0, 0);
+}
+
 template <typename T, int VB, int CB, int TXL>
 __global__ __launch_bounds__(256, 2) void lp_conv_s1_kernel(const LpS1Params p) {
   constexpr int TX = 1 << TXL, R = 32 / TX, TY = VB * R, TZ = 4;
@@ -195,42 +202,54 @@ __global__ __launch_bounds__(256, 2) void lp_conv_s1_kernel(const LpS1Params p) 
   constexpr int NVOX = SX * SY * SZ;
   constexpr int NSLOT = (NVOX * 2 + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  float* const bsh = reinterpret_cast<float*>(lds + NVOX * LPS);     // the tile's 32 * CB bias values (behind the halo tile)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l32 = lane & 31;
   const int lx = l32 & (TX - 1), ly = l32 >> TXL;
-  // persistent over tiles: a launch has a few workgroups per CU, each walking tiles blockIdx.x, + gridDim.x, ... (with one short
-  // tile per workgroup the dispatcher, not the CUs, set the pace: 0.5 resident waves per SIMD on the 160x192x160 layers)
-  for (long tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-  long b = tile;
-  const int cg = (int)(b % p.ncg); b /= p.ncg;
-  const int tx = (int)(b % p.ntx); b /= p.ntx;
-  const int ty = (int)(b % p.nty); b /= p.nty;
-  const int tz = (int)(b % p.ntz);
-  const int n = (int)(b / p.ntz);
-  const int ox0 = tx * TX, oy0 = ty * TY, oz0 = tz * TZ;
-  // halo origin; slots outside the image get an offset outside the descriptor -> the load returns zeros (the 'same' padding)
-  const unsigned short* xorg = p.x + ((((long)n * p.D + (oz0 - 1)) * p.H + (oy0 - 1)) * p.W + (ox0 - 1)) * (long)p.ldx;
-  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xorg, 0, 0x7fffffff, 0x00020000);
+  // Persistent over tiles (blockIdx.x, + gridDim.x, ...), and a tile boundary is a k-step boundary: during a tile's LAST k-step
+  // the first halo slab and weight groups of the workgroup's next tile are requested, so the output side below runs with its
+  // successor's operands in flight (with 32 input channels a tile has only two k-steps: a fresh global round trip per tile was
+  // most of its time).  Everything on the vector-memory queue is issued unconditionally -- masked lanes get an offset outside the
+  // buffer descriptor -- so that the compiler's vmcnt waits are exact and the wait for a halo slab never drains the stores issued
+  // after it.
+  struct Tile { int cg, n, ox0, oy0, oz0; };
+  auto coords = [&](long tile) {
+    Tile t;
+    long b = tile;
+    t.cg = (int)(b % p.ncg); b /= p.ncg;
+    t.ox0 = (int)(b % p.ntx) * TX; b /= p.ntx;
+    t.oy0 = (int)(b % p.nty) * TY; b /= p.nty;
+    t.oz0 = (int)(b % p.ntz) * TZ;
+    t.n = (int)(b / p.ntz);
+    return t;
+  };
+  __amdgpu_buffer_rsrc_t xr;
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.bias ? (unsigned)p.Cout * 4u : 0u, 0x00020000);
   unsigned goff[NSLOT];
+  // halo origin + per-slot offsets of a tile; slots outside the image get an offset outside the descriptor -> zeros ('same' padding)
+  auto setup = [&](const Tile& t) {
+    const unsigned short* xorg = p.x + ((((long)t.n * p.D + (t.oz0 - 1)) * p.H + (t.oy0 - 1)) * p.W + (t.ox0 - 1)) * (long)p.ldx;
+    xr = __builtin_amdgcn_make_buffer_rsrc((void*)xorg, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-  for (int i = 0; i < NSLOT; ++i) {
-    const int e = tid + i * 256;
-    goff[i] = 0x80000000u;
-    if (e < NVOX * 2) {
-      const int vox = e >> 1, q = e & 1;
-      const int vz = vox / (SY * SX);
-      const int r = vox - vz * (SY * SX);
-      const int vy = r / SX, vx = r - vy * SX;
-      if ((unsigned)(oz0 - 1 + vz) < (unsigned)p.D && (unsigned)(oy0 - 1 + vy) < (unsigned)p.H && (unsigned)(ox0 - 1 + vx) < (unsigned)p.W)
-        goff[i] = (unsigned)(((vz * p.H + vy) * p.W + vx) * p.ldx + q * 8) * 2u;
+    for (int i = 0; i < NSLOT; ++i) {
+      const int e = tid + i * 256;
+      goff[i] = 0x80000000u;
+      if (e < NVOX * 2) {
+        const int vox = e >> 1, q = e & 1;
+        const int vz = vox / (SY * SX);
+        const int r = vox - vz * (SY * SX);
+        const int vy = r / SX, vx = r - vy * SX;
+        if ((unsigned)(t.oz0 - 1 + vz) < (unsigned)p.D && (unsigned)(t.oy0 - 1 + vy) < (unsigned)p.H && (unsigned)(t.ox0 - 1 + vx) < (unsigned)p.W)
+          goff[i] = (unsigned)(((vz * p.H + vy) * p.W + vx) * p.ldx + q * 8) * 2u;
+      }
     }
-  }
+  };
   u32x4 pre[NSLOT];
-  auto fetch = [&](int ks) {
+  auto fetch = [&](unsigned soff) {     // soff = k-step * 32 bytes, or 0x80000000: nothing to fetch (zeros, no traffic)
 #pragma unroll
-    for (int i = 0; i < NSLOT; ++i) pre[i] = bload16(xr, goff[i], (unsigned)ks * 32u);
+    for (int i = 0; i < NSLOT; ++i) pre[i] = bload16(xr, goff[i], soff);
   };
   auto commit = [&]() {
 #pragma unroll
@@ -239,14 +258,11 @@ __global__ __launch_bounds__(256, 2) void lp_conv_s1_kernel(const LpS1Params p) 
       if (e < NVOX * 2) *reinterpret_cast<u32x4*>(lds + (e >> 1) * LPS + (e & 1) * 8) = pre[i];
     }
   };
-  f32x16 acc[VB][CB];
-#pragma unroll
-  for (int v = 0; v < VB; ++v)
-#pragma unroll
-    for (int c = 0; c < CB; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[v][c][r] = 0.f;
-
+  auto bias_of = [&](const Tile& t) {   // thread i < 32*CB holds bias[cout block base + i]; out-of-range -> 0 (one request on every path)
+    const int co = t.cg * CB * 32 + tid;
+    const unsigned off = (tid < 32 * CB && co < p.Cout) ? (unsigned)co * 4u : 0x80000000u;
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, off, 0, 0));
+  };
   // this lane's B-operand base inside the tile: voxel (z = wave, y = ly, x = lx), channel half h
   const int bbase = ((wave * SY + ly) * SX + lx) * LPS + h * 8;
   const unsigned wlane = (unsigned)((h * 32 + l32) * 16);
@@ -257,132 +273,158 @@ __global__ __launch_bounds__(256, 2) void lp_conv_s1_kernel(const LpS1Params p) 
     ks1 = ks0 + p.ks_per;
     if (ks1 > p.KS) ks1 = p.KS;
   }
-  auto wfrag = [&](int t, int ks, int c) {
+  auto wfrag = [&](int t, int ks, int c, int cg) {
     const int cb = cg * CB + c;
     return bload16(wr, wlane, (unsigned)((((t * p.KS + ks) * p.NB) + (cb < p.NB ? cb : 0)) * 1024));
   };
-  if constexpr (R == 1) {
-    // 32-wide tiles: a wave's VB voxel blocks are VB consecutive y rows of its z plane, so for a fixed (dz, dx) the VB + 2 input
-    // rows it needs serve all three dy taps: (VB + 2) LDS reads feed 3 * VB * CB matrix instructions (one read per instruction
-    // otherwise -- with 32 couts the LDS port, not the matrix pipe, was the limit).  Taps run in (dz, dx) groups of three dy; the
-    // weights of group g live in a[g % 3] and are requested one group ahead.
-    // weights of group g live in a[g % WR], requested WD groups ahead (2 where the registers allow it: an L2 round trip is
-    // longer than one group's 12 matrix instructions); the input rows of group g+1 are read from LDS while group g computes
-    constexpr int WD = (CB == 1) ? 2 : 1, WR = 3;   // (9 groups per k-step: a ring of 3 keeps the slot of group g the same in every k-step)
-    u32x4 a[WR][3][CB];
-    auto wgroup = [&](u32x4 (&dst)[3][CB], int g, int ks) {
-      const int dz = g / 3, dx = g % 3;
+  constexpr bool ROWS = (R == 1);   // 32-wide tiles: input rows shared by the three dy taps
+  // weights: the tap consumed u-th in a k-step (ROWS: (dz, dx) groups of three dy, else plain tap order) lives in a[u % 9] and is
+  // requested WT taps ahead (27 % 9 == 0: the slot of a tap is the same in every k-step)
+  constexpr int WT = ROWS ? ((CB == 1) ? 6 : 3) : 2;
+  u32x4 a[9][CB];
+  auto tap_of = [](int u) { return ROWS ? (((u / 9) * 3 + (u % 3)) * 3 + (u / 3) % 3) : u; };   // u -> (dz, dy, dx) tap index
+  auto wtap = [&](int u, int ks, int cg) {
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
+    for (int c = 0; c < CB; ++c) a[u % 9][c] = wfrag(tap_of(u), ks, c, cg);
+  };
+
+  f32x16 acc[VB][CB];
+  long tile = blockIdx.x;
+  if (tile >= p.ntiles) return;
+  Tile cur = coords(tile);
+  setup(cur);
+  float bias_v = bias_of(cur);
+  fetch((unsigned)ks0 * 32u);
 #pragma unroll
-        for (int c = 0; c < CB; ++c) dst[dy][c] = wfrag((dz * 3 + dy) * 3 + dx, ks, c);
-    };
-    auto rows = [&](u32x4 (&bj)[VB + 2], int g) {
-      const int dz = g / 3, dx = g % 3;
+  for (int u = 0; u < WT; ++u) wtap(u, ks0, cur.cg);
+  for (; tile < p.ntiles; tile += gridDim.x) {
+    const bool have_next = tile + gridDim.x < p.ntiles;
+    const Tile nxt = have_next ? coords(tile + gridDim.x) : cur;
 #pragma unroll
-      for (int j = 0; j < VB + 2; ++j) bj[j] = *reinterpret_cast<const u32x4*>(lds + bbase + ((dz * SY + j) * SX + dx) * LPS);
-    };
-    fetch(ks0);
+    for (int v = 0; v < VB; ++v)
 #pragma unroll
-    for (int g = 0; g < WD; ++g) wgroup(a[g], g, ks0);
+      for (int c = 0; c < CB; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[v][c][r] = 0.f;
     for (int ks = ks0; ks < ks1; ++ks) {
-      __syncthreads();        // every wave is done reading the previous k-step's tile
+      __syncthreads();        // every wave is done reading the previous k-step's tile (and the previous tile's bias)
       commit();
+      if (ks == ks0 && tid < 32 * CB) bsh[tid] = bias_v;
       __syncthreads();
-      const bool more = ks + 1 < ks1;
-      if (more) fetch(ks + 1);
-      const int ksn = more ? ks + 1 : ks;   // (the last step re-requests its own first groups: same request count on every path)
-      u32x4 bj[2][VB + 2];
-      rows(bj[0], 0);
+      const bool last = ks + 1 == ks1;
+      if (last && have_next) {   // from here on the input-side state is the next tile's
+        setup(nxt);
+        bias_v = bias_of(nxt);
+      } else {
+        bias_v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, 0x80000000u, 0, 0));   // (same request count)
+      }
+      fetch(last ? (have_next ? (unsigned)ks0 * 32u : 0x80000000u) : (unsigned)(ks + 1) * 32u);
+      const int ksn = last ? ks0 : ks + 1;
+      const int cgn = last ? nxt.cg : cur.cg;
+      if constexpr (ROWS) {
+        // the input rows of group g+1 are read while group g computes -- where the registers allow it (4 x 2 tiles: 128 accumulators
+        // + weight ring + halo prefetch leave room for one row set only)
+        constexpr int NB_ = (VB * CB >= 8) ? 1 : 2;
+        u32x4 bj[NB_][VB + 2];
+        auto rows = [&](u32x4 (&dst)[VB + 2], int g) {
+          const int dz = g / 3, dx = g % 3;
 #pragma unroll
-      for (int g = 0; g < 9; ++g) {
-        wgroup(a[(g + WD) % WR], (g + WD) % 9, (g + WD < 9) ? ks : ksn);
-        if (g + 1 < 9) rows(bj[(g + 1) & 1], g + 1);
+          for (int j = 0; j < VB + 2; ++j) dst[j] = *reinterpret_cast<const u32x4*>(lds + bbase + ((dz * SY + j) * SX + dx) * LPS);
+        };
+        if (NB_ == 2) rows(bj[0], 0);
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+        for (int u = 0; u < 27; ++u) {
+          const int g = u / 3, dy = u % 3;
+          if (u + WT < 27) wtap(u + WT, ks, cur.cg); else wtap(u + WT - 27, ksn, cgn);
+          if (dy == 0) { if (NB_ == 2) { if (g + 1 < 9) rows(bj[(g + 1) % NB_], g + 1); } else rows(bj[0], g); }
 #pragma unroll
           for (int v = 0; v < VB; ++v)
 #pragma unroll
-            for (int c = 0; c < CB; ++c) acc[v][c] = T::mfma(a[g % WR][dy][c], bj[g & 1][v + dy], acc[v][c]);
-      }
-    }
-  } else {
-    // narrower tiles (small grids): weight fragments of tap t live in a[t % 3], two taps are always in flight (an L2 round
-    // trip is ~10x the 4-8 matrix instructions one tap feeds)
-    u32x4 a[3][CB];
-    auto wload = [&](u32x4 (&dst)[CB], int t, int ks) {
-#pragma unroll
-      for (int c = 0; c < CB; ++c) dst[c] = wfrag(t, ks, c);
-    };
-    fetch(ks0);
-    wload(a[0], 0, ks0);
-    wload(a[1], 1, ks0);
-    for (int ks = ks0; ks < ks1; ++ks) {
-      __syncthreads();        // every wave is done reading the previous k-step's tile
-      commit();
-      __syncthreads();
-      const bool more = ks + 1 < ks1;
-      if (more) fetch(ks + 1);
-      const int ksn = more ? ks + 1 : ks;   // (the last step re-requests its own first taps: same request count on every path)
-#pragma unroll
-      for (int t = 0; t < 27; ++t) {
-        const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
-        wload(a[(t + 2) % 3], (t + 2) % 27, (t + 2 < 27) ? ks : ksn);
-#pragma unroll
-        for (int v = 0; v < VB; ++v) {
-          const u32x4 bv = *reinterpret_cast<const u32x4*>(lds + bbase + ((dz * SY + (v * R + dy)) * SX + dx) * LPS);
-#pragma unroll
-          for (int c = 0; c < CB; ++c) acc[v][c] = T::mfma(a[t % 3][c], bv, acc[v][c]);
+            for (int c = 0; c < CB; ++c) acc[v][c] = T::mfma(a[u % 9][c], bj[g % NB_][v + dy], acc[v][c]);
         }
-      }
-    }
-  }
-  if (p.ksplit > 1) {   // raw fp32 partial sums [split][voxel][NB*32]; bias / rounding happen in the reduce kernel
-    const int oz = oz0 + wave, ox = ox0 + lx;
+      } else {
 #pragma unroll
-    for (int c = 0; c < CB; ++c) {
-      const int cb = cg * CB + c;
+        for (int t = 0; t < 27; ++t) {
+          const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+          if (t + WT < 27) wtap(t + WT, ks, cur.cg); else wtap(t + WT - 27, ksn, cgn);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+          for (int v = 0; v < VB; ++v) {
+            const u32x4 bv = *reinterpret_cast<const u32x4*>(lds + bbase + ((dz * SY + (v * R + dy)) * SX + dx) * LPS);
 #pragma unroll
-        for (int v = 0; v < VB; ++v) {
-          const int oy = oy0 + v * R + ly;
-          if (cb < p.NB && oz < p.D && oy < p.H && ox < p.W) {
-            float* dst = p.part + ((((long)blockIdx.y * p.N + n) * p.D + oz) * p.H + oy) * (long)p.W * (p.NB * 32) +
-                         (long)ox * (p.NB * 32) + cb * 32 + 8 * q + 4 * h;
-            *reinterpret_cast<f32x4*>(dst) = f32x4{acc[v][c][4 * q], acc[v][c][4 * q + 1], acc[v][c][4 * q + 2], acc[v][c][4 * q + 3]};
+            for (int c = 0; c < CB; ++c) acc[v][c] = T::mfma(a[t % 9][c], bv, acc[v][c]);
           }
         }
       }
     }
-    continue;
-  }
-  // epilogue: bias, convert, one 8-byte store per register quad
-  const int oz = oz0 + wave, ox = ox0 + lx;
+    // ---- output side of `cur` ----
+    const int oz = cur.oz0 + wave, ox = cur.ox0 + lx;
+    if (p.ksplit > 1) {   // raw fp32 partial sums [split][voxel][NB*32]; bias / rounding happen in the reduce kernel
 #pragma unroll
-  for (int c = 0; c < CB; ++c) {
-    const int cb = cg * CB + c;
+      for (int c = 0; c < CB; ++c) {
+        const int cb = cur.cg * CB + c;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int co = cb * 32 + 8 * q + 4 * h;
-      float bq[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias && cb < p.NB) {
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (co + j < p.Cout) bq[j] = p.bias[co + j];
+          for (int v = 0; v < VB; ++v) {
+            const int oy = cur.oy0 + v * R + ly;
+            if (cb < p.NB && oz < p.D && oy < p.H && ox < p.W) {
+              float* dst = p.part + ((((long)blockIdx.y * p.N + cur.n) * p.D + oz) * p.H + oy) * (long)p.W * (p.NB * 32) +
+                           (long)ox * (p.NB * 32) + cb * 32 + 8 * q + 4 * h;
+              *reinterpret_cast<f32x4*>(dst) = f32x4{acc[v][c][4 * q], acc[v][c][4 * q + 1], acc[v][c][4 * q + 2], acc[v][c][4 * q + 3]};
+            }
+          }
+        }
       }
+    } else if (p.Cout % 4 == 0) {
+      // bias from LDS, convert, one 8-byte buffer store per register quad (masked positions out of range)
+      const __amdgpu_buffer_rsrc_t yr =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long)cur.n * p.D * p.H * p.W * (long)p.ldy), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-      for (int v = 0; v < VB; ++v) {
-        const int oy = oy0 + v * R + ly;
-        if (cb < p.NB && oz < p.D && oy < p.H && ox < p.W && co < p.Cout) {
-          unsigned short* dst = p.y + ((((long)n * p.D + oz) * p.H + oy) * p.W + ox) * (long)p.ldy + co;
-          const float o0 = acc[v][c][4 * q] + bq[0], o1 = acc[v][c][4 * q + 1] + bq[1], o2 = acc[v][c][4 * q + 2] + bq[2],
-                      o3 = acc[v][c][4 * q + 3] + bq[3];
-          lp_store_quad<T>(dst, o0, o1, o2, o3, p.Cout - co, p.accum);
+      for (int c = 0; c < CB; ++c) {
+        const int cb = cur.cg * CB + c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = cb * 32 + 8 * q + 4 * h;
+          const f32x4 bq = *reinterpret_cast<const f32x4*>(bsh + c * 32 + 8 * q + 4 * h);
+#pragma unroll
+          for (int v = 0; v < VB; ++v) {
+            const int oy = cur.oy0 + v * R + ly;
+            const bool ok = cb < p.NB && co < p.Cout && oz < p.D && oy < p.H && ox < p.W;
+            const unsigned off = ok ? (unsigned)((((oz * p.H + oy) * p.W + ox) * p.ldy + co) * 2) : 0x80000000u;
+            float o0 = acc[v][c][4 * q] + bq[0], o1 = acc[v][c][4 * q + 1] + bq[1], o2 = acc[v][c][4 * q + 2] + bq[2],
+                  o3 = acc[v][c][4 * q + 3] + bq[3];
+            if (p.accum) {
+              const u32x2 old = bload8(yr, off);
+              o0 += T::ld((unsigned short)(old[0] & 0xffffu)); o1 += T::ld((unsigned short)(old[0] >> 16));
+              o2 += T::ld((unsigned short)(old[1] & 0xffffu)); o3 += T::ld((unsigned short)(old[1] >> 16));
+            }
+            bstore8(yr, off, u32x2{pack2<T>(o0, o1), pack2<T>(o2, o3)});
+          }
+        }
+      }
+    } else {
+      // heads with fewer than four output channels per quad: element-wise stores
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        const int cb = cur.cg * CB + c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = cb * 32 + 8 * q + 4 * h;
+          const f32x4 bq = *reinterpret_cast<const f32x4*>(bsh + c * 32 + 8 * q + 4 * h);
+#pragma unroll
+          for (int v = 0; v < VB; ++v) {
+            const int oy = cur.oy0 + v * R + ly;
+            if (cb < p.NB && oz < p.D && oy < p.H && ox < p.W && co < p.Cout) {
+              unsigned short* dst = p.y + ((((long)cur.n * p.D + oz) * p.H + oy) * p.W + ox) * (long)p.ldy + co;
+              lp_store_quad<T>(dst, acc[v][c][4 * q] + bq[0], acc[v][c][4 * q + 1] + bq[1], acc[v][c][4 * q + 2] + bq[2],
+                               acc[v][c][4 * q + 3] + bq[3], p.Cout - co, p.accum);
+            }
+          }
         }
       }
     }
+    cur = nxt;
   }
-  }   // tile loop
 }
 
 // finish of a split-K launch: y = round(bias + sum_z part[z]) in fixed order
@@ -430,7 +472,8 @@ static int lp_s1_launch(LpS1Params p, void* ws, long ws_bytes, hipStream_t strea
     p.ksplit = (p.KS + p.ks_per - 1) / p.ks_per;
     if (ws == nullptr || ws_bytes < (long)p.ksplit * nvox * p.NB * 32 * 4 || (((uintptr_t)ws) & 15)) { p.ksplit = 1; p.ks_per = p.KS; }
   }
-  const size_t shmem = (size_t)(TX + 2) * (TY + 2) * (TZ + 2) * LPS * 2;
+  const size_t shmem = (size_t)(TX + 2) * (TY + 2) * (TZ + 2) * LPS * 2 + 32 * CB * 4;   // halo tile + the tile's bias values
+  if ((long)p.D * p.H * p.W * (long)p.ldy * 2 >= 0x7fffff00L) return BTS_ERR_SHAPE;   // 31-bit output offsets inside one sample
   auto kern = lp_conv_s1_kernel<T, VB, CB, TXL>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -465,6 +508,7 @@ static void lp_s1_shape(int N, int D, int H, int W, int NB, int& vb, int& cb, in
   cb = NB >= 2 ? 2 : 1;
   const long vox = (long)N * D * H * W;
   vb = vox >= 4096 ? 4 : (vox >= 1024 ? 2 : 1);
+  if (vb == 4 && txl == 5) cb = 1;   // 4 x 2 tiles (128 accumulators + weight ring + halo prefetch) spill at two waves per SIMD
 }
 static long lp_s1_wgs(int N, int D, int H, int W, int NB, int vb, int cb, int txl) {
   const int TX = 1 << txl, TY = vb * (32 / TX);
