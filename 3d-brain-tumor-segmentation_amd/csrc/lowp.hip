@@ -1309,7 +1309,7 @@ struct LpWgParams {
 #define LPW_TY 8
 #define LPW_TZ 4
 
-template <typename T, int NQ>
+template <typename T, int NQ, bool K3>
 __global__ __launch_bounds__(512, 1) void lp_wgrad_kernel(const LpWgParams p) {
   constexpr int TX = LPW_TX, TY = LPW_TY, TZ = LPW_TZ;
   constexpr int PS = 36, QS = 32 * NQ + 4;          // halves per staged voxel (8-byte aligned rows, bank-skewed)
@@ -1317,10 +1317,10 @@ __global__ __launch_bounds__(512, 1) void lp_wgrad_kernel(const LpWgParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l32 = lane & 31;
-  const bool k3 = p.ntaps == 27;
-  const int halo = k3 ? 1 : 0;
-  const int SX = TX + 2 * halo, SY = TY + 2 * halo, SZ = TZ + 2 * halo;
-  const int nvp = SX * SY * SZ;
+  constexpr bool k3 = K3;
+  constexpr int halo = K3 ? 1 : 0;
+  constexpr int SX = TX + 2 * halo, SY = TY + 2 * halo, SZ = TZ + 2 * halo;
+  constexpr int nvp = SX * SY * SZ;
   unsigned short* ldsP = lds;
   unsigned short* ldsQ = lds + (TX + 2) * (TY + 2) * (TZ + 2) * PS;
   const int cpt = blockIdx.y / p.ncqg, cqg = blockIdx.y % p.ncqg;
@@ -1403,23 +1403,36 @@ __global__ __launch_bounds__(512, 1) void lp_wgrad_kernel(const LpWgParams p) {
     commit();
     __syncthreads();
     if (tile + gridDim.x < p.ntiles) fetch(tile + gridDim.x);
-    if (k3) {
-      // wave w owns taps w, w+8, w+16 (and w+24 for w < 3) and walks all 32 x-rows of the tile
-#pragma unroll 2
+    if constexpr (K3) {
+      // wave w owns taps w, w+8, w+16 (and w+24 for w < 3) and walks all 32 x-rows of the tile; the taps' LDS offsets are
+      // wave constants, the rows' offsets compile-time ones
+      int toff[4];
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        const int t = wave + 8 * ti;
+        const int tt = t < 27 ? t : 0;
+        toff[ti] = (((tt / 9) * SY + (tt / 3) % 3) * SX + tt % 3) * PS;
+      }
+      const bool t3 = wave + 24 < 27;
+      const unsigned short* pbase = ldsP + 8 * h * PS + l32;
+      const unsigned short* qbase = ldsQ + 8 * h * QS + l32;
+#pragma unroll 4
       for (int kb = 0; kb < TY * TZ; ++kb) {
         const int z = kb / TY, y = kb % TY;
         u32x4 bq[NQ];
 #pragma unroll
-        for (int c = 0; c < NQ; ++c) bq[c] = gather(ldsQ + ((z * TY + y) * TX + 8 * h) * QS + c * 32 + l32, QS);
+        for (int c = 0; c < NQ; ++c) bq[c] = gather(qbase + ((z * TY + y) * TX) * QS + c * 32, QS);
+        const unsigned short* prow = pbase + ((z * SY + y) * SX) * PS;
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-          const int t = wave + 8 * ti;
-          if (t < 27) {
-            const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
-            const u32x4 a = gather(ldsP + (((z + dz) * SY + (y + dy)) * SX + 8 * h + dx) * PS + l32, PS);
+        for (int ti = 0; ti < 3; ++ti) {
+          const u32x4 a = gather(prow + toff[ti], PS);
 #pragma unroll
-            for (int c = 0; c < NQ; ++c) acc[ti][c] = T::mfma(a, bq[c], acc[ti][c]);
-          }
+          for (int c = 0; c < NQ; ++c) acc[ti][c] = T::mfma(a, bq[c], acc[ti][c]);
+        }
+        if (t3) {
+          const u32x4 a = gather(prow + toff[3], PS);
+#pragma unroll
+          for (int c = 0; c < NQ; ++c) acc[3][c] = T::mfma(a, bq[c], acc[3][c]);
         }
       }
     } else {
@@ -1544,9 +1557,9 @@ extern "C" int bts_lp_conv3d_bwd_weight(int kind, int dtype, const void* x, cons
   p.ntx = (W + LPW_TX - 1) / LPW_TX; p.nty = (H + LPW_TY - 1) / LPW_TY; p.ntz = (D + LPW_TZ - 1) / LPW_TZ;
   const size_t shmem = ((size_t)(LPW_TX + 2) * (LPW_TY + 2) * (LPW_TZ + 2) * 36 + (size_t)LPW_TX * LPW_TY * LPW_TZ * (32 * nq + 4)) * 2;
   (void)hipGetLastError();
-#define LPW_LAUNCH(TT, NQ_)                                                                                                   \
+#define LPW_LAUNCH(TT, NQ_, K3_)                                                                                                \
   do {                                                                                                                        \
-    auto kern = lp_wgrad_kernel<TT, NQ_>;                                                                                     \
+    auto kern = lp_wgrad_kernel<TT, NQ_, K3_>;                                                                                \
     static bool done = false;                                                                                                 \
     if (!done) {                                                                                                              \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -1555,8 +1568,14 @@ extern "C" int bts_lp_conv3d_bwd_weight(int kind, int dtype, const void* x, cons
     }                                                                                                                         \
     hipLaunchKernelGGL(kern, dim3(nwg, p.ncp * p.ncqg), dim3(512), shmem, stream, p);                                         \
   } while (0)
-  if (dtype == LP_F16) { if (nq == 2) LPW_LAUNCH(TF16, 2); else LPW_LAUNCH(TF16, 1); }
-  else { if (nq == 2) LPW_LAUNCH(TBF16, 2); else LPW_LAUNCH(TBF16, 1); }
+  const bool k3 = kind == BTS_CONV_K3S1;
+  if (dtype == LP_F16) {
+    if (k3) { if (nq == 2) LPW_LAUNCH(TF16, 2, true); else LPW_LAUNCH(TF16, 1, true); }
+    else { if (nq == 2) LPW_LAUNCH(TF16, 2, false); else LPW_LAUNCH(TF16, 1, false); }
+  } else {
+    if (k3) { if (nq == 2) LPW_LAUNCH(TBF16, 2, true); else LPW_LAUNCH(TBF16, 1, true); }
+    else { if (nq == 2) LPW_LAUNCH(TBF16, 2, false); else LPW_LAUNCH(TBF16, 1, false); }
+  }
 #undef LPW_LAUNCH
   BTS_LAUNCH_CHECK();
   LpWfParams f;
