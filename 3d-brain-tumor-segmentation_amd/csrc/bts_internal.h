@@ -13,3 +13,7 @@ long bts_wino_workspace_(int N, int D, int H, int W, int Cin, int Cout);
 // conv_igemm.hip: y (+)= bias + sum_z part[z][voxel][Npad]  (finish of a split-K launch, fixed summation order)
 int bts_igemm_reduce_(const float* part, const float* bias, float* y, long nvox, int Cout, int Npad, int ldy, int ksplit,
                       int with_bias, int accum, hipStream_t stream);
+// se.hip: stages 2a + 2 of the gate backward (sum the per-block partials [n][b][F][{ch, w}], SE-MLP backward, dgap / V)
+int bts_se_bwd_middle_(double* partial, double* red, double* scratch, const float* gap, const float* h, const float* ch, const float* w1,
+                       const float* w2, float* dw1, float* dw2, float* dwsp, float* dgap, int N, int B, long V, int F, int R,
+                       int accumulate_params, hipStream_t stream);

@@ -1598,3 +1598,121 @@ extern "C" int bts_lp_conv3d_bwd_weight(int kind, int dtype, const void* x, cons
   }
   return BTS_OK;
 }
+
+// =====================================================================================================================
+// Gate (squeeze-excitation) backward on 16-bit tensors (resnet.py:121-130 under TF autodiff): with g = dout * res per element,
+//   t_v = sum_c g, ds_v = t_v sp_v (1 - sp_v)            (spatial gate, fp32 per voxel)
+//   Pch[n][c] = sum_v g, Pw[c] = sum_v ds_v res          (per-block partials, fp64, layout of se.hip; stages 2a / 2 are se.hip's)
+//   dres = dout (sp + ch) + ds w_sp + dgap / V           (written in the storage type)
+// =====================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void lp_se_bwd_reduce_kernel(const unsigned short* dout, const unsigned short* res, const float* sp,
+                                                               float* ds_out, double* partial, long V, int F, int lddo, long vspan) {
+  __shared__ double sh[256 * 16];
+  const int F8 = F >> 3;
+  const int vpb = 256 / F8;
+  const int lg = threadIdx.x % F8, vl = threadIdx.x / F8;
+  const int c = lg * 8;
+  const long n = blockIdx.y;
+  const long v0 = (long)blockIdx.x * vspan;
+  long v1 = v0 + vspan;
+  if (v1 > V) v1 = V;
+  double a[8], b[8];
+  float fa[8], fb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] = b[e] = 0.0; fa[e] = fb[e] = 0.f; }
+  int cnt = 0;
+  for (long vv = v0 + vl; vv < v1; vv += vpb) {
+    const long v = n * V + vv;
+    float r[8], d[8];
+    unpack8<T>(*reinterpret_cast<const u32x4*>(res + v * F + c), r);
+    unpack8<T>(*reinterpret_cast<const u32x4*>(dout + v * lddo + c), d);
+    float t = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t = fmaf(d[e], r[e], t);
+    for (int o = F8 >> 1; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    const float s = sp[v];
+    const float dsv = t * s * (1.f - s);
+    if (lg == 0) ds_out[v] = dsv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { fa[e] = fmaf(d[e], r[e], fa[e]); fb[e] = fmaf(dsv, r[e], fb[e]); }
+    if (++cnt == 64) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a[e] += fa[e]; b[e] += fb[e]; fa[e] = fb[e] = 0.f; }
+      cnt = 0;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sh[threadIdx.x * 16 + e] = a[e] + fa[e]; sh[threadIdx.x * 16 + 8 + e] = b[e] + fb[e]; }
+  __syncthreads();
+  for (int col = threadIdx.x; col < F; col += 256) {
+    const int e = col & 7, l = col >> 3;
+    double sa = 0.0, sb = 0.0;
+    for (int k = 0; k < vpb; ++k) { sa += sh[(k * F8 + l) * 16 + e]; sb += sh[(k * F8 + l) * 16 + 8 + e]; }
+    const long o = (((long)n * gridDim.x + blockIdx.x) * F + col) * 2;
+    partial[o] = sa;
+    partial[o + 1] = sb;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void lp_se_bwd_apply_kernel(const unsigned short* dout, const float* sp, const float* ds, const float* ch,
+                                                              const float* wsp, const float* dgap, unsigned short* dres, long NV, long V, int F,
+                                                              int lddo) {
+  const int F8 = F >> 3;
+  const long total = NV * F8;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long v = i / F8;
+    const int c = (int)(i - v * F8) * 8;
+    const long n = v / V;
+    float d[8], o[8];
+    unpack8<T>(*reinterpret_cast<const u32x4*>(dout + v * lddo + c), d);
+    const float s = sp[v], dsv = ds[v];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = fmaf(d[e], s + ch[n * F + c + e], fmaf(dsv, wsp[c + e], dgap[n * F + c + e]));
+    *reinterpret_cast<u32x4*>(dres + v * F + c) = pack8<T>(o);
+  }
+}
+static int lp_se_blocks(long V, int N, int F, long* vspan) {
+  const int vpb = 256 / (F / 8);
+  long B = (1024 + N - 1) / N;
+  if (B > 512) B = 512;
+  long span = (V + B - 1) / B;
+  span = (span + vpb - 1) / vpb * vpb;
+  *vspan = span;
+  return (int)((V + span - 1) / span);
+}
+extern "C" long bts_lp_se_bwd_workspace(int N, long V, int F, int R) {
+  if (N <= 0 || V <= 0 || F < 8 || R <= 0) return -1;
+  long vspan;
+  const int B = lp_se_blocks(V, N, F, &vspan);
+  return (long)N * B * F * 2 * 8 + ((long)N * F * 3 + (long)N * R) * 8 + 128;
+}
+// dout rows of stride lddo, res dense, both in the storage type; sp fp32 [N*V] (bts_lp_block_epilogue's sp_out); gap / h / ch from the forward.
+// Outputs: dres dense in the storage type, ds [N*V] and dgap [N*F] fp32 scratch, parameter gradients fp32 (+= when accumulate_params).
+extern "C" int bts_lp_se_bwd(int dtype, const void* dout, const void* res, const float* sp, const float* gap, const float* h, const float* ch,
+                             const float* w1, const float* w2, const float* wsp, void* dres, float* ds, float* dgap, float* dw1, float* dw2,
+                             float* dwsp, void* workspace, long workspace_bytes, int N, long V, int F, int R, int lddo, int accumulate_params,
+                             hipStream_t stream) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  if (N <= 0 || V <= 0 || F < 8 || (F & (F - 1)) || F > 256 || lddo < F || lddo % 8) return BTS_ERR_SHAPE;
+  if ((((uintptr_t)dout) & 15) || (((uintptr_t)res) & 15) || (((uintptr_t)dres) & 15)) return BTS_ERR_ALIGN;
+  if (workspace_bytes < bts_lp_se_bwd_workspace(N, V, F, R)) return BTS_ERR_WORKSPACE;
+  long vspan;
+  const int B = lp_se_blocks(V, N, F, &vspan);
+  double* partial = reinterpret_cast<double*>(workspace);
+  double* red = partial + (long)N * B * F * 2;
+  double* scratch = red + (long)N * F * 2;
+  (void)hipGetLastError();
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_se_bwd_reduce_kernel<TF16>, dim3(B, N), dim3(256), 0, stream, (const unsigned short*)dout, (const unsigned short*)res, sp, ds, partial, V, F, lddo, vspan);
+  else hipLaunchKernelGGL(lp_se_bwd_reduce_kernel<TBF16>, dim3(B, N), dim3(256), 0, stream, (const unsigned short*)dout, (const unsigned short*)res, sp, ds, partial, V, F, lddo, vspan);
+  BTS_LAUNCH_CHECK();
+  const int r = bts_se_bwd_middle_(partial, red, scratch, gap, h, ch, w1, w2, dw1, dw2, dwsp, dgap, N, B, V, F, R, accumulate_params, stream);
+  if (r != BTS_OK) return r;
+  const long total = (long)N * V * (F / 8);
+  long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_se_bwd_apply_kernel<TF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)dout, sp, ds, ch, wsp, dgap, (unsigned short*)dres, (long)N * V, V, F, lddo);
+  else hipLaunchKernelGGL(lp_se_bwd_apply_kernel<TBF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)dout, sp, ds, ch, wsp, dgap, (unsigned short*)dres, (long)N * V, V, F, lddo);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}

@@ -351,6 +351,18 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const float* __restri
   }
 }
 
+// stages 2a + 2 for callers that produced the per-block partials themselves (lowp.hip: 16-bit dout / res), same layouts as above
+int bts_se_bwd_middle_(double* partial, double* red, double* scratch, const float* gap, const float* h, const float* ch, const float* w1,
+                       const float* w2, float* dw1, float* dw2, float* dwsp, float* dgap, int N, int B, long V, int F, int R,
+                       int accumulate_params, hipStream_t stream) {
+  (void)hipGetLastError(); hipLaunchKernelGGL(se_bwd_partial_reduce_kernel, dim3((N * F + 3) / 4), dim3(256), 0, stream, partial, red, N, B, F);
+  BTS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(1), dim3(256), 0, stream, red, gap, h, ch, w1, w2, dw1, dw2, dwsp, dgap, scratch, N, B, F, R,
+                     1.0 / (double)V, accumulate_params);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
 static int se_bwd_blocks(long V, int N, int F, long* vspan) {
   const int vpb = 256 / (F / 4);
   long B = (1024 + N - 1) / N;

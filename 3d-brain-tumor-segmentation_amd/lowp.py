@@ -173,6 +173,21 @@ def block_epilogue(code, res, c2, out, wsp, ch, gamma, beta, mean, rstd, groups,
     return out
 
 
+def se_bwd(code, tdt, dout, res, sp, gap, h, ch, w1, w2, wsp, dw1, dw2, dwsp):
+    """gate backward on 16-bit tensors -> dres (storage type, dense); parameter gradients accumulate"""
+    n, f = res.shape[0], res.shape[4]
+    v = res.shape[1] * res.shape[2] * res.shape[3]
+    r = w1.shape[1]
+    nb = lib().query('bts_lp_se_bwd_workspace', n, v, f, r)
+    ws = ops.workspace(nb, res.device)
+    dres = torch.empty_like(res)
+    ds = torch.empty(n * v, dtype=torch.float32, device=res.device)
+    dgap = torch.empty((n, f), dtype=torch.float32, device=res.device)
+    lib().call('bts_lp_se_bwd', code, _p(dout), _p(res), _p(sp), _p(gap), _p(h), _p(ch), _p(w1), _p(w2), _p(wsp), _p(dres), _p(ds), _p(dgap),
+               _p(dw1), _p(dw2), _p(dwsp), _p(ws), nb, n, v, f, r, _ld(dout), 1, _stream())
+    return dres
+
+
 def head(code, x, w, bias, sigmoid=True):
     n, d, h, wd, c = x.shape
     k = w.shape[-1]

@@ -136,7 +136,6 @@ class LowPrecisionTrainer(object):
         cin_slab = s['cin_slab']
         lp2 = lowp.wgrad_supported(ops.K3S1, f, f)                       # conv2's weight gradient on the 16-bit kernel?
         lp1 = lowp.wgrad_supported(ops.K3S1, cin_slab, f) and cin_slab == x.shape[-1]   # conv1 / shortcut (not the padded 2-channel input)
-        dout32 = self._f32(dout)
         # conv branch: GN2 (+ReLU) -> conv2 -> GN1 (+ReLU) -> conv1
         dc2_16, dc2 = self._gn_bwd(n2, s['c2'], dout, s['m2'], s['r2'], want_f32=not lp2)
         if lp2:
@@ -152,12 +151,11 @@ class LowPrecisionTrainer(object):
         del dc2, dc2_16
         dc1_16, dc1 = self._gn_bwd(n1, s['c1'], da, s['m1'], s['r1'], want_f32=not lp1)
         del da
-        # gate branch
-        dres = ops.se_bwd(dout32, self._f32(s['res']), s['sp'], s['gap'], s['hbuf'], s['ch'], blk.se_w1.t, blk.se_w2.t,
-                          blk.spatial_k.t.reshape(-1), self._gslot(blk.se_w1), self._gslot(blk.se_w2),
-                          self._gslot(blk.spatial_k).reshape(-1), accumulate_params=True)
-        del dout32
-        dres_16 = self._b16(dres)
+        # gate branch (16-bit kernels; fp32 copies only where a weight gradient still runs on the fp32 kernels)
+        dres_16 = lowp.se_bwd(code, self.tdt, dout, s['res'], s['sp'], s['gap'], s['hbuf'], s['ch'], blk.se_w1.t, blk.se_w2.t,
+                              blk.spatial_k.t.reshape(-1), self._gslot(blk.se_w1), self._gslot(blk.se_w2),
+                              self._gslot(blk.spatial_k).reshape(-1))
+        dres = None if lp1 else self._f32(dres_16)
         # weight gradients of the two convolutions that read the block input
         if lp1:
             def wgrads():

@@ -284,6 +284,12 @@ int bts_lp_colsum(int dtype, const void* x, float* out, void* workspace, long wo
 int bts_lp_block_epilogue(int dtype, const void* res, const void* c2, void* out, float* sp_out, const float* wsp, const float* ch, const float* gamma,
                           const float* beta, const float* mean, const float* rstd, int N, long V, int C, int ldo, int G, int mode,
                           bts_stream_t stream);
+/* gate backward (resnet.py:121-130 under autodiff) on 16-bit dout / res -> dres in the storage type; fp32 parameter gradients;
+ * sp = the sp_out of bts_lp_block_epilogue; ds [N*V] and dgap [N*F] are fp32 scratch outputs */
+long bts_lp_se_bwd_workspace(int N, long V, int F, int R);
+int bts_lp_se_bwd(int dtype, const void* dout, const void* res, const float* sp, const float* gap, const float* h, const float* ch,
+                  const float* w1, const float* w2, const float* wsp, void* dres, float* ds, float* dgap, float* dw1, float* dw2, float* dwsp,
+                  void* workspace, long workspace_bytes, int N, long V, int F, int R, int lddo, int accumulate_params, bts_stream_t stream);
 /* output head (decoder.py:55-63): y = sigmoid(x . W + b), W (C, K <= 4) fp32, y fp32 (the label map is taken from it) */
 int bts_lp_head(int dtype, const void* x, const float* w, const float* bias, float* y, long nvox, int C, int ldx, int K, int sigmoid,
                 bts_stream_t stream);

@@ -376,3 +376,38 @@ def test_weight_gradient_kernel(case, dtype):
     assert float((err / bound).max()) <= 1.0, 'dw: max err %.3e at %.2fx the bound' % (float(err.max()), float((err / bound).max()))
     eb = (db.double().cpu() - (db_ref + db0.double())).abs()
     assert float(eb.max()) <= 1e-5 * float(db_ref.abs().max()) + 1e-5
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('shape', [(2, 8, 16, 16, 16), (1, 6, 10, 12, 32), (2, 4, 4, 8, 128), (1, 2, 4, 4, 256)])
+def test_gate_backward_kernel(shape, dtype):
+    """16-bit gate (squeeze-excitation) backward against the fp32 engine's kernel (pinned to the oracle by tests/test_kernels_gpu.py) on
+    the same rounded dout / res: dres in the storage type, SE-MLP and spatial-gate parameter gradients accumulated onto non-zero
+    buffers; dout arrives as a channel slice of a wider slab; ragged voxel counts"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    code, tdt = lowp.DTYPES[dtype]
+    n, d, h, w, f = shape
+    r = f // 2
+    g = torch.Generator().manual_seed(f + d)
+    res = torch.randn(shape, generator=g).to(tdt).to(DEV)
+    slab = torch.randn((n, d, h, w, f + 16), generator=g).to(tdt).to(DEV)
+    dout = slab[..., 8:8 + f]
+    sp = torch.sigmoid(torch.randn((n, d, h, w, 1), generator=g)).to(DEV).contiguous()
+    gap = torch.randn((n, f), generator=g).to(DEV)
+    w1 = (0.3 * torch.randn((f, r), generator=g)).to(DEV)
+    w2 = (0.3 * torch.randn((r, f), generator=g)).to(DEV)
+    wsp = (0.3 * torch.randn(f, generator=g)).to(DEV)
+    hbuf, ch = ops.se_mlp_fwd(gap, w1, w2)
+    res32, dout32 = lowp.uncast(code, res), lowp.uncast(code, dout)
+    init = [torch.randn(t.shape, generator=g).to(DEV) for t in (w1, w2, wsp)]
+    ref_g = [t.clone() for t in init]
+    dres_r = ops.se_bwd(dout32, res32, sp, gap, hbuf, ch, w1, w2, wsp, *ref_g, accumulate_params=True)
+    got_g = [t.clone() for t in init]
+    dres = lowp.se_bwd(code, tdt, dout, res, sp, gap, hbuf, ch, w1, w2, wsp, *got_g)
+    torch.cuda.synchronize()
+    assert dres.dtype == tdt and dres.shape == res.shape
+    scale = float(dres_r.abs().max())
+    assert float((dres.float() - dres_r).abs().max()) <= U[dtype] * scale * 1.01 + 2e-5 * scale
+    for a, b in zip(got_g, ref_g):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-5
