@@ -10,6 +10,10 @@ int bts_gn_finalize_partials_(const double* partial, float* mean, float* rstd, i
 int bts_wino_launch_(const float* x, const float* up, const float* bias, float* y, int N, int D, int H, int W, int Cin, int ldx,
                      int Cout, int ldy, int accum, double* gnp, int gnG, long* gn_B, void* ws, long ws_bytes, hipStream_t stream);
 long bts_wino_workspace_(int N, int D, int H, int W, int Cin, int Cout);
+// conv_wino3.hip: the same convolution in Winograd F(2x2x2,3x3x3) form on the third part of the K3S1 image; offered first
+int bts_w3_launch_(const float* x, const float* up3, const float* bias, float* y, int N, int D, int H, int W, int Cin, int ldx,
+                   int Cout, int ldy, int accum, double* gnp, int gnG, long* gn_B, void* ws, long ws_bytes, hipStream_t stream);
+long bts_w3_workspace_(int N, int D, int H, int W, int Cin, int Cout);
 // conv_igemm.hip: y (+)= bias + sum_z part[z][voxel][Npad]  (finish of a split-K launch, fixed summation order)
 int bts_igemm_reduce_(const float* part, const float* bias, float* y, long nvox, int Cout, int Npad, int ldy, int ksplit,
                       int with_bias, int accum, hipStream_t stream);

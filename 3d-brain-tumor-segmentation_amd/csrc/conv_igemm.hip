@@ -538,6 +538,8 @@ struct PackParams {
   int cin_is_k;     // 1: the (possibly folded) input-channel axis is k, 0: it is n, -1: no fold
   int shift, dup_start;
   long wino_off;    // K3S1 images: element index where the Winograd part starts; otherwise beyond the image
+  long w3_item0;    // K3S1 images: first work item of the 3-D Winograd part (conv_wino3.hip); its floats start at w3_off
+  long w3_off;
   long total;       // floats of the whole image
   long items;       // work items (pack_item): implicit-GEMM floats + Winograd positions (16 floats each)
 };
@@ -566,7 +568,46 @@ __device__ __forceinline__ float pack_src(const PackParams& q, int t, int k, int
 // 16 transform points of one (cout block, k-group, x tap, half, cout, cin) position of the Winograd part (conv_wino.hip):
 // U = G g G^T over the (z, y) taps, layout [cout block of 32][k-group][x tap][xi_z*4 + xi_y][half][32][4]; the 9 source
 // taps are read once.  rows of G: (1 0 0) (.5 .5 .5) (.5 -.5 .5) (0 0 1)
+__device__ __forceinline__ float pack_g_(int r, float g0, float g1, float g2) {   // row r of G applied to three taps
+  return r == 0 ? g0 : r == 1 ? fmaf(0.5f, g2, fmaf(0.5f, g1, 0.5f * g0)) : r == 2 ? fmaf(0.5f, g2, fmaf(-0.5f, g1, 0.5f * g0)) : g2;
+}
 __device__ __forceinline__ void pack_item(const PackParams& q, long i) {
+  if (i >= q.w3_item0) {
+    // third part: U = (G x G x G) g over all 27 taps, 64 transform points xi = (xi_z*4 + xi_y)*4 + xi_x per (cin, cout) pair,
+    // layout [cout block of 32][k-group of 8 cin][xi][half][32 couts][4 cin] (conv_wino3.hip)
+    long r = i - q.w3_item0;
+    const int j = (int)(r & 3);
+    const int n32 = (int)((r >> 2) & 31);
+    const int hh = (int)((r >> 7) & 1);
+    r >>= 8;
+    const int kg = (int)(r % q.KG);
+    const int cb = (int)(r / q.KG);
+    const int k = kg * 8 + hh * 4 + j, n = cb * 32 + n32;
+    float t[4][3][3], u[4][4][3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float g0 = pack_src(q, (0 * 3 + ky) * 3 + kx, k, n), g1 = pack_src(q, (1 * 3 + ky) * 3 + kx, k, n),
+                    g2 = pack_src(q, (2 * 3 + ky) * 3 + kx, k, n);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) t[a][ky][kx] = pack_g_(a, g0, g1, g2);
+      }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) u[a][b][kx] = pack_g_(b, t[a][0][kx], t[a][1][kx], t[a][2][kx]);
+    float* o = q.wp + q.w3_off + (((long)cb * q.KG + kg) * 64) * 256 + hh * 128 + n32 * 4 + j;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[((a * 4 + b) * 4 + c) * 256] = pack_g_(c, u[a][b][0], u[a][b][1], u[a][b][2]);
+    return;
+  }
   if (i >= q.wino_off) {
     long r = i - q.wino_off;
     const int j = (int)(r & 3);
@@ -643,8 +684,8 @@ extern "C" long bts_conv_packed_floats(int kind, int role, int Cin, int Cout) {
   const int ntaps = (kind == BTS_CONV_K1) ? 1 : 27;
   const int K = (role == BTS_ROLE_FWD) ? Cin : Cout;
   const int N = (role == BTS_ROLE_FWD) ? Cout : Cin;
-  // K3S1 images carry a second, Winograd-domain copy (16 transform points x 3 x taps) for conv_wino.hip
-  return (long)(ntaps + (kind == BTS_CONV_K3S1 ? 48 : 0)) * ((K + 7) / 8) * 2 * npad32(N) * 4;
+  // K3S1 images carry two Winograd-domain copies: 16 transform points x 3 x taps (conv_wino.hip), 64 points (conv_wino3.hip)
+  return (long)(ntaps + (kind == BTS_CONV_K3S1 ? 48 + 64 : 0)) * ((K + 7) / 8) * 2 * npad32(N) * 4;
 }
 
 static int pack_params(PackParams& q, int kind, int role, const float* w, float* wp, int Cin_ref, int Cout, int Cin_slab,
@@ -671,8 +712,11 @@ static int pack_params(PackParams& q, int kind, int role, const float* w, float*
   q.Npad = npad32(q.N);
   const long ig = (long)q.ntaps * q.KG * 2 * q.Npad * 4;
   q.wino_off = (kind == BTS_CONV_K3S1) ? ig : (1L << 62);
-  q.total = ig + ((kind == BTS_CONV_K3S1) ? 48L * q.KG * 2 * q.Npad * 4 : 0L);
-  q.items = ig + ((kind == BTS_CONV_K3S1) ? 3L * q.KG * 2 * q.Npad * 4 : 0L);
+  const long pairs = (long)q.KG * 2 * q.Npad * 4;   // (contraction index, column) pairs of the padded image
+  q.total = ig + ((kind == BTS_CONV_K3S1) ? (48L + 64L) * pairs : 0L);
+  q.items = ig + ((kind == BTS_CONV_K3S1) ? (3L + 1L) * pairs : 0L);
+  q.w3_item0 = (kind == BTS_CONV_K3S1) ? ig + 3L * pairs : (1L << 62);
+  q.w3_off = ig + 48L * pairs;
   return BTS_OK;
 }
 
@@ -1502,9 +1546,13 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
   if (geo == GEO_S1 && need_out == nullptr && !(flags & IG_FLAG_SIGMOID)) {
     // Winograd form (conv_wino.hip) on the second part of the K3S1 image; the fused shortcut output / second input of the
     // pair entry points then run as their own 1x1x1 launches
-    const float* up = wp + 27L * ((Cin + 7) / 8) * 2 * npad32(Cout) * 4;
-    const int r = bts_wino_launch_(x, up, (flags & IG_FLAG_BIAS) ? bias : nullptr, y, N, Di, Hi, Wi, Cin, ldx, Cout, ldy,
-                                   (flags & IG_FLAG_ACCUM) ? 1 : 0, gnp, gnG, gn_B, ws, ws_bytes, stream);
+    const long pairs = (long)((Cin + 7) / 8) * 2 * npad32(Cout) * 4;
+    const float* up = wp + 27L * pairs;
+    int r = bts_w3_launch_(x, up + 48L * pairs, (flags & IG_FLAG_BIAS) ? bias : nullptr, y, N, Di, Hi, Wi, Cin, ldx, Cout, ldy,
+                           (flags & IG_FLAG_ACCUM) ? 1 : 0, gnp, gnG, gn_B, ws, ws_bytes, stream);
+    if (r == 1)
+      r = bts_wino_launch_(x, up, (flags & IG_FLAG_BIAS) ? bias : nullptr, y, N, Di, Hi, Wi, Cin, ldx, Cout, ldy,
+                           (flags & IG_FLAG_ACCUM) ? 1 : 0, gnp, gnG, gn_B, ws, ws_bytes, stream);
     if (r == BTS_OK) {
       if (y2 != nullptr)
         return launch_igemm(GEO_K1, x, wp2, bias2, y2, N, Di, Hi, Wi, Cin, ldx, Di, Hi, Wi, Cout, ldy2, Di, Hi, Wi, 0, 0, 0,
@@ -1703,6 +1751,8 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
     if (geo == GEO_S1) {  // the Winograd form may split the contraction where the implicit GEMM does not (and vice versa)
       const long wn = bts_wino_workspace_(N, Di, Hi, Wi, Cin, Cout);
       if (wn > *need_out) *need_out = wn;
+      const long w3 = bts_w3_workspace_(N, Di, Hi, Wi, Cin, Cout);
+      if (w3 > *need_out) *need_out = w3;
     }
   }
   if (gn_B && rc == BTS_OK && p.gnp != nullptr) *gn_B = (long)p.gn_zt * p.nty * p.ntx * p.gn_gridy;

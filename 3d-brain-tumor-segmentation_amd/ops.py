@@ -38,6 +38,8 @@ def kernel_symbol(sym):
         return 'c2_kernel'
     if sym == 26:
         return 'k1w_kernel'
+    if sym == 27:
+        return 'w3_kernel'
     if sym == 30:
         return 'lp_conv_s1_kernel'
     if sym == 31:

@@ -61,7 +61,7 @@ def test_argument_validation_without_gpu(cdll):
     assert L._bts_conv_pack(7, 0, None, None, 4, 4, 4, 0, 0, None) == -3                          # unknown kind
     assert L._bts_gn_stats(None, None, None, None, 0, 1, 8, 6, 4, 0, 1e-5, None) == -1            # C % G != 0
     assert L._bts_gn_workspace(1, 512, 32, 8, 0) > 0
-    assert L._bts_conv_packed_floats(1, 0, 32, 32) == (27 + 48) * 4 * 2 * 32 * 4   # implicit-GEMM image + Winograd image
+    assert L._bts_conv_packed_floats(1, 0, 32, 32) == (27 + 48 + 64) * 4 * 2 * 32 * 4   # implicit-GEMM image + the two Winograd images
     assert L._bts_conv_packed_floats(2, 0, 32, 32) == 27 * 4 * 2 * 32 * 4
     assert L._bts_conv3d_bwd_weight_workspace(1, 1, 128, 128, 128, 32, 32) > 0
     assert L._bts_adam_tf_step(None, None, None, None, 0, 1e-4, 0.9, 0.999, 1e-7, 1.0, None) == -1

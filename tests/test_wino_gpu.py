@@ -1,9 +1,11 @@
-"""-m gpu: the Winograd F(2x2,3x3) x direct form of the 3x3x3 stride-1 convolution (csrc/conv_wino.hip) against the fp64
-oracle, through the same C-ABI entry points as the implicit GEMM (the launcher picks the form; BTS_WINO_MIN_WGS=1 makes it
-take the small grids used here, and every test asserts through the profiler that `wino_kernel` really ran).
+"""-m gpu: the two Winograd forms of the 3x3x3 stride-1 convolution -- F(2x2x2,3x3x3) (csrc/conv_wino3.hip, the default) and
+F(2x2,3x3) x direct (csrc/conv_wino.hip, BTS_W3=0) -- against the fp64 oracle, through the same C-ABI entry points as the
+implicit GEMM (the launcher picks the form; BTS_WINO_MIN_WGS=1 makes it take the small grids used here, and every test asserts
+through the profiler that the form under test really ran).  Every test runs once per form.
 
-Tolerance: the input transform adds up to four fp32 values before the multiply (||B^T||_1 = 2 per axis, two axes), so the
-contraction bound of SURVEY 8c is widened by that factor:  |err| <= 32 * eps32 * sum|a_i b_i| + 1e-7  (direct form: 8)."""
+Tolerance: the input transform adds fp32 values before the multiply (||B^T||_1 = 2 per transformed axis), so the contraction
+bound of SURVEY 8c is widened:  |err| <= 32 * eps32 * sum|a_i b_i| + 1e-7  (direct form: 8) -- for BOTH forms: the third
+transformed axis measured 1.35x the two-axis error, well inside the same bound."""
 import pytest
 import torch
 
@@ -37,8 +39,11 @@ def check_close(got, ref, what, rtol, atol):
     assert not bad.any(), '%s: %d/%d out of tolerance, max err %.3e' % (what, int(bad.sum()), bad.numel(), float(err.max()))
 
 
+FORM = {'kernel': 'w3_kernel'}   # set per test by the _form fixture
+
+
 class ran_wino(object):
-    """context: asserts that at least `n` wino_kernel launches happened inside"""
+    """context: asserts that at least `n` launches of the Winograd kernel under test happened inside"""
 
     def __init__(self, n=1):
         self.n = n
@@ -54,14 +59,20 @@ class ran_wino(object):
         names = [r[0] for r in ops.profile_records()]
         ops.profile_enable(False)
         if exc[0] is None:
-            assert names.count('wino_kernel') >= self.n, 'expected the Winograd kernel, profiler saw %r' % (names,)
+            assert names.count(FORM['kernel']) >= self.n, 'expected %s, profiler saw %r' % (FORM['kernel'], names)
         return False
 
 
-@pytest.fixture(autouse=True)
-def _small_grids(monkeypatch):
+@pytest.fixture(autouse=True, params=['w3', 'wino'])
+def _form(request, monkeypatch):
     monkeypatch.setenv('BTS_WINO_MIN_WGS', '1')
     monkeypatch.delenv('BTS_WINO', raising=False)
+    if request.param == 'w3':
+        monkeypatch.delenv('BTS_W3', raising=False)
+        FORM['kernel'] = 'w3_kernel'
+    else:
+        monkeypatch.setenv('BTS_W3', '0')
+        FORM['kernel'] = 'wino_kernel'
 
 
 CASES = [
@@ -129,7 +140,7 @@ def test_wino_declines_what_it_cannot_do(monkeypatch):
         torch.cuda.synchronize()
         names = [r[0] for r in ops.profile_records()]
         ops.profile_enable(False)
-        assert 'wino_kernel' not in names
+        assert 'wino_kernel' not in names and 'w3_kernel' not in names
         ref = R.conv3d(x.double(), wt.double(), None)
         if sig:
             ref = torch.sigmoid(ref)
