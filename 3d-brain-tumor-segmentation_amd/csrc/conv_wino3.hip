@@ -12,11 +12,13 @@
 // Work decomposition: 256 threads = 4 waves; workgroup tile = 16 (x) x 4 (y) x 4 (z) output voxels x 32 couts = 32 patches of
 // 2x2x2 = the 32 matrix columns of every wave.  Wave a owns the 16 transform points with xi_z = a: 16 accumulators of
 // 32 patches x 32 couts = 256 accumulation registers, one wave per SIMD.  The 18 x 6 x 6 halo tile of 8 input channels is staged
-// global -> registers -> LDS (double buffered; voxel stride 12 dwords; even and odd x columns in separate half rows so that
-// lanes of neighbouring patches are 12 dwords apart; row stride 20 voxels puts the two y patches 32 banks apart: conflict-free
-// ds_read_b128).  Lane (h, patch) reads the two z planes its xi_z combines, 4 x 4 voxels each, channels h*4..h*4+3, forms the
-// z combination once per stage and the (y, x) transform one group (one xi_y, four xi_x) ahead of the matrix instructions that
-// consume it; U fragments stream from L2 two groups ahead.  The stage barrier sits before the stage's LAST group: the next
+// global -> registers -> LDS (double buffered) with the z transform applied ON THE WAY: a staging thread holds the six z planes
+// of its (y, x) column and writes the eight z-combined planes (2 z patches x 4 xi_z) -- every consumer lane then reads ONE
+// plane and no wave repeats the z combination.  LDS: voxel stride 12 dwords; even and odd x columns in separate half rows so
+// that lanes of neighbouring patches are 12 dwords apart; row stride 20 voxels puts the two y patches 32 banks apart:
+// conflict-free ds_read_b128.  Lane (h, patch) reads the 4 x 4 voxels of its patch in plane (z patch, xi_z), channels
+// h*4..h*4+3, and forms the (y, x) transform one group (one xi_y, four xi_x) ahead of the matrix instructions that consume it;
+// U fragments stream from L2 two groups ahead.  The stage barrier sits before the stage's LAST group: the next
 // stage's first operands are formed under that group's matrix instructions.
 // Output: each wave transforms its 16 accumulators over (y, x), the four z partial results meet in LDS, wave w finishes and
 // stores the outputs of (oy, ox) = w.
@@ -66,19 +68,13 @@ struct W3Params {
 #define W3S 12                    // dwords per staged voxel: 8 channels + 4 pad
 #define W3SX 18                   // staged halo columns
 #define W3LX 20                   // LDS row stride (voxels): 10 even + 10 odd columns
-#define W3NST (W3SX * 6 * 6)      // staged voxels (648)
-#define W3BUF (W3LX * 36 * W3S)   // dwords per staging buffer (8640)
-#define W3NSLOT 6                 // staging slots (16 bytes) per thread and stage: 1296 of 1536 used
+#define W3NCOL (W3SX * 6 * 2)     // staging threads in use: one per (y, x) column and channel half (216)
+#define W3PL (6 * W3LX * W3S)     // dwords per z-combined plane (1440)
+#define W3BUF (8 * W3PL)          // dwords per staging buffer: 8 planes = (z patch, xi_z) (11520)
+#define W3NSLOT 6                 // staging slots (16 bytes) per thread and stage = the six z planes of the thread's column
 #define W3EX (4 * 4 * 4 * 64 * 4) // dwords of the output exchange [xi_z][cout quad][oy*2+ox][lane] x 4
 // patch-relative LDS offset (dwords) of row j, column k of a plane
 #define W3OFF(j, k) ((((j) * W3LX) + ((k) & 1) * 10 + ((k) >> 1)) * W3S)
-
-__device__ __forceinline__ f32x4 fma4s(f32x4 q, f32x2 s, f32x4 p) {   // p + s * q  (s = +-1: exact)
-  f32x2 lo, hi;
-  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(q.xy), "v"(s), "v"(p.xy));
-  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(q.zw), "v"(s), "v"(p.zw));
-  return f32x4{lo.x, lo.y, hi.x, hi.y};
-}
 
 __global__ __launch_bounds__(256, 1) void w3_kernel(const W3Params p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -122,38 +118,21 @@ __global__ __launch_bounds__(256, 1) void w3_kernel(const W3Params p) {
     ++it.n;
   };
 
-  // staging pattern (tile independent): slot -> halo voxel, byte offset from the halo origin, LDS offset
-  unsigned gbase[W3NSLOT], gpos[W3NSLOT];
-  int loff[W3NSLOT];
-#pragma unroll
-  for (int i = 0; i < W3NSLOT; ++i) {
-    const int e = tid + i * 256;
-    gbase[i] = 0x80000000u;
-    gpos[i] = 0x00ffffffu;   // (255, 255, 255): never inside an image
-    loff[i] = -1;
-    if (e < W3NST * 2) {
-      const int vox = e >> 1, q = e & 1;
-      const int vz = vox / (6 * W3SX);
-      const int r = vox - vz * (6 * W3SX);
-      const int vy = r / W3SX;
-      const int vx = r - vy * W3SX;
-      gbase[i] = (unsigned)(((vz * p.H + vy) * p.W + vx) * p.ldx + q * 4) * 4u;
-      gpos[i] = (unsigned)((vz << 16) | (vy << 8) | vx);
-      loff[i] = ((vz * 6 + vy) * W3LX + (vx & 1) * 10 + (vx >> 1)) * W3S + q * 4;
-    }
-  }
+  // staging pattern (tile independent): thread -> (y, x) column and channel half; slot i = z plane i of the halo
+  const int s_q = tid & 1, s_vy = (tid >> 1) / W3SX, s_vx = (tid >> 1) - s_vy * W3SX;
+  const bool s_on = tid < W3NCOL;
+  const unsigned gcol = (unsigned)((s_vy * p.W + s_vx) * p.ldx + s_q * 4) * 4u;
+  const unsigned gplane = (unsigned)(p.H * p.W * p.ldx) * 4u;
+  const int lcol = (s_vy * W3LX + (s_vx & 1) * 10 + (s_vx >> 1)) * W3S + s_q * 4;
   __amdgpu_buffer_rsrc_t xr, wr, wr_n;
   unsigned goff[W3NSLOT];
   auto setup_x = [&](const Item& it) {
     const int iz0 = it.tz * 4 - 1, iy0 = it.ty * 4 - 1, ix0 = it.tx * 16 - 1;
     const float* xorg = p.x + ((((long)it.n * p.D + iz0) * p.H + iy0) * p.W + ix0) * (long)p.ldx;
     xr = __builtin_amdgcn_make_buffer_rsrc((void*)xorg, 0, 0x7fffffff, 0x00020000);
+    const bool col_in = s_on && (unsigned)(iy0 + s_vy) < (unsigned)p.H && (unsigned)(ix0 + s_vx) < (unsigned)p.W;
 #pragma unroll
-    for (int i = 0; i < W3NSLOT; ++i) {
-      const int vz = (int)(gpos[i] >> 16), vy = (int)((gpos[i] >> 8) & 255), vx = (int)(gpos[i] & 255);
-      const bool in = (unsigned)(iz0 + vz) < (unsigned)p.D && (unsigned)(iy0 + vy) < (unsigned)p.H && (unsigned)(ix0 + vx) < (unsigned)p.W;
-      goff[i] = in ? gbase[i] : 0x80000000u;
-    }
+    for (int i = 0; i < W3NSLOT; ++i) goff[i] = (col_in && (unsigned)(iz0 + i) < (unsigned)p.D) ? gcol + (unsigned)i * gplane : 0x80000000u;
   };
   auto wdesc = [&](const Item& it) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)(p.up + (long)it.cb * p.KG * (64 * 256)), 0, 0x7fffffff, 0x00020000);
@@ -171,12 +150,8 @@ __global__ __launch_bounds__(256, 1) void w3_kernel(const W3Params p) {
     if (st1 > p.KG) st1 = p.KG;
   }
 
-  // the two z planes this wave's xi_z combines: xi_z = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
-  const int zP = (0x1210 >> (4 * wave)) & 15, zQ = (0x3122 >> (4 * wave)) & 15;
-  const float sgn = (wave == 1) ? 1.f : -1.f;
-  const f32x2 s2 = {sgn, sgn};
-  const int bbase = ((2 * ptz * 6 + 2 * pty) * W3LX + ptx) * W3S + h * 4;
-  const int offP = bbase + zP * 6 * W3LX * W3S, offQ = bbase + zQ * 6 * W3LX * W3S;
+  // this lane's operand plane (z patch, xi_z = wave) and patch origin inside it
+  const int offP = (ptz * 4 + wave) * W3PL + (2 * pty * W3LX + ptx) * W3S + h * 4;
   const unsigned wlane = (unsigned)((h * 32 + l32) * 16);
   const unsigned wwave = (unsigned)(wave * 16 * 1024);
 
@@ -188,10 +163,19 @@ __global__ __launch_bounds__(256, 1) void w3_kernel(const W3Params p) {
 #pragma unroll
     for (int i = 0; i < W3NSLOT; ++i) pre[i] = bufload(xr, goff[i], soff);
   };
+  // z transform on the way to LDS: plane (zp, xi_z) = xi_z 0: d0 - d2 | 1: d1 + d2 | 2: d2 - d1 | 3: d1 - d3 of the raw planes 2 zp + (0..3)
   auto commit = [&](float* buf) {
+    if (s_on) {
+      float* o = buf + lcol;
 #pragma unroll
-    for (int i = 0; i < W3NSLOT; ++i)
-      if (loff[i] >= 0) *reinterpret_cast<f32x4*>(buf + loff[i]) = pre[i];
+      for (int zp = 0; zp < 2; ++zp) {
+        const f32x4 d0 = pre[2 * zp], d1 = pre[2 * zp + 1], d2 = pre[2 * zp + 2], d3 = pre[2 * zp + 3];
+        *reinterpret_cast<f32x4*>(o + (zp * 4 + 0) * W3PL) = sub4(d0, d2);
+        *reinterpret_cast<f32x4*>(o + (zp * 4 + 1) * W3PL) = add4(d1, d2);
+        *reinterpret_cast<f32x4*>(o + (zp * 4 + 2) * W3PL) = sub4(d2, d1);
+        *reinterpret_cast<f32x4*>(o + (zp * 4 + 3) * W3PL) = sub4(d1, d3);
+      }
+    }
   };
   // U fragments of group G = 4*stage + gi live in aw[gi]; the groups of a stage run xi_y = 1, 2, 0, 3
   f32x4 aw[4][4];
@@ -207,30 +191,20 @@ __global__ __launch_bounds__(256, 1) void w3_kernel(const W3Params p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) dst[e] = bufload(d, wlane + e * 1024, so);
   };
-  f32x4 c[4][4], v[2][4], rp[4], rq[4], t[4];
-  auto rd_row = [&](const float* lb, int j) {
+  f32x4 c[4][4], v[2][4], t[4];
+  auto rd_row = [&](const float* lb, int j) {   // row j of the lane's patch: 4 voxels x 4 channels, already z-combined
 #ifdef W3_EXP_NOLDS   // timing experiment (wrong results): no operand reads from LDS
     return;
 #endif
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      rp[k] = *reinterpret_cast<const f32x4*>(lb + offP + W3OFF(j, k));
-      rq[k] = *reinterpret_cast<const f32x4*>(lb + offQ + W3OFF(j, k));
-    }
-  };
-  auto zc_row = [&](int j) {
-#ifdef W3_EXP_NOXF    // timing experiment (wrong results): no transforms
-    return;
-#endif
-#pragma unroll
-    for (int k = 0; k < 4; ++k) c[j][k] = fma4s(rq[k], s2, rp[k]);
+    for (int k = 0; k < 4; ++k) c[j][k] = *reinterpret_cast<const f32x4*>(lb + offP + W3OFF(j, k));
   };
   float* const ex = lds + 2 * W3BUF;
   float* const bsh = ex + W3EX;                                  // 2 x 32 bias values (current / next item)
   double* const gsh = reinterpret_cast<double*>(bsh + 64);       // GroupNorm partial exchange
   float bias_v = 0.f;
 
-  // One k-group stage on LDS buffer `par`.  On entry c[1], c[2] hold this stage's z-combined rows 1, 2 and v[0] the operands of
+  // One k-group stage on LDS buffer `par`.  On entry c[1], c[2] hold this stage's rows 1, 2 and v[0] the operands of
   // xi_y = 1.  FIRST: the item's first stage (accumulators start from zero; the item's bias goes to LDS slot `bslot`).
   // f_soff: the halo tile two stages ahead in the workgroup's stage stream (xr / goff already belong to its item).
   // wt / stn: weight descriptor and k-group of the NEXT stage of the stream.
@@ -249,9 +223,8 @@ __global__ __launch_bounds__(256, 1) void w3_kernel(const W3Params p) {
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_nop 1" ::: "memory");
     }
-    {  // MFMA xi_y = 2 ; combine row 0, form xi_y = 0 : c0 - c2 ; request row 3
+    {  // MFMA xi_y = 2 ; form xi_y = 0 : c0 - c2 ; request row 3
       wload(aw[3], wr, st, 3);
-      zc_row(0);
       rd_row(lb, 3);
 #pragma unroll
       for (int k = 0; k < 4; ++k) t[k] = sub4(c[0][k], c[2][k]);
@@ -261,9 +234,8 @@ __global__ __launch_bounds__(256, 1) void w3_kernel(const W3Params p) {
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_nop 1" ::: "memory");
     }
-    {  // MFMA xi_y = 0 ; combine row 3, form xi_y = 3 : c1 - c3 ; hand the next halo tile to LDS
+    {  // MFMA xi_y = 0 ; form xi_y = 3 : c1 - c3 ; hand the next halo tile to LDS (z transform on the way)
       wload(aw[0], wt, stn, 1);
-      zc_row(3);
 #pragma unroll
       for (int k = 0; k < 4; ++k) t[k] = sub4(c[1][k], c[3][k]);
       wino_yt(t, v[1]);
@@ -281,12 +253,10 @@ __global__ __launch_bounds__(256, 1) void w3_kernel(const W3Params p) {
       fetch(f_soff);
 #endif
     }
-    {  // MFMA xi_y = 3 ; read, combine rows 1, 2 of the NEXT stage and form its xi_y = 1 : c1 + c2
+    {  // MFMA xi_y = 3 ; read rows 1, 2 of the NEXT stage and form its xi_y = 1 : c1 + c2
       wload(aw[1], wt, stn, 2);
       rd_row(ln, 1);
-      zc_row(1);
       rd_row(ln, 2);
-      zc_row(2);
 #pragma unroll
       for (int k = 0; k < 4; ++k) t[k] = add4(c[1][k], c[2][k]);
       wino_yt(t, v[0]);
@@ -330,7 +300,8 @@ __global__ __launch_bounds__(256, 1) void w3_kernel(const W3Params p) {
     }
     __syncthreads();
     W3STAMP(4);
-    float gn_s = 0.f, gn_q = 0.f;
+    f32x2 gn_s2 = {0.f, 0.f}, gn_q2 = {0.f, 0.f};
+    const bool gn_on = p.gnp != nullptr;
     {
       const int oy = wave >> 1, ox = wave & 1;
       const int zb = o.tz * 4 + 2 * ptz, yy = o.ty * 4 + 2 * pty + oy, xx = o.tx * 16 + 2 * ptx + ox;
@@ -365,11 +336,10 @@ __global__ __launch_bounds__(256, 1) void w3_kernel(const W3Params p) {
           const unsigned off = cok ? yo[oz] : 0x80000000u;
           const bool live = off != 0x80000000u;
           f32x4 w = ov[oz];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float tt = live ? w[j] : 0.f;
-            gn_s += tt;
-            gn_q = fmaf(tt, tt, gn_q);
+          if (gn_on) {   // (wave-uniform) masked positions contribute nothing to the GroupNorm sums
+            const f32x4 tt = live ? w : f32x4{0.f, 0.f, 0.f, 0.f};
+            gn_s2 = pk_add(pk_add(gn_s2, tt.xy), tt.zw);
+            gn_q2 = pk_fma(tt.zw, tt.zw, pk_fma(tt.xy, tt.xy, gn_q2));
           }
           w += old[g][oz];
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w), yr, off + 32u * g, 0, 0);
@@ -378,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void w3_kernel(const W3Params p) {
     }
     {  // GroupNorm partials: lanes (shuffle tree) -> 4 waves (LDS) -> one (sum, sumsq) pair per item, fixed order; thread 0
        // stores (out of range when there is no consumer)
-      const double ds = wave_sum_f64((double)gn_s), dq = wave_sum_f64((double)gn_q);
+      const double ds = wave_sum_f64((double)gn_s2.x + (double)gn_s2.y), dq = wave_sum_f64((double)gn_q2.x + (double)gn_q2.y);
       if (lane == 0) { gsh[wave * 2] = ds; gsh[wave * 2 + 1] = dq; }
       __syncthreads();
       const int gn_g = o.tz / p.gn_zt;
@@ -425,9 +395,7 @@ __global__ __launch_bounds__(256, 1) void w3_kernel(const W3Params p) {
   __syncthreads();
   fetch(st0 + 1 < st1 ? (unsigned)(st0 + 1) * 32u : 0x80000000u);
   rd_row(lds, 1);
-  zc_row(1);
   rd_row(lds, 2);
-  zc_row(2);
 #pragma unroll
   for (int k = 0; k < 4; ++k) t[k] = add4(c[1][k], c[2][k]);
   wino_yt(t, v[0]);
@@ -543,13 +511,22 @@ int bts_w3_launch_(const float* x, const float* up3, const float* bias, float* y
   }
   static bool attr_done = false;
   const size_t shmem = (2 * W3BUF + W3EX + 64 + 16) * sizeof(float);
-  // items per workgroup: as many as leave every CU (32 per XCD, one workgroup each at a time) at least four workgroups; chaining
-  // needs two stages per item
+  // items per workgroup (chaining needs two stages per item): each XCD runs 32 workgroups at a time (one per CU), so a launch
+  // takes ceil(workgroups per XCD / 32) rounds of T items; the T <= 8 with the fewest item-times wins, ties go to the larger T
+  // (fewer un-overlapped first fetches)
   {
-    const long per_cu = ((long)p.tiles_per_xcd * q.nb) / 32;
-    p.T = (q.ksplit > 1 || p.KG < 2) ? 1 : (per_cu >= 32 ? 8 : per_cu >= 16 ? 4 : per_cu >= 8 ? 2 : 1);
-    const char* e = getenv("BTS_W3_T");   // A/B aid
-    if (e && q.ksplit == 1 && p.KG >= 2) p.T = atoi(e) > 0 ? atoi(e) : 1;
+    const long items = (long)p.tiles_per_xcd * q.nb;
+    p.T = 1;
+    if (q.ksplit == 1 && p.KG >= 2) {
+      long best = -1;
+      for (int t = 1; t <= 8; ++t) {
+        const long rounds = ((items + t - 1) / t + 31) / 32;
+        const long cost = rounds * (8L * t + 1);   // (+1: the first item of a round waits for its fetch)
+        if (best < 0 || cost <= best) { best = cost; p.T = t; }
+      }
+      const char* e = getenv("BTS_W3_T");   // A/B aid
+      if (e && atoi(e) > 0) p.T = atoi(e);
+    }
   }
   const long wgs_per_xcd = ((long)p.tiles_per_xcd * q.nb + p.T - 1) / p.T;
   if (!attr_done) {

@@ -21,6 +21,11 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
   asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 __device__ __forceinline__ f32x4 add4(f32x4 a, f32x4 b) {
   const f32x2 lo = pk_add(a.xy, b.xy), hi = pk_add(a.zw, b.zw);
   return f32x4{lo.x, lo.y, hi.x, hi.y};
