@@ -18,10 +18,10 @@ for d, cin, cout in shapes:
     x = torch.randn((1, d, d, d, cin), device=D)
     w = torch.randn((3, 3, 3, cin, cout), device=D) * (2.0 / (27 * cin)) ** 0.5
     b = torch.randn(cout, device=D)
-    wp = ops.conv_pack(K, ops.ROLE_FWD, w, cin, cout)
     res = {}
     for mode in ('0', '1'):
         os.environ['BTS_W3'] = mode
+        wp = ops.conv_pack(K, ops.ROLE_FWD, w, cin, cout)   # (the image holds the enabled form's part only)
         y = ops.conv_fwd(K, x, wp, b, cout)
         for _ in range(3):
             ops.conv_fwd(K, x, wp, b, cout, out=y)
