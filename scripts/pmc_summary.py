@@ -14,7 +14,7 @@ for f in sorted(glob.glob('%s/pmck_%s_%s_*/**/p_counter_collection.csv' % (O, TA
         vals[r['Kernel_Name'].split('(')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
 print('== one_conv.py %s' % spec)
 for k, cs in sorted(vals.items()):
-    if not any(s in k for s in ('wino', 'wgw', 'wgrad_kernel', 'igemm', 'k1', 'upm', 'dsc', 'c2_')):
+    if not any(s in k for s in ('w3_', 'wino', 'wgw', 'wgrad_kernel', 'igemm', 'k1', 'upm', 'dsc', 'c2_')):
         continue
     m = {c: sum(v) / len(v) for c, v in cs.items()}
     print('-- %s  (%d launches)' % (k, max(len(v) for v in cs.values())))
