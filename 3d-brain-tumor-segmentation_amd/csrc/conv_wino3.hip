@@ -341,24 +341,29 @@ __global__ __launch_bounds__(256, 1) void w3_kernel(const W3Params p) {
             gn_s2 = pk_add(pk_add(gn_s2, tt.xy), tt.zw);
             gn_q2 = pk_fma(tt.zw, tt.zw, pk_fma(tt.xy, tt.xy, gn_q2));
           }
-          w += old[g][oz];
+          w = add4(w, old[g][oz]);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w), yr, off + 32u * g, 0, 0);
         }
       }
     }
     {  // GroupNorm partials: lanes (shuffle tree) -> 4 waves (LDS) -> one (sum, sumsq) pair per item, fixed order; thread 0
-       // stores (out of range when there is no consumer)
-      const double ds = wave_sum_f64((double)gn_s2.x + (double)gn_s2.y), dq = wave_sum_f64((double)gn_q2.x + (double)gn_q2.y);
-      if (lane == 0) { gsh[wave * 2] = ds; gsh[wave * 2 + 1] = dq; }
-      __syncthreads();
-      const int gn_g = o.tz / p.gn_zt;
-      const long B = (long)p.gn_zt * p.nty * p.ntx * nb_;
-      const long gn_slot = (((long)(o.tz - gn_g * p.gn_zt) * p.nty + o.ty) * p.ntx + o.tx) * nb_ + o.cb;
-      const double* dst = p.gnp ? p.gnp + (((long)o.n * p.gn_G + gn_g) * B + gn_slot) * 2 : nullptr;
-      const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, p.gnp ? 16 : 0, 0x00020000);
-      const double s0 = gsh[0] + gsh[2] + gsh[4] + gsh[6], s1 = gsh[1] + gsh[3] + gsh[5] + gsh[7];
+       // stores (the store is issued on every path -- out of range when there is no consumer -- the arithmetic is not)
+      double s0 = 0.0, s1 = 0.0;
+      const double* dst = nullptr;
+      if (gn_on) {   // (launch-uniform)
+        const double ds = wave_sum_f64((double)gn_s2.x + (double)gn_s2.y), dq = wave_sum_f64((double)gn_q2.x + (double)gn_q2.y);
+        if (lane == 0) { gsh[wave * 2] = ds; gsh[wave * 2 + 1] = dq; }
+        __syncthreads();
+        const int gn_g = o.tz / p.gn_zt;
+        const long B = (long)p.gn_zt * p.nty * p.ntx * nb_;
+        const long gn_slot = (((long)(o.tz - gn_g * p.gn_zt) * p.nty + o.ty) * p.ntx + o.tx) * nb_ + o.cb;
+        dst = p.gnp + (((long)o.n * p.gn_G + gn_g) * B + gn_slot) * 2;
+        s0 = gsh[0] + gsh[2] + gsh[4] + gsh[6];
+        s1 = gsh[1] + gsh[3] + gsh[5] + gsh[7];
+      }
+      const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, gn_on ? 16 : 0, 0x00020000);
       struct D2 { double a, b; } d2{s0, s1};
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d2), gr, tid == 0 ? 0u : 0x80000000u, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d2), gr, (gn_on && tid == 0) ? 0u : 0x80000000u, 0, 0);
     }
   };
 
