@@ -434,12 +434,13 @@ def main():
         traffic = pmc_traffic(sym)
         t_launch = tsec / nl
         # which roofline bounds it: time the executed FLOPs need at the matrix peak vs time the measured HBM traffic needs
-        t_mfma = (fl / nl) * WINOGRAD_EXECUTED.get(sym, 1.0) / (PEAK_F32_MFMA_TFLOPS * 1e12)
+        peak = PEAK_F16_MFMA_TFLOPS if sym.startswith('lp_') else PEAK_F32_MFMA_TFLOPS   # 16-bit kernels against the 16-bit dense peak
+        t_mfma = (fl / nl) * WINOGRAD_EXECUTED.get(sym, 1.0) / (peak * 1e12)
         t_hbm = (traffic['bytes'] / (PEAK_HBM_TBS * 1e12)) if traffic else 0.0
         out['roofline'] = {
             'kernel': sym, 'bound': 'mfma' if t_mfma >= t_hbm else 'hbm',
-            'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
-            'achieved_algorithmic': alg, 'frac_algorithmic': alg / PEAK_F32_MFMA_TFLOPS,
+            'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+            'achieved_algorithmic': alg, 'frac_algorithmic': alg / peak,
             'traffic': traffic['bytes'] if traffic else None, 'traffic_detail': traffic,
             'hbm_frac_of_launch': (t_hbm / t_launch) if traffic else None,
             'launches_per_step': nl / steps_p, 'avg_launch_ms': 1e3 * t_launch,
