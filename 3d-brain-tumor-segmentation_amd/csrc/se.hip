@@ -301,11 +301,15 @@ __global__ void se_mlp_bwd_kernel(const double* partial, const float* gap, const
     dwsp[c] = accum ? dwsp[c] + (float)s : (float)s;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < N * R; i += blockDim.x) {
-    const int n = i / R, k = i % R;
-    double s = 0.0;
-    for (int c = 0; c < F; ++c) s += (double)w2[k * F + c] * dz2[n * F + c];
-    dz1[i] = (hbuf[i] > 0.f) ? s : 0.0;
+  {  // dz1[n][k] = relu'(h) * sum_c W2[k][c] dz2[n][c]: one wave per output (the F-long sum was the kernel's critical path)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    for (int i = wave; i < N * R; i += nwave) {
+      const int n = i / R, k = i % R;
+      double s = 0.0;
+      for (int c = lane; c < F; c += 64) s += (double)w2[k * F + c] * dz2[n * F + c];
+      s = wave_sum_f64(s);
+      if (lane == 0) dz1[i] = (hbuf[i] > 0.f) ? s : 0.0;
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < R * F; i += blockDim.x) {  // dW2[k][c] = sum_n h[n][k]*dz2[n][c]
