@@ -542,6 +542,7 @@ struct LpGatherParams {
   int s, os, ooz, ooy, oox;         // in = g*s + off_t ; out = g*os + oo
   int KS, NB, ncg, ntaps, accum;
   long npos;                        // N*Dg*Hg*Wg
+  double* gap_part;                 // fused global-average-pool partials [position block][Cout] (1x1x1 launches only), else NULL
   LpTap taps[27];
 };
 
@@ -629,6 +630,11 @@ __global__ __launch_bounds__(256, 2) void lp_conv_gather_kernel(const LpGatherPa
       }
     }
   }
+  float csum[CB][16];   // column sums of what this lane stores (dead code unless p.gap_part)
+#pragma unroll
+  for (int c = 0; c < CB; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) csum[c][r] = 0.f;
 #pragma unroll
   for (int c = 0; c < CB; ++c) {
     const int cb = cg * CB + c;
@@ -649,20 +655,46 @@ __global__ __launch_bounds__(256, 2) void lp_conv_gather_kernel(const LpGatherPa
             const float o0 = acc[v][c][4 * q] + bq[0], o1 = acc[v][c][4 * q + 1] + bq[1], o2 = acc[v][c][4 * q + 2] + bq[2],
                         o3 = acc[v][c][4 * q + 3] + bq[3];
             lp_store_quad<T>(dst, o0, o1, o2, o3, p.Cout - co, p.accum);
+            csum[c][4 * q] += o0; csum[c][4 * q + 1] += o1; csum[c][4 * q + 2] += o2; csum[c][4 * q + 3] += o3;
           }
         }
       }
     }
   }
+  // Fused global average pool of the output (resnet.py:121: the squeeze of the block's 1x1x1 shortcut output): column sums of
+  // this block's 128 * VB positions -- lanes (xor shuffles over the 32 positions of a wave), the 4 waves through LDS in fixed
+  // order, one fp64 partial per (position block, cout); bts_lp_conv1_gap's finalize adds the blocks of a sample
+  if (p.gap_part != nullptr) {   // (launch-uniform)
+    __shared__ float csh[4][CB * 32];
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = csum[c][r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (l32 == 0) csh[wave][c * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = v;
+      }
+    __syncthreads();
+    if (tid < CB * 32) {
+      const int co = cg * CB * 32 + tid;
+      if (co < p.Cout) p.gap_part[blk * p.Cout + co] = ((double)csh[0][tid] + (double)csh[1][tid]) + ((double)csh[2][tid] + (double)csh[3][tid]);
+    }
+  }
 }
 
+// positions per workgroup of a gather launch (4 waves x VB x 32)
+static int lp_gather_vb(long npos, int NB) {
+  const int cb = NB >= 2 ? 2 : 1;
+  const long wg4 = ((npos + 511) / 512) * ((NB + cb - 1) / cb);
+  return wg4 >= 512 ? 4 : (wg4 >= 128 ? 2 : 1);
+}
 template <typename T>
 static int lp_gather_launch(LpGatherParams p, hipStream_t stream) {
   p.npos = (long)p.N * p.Dg * p.Hg * p.Wg;
   const int cb = p.NB >= 2 ? 2 : 1;
   p.ncg = (p.NB + cb - 1) / cb;
-  const long wg4 = ((p.npos + 511) / 512) * p.ncg;
-  const int vb = wg4 >= 512 ? 4 : (wg4 >= 128 ? 2 : 1);
+  const int vb = lp_gather_vb(p.npos, p.NB);
   const long blocks = ((p.npos + 128L * vb - 1) / (128L * vb)) * p.ncg;
   if (blocks > 0x7fffffffL) return BTS_ERR_SHAPE;
   const bool prof = bts_prof_on();
@@ -680,7 +712,8 @@ static int lp_gather_launch(LpGatherParams p, hipStream_t stream) {
 // in = 2o + k - pad), 3 = 8 output-parity classes of the transposed form (out = 2 in; even outputs take (i, k=0) and (i-1, k=2),
 // odd ones (i, k=1)).  (D,H,W) are the dims of `x`, the tensor the taps read; Cin its channels (the contraction).
 static int lp_conv_run(int geo, int dtype, const void* x, const void* wp, const float* bias, void* y, void* workspace, long workspace_bytes,
-                       int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, int accum, hipStream_t stream) {
+                       int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, int accum, hipStream_t stream,
+                       double* gap_part = nullptr) {
   if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return BTS_ERR_SHAPE;
   // (results are stored four couts = 8 bytes at a time; a head with fewer than four output channels stores them one by one)
@@ -698,6 +731,7 @@ static int lp_conv_run(int geo, int dtype, const void* x, const void* wp, const 
   LpGatherParams g;
   g.x = (const unsigned short*)x; g.wp = (const unsigned short*)wp; g.bias = bias; g.y = (unsigned short*)y;
   g.N = N; g.Di = D; g.Hi = H; g.Wi = W; g.ldx = ldx; g.ldy = ldy; g.Cout = Cout; g.KS = KS; g.NB = NB; g.accum = accum;
+  g.gap_part = (geo == 0) ? gap_part : nullptr;
   auto run = [&](const LpGatherParams& q) { return dtype == LP_F16 ? lp_gather_launch<TF16>(q, stream) : lp_gather_launch<TBF16>(q, stream); };
   if (geo == 0) {
     g.Dg = g.Do = D; g.Hg = g.Ho = H; g.Wg = g.Wo = W; g.s = 1; g.os = 1; g.ooz = g.ooy = g.oox = 0; g.ntaps = 1;
@@ -750,6 +784,37 @@ extern "C" int bts_lp_conv3d_fwd(int kind, int dtype, const void* x, const void*
                                  long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, hipStream_t stream) {
   if (kind < 0 || kind > 3) return BTS_ERR_UNSUPPORTED;
   return lp_conv_run(kind, dtype, x, wp, bias, y, workspace, workspace_bytes, N, D, H, W, Cin, ldx, Cout, ldy, 0, stream);
+}
+__global__ __launch_bounds__(256) void lp_colsum_finalize_kernel(const double* partial, float* out, int N, int C, int B, double scale);
+// res = conv1x1x1(x) + bias in the storage type AND gap[n][c] = mean over the voxels of (the unrounded) res -- the block's shortcut
+// and the squeeze of its gate (resnet.py:118-121) in one pass: the column sums leave the conv's epilogue as per-block partials, a
+// small finalize adds them.  Sample volumes that are not whole position blocks run the conv and bts_lp_colsum on the stored res.
+extern "C" long bts_lp_conv1_gap_workspace(int N, long V, int Cout) {
+  if (N <= 0 || V <= 0 || Cout <= 0) return -1;
+  const long a = ((long)N * V / 128 + 1) * Cout * 8 + 64;      // (VB >= 1: at most N*V/128 position blocks)
+  const long b = bts_lp_colsum_workspace(N, V, Cout);
+  return a > b ? a : b;
+}
+extern "C" int bts_lp_conv1_gap(int dtype, const void* x, const void* wp, const float* bias, void* res, float* gap, void* workspace,
+                                long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldres, hipStream_t stream) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0) return BTS_ERR_SHAPE;
+  const long V = (long)D * H * W;
+  if (workspace == nullptr || workspace_bytes < bts_lp_conv1_gap_workspace(N, V, Cout) || (((uintptr_t)workspace) & 15)) return BTS_ERR_WORKSPACE;
+  const int NB = (Cout + 31) / 32;
+  const long ppb = 128L * lp_gather_vb((long)N * V, NB);     // positions per block
+  if (V % ppb != 0 || ldres != Cout) {
+    const int r = lp_conv_run(0, dtype, x, wp, bias, res, nullptr, 0, N, D, H, W, Cin, ldx, Cout, ldres, 0, stream);
+    if (r != BTS_OK) return r;
+    if (ldres != Cout) return BTS_ERR_UNSUPPORTED;
+    return bts_lp_colsum(dtype, res, gap, workspace, workspace_bytes, N, V, Cout, (float)(1.0 / (double)V), stream);
+  }
+  double* part = reinterpret_cast<double*>(workspace);
+  const int r = lp_conv_run(0, dtype, x, wp, bias, res, nullptr, 0, N, D, H, W, Cin, ldx, Cout, ldres, 0, stream, part);
+  if (r != BTS_OK) return r;
+  hipLaunchKernelGGL(lp_colsum_finalize_kernel, dim3((N * Cout + 3) / 4), dim3(256), 0, stream, part, gap, N, Cout, (int)(V / ppb),
+                     1.0 / (double)V);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
 }
 // dx (+)= conv^T(dy) (replaces tf.GradientTape for these ops, train.py:142-151).  (D,H,W) are the forward INPUT dims, Cin / Cout
 // the forward channel counts; wp_bwd = bts_lp_pack(kind, BTS_ROLE_BWD_DATA, ...).  The data gradient of each kind is one of the

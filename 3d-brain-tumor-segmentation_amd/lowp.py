@@ -155,6 +155,18 @@ def gn_bwd(code, tdt, x, dy, gamma, beta, mean, rstd, dgamma, dbeta, groups, rel
     return dx, dx32
 
 
+def conv1_gap(code, x, wp, bias, cout, tdt):
+    """(res, gap): the block's 1x1x1 shortcut conv and the mean over voxels of its output (the gate's squeeze) in one pass"""
+    n, d, h, w, cin = x.shape
+    res = torch.empty((n, d, h, w, cout), dtype=tdt, device=x.device)
+    gap = torch.empty((n, cout), dtype=torch.float32, device=x.device)
+    nb = lib().query('bts_lp_conv1_gap_workspace', n, d * h * w, cout)
+    ws = ops.workspace(nb, x.device)
+    lib().call('bts_lp_conv1_gap', code, _p(x), _p(wp), _p(bias), _p(res), _p(gap), _p(ws), nb, n, d, h, w, cin, _ld(x), cout, cout,
+               _stream())
+    return res, gap
+
+
 def colsum(code, x, scale):
     n, c = x.shape[0], x.shape[4]
     v = x.shape[1] * x.shape[2] * x.shape[3]
@@ -246,9 +258,8 @@ class LowPrecisionForward(object):
         cin_slab = min(cin, blk.cin_ref) if fold is None else cin
         wp_pt = self._packed((key, 'pt'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
         wp_c1 = self._packed((key, 'c1'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
-        res = conv(ops.K1, code, tdt, x, wp_pt, blk.ptwise_b.t, f)
+        res, gap = conv1_gap(code, x, wp_pt, blk.ptwise_b.t, f, tdt)      # shortcut conv + the gate's squeeze in one pass
         c1 = conv(ops.K3S1, code, tdt, x, wp_c1, blk.conv1_b.t, f)
-        gap = colsum(code, res, 1.0 / v)
         _, ch = ops.se_mlp_fwd(gap, blk.se_w1.t, blk.se_w2.t)
         a = self._gn(blk.norm1, c1, True)
         del c1

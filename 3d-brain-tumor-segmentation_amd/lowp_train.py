@@ -22,7 +22,7 @@ to the storage type, which is part of what "16-bit storage" means and is bounded
 import torch
 
 from . import lowp, ops, parallel
-from .lowp import DTYPES, block_epilogue, cast, colsum, conv, conv_bwd_data, gn_apply, gn_stats, head, uncast
+from .lowp import DTYPES, block_epilogue, cast, colsum, conv, conv1_gap, conv_bwd_data, gn_apply, gn_stats, head, uncast
 from .tape import Tensor, bump_weights_epoch, weights_epoch
 
 
@@ -106,9 +106,8 @@ class LowPrecisionTrainer(object):
         key = id(blk)
         wp_pt = self._pk((key, 'pt'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
         wp_c1 = self._pk((key, 'c1'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
-        res = conv(ops.K1, code, tdt, x, wp_pt, blk.ptwise_b.t, f)
+        res, gap = conv1_gap(code, x, wp_pt, blk.ptwise_b.t, f, tdt)      # shortcut conv + the gate's squeeze in one pass
         c1 = conv(ops.K3S1, code, tdt, x, wp_c1, blk.conv1_b.t, f)
-        gap = colsum(code, res, 1.0 / v)
         hbuf, ch = ops.se_mlp_fwd(gap, blk.se_w1.t, blk.se_w2.t)
         m1, r1 = gn_stats(code, c1, g, blk.norm1._mode, blk.norm1.epsilon)
         a = gn_apply(code, c1, blk.norm1.gamma.t, blk.norm1.beta.t, m1, r1, g, blk.norm1._mode, True)

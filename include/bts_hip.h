@@ -284,6 +284,11 @@ int bts_lp_colsum(int dtype, const void* x, float* out, void* workspace, long wo
 int bts_lp_block_epilogue(int dtype, const void* res, const void* c2, void* out, float* sp_out, const float* wsp, const float* ch, const float* gamma,
                           const float* beta, const float* mean, const float* rstd, int N, long V, int C, int ldo, int G, int mode,
                           bts_stream_t stream);
+/* res = conv1x1x1(x) + bias in the storage type (dense, ldres == Cout) and gap[n][c] = mean over voxels of res: the block's
+ * shortcut and the squeeze of its gate (resnet.py:118-121) in one pass (column sums from the conv epilogue + a small finalize) */
+long bts_lp_conv1_gap_workspace(int N, long V, int Cout);
+int bts_lp_conv1_gap(int dtype, const void* x, const void* wp, const float* bias, void* res, float* gap, void* workspace,
+                     long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldres, bts_stream_t stream);
 /* gate backward (resnet.py:121-130 under autodiff) on 16-bit dout / res -> dres in the storage type; fp32 parameter gradients;
  * sp = the sp_out of bts_lp_block_epilogue; ds [N*V] and dgap [N*F] are fp32 scratch outputs */
 long bts_lp_se_bwd_workspace(int N, long V, int F, int R);

@@ -411,3 +411,35 @@ def test_gate_backward_kernel(shape, dtype):
     assert float((dres.float() - dres_r).abs().max()) <= U[dtype] * scale * 1.01 + 2e-5 * scale
     for a, b in zip(got_g, ref_g):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-5
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('case', [((1, 16, 16, 32), 48, 32, True), ((2, 8, 16, 16), 32, 64, False), ((1, 6, 10, 12), 16, 32, False)],
+                         ids=['slab-48-32', 'batch2-32-64', 'ragged-fallback'])
+def test_shortcut_conv_with_fused_squeeze(case, dtype):
+    """bts_lp_conv1_gap: the 1x1x1 shortcut conv and the mean over voxels of its output in one pass -- res equal to the plain 16-bit
+    conv's (same kernel), gap against the fp64 mean of the oracle's conv on the rounded operands; input as a slab view; a volume that
+    is not whole position blocks takes the two-pass route"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    (n, d, h, w), cin, cout, slab = case
+    code, tdt = lowp.DTYPES[dtype]
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn((n, d, h, w, cin), generator=g)
+    wt = torch.randn((1, 1, 1, cin, cout), generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    buf = torch.zeros((n, d, h, w, cin + 16), dtype=tdt, device=DEV)
+    xin = buf[..., 8:8 + cin] if slab else torch.empty((n, d, h, w, cin), dtype=tdt, device=DEV)
+    xin.copy_(x.to(tdt).to(DEV))
+    wp = lowp.pack(ops.K1, code, wt.to(DEV), cin, cout)
+    res, gap = lowp.conv1_gap(code, xin, wp, b.to(DEV), cout, tdt)
+    ref_res = lowp.conv(ops.K1, code, tdt, xin, wp, b.to(DEV), cout)
+    torch.cuda.synchronize()
+    assert torch.equal(res, ref_res)
+    y64 = R.conv3d(_round(x, tdt), _round(wt, tdt), b.double())
+    ref_gap = y64.mean(dim=(1, 2, 3))
+    fused = (d * h * w) % 512 == 0 or (d * h * w) % 128 == 0 and n * d * h * w < 128 * 512
+    # fused route: fp32 sums of unrounded outputs; two-pass route (ragged volumes): sums of the STORED, rounded res -- the
+    # rounding noise of V values averages down by sqrt(V) only
+    tol = (3e-6 if fused else U[dtype]) * float(y64.abs().mean()) + 2e-6
+    assert float((gap.double().cpu() - ref_gap).abs().max()) <= tol, (fused, float((gap.double().cpu() - ref_gap).abs().max()), tol)
