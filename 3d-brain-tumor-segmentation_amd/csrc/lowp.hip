@@ -185,6 +185,8 @@ struct LpS1Params {
   long ntiles;
   int accum;                                 // y += result (gradient accumulation into a slab), else y = result
   float* part;
+  double* gnp;                               // fused GroupNorm partial sums of y (slab semantics), [N*G][B][2], B = gn_zt*nty*ntx*ncg; or NULL
+  int gn_G, gn_zt;                           // groups; z planes per slab group (D / G)
 };
 #define LPS 24   // halves per staged voxel: 16 channels + 8 pad (48-byte stride: conflict-free 16-byte reads)
 
@@ -358,6 +360,8 @@ __global__ __launch_bounds__(256, 2) void lp_conv_s1_kernel(const LpS1Params p) 
     }
     // ---- output side of `cur` ----
     const int oz = cur.oz0 + wave, ox = cur.ox0 + lx;
+    const bool gn_on = p.gnp != nullptr;
+    float gn_s = 0.f, gn_q = 0.f;
     if (p.ksplit > 1) {   // raw fp32 partial sums [split][voxel][NB*32]; bias / rounding happen in the reduce kernel
 #pragma unroll
       for (int c = 0; c < CB; ++c) {
@@ -399,7 +403,23 @@ __global__ __launch_bounds__(256, 2) void lp_conv_s1_kernel(const LpS1Params p) 
               o2 += T::ld((unsigned short)(old[1] & 0xffffu)); o3 += T::ld((unsigned short)(old[1] >> 16));
             }
             bstore8(yr, off, u32x2{pack2<T>(o0, o1), pack2<T>(o2, o3)});
+            if (gn_on && ok) {   // (gn_on is launch-uniform) the unrounded outputs: what the stored values estimate
+              gn_s += (o0 + o1) + (o2 + o3);
+              gn_q = fmaf(o0, o0, fmaf(o1, o1, fmaf(o2, o2, fmaf(o3, o3, gn_q))));
+            }
           }
+        }
+      }
+      if (gn_on) {   // one fp64 (sum, sumsq) pair per (z plane = wave, tile column, cout group): lanes by shuffle tree, fixed order
+        const double ds = wave_sum_f64((double)gn_s), dq = wave_sum_f64((double)gn_q);
+        if (lane == 0 && oz < p.D) {
+          const int ty = cur.oy0 / TY, tx = cur.ox0 / TX;
+          const int gg = oz / p.gn_zt;      // gn_zt = planes per z-slab group
+          const long B = (long)p.gn_zt * p.nty * p.ntx * p.ncg;
+          const long slot = (((long)(oz - gg * p.gn_zt) * p.nty + ty) * p.ntx + tx) * p.ncg + cur.cg;
+          double* dst = p.gnp + (((long)cur.n * p.gn_G + gg) * B + slot) * 2;
+          dst[0] = ds;
+          dst[1] = dq;
         }
       }
     } else {
@@ -472,6 +492,7 @@ static int lp_s1_launch(LpS1Params p, void* ws, long ws_bytes, hipStream_t strea
     p.ksplit = (p.KS + p.ks_per - 1) / p.ks_per;
     if (ws == nullptr || ws_bytes < (long)p.ksplit * nvox * p.NB * 32 * 4 || (((uintptr_t)ws) & 15)) { p.ksplit = 1; p.ks_per = p.KS; }
   }
+  if (p.gnp != nullptr && p.ksplit > 1) return BTS_ERR_UNSUPPORTED;   // (bts_lp_conv3d_fwd_gn plans with the same rule: not reached)
   const size_t shmem = (size_t)(TX + 2) * (TY + 2) * (TZ + 2) * LPS * 2 + 32 * CB * 4;   // halo tile + the tile's bias values
   if ((long)p.D * p.H * p.W * (long)p.ldy * 2 >= 0x7fffff00L) return BTS_ERR_SHAPE;   // 31-bit output offsets inside one sample
   auto kern = lp_conv_s1_kernel<T, VB, CB, TXL>;
@@ -713,7 +734,7 @@ static int lp_gather_launch(LpGatherParams p, hipStream_t stream) {
 // odd ones (i, k=1)).  (D,H,W) are the dims of `x`, the tensor the taps read; Cin its channels (the contraction).
 static int lp_conv_run(int geo, int dtype, const void* x, const void* wp, const float* bias, void* y, void* workspace, long workspace_bytes,
                        int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, int accum, hipStream_t stream,
-                       double* gap_part = nullptr) {
+                       double* gap_part = nullptr, double* gn_part = nullptr, int gn_G = 0) {
   if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return BTS_ERR_SHAPE;
   // (results are stored four couts = 8 bytes at a time; a head with fewer than four output channels stores them one by one)
@@ -726,6 +747,7 @@ static int lp_conv_run(int geo, int dtype, const void* x, const void* wp, const 
     LpS1Params p;
     p.x = (const unsigned short*)x; p.wp = (const unsigned short*)wp; p.bias = bias; p.y = (unsigned short*)y;
     p.N = N; p.D = D; p.H = H; p.W = W; p.ldx = ldx; p.ldy = ldy; p.Cout = Cout; p.KS = KS; p.NB = NB; p.accum = accum;
+    p.gnp = gn_part; p.gn_G = gn_G; p.gn_zt = gn_G > 0 ? D / gn_G : 1;
     return dtype == LP_F16 ? lp_s1_dispatch<TF16>(p, workspace, workspace_bytes, stream) : lp_s1_dispatch<TBF16>(p, workspace, workspace_bytes, stream);
   }
   LpGatherParams g;
@@ -784,6 +806,48 @@ extern "C" int bts_lp_conv3d_fwd(int kind, int dtype, const void* x, const void*
                                  long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, hipStream_t stream) {
   if (kind < 0 || kind > 3) return BTS_ERR_UNSUPPORTED;
   return lp_conv_run(kind, dtype, x, wp, bias, y, workspace, workspace_bytes, N, D, H, W, Cin, ldx, Cout, ldy, 0, stream);
+}
+// y = conv3x3x3(x) + bias in the storage type (dense) AND the slab-mode GroupNorm statistics of y (group_norm.py:83-108 as the
+// reference runs it on channels_last data: resnet.py:80-93 conv -> GroupNormalization) in one pass: (sum, sumsq) partials leave the
+// conv's epilogue per (z plane, tile column), bts_gn_finalize_partials_ turns them into mean / rstd.  Grids that split the input
+// channels, z-slabs that are not whole planes (D % G != 0) and heads with Cout % 4 != 0 run the conv and bts_lp_gn_stats on the stored y.
+static bool lp_s1_gn_plan(int N, int D, int H, int W, int Cin, int Cout, int G, long* B) {
+  if (Cin % 16 != 0 || Cout % 4 != 0 || G <= 0 || D % G != 0) return false;
+  const int NB = (Cout + 31) / 32;
+  int vb, cb, txl;
+  lp_s1_shape(N, D, H, W, NB, vb, cb, txl);
+  if (lp_s1_ksplit(lp_s1_wgs(N, D, H, W, NB, vb, cb, txl), Cin / 16) > 1) return false;
+  const int TX = 1 << txl, TY = vb * (32 / TX);
+  *B = (long)(D / G) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX) * ((NB + cb - 1) / cb);
+  return true;
+}
+extern "C" long bts_lp_conv3d_fwd_gn_workspace(int N, int D, int H, int W, int Cin, int Cout, int G) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || G <= 0 || Cout % G != 0) return -1;
+  long B = 0;
+  const long fused = lp_s1_gn_plan(N, D, H, W, Cin, Cout, G, &B) ? (long)N * G * B * 16 + 64 : 0;
+  const long conv = ((lp_s1_workspace(N, D, H, W, Cin, Cout) + 63) / 64) * 64;
+  const long stats = bts_lp_gn_workspace(N, (long)D * H * W, Cout, G);
+  return conv + (fused > stats ? fused : stats) + 64;
+}
+extern "C" int bts_lp_conv3d_fwd_gn(int dtype, const void* x, const void* wp, const float* bias, void* y, float* mean, float* rstd,
+                                    void* workspace, long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int G,
+                                    float eps, hipStream_t stream) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || G <= 0 || Cout % G != 0) return BTS_ERR_SHAPE;
+  if (workspace == nullptr || workspace_bytes < bts_lp_conv3d_fwd_gn_workspace(N, D, H, W, Cin, Cout, G) || (((uintptr_t)workspace) & 15))
+    return BTS_ERR_WORKSPACE;
+  const long conv_ws = ((lp_s1_workspace(N, D, H, W, Cin, Cout) + 63) / 64) * 64;
+  char* tail = reinterpret_cast<char*>(workspace) + conv_ws;
+  const long V = (long)D * H * W;
+  long B = 0;
+  if (lp_s1_gn_plan(N, D, H, W, Cin, Cout, G, &B)) {
+    double* part = reinterpret_cast<double*>(tail);
+    const int r = lp_conv_run(1, dtype, x, wp, bias, y, nullptr, 0, N, D, H, W, Cin, ldx, Cout, Cout, 0, stream, nullptr, part, G);
+    if (r != BTS_OK) return r;
+    return bts_gn_finalize_partials_(part, mean, rstd, N * G, B, (double)(V * Cout / G), eps, stream);
+  }
+  const int r = lp_conv_run(1, dtype, x, wp, bias, y, workspace, conv_ws, N, D, H, W, Cin, ldx, Cout, Cout, 0, stream);
+  if (r != BTS_OK) return r;
+  return bts_lp_gn_stats(dtype, y, mean, rstd, tail, workspace_bytes - conv_ws, N, V, Cout, G, BTS_GN_SLAB, eps, stream);
 }
 __global__ __launch_bounds__(256) void lp_colsum_finalize_kernel(const double* partial, float* out, int N, int C, int B, double scale);
 // res = conv1x1x1(x) + bias in the storage type AND gap[n][c] = mean over the voxels of (the unrounded) res -- the block's shortcut

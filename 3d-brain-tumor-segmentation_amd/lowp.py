@@ -115,6 +115,23 @@ def uncast(code, src):
     return out
 
 
+def conv_gn(code, tdt, x, wp, bias, cout, norm):
+    """(y, mean, rstd): y = conv3x3x3(x) + bias (dense, storage type) and GroupNorm `norm`'s statistics of y -- from the conv's
+    epilogue where the library can (slab mode: the layout the reference's channels_last GroupNormalization reduces over)"""
+    if norm._mode != ops.GN_SLAB:
+        y = conv(ops.K3S1, code, tdt, x, wp, bias, cout)
+        return (y,) + tuple(gn_stats(code, y, norm.groups, norm._mode, norm.epsilon))
+    n, d, h, w, cin = x.shape
+    y = torch.empty((n, d, h, w, cout), dtype=tdt, device=x.device)
+    mean = torch.empty(n * norm.groups, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(n * norm.groups, dtype=torch.float32, device=x.device)
+    nb = lib().query('bts_lp_conv3d_fwd_gn_workspace', n, d, h, w, cin, cout, norm.groups)
+    ws = ops.workspace(nb, x.device)
+    lib().call('bts_lp_conv3d_fwd_gn', code, _p(x), _p(wp), _p(bias), _p(y), _p(mean), _p(rstd), _p(ws), nb, n, d, h, w, cin, _ld(x), cout,
+               norm.groups, float(norm.epsilon), _stream())
+    return y, mean, rstd
+
+
 def gn_stats(code, x, groups, mode, eps):
     n, c = x.shape[0], x.shape[4]
     v = x.shape[1] * x.shape[2] * x.shape[3]
@@ -259,14 +276,13 @@ class LowPrecisionForward(object):
         wp_pt = self._packed((key, 'pt'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
         wp_c1 = self._packed((key, 'c1'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
         res, gap = conv1_gap(code, x, wp_pt, blk.ptwise_b.t, f, tdt)      # shortcut conv + the gate's squeeze in one pass
-        c1 = conv(ops.K3S1, code, tdt, x, wp_c1, blk.conv1_b.t, f)
+        c1, m1, r1 = conv_gn(code, tdt, x, wp_c1, blk.conv1_b.t, f, blk.norm1)      # conv + the statistics of its output
         _, ch = ops.se_mlp_fwd(gap, blk.se_w1.t, blk.se_w2.t)
-        a = self._gn(blk.norm1, c1, True)
+        a = gn_apply(code, c1, blk.norm1.gamma.t, blk.norm1.beta.t, m1, r1, g, blk.norm1._mode, True)
         del c1
         wp_c2 = self._packed((id(blk), 'c2'), ops.K3S1, blk.conv2_k, f, f)
-        c2 = conv(ops.K3S1, code, tdt, a, wp_c2, blk.conv2_b.t, f)
+        c2, m2, r2 = conv_gn(code, tdt, a, wp_c2, blk.conv2_b.t, f, blk.norm2)
         del a
-        m2, r2 = gn_stats(code, c2, g, blk.norm2._mode, blk.norm2.epsilon)
         if out is None:
             out = torch.empty((n, d, h, w, f), dtype=tdt, device=res.device)
         return block_epilogue(code, res, c2, out, blk.spatial_k.t.reshape(-1), ch, blk.norm2.gamma.t, blk.norm2.beta.t, m2, r2, g,

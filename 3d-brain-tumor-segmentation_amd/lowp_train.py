@@ -22,7 +22,7 @@ to the storage type, which is part of what "16-bit storage" means and is bounded
 import torch
 
 from . import lowp, ops, parallel
-from .lowp import DTYPES, block_epilogue, cast, colsum, conv, conv1_gap, conv_bwd_data, gn_apply, gn_stats, head, uncast
+from .lowp import DTYPES, block_epilogue, cast, colsum, conv, conv1_gap, conv_bwd_data, conv_gn, gn_apply, gn_stats, head, uncast
 from .tape import Tensor, bump_weights_epoch, weights_epoch
 
 
@@ -107,13 +107,11 @@ class LowPrecisionTrainer(object):
         wp_pt = self._pk((key, 'pt'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
         wp_c1 = self._pk((key, 'c1'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
         res, gap = conv1_gap(code, x, wp_pt, blk.ptwise_b.t, f, tdt)      # shortcut conv + the gate's squeeze in one pass
-        c1 = conv(ops.K3S1, code, tdt, x, wp_c1, blk.conv1_b.t, f)
+        c1, m1, r1 = conv_gn(code, tdt, x, wp_c1, blk.conv1_b.t, f, blk.norm1)      # conv + the statistics of its output
         hbuf, ch = ops.se_mlp_fwd(gap, blk.se_w1.t, blk.se_w2.t)
-        m1, r1 = gn_stats(code, c1, g, blk.norm1._mode, blk.norm1.epsilon)
         a = gn_apply(code, c1, blk.norm1.gamma.t, blk.norm1.beta.t, m1, r1, g, blk.norm1._mode, True)
         wp_c2 = self._pk((key, 'c2'), ops.K3S1, blk.conv2_k, f, f)
-        c2 = conv(ops.K3S1, code, tdt, a, wp_c2, blk.conv2_b.t, f)
-        m2, r2 = gn_stats(code, c2, g, blk.norm2._mode, blk.norm2.epsilon)
+        c2, m2, r2 = conv_gn(code, tdt, a, wp_c2, blk.conv2_b.t, f, blk.norm2)
         if out is None:
             out = torch.empty((n, d, h, w, f), dtype=tdt, device=x.device)
         sp = torch.empty(n * v, dtype=torch.float32, device=x.device)

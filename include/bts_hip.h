@@ -284,6 +284,12 @@ int bts_lp_colsum(int dtype, const void* x, float* out, void* workspace, long wo
 int bts_lp_block_epilogue(int dtype, const void* res, const void* c2, void* out, float* sp_out, const float* wsp, const float* ch, const float* gamma,
                           const float* beta, const float* mean, const float* rstd, int N, long V, int C, int ldo, int G, int mode,
                           bts_stream_t stream);
+/* y = conv3x3x3(x) + bias in the storage type (dense) and the BTS_GN_SLAB statistics of y (resnet.py:80-93 conv -> GroupNormalization)
+ * in one pass where the tiled kernel can emit the partial sums from its epilogue; the 16-bit counterpart of bts_conv3d_fwd_gn */
+long bts_lp_conv3d_fwd_gn_workspace(int N, int D, int H, int W, int Cin, int Cout, int G);
+int bts_lp_conv3d_fwd_gn(int dtype, const void* x, const void* wp, const float* bias, void* y, float* mean, float* rstd, void* workspace,
+                         long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int G, float eps,
+                         bts_stream_t stream);
 /* res = conv1x1x1(x) + bias in the storage type (dense, ldres == Cout) and gap[n][c] = mean over voxels of res: the block's
  * shortcut and the squeeze of its gate (resnet.py:118-121) in one pass (column sums from the conv epilogue + a small finalize) */
 long bts_lp_conv1_gap_workspace(int N, long V, int Cout);

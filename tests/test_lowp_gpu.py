@@ -443,3 +443,36 @@ def test_shortcut_conv_with_fused_squeeze(case, dtype):
     # rounding noise of V values averages down by sqrt(V) only
     tol = (3e-6 if fused else U[dtype]) * float(y64.abs().mean()) + 2e-6
     assert float((gap.double().cpu() - ref_gap).abs().max()) <= tol, (fused, float((gap.double().cpu() - ref_gap).abs().max()), tol)
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('case', [((1, 32, 16, 32), 32, 32, 8), ((2, 16, 8, 16), 16, 64, 4), ((1, 16, 16, 16), 128, 32, 2), ((1, 12, 8, 16), 16, 32, 2)],
+                         ids=['32-32-g8', 'batch2-16-64-g4', 'splitk-fallback', 'slab-not-whole-tiles'])
+def test_conv_with_fused_groupnorm_statistics(case, dtype):
+    """bts_lp_conv3d_fwd_gn: y bit-equal to the plain 16-bit conv's, (mean, rstd) against the fp64 slab statistics of the oracle's
+    conv on the rounded operands (the fused sums see the unrounded outputs, the two-pass route the stored ones: both within the
+    storage type's rounding of a value, divided by the square root of the group size)"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    (n, d, h, w), cin, cout, G = case
+    code, tdt = lowp.DTYPES[dtype]
+    g = torch.Generator().manual_seed(cin * 3 + cout)
+    x = torch.randn((n, d, h, w, cin), generator=g)
+    wt = torch.randn((3, 3, 3, cin, cout), generator=g) * (2.0 / (27 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g)
+    xin = x.to(tdt).to(DEV)
+    wp = lowp.pack(ops.K3S1, code, wt.to(DEV), cin, cout)
+
+    class _Norm(object):
+        groups, epsilon, _mode = G, 1e-5, ops.GN_SLAB
+    y, mean, rstd = lowp.conv_gn(code, tdt, xin, wp, b.to(DEV), cout, _Norm)
+    y_ref = lowp.conv(ops.K3S1, code, tdt, xin, wp, b.to(DEV), cout)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref)
+    y64 = R.conv3d(_round(x, tdt), _round(wt, tdt), b.double())            # (n, d, h, w, cout)
+    slabs = y64.reshape(n, G, -1)                                           # slab semantics: G equal chunks of the flattened sample
+    m_ref = slabs.mean(dim=2).reshape(-1)
+    r_ref = 1.0 / torch.sqrt(slabs.var(dim=2, unbiased=False) + 1e-5).reshape(-1)
+    scale = float(y64.abs().mean())
+    assert float((mean.double().cpu() - m_ref).abs().max()) <= U[dtype] * scale * 0.05 + 1e-5
+    assert float((rstd.double().cpu() / r_ref - 1).abs().max()) <= U[dtype] * 0.05 + 1e-5
