@@ -1454,9 +1454,6 @@ __global__ __launch_bounds__(512, 1) void lp_wgrad_kernel(const LpWgParams p) {
   unsigned short* ldsQ = lds + (TX + 2) * (TY + 2) * (TZ + 2) * PS;
   const int cpt = blockIdx.y / p.ncqg, cqg = blockIdx.y % p.ncqg;
   const int cp0 = cpt * 32, cq0 = cqg * 32 * NQ;
-  constexpr int PSLOT = ((TX + 2) * (TY + 2) * (TZ + 2) * 4 + 511) / 512;   // 16-byte chunks of the P tile per thread
-  constexpr int QSLOT = (TX * TY * TZ * 4 * NQ + 511) / 512;
-  u32x4 preP[PSLOT], preQ[QSLOT];
   f32x16 acc[4][NQ];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -1464,108 +1461,206 @@ __global__ __launch_bounds__(512, 1) void lp_wgrad_kernel(const LpWgParams p) {
     for (int c = 0; c < NQ; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
-
-  auto fetch = [&](long tile) {
+  auto tile_origin = [&](long tile, int& n, int& x0, int& y0, int& z0) {
     long b = tile;
     const int tx = (int)(b % p.ntx); b /= p.ntx;
     const int ty = (int)(b % p.nty); b /= p.nty;
     const int tz = (int)(b % p.ntz);
-    const int n = (int)(b / p.ntz);
-    const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
-#pragma unroll
-    for (int i = 0; i < PSLOT; ++i) {
-      const int e = tid + i * 512;
-      preP[i] = u32x4{0u, 0u, 0u, 0u};
-      if (e < nvp * 4) {
-        const int vox = e >> 2, cq = e & 3;
-        const int vz = vox / (SY * SX), r = vox - vz * (SY * SX), vy = r / SX, vx = r - vy * SX;
-        const int gz = z0 - halo + vz, gy = y0 - halo + vy, gx = x0 - halo + vx;
-        if ((unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && cp0 + cq * 8 < p.Cp)
-          preP[i] = *reinterpret_cast<const u32x4*>(p.p + ((((long)n * p.D + gz) * p.H + gy) * p.W + gx) * (long)p.ldp + cp0 + cq * 8);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < QSLOT; ++i) {
-      const int e = tid + i * 512;
-      preQ[i] = u32x4{0u, 0u, 0u, 0u};
-      if (e < TX * TY * TZ * 4 * NQ) {
-        const int vox = e / (4 * NQ), cq = e % (4 * NQ);
-        const int vz = vox / (TY * TX), r = vox - vz * (TY * TX), vy = r / TX, vx = r - vy * TX;
-        const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
-        if (gz < p.D && gy < p.H && gx < p.W && cq0 + cq * 8 < p.Cq)
-          preQ[i] = *reinterpret_cast<const u32x4*>(p.q + ((((long)n * p.D + gz) * p.H + gy) * p.W + gx) * (long)p.ldq + cq0 + cq * 8);
-      }
-    }
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int i = 0; i < PSLOT; ++i) {
-      const int e = tid + i * 512;
-      if (e < nvp * 4) {
-        u32x2* d = reinterpret_cast<u32x2*>(ldsP + (e >> 2) * PS + (e & 3) * 8);
-        d[0] = u32x2{preP[i][0], preP[i][1]};
-        d[1] = u32x2{preP[i][2], preP[i][3]};
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < QSLOT; ++i) {
-      const int e = tid + i * 512;
-      if (e < TX * TY * TZ * 4 * NQ) {
-        u32x2* d = reinterpret_cast<u32x2*>(ldsQ + (e / (4 * NQ)) * QS + (e % (4 * NQ)) * 8);
-        d[0] = u32x2{preQ[i][0], preQ[i][1]};
-        d[1] = u32x2{preQ[i][2], preQ[i][3]};
-      }
-    }
-  };
-  // eight 2-byte reads -> one 16-byte matrix operand (K = 8 consecutive voxels along x of one channel)
-  auto gather = [&](const unsigned short* base, int stride) {
-    unsigned v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = base[j * stride];
-    return u32x4{v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
+    n = (int)(b / p.ntz);
+    x0 = tx * TX; y0 = ty * TY; z0 = tz * TZ;
   };
 
-  long tile = blockIdx.x;
-  if (tile < p.ntiles) fetch(tile);
-  for (; tile < p.ntiles; tile += gridDim.x) {
-    __syncthreads();      // every wave is done with the previous tile
-    commit();
-    __syncthreads();
-    if (tile + gridDim.x < p.ntiles) fetch(tile + gridDim.x);
-    if constexpr (K3) {
-      // wave w owns taps w, w+8, w+16 (and w+24 for w < 3) and walks all 32 x-rows of the tile; the taps' LDS offsets are
-      // wave constants, the rows' offsets compile-time ones
-      int toff[4];
+  if constexpr (K3) {
+    // ---- 3x3x3: LDS tiles with PAIRS of x-neighbours interleaved per channel, [row (z, y)][x pair][channel] dwords (low half = the
+    // even slot).  A matrix operand (8 consecutive voxels of one channel) is then 4 consecutive pair-dwords of a lane's channel: 4 or
+    // 5 ds_read_b32 + 4 v_alignbit (a tap's window starts at an odd slot for kx = 0, 2) instead of eight 2-byte reads and their
+    // packing.  Staging interleaves two voxels' 8-channel chunks with v_perm and writes 32 contiguous bytes.
+    constexpr int NPP = (SX + 2) / 2;            // pairs per P row: slots x = -2 .. SX - 1
+    constexpr int NPQ = TX / 2;
+    constexpr int PU = SZ * SY * NPP * 4, QU = TZ * TY * NPQ * 4 * NQ;    // staging units: (row, pair, channel octet)
+    constexpr int PUS = (PU + 511) / 512, QUS = (QU + 511) / 512;
+    unsigned* const ldsP32 = reinterpret_cast<unsigned*>(lds);
+    unsigned* const ldsQ32 = ldsP32 + SZ * SY * NPP * 32;
+    u32x4 preP[PUS][2], preQ[QUS][2];
+    auto fetch = [&](long tile) {
+      int n, x0, y0, z0;
+      tile_origin(tile, n, x0, y0, z0);
 #pragma unroll
-      for (int ti = 0; ti < 4; ++ti) {
-        const int t = wave + 8 * ti;
-        const int tt = t < 27 ? t : 0;
-        toff[ti] = (((tt / 9) * SY + (tt / 3) % 3) * SX + tt % 3) * PS;
+      for (int i = 0; i < PUS; ++i) {
+        const int e = tid + i * 512;
+        preP[i][0] = preP[i][1] = u32x4{0u, 0u, 0u, 0u};
+        if (e < PU) {
+          const int oct = e & 3, xp = (e >> 2) % NPP, row = (e >> 2) / NPP;
+          const int gz = z0 - 1 + row / SY, gy = y0 - 1 + row % SY;
+          if ((unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && cp0 + oct * 8 < p.Cp) {
+            const unsigned short* rowp = p.p + (((long)n * p.D + gz) * p.H + gy) * (long)p.W * p.ldp + cp0 + oct * 8;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+              const int slot = 2 * xp + s2, gx = x0 - 2 + slot;   // slots 1 .. SX are the halo tile's columns -1 .. TX
+              if (slot >= 1 && slot <= SX && (unsigned)gx < (unsigned)p.W) preP[i][s2] = *reinterpret_cast<const u32x4*>(rowp + (long)gx * p.ldp);
+            }
+          }
+        }
       }
-      const bool t3 = wave + 24 < 27;
-      const unsigned short* pbase = ldsP + 8 * h * PS + l32;
-      const unsigned short* qbase = ldsQ + 8 * h * QS + l32;
+#pragma unroll
+      for (int i = 0; i < QUS; ++i) {
+        const int e = tid + i * 512;
+        preQ[i][0] = preQ[i][1] = u32x4{0u, 0u, 0u, 0u};
+        if (e < QU) {
+          const int oct = e % (4 * NQ), xp = (e / (4 * NQ)) % NPQ, row = e / (4 * NQ * NPQ);
+          const int gz = z0 + row / TY, gy = y0 + row % TY;
+          if (gz < p.D && gy < p.H && cq0 + oct * 8 < p.Cq) {
+            const unsigned short* rowq = p.q + (((long)n * p.D + gz) * p.H + gy) * (long)p.W * p.ldq + cq0 + oct * 8;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+              const int gx = x0 + 2 * xp + s2;
+              if (gx < p.W) preQ[i][s2] = *reinterpret_cast<const u32x4*>(rowq + (long)gx * p.ldq);
+            }
+          }
+        }
+      }
+    };
+    // (even voxel's channels c, c+1 | odd voxel's c, c+1) x 4 -> channel c: (even, odd), channel c+1: (even, odd)
+    auto weave = [&](const u32x4 ev, const u32x4 od, unsigned* dst) {
+      u32x4 lo, hi;
+      lo[0] = __builtin_amdgcn_perm(od[0], ev[0], 0x05040100u); lo[1] = __builtin_amdgcn_perm(od[0], ev[0], 0x07060302u);
+      lo[2] = __builtin_amdgcn_perm(od[1], ev[1], 0x05040100u); lo[3] = __builtin_amdgcn_perm(od[1], ev[1], 0x07060302u);
+      hi[0] = __builtin_amdgcn_perm(od[2], ev[2], 0x05040100u); hi[1] = __builtin_amdgcn_perm(od[2], ev[2], 0x07060302u);
+      hi[2] = __builtin_amdgcn_perm(od[3], ev[3], 0x05040100u); hi[3] = __builtin_amdgcn_perm(od[3], ev[3], 0x07060302u);
+      reinterpret_cast<u32x4*>(dst)[0] = lo;
+      reinterpret_cast<u32x4*>(dst)[1] = hi;
+    };
+    auto commit = [&]() {
+#pragma unroll
+      for (int i = 0; i < PUS; ++i) {
+        const int e = tid + i * 512;
+        if (e < PU) weave(preP[i][0], preP[i][1], ldsP32 + (e >> 2) * 32 + (e & 3) * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < QUS; ++i) {
+        const int e = tid + i * 512;
+        if (e < QU) weave(preQ[i][0], preQ[i][1], ldsQ32 + (e / (4 * NQ)) * (32 * NQ) + (e % (4 * NQ)) * 8);
+      }
+    };
+    // wave w owns taps w, w+8, w+16 (and w+24 for w < 3) and walks all 32 x-rows of the tile; a tap's window starts at slot
+    // kx + 1 (+ 8 for the lanes of the upper K half): pair offset and alignbit shift are wave constants
+    int toff[4], tsh[4];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      const int t = wave + 8 * ti;
+      const int tt = t < 27 ? t : 0;
+      const int kx = tt % 3;
+      toff[ti] = ((((tt / 9) * SY + (tt / 3) % 3) * NPP) + ((kx + 1) >> 1)) * 32;
+      tsh[ti] = ((kx + 1) & 1) ? 16 : 0;
+    }
+    const bool t3 = wave + 24 < 27;
+    const unsigned* pbase = ldsP32 + 4 * h * 32 + l32;
+    const unsigned* qbase = ldsQ32 + 4 * h * (32 * NQ) + l32;
+    auto pfrag = [&](const unsigned* prow, int off, int sh) {
+      unsigned pp[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) pp[k] = prow[off + k * 32];
+      return u32x4{__builtin_amdgcn_alignbit(pp[1], pp[0], sh), __builtin_amdgcn_alignbit(pp[2], pp[1], sh),
+                   __builtin_amdgcn_alignbit(pp[3], pp[2], sh), __builtin_amdgcn_alignbit(pp[4], pp[3], sh)};
+    };
+    long tile = blockIdx.x;
+    if (tile < p.ntiles) fetch(tile);
+    for (; tile < p.ntiles; tile += gridDim.x) {
+      __syncthreads();      // every wave is done with the previous tile
+      commit();
+      __syncthreads();
+      if (tile + gridDim.x < p.ntiles) fetch(tile + gridDim.x);
 #pragma unroll 4
       for (int kb = 0; kb < TY * TZ; ++kb) {
         const int z = kb / TY, y = kb % TY;
         u32x4 bq[NQ];
 #pragma unroll
-        for (int c = 0; c < NQ; ++c) bq[c] = gather(qbase + ((z * TY + y) * TX) * QS + c * 32, QS);
-        const unsigned short* prow = pbase + ((z * SY + y) * SX) * PS;
+        for (int c = 0; c < NQ; ++c) {
+          const unsigned* qr = qbase + (kb * NPQ) * (32 * NQ) + c * 32;
+          bq[c] = u32x4{qr[0], qr[32 * NQ], qr[2 * 32 * NQ], qr[3 * 32 * NQ]};
+        }
+        const unsigned* prow = pbase + ((z * SY + y) * NPP) * 32;
 #pragma unroll
         for (int ti = 0; ti < 3; ++ti) {
-          const u32x4 a = gather(prow + toff[ti], PS);
+          const u32x4 a = pfrag(prow, toff[ti], tsh[ti]);
 #pragma unroll
           for (int c = 0; c < NQ; ++c) acc[ti][c] = T::mfma(a, bq[c], acc[ti][c]);
         }
         if (t3) {
-          const u32x4 a = gather(prow + toff[3], PS);
+          const u32x4 a = pfrag(prow, toff[3], tsh[3]);
 #pragma unroll
           for (int c = 0; c < NQ; ++c) acc[3][c] = T::mfma(a, bq[c], acc[3][c]);
         }
       }
-    } else {
-      // 1x1x1: wave w takes x-rows w, w+8, w+16, w+24 (one accumulator per wave; the finalize adds the eight)
+    }
+  } else {
+    // ---- 1x1x1: voxel-major tiles as they come, every fragment gathered with eight 2-byte LDS reads; wave w takes x-rows w, w+8,
+    // w+16, w+24 (one accumulator per wave; the finalize adds the eight)
+    constexpr int PSLOT = (nvp * 4 + 511) / 512;   // 16-byte chunks of the P tile per thread
+    constexpr int QSLOT = (TX * TY * TZ * 4 * NQ + 511) / 512;
+    u32x4 preP[PSLOT], preQ[QSLOT];
+    auto fetch = [&](long tile) {
+      int n, x0, y0, z0;
+      tile_origin(tile, n, x0, y0, z0);
+#pragma unroll
+      for (int i = 0; i < PSLOT; ++i) {
+        const int e = tid + i * 512;
+        preP[i] = u32x4{0u, 0u, 0u, 0u};
+        if (e < nvp * 4) {
+          const int vox = e >> 2, cq = e & 3;
+          const int vz = vox / (SY * SX), r = vox - vz * (SY * SX), vy = r / SX, vx = r - vy * SX;
+          const int gz = z0 - halo + vz, gy = y0 - halo + vy, gx = x0 - halo + vx;
+          if ((unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && cp0 + cq * 8 < p.Cp)
+            preP[i] = *reinterpret_cast<const u32x4*>(p.p + ((((long)n * p.D + gz) * p.H + gy) * p.W + gx) * (long)p.ldp + cp0 + cq * 8);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < QSLOT; ++i) {
+        const int e = tid + i * 512;
+        preQ[i] = u32x4{0u, 0u, 0u, 0u};
+        if (e < TX * TY * TZ * 4 * NQ) {
+          const int vox = e / (4 * NQ), cq = e % (4 * NQ);
+          const int vz = vox / (TY * TX), r = vox - vz * (TY * TX), vy = r / TX, vx = r - vy * TX;
+          const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
+          if (gz < p.D && gy < p.H && gx < p.W && cq0 + cq * 8 < p.Cq)
+            preQ[i] = *reinterpret_cast<const u32x4*>(p.q + ((((long)n * p.D + gz) * p.H + gy) * p.W + gx) * (long)p.ldq + cq0 + cq * 8);
+        }
+      }
+    };
+    auto commit = [&]() {
+#pragma unroll
+      for (int i = 0; i < PSLOT; ++i) {
+        const int e = tid + i * 512;
+        if (e < nvp * 4) {
+          u32x2* d = reinterpret_cast<u32x2*>(ldsP + (e >> 2) * PS + (e & 3) * 8);
+          d[0] = u32x2{preP[i][0], preP[i][1]};
+          d[1] = u32x2{preP[i][2], preP[i][3]};
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < QSLOT; ++i) {
+        const int e = tid + i * 512;
+        if (e < TX * TY * TZ * 4 * NQ) {
+          u32x2* d = reinterpret_cast<u32x2*>(ldsQ + (e / (4 * NQ)) * QS + (e % (4 * NQ)) * 8);
+          d[0] = u32x2{preQ[i][0], preQ[i][1]};
+          d[1] = u32x2{preQ[i][2], preQ[i][3]};
+        }
+      }
+    };
+    // eight 2-byte reads -> one 16-byte matrix operand (K = 8 consecutive voxels along x of one channel)
+    auto gather = [&](const unsigned short* base, int stride) {
+      unsigned v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = base[j * stride];
+      return u32x4{v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
+    };
+    long tile = blockIdx.x;
+    if (tile < p.ntiles) fetch(tile);
+    for (; tile < p.ntiles; tile += gridDim.x) {
+      __syncthreads();      // every wave is done with the previous tile
+      commit();
+      __syncthreads();
+      if (tile + gridDim.x < p.ntiles) fetch(tile + gridDim.x);
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti) {
         const int kb = wave + 8 * ti;
