@@ -1542,54 +1542,140 @@ __global__ __launch_bounds__(512, 1) void lp_wgrad_kernel(const LpWgParams p) {
         if (e < QU) weave(preQ[i][0], preQ[i][1], ldsQ32 + (e / (4 * NQ)) * (32 * NQ) + (e % (4 * NQ)) * 8);
       }
     };
-    // wave w owns taps w, w+8, w+16 (and w+24 for w < 3) and walks all 32 x-rows of the tile; a tap's window starts at slot
-    // kx + 1 (+ 8 for the lanes of the upper K half): pair offset and alignbit shift are wave constants
-    int toff[4], tsh[4];
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti) {
-      const int t = wave + 8 * ti;
-      const int tt = t < 27 ? t : 0;
-      const int kx = tt % 3;
-      toff[ti] = ((((tt / 9) * SY + (tt / 3) % 3) * NPP) + ((kx + 1) >> 1)) * 32;
-      tsh[ti] = ((kx + 1) & 1) ? 16 : 0;
-    }
-    const bool t3 = wave + 24 < 27;
-    const unsigned* pbase = ldsP32 + 4 * h * 32 + l32;
-    const unsigned* qbase = ldsQ32 + 4 * h * (32 * NQ) + l32;
-    auto pfrag = [&](const unsigned* prow, int off, int sh) {
-      unsigned pp[5];
-#pragma unroll
-      for (int k = 0; k < 5; ++k) pp[k] = prow[off + k * 32];
-      return u32x4{__builtin_amdgcn_alignbit(pp[1], pp[0], sh), __builtin_amdgcn_alignbit(pp[2], pp[1], sh),
-                   __builtin_amdgcn_alignbit(pp[3], pp[2], sh), __builtin_amdgcn_alignbit(pp[4], pp[3], sh)};
-    };
-    long tile = blockIdx.x;
-    if (tile < p.ntiles) fetch(tile);
-    for (; tile < p.ntiles; tile += gridDim.x) {
-      __syncthreads();      // every wave is done with the previous tile
-      commit();
+    if constexpr (NQ == 1) {
+      // Tap dealing: six compute waves = (dy, half of the tile's y rows); a wave walks the P rows (z', y' = y + dy) of its four y
+      // and uses each row's three x windows (kx = 0, 1, 2: window starts at slots 1, 2, 3 -- six pair reads, five alignbits) for
+      // ALL three dz with the Q rows z = z' - dz, which roll through three fragment registers: 10 LDS reads + 5 vector-ALU
+      // instructions per 9 matrix instructions at full depth.  Nine accumulators (dz, kx) per wave; the two halves of a dy meet in
+      // LDS at the end.  Waves 6, 7 only help staging.
+      const bool cw = wave < 6;
+      const int dy = wave % 3, half = (wave / 3) & 1;
+      const unsigned* pbase = ldsP32 + 4 * h * 32 + l32;
+      const unsigned* qbase = ldsQ32 + 4 * h * 32 + l32;
+      f32x16 a9[3][3];
+  #pragma unroll
+      for (int dz = 0; dz < 3; ++dz)
+  #pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) a9[dz][kx][r] = 0.f;
+      long tile = blockIdx.x;
+      if (tile < p.ntiles) fetch(tile);
+      for (; tile < p.ntiles; tile += gridDim.x) {
+        __syncthreads();      // every wave is done with the previous tile
+        commit();
+        __syncthreads();
+        if (tile + gridDim.x < p.ntiles) fetch(tile + gridDim.x);
+        if (cw) {
+  #pragma unroll 2
+          for (int yi = 0; yi < TY / 2; ++yi) {
+            const int yq = half * (TY / 2) + yi;
+            const unsigned* prow = pbase + ((yq + dy) * NPP) * 32;
+            const unsigned* qrow = qbase + (yq * NPQ) * 32;
+            u32x4 qf[3];
+  #pragma unroll
+            for (int zp = 0; zp < SZ; ++zp) {
+              if (zp < TZ) {
+                const unsigned* qr = qrow + (zp * TY * NPQ) * 32;
+                qf[zp % 3] = u32x4{qr[0], qr[32], qr[64], qr[96]};
+              }
+              const unsigned* pr = prow + (zp * SY * NPP) * 32;
+              unsigned pp[6], sh[5];
+  #pragma unroll
+              for (int k = 0; k < 6; ++k) pp[k] = pr[k * 32];
+  #pragma unroll
+              for (int k = 0; k < 5; ++k) sh[k] = __builtin_amdgcn_alignbit(pp[k + 1], pp[k], 16);
+              const u32x4 w0 = {sh[0], sh[1], sh[2], sh[3]}, w1 = {pp[1], pp[2], pp[3], pp[4]}, w2 = {sh[1], sh[2], sh[3], sh[4]};
+  #pragma unroll
+              for (int dz = 0; dz < 3; ++dz) {
+                const int z = zp - dz;
+                if (z >= 0 && z < TZ) {
+                  a9[dz][0] = T::mfma(w0, qf[z % 3], a9[dz][0]);
+                  a9[dz][1] = T::mfma(w1, qf[z % 3], a9[dz][1]);
+                  a9[dz][2] = T::mfma(w2, qf[z % 3], a9[dz][2]);
+                }
+              }
+            }
+          }
+        }
+      }
+      // the two halves of a dy: waves 3..5 hand their nine accumulators over through LDS, waves 0..2 add and write the partials
       __syncthreads();
-      if (tile + gridDim.x < p.ntiles) fetch(tile + gridDim.x);
-#pragma unroll 4
-      for (int kb = 0; kb < TY * TZ; ++kb) {
-        const int z = kb / TY, y = kb % TY;
-        u32x4 bq[NQ];
-#pragma unroll
-        for (int c = 0; c < NQ; ++c) {
-          const unsigned* qr = qbase + (kb * NPQ) * (32 * NQ) + c * 32;
-          bq[c] = u32x4{qr[0], qr[32 * NQ], qr[2 * 32 * NQ], qr[3 * 32 * NQ]};
-        }
-        const unsigned* prow = pbase + ((z * SY + y) * NPP) * 32;
-#pragma unroll
-        for (int ti = 0; ti < 3; ++ti) {
-          const u32x4 a = pfrag(prow, toff[ti], tsh[ti]);
-#pragma unroll
-          for (int c = 0; c < NQ; ++c) acc[ti][c] = T::mfma(a, bq[c], acc[ti][c]);
-        }
-        if (t3) {
-          const u32x4 a = pfrag(prow, toff[3], tsh[3]);
-#pragma unroll
-          for (int c = 0; c < NQ; ++c) acc[3][c] = T::mfma(a, bq[c], acc[3][c]);
+      float* xch = reinterpret_cast<float*>(lds);
+      if (wave >= 3 && wave < 6) {
+  #pragma unroll
+        for (int dz = 0; dz < 3; ++dz)
+  #pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) xch[((((wave - 3) * 9 + dz * 3 + kx) * 16) + r) * 64 + lane] = a9[dz][kx][r];
+      }
+      __syncthreads();
+      if (wave < 3) {
+        float* pb = p.part + (((long)blockIdx.x * p.ncp + cpt) * p.ncqg + cqg) * (long)27 * 32 * 32;
+  #pragma unroll
+        for (int dz = 0; dz < 3; ++dz)
+  #pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int slot = (dz * 3 + dy) * 3 + kx;
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+              pb[((long)slot * 32 + row) * 32 + l32] = a9[dz][kx][r] + xch[(((wave * 9 + dz * 3 + kx) * 16) + r) * 64 + lane];
+            }
+          }
+      }
+      return;
+    } else {
+      // wave w owns taps w, w+8, w+16 (and w+24 for w < 3) and walks all 32 x-rows of the tile; a tap's window starts at slot
+      // kx + 1 (+ 8 for the lanes of the upper K half): pair offset and alignbit shift are wave constants
+      int toff[4], tsh[4];
+  #pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        const int t = wave + 8 * ti;
+        const int tt = t < 27 ? t : 0;
+        const int kx = tt % 3;
+        toff[ti] = ((((tt / 9) * SY + (tt / 3) % 3) * NPP) + ((kx + 1) >> 1)) * 32;
+        tsh[ti] = ((kx + 1) & 1) ? 16 : 0;
+      }
+      const bool t3 = wave + 24 < 27;
+      const unsigned* pbase = ldsP32 + 4 * h * 32 + l32;
+      const unsigned* qbase = ldsQ32 + 4 * h * (32 * NQ) + l32;
+      auto pfrag = [&](const unsigned* prow, int off, int sh) {
+        unsigned pp[5];
+  #pragma unroll
+        for (int k = 0; k < 5; ++k) pp[k] = prow[off + k * 32];
+        return u32x4{__builtin_amdgcn_alignbit(pp[1], pp[0], sh), __builtin_amdgcn_alignbit(pp[2], pp[1], sh),
+                     __builtin_amdgcn_alignbit(pp[3], pp[2], sh), __builtin_amdgcn_alignbit(pp[4], pp[3], sh)};
+      };
+      long tile = blockIdx.x;
+      if (tile < p.ntiles) fetch(tile);
+      for (; tile < p.ntiles; tile += gridDim.x) {
+        __syncthreads();      // every wave is done with the previous tile
+        commit();
+        __syncthreads();
+        if (tile + gridDim.x < p.ntiles) fetch(tile + gridDim.x);
+  #pragma unroll 4
+        for (int kb = 0; kb < TY * TZ; ++kb) {
+          const int z = kb / TY, y = kb % TY;
+          u32x4 bq[NQ];
+  #pragma unroll
+          for (int c = 0; c < NQ; ++c) {
+            const unsigned* qr = qbase + (kb * NPQ) * (32 * NQ) + c * 32;
+            bq[c] = u32x4{qr[0], qr[32 * NQ], qr[2 * 32 * NQ], qr[3 * 32 * NQ]};
+          }
+          const unsigned* prow = pbase + ((z * SY + y) * NPP) * 32;
+  #pragma unroll
+          for (int ti = 0; ti < 3; ++ti) {
+            const u32x4 a = pfrag(prow, toff[ti], tsh[ti]);
+  #pragma unroll
+            for (int c = 0; c < NQ; ++c) acc[ti][c] = T::mfma(a, bq[c], acc[ti][c]);
+          }
+          if (t3) {
+            const u32x4 a = pfrag(prow, toff[3], tsh[3]);
+  #pragma unroll
+            for (int c = 0; c < NQ; ++c) acc[3][c] = T::mfma(a, bq[c], acc[3][c]);
+          }
         }
       }
     }
@@ -1793,6 +1879,8 @@ extern "C" int bts_lp_conv3d_bwd_weight(int kind, int dtype, const void* x, cons
     hipLaunchKernelGGL(kern, dim3(nwg, p.ncp * p.ncqg), dim3(512), shmem, stream, p);                                         \
   } while (0)
   const bool k3 = kind == BTS_CONV_K3S1;
+  const bool prof = bts_prof_on();
+  if (prof) bts_prof_begin(32, 2.0 * p.ntaps * (double)Cin * Cout * (double)N * D * H * W, stream);
   if (dtype == LP_F16) {
     if (k3) { if (nq == 2) LPW_LAUNCH(TF16, 2, true); else LPW_LAUNCH(TF16, 1, true); }
     else { if (nq == 2) LPW_LAUNCH(TF16, 2, false); else LPW_LAUNCH(TF16, 1, false); }
@@ -1801,6 +1889,7 @@ extern "C" int bts_lp_conv3d_bwd_weight(int kind, int dtype, const void* x, cons
     else { if (nq == 2) LPW_LAUNCH(TBF16, 2, false); else LPW_LAUNCH(TBF16, 1, false); }
   }
 #undef LPW_LAUNCH
+  if (prof) bts_prof_end(stream);
   BTS_LAUNCH_CHECK();
   LpWfParams f;
   f.part = p.part; f.dw = dw; f.nwg = nwg; f.ncp = p.ncp; f.ncqg = p.ncqg; f.nslot = kind == BTS_CONV_K3S1 ? 27 : 8; f.ntaps = p.ntaps; f.NQ = nq;
