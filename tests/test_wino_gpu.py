@@ -279,3 +279,31 @@ def test_wino_full_size_agrees_with_direct_form():
     lin = (ys - (y + ya)).abs()
     tol2 = 3 * 32 * EPS32 * (bound + bound2) + 1e-6      # three Winograd evaluations + the fp32 sums x + x2, y + ya
     assert not bool((lin > tol2).any()), 'linearity: max err %.3e' % float(lin.max())
+
+
+@pytest.mark.parametrize('t', [1, 2, 3, 5, 8])
+def test_w3_chained_items_any_length(t, monkeypatch):
+    """conv_wino3.hip walks T consecutive (tile, cout block) items per workgroup as one stage stream (the successor's halo tiles and
+    weight fragments ride in the predecessor's last stages); the launcher picks T per launch, BTS_W3_T forces it: every chain
+    length -- including ones that do not divide an XCD's item count, so that the last workgroup's chain is cut short -- gives the
+    bits of T = 1, and those agree with the oracle.  (Runs for the F(2x2x2,3x3x3) form only.)"""
+    from bts_amd import ops
+    if FORM['kernel'] != 'w3_kernel':
+        pytest.skip('item chaining of this kind exists in w3_kernel only')
+    n, (d, h, w), cin, cout = 2, (8, 12, 48), 24, 80     # 2*2*3*3 = 36 tiles over 8 XCDs (ragged eighths), 3 cout blocks, 3 stages
+    x = rnd((n, d, h, w, cin), 31)
+    wt = rnd((3, 3, 3, cin, cout), 32, 0.2)
+    b = rnd((cout,), 33)
+    ref = R.conv3d(x.double(), wt.double(), b.double())
+    bound = R.conv3d(x.double().abs(), wt.double().abs(), b.double().abs())
+    xg = x.to(dev())
+    wp = ops.conv_pack(ops.K3S1, ops.ROLE_FWD, wt.to(dev()), cin, cout)
+    monkeypatch.setenv('BTS_W3_T', '1')
+    with ran_wino():
+        y1 = ops.conv_fwd(ops.K3S1, xg, wp, b.to(dev()), cout)
+    monkeypatch.setenv('BTS_W3_T', str(t))
+    with ran_wino():
+        yt = ops.conv_fwd(ops.K3S1, xg, wp, b.to(dev()), cout)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, yt)
+    check_wino(yt, ref, bound, 'w3 chain T=%d' % t)
