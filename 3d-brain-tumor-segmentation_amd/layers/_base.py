@@ -132,7 +132,7 @@ class _PackEntry(object):
 
 
 _pack_registry = []
-_pack_table = ops.PackTable()
+_pack_tables = {}
 
 
 def _repack_all():
@@ -149,11 +149,21 @@ def _repack_all():
         if not e.param.t.is_contiguous():
             kind, role, cin_ref, cout, cin_slab, dup_start, dup_shift = e.sig
             e.wp = ops.conv_pack(kind, role, e.param.t, cin_ref, cout, cin_slab, dup_start, dup_shift)
+    # forward-role images are needed at once; data-gradient-role images only when the backward starts (tape.gradient joins the
+    # side streams first): their half of the pack runs on the weight-gradient stream, idle during the forward
     by_dev = {}
     for e in batch:
-        by_dev.setdefault(e.wp.device, []).append(e)
-    for dev, es in by_dev.items():
-        _pack_table.run([(e.sig[0], e.sig[1], e.param.t, e.wp) + tuple(e.sig[2:]) for e in es])
+        by_dev.setdefault((e.wp.device, e.sig[1] == ops.ROLE_BWD), []).append(e)
+    for (dev, bwd), es in by_dev.items():
+        entries = [(e.sig[0], e.sig[1], e.param.t, e.wp) + tuple(e.sig[2:]) for e in es]
+        side = ops.side_stream('wgrad') if (bwd and dev.type == 'cuda') else None
+        table = _pack_tables.setdefault((dev, bwd), ops.PackTable())
+        if side is None:
+            table.run(entries)
+        else:
+            side.wait_stream(torch.cuda.current_stream())     # the optimiser step that changed the parameters
+            with torch.cuda.stream(side):
+                table.run(entries)
     for e in todo:
         e.epoch = ep
 

@@ -225,6 +225,7 @@ class GradientTape(object):
         self.grad_sync = grad_sync
         self._touched = [] if grad_sync is not None else None
         try:
+            ops.join_side_stream()      # data-gradient weight images packed on the side stream during the forward (layers/_base.py)
             if grad_sync is not None:
                 grad_sync.begin(self)
             nodes = self.nodes if self.persistent else None
