@@ -49,8 +49,6 @@ extern "C" int bts_w3_stamps_copy_(long long* dst, long n) {
 #define W3STAMP(slot) do { } while (0)
 #endif
 
-template <int I> struct IC { static constexpr int value = I; };
-
 struct W3Params {
   const float* x;
   const float* up;
@@ -445,181 +443,6 @@ __global__ __launch_bounds__(256, 1) void w3_kernel(const W3Params p) {
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// EXPERIMENT (BTS_W3B=1): the same convolution with TWO waves per SIMD -- 8 waves, wave = (xi_z, y pair): 8 accumulators each
-// (xi_y in {1, 2} or {0, 3}), 128 accumulation + <= 128 vector registers, so that one wave's transforms / memory instructions
-// issue under the other's matrix instructions.  Plain launches only (one item per workgroup, no split-K / accumulate / fused
-// GroupNorm sums): it exists to measure whether the second wave pays on this part (the two-axis kernel's did not: the clock drops).
-// ---------------------------------------------------------------------------------------------------------------------
-#define W3B_EXH (8 * 2 * 4 * 64 * 4)   // dwords of one exchange half: [wave][cout quad of the half][oy*2+ox][lane] x 4
-__global__ __launch_bounds__(512, 1) void w3b_kernel(const W3Params p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int a = wave & 3, yp = wave >> 2;
-  const int h = lane >> 5, l32 = lane & 31;
-  const int ptx = l32 & 7, pty = (l32 >> 3) & 1, ptz = l32 >> 4;
-  const int nb_ = p.nb;
-  const int xcd_ = blockIdx.x & 7;
-  const int seq = blockIdx.x >> 3;
-  int tiles_left = p.ntiles - xcd_ * p.tiles_per_xcd;
-  if (tiles_left > p.tiles_per_xcd) tiles_left = p.tiles_per_xcd;
-  if (seq >= tiles_left * nb_) return;
-  const int cb = seq % nb_;
-  int tb = xcd_ * p.tiles_per_xcd + seq / nb_;
-  const int ttx = tb % p.ntx; tb /= p.ntx;
-  const int tty = tb % p.nty; tb /= p.nty;
-  const int ttz = tb % p.ntz;
-  const int n = tb / p.ntz;
-  // staging: thread -> (z patch zp, (y, x) column, channel half); threads 432..511 repeat 352..431 (same values, same cells)
-  const int s_t = tid < 432 ? tid : tid - 80;
-  const int s_q = s_t & 1, s_c = (s_t >> 1) % 108, s_zp = (s_t >> 1) / 108;
-  const int s_vy = s_c / W3SX, s_vx = s_c - s_vy * W3SX;
-  const int iz0 = ttz * 4 - 1, iy0 = tty * 4 - 1, ix0 = ttx * 16 - 1;
-  const float* xorg = p.x + ((((long)n * p.D + iz0) * p.H + iy0) * p.W + ix0) * (long)p.ldx;
-  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xorg, 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wr =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(p.up + (long)cb * p.KG * (64 * 256)), 0, 0x7fffffff, 0x00020000);
-  unsigned goff[4];
-  {
-    const bool col_in = (unsigned)(iy0 + s_vy) < (unsigned)p.H && (unsigned)(ix0 + s_vx) < (unsigned)p.W;
-    const unsigned gcol = (unsigned)((s_vy * p.W + s_vx) * p.ldx + s_q * 4) * 4u;
-    const unsigned gplane = (unsigned)(p.H * p.W * p.ldx) * 4u;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int z = 2 * s_zp + i;
-      goff[i] = (col_in && (unsigned)(iz0 + z) < (unsigned)p.D) ? gcol + (unsigned)z * gplane : 0x80000000u;
-    }
-  }
-  const int lcol = (s_zp * 4) * W3PL + (s_vy * W3LX + (s_vx & 1) * 10 + (s_vx >> 1)) * W3S + s_q * 4;
-  const int offP = (ptz * 4 + a) * W3PL + (2 * pty * W3LX + ptx) * W3S + h * 4;
-  const unsigned wlane = (unsigned)((h * 32 + l32) * 16);
-  const unsigned wwave = (unsigned)(a * 16 * 1024);
-  const int st0 = 0, st1 = p.KG;
-
-  f32x16 acc[2][4];
-  f32x4 pre[4], aw[4], c[2][4], t[4], v[4];
-  auto fetch = [&](unsigned soff) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) pre[i] = bufload(xr, goff[i], soff);
-  };
-  auto commit = [&](float* buf) {
-    float* o = buf + lcol;
-    *reinterpret_cast<f32x4*>(o + 0 * W3PL) = sub4(pre[0], pre[2]);
-    *reinterpret_cast<f32x4*>(o + 1 * W3PL) = add4(pre[1], pre[2]);
-    *reinterpret_cast<f32x4*>(o + 2 * W3PL) = sub4(pre[2], pre[1]);
-    *reinterpret_cast<f32x4*>(o + 3 * W3PL) = sub4(pre[1], pre[3]);
-  };
-  auto wload = [&](int st, int b) {
-    const unsigned so = (unsigned)(st * (64 * 1024) + b * 4096) + wwave;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) aw[e] = bufload(wr, wlane + e * 1024, so);
-  };
-  auto rd2 = [&](const float* lb, int r0, int r1) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      c[0][k] = *reinterpret_cast<const f32x4*>(lb + W3OFF(r0, k));
-      c[1][k] = *reinterpret_cast<const f32x4*>(lb + W3OFF(r1, k));
-    }
-  };
-  auto stage = [&](auto first_tag, auto yp_tag, int st, int par) {
-    constexpr bool FIRST = decltype(first_tag)::value;
-    constexpr int YP = decltype(yp_tag)::value;
-    const float* lb = lds + par * W3BUF + offP;
-    __syncthreads();
-    fetch(st + 1 < st1 ? (unsigned)(st + 1) * 32u : 0x80000000u);
-    // group 0: xi_y = 1 (c1 + c2) | 0 (c0 - c2)
-    rd2(lb, YP ? 0 : 1, 2);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) t[k] = YP ? sub4(c[0][k], c[1][k]) : add4(c[0][k], c[1][k]);
-    wino_yt(t, v);
-    wino_mfma16<FIRST>(v, reinterpret_cast<const f32x4(&)[4]>(aw), acc[0]);
-    __builtin_amdgcn_sched_barrier(0);
-    wload(st, YP ? 3 : 2);
-    // group 1: xi_y = 2 (c2 - c1) | 3 (c1 - c3)
-    if (YP) rd2(lb, 1, 3);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) t[k] = YP ? sub4(c[0][k], c[1][k]) : sub4(c[1][k], c[0][k]);
-    wino_yt(t, v);
-    wino_mfma16<FIRST>(v, reinterpret_cast<const f32x4(&)[4]>(aw), acc[1]);
-    __builtin_amdgcn_sched_barrier(0);
-    wload(st + 1 < st1 ? st + 1 : st, YP ? 0 : 1);
-    commit(lds + (par ^ 1) * W3BUF);
-  };
-
-  fetch((unsigned)st0 * 32u);
-  wload(st0, yp ? 0 : 1);
-  commit(lds);
-  int par = 0;
-  if (yp) {
-    stage(std::true_type{}, IC<1>{}, st0, 0);
-    par = 1;
-    for (int st = st0 + 1; st < st1; ++st) { stage(std::false_type{}, IC<1>{}, st, par); par ^= 1; }
-  } else {
-    stage(std::true_type{}, IC<0>{}, st0, 0);
-    par = 1;
-    for (int st = st0 + 1; st < st1; ++st) { stage(std::false_type{}, IC<0>{}, st, par); par ^= 1; }
-  }
-
-  // ---- output: x transform + this wave's share of the y transform, exchange in two halves of the cout quads, z + y combine ----
-  const float* obase = p.y + (long)n * p.D * p.H * p.W * (long)p.ldy;
-  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, 0x7fffffff, 0x00020000);
-  float* const ex = lds;
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    __syncthreads();   // the staging buffers (first half) / the previous half's exchange are free
-#pragma unroll
-    for (int gi = 0; gi < 2; ++gi) {
-      const int g = 2 * half + gi;
-      f32x4 tq[2][2];
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        f32x4 q[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          q[k] = f32x4{acc_rd(acc[b][k][4 * g]), acc_rd(acc[b][k][4 * g + 1]), acc_rd(acc[b][k][4 * g + 2]), acc_rd(acc[b][k][4 * g + 3])};
-        tq[b][0] = add4(add4(q[0], q[1]), q[2]);
-        tq[b][1] = sub4(sub4(q[1], q[2]), q[3]);
-      }
-#pragma unroll
-      for (int ox = 0; ox < 2; ++ox) {
-        // y pair {1, 2}: oy0 += t1 + t2, oy1 += t1 - t2 ; y pair {0, 3}: oy0 += t0, oy1 -= t3
-        const f32x4 m0 = yp ? tq[0][ox] : add4(tq[0][ox], tq[1][ox]);
-        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 m1 = yp ? sub4(z4, tq[1][ox]) : sub4(tq[0][ox], tq[1][ox]);
-        *reinterpret_cast<f32x4*>(ex + (((wave * 2 + gi) * 4 + 0 + ox) * 64 + lane) * 4) = m0;
-        *reinterpret_cast<f32x4*>(ex + (((wave * 2 + gi) * 4 + 2 + ox) * 64 + lane) * 4) = m1;
-      }
-    }
-    __syncthreads();
-    {
-      const int oyox = wave & 3, gi = wave >> 2, g = 2 * half + gi;
-      const int oy = oyox >> 1, ox = oyox & 1;
-      f32x4 m[4];
-#pragma unroll
-      for (int aa = 0; aa < 4; ++aa)
-        m[aa] = add4(*reinterpret_cast<const f32x4*>(ex + (((aa * 2 + gi) * 4 + oyox) * 64 + lane) * 4),
-                     *reinterpret_cast<const f32x4*>(ex + ((((aa + 4) * 2 + gi) * 4 + oyox) * 64 + lane) * 4));
-      f32x4 bq = {0.f, 0.f, 0.f, 0.f};
-      const int co = cb * 32 + 8 * g + 4 * h;
-      if (p.bias) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (co + j < p.Cout) bq[j] = p.bias[co + j];
-      }
-      const f32x4 o0 = add4(add4(add4(m[0], m[1]), m[2]), bq), o1 = add4(sub4(sub4(m[1], m[2]), m[3]), bq);
-      const int zb = ttz * 4 + 2 * ptz, yy = tty * 4 + 2 * pty + oy, xx = ttx * 16 + 2 * ptx + ox;
-#pragma unroll
-      for (int oz = 0; oz < 2; ++oz) {
-        const bool ok = xx < p.W && yy < p.H && (zb + oz) < p.D && co < p.Cout;
-        const unsigned off = ok ? (unsigned)(((((zb + oz) * p.H + yy) * p.W + xx) * p.ldy + co) * 4) : 0x80000000u;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oz ? o1 : o0), yr, off, 0, 0);
-      }
-    }
-  }
-}
-
 static int w3_enabled() {  // BTS_WINO=0: no Winograd form at all; BTS_W3=0: this one off, conv_wino.hip's F(2x2,3x3) x direct form stays
   const char* e = getenv("BTS_WINO");   // (read per call: tests and A/B runs toggle them)
   if (e && atoi(e) == 0) return 0;
@@ -690,22 +513,6 @@ int bts_w3_launch_(const float* x, const float* up3, const float* bias, float* y
   p.gnp = nullptr; p.gn_G = 0; p.gn_zt = 1;
   if (q.ksplit == 1 && gnp != nullptr && gnG > 0 && D % gnG == 0 && (D / gnG) % 4 == 0 && getenv("BTS_IGEMM_NOGNFUSE") == nullptr) {
     p.gnp = gnp; p.gn_G = gnG; p.gn_zt = (D / gnG) / 4;
-  }
-  {  // experiment: two waves per SIMD (plain launches only)
-    const char* e = getenv("BTS_W3B");
-    if (e && atoi(e) && q.ksplit == 1 && !accum && p.gnp == nullptr) {
-      static bool attr_b = false;
-      const size_t shb = (size_t)(2 * W3BUF > W3B_EXH ? 2 * W3BUF : W3B_EXH) * sizeof(float);
-      if (!attr_b) {
-        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(w3b_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (er != hipSuccess) return (int)er;
-        attr_b = true;
-      }
-      (void)hipGetLastError();
-      hipLaunchKernelGGL(w3b_kernel, dim3((unsigned)(8L * p.tiles_per_xcd * q.nb), 1, 1), dim3(512), shb, stream, p);
-      BTS_LAUNCH_CHECK();
-      return BTS_OK;
-    }
   }
   static bool attr_done = false;
   const size_t shmem = (2 * W3BUF + W3EX + 64 + 16) * sizeof(float);
