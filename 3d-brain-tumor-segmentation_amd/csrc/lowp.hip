@@ -28,83 +28,19 @@ int bts_prof_on();
 void bts_prof_begin(int sym, double flops, hipStream_t stream);
 void bts_prof_end(hipStream_t stream);
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+#include "lowp_common.h"
 
-#define LP_F16 1
-#define LP_BF16 2
-
-// ---- storage-type traits: conversions are explicit, sums never happen in 16 bits ----
-struct TF16 {
-  typedef h16x8 frag;
-  static __device__ __forceinline__ float ld(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
-  static __device__ __forceinline__ unsigned short st(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }   // RNE
-  static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
-  }
-};
-struct TBF16 {
-  typedef b16x8 frag;
-  static __device__ __forceinline__ float ld(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
-  static __device__ __forceinline__ unsigned short st(float f) {   // round to nearest even (NaN stays NaN)
-    unsigned u = __builtin_bit_cast(unsigned, f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-  }
-  static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b16x8, a), __builtin_bit_cast(b16x8, b), c, 0, 0, 0);
-  }
-};
-template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b) {
-  return (unsigned)T::st(a) | ((unsigned)T::st(b) << 16);
-}
-template <typename T> __device__ __forceinline__ void unpack8(u32x4 v, float (&o)[8]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { o[2 * i] = T::ld((unsigned short)(v[i] & 0xffffu)); o[2 * i + 1] = T::ld((unsigned short)(v[i] >> 16)); }
-}
-template <typename T> __device__ __forceinline__ u32x4 pack8(const float (&o)[8]) {
-  return u32x4{pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7])};
-}
-__device__ __forceinline__ u32x4 bload16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-}
+// lowp_s1d.hip: LDS-DMA staged stride-1 3x3x3 kernel (offered first; 1 = declined) and its part of the K3S1 image
+long bts_lp_s1d_image_bytes_(int K, int N);
+int bts_lp_s1d_pack_(int dtype, const LpPackParams& p, void* dst, hipStream_t stream);
+long bts_lp_s1d_workspace_(int N, int D, int H, int W, int Cin, int Cout);
+long bts_lp_s1d_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn);
+int bts_lp_s1d_launch_(int dtype, const void* x, const void* wp_dma, const float* bias, void* y, void* ws, long ws_bytes, int N, int D, int H,
+                       int W, int Cin, int ldx, int Cout, int ldy, int accum, double* gnp, int gn_G, hipStream_t stream);
 
 // =====================================================================================================================
 // weight packing: Keras layout fp32 -> [tap][k-step of 16 cin][cout block of 32][h][32 couts][8 cin] 16-bit
 // =====================================================================================================================
-struct LpPackParams {
-  const float* w;
-  unsigned short* wp;
-  int ntaps, K, N, KS, NB;
-  long sT, sK, sN;    // source strides of (tap, contraction index k, column n)
-  int flip;           // tap t reads source tap ntaps-1-t (stride-1 data gradient)
-  int cin_is_k;       // 1: the (possibly folded) input-channel axis is k (forward role), 0: it is n (data-gradient role)
-  int shift, dup_start;
-};
-// source value of packed position (tap t, k, n) -- same conventions as the fp32 images (conv_igemm.hip: pack_src)
-__device__ __forceinline__ float lp_pack_src(const LpPackParams& q, int t, int k, int n) {
-  if (k >= q.K || n >= q.N) return 0.f;
-  const int ts = q.flip ? (q.ntaps - 1 - t) : t;
-  int kk = k, nn = n, k2 = -1, n2 = -1;
-  if (q.cin_is_k == 1) {
-    // slab channel c is reference channel c + shift; inside [dup_start, ...) it is ALSO reference channel c - dup_start
-    // (encoder.py:83-87: [o_{j-1}, o_0 .. o_{j-1}] read once from the slab [o_0 .. o_{j-1}])
-    if (k >= q.dup_start) k2 = k - q.dup_start;
-    kk = k + q.shift;
-    n2 = n;
-  } else {
-    if (n >= q.dup_start) n2 = n - q.dup_start;
-    nn = n + q.shift;
-    k2 = k;
-  }
-  float v = q.w[ts * q.sT + kk * q.sK + nn * q.sN];
-  if (q.shift > 0 && k2 >= 0 && n2 >= 0 && k2 < (q.cin_is_k ? q.shift : q.K) && n2 < (q.cin_is_k ? q.N : q.shift))
-    v += q.w[ts * q.sT + k2 * q.sK + n2 * q.sN];
-  return v;
-}
 template <typename T>
 __global__ __launch_bounds__(256) void lp_pack_kernel(const LpPackParams p) {
   const long total = (long)p.ntaps * p.KS * p.NB * 512;
@@ -123,8 +59,12 @@ static int lp_ntaps(int kind) { return kind == BTS_CONV_K1 ? 1 : 27; }
 extern "C" long bts_lp_packed_bytes(int kind, int role, int Cin_slab, int Cout) {
   if (kind < 0 || kind > 3 || role < 0 || role > 1 || Cin_slab <= 0 || Cout <= 0) return -1;
   const int K = role == BTS_ROLE_FWD ? Cin_slab : Cout, N = role == BTS_ROLE_FWD ? Cout : Cin_slab;
-  return (long)lp_ntaps(kind) * ((K + 15) / 16) * ((N + 31) / 32) * 512 * 2;
+  const long first = (long)lp_ntaps(kind) * ((K + 15) / 16) * ((N + 31) / 32) * 512 * 2;
+  // stride-1 3x3x3 images carry a second part, the same weights in the stage order of the LDS-DMA kernel (lowp_s1d.hip)
+  return kind == BTS_CONV_K3S1 ? first + bts_lp_s1d_image_bytes_(K, N) : first;
 }
+// byte offset of the DMA part inside a K3S1 image with K contraction channels and N output columns
+static long lp_s1d_part_offset(int K, int N) { return 27L * ((K + 15) / 16) * ((N + 31) / 32) * 1024; }
 extern "C" int bts_lp_pack(int kind, int role, int dtype, const float* w, void* wp, int Cin_ref, int Cout, int Cin_slab, int dup_start,
                            int dup_shift, hipStream_t stream) {
   if (kind < 0 || kind > 3 || role < 0 || role > 1 || (dtype != LP_F16 && dtype != LP_BF16)) return BTS_ERR_UNSUPPORTED;
@@ -152,6 +92,7 @@ extern "C" int bts_lp_pack(int kind, int role, int dtype, const float* w, void* 
   if (dtype == LP_F16) hipLaunchKernelGGL(lp_pack_kernel<TF16>, dim3(blocks), dim3(256), 0, stream, p);
   else hipLaunchKernelGGL(lp_pack_kernel<TBF16>, dim3(blocks), dim3(256), 0, stream, p);
   BTS_LAUNCH_CHECK();
+  if (kind == BTS_CONV_K3S1) return bts_lp_s1d_pack_(dtype, p, reinterpret_cast<char*>(wp) + lp_s1d_part_offset(p.K, p.N), stream);
   return BTS_OK;
 }
 
@@ -467,6 +408,21 @@ __global__ __launch_bounds__(256) void lp_splitk_reduce_kernel(const float* part
   }
 }
 
+int bts_lp_splitk_reduce_(int dtype, const float* part, const float* bias, void* y, long nvox, int Cout, int Npad, int ldy, int ksplit,
+                          int accum, hipStream_t stream) {
+  long blocks = (nvox * (Npad / 4) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  (void)hipGetLastError();
+  if (dtype == LP_F16)
+    hipLaunchKernelGGL(lp_splitk_reduce_kernel<TF16>, dim3((unsigned)blocks), dim3(256), 0, stream, part, bias, (unsigned short*)y, nvox, Cout, Npad, ldy,
+                       ksplit, accum);
+  else
+    hipLaunchKernelGGL(lp_splitk_reduce_kernel<TBF16>, dim3((unsigned)blocks), dim3(256), 0, stream, part, bias, (unsigned short*)y, nvox, Cout, Npad, ldy,
+                       ksplit, accum);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
 // split-K plan of the stride-1 kernel: grids that cannot give every CU a workgroup split the input channels
 static int lp_s1_ksplit(long wgs, int KS) {
   if (wgs >= 192 || KS < 8) return 1;
@@ -744,6 +700,11 @@ static int lp_conv_run(int geo, int dtype, const void* x, const void* wp, const 
   const int KS = Cin / 16, NB = (Cout + 31) / 32;
   if (geo == 1) {
     if (((long)(D + 2) * H * W + 64) * (long)ldx * 2 >= 0x7fffffffL) return BTS_ERR_SHAPE;   // 31-bit offsets inside one volume
+    {
+      const int r = bts_lp_s1d_launch_(dtype, x, reinterpret_cast<const char*>(wp) + lp_s1d_part_offset(Cin, Cout), bias, y, workspace,
+                                       workspace_bytes, N, D, H, W, Cin, ldx, Cout, ldy, accum, gn_part, gn_G, stream);
+      if (r != 1) return r;
+    }
     LpS1Params p;
     p.x = (const unsigned short*)x; p.wp = (const unsigned short*)wp; p.bias = bias; p.y = (unsigned short*)y;
     p.N = N; p.D = D; p.H = H; p.W = W; p.ldx = ldx; p.ldy = ldy; p.Cout = Cout; p.KS = KS; p.NB = NB; p.accum = accum;
@@ -791,6 +752,10 @@ static int lp_conv_run(int geo, int dtype, const void* x, const void* wp, const 
 
 static long lp_s1_workspace(int N, int D, int H, int W, int Cin, int Cout) {
   if (Cin % 16 != 0) return 0;
+  {
+    const long d = bts_lp_s1d_workspace_(N, D, H, W, Cin, Cout);
+    if (d >= 0) return d;
+  }
   const int NB = (Cout + 31) / 32;
   int vb, cb, txl;
   lp_s1_shape(N, D, H, W, NB, vb, cb, txl);
@@ -813,6 +778,10 @@ extern "C" int bts_lp_conv3d_fwd(int kind, int dtype, const void* x, const void*
 // channels, z-slabs that are not whole planes (D % G != 0) and heads with Cout % 4 != 0 run the conv and bts_lp_gn_stats on the stored y.
 static bool lp_s1_gn_plan(int N, int D, int H, int W, int Cin, int Cout, int G, long* B) {
   if (Cin % 16 != 0 || Cout % 4 != 0 || G <= 0 || D % G != 0) return false;
+  if (bts_lp_s1d_workspace_(N, D, H, W, Cin, Cout) >= 0) {      // the DMA kernel takes this shape: its partial layout
+    *B = bts_lp_s1d_gn_B_(N, D, H, W, Cin, Cout, G);
+    return *B > 0;
+  }
   const int NB = (Cout + 31) / 32;
   int vb, cb, txl;
   lp_s1_shape(N, D, H, W, NB, vb, cb, txl);

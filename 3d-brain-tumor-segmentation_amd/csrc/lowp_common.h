@@ -1,0 +1,84 @@
+// Storage-type traits and small helpers shared by the 16-bit translation units (lowp.hip, lowp_s1d.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include "common.h"
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+
+#define LP_F16 1
+#define LP_BF16 2
+
+// ---- storage-type traits: conversions are explicit, sums never happen in 16 bits ----
+struct TF16 {
+  typedef h16x8 frag;
+  static __device__ __forceinline__ float ld(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+  static __device__ __forceinline__ unsigned short st(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }   // RNE
+  static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  }
+};
+struct TBF16 {
+  typedef b16x8 frag;
+  static __device__ __forceinline__ float ld(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+  static __device__ __forceinline__ unsigned short st(float f) {   // round to nearest even: v_cvt_pk_bf16_f32 (NaN stays NaN)
+    return __builtin_bit_cast(unsigned short, (__bf16)f);
+  }
+  static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b16x8, a), __builtin_bit_cast(b16x8, b), c, 0, 0, 0);
+  }
+};
+template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b) {
+  return (unsigned)T::st(a) | ((unsigned)T::st(b) << 16);
+}
+typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+template <> __device__ __forceinline__ unsigned pack2<TBF16>(float a, float b) {   // one v_cvt_pk_bf16_f32
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_{a, b}, b16x2));
+}
+template <typename T> __device__ __forceinline__ void unpack8(u32x4 v, float (&o)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { o[2 * i] = T::ld((unsigned short)(v[i] & 0xffffu)); o[2 * i + 1] = T::ld((unsigned short)(v[i] >> 16)); }
+}
+template <typename T> __device__ __forceinline__ u32x4 pack8(const float (&o)[8]) {
+  return u32x4{pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7])};
+}
+__device__ __forceinline__ u32x4 bload16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+}
+
+// ---- weight packing: source addressing shared by every packed-image layout ----
+struct LpPackParams {
+  const float* w;
+  unsigned short* wp;
+  int ntaps, K, N, KS, NB;
+  long sT, sK, sN;    // source strides of (tap, contraction index k, column n)
+  int flip;           // tap t reads source tap ntaps-1-t (stride-1 data gradient)
+  int cin_is_k;       // 1: the (possibly folded) input-channel axis is k (forward role), 0: it is n (data-gradient role)
+  int shift, dup_start;
+};
+// source value of packed position (tap t, k, n) -- same conventions as the fp32 images (conv_igemm.hip: pack_src)
+__device__ __forceinline__ float lp_pack_src(const LpPackParams& q, int t, int k, int n) {
+  if (k >= q.K || n >= q.N) return 0.f;
+  const int ts = q.flip ? (q.ntaps - 1 - t) : t;
+  int kk = k, nn = n, k2 = -1, n2 = -1;
+  if (q.cin_is_k == 1) {
+    // slab channel c is reference channel c + shift; inside [dup_start, ...) it is ALSO reference channel c - dup_start
+    // (encoder.py:83-87: [o_{j-1}, o_0 .. o_{j-1}] read once from the slab [o_0 .. o_{j-1}])
+    if (k >= q.dup_start) k2 = k - q.dup_start;
+    kk = k + q.shift;
+    n2 = n;
+  } else {
+    if (n >= q.dup_start) n2 = n - q.dup_start;
+    nn = n + q.shift;
+    k2 = k;
+  }
+  float v = q.w[ts * q.sT + kk * q.sK + nn * q.sN];
+  if (q.shift > 0 && k2 >= 0 && n2 >= 0 && k2 < (q.cin_is_k ? q.shift : q.K) && n2 < (q.cin_is_k ? q.N : q.shift))
+    v += q.w[ts * q.sT + k2 * q.sK + n2 * q.sN];
+  return v;
+}

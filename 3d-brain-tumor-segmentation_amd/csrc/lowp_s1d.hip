@@ -1,0 +1,456 @@
+// 3x3x3 stride-1 'same' convolution on 16-bit storage, LDS-DMA staged (round 3).  Replaces, for every shape it takes, the
+// register-staged lp_conv_s1_kernel of lowp.hip: the Conv3D of resnet.py:80-87 (both convs of a ResnetBlock), decoder.py / vae.py
+// blocks, and -- on role-swapped weight images -- their data gradients (train.py:142-151 under TF autodiff).
+//
+// Why a second kernel: the first one fetched every weight fragment per wave straight from L2 (27 KB per wave and k-step, 2.9 scalar
+// + 3.8 vector instructions per matrix instruction of run-time address arithmetic, halo tile global -> registers -> LDS) and sat at
+// 0.25-0.27 of the 2.5 PF dense peak with its waves parked 64 % of the time (profiles/r02b_pmc_lp_s1.txt).  Here
+//   * BOTH operands reach LDS by buffer_load_dwordx4 ... lds (no staging registers, no ds_write pass): the halo tile of one k-step
+//     (16 input channels) as two planes [k-half][voxel][8 channels] -- 32 consecutive voxels of a plane are 512 contiguous bytes, so
+//     a B fragment is ONE conflict-free ds_read_b128 at a compile-time offset from a per-lane base, for every tap; out-of-image
+//     voxels use an offset outside the buffer descriptor (the DMA then writes zeros: 'same' padding without a branch);
+//   * the weights of a STAGE (k-step, dz: 9 taps x 16 cin x 32|64 couts = 9|18 KB) are copied verbatim from a packed image laid out
+//     as the LDS image [tap][k-half][cout][8 cin] and shared by the 8 waves (A fragment = one ds_read_b128 at an immediate offset);
+//   * 512 threads: wave = (z plane, g) with g = y half of a 32x8x4 tile (32-cout items) or cout block of a 32x4x4 tile (64-cout
+//     items); per (dz, dx) a wave reads 6 input rows + 3 weight fragments for 12 matrix instructions (rows serve the three dy taps);
+//   * a three-slot weight ring and a double-buffered halo tile are filled two stages / one k-step ahead; a stage boundary is
+//     `s_waitcnt vmcnt(N)` with N counted (never 0) + one s_barrier; a workgroup walks its items (tile x cout group, XCD-aware
+//     order) as ONE stage stream, the next item's operands in flight under the current item's output side.
+// Declines (caller runs the old kernel): W < 12, Cout % 4 != 0, offsets beyond 31 bits.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+#include "bts_internal.h"
+#include "lowp_common.h"
+
+int bts_prof_on();
+void bts_prof_begin(int sym, double flops, hipStream_t stream);
+void bts_prof_end(hipStream_t stream);
+int bts_lp_splitk_reduce_(int dtype, const float* part, const float* bias, void* y, long nvox, int Cout, int Npad, int ldy, int ksplit,
+                          int accum, hipStream_t stream);
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct LpS1dParams {
+  const unsigned short* x;
+  const unsigned short* wp;   // the DMA part of the K3S1 image: [cout group][k-step][dz][dy*3+dx][k-half][cout in group][8 cin]
+  const float* bias;
+  unsigned short* y;
+  int N, D, H, W, ldx, ldy, Cout, KS, NB;
+  int ntx, nty, ntz, ncg;
+  long nitems;
+  int ksplit, ks_per;
+  int accum;
+  float* part;       // split-K: fp32 partial sums [split][voxel][NB*32]
+  double* gnp;       // fused GroupNorm partial sums (slab semantics) [N*G][gn_B][2], or NULL
+  int gn_G, gn_zt;
+  long gn_B;
+};
+
+template <int MODE, int TXL>
+struct S1dGeo {
+  static constexpr int TX = 1 << TXL, ZP = 32 / TX;          // x extent of a fragment, z planes per fragment
+  static constexpr int CBW = MODE ? 2 : 1;                   // cout blocks of 32 per item
+  static constexpr int YG = MODE ? 1 : 2;                    // groups of 4 output rows per tile
+  static constexpr int TY = 4 * YG, TZ = 4 * ZP;
+  static constexpr int SX = TX + 2, SY = TY + 2, SZ = TZ + 2;
+  // plane stride in voxels: two-plane fragments (TX = 16) need it a multiple of 16 voxels = 256 bytes, so that the two 256-byte
+  // runs of a 16-byte-per-lane read land on the same bank phase (MI355X LDS: ds_read_b128 is served in 16-lane groups)
+  static constexpr int PS = (ZP == 1) ? SY * SX : ((SY * SX + 15) / 16) * 16;
+  static constexpr int NVOX = SZ * PS;
+  static constexpr int NCH = ((NVOX + 511) / 512) * 8;       // 64-voxel DMA chunks per k-half plane (whole rounds of the 8 waves)
+  static constexpr int HPLANE = NCH * 1024, HBUF = 2 * HPLANE;
+  static constexpr int NHC = 2 * NCH, NH = NHC / 8;          // halo chunks per k-step / per wave (an even number: plane pairs)
+  static constexpr int NHA = 2 * ((NH / 2 + 1) / 2), NHB = NH - NHA;   // issued in stage 0 / stage 1
+  static constexpr int WTAP = CBW * 1024, WSTAGE = 9 * WTAP;
+  static constexpr int NWC = 9 * CBW, NW = (NWC + 7) / 8;    // weight chunks per stage / per wave
+  static constexpr int OFF_W = 2 * HBUF, OFF_SCR = OFF_W + 3 * WSTAGE, OFF_BIAS = OFF_SCR + 1024;
+  static constexpr int LDS_BYTES = OFF_BIAS + 2 * 256;       // two bias slots of 64 floats (a 4-byte DMA writes all 64 lanes)
+  static constexpr int NST = 16;                             // output-side store instructions per wave and item
+};
+
+template <int N> __device__ __forceinline__ void s1d_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void s1d_barrier() {
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <typename T, int MODE, int TXL>
+__global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
+  // (the host pass of hipcc 7.2 silently drops this template's launch stub when it instantiates the body -- the array-indexed
+  // LDS-DMA offsets trigger it -- so the body exists in the device pass only; there is no other code path)
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef S1dGeo<MODE, TXL> G;
+  constexpr int TX = G::TX, ZP = G::ZP, CBW = G::CBW, SX = G::SX, SY = G::SY, PS = G::PS, NVOX = G::NVOX, NCH = G::NCH;
+  constexpr int NH = G::NH, NHA = G::NHA, NHB = G::NHB, NW = G::NW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l32 = lane & 31;
+  const int lx = l32 & (TX - 1), lz = l32 >> TXL;
+  const int zz = wave & 3, g = wave >> 2;
+  const int y0 = MODE ? 0 : 4 * g;        // first output row of this wave inside the tile
+  const int cbw = MODE ? g : 0;           // cout block of this wave inside the item
+
+  // ---- item walk: (n, tz, ty, tx, cg), cg fastest; XCD k walks its own contiguous eighth, its workgroups interleaved ----
+  long it, it_end, it_step;
+  {
+    const long Gx = gridDim.x, b = blockIdx.x;
+    if (Gx >= 8) {
+      const long xcd = b & 7, slot = b >> 3;
+      const long q = p.nitems / 8, r = p.nitems % 8;
+      const long start = xcd * q + (xcd < r ? xcd : r);
+      it_end = start + q + (xcd < r ? 1 : 0);
+      it_step = (Gx - xcd + 7) >> 3;
+      it = start + slot;
+    } else {
+      it = b; it_end = p.nitems; it_step = Gx;
+    }
+  }
+  if (it >= it_end) return;
+  struct Item { int cg, n, ox0, oy0, oz0; };
+  auto decode = [&](long i) {
+    Item t;
+    t.cg = (int)(i % p.ncg); i /= p.ncg;
+    t.ox0 = (int)(i % p.ntx) * TX; i /= p.ntx;
+    t.oy0 = (int)(i % p.nty) * G::TY; i /= p.nty;
+    t.oz0 = (int)(i % p.ntz) * G::TZ;
+    t.n = (int)(i / p.ntz);
+    return t;
+  };
+  int ks0 = 0, ks1 = p.KS;
+  if (p.ksplit > 1) {
+    ks0 = blockIdx.y * p.ks_per;
+    ks1 = ks0 + p.ks_per;
+    if (ks1 > p.KS) ks1 = p.KS;
+  }
+
+  // ---- DMA side ----
+  // request r of a wave: k-half plane r & 1 of the 64-voxel group (r >> 1)*8 + wave of the (padded) halo tile -- the two requests
+  // that touch the same 32 bytes of a voxel are issued back to back (the second one finds the line in the vector L1: one L2
+  // request per voxel and k-step instead of two)
+  unsigned hrel[NH], hcrd[NH];
+#pragma unroll
+  for (int r = 0; r < NH; ++r) {
+    const int hp = r & 1, vox = ((r >> 1) * 8 + wave) * 64 + lane;
+    const int vz = vox / PS, rem = vox - vz * PS;
+    const int vy = rem / SX, vx = rem - vy * SX;
+    const bool geo = vox < NVOX && rem < SY * SX;
+    hrel[r] = (unsigned)(((vz * p.H + vy) * p.W + vx) * p.ldx * 2 + hp * 16);
+    hcrd[r] = (unsigned)(vx | (vy << 8)) | (geo ? (unsigned)vz << 16 : 0xffff0000u);   // padding voxels: a z no image reaches
+  }
+  unsigned hoff[NH];
+  __amdgpu_buffer_rsrc_t xr;
+  auto dma_item = [&](const Item& t, bool live) {   // halo origin + per-chunk offsets of the item the NEXT k-step belongs to
+    const unsigned short* xorg = p.x + ((((long)t.n * p.D + (t.oz0 - 1)) * p.H + (t.oy0 - 1)) * p.W + (t.ox0 - 1)) * (long)p.ldx;
+    xr = __builtin_amdgcn_make_buffer_rsrc((void*)xorg, 0, 0x7fffffff, 0x00020000);
+    const int zb = live ? t.oz0 - 1 : 0x100000;       // no next item: every voxel out of range (zeros, no traffic)
+#pragma unroll
+    for (int r = 0; r < NH; ++r) {
+      const int vx = hcrd[r] & 0xff, vy = (hcrd[r] >> 8) & 0xff, vz = hcrd[r] >> 16;
+      const bool ok = (unsigned)(zb + vz) < (unsigned)p.D && (unsigned)(t.oy0 - 1 + vy) < (unsigned)p.H &&
+                      (unsigned)(t.ox0 - 1 + vx) < (unsigned)p.W;
+      hoff[r] = ok ? hrel[r] : 0x80000000u;
+    }
+  };
+  static_assert(NCH % 8 == 0 && NH % 2 == 0 && NHA % 2 == 0, "64-voxel groups are dealt to the 8 waves in whole rounds, as plane pairs");
+  auto issue_halo = [&](int r_lo, int r_hi, int ks, int buf) {
+#pragma unroll
+    for (int r = r_lo; r < r_hi; ++r)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(lds + buf * G::HBUF + (r & 1) * G::HPLANE + ((r >> 1) * 8 + wave) * 1024), 16, hoff[r], (unsigned)ks * 32u, 0, 0);
+  };
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7fffffff, 0x00020000);
+  auto issue_w = [&](int cg, int ks, int dz, bool live) {   // stage (cg, ks, dz) -> ring slot dz
+    const unsigned soff = (unsigned)((((cg * p.KS + ks) * 3) + dz) * G::WSTAGE);
+#pragma unroll
+    for (int r = 0; r < NW; ++r) {
+      const int c = r * 8 + wave;
+      const bool ok = live && c < G::NWC;
+      const lds_ptr_t dst = (lds_ptr_t)(lds + (c < G::NWC ? G::OFF_W + dz * G::WSTAGE + c * 1024 : G::OFF_SCR));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, dst, 16, ok ? (unsigned)(c * 1024 + lane * 16) : 0x80000000u, soff, 0, 0);
+    }
+  };
+  const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.bias ? (unsigned)p.Cout * 4u : 0u, 0x00020000);
+  auto issue_bias = [&](int cg, int slot) {   // every wave writes the same 32*CBW values (benign duplicates, uniform request counts)
+    const int co = cg * CBW * 32 + lane;
+    const unsigned off = (lane < 32 * CBW && co < p.Cout) ? (unsigned)co * 4u : 0x80000000u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (lds_ptr_t)(lds + G::OFF_BIAS + slot * 256), 4, off, 0, 0, 0);
+  };
+
+  // ---- compute side ----
+  const unsigned hbB = (unsigned)(h * G::HPLANE + (((zz * ZP + lz) * PS) + y0 * SX + lx) * 16);
+  const unsigned wbA = (unsigned)(G::OFF_W + h * (CBW * 512) + cbw * 512 + l32 * 16);
+  f32x16 acc[4];
+  auto compute = [&](auto dzc, int buf) {
+    constexpr int DZ = decltype(dzc)::value;
+    const unsigned char* hb = lds + hbB + (buf ? G::HBUF : 0);
+    const unsigned char* wb = lds + wbA + DZ * G::WSTAGE;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      u32x4 bj[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) bj[j] = *reinterpret_cast<const u32x4*>(hb + ((DZ * PS) + j * SX + dx) * 16);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(wb + (dy * 3 + dx) * G::WTAP);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] = T::mfma(a, bj[v + dy], acc[v]);
+      }
+    }
+  };
+
+  Item ci = decode(it);
+  dma_item(ci, true);
+  int ipar = 0, buf = 0;
+  // prologue: the request order of a steady-state k-step's tail (stage 0 below waits for everything but the last weight stage)
+  issue_halo(0, NHA, ks0, 0);
+  issue_w(ci.cg, ks0, 0, true);
+  issue_halo(NHA, NH, ks0, 0);
+  issue_bias(ci.cg, 0);
+  issue_w(ci.cg, ks0, 1, true);
+  bool after_out = false;
+  for (;;) {
+    const long nit = it + it_step;
+    const bool have_next = nit < it_end;
+    const Item ni = have_next ? decode(nit) : ci;
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
+    for (int ks = ks0; ks < ks1; ++ks) {
+      const bool last = ks + 1 == ks1;
+      const bool nlive = !last || have_next;
+      const int ncg_ = last ? ni.cg : ci.cg, nks = last ? ks0 : ks + 1;
+      // ---- stage 0 (dz = 0) ----
+      if (after_out) s1d_wait<NW + G::NST>(); else s1d_wait<NW>();
+      s1d_barrier();
+      after_out = false;
+      issue_w(ci.cg, ks, 2, true);
+      if (last) dma_item(ni, have_next);
+      issue_halo(0, NHA, nks, buf ^ 1);
+      compute(std::integral_constant<int, 0>(), buf);
+      // ---- stage 1 ----
+      s1d_wait<NW + NHA>();
+      s1d_barrier();
+      issue_w(ncg_, nks, 0, nlive);
+      issue_halo(NHA, NH, nks, buf ^ 1);
+      issue_bias(ncg_, last ? (ipar ^ 1) : ipar);
+      compute(std::integral_constant<int, 1>(), buf);
+      // ---- stage 2 ----
+      s1d_wait<NHA + NW + NHB + 1>();
+      s1d_barrier();
+      issue_w(ncg_, nks, 1, nlive);
+      compute(std::integral_constant<int, 2>(), buf);
+      buf ^= 1;
+    }
+    // ---- output side of `ci` ----
+    {
+      const int oy = ci.oy0 + y0, ox = ci.ox0 + lx, oz = ci.oz0 + zz * ZP + lz;
+      const float* bsh = reinterpret_cast<const float*>(lds + G::OFF_BIAS + ipar * 256) + cbw * 32;
+      const int cb = ci.cg * CBW + cbw;
+      if (p.ksplit > 1) {   // raw fp32 partial sums [split][voxel][NB*32]; bias / rounding happen in the reduce kernel
+        const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.part + (((long)blockIdx.y * p.N + ci.n) * p.D * p.H * p.W) * (long)(p.NB * 32)), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const bool ok = cb < p.NB && oz < p.D && oy + v < p.H && ox < p.W;
+            const unsigned off = ok ? (unsigned)((((oz * p.H + oy + v) * p.W + ox) * (p.NB * 32) + cb * 32 + 8 * q + 4 * h) * 4) : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(
+                __builtin_bit_cast(u32x4, f32x4{acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]}), pr, off, 0, 0);
+          }
+      } else {
+        const __amdgpu_buffer_rsrc_t yr =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long)ci.n * p.D * p.H * p.W * (long)p.ldy), 0, 0x7fffffff, 0x00020000);
+        const bool gn_on = p.gnp != nullptr;
+        float gn_s = 0.f, gn_q = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = cb * 32 + 8 * q + 4 * h;
+          const f32x4 bq = *reinterpret_cast<const f32x4*>(bsh + 8 * q + 4 * h);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const bool ok = co < p.Cout && oz < p.D && oy + v < p.H && ox < p.W;
+            const unsigned off = ok ? (unsigned)((((oz * p.H + oy + v) * p.W + ox) * p.ldy + co) * 2) : 0x80000000u;
+            float o0 = acc[v][4 * q] + bq[0], o1 = acc[v][4 * q + 1] + bq[1], o2 = acc[v][4 * q + 2] + bq[2], o3 = acc[v][4 * q + 3] + bq[3];
+            if (p.accum) {
+              const u32x2 old = __builtin_amdgcn_raw_buffer_load_b64(yr, off, 0, 0);
+              o0 += T::ld((unsigned short)(old[0] & 0xffffu)); o1 += T::ld((unsigned short)(old[0] >> 16));
+              o2 += T::ld((unsigned short)(old[1] & 0xffffu)); o3 += T::ld((unsigned short)(old[1] >> 16));
+            }
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2<T>(o0, o1), pack2<T>(o2, o3)}, yr, off, 0, 0);
+            if (gn_on && ok) {
+              gn_s += (o0 + o1) + (o2 + o3);
+              gn_q = fmaf(o0, o0, fmaf(o1, o1, fmaf(o2, o2, fmaf(o3, o3, gn_q))));
+            }
+          }
+        }
+        if (gn_on) {   // one fp64 (sum, sumsq) pair per (z plane, tile column, cout group, wave of that plane): fixed order
+          const int ty = ci.oy0 / G::TY, tx = ci.ox0 / TX;
+#pragma unroll
+          for (int zl = 0; zl < ZP; ++zl) {
+            const bool mine = (ZP == 1) || lz == zl;
+            const double ds = wave_sum_f64(mine ? (double)gn_s : 0.0), dq = wave_sum_f64(mine ? (double)gn_q : 0.0);
+            const int ozp = ci.oz0 + zz * ZP + zl;
+            if (lane == 0 && ozp < p.D) {
+              const int gg = ozp / p.gn_zt;
+              const long slot = (((((long)(ozp - gg * p.gn_zt) * p.nty + ty) * p.ntx + tx) * p.ncg + ci.cg) * 2) + g;
+              double* dst = p.gnp + (((long)ci.n * p.gn_G + gg) * p.gn_B + slot) * 2;
+              dst[0] = ds;
+              dst[1] = dq;
+            }
+          }
+        }
+      }
+    }
+    after_out = true;
+    if (!have_next) break;
+    ci = ni;
+    it = nit;
+    ipar ^= 1;
+  }
+  s1d_wait<0>();   // the last k-step's look-ahead requests (zeros into LDS) must not outlive the workgroup's LDS allocation
+#endif
+}
+
+// =====================================================================================================================
+// packed image of the DMA kernel: [cout group of CBW blocks][k-step][dz][dy*3+dx][k-half][cout in group][8 cin]
+// =====================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void lp_s1d_pack_kernel(const LpPackParams p, int CBW, int NCG) {
+  const long per_stage = 9L * CBW * 512;   // elements
+  const long total = (long)NCG * p.KS * 3 * per_stage;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int e = (int)(i & 7);
+    long q = i >> 3;
+    const int row = (int)(q % (32 * CBW)); q /= 32 * CBW;
+    const int hh = (int)(q & 1); q >>= 1;
+    const int t9 = (int)(q % 9); q /= 9;
+    const int dz = (int)(q % 3); q /= 3;
+    const int ks = (int)(q % p.KS);
+    const int cg = (int)(q / p.KS);
+    p.wp[i] = T::st(lp_pack_src(p, dz * 9 + t9, ks * 16 + hh * 8 + e, cg * CBW * 32 + row));
+  }
+}
+
+static int s1d_cbw(int NB) { return NB >= 2 ? 2 : 1; }
+// bytes of the DMA part of a K3S1 image with K contraction channels and N output columns
+long bts_lp_s1d_image_bytes_(int K, int N) {
+  const int KS = (K + 15) / 16, NB = (N + 31) / 32, cbw = s1d_cbw(NB), ncg = (NB + cbw - 1) / cbw;
+  return (long)ncg * KS * 3 * 9 * cbw * 1024;
+}
+int bts_lp_s1d_pack_(int dtype, const LpPackParams& p0, void* dst, hipStream_t stream) {
+  LpPackParams p = p0;
+  p.wp = reinterpret_cast<unsigned short*>(dst);
+  const int cbw = s1d_cbw(p.NB), ncg = (p.NB + cbw - 1) / cbw;
+  const long total = (long)ncg * p.KS * 3 * 9 * cbw * 512;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  (void)hipGetLastError();
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_s1d_pack_kernel<TF16>, dim3(blocks), dim3(256), 0, stream, p, cbw, ncg);
+  else hipLaunchKernelGGL(lp_s1d_pack_kernel<TBF16>, dim3(blocks), dim3(256), 0, stream, p, cbw, ncg);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+// =====================================================================================================================
+// plan + launch
+// =====================================================================================================================
+struct S1dPlan {
+  int mode, txl, ntx, nty, ntz, ncg, ksplit, ks_per;
+  long nitems;
+};
+static bool s1d_enabled() {   // BTS_LP_S1D=0: every stride-1 conv on the register-staged kernel (A/B; read per call so one process can do both)
+  const char* e = getenv("BTS_LP_S1D");
+  return !(e && atoi(e) == 0);
+}
+static bool s1d_plan(int N, int D, int H, int W, int Cin, int Cout, S1dPlan& pl) {
+  if (!s1d_enabled() || Cin % 16 != 0 || Cout % 4 != 0 || W < 12) return false;
+  const int NB = (Cout + 31) / 32, KS = Cin / 16;
+  pl.mode = NB >= 2 ? 1 : 0;
+  pl.txl = W >= 24 ? 5 : 4;
+  const int TX = 1 << pl.txl, ZP = 32 / TX, TY = pl.mode ? 4 : 8, TZ = 4 * ZP;
+  pl.ntx = (W + TX - 1) / TX; pl.nty = (H + TY - 1) / TY; pl.ntz = (D + TZ - 1) / TZ;
+  pl.ncg = pl.mode ? (NB + 1) / 2 : 1;
+  pl.nitems = (long)N * pl.ntz * pl.nty * pl.ntx * pl.ncg;
+  if (pl.nitems > 0x7fffffffL) return false;
+  // split-K: grids that cannot give most CUs an item split the input channels (>= 2 k-steps per workgroup)
+  pl.ksplit = 1; pl.ks_per = KS;
+  if (pl.nitems < 160 && KS >= 4) {
+    int ks = (int)((256 + pl.nitems - 1) / pl.nitems);
+    if (ks > KS / 2) ks = KS / 2;
+    if (ks > 16) ks = 16;
+    if (ks > 1) {
+      pl.ks_per = (KS + ks - 1) / ks;
+      pl.ksplit = (KS + pl.ks_per - 1) / pl.ks_per;
+    }
+  }
+  return true;
+}
+long bts_lp_s1d_workspace_(int N, int D, int H, int W, int Cin, int Cout) {
+  S1dPlan pl;
+  if (!s1d_plan(N, D, H, W, Cin, Cout, pl)) return -1;
+  return pl.ksplit > 1 ? (long)pl.ksplit * N * D * H * W * ((Cout + 31) / 32) * 32 * 4 : 0;
+}
+// GroupNorm-partial slots per (n, group) when the conv can emit them (no split-K, whole planes per group); 0 otherwise
+long bts_lp_s1d_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn) {
+  S1dPlan pl;
+  if (Gn <= 0 || D % Gn != 0 || !s1d_plan(N, D, H, W, Cin, Cout, pl) || pl.ksplit > 1) return 0;
+  return (long)(D / Gn) * pl.nty * pl.ntx * pl.ncg * 2;
+}
+
+template <typename T, int MODE, int TXL>
+static int s1d_launch_t(const LpS1dParams& p, hipStream_t stream) {
+  typedef S1dGeo<MODE, TXL> G;
+  auto kern = lp_s1d_kernel<T, MODE, TXL>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  long gx = p.nitems < 256 ? p.nitems : 256;
+  if (p.ksplit > 1) { gx = (256 + p.ksplit - 1) / p.ksplit; if (gx > p.nitems) gx = p.nitems; if (gx < 1) gx = 1; }
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, p.ksplit), dim3(512), G::LDS_BYTES, stream, p);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
+// BTS_OK = ran, 1 = declined.  wp_dma = the DMA part of the K3S1 image.  gn_B (out, may be NULL): partial slots per (n, group) written.
+int bts_lp_s1d_launch_(int dtype, const void* x, const void* wp_dma, const float* bias, void* y, void* ws, long ws_bytes, int N, int D, int H,
+                       int W, int Cin, int ldx, int Cout, int ldy, int accum, double* gnp, int gn_G, hipStream_t stream) {
+  S1dPlan pl;
+  if (!s1d_plan(N, D, H, W, Cin, Cout, pl)) return 1;
+  if (((long)(D + 2) * H * W + 64) * (long)ldx * 2 >= 0x7fffffffL) return 1;
+  const long omax = (long)ldy > (long)((Cout + 31) / 32) * 32 * 2 ? ldy : (long)((Cout + 31) / 32) * 32 * 2;
+  if ((long)D * H * W * omax * 2 >= 0x7fffff00L) return 1;
+  LpS1dParams p;
+  p.x = (const unsigned short*)x; p.wp = (const unsigned short*)wp_dma; p.bias = bias; p.y = (unsigned short*)y;
+  p.N = N; p.D = D; p.H = H; p.W = W; p.ldx = ldx; p.ldy = ldy; p.Cout = Cout; p.KS = Cin / 16; p.NB = (Cout + 31) / 32;
+  p.ntx = pl.ntx; p.nty = pl.nty; p.ntz = pl.ntz; p.ncg = pl.ncg; p.nitems = pl.nitems;
+  p.ksplit = pl.ksplit; p.ks_per = pl.ks_per; p.accum = accum;
+  p.part = reinterpret_cast<float*>(ws);
+  const long nvox = (long)N * D * H * W;
+  if (p.ksplit > 1 && (ws == nullptr || ws_bytes < (long)p.ksplit * nvox * p.NB * 32 * 4 || (((uintptr_t)ws) & 15))) {
+    p.ksplit = 1; p.ks_per = p.KS;
+  }
+  p.gnp = gnp; p.gn_G = gn_G; p.gn_zt = gn_G > 0 ? D / gn_G : 1;
+  p.gn_B = gn_G > 0 ? (long)p.gn_zt * pl.nty * pl.ntx * pl.ncg * 2 : 0;
+  if (gnp != nullptr && p.ksplit > 1) return BTS_ERR_UNSUPPORTED;
+  const bool prof = bts_prof_on();
+  if (prof) bts_prof_begin(33, 2.0 * 27.0 * Cin * (double)Cout * (double)nvox, stream);
+  int r;
+#define S1D_CASE(M_, X_)                                                                                                  \
+  if (pl.mode == M_ && pl.txl == X_)                                                                                      \
+    r = dtype == LP_F16 ? s1d_launch_t<TF16, M_, X_>(p, stream) : s1d_launch_t<TBF16, M_, X_>(p, stream);
+  S1D_CASE(0, 5) else S1D_CASE(1, 5) else S1D_CASE(0, 4) else S1D_CASE(1, 4) else r = BTS_ERR_UNSUPPORTED;
+#undef S1D_CASE
+  if (prof) bts_prof_end(stream);
+  if (r != BTS_OK) return r;
+  if (p.ksplit > 1) return bts_lp_splitk_reduce_(dtype, p.part, bias, y, nvox, Cout, p.NB * 32, ldy, p.ksplit, accum, stream);
+  return BTS_OK;
+}

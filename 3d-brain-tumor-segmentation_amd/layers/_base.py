@@ -119,6 +119,8 @@ class Layer(object):
             _pack_registry.append(ent)
         elif ent.epoch != weights_epoch():
             _repack_all()
+        if role == ops.ROLE_BWD:
+            _order_behind_bwd_pack()
         return ent.wp
 
 
@@ -133,6 +135,23 @@ class _PackEntry(object):
 
 _pack_registry = []
 _pack_tables = {}
+_bwd_pack_event = {}      # device index -> (event recorded on the side stream after the data-gradient-role pack, streams already ordered behind it)
+
+
+def _order_behind_bwd_pack():
+    """Data-gradient-role images are packed on the weight-gradient stream (below).  Whoever is handed one must run behind that
+    pack: tape.gradient joins the side streams before its first node, but a caller outside a tape replay (lowp_train's head /
+    VAE-output data gradients) would otherwise read the previous step's image -- or a half-written one."""
+    if not torch.cuda.is_available():
+        return
+    ent = _bwd_pack_event.get(torch.cuda.current_device())
+    if ent is None:
+        return
+    ev, done = ent
+    cur = torch.cuda.current_stream()
+    if cur.cuda_stream not in done:
+        cur.wait_event(ev)
+        done.add(cur.cuda_stream)
 
 
 def _repack_all():
@@ -164,6 +183,9 @@ def _repack_all():
             side.wait_stream(torch.cuda.current_stream())     # the optimiser step that changed the parameters
             with torch.cuda.stream(side):
                 table.run(entries)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            _bwd_pack_event[dev.index if dev.index is not None else torch.cuda.current_device()] = (ev, {side.cuda_stream})
     for e in todo:
         e.epoch = ep
 

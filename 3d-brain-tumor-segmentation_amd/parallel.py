@@ -83,6 +83,15 @@ def all_reduce_sum(t):
     return t
 
 
+def gather_objects(obj):
+    """[obj of rank 0, obj of rank 1, ...] on every rank (a collective when a process group exists; [obj] otherwise)"""
+    if not active():
+        return [obj]
+    out = [None] * world()
+    torch.distributed.all_gather_object(out, obj)
+    return out
+
+
 def bucket_ranges(n, elem_bytes=4, bucket_bytes=BUCKET_BYTES):
     per = max(1, bucket_bytes // elem_bytes)
     return [(o, min(per, n - o)) for o in range(0, n, per)]

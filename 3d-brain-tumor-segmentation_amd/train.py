@@ -118,8 +118,16 @@ def _rng_layers(model):
     return out
 
 
-def save_checkpoint(folder, model, optimizer=None, completed=False, tracker=None, datasets=None):
+_RANK_STRIDE = 0x9E3779B97F4A7C15      # parallel.decorrelate_rng: rank r's counters run at base + r * stride (mod 2^63)
+
+
+def save_checkpoint(folder, model, optimizer=None, completed=False, tracker=None, datasets=None, write=True):
     """weights by variable name + `epoch`; with an optimizer also Adam m / v (flat order) and its step count.
+
+    Data-parallel runs: EVERY rank calls this (it gathers the per-rank random state: each rank's augmentation generator;
+    the dropout / reparameterisation counters are stored rank-independent, as their base value), rank 0 alone passes
+    write=True.  A resumed rank r gets back ITS generator state and base + r * stride counters, so all ranks continue the
+    uninterrupted trajectory instead of replaying rank 0's draws.
 
     completed=True (what fit() passes: it saves AFTER the epoch's last step): the container also records
     `next_epoch = epoch + 1`, and a resumed fit() starts there -- the reference restarts at the saved epoch
@@ -128,16 +136,28 @@ def save_checkpoint(folder, model, optimizer=None, completed=False, tracker=None
     overwrite a better checkpoint).  datasets: {'train': ds, 'val': ds}; objects with state_dict() (data._Dataset: shuffle
     and augmentation generators) are persisted."""
     tensors = {'var/' + p.name: p.t for p in model.trainable_variables}
+    rk = parallel.rank() if getattr(model, '_rng_rank', None) is not None else 0      # offset decorrelate_rng applied, if it ran
     meta = {'format': FORMAT_VERSION, 'epoch': int(model.epoch.value().numpy()), 'n_params': int(model.n_params),
-            'rng': {k: int(v._seed) for k, v in _rng_layers(model).items()}}
+            'rng': {k: (int(v._seed) - rk * _RANK_STRIDE) & 0x7FFFFFFFFFFFFFFF for k, v in _rng_layers(model).items()},
+            'rng_is_base': True}
     if completed:
         meta['next_epoch'] = meta['epoch'] + 1
     if tracker is not None:
         meta['tracker'] = {'best': float(tracker.best), 'patience': int(tracker.patience)}
+    local = {}
     for key, ds in (datasets or {}).items():
         if hasattr(ds, 'state_dict'):
             for k, v in ds.state_dict().items():
-                tensors['data/%s/%s' % (key, k)] = v
+                local['data/%s/%s' % (key, k)] = v
+    per_rank = parallel.gather_objects(local)          # a collective when a process group exists: all ranks are here
+    for r, st in enumerate(per_rank):
+        for k, v in st.items():
+            if k.endswith('/gen'):
+                tensors['%s@%d' % (k, r)] = v          # augmentation draws: one stream per rank
+            elif r == 0:
+                tensors[k] = v                         # the shuffle generator is common to all ranks
+    if not write:
+        return meta
     if optimizer is not None:
         meta['optimizer'] = {'iterations': int(optimizer.iterations), 'learning_rate': float(optimizer.learning_rate),
                              'init_lr': float(optimizer.init_lr), 'n_epochs': float(optimizer.n_epochs)}
@@ -166,11 +186,24 @@ def load_checkpoint(folder, model, optimizer=None):
         p.t.copy_(src.to(p.t.device))
     model.epoch.assign(int(meta.get('next_epoch', meta.get('epoch', 0))))
     # consumed by the next fit(): PatienceTracker state and the datasets' generator states
-    model._resume = {'tracker': meta.get('tracker'),
-                     'data': {k[len('data/'):]: v for k, v in tensors.items() if k.startswith('data/')}}
+    data = {}
+    mine = '@%d' % parallel.rank()
+    for k, v in tensors.items():
+        if not k.startswith('data/'):
+            continue
+        if '@' in k:                                  # per-rank entries: keep this rank's, under the plain name
+            if k.endswith(mine):
+                data[k[len('data/'):-len(mine)]] = v
+        else:
+            data.setdefault(k[len('data/'):], v)
+    model._resume = {'tracker': meta.get('tracker'), 'data': data}
     for k, lay in _rng_layers(model).items():
         if k in meta.get('rng', {}):
             lay._seed = int(meta['rng'][k])
+    if meta.get('rng_is_base'):                       # counters were stored without the rank offset: re-apply this rank's
+        model._rng_rank = None
+        if parallel.active():
+            parallel.decorrelate_rng(model)
     if optimizer is not None and 'optimizer' in meta:
         o = meta['optimizer']
         optimizer.iterations = int(o['iterations'])
@@ -259,9 +292,9 @@ def fit(model, optimizer, loss_fn, dice_fn, train_data, val_data, n_epochs, pati
                 f.write(log_row(epoch, row['lr'], *[row[k] for k in names]) + '\n')
         action = tracker.update(float(row['val_macro_dice']))
         if action == 'save':
-            if writer:
+            if save_folder is not None:          # every rank: the per-rank random state is gathered; rank 0 writes
                 save_checkpoint(save_folder, model, optimizer, completed=True, tracker=tracker,
-                                datasets={'train': train_data, 'val': val_data})
+                                datasets={'train': train_data, 'val': val_data}, write=writer)
             log('Saved model weights.')
         elif action == 'stop':
             log('Validation dice has not improved in {} epochs. Stopped training.'.format(patience))

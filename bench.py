@@ -168,21 +168,25 @@ INFER_ALGORITHMIC_GFLOP = 3984.7   # 160x192x160 forward without th
 INFER_ALGORITHMIC_GB = {'f16': 8.7, 'bf16': 8.7, 'f32': 17.25}   # 8.55 GB of 16-bit activations + 149 MB weights
 
 
-def run_infer(args, world, rank, dev, overrides):
+def measure_infer(args, world, rank, dev, overrides, dtype=None, shape=None, batch=None, steps=None, warmup=None):
     """BASELINE configs[4]: 2ch x 155x190x147 zero-padded to 160x192x160 (test.py:164-178), inference=True (VAE skipped,
     model.py:67-68), CLI-default model, batch 1 per GPU.  A step = one forward.  N > 1: independent replicas (the path has no
-    exchange step)."""
+    exchange step).  Returns the result dict on rank 0 (None elsewhere)."""
     import torch
     from bts_amd import lowp, ops, parallel
     from bts_amd.model import Model
+    dtype = args.dtype if dtype is None else dtype
+    batch = args.batch if batch is None else batch
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     dt = {'f32': 'f32', 'fp32': 'f32', 'float32': 'f32', None: 'f16', 'f16': 'f16', 'fp16': 'f16', 'float16': 'f16',
-          'bf16': 'bf16', 'bfloat16': 'bf16'}[args.dtype]
+          'bf16': 'bf16', 'bfloat16': 'bf16'}[dtype]
     model = Model(base_filters=32, reduction=8, depth=4, groups=8)
     model.build((1, 128, 128, 128, 2))     # the weights belong to the training crop (the VAE is tied to it, vae.py:101-111)
     g = torch.Generator().manual_seed(1234 + rank)
-    shape = tuple(int(v) for v in args.infer_shape.split(','))
-    canonical = shape == (160, 192, 160) and args.batch == 1
-    x = torch.randn((args.batch,) + shape + (2,), generator=g)
+    shape = tuple(int(v) for v in (args.infer_shape if shape is None else shape).split(','))
+    canonical = shape == (160, 192, 160) and batch == 1
+    x = torch.randn((batch,) + shape + (2,), generator=g)
     if canonical:        # the zero padding of test.py:164-178
         x[:, 155:] = 0
         x[:, :, 190:] = 0
@@ -193,17 +197,14 @@ def run_infer(args, world, rank, dev, overrides):
     else:
         run = lowp.LowPrecisionForward(model, {'f16': 'float16', 'bf16': 'bfloat16'}[dt])
         fwd = lambda: run(x)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         y = fwd()
     torch.cuda.synchronize()
     if parallel.active():
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    do_prof = not args.no_profile
-    if do_prof:
-        ops.profile_enable(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         y = fwd()
     torch.cuda.synchronize()
     if parallel.active():
@@ -218,30 +219,35 @@ def run_infer(args, world, rank, dev, overrides):
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         torch.distributed.all_reduce(one, op=torch.distributed.ReduceOp.SUM)
         dts, ranks_seen = float(tt.item()), int(round(float(one.item())))
+    # per-kernel pass AFTER the timed region (the HIP-event hooks cost a few percent of a 7-ms forward): `roofline` / `kernel_breakdown`
     prof = None
-    if do_prof:
+    prof_steps = min(steps, 5)
+    if not args.no_profile and rank == 0:
+        ops.profile_enable(True)
+        t1 = time.perf_counter()
+        for _ in range(prof_steps):
+            y = fwd()
+        torch.cuda.synchronize()
+        dt_prof = time.perf_counter() - t1
         ops.profile_enable(False)
         prof = ops.profile_records()
-    if parallel.active():
-        torch.distributed.destroy_process_group()
     if rank != 0:
-        return
-    sec = dts / args.steps
+        return None
+    sec = dts / steps
     out = {
         'metric': 'inference volumes/sec (2ch x 155x190x147 padded to 160x192x160, VAE off)' if canonical else
-                  'forward volumes/sec (2ch x %dx%dx%d, batch %d, VAE off)' % (shape + (args.batch,)),
-        'value': ranks_seen * args.batch / sec,
-        'unit': 'volumes/s', 'n_gpus': world, 'ranks_seen': ranks_seen, 'steps': args.steps, 'warmup': args.warmup,
+                  'forward volumes/sec (2ch x %dx%dx%d, batch %d, VAE off)' % (shape + (batch,)),
+        'value': ranks_seen * batch / sec,
+        'unit': 'volumes/s', 'n_gpus': world, 'ranks_seen': ranks_seen, 'steps': steps, 'warmup': warmup,
         'ms_per_step': 1e3 * sec, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dt, 'data': 'synthetic',
         'config': {'workload': ('BASELINE configs[4]: full-volume inference, 2ch x 155x190x147 zero-padded to 160x192x160, inference=True '
                                 '(decoder path, VAE off), batch 1 per GPU, CLI-default model; storage %s, fp32 sums' % dt) if canonical else
                                ('NOT a BASELINE line: forward only (VAE off) at 2ch x %dx%dx%d, batch %d per GPU, CLI-default model; storage %s'
-                                % (shape + (args.batch, dt))),
+                                % (shape + (batch, dt))),
                    'parallelism': 'replicas%d' % world},
         'y_pred_mean': float(y.mean()),
-        # whole-forward rooflines (SURVEY 8d figures): both terms, the larger one bounds the forward
     }
-    if canonical:
+    if canonical:      # whole-forward rooflines (SURVEY 8d figures): both terms, the larger one bounds the forward
         out['forward_rooflines'] = {
             'algorithmic_gflop': INFER_ALGORITHMIC_GFLOP, 'algorithmic_gb': INFER_ALGORITHMIC_GB[dt],
             'mfma_frac': INFER_ALGORITHMIC_GFLOP / 1e3 / sec / (PEAK_F32_MFMA_TFLOPS if dt == 'f32' else PEAK_F16_MFMA_TFLOPS),
@@ -249,82 +255,64 @@ def run_infer(args, world, rank, dev, overrides):
     if overrides:
         out['overrides'] = overrides
     if prof:
-        agg = {}
-        for sym, flops, ms in prof:
-            a = agg.setdefault(sym, [0.0, 0.0, 0])
-            a[0] += ms * 1e-3
-            a[1] += flops
-            a[2] += 1
-        sym, (tsec, fl, nl) = max(agg.items(), key=lambda kv: kv[1][0])
-        lowp_kernel = sym.startswith('lp_')
-        peak = PEAK_F16_MFMA_TFLOPS if lowp_kernel else PEAK_F32_MFMA_TFLOPS
-        ach = fl / tsec / 1e12 * WINOGRAD_EXECUTED.get(sym, 1.0)
-        out['roofline'] = {'kernel': sym, 'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                           'traffic': None, 'launches_per_step': nl / args.steps, 'avg_launch_ms': 1e3 * tsec / nl,
-                           'algorithmic_gflop_per_launch': fl / nl / 1e9, 'time_share_of_step': tsec / dts}
-        out['kernel_breakdown'] = {k: {'ms_per_step': 1e3 * v[0] / args.steps, 'tflops': v[1] / v[0] / 1e12,
-                                       'launches_per_step': v[2] / args.steps} for k, v in sorted(agg.items())}
-    print(json.dumps(out), flush=True)
+        out.update(_roofline_from_records(prof, prof_steps, dt_prof, None,
+                                          'HIP events on the launch stream over %d further forwards right after the timed region' % prof_steps))
+    del model
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--crop', type=int, default=128)
-    ap.add_argument('--batch', type=int, default=1, help='samples per GPU')
-    ap.add_argument('--share-gpu', action='store_true', help='let ranks share devices (gloo); functional check only')
-    ap.add_argument('--allow-overrides', action='store_true', help='run although BTS_* A/B switches are set')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-baseline-crop', type=int, default=128)
-    ap.add_argument('--no-profile', action='store_true')
-    ap.add_argument('--serial-streams', action='store_true',
-                    help='one HIP stream for the whole step (the per-kernel rocprofv3 capture that backs `roofline` is taken this way)')
-    ap.add_argument('--infer', action='store_true', help='BASELINE configs[4]: full-volume inference (VAE off) instead of the train step')
-    ap.add_argument('--infer-shape', default='160,192,160', help='D,H,W of the --infer volume (multiples of 8)')
-    ap.add_argument('--dtype', default=None, help="storage type of the --infer forward: f32 | f16 (default) | bf16")
-    ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
-    args = ap.parse_args()
-    if args.cpu_baseline_worker:
-        _cpu_baseline_worker(args.crop)
-        return
-    overrides = active_overrides()
-    if overrides and not args.allow_overrides:
-        raise SystemExit('bench.py measures the product defaults; unset %s or pass --allow-overrides (they are then listed '
-                         'in the JSON line)' % ', '.join(overrides))
+def _roofline_from_records(prof, steps_p, dt_p, traffic_of, measured):
+    """`roofline` (dominant kernel by summed launch time) + `kernel_breakdown` from the library's HIP-event records"""
+    agg = {}
+    for sym, flops, ms in prof:
+        a = agg.setdefault(sym, [0.0, 0.0, 0])
+        a[0] += ms * 1e-3
+        a[1] += flops
+        a[2] += 1
+    sym, (tsec, fl, nl) = max(agg.items(), key=lambda kv: kv[1][0])
+    alg = fl / tsec / 1e12                        # ALGORITHMIC (direct-form) FLOP rate
+    wino = sym in WINOGRAD_EXECUTED
+    ach = alg * WINOGRAD_EXECUTED.get(sym, 1.0)   # what the matrix pipe executes
+    traffic = traffic_of(sym) if traffic_of else None
+    t_launch = tsec / nl
+    peak = PEAK_F16_MFMA_TFLOPS if sym.startswith('lp_') else PEAK_F32_MFMA_TFLOPS   # 16-bit kernels against the 16-bit dense peak
+    # which roofline bounds it: time the executed FLOPs need at the matrix peak vs time the measured HBM traffic needs
+    t_mfma = (fl / nl) * WINOGRAD_EXECUTED.get(sym, 1.0) / (peak * 1e12)
+    t_hbm = (traffic['bytes'] / (PEAK_HBM_TBS * 1e12)) if traffic else 0.0
+    roof = {
+        'kernel': sym, 'bound': 'mfma' if t_mfma >= t_hbm else 'hbm',
+        'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+        'achieved_algorithmic': alg, 'frac_algorithmic': alg / peak,
+        'traffic': traffic['bytes'] if traffic else None, 'traffic_detail': traffic,
+        'hbm_frac_of_launch': (t_hbm / t_launch) if traffic else None,
+        'launches_per_step': nl / steps_p, 'avg_launch_ms': 1e3 * t_launch,
+        'algorithmic_gflop_per_launch': fl / nl / 1e9,
+        'time_share_of_step': tsec / dt_p,
+        'measured': measured,
+    }
+    if wino:
+        roof['note'] = ('Winograd forms issue fewer matrix instructions than algorithmic MACs (F(2x2x2,3x3x3): 8 per 27, '
+                        'F(2x2,3x3) x direct: 12 per 27; executed/algorithmic = %.4f here): ' % WINOGRAD_EXECUTED[sym] +
+                        '`achieved`/`frac` are the EXECUTED rate (what is left to gain); *_algorithmic is '
+                        'direct-form FLOPs / time and may exceed the peak')
+    return {'roofline': roof,
+            'kernel_breakdown': {k: {'ms_per_step': 1e3 * v[0] / steps_p, 'tflops': v[1] / v[0] / 1e12,
+                                     'launches_per_step': v[2] / steps_p} for k, v in sorted(agg.items())}}
 
-    env_world = os.environ.get('WORLD_SIZE')
-    if env_world is None and args.gpus > 1:
-        launch_ranks(args, sys.argv[1:])
-        return
-    world = int(env_world) if env_world is not None else 1
-    if world != args.gpus:
-        raise SystemExit('bench.py --gpus %d but WORLD_SIZE=%d: refusing to report a %d-rank run as %d GPUs'
-                         % (args.gpus, world, world, args.gpus))
 
+def measure_train(args, world, rank, dev, overrides, dtype=None, batch=None, steps=None, warmup=None, shared=None):
+    """one training configuration -> result dict on rank 0 (None elsewhere).  dtype f32: BASELINE configs[1] (the headline);
+    bf16 / f16: the 16-bit STORAGE step of BASELINE configs[2] (bts_amd.lowp_train)."""
     import torch
-    import bts_amd  # noqa: F401
     from bts_amd import ops, parallel
     from bts_amd.data import synthetic_batch
     from bts_amd.model import Model
     from bts_amd.util import DiceCoefficient, DiceVAELoss, ScheduledOptim, train_step
-
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X (no CPU execution path exists for the product)')
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    shared = os.environ.get('BTS_BENCH_SHARED_DEVICES')
-    torch.cuda.set_device(local)
-    if world > 1 or os.environ.get('BTS_FORCE_PG'):   # BTS_FORCE_PG=1: 1-rank RCCL group, smoke-tests the N>1 code path
-        parallel.init_from_env('gloo' if shared else 'nccl')
-    dev = torch.device('cuda', local)
-
-    if args.infer:
-        run_infer(args, world, rank, dev, overrides)
-        return
+    dtype = args.dtype if dtype is None else dtype
+    nb = args.batch if batch is None else batch
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     crop = (args.crop,) * 3
-    nb = args.batch
     kw = dict(base_filters=32, reduction=8, depth=4, groups=8)
     model = Model(**kw)
     model.build((nb,) + crop + (2,))
@@ -335,7 +323,7 @@ def main():
     opt(epoch=0)
     loss_fn, dice_fn = DiceVAELoss(), DiceCoefficient()
     tdt = {None: 'f32', 'f32': 'f32', 'fp32': 'f32', 'float32': 'f32', 'bf16': 'bf16', 'bfloat16': 'bf16', 'f16': 'f16', 'fp16': 'f16',
-           'float16': 'f16'}[args.dtype]
+           'float16': 'f16'}[dtype]
     if tdt != 'f32':      # BASELINE configs[2]: 16-bit storage, fp32 sums / master weights (bts_amd.lowp_train); its own line, never the headline
         from bts_amd.lowp_train import LowPrecisionTrainer
         trainer = LowPrecisionTrainer(model, {'bf16': 'bfloat16', 'f16': 'float16'}[tdt])
@@ -343,14 +331,14 @@ def main():
 
     if args.serial_streams:
         ops.enable_side_streams(False)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         loss, macro, micro = train_step(model, opt, loss_fn, dice_fn, x, y)
     torch.cuda.synchronize()
     if parallel.active():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss, macro, micro = train_step(model, opt, loss_fn, dice_fn, x, y)
     torch.cuda.synchronize()
     if parallel.active():
@@ -374,7 +362,7 @@ def main():
     # (`bench.py --serial-streams` under rocprofv3 is the capture these averages must agree with).
     do_prof = (not args.no_profile) and rank == 0
     prof = None
-    prof_steps = min(args.steps, 5)
+    prof_steps = min(steps, 5)
     loss_v, macro_v = float(loss), float(macro)
     if parallel.active():
         torch.distributed.barrier()
@@ -391,25 +379,22 @@ def main():
         ops.profile_enable(False)
         prof = ops.profile_records()
         ops.enable_side_streams(not args.serial_streams)
-
     if rank != 0:
-        if parallel.active():
-            torch.distributed.destroy_process_group()
-        return
-    volumes = ranks_seen * nb * args.steps
+        return None
+    volumes = ranks_seen * nb * steps
     n_gpus = min(world, int(shared)) if shared else world
     out = {
         'metric': 'training volumes/sec (2ch x %d^3)' % args.crop, 'value': volumes / dt, 'unit': 'volumes/s',
-        'n_gpus': n_gpus, 'ranks_seen': ranks_seen, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': 1e3 * dt / args.steps,
+        'n_gpus': n_gpus, 'ranks_seen': ranks_seen, 'steps': steps, 'warmup': warmup,
+        'ms_per_step': 1e3 * dt / steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': tdt, 'data': 'synthetic',
         'config': {'workload': ('BASELINE configs[1]: 2ch x %d^3, batch %d per GPU, fp32, full fwd+bwd with '
                                 'Dice+KL+L2 VAE loss + Dice metric + TF-form Adam; CLI-default model '
                                 '(base_filters=32, depth=4, groups=8, reduction=8; 42,174,773 params)' % (args.crop, nb)) if tdt == 'f32' else
                                ('BASELINE configs[2] (when batch = 8, bf16): 2ch x %d^3, batch %d per GPU, %s STORAGE of activations / their '
-                                'gradients / weight images, fp32 sums, fp32 master weights and Adam; full train step; forward and data '
-                                'gradients on the 16-bit kernels, weight / GroupNorm / gate gradients on the fp32 kernels over widened '
-                                'operands; CLI-default model' % (args.crop, nb, tdt)),
+                                'gradients / weight images, fp32 sums, fp32 master weights and Adam; full train step (forward, data, '
+                                'weight, GroupNorm and gate gradients on the 16-bit kernels; loss, metric, regulariser, Adam and the '
+                                'dense VAE head in fp32); CLI-default model' % (args.crop, nb, tdt)),
                    'parallelism': 'dp%d' % world, 'global_batch': world * nb},
         'loss': loss_v, 'macro_dice': macro_v,
         'streams': 'serial (one HIP stream)' if args.serial_streams else 'main + weight-gradient + gate streams',
@@ -419,47 +404,90 @@ def main():
     if overrides:
         out['overrides'] = overrides
     if do_prof and prof:
-        steps_p, dt_p = prof_steps, dt_prof
-        agg = {}
-        for sym, flops, ms in prof:
-            a = agg.setdefault(sym, [0.0, 0.0, 0])
-            a[0] += ms * 1e-3
-            a[1] += flops
-            a[2] += 1
-        dom = max(agg.items(), key=lambda kv: kv[1][0])
-        sym, (tsec, fl, nl) = dom
-        alg = fl / tsec / 1e12                     # ALGORITHMIC (direct-form) FLOP rate
-        wino = sym in WINOGRAD_EXECUTED
-        ach = alg * WINOGRAD_EXECUTED.get(sym, 1.0)   # what the matrix pipe executes
-        traffic = pmc_traffic(sym)
-        t_launch = tsec / nl
-        # which roofline bounds it: time the executed FLOPs need at the matrix peak vs time the measured HBM traffic needs
-        peak = PEAK_F16_MFMA_TFLOPS if sym.startswith('lp_') else PEAK_F32_MFMA_TFLOPS   # 16-bit kernels against the 16-bit dense peak
-        t_mfma = (fl / nl) * WINOGRAD_EXECUTED.get(sym, 1.0) / (peak * 1e12)
-        t_hbm = (traffic['bytes'] / (PEAK_HBM_TBS * 1e12)) if traffic else 0.0
-        out['roofline'] = {
-            'kernel': sym, 'bound': 'mfma' if t_mfma >= t_hbm else 'hbm',
-            'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-            'achieved_algorithmic': alg, 'frac_algorithmic': alg / peak,
-            'traffic': traffic['bytes'] if traffic else None, 'traffic_detail': traffic,
-            'hbm_frac_of_launch': (t_hbm / t_launch) if traffic else None,
-            'launches_per_step': nl / steps_p, 'avg_launch_ms': 1e3 * t_launch,
-            'algorithmic_gflop_per_launch': fl / nl / 1e9,
-            'time_share_of_step': tsec / dt_p,
-            'measured': ('HIP events on the launch stream over %d one-stream steps run right after the timed region (%.2f ms per '
-                         'step that way): in the timed region the kernel shares the chip with the weight-gradient / gate streams '
-                         'and has no launch duration of its own' % (steps_p, 1e3 * dt_p / steps_p)),
-        }
-        if wino:
-            out['roofline']['note'] = ('Winograd forms issue fewer matrix instructions than algorithmic MACs (F(2x2x2,3x3x3): 8 per 27, '
-                                       'F(2x2,3x3) x direct: 12 per 27; executed/algorithmic = %.4f here): ' % WINOGRAD_EXECUTED[sym] +
-                                       '`achieved`/`frac` are the EXECUTED rate (what is left to gain); *_algorithmic is '
-                                       'direct-form FLOPs / time and may exceed the peak')
-        out['kernel_breakdown'] = {k: {'ms_per_step': 1e3 * v[0] / steps_p, 'tflops': v[1] / v[0] / 1e12,
-                                       'launches_per_step': v[2] / steps_p} for k, v in sorted(agg.items())}
-    if world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(args.cpu_baseline_crop)
-    print(json.dumps(out), flush=True)
+        out.update(_roofline_from_records(
+            prof, prof_steps, dt_prof, pmc_traffic,
+            'HIP events on the launch stream over %d one-stream steps run right after the timed region (%.2f ms per step that way): in the '
+            'timed region the kernel shares the chip with the weight-gradient / gate streams and has no launch duration of its own'
+            % (prof_steps, 1e3 * dt_prof / prof_steps)))
+    del model, opt
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--crop', type=int, default=128)
+    ap.add_argument('--batch', type=int, default=1, help='samples per GPU')
+    ap.add_argument('--share-gpu', action='store_true', help='let ranks share devices (gloo); functional check only')
+    ap.add_argument('--allow-overrides', action='store_true', help='run although BTS_* A/B switches are set')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-crop', type=int, default=128)
+    ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--no-also', action='store_true',
+                    help='headline only: skip the BASELINE configs[2] / configs[4] measurements nested under "also"')
+    ap.add_argument('--serial-streams', action='store_true',
+                    help='one HIP stream for the whole step (the per-kernel rocprofv3 capture that backs `roofline` is taken this way)')
+    ap.add_argument('--infer', action='store_true', help='BASELINE configs[4]: full-volume inference (VAE off) instead of the train step')
+    ap.add_argument('--infer-shape', default='160,192,160', help='D,H,W of the --infer volume (multiples of 8)')
+    ap.add_argument('--dtype', default=None, help="storage type: training f32 (default) | bf16 | f16; --infer f16 (default) | bf16 | f32")
+    ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        _cpu_baseline_worker(args.crop)
+        return
+    overrides = active_overrides()
+    if overrides and not args.allow_overrides:
+        raise SystemExit('bench.py measures the product defaults; unset %s or pass --allow-overrides (they are then listed '
+                         'in the JSON line)' % ', '.join(overrides))
+
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is None and args.gpus > 1:
+        launch_ranks(args, sys.argv[1:])
+        return
+    world = int(env_world) if env_world is not None else 1
+    if world != args.gpus:
+        raise SystemExit('bench.py --gpus %d but WORLD_SIZE=%d: refusing to report a %d-rank run as %d GPUs'
+                         % (args.gpus, world, world, args.gpus))
+
+    import torch
+    import bts_amd  # noqa: F401
+    from bts_amd import parallel
+
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU execution path exists for the product)')
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    shared = os.environ.get('BTS_BENCH_SHARED_DEVICES')
+    torch.cuda.set_device(local)
+    if world > 1 or os.environ.get('BTS_FORCE_PG'):   # BTS_FORCE_PG=1: 1-rank RCCL group, smoke-tests the N>1 code path
+        parallel.init_from_env('gloo' if shared else 'nccl')
+    dev = torch.device('cuda', local)
+
+    if args.infer:
+        out = measure_infer(args, world, rank, dev, overrides)
+    else:
+        out = measure_train(args, world, rank, dev, overrides, shared=shared)
+        headline = args.dtype in (None, 'f32', 'fp32', 'float32') and args.batch == 1 and args.crop == 128
+        if headline and world == 1 and not parallel.active() and not args.no_also and out is not None:
+            # The two secondary BASELINE configurations, measured in this same process right after the (untouched) headline and
+            # nested under "also": driver-witnessed numbers for the 16-bit engine.  Each is its own workload with its own timed
+            # region (warm-up, then steps bracketed by synchronize); none of it is inside the headline's timed region.
+            torch.cuda.empty_cache()
+            also = {}
+            try:
+                also['configs[2]'] = measure_train(args, world, rank, dev, overrides, dtype='bf16', batch=8, steps=5, warmup=3)
+                torch.cuda.empty_cache()
+                also['configs[4]'] = measure_infer(args, world, rank, dev, overrides, dtype='f16', shape='160,192,160', batch=1,
+                                                   steps=10, warmup=3)
+            except Exception as e:   # the headline stands on its own; a failure here is reported, not hidden
+                also['error'] = '%s: %s' % (type(e).__name__, str(e)[:300])
+            out['also'] = also
+        if world == 1 and not args.no_cpu_baseline and out is not None:
+            out['cpu_baseline'] = cpu_baseline(args.cpu_baseline_crop)
+    if out is not None:
+        print(json.dumps(out), flush=True)
     if parallel.active():
         torch.distributed.destroy_process_group()
 

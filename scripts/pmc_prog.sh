@@ -6,6 +6,7 @@ set -euo pipefail
 TAG=${1:?tag}; FILTER=${2:?kernel filter}; shift 2
 R=${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}
 O=$R/gpurun_out
+mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 GROUPS_=(
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE"

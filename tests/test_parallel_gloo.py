@@ -79,3 +79,52 @@ def test_two_rank_data_parallel_equals_global_batch():
     dloss, dgrad, gscale = res
     assert dloss < 1e-12, res
     assert dgrad < 1e-10 * max(gscale, 1.0), res
+
+
+def _ckpt_worker(rank, world, port, folder, q):
+    """two ranks run one 'epoch' of random draws, save (all ranks call, rank 0 writes), then FRESH objects load: every rank must get
+    back its own augmentation generator and its own dropout / reparameterisation counters (all ranks used to
+    resume with rank 0's)"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import bts_amd  # noqa: F401
+    from bts_amd import data as D, parallel, train as T
+    from bts_amd.model import Model
+    torch.set_num_threads(1)
+    parallel.init_from_env('gloo')
+    m = Model(base_filters=8, reduction=2, depth=2, groups=2)
+    m.build((1, 8, 8, 8, 2))
+    parallel.decorrelate_rng(m)                        # (broadcast_parameters does this after the C2 broadcast)
+    m.encoder._seed += 3                               # three steps' worth of draws on every rank
+    m.vae._seed += 3
+    ds = D._Dataset(['a', 'b', 'c', 'd'], 1, (8, 8, 8, 2), (8, 8, 8), 3, True, seed=3, device='cpu', rank=rank, world=world)
+    torch.randperm(4, generator=ds.order_gen)
+    torch.rand(5 + rank, generator=ds.gen)             # ranks are at different positions of different streams
+    want = (int(m.encoder._seed), int(m.vae._seed), torch.rand(4, generator=torch.Generator().set_state(ds.gen.get_state())).tolist(),
+            torch.randperm(4, generator=torch.Generator().set_state(ds.order_gen.get_state())).tolist())
+    T.save_checkpoint(folder, m, None, completed=True, datasets={'train': ds}, write=(rank == 0))
+    torch.distributed.barrier()
+    m2 = Model(base_filters=8, reduction=2, depth=2, groups=2)
+    m2.build((1, 8, 8, 8, 2))
+    T.load_checkpoint(folder, m2)
+    ds2 = D._Dataset(['a', 'b', 'c', 'd'], 1, (8, 8, 8, 2), (8, 8, 8), 3, True, seed=77, device='cpu', rank=rank, world=world)
+    ds2.load_state_dict({k[len('train/'):]: v for k, v in m2._resume['data'].items() if k.startswith('train/')})
+    got = (int(m2.encoder._seed), int(m2.vae._seed), torch.rand(4, generator=ds2.gen).tolist(), torch.randperm(4, generator=ds2.order_gen).tolist())
+    q.put((rank, want == got, want[0]))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_checkpoint_keeps_per_rank_random_state(tmp_path):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ckpt_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1], res
+    assert res[0][2] != res[1][2]                      # the ranks' counters differ, and each got its own back
