@@ -537,6 +537,10 @@ int bts_wino_launch_(const float* x, const float* up, const float* bias, float* 
   if (((long)(D + 2) * H * W + 64) * (long)ldx * 4 >= 0x7fffffffL) return 1;  // 31-bit byte offsets inside one volume
   WinoPlan q;
   if (!wino_plan(q, N, D, H, W, Cin, Cout)) return 1;
+  {  // the output side forms 31-bit byte offsets too: voxel index * (ldy, or the padded split-K row) * 4, 0x80000000 = masked lane
+    const long orow = (long)ldy > (long)q.nb * 32 ? (long)ldy : (long)q.nb * 32;
+    if (((long)D * H * W + 64) * orow * 4 >= 0x7fffffffL) return 1;
+  }
   if (q.ksplit > 1 && (ws == nullptr || ws_bytes < q.need || (((uintptr_t)ws) & 15))) { q.ksplit = 1; q.kg_per = Cin / 8; }
   int min_wgs = 192;
   { const char* e = getenv("BTS_WINO_MIN_WGS"); if (e) min_wgs = atoi(e); }

@@ -6,9 +6,12 @@
 // + 3.8 vector instructions per matrix instruction of run-time address arithmetic, halo tile global -> registers -> LDS) and sat at
 // 0.25-0.27 of the 2.5 PF dense peak with its waves parked 64 % of the time (profiles/r02b_pmc_lp_s1.txt).  Here
 //   * BOTH operands reach LDS by buffer_load_dwordx4 ... lds (no staging registers, no ds_write pass): the halo tile of one k-step
-//     (16 input channels) as two planes [k-half][voxel][8 channels] -- 32 consecutive voxels of a plane are 512 contiguous bytes, so
-//     a B fragment is ONE conflict-free ds_read_b128 at a compile-time offset from a per-lane base, for every tap; out-of-image
-//     voxels use an offset outside the buffer descriptor (the DMA then writes zeros: 'same' padding without a branch);
+//     (16 input channels) as [voxel][2 x 8 channels] with the two 16-byte halves of a voxel swapped where bit 3 of its x is set --
+//     two neighbouring lanes fetch one voxel's 32 contiguous bytes (one L2 request per line; k-half planes fetched by separate
+//     requests doubled the L2 request count, which is what bounds the 128^3 layers), and a B fragment (32 consecutive x of one
+//     k-half) is ONE conflict-free ds_read_b128 at a compile-time offset from one of three per-lane bases (one per x tap: the swap
+//     depends on x only, rows and planes are whole multiples of 32 bytes); out-of-image voxels use an offset outside the buffer
+//     descriptor (the DMA then writes zeros: 'same' padding without a branch);
 //   * the weights of a STAGE (k-step, dz: 9 taps x 16 cin x 32|64 couts = 9|18 KB) are copied verbatim from a packed image laid out
 //     as the LDS image [tap][k-half][cout][8 cin] and shared by the 8 waves (A fragment = one ds_read_b128 at an immediate offset);
 //   * 512 threads: wave = (z plane, g) with g = y half of a 32x8x4 tile (32-cout items) or cout block of a 32x4x4 tile (64-cout
@@ -16,7 +19,7 @@
 //   * a three-slot weight ring and a double-buffered halo tile are filled two stages / one k-step ahead; a stage boundary is
 //     `s_waitcnt vmcnt(N)` with N counted (never 0) + one s_barrier; a workgroup walks its items (tile x cout group, XCD-aware
 //     order) as ONE stage stream, the next item's operands in flight under the current item's output side.
-// Declines (caller runs the old kernel): W < 12, Cout % 4 != 0, offsets beyond 31 bits.
+// Declines (caller runs the old kernel): W < 12, Cout % 8 != 0, offsets beyond 31 bits.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -60,15 +63,15 @@ struct S1dGeo {
   // runs of a 16-byte-per-lane read land on the same bank phase (MI355X LDS: ds_read_b128 is served in 16-lane groups)
   static constexpr int PS = (ZP == 1) ? SY * SX : ((SY * SX + 15) / 16) * 16;
   static constexpr int NVOX = SZ * PS;
-  static constexpr int NCH = ((NVOX + 511) / 512) * 8;       // 64-voxel DMA chunks per k-half plane (whole rounds of the 8 waves)
-  static constexpr int HPLANE = NCH * 1024, HBUF = 2 * HPLANE;
-  static constexpr int NHC = 2 * NCH, NH = NHC / 8;          // halo chunks per k-step / per wave (an even number: plane pairs)
-  static constexpr int NHA = 2 * ((NH / 2 + 1) / 2), NHB = NH - NHA;   // issued in stage 0 / stage 1
+  static constexpr int NCH = ((NVOX + 255) / 256) * 8;       // 1 KB DMA chunks (32 voxels x 32 bytes) per k-step, whole rounds of the 8 waves
+  static constexpr int HBUF = NCH * 1024;
+  static constexpr int NH = NCH / 8;                         // halo requests per wave and k-step
+  static constexpr int NHA = (NH + 1) / 2, NHB = NH - NHA;   // issued in stage 0 / stage 1
   static constexpr int WTAP = CBW * 1024, WSTAGE = 9 * WTAP;
   static constexpr int NWC = 9 * CBW, NW = (NWC + 7) / 8;    // weight chunks per stage / per wave
   static constexpr int OFF_W = 2 * HBUF, OFF_SCR = OFF_W + 3 * WSTAGE, OFF_BIAS = OFF_SCR + 1024;
   static constexpr int LDS_BYTES = OFF_BIAS + 2 * 256;       // two bias slots of 64 floats (a 4-byte DMA writes all 64 lanes)
-  static constexpr int NST = 16;                             // output-side store instructions per wave and item
+  static constexpr int NST = 8;                              // output-side store instructions per wave and item (16 bytes per lane)
 };
 
 template <int N> __device__ __forceinline__ void s1d_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
   // LDS-DMA offsets trigger it -- so the body exists in the device pass only; there is no other code path)
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef S1dGeo<MODE, TXL> G;
-  constexpr int TX = G::TX, ZP = G::ZP, CBW = G::CBW, SX = G::SX, SY = G::SY, PS = G::PS, NVOX = G::NVOX, NCH = G::NCH;
+  constexpr int TX = G::TX, ZP = G::ZP, CBW = G::CBW, SX = G::SX, SY = G::SY, PS = G::PS, NVOX = G::NVOX;
   constexpr int NH = G::NH, NHA = G::NHA, NHB = G::NHB, NW = G::NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -128,15 +131,15 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
   }
 
   // ---- DMA side ----
-  // request r of a wave: k-half plane r & 1 of the 64-voxel group (r >> 1)*8 + wave of the (padded) halo tile -- the two requests
-  // that touch the same 32 bytes of a voxel are issued back to back (the second one finds the line in the vector L1: one L2
-  // request per voxel and k-step instead of two)
+  // request r of a wave fills the 1 KB chunk r*8 + wave of the halo buffer: 32 voxels, lanes (2i, 2i+1) the two 16-byte slots of
+  // voxel i; slot c of a voxel at halo column x holds k-half c ^ bit3(x)
   unsigned hrel[NH], hcrd[NH];
 #pragma unroll
   for (int r = 0; r < NH; ++r) {
-    const int hp = r & 1, vox = ((r >> 1) * 8 + wave) * 64 + lane;
+    const int vox = (r * 8 + wave) * 32 + (lane >> 1);
     const int vz = vox / PS, rem = vox - vz * PS;
     const int vy = rem / SX, vx = rem - vy * SX;
+    const int hp = (lane & 1) ^ ((vx >> 3) & 1);
     const bool geo = vox < NVOX && rem < SY * SX;
     hrel[r] = (unsigned)(((vz * p.H + vy) * p.W + vx) * p.ldx * 2 + hp * 16);
     hcrd[r] = (unsigned)(vx | (vy << 8)) | (geo ? (unsigned)vz << 16 : 0xffff0000u);   // padding voxels: a z no image reaches
@@ -155,22 +158,28 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
       hoff[r] = ok ? hrel[r] : 0x80000000u;
     }
   };
-  static_assert(NCH % 8 == 0 && NH % 2 == 0 && NHA % 2 == 0, "64-voxel groups are dealt to the 8 waves in whole rounds, as plane pairs");
-  auto issue_halo = [&](int r_lo, int r_hi, int ks, int buf) {
-#pragma unroll
-    for (int r = r_lo; r < r_hi; ++r)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(lds + buf * G::HBUF + (r & 1) * G::HPLANE + ((r >> 1) * 8 + wave) * 1024), 16, hoff[r], (unsigned)ks * 32u, 0, 0);
+  // one request each (the k-step body below deals them out between its matrix instructions)
+  auto issue_halo1 = [&](int r, int ks, int buf) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(lds + buf * G::HBUF + (r * 8 + wave) * 1024), 16, hoff[r],
+                                             (unsigned)ks * 32u, 0, 0);
   };
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7fffffff, 0x00020000);
-  auto issue_w = [&](int cg, int ks, int dz, bool live) {   // stage (cg, ks, dz) -> ring slot dz
-    const unsigned soff = (unsigned)((((cg * p.KS + ks) * 3) + dz) * G::WSTAGE);
+  // weight chunk c = r*8 + wave of stage (cg, ks, dz) -> ring slot dz; chunks past the stage's 9*CBW go to the scratch KB with an
+  // out-of-range offset (every wave issues the same number of requests: the vmcnt counts below are compile-time constants)
+  unsigned wvo[NW];
+  int wdst[NW];
 #pragma unroll
-    for (int r = 0; r < NW; ++r) {
-      const int c = r * 8 + wave;
-      const bool ok = live && c < G::NWC;
-      const lds_ptr_t dst = (lds_ptr_t)(lds + (c < G::NWC ? G::OFF_W + dz * G::WSTAGE + c * 1024 : G::OFF_SCR));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, dst, 16, ok ? (unsigned)(c * 1024 + lane * 16) : 0x80000000u, soff, 0, 0);
-    }
+  for (int r = 0; r < NW; ++r) {
+    const int c = r * 8 + wave;
+    wvo[r] = c < G::NWC ? (unsigned)(c * 1024 + lane * 16) : 0x80000000u;
+    wdst[r] = c < G::NWC ? G::OFF_W + c * 1024 : G::OFF_SCR;
+  }
+  auto w_soff = [&](int cg, int ks, int dz, bool live) -> unsigned {
+    return live ? (unsigned)((((cg * p.KS + ks) * 3) + dz) * G::WSTAGE) : 0x80000000u;    // (no next item: nothing to fetch)
+  };
+  auto issue_w1 = [&](int r, unsigned soff, int dz) {
+    const int c = r * 8 + wave;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(lds + wdst[r] + (c < G::NWC ? dz * G::WSTAGE : 0)), 16, wvo[r], soff, 0, 0);
   };
   const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.bias ? (unsigned)p.Cout * 4u : 0u, 0x00020000);
   auto issue_bias = [&](int cg, int slot) {   // every wave writes the same 32*CBW values (benign duplicates, uniform request counts)
@@ -180,36 +189,54 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
   };
 
   // ---- compute side ----
-  const unsigned hbB = (unsigned)(h * G::HPLANE + (((zz * ZP + lz) * PS) + y0 * SX + lx) * 16);
+  // A k-step is nine groups (dz, dx) of 12 matrix instructions: 6 input rows (they serve the three dy taps of the wave's four output
+  // rows) + 3 weight fragments.  The fragments of group g+1 are read from LDS while group g multiplies (two register sets; the
+  // compiler, left alone, reads each fragment right before its first use and exposes the LDS latency 27 times per k-step), the rows
+  // of a stage's first group already before the stage barrier (the halo tile is complete since stage 0; only the weights are new).
+  unsigned hbB[3];      // this lane's B-operand base for x tap dx: voxel (z, y0, lx + dx), physical slot of k-half h
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) hbB[dx] = (unsigned)((((zz * ZP + lz) * PS) + y0 * SX + lx + dx) * 32 + ((h ^ (((lx + dx) >> 3) & 1)) * 16));
   const unsigned wbA = (unsigned)(G::OFF_W + h * (CBW * 512) + cbw * 512 + l32 * 16);
   f32x16 acc[4];
-  auto compute = [&](auto dzc, int buf) {
-    constexpr int DZ = decltype(dzc)::value;
-    const unsigned char* hb = lds + hbB + (buf ? G::HBUF : 0);
-    const unsigned char* wb = lds + wbA + DZ * G::WSTAGE;
+  u32x4 Bc[6], Ac[3], Bn[6], An[3];
+  auto ldB = [&](u32x4 (&B)[6], const unsigned char* hb, auto dzc, auto dxc) {     // hb = the halo buffer of this k-step
+    constexpr int DZ = decltype(dzc)::value, DX = decltype(dxc)::value;
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      u32x4 bj[6];
+    for (int j = 0; j < 6; ++j) B[j] = *reinterpret_cast<const u32x4*>(hb + hbB[DX] + ((DZ * PS) + j * SX) * 32);
+  };
+  auto ldA = [&](u32x4 (&A)[3], auto dzc, auto dxc) {
+    constexpr int DZ = decltype(dzc)::value, DX = decltype(dxc)::value;
 #pragma unroll
-      for (int j = 0; j < 6; ++j) bj[j] = *reinterpret_cast<const u32x4*>(hb + ((DZ * PS) + j * SX + dx) * 16);
+    for (int dy = 0; dy < 3; ++dy) A[dy] = *reinterpret_cast<const u32x4*>(lds + wbA + DZ * G::WSTAGE + (dy * 3 + DX) * G::WTAP);
+  };
+  // 12 matrix instructions; hook(0..2) runs after each dy's four (one LDS-DMA request each: issued between matrix instructions a
+  // request costs its issue slot, issued in a block at the head of a stage it cost the matrix pipe ~100 cycles apiece)
+  auto mm = [&](const u32x4 (&A)[3], const u32x4 (&B)[6], auto&& hook) {
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const u32x4 a = *reinterpret_cast<const u32x4*>(wb + (dy * 3 + dx) * G::WTAP);
+    for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[v] = T::mfma(a, bj[v + dy], acc[v]);
-      }
+      for (int v = 0; v < 4; ++v) acc[v] = T::mfma(A[dy], B[v + dy], acc[v]);
+      hook(dy);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
 
   Item ci = decode(it);
   dma_item(ci, true);
   int ipar = 0, buf = 0;
   // prologue: the request order of a steady-state k-step's tail (stage 0 below waits for everything but the last weight stage)
-  issue_halo(0, NHA, ks0, 0);
-  issue_w(ci.cg, ks0, 0, true);
-  issue_halo(NHA, NH, ks0, 0);
+#pragma unroll
+  for (int r = 0; r < NHA; ++r) issue_halo1(r, ks0, 0);
+#pragma unroll
+  for (int r = 0; r < NW; ++r) issue_w1(r, w_soff(ci.cg, ks0, 0, true), 0);
+#pragma unroll
+  for (int r = NHA; r < NH; ++r) issue_halo1(r, ks0, 0);
   issue_bias(ci.cg, 0);
-  issue_w(ci.cg, ks0, 1, true);
+#pragma unroll
+  for (int r = 0; r < NW; ++r) issue_w1(r, w_soff(ci.cg, ks0, 1, true), 1);
   bool after_out = false;
   for (;;) {
     const long nit = it + it_step;
@@ -223,26 +250,57 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
       const bool last = ks + 1 == ks1;
       const bool nlive = !last || have_next;
       const int ncg_ = last ? ni.cg : ci.cg, nks = last ? ks0 : ks + 1;
-      // ---- stage 0 (dz = 0) ----
+      const unsigned char* hb = lds + (buf ? G::HBUF : 0);
+      const int nbuf = buf ^ 1;
+      // ---- stage 0 (dz = 0): requests W(ks, 2) then the first half of the next k-step's halo tile ----
       if (after_out) s1d_wait<NW + G::NST>(); else s1d_wait<NW>();
       s1d_barrier();
       after_out = false;
-      issue_w(ci.cg, ks, 2, true);
+      ldB(Bc, hb, I0(), I0()); ldA(Ac, I0(), I0());
       if (last) dma_item(ni, have_next);
-      issue_halo(0, NHA, nks, buf ^ 1);
-      compute(std::integral_constant<int, 0>(), buf);
-      // ---- stage 1 ----
+      const unsigned so0 = w_soff(ci.cg, ks, 2, true);
+      ldB(Bn, hb, I0(), I1()); ldA(An, I0(), I1());
+      __builtin_amdgcn_sched_barrier(0);
+      mm(Ac, Bc, [&](int i) { if (i < NW) issue_w1(i, so0, 2); else if (i - NW < NHA) issue_halo1(i - NW, nks, nbuf); });
+      ldB(Bc, hb, I0(), I2()); ldA(Ac, I0(), I2());
+      __builtin_amdgcn_sched_barrier(0);
+      mm(An, Bn, [&](int i) { const int j = i + 3; if (j < NW) issue_w1(j, so0, 2); else if (j - NW < NHA) issue_halo1(j - NW, nks, nbuf); });
+      ldB(Bn, hb, I1(), I0());
+      __builtin_amdgcn_sched_barrier(0);
+      mm(Ac, Bc, [&](int i) { const int j = i + 6; if (j < NW) issue_w1(j, so0, 2); else if (j - NW < NHA) issue_halo1(j - NW, nks, nbuf); });
+      static_assert(NW + NHA <= 9 && NW + NHB + 1 <= 9, "a stage has nine request slots");
+      // ---- stage 1: W(next k-step, 0), the second half of its halo tile, its bias ----
       s1d_wait<NW + NHA>();
       s1d_barrier();
-      issue_w(ncg_, nks, 0, nlive);
-      issue_halo(NHA, NH, nks, buf ^ 1);
-      issue_bias(ncg_, last ? (ipar ^ 1) : ipar);
-      compute(std::integral_constant<int, 1>(), buf);
-      // ---- stage 2 ----
+      ldA(An, I1(), I0());
+      const unsigned so1 = w_soff(ncg_, nks, 0, nlive);
+      const int bslot = last ? (ipar ^ 1) : ipar;
+      auto hook1 = [&](int j) {
+        if (j < NW) issue_w1(j, so1, 0);
+        else if (j - NW < NHB) issue_halo1(NHA + j - NW, nks, nbuf);
+        else if (j - NW == NHB) issue_bias(ncg_, bslot);
+      };
+      ldB(Bc, hb, I1(), I1()); ldA(Ac, I1(), I1());
+      __builtin_amdgcn_sched_barrier(0);
+      mm(An, Bn, [&](int i) { hook1(i); });
+      ldB(Bn, hb, I1(), I2()); ldA(An, I1(), I2());
+      __builtin_amdgcn_sched_barrier(0);
+      mm(Ac, Bc, [&](int i) { hook1(i + 3); });
+      ldB(Bc, hb, I2(), I0());
+      __builtin_amdgcn_sched_barrier(0);
+      mm(An, Bn, [&](int i) { hook1(i + 6); });
+      // ---- stage 2: W(next k-step, 1) ----
       s1d_wait<NHA + NW + NHB + 1>();
       s1d_barrier();
-      issue_w(ncg_, nks, 1, nlive);
-      compute(std::integral_constant<int, 2>(), buf);
+      ldA(Ac, I2(), I0());
+      const unsigned so2 = w_soff(ncg_, nks, 1, nlive);
+      ldB(Bn, hb, I2(), I1()); ldA(An, I2(), I1());
+      __builtin_amdgcn_sched_barrier(0);
+      mm(Ac, Bc, [&](int i) { if (i < NW) issue_w1(i, so2, 1); });
+      ldB(Bc, hb, I2(), I2()); ldA(Ac, I2(), I2());
+      __builtin_amdgcn_sched_barrier(0);
+      mm(An, Bn, [&](int i) { if (i + 3 < NW) issue_w1(i + 3, so2, 1); });
+      mm(Ac, Bc, [&](int) {});
       buf ^= 1;
     }
     // ---- output side of `ci` ----
@@ -267,25 +325,41 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
             __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long)ci.n * p.D * p.H * p.W * (long)p.ldy), 0, 0x7fffffff, 0x00020000);
         const bool gn_on = p.gnp != nullptr;
         float gn_s = 0.f, gn_q = 0.f;
+        // The matrix instruction leaves a lane (voxel, h) with couts 8q + 4h + {0..3}: four 8-byte pieces of the voxel's 64-byte
+        // row.  v_permlane32_swap between the two lanes of a voxel (q even of the upper lane <-> q odd of the lower one) gives each
+        // lane EIGHT consecutive couts = one 16-byte store, the pair of lanes 32 contiguous bytes: half the store instructions and
+        // half the L2 write requests of the 8-byte form (the 128^3 layers are bound by L2 requests, not bytes).
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int co = cb * 32 + 8 * q + 4 * h;
-          const f32x4 bq = *reinterpret_cast<const f32x4*>(bsh + 8 * q + 4 * h);
+        for (int qp = 0; qp < 2; ++qp) {
+          const int co = cb * 32 + 16 * qp + 8 * h;
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(bsh + 16 * qp + 4 * h);
+          const f32x4 b1 = *reinterpret_cast<const f32x4*>(bsh + 16 * qp + 8 + 4 * h);
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             const bool ok = co < p.Cout && oz < p.D && oy + v < p.H && ox < p.W;
             const unsigned off = ok ? (unsigned)((((oz * p.H + oy + v) * p.W + ox) * p.ldy + co) * 2) : 0x80000000u;
-            float o0 = acc[v][4 * q] + bq[0], o1 = acc[v][4 * q + 1] + bq[1], o2 = acc[v][4 * q + 2] + bq[2], o3 = acc[v][4 * q + 3] + bq[3];
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float f = acc[v][8 * qp + j] + b0[j], g2 = acc[v][8 * qp + 4 + j] + b1[j];
+              if (gn_on && ok) {      // (own values, before the exchange: the sums run over all lanes anyway)
+                gn_s += f + g2;
+                gn_q = fmaf(f, f, fmaf(g2, g2, gn_q));
+              }
+              // (inline asm, pad inside the string: with the two-result builtin hipcc 7.2 dropped the second result in one of the
+              // loop-unswitched copies of this block -- ragged launches came out wrong at couts 8k + 4..7)
+              float lo = f, hi = g2;
+              asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1\n\tv_nop" : "+v"(lo), "+v"(hi));
+              o[j] = lo;
+              o[4 + j] = hi;
+            }
             if (p.accum) {
-              const u32x2 old = __builtin_amdgcn_raw_buffer_load_b64(yr, off, 0, 0);
-              o0 += T::ld((unsigned short)(old[0] & 0xffffu)); o1 += T::ld((unsigned short)(old[0] >> 16));
-              o2 += T::ld((unsigned short)(old[1] & 0xffffu)); o3 += T::ld((unsigned short)(old[1] >> 16));
+              float old[8];
+              unpack8<T>(__builtin_amdgcn_raw_buffer_load_b128(yr, off, 0, 0), old);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) o[j] += old[j];
             }
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2<T>(o0, o1), pack2<T>(o2, o3)}, yr, off, 0, 0);
-            if (gn_on && ok) {
-              gn_s += (o0 + o1) + (o2 + o3);
-              gn_q = fmaf(o0, o0, fmaf(o1, o1, fmaf(o2, o2, fmaf(o3, o3, gn_q))));
-            }
+            __builtin_amdgcn_raw_buffer_store_b128(pack8<T>(o), yr, off, 0, 0);
           }
         }
         if (gn_on) {   // one fp64 (sum, sumsq) pair per (z plane, tile column, cout group, wave of that plane): fixed order
@@ -368,7 +442,7 @@ static bool s1d_enabled() {   // BTS_LP_S1D=0: every stride-1 conv on the regist
   return !(e && atoi(e) == 0);
 }
 static bool s1d_plan(int N, int D, int H, int W, int Cin, int Cout, S1dPlan& pl) {
-  if (!s1d_enabled() || Cin % 16 != 0 || Cout % 4 != 0 || W < 12) return false;
+  if (!s1d_enabled() || Cin % 16 != 0 || Cout % 8 != 0 || W < 12) return false;
   const int NB = (Cout + 31) / 32, KS = Cin / 16;
   pl.mode = NB >= 2 ? 1 : 0;
   pl.txl = W >= 24 ? 5 : 4;

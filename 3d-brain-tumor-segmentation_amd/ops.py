@@ -136,6 +136,19 @@ def join_side_stream():
             torch.cuda.current_stream().wait_stream(s)
 
 
+def wait_side_stream_event(which='wgrad'):
+    """the current stream waits for what side stream `which` holds at this moment (an event recorded there now); later launches on
+    the side stream are not waited for.  A gloo group drains the producing stream on the host instead (parallel._sum_over_ranks)."""
+    if not torch.cuda.is_available():
+        return
+    s = _side.get((torch.cuda.current_device(), which))
+    if s is None:
+        return
+    ev = torch.cuda.Event()
+    ev.record(s)
+    torch.cuda.current_stream().wait_event(ev)
+
+
 def workspace(nbytes, device):
     """one grow-only scratch buffer per device AND stream; all users of a buffer are ordered on that stream"""
     key = (device.type, device.index, torch.cuda.current_stream().cuda_stream if device.type == 'cuda' else 0)

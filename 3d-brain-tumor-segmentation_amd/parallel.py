@@ -202,7 +202,10 @@ class GradSync(object):
 
     def _launch(self, bi):
         from . import ops
-        ops.join_side_stream()      # the bucket's weight gradients were enqueued on the side stream
+        # the bucket's weight gradients were enqueued on the weight-gradient stream: order this bucket behind what that stream
+        # holds NOW (an event), not behind the stream itself -- joining it would also make the main stream's data-gradient
+        # chain wait for every weight gradient queued so far, which is the overlap the side stream exists for
+        ops.wait_side_stream_event('wgrad')
         off, ln, _ = self.buckets[bi]
         m = self.model
         fresh = getattr(m, '_l2_val', None) is not None and getattr(m, '_l2_val_gen', None) == self.tape.gen

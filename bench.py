@@ -154,13 +154,34 @@ def launch_ranks(args, argv):
             env['BTS_BENCH_SHARED_DEVICES'] = str(ndev)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0)
+    # poll ALL ranks: when one dies (init failure, out of memory) the others sit in a collective forever -- end them and fail
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            failed = codes
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.2)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        raise SystemExit('rank exit codes %s (remaining ranks were terminated)' % failed)
+    reader.join(timeout=10)
+    sys.stdout.write(buf[0] if buf else '')
     sys.stdout.flush()
-    bad = [c for c in codes if c != 0]
-    if bad:
-        raise SystemExit('rank exit codes %s' % codes)
 
 
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak (v_mfma_f32_32x32x16_*)
