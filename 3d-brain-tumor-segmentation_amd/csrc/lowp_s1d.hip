@@ -19,7 +19,7 @@
 //   * a three-slot weight ring and a double-buffered halo tile are filled two stages / one k-step ahead; a stage boundary is
 //     `s_waitcnt vmcnt(N)` with N counted (never 0) + one s_barrier; a workgroup walks its items (tile x cout group, XCD-aware
 //     order) as ONE stage stream, the next item's operands in flight under the current item's output side.
-// Declines (caller runs the old kernel): W < 12, Cout % 8 != 0, offsets beyond 31 bits.
+// Declines (caller runs the old kernel): W < 12, fewer than 12288 voxels, Cout % 8 != 0, offsets beyond 31 bits.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -44,6 +44,13 @@ struct LpS1dParams {
   int N, D, H, W, ldx, ldy, Cout, KS, NB;
   int ntx, nty, ntz, ncg;
   long nitems;
+  // item order: cout group fastest, then the tiles of a block of bx x by x bz tiles (x fastest), then the blocks (x fastest), then
+  // the samples -- a block is what the 32 workgroups of an XCD hold at a time, so the halo voxels its tiles share are fetched from
+  // HBM once and found in that XCD's L2 by the neighbours.  Divisions by run-time constants as multiply-high + shift.
+  int dbg;          // timing experiments (builds with -DBTS_TIMING_EXPERIMENTS only): 1 no output stores, 2 no halo traffic, 4 no matrix instructions
+  int bx, by, bz_;
+  unsigned bvol_, nbx_, nby_, nbz_;
+  unsigned dv_mul[7], dv_sh[7];    // divisors: ncg, bx*by*bz, bx, by, ntx/bx, nty/by, ntz/bz
   int ksplit, ks_per;
   int accum;
   float* part;       // split-K: fp32 partial sums [split][voxel][NB*32]
@@ -98,29 +105,41 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
   const int cbw = MODE ? g : 0;           // cout block of this wave inside the item
 
   // ---- item walk: (n, tz, ty, tx, cg), cg fastest; XCD k walks its own contiguous eighth, its workgroups interleaved ----
-  long it, it_end, it_step;
+  unsigned it, it_end, it_step;      // (32-bit: the decode below runs once per item on the scalar unit)
   {
-    const long Gx = gridDim.x, b = blockIdx.x;
+    const unsigned Gx = gridDim.x, b = blockIdx.x, ni_ = (unsigned)p.nitems;
     if (Gx >= 8) {
-      const long xcd = b & 7, slot = b >> 3;
-      const long q = p.nitems / 8, r = p.nitems % 8;
-      const long start = xcd * q + (xcd < r ? xcd : r);
+      const unsigned xcd = b & 7, slot = b >> 3;
+      const unsigned q = ni_ / 8, r = ni_ % 8;
+      const unsigned start = xcd * q + (xcd < r ? xcd : r);
       it_end = start + q + (xcd < r ? 1 : 0);
       it_step = (Gx - xcd + 7) >> 3;
       it = start + slot;
     } else {
-      it = b; it_end = p.nitems; it_step = Gx;
+      it = b; it_end = ni_; it_step = Gx;
     }
   }
   if (it >= it_end) return;
   struct Item { int cg, n, ox0, oy0, oz0; };
-  auto decode = [&](long i) {
+  auto fdiv = [&](unsigned n, int k, unsigned d, unsigned& rem) -> unsigned {      // n < 2^31
+    const unsigned q = p.dv_mul[k] ? (__umulhi(n, p.dv_mul[k]) >> p.dv_sh[k]) : n;
+    rem = n - q * d;
+    return q;
+  };
+  auto decode = [&](unsigned i) {
     Item t;
-    t.cg = (int)(i % p.ncg); i /= p.ncg;
-    t.ox0 = (int)(i % p.ntx) * TX; i /= p.ntx;
-    t.oy0 = (int)(i % p.nty) * G::TY; i /= p.nty;
-    t.oz0 = (int)(i % p.ntz) * G::TZ;
-    t.n = (int)(i / p.ntz);
+    unsigned r, lx_, ly_, lz_, Bx, By, Bz;
+    unsigned q = fdiv(i, 0, (unsigned)p.ncg, r);
+    t.cg = (int)r;
+    unsigned blk = fdiv(q, 1, p.bvol_, r);             // r = tile inside the block
+    unsigned rz = fdiv(r, 2, (unsigned)p.bx, lx_);     // rz = ly + by * lz
+    lz_ = fdiv(rz, 3, (unsigned)p.by, ly_);
+    unsigned b2 = fdiv(blk, 4, p.nbx_, Bx);
+    unsigned b3 = fdiv(b2, 5, p.nby_, By);
+    t.n = (int)fdiv(b3, 6, p.nbz_, Bz);
+    t.ox0 = (int)(Bx * p.bx + lx_) * TX;
+    t.oy0 = (int)(By * p.by + ly_) * G::TY;
+    t.oz0 = (int)(Bz * p.bz_ + lz_) * G::TZ;
     return t;
   };
   int ks0 = 0, ks1 = p.KS;
@@ -149,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
   auto dma_item = [&](const Item& t, bool live) {   // halo origin + per-chunk offsets of the item the NEXT k-step belongs to
     const unsigned short* xorg = p.x + ((((long)t.n * p.D + (t.oz0 - 1)) * p.H + (t.oy0 - 1)) * p.W + (t.ox0 - 1)) * (long)p.ldx;
     xr = __builtin_amdgcn_make_buffer_rsrc((void*)xorg, 0, 0x7fffffff, 0x00020000);
-    const int zb = live ? t.oz0 - 1 : 0x100000;       // no next item: every voxel out of range (zeros, no traffic)
+    const int zb = (live && !(BTS_DBG(p) & 2)) ? t.oz0 - 1 : 0x100000;       // no next item: every voxel out of range (zeros, no traffic)
 #pragma unroll
     for (int r = 0; r < NH; ++r) {
       const int vx = hcrd[r] & 0xff, vy = (hcrd[r] >> 8) & 0xff, vz = hcrd[r] >> 16;
@@ -214,8 +233,13 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
   auto mm = [&](const u32x4 (&A)[3], const u32x4 (&B)[6], auto&& hook) {
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
+      if (!(BTS_DBG(p) & 4)) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) acc[v] = T::mfma(A[dy], B[v + dy], acc[v]);
+        for (int v = 0; v < 4; ++v) acc[v] = T::mfma(A[dy], B[v + dy], acc[v]);
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) asm volatile("" ::"v"(A[dy]), "v"(B[v + dy]));
+      }
       hook(dy);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -239,13 +263,9 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
   for (int r = 0; r < NW; ++r) issue_w1(r, w_soff(ci.cg, ks0, 1, true), 1);
   bool after_out = false;
   for (;;) {
-    const long nit = it + it_step;
+    const unsigned nit = it + it_step;
     const bool have_next = nit < it_end;
     const Item ni = have_next ? decode(nit) : ci;
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
     for (int ks = ks0; ks < ks1; ++ks) {
       const bool last = ks + 1 == ks1;
       const bool nlive = !last || have_next;
@@ -257,6 +277,18 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
       s1d_barrier();
       after_out = false;
       ldB(Bc, hb, I0(), I0()); ldA(Ac, I0(), I0());
+      if (ks == ks0) {     // the accumulators start at the bias (split-K partial sums: at zero; the reduce kernel adds it)
+        const float* bsh = reinterpret_cast<const float*>(lds + G::OFF_BIAS + ipar * 256) + cbw * 32 + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 bq = *reinterpret_cast<const f32x4*>(bsh + 8 * q);
+          if (p.ksplit > 1) bq = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[v][4 * q + j] = bq[j];
+        }
+      }
       if (last) dma_item(ni, have_next);
       const unsigned so0 = w_soff(ci.cg, ks, 2, true);
       ldB(Bn, hb, I0(), I1()); ldA(An, I0(), I1());
@@ -306,7 +338,6 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
     // ---- output side of `ci` ----
     {
       const int oy = ci.oy0 + y0, ox = ci.ox0 + lx, oz = ci.oz0 + zz * ZP + lz;
-      const float* bsh = reinterpret_cast<const float*>(lds + G::OFF_BIAS + ipar * 256) + cbw * 32;
       const int cb = ci.cg * CBW + cbw;
       if (p.ksplit > 1) {   // raw fp32 partial sums [split][voxel][NB*32]; bias / rounding happen in the reduce kernel
         const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(
@@ -332,34 +363,35 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
 #pragma unroll
         for (int qp = 0; qp < 2; ++qp) {
           const int co = cb * 32 + 16 * qp + 8 * h;
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(bsh + 16 * qp + 4 * h);
-          const f32x4 b1 = *reinterpret_cast<const f32x4*>(bsh + 16 * qp + 8 + 4 * h);
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             const bool ok = co < p.Cout && oz < p.D && oy + v < p.H && ox < p.W;
-            const unsigned off = ok ? (unsigned)((((oz * p.H + oy + v) * p.W + ox) * p.ldy + co) * 2) : 0x80000000u;
-            float o[8];
+            const unsigned off = (ok && !(BTS_DBG(p) & 1)) ? (unsigned)((((oz * p.H + oy + v) * p.W + ox) * p.ldy + co) * 2) : 0x80000000u;
+            float f[4], g2[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float f = acc[v][8 * qp + j] + b0[j], g2 = acc[v][8 * qp + 4 + j] + b1[j];
-              if (gn_on && ok) {      // (own values, before the exchange: the sums run over all lanes anyway)
-                gn_s += f + g2;
-                gn_q = fmaf(f, f, fmaf(g2, g2, gn_q));
-              }
-              // (inline asm, pad inside the string: with the two-result builtin hipcc 7.2 dropped the second result in one of the
-              // loop-unswitched copies of this block -- ragged launches came out wrong at couts 8k + 4..7)
-              float lo = f, hi = g2;
-              asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1\n\tv_nop" : "+v"(lo), "+v"(hi));
-              o[j] = lo;
-              o[4 + j] = hi;
-            }
-            if (p.accum) {
+            for (int j = 0; j < 4; ++j) { f[j] = acc[v][8 * qp + j]; g2[j] = acc[v][8 * qp + 4 + j]; }
+            if (p.accum) {     // old values arrive in the exchanged layout: the exchange is its own inverse
+              u32x4 e = __builtin_amdgcn_raw_buffer_load_b128(yr, off, 0, 0);
+              asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\tv_nop"
+                           : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]));
               float old[8];
-              unpack8<T>(__builtin_amdgcn_raw_buffer_load_b128(yr, off, 0, 0), old);
+              unpack8<T>(e, old);
 #pragma unroll
-              for (int j = 0; j < 8; ++j) o[j] += old[j];
+              for (int j = 0; j < 4; ++j) { f[j] += old[j]; g2[j] += old[4 + j]; }
             }
-            __builtin_amdgcn_raw_buffer_store_b128(pack8<T>(o), yr, off, 0, 0);
+            if (gn_on && ok) {      // (own values, before the exchange: the sums run over all lanes anyway)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                gn_s += f[j] + g2[j];
+                gn_q = fmaf(f[j], f[j], fmaf(g2[j], g2[j], gn_q));
+              }
+            }
+            // (inline asm, pad inside the string: with the two-result builtin hipcc 7.2 dropped the second result in one of the
+            // loop-unswitched copies of this block -- ragged launches came out wrong at couts 8k + 4..7)
+            unsigned d0 = pack2<T>(f[0], f[1]), d1 = pack2<T>(f[2], f[3]), d2 = pack2<T>(g2[0], g2[1]), d3 = pack2<T>(g2[2], g2[3]);
+            asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\tv_nop"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{d0, d1, d2, d3}, yr, off, 0, 0);
           }
         }
         if (gn_on) {   // one fp64 (sum, sumsq) pair per (z plane, tile column, cout group, wave of that plane): fixed order
@@ -435,14 +467,41 @@ int bts_lp_s1d_pack_(int dtype, const LpPackParams& p0, void* dst, hipStream_t s
 // =====================================================================================================================
 struct S1dPlan {
   int mode, txl, ntx, nty, ntz, ncg, ksplit, ks_per;
+  int bx, by, bz;
   long nitems;
 };
+// q = n / d for n < 2^31 as (n * mul) >> (32 + sh); mul == 0 means d == 1
+static void s1d_fastdiv(unsigned d, unsigned& mul, unsigned& sh) {
+  if (d <= 1) { mul = 0; sh = 0; return; }
+  int l = 0;
+  while ((1u << l) < d) ++l;                                          // l = ceil(log2 d) >= 1
+  const unsigned long long m = ((1ull << (31 + l)) + d - 1) / d;     // ceil(2^(31+l) / d) < 2^32
+  mul = (unsigned)m; sh = (unsigned)(l - 1);
+}
+// block of tiles one XCD's workgroups hold at a time: divisors of the tile grid (no partial blocks), at most `target` tiles, the
+// largest shared-halo fraction (smallest unique volume per tile)
+static void s1d_block(int ntx, int nty, int ntz, int tx, int ty, int tz, int target, int& bx, int& by, int& bz) {
+  double best = 1e30;
+  bx = by = bz = 1;
+  for (int x = 1; x <= ntx; ++x) {
+    if (ntx % x) continue;
+    for (int y = 1; y <= nty; ++y) {
+      if (nty % y) continue;
+      for (int z = 1; z <= ntz; ++z) {
+        if (ntz % z || x * y * z > target) continue;
+        const double u = (double)(x * tx + 2) * (y * ty + 2) * (z * tz + 2) / ((double)x * y * z);   // unique halo voxels per tile
+        if (u < best - 1e-9) { best = u; bx = x; by = y; bz = z; }
+      }
+    }
+  }
+}
 static bool s1d_enabled() {   // BTS_LP_S1D=0: every stride-1 conv on the register-staged kernel (A/B; read per call so one process can do both)
   const char* e = getenv("BTS_LP_S1D");
   return !(e && atoi(e) == 0);
 }
 static bool s1d_plan(int N, int D, int H, int W, int Cin, int Cout, S1dPlan& pl) {
   if (!s1d_enabled() || Cin % 16 != 0 || Cout % 8 != 0 || W < 12) return false;
+  if ((long)N * D * H * W < 12288) return false;      // (20x24x20, the deepest level of the full inference volume: the small-tile kernel wins)
   const int NB = (Cout + 31) / 32, KS = Cin / 16;
   pl.mode = NB >= 2 ? 1 : 0;
   pl.txl = W >= 24 ? 5 : 4;
@@ -451,6 +510,7 @@ static bool s1d_plan(int N, int D, int H, int W, int Cin, int Cout, S1dPlan& pl)
   pl.ncg = pl.mode ? (NB + 1) / 2 : 1;
   pl.nitems = (long)N * pl.ntz * pl.nty * pl.ntx * pl.ncg;
   if (pl.nitems > 0x7fffffffL) return false;
+  s1d_block(pl.ntx, pl.nty, pl.ntz, TX, TY, TZ, pl.ncg >= 32 ? 1 : 32 / pl.ncg, pl.bx, pl.by, pl.bz);
   // split-K: grids that cannot give most CUs an item split the input channels (>= 2 k-steps per workgroup)
   pl.ksplit = 1; pl.ks_per = KS;
   if (pl.nitems < 160 && KS >= 4) {
@@ -506,12 +566,22 @@ int bts_lp_s1d_launch_(int dtype, const void* x, const void* wp_dma, const float
   p.x = (const unsigned short*)x; p.wp = (const unsigned short*)wp_dma; p.bias = bias; p.y = (unsigned short*)y;
   p.N = N; p.D = D; p.H = H; p.W = W; p.ldx = ldx; p.ldy = ldy; p.Cout = Cout; p.KS = Cin / 16; p.NB = (Cout + 31) / 32;
   p.ntx = pl.ntx; p.nty = pl.nty; p.ntz = pl.ntz; p.ncg = pl.ncg; p.nitems = pl.nitems;
+  p.bx = pl.bx; p.by = pl.by; p.bz_ = pl.bz;
+  p.bvol_ = (unsigned)(pl.bx * pl.by * pl.bz); p.nbx_ = (unsigned)(pl.ntx / pl.bx); p.nby_ = (unsigned)(pl.nty / pl.by); p.nbz_ = (unsigned)(pl.ntz / pl.bz);
+  {
+    const unsigned dv[7] = {(unsigned)pl.ncg, p.bvol_, (unsigned)pl.bx, (unsigned)pl.by, p.nbx_, p.nby_, p.nbz_};
+    for (int k = 0; k < 7; ++k) s1d_fastdiv(dv[k], p.dv_mul[k], p.dv_sh[k]);
+  }
   p.ksplit = pl.ksplit; p.ks_per = pl.ks_per; p.accum = accum;
   p.part = reinterpret_cast<float*>(ws);
   const long nvox = (long)N * D * H * W;
   if (p.ksplit > 1 && (ws == nullptr || ws_bytes < (long)p.ksplit * nvox * p.NB * 32 * 4 || (((uintptr_t)ws) & 15))) {
     p.ksplit = 1; p.ks_per = p.KS;
   }
+  p.dbg = 0;
+#ifdef BTS_TIMING_EXPERIMENTS
+  { const char* e = getenv("BTS_S1D_DBG"); if (e) p.dbg = atoi(e); }
+#endif
   p.gnp = gnp; p.gn_G = gn_G; p.gn_zt = gn_G > 0 ? D / gn_G : 1;
   p.gn_B = gn_G > 0 ? (long)p.gn_zt * pl.nty * pl.ntx * pl.ncg * 2 : 0;
   if (gnp != nullptr && p.ksplit > 1) return BTS_ERR_UNSUPPORTED;
