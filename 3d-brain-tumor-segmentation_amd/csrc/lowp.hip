@@ -35,6 +35,10 @@ long bts_lp_s1d_image_bytes_(int K, int N);
 int bts_lp_s1d_pack_(int dtype, const LpPackParams& p, void* dst, hipStream_t stream);
 long bts_lp_s1d_workspace_(int N, int D, int H, int W, int Cin, int Cout);
 long bts_lp_s1d_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn);
+// lowp_k1.hip: streaming 1x1x1 kernel (offered first; 1 = declined); gap partials per block of bts_lp_k1_gap_block_ positions
+int bts_lp_k1_gap_block_(long npos, int Cin, int Cout);
+int bts_lp_k1_launch_(int dtype, const void* x, const void* wp, const float* bias, void* y, long npos, int Cin, int ldx, int Cout, int ldy,
+                      int accum, double* gap_part, hipStream_t stream);
 int bts_lp_s1d_launch_(int dtype, const void* x, const void* wp_dma, const float* bias, void* y, void* ws, long ws_bytes, int N, int D, int H,
                        int W, int Cin, int ldx, int Cout, int ldy, int accum, double* gnp, int gn_G, hipStream_t stream);
 
@@ -716,6 +720,10 @@ static int lp_conv_run(int geo, int dtype, const void* x, const void* wp, const 
   g.N = N; g.Di = D; g.Hi = H; g.Wi = W; g.ldx = ldx; g.ldy = ldy; g.Cout = Cout; g.KS = KS; g.NB = NB; g.accum = accum;
   g.gap_part = (geo == 0) ? gap_part : nullptr;
   auto run = [&](const LpGatherParams& q) { return dtype == LP_F16 ? lp_gather_launch<TF16>(q, stream) : lp_gather_launch<TBF16>(q, stream); };
+  if (geo == 0 && gap_part == nullptr) {     // (the fused-pool form is offered the streaming kernel by bts_lp_conv1_gap itself)
+    const int r = bts_lp_k1_launch_(dtype, x, wp, bias, y, (long)N * D * H * W, Cin, ldx, Cout, ldy, accum, nullptr, stream);
+    if (r != 1) return r;
+  }
   if (geo == 0) {
     g.Dg = g.Do = D; g.Hg = g.Ho = H; g.Wg = g.Wo = W; g.s = 1; g.os = 1; g.ooz = g.ooy = g.oox = 0; g.ntaps = 1;
     g.taps[0] = LpTap{0, 0, 0, 0};
@@ -834,6 +842,19 @@ extern "C" int bts_lp_conv1_gap(int dtype, const void* x, const void* wp, const 
   const long V = (long)D * H * W;
   if (workspace == nullptr || workspace_bytes < bts_lp_conv1_gap_workspace(N, V, Cout) || (((uintptr_t)workspace) & 15)) return BTS_ERR_WORKSPACE;
   const int NB = (Cout + 31) / 32;
+  {   // streaming kernel: column sums per block of 256 positions
+    const int kb = bts_lp_k1_gap_block_((long)N * V, Cin, Cout);
+    if (kb > 0 && V % kb == 0 && ldres == Cout) {
+      double* part = reinterpret_cast<double*>(workspace);
+      const int r = bts_lp_k1_launch_(dtype, x, wp, bias, res, (long)N * V, Cin, ldx, Cout, ldres, 0, part, stream);
+      if (r == BTS_OK) {
+        hipLaunchKernelGGL(lp_colsum_finalize_kernel, dim3((N * Cout + 3) / 4), dim3(256), 0, stream, part, gap, N, Cout, (int)(V / kb), 1.0 / (double)V);
+        BTS_LAUNCH_CHECK();
+        return BTS_OK;
+      }
+      if (r != 1) return r;
+    }
+  }
   const long ppb = 128L * lp_gather_vb((long)N * V, NB);     // positions per block
   if (V % ppb != 0 || ldres != Cout) {
     const int r = lp_conv_run(0, dtype, x, wp, bias, res, nullptr, 0, N, D, H, W, Cin, ldx, Cout, ldres, 0, stream);
