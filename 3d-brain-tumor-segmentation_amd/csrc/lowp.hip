@@ -39,6 +39,9 @@ long bts_lp_s1d_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn);
 int bts_lp_k1_gap_block_(long npos, int Cin, int Cout);
 int bts_lp_k1_launch_(int dtype, const void* x, const void* wp, const float* bias, void* y, long npos, int Cin, int ldx, int Cout, int ldy,
                       int accum, double* gap_part, hipStream_t stream);
+// lowp_up.hip: transposed form, all eight output classes in one pass (offered first; 1 = declined)
+int bts_lp_up_launch_(int dtype, const void* x, const void* wp_dma, const float* bias, void* y, int N, int D, int H, int W, int Cin, int ldx,
+                      int Cout, int ldy, int accum, hipStream_t stream);
 int bts_lp_s1d_launch_(int dtype, const void* x, const void* wp_dma, const float* bias, void* y, void* ws, long ws_bytes, int N, int D, int H,
                        int W, int Cin, int ldx, int Cout, int ldy, int accum, double* gnp, int gn_G, hipStream_t stream);
 
@@ -60,12 +63,16 @@ __global__ __launch_bounds__(256) void lp_pack_kernel(const LpPackParams p) {
 
 static int lp_ntaps(int kind) { return kind == BTS_CONV_K1 ? 1 : 27; }
 
+static bool lp_has_dma_part(int kind, int role) {
+  return kind == BTS_CONV_K3S1 || (kind == BTS_CONV_K3S2T && role == BTS_ROLE_FWD) || (kind == BTS_CONV_K3S2 && role == BTS_ROLE_BWD_DATA);
+}
 extern "C" long bts_lp_packed_bytes(int kind, int role, int Cin_slab, int Cout) {
   if (kind < 0 || kind > 3 || role < 0 || role > 1 || Cin_slab <= 0 || Cout <= 0) return -1;
   const int K = role == BTS_ROLE_FWD ? Cin_slab : Cout, N = role == BTS_ROLE_FWD ? Cout : Cin_slab;
   const long first = (long)lp_ntaps(kind) * ((K + 15) / 16) * ((N + 31) / 32) * 512 * 2;
-  // stride-1 3x3x3 images carry a second part, the same weights in the stage order of the LDS-DMA kernel (lowp_s1d.hip)
-  return kind == BTS_CONV_K3S1 ? first + bts_lp_s1d_image_bytes_(K, N) : first;
+  // stride-1 3x3x3 images -- and the two images the transposed form runs on -- carry a second part, the same weights in the stage
+  // order of the LDS-DMA kernels (lowp_s1d.hip, lowp_up.hip)
+  return lp_has_dma_part(kind, role) ? first + bts_lp_s1d_image_bytes_(K, N) : first;
 }
 // byte offset of the DMA part inside a K3S1 image with K contraction channels and N output columns
 static long lp_s1d_part_offset(int K, int N) { return 27L * ((K + 15) / 16) * ((N + 31) / 32) * 1024; }
@@ -96,7 +103,7 @@ extern "C" int bts_lp_pack(int kind, int role, int dtype, const float* w, void* 
   if (dtype == LP_F16) hipLaunchKernelGGL(lp_pack_kernel<TF16>, dim3(blocks), dim3(256), 0, stream, p);
   else hipLaunchKernelGGL(lp_pack_kernel<TBF16>, dim3(blocks), dim3(256), 0, stream, p);
   BTS_LAUNCH_CHECK();
-  if (kind == BTS_CONV_K3S1) return bts_lp_s1d_pack_(dtype, p, reinterpret_cast<char*>(wp) + lp_s1d_part_offset(p.K, p.N), stream);
+  if (lp_has_dma_part(kind, role)) return bts_lp_s1d_pack_(dtype, p, reinterpret_cast<char*>(wp) + lp_s1d_part_offset(p.K, p.N), stream);
   return BTS_OK;
 }
 
@@ -738,6 +745,11 @@ static int lp_conv_run(int geo, int dtype, const void* x, const void* wp, const 
     return run(g);
   }
   if (geo == 3) {  // y[2i+k] += x[i] w[k], cropped to [0, 2n): 8 output-parity classes, every output written once
+    {
+      const int r = bts_lp_up_launch_(dtype, x, reinterpret_cast<const char*>(wp) + lp_s1d_part_offset(Cin, Cout), bias, y, N, D, H, W, Cin, ldx,
+                                      Cout, ldy, accum, stream);
+      if (r != 1) return r;
+    }
     g.Do = 2 * D; g.Ho = 2 * H; g.Wo = 2 * W; g.Dg = D; g.Hg = H; g.Wg = W; g.s = 1; g.os = 2;
     for (int cls = 0; cls < 8; ++cls) {
       const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
