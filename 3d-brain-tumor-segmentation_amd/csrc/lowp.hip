@@ -1825,6 +1825,23 @@ __global__ __launch_bounds__(256) void lp_wgrad_finalize_kernel(const LpWfParams
     }
   }
 }
+int bts_lp_wgrad_finalize_(const float* part, float* dw, int nwg, int ncp, int ncqg, int nslot, int ntaps, int NQ, int Cp, int Cq, int Cin_ref,
+                           int dup_start, int dup_shift, int accum, hipStream_t stream) {
+  LpWfParams f;
+  f.part = part; f.dw = dw; f.nwg = nwg; f.ncp = ncp; f.ncqg = ncqg; f.nslot = nslot; f.ntaps = ntaps; f.NQ = NQ;
+  f.Cp = Cp; f.Cq = Cq; f.Cin_ref = Cin_ref; f.dup_start = dup_start; f.dup_shift = dup_shift; f.accum = accum;
+  const long total = (long)ntaps * Cp * Cq;
+  long blocks = (total + 31) / 32;
+  if (blocks > 8192) blocks = 8192;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(lp_wgrad_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, f);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+// lowp_wgs.hip: weight gradient of the strided convolutions (P on the fine grid, Q on the coarse one)
+long bts_lp_wgs_workspace_(int N, int Dc, int Hc, int Wc, int Cp, int Cq);
+int bts_lp_wgs_launch_(int dtype, const void* P, const void* Q, float* dw, void* ws, long ws_bytes, int N, int Df, int Hf, int Wf, int Dc, int Hc,
+                       int Wc, int Cp, int ldp, int Cq, int ldq, int accum, hipStream_t stream);
 // db[k] (+)= sum_n colsum[n][k]
 __global__ void lp_bias_grad_kernel(const float* cs, float* db, int N, int C, int accum) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1843,7 +1860,18 @@ static void lp_wg_plan(int kind, int N, int D, int H, int W, int Cp, int Cq, int
   if (cap < 1) cap = 1;
   nwg = (int)(ntiles < cap ? ntiles : cap);
 }
+// strided kinds: (P channels, Q channels, coarse dims, voxels dy lives on) of a call with forward-input dims (D,H,W)
+static void lp_wgs_roles(int kind, int D, int H, int W, int Cin, int Cout, int& Cp, int& Cq, int& Dc, int& Hc, int& Wc, long& Vdy) {
+  if (kind == BTS_CONV_K3S2) { Cp = Cin; Cq = Cout; Dc = D / 2; Hc = H / 2; Wc = W / 2; Vdy = (long)Dc * Hc * Wc; }
+  else { Cp = Cout; Cq = Cin; Dc = D; Hc = H; Wc = W; Vdy = 8L * D * H * W; }
+}
 extern "C" long bts_lp_conv3d_bwd_weight_workspace(int kind, int N, int D, int H, int W, int Cin, int Cout) {
+  if (kind == BTS_CONV_K3S2 || kind == BTS_CONV_K3S2T) {
+    int Cp, Cq, Dc, Hc, Wc; long Vdy;
+    lp_wgs_roles(kind, D, H, W, Cin, Cout, Cp, Cq, Dc, Hc, Wc, Vdy);
+    const long part = ((bts_lp_wgs_workspace_(N, Dc, Hc, Wc, Cp, Cq) + 255) & ~255L);
+    return part + (long)N * ((Cout + 7) / 8 * 8) * 4 + 256 + bts_lp_colsum_workspace(N, Vdy, (Cout + 7) / 8 * 8) + 256;
+  }
   if (kind != BTS_CONV_K3S1 && kind != BTS_CONV_K1) return -1;
   int nq, nwg, ncp, ncqg; long ntiles;
   lp_wg_plan(kind, N, D, H, W, Cin, Cout, nq, nwg, ntiles, ncp, ncqg);
@@ -1856,6 +1884,35 @@ extern "C" int bts_lp_conv3d_bwd_weight(int kind, int dtype, const void* x, cons
                                         long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int lddy, int dup_start,
                                         int dup_shift, int accumulate, hipStream_t stream) {
   if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  if (kind == BTS_CONV_K3S2 || kind == BTS_CONV_K3S2T) {
+    // strided kinds (lowp_wgs.hip): x lives on the forward-input grid (D,H,W), dy on the half grid (stride-2 conv; TF 'same' with even
+    // sizes pads (0,1): input 2o + t) or the doubled grid (transposed conv: output 2i + k)
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin % 8 != 0 || Cout % 8 != 0 || ldx % 8 != 0 || lddy % 8 != 0) return BTS_ERR_SHAPE;
+    if (kind == BTS_CONV_K3S2 && ((D | H | W) & 1)) return BTS_ERR_UNSUPPORTED;
+    if (dup_shift != 0) return BTS_ERR_UNSUPPORTED;
+    if ((((uintptr_t)x) & 15) || (((uintptr_t)dy) & 15) || (((uintptr_t)workspace) & 15)) return BTS_ERR_ALIGN;
+    if (workspace_bytes < bts_lp_conv3d_bwd_weight_workspace(kind, N, D, H, W, Cin, Cout)) return BTS_ERR_WORKSPACE;
+    int Cp, Cq, Dc, Hc, Wc; long Vdy;
+    lp_wgs_roles(kind, D, H, W, Cin, Cout, Cp, Cq, Dc, Hc, Wc, Vdy);
+    const long part = ((bts_lp_wgs_workspace_(N, Dc, Hc, Wc, Cp, Cq) + 255) & ~255L);
+    int r;
+    if (kind == BTS_CONV_K3S2)
+      r = bts_lp_wgs_launch_(dtype, x, dy, dw, workspace, part, N, D, H, W, Dc, Hc, Wc, Cp, ldx, Cq, lddy, accumulate, stream);
+    else
+      r = bts_lp_wgs_launch_(dtype, dy, x, dw, workspace, part, N, 2 * D, 2 * H, 2 * W, Dc, Hc, Wc, Cp, lddy, Cq, ldx, accumulate, stream);
+    if (r != BTS_OK) return r;
+    if (db != nullptr) {
+      if (lddy != Cout) return BTS_ERR_UNSUPPORTED;
+      char* wsb = reinterpret_cast<char*>(workspace) + part;
+      float* cs = reinterpret_cast<float*>(wsb);
+      void* cws = wsb + (((long)N * Cout * 4 + 255) & ~255L);
+      r = bts_lp_colsum(dtype, dy, cs, cws, bts_lp_colsum_workspace(N, Vdy, Cout), N, Vdy, Cout, 1.0f, stream);
+      if (r != BTS_OK) return r;
+      hipLaunchKernelGGL(lp_bias_grad_kernel, dim3((Cout + 255) / 256), dim3(256), 0, stream, cs, db, N, Cout, accumulate);
+      BTS_LAUNCH_CHECK();
+    }
+    return BTS_OK;
+  }
   if (kind != BTS_CONV_K3S1 && kind != BTS_CONV_K1) return BTS_ERR_UNSUPPORTED;
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin % 8 != 0 || Cout % 8 != 0 || ldx % 8 != 0 || lddy % 8 != 0) return BTS_ERR_SHAPE;
   if ((((uintptr_t)x) & 15) || (((uintptr_t)dy) & 15) || (((uintptr_t)workspace) & 15)) return BTS_ERR_ALIGN;

@@ -79,17 +79,22 @@ def conv(kind, code, tdt, x, wp, bias, cout, out=None):
 
 
 def wgrad_supported(kind, cin, cout):
-    """shapes the 16-bit weight-gradient kernel takes (stride-1 3x3x3 / 1x1x1, channel counts in whole 16-byte chunks)"""
+    """shapes the 16-bit weight-gradient kernels take (channel counts in whole 16-byte chunks; the stride-1 3x3x3 / 1x1x1 kernel also
+    wants a power-of-two number of them per cout block)"""
+    if kind in (ops.K3S2, ops.K3S2T):
+        return cin % 8 == 0 and cout % 8 == 0
     return kind in (ops.K3S1, ops.K1) and cin % 8 == 0 and cout % 8 == 0 and cout <= 256 and ((cout // 8) & (cout // 8 - 1)) == 0
 
 
 def conv_bwd_weight(kind, code, x, dy, dw, db, dup_start=0, dup_shift=0, accumulate=True):
-    """16-bit weight gradient of a stride-1 3x3x3 / 1x1x1 conv -> True, or False when the shape is outside the kernel's reach (the
-    caller then runs the fp32 kernel on widened copies)"""
+    """16-bit weight gradient of a conv (stride-1 3x3x3, 1x1x1; stride-2 3x3x3 and its transposed sibling through the transposing-read
+    kernel of csrc/lowp_wgs.hip: x on the forward-input grid, dy on the half / doubled grid) -> True, or False when the shape is outside
+    the kernels' reach (the caller then runs the fp32 kernel on widened copies)"""
     n, d, h, w, cin = x.shape
     cout = dy.shape[-1]
-    if kind not in (ops.K3S1, ops.K1) or cin % 8 or cout % 8 or cout > 256 or (cout // 8) & (cout // 8 - 1) or \
-            (db is not None and not dy.is_contiguous()):
+    if not wgrad_supported(kind, cin, cout) or (db is not None and not dy.is_contiguous()):
+        return False
+    if kind == ops.K3S2 and ((d | h | w) & 1):
         return False
     nb = lib().query('bts_lp_conv3d_bwd_weight_workspace', kind, n, d, h, w, cin, cout)
     ws = ops.workspace(nb, x.device)

@@ -185,17 +185,27 @@ class LowPrecisionTrainer(object):
         data gradient into dx (None: not needed).  cin_live: real input channels when the input was zero-padded to 16"""
         lay, kind = s['lay'], s['kind']
         nrm = lay.norm
-        dc16, dc = self._gn_bwd(nrm, s['c'], dy, s['m'], s['r'])
         x = s['x'] if cin_live is None else s['x'][..., :cin_live]
-        x32 = self._f32(x)
+        cout = s['c'].shape[-1]
+        lp16 = cin_live is None and cout % 16 == 0 and lowp.wgrad_supported(kind, x.shape[-1], cout) and \
+            not (kind == ops.K3S2 and any(v & 1 for v in x.shape[1:4]))
+        dc16, dc = self._gn_bwd(nrm, s['c'], dy, s['m'], s['r'], want_f32=not lp16)
+        if lp16 and dc16.is_contiguous():
+            # 16-bit operands straight into the transposing-read weight-gradient kernel (no widened copies)
+            self._wg((x, dc16), lambda: lowp.conv_bwd_weight(kind, self.code, x, dc16, self._gslot(lay.conv_k), self._gslot(lay.conv_b),
+                                                             accumulate=True))
+        else:
+            x32 = self._f32(x)
+            if dc is None:
+                dc = self._f32(dc16)
 
-        def wgrads():
-            if kind == ops.K3S2T:
-                ops.conv_bwd_weight(kind, x32, dc, self._gslot(lay.conv_k), None, accumulate=True)
-                ops.colsum(dc, sum_over_n=True, out=self._gslot(lay.conv_b), accumulate=True)
-            else:
-                ops.conv_bwd_weight(kind, x32, dc, self._gslot(lay.conv_k), self._gslot(lay.conv_b), accumulate=True)
-        self._wg((x32, dc), wgrads)
+            def wgrads():
+                if kind == ops.K3S2T:
+                    ops.conv_bwd_weight(kind, x32, dc, self._gslot(lay.conv_k), None, accumulate=True)
+                    ops.colsum(dc, sum_over_n=True, out=self._gslot(lay.conv_b), accumulate=True)
+                else:
+                    ops.conv_bwd_weight(kind, x32, dc, self._gslot(lay.conv_k), self._gslot(lay.conv_b), accumulate=True)
+            self._wg((x32, dc), wgrads)
         if dx is not None:
             wpb = self._pk((id(lay), 'b'), kind, lay.conv_k, lay.cin, lay.filters, role=ops.ROLE_BWD)
             conv_bwd_data(kind, self.code, dc16, wpb, dx, accumulate)

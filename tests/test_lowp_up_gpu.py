@@ -98,3 +98,52 @@ def test_stride2_conv_data_gradient(dtype, accumulate):
     err = (dx.double().cpu() - ref.detach()).abs()
     assert float((err / bound).max()) <= 1.0
     assert bool((slab[..., :16] == 3.0).all()) and bool((slab[..., 16 + cin:] == 3.0).all())
+
+
+WG_CASES = [
+    # kind, n, forward-input (D,H,W), Cin, Cout, slab_x
+    ('K3S2', 2, (8, 12, 36), 32, 64, True),      # stride-2 conv: P = x (fine, slab view), Q = dy (coarse); ragged coarse tiles
+    ('K3S2', 1, (16, 16, 32), 64, 128, False),   # two cp blocks, two cq groups of 64
+    ('K3S2T', 2, (6, 8, 20), 64, 32, False),     # transposed conv: P = dy (fine), Q = x (coarse): dW (kd,kh,kw,Cout,Cin)
+    ('K3S2T', 1, (8, 8, 16), 128, 64, True),
+    ('K3S2', 1, (4, 6, 34), 16, 32, False),      # half-empty P channel block (16 of 32), odd coarse width
+]
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('accumulate', [False, True])
+@pytest.mark.parametrize('case', WG_CASES, ids=lambda c: '%s-n%d-%dx%dx%d-%d-%d' % (c[0], c[1], *c[2], c[3], c[4]))
+def test_strided_weight_gradients(case, accumulate, dtype):
+    """dW, db of the stride-2 conv and the transposed conv from 16-bit operands (csrc/lowp_wgs.hip: transposing LDS reads) against torch
+    autograd of the oracle's op on the same rounded operands in fp64; bound 8 * 2^-24 * sum|a_i b_i| (fp32 sums of exact products)"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    name, n, (d, h, w), cin, cout, slab_x = case
+    kind = getattr(ops, name)
+    code, tdt = lowp.DTYPES[dtype]
+    g = torch.Generator().manual_seed(hash((name, d, h, w, cin, cout)) % 10000)
+    x = torch.randn((n, d, h, w, cin), generator=g)
+    oshape = (n, d // 2, h // 2, w // 2, cout) if kind == ops.K3S2 else (n, 2 * d, 2 * h, 2 * w, cout)
+    dy = torch.randn(oshape, generator=g)
+    wshape = (3, 3, 3, cin, cout) if kind == ops.K3S2 else (3, 3, 3, cout, cin)
+    xr, dyr = _round(x, tdt), _round(dy, tdt)
+    fwd = (lambda xx, ww, bb: R.conv3d(xx, ww, bb, stride=2)) if kind == ops.K3S2 else R.conv3d_transpose
+    w0 = torch.zeros(wshape, dtype=torch.float64, requires_grad=True)
+    b0 = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    (fwd(xr, w0, b0) * dyr).sum().backward()
+    wa = torch.zeros(wshape, dtype=torch.float64, requires_grad=True)
+    (fwd(xr.abs(), wa, None) * dyr.abs()).sum().backward()
+    old_w = torch.randn(wshape, generator=g)
+    old_b = torch.randn(cout, generator=g)
+    ref_w = w0.grad + (old_w.double() if accumulate else 0)
+    ref_b = b0.grad + (old_b.double() if accumulate else 0)
+    ldx = cin + 16 if slab_x else cin
+    xin = torch.zeros((n, d, h, w, ldx), dtype=tdt, device=DEV)
+    c0 = 16 if slab_x else 0
+    xin[..., c0:c0 + cin] = x.to(tdt).to(DEV)
+    dw, db = old_w.clone().to(DEV), old_b.clone().to(DEV)
+    ok, syms = _records(lambda: lowp.conv_bwd_weight(kind, code, xin[..., c0:c0 + cin], dy.to(tdt).to(DEV), dw, db, accumulate=accumulate))
+    assert ok and 'lp_wgs_kernel' in syms, syms
+    bound_w = 8 * 2.0 ** -24 * wa.grad + 2.0 ** -22 * ref_w.abs() + 1e-30        # (+ the final fp32 rounding of dw (+ old))
+    assert float(((dw.double().cpu() - ref_w).abs() / bound_w).max()) <= 1.0
+    assert float((db.double().cpu() - ref_b).abs().max()) <= 1e-4 * max(1.0, float(ref_b.abs().max()))
