@@ -1228,6 +1228,32 @@ extern "C" int bts_lp_head(int dtype, const void* x, const float* w, const float
   return BTS_OK;
 }
 
+// Bias gradient of the conv that produced the tensor a backward apply pass writes (its dy): db[c] = sum over voxels and samples.  The
+// apply kernels walk octets with a stride that is a multiple of the channel count, so a thread's channel octet never changes: it keeps
+// eight running sums, the block adds the threads of equal octet in LDS (fixed order) and leaves one fp64 partial row per block;
+// lp_dbias_finalize_kernel adds the rows in block order.  (Round 2 read every such dy a second time: bts_lp_colsum, 4.5 ms per step.)
+__device__ __forceinline__ void lp_dbias_block(const float (&cs)[8], int oct, int noct, double* part_row, float* sh /* [256][8] */) {
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sh[threadIdx.x * 8 + e] = cs[e];
+  __syncthreads();
+  if ((int)threadIdx.x < noct * 8) {
+    const int o = threadIdx.x >> 3, e = threadIdx.x & 7;
+    double s = 0.0;
+    for (int t = o; t < 256; t += noct) s += (double)sh[t * 8 + e];     // threads t = o (mod noct) hold octet o
+    part_row[o * 8 + e] = s;
+  }
+  (void)oct;
+}
+__global__ __launch_bounds__(256) void lp_dbias_finalize_kernel(const double* part, float* db, int nblocks, int C, int accum) {
+  // one workgroup per channel: threads split the block rows, fixed-order combine
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) s += part[(long)b * C + c];
+  s = block_sum_f64(s, sh);
+  if (threadIdx.x == 0) db[c] = accum ? db[c] + (float)s : (float)s;
+}
 // =====================================================================================================================
 // GroupNormalization backward on 16-bit tensors (channels_last = slab semantics; group_norm.py:83-124 under TF autodiff).
 // With xh = (x - mean) * rstd, y = gamma_i xh + beta_i (i = g*cg + c mod cg), dyE = dy * [y > 0] (fused ReLU):
@@ -1345,7 +1371,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void lp_gn_bwd_apply_kernel(const unsigned short* x, const unsigned short* dy, unsigned short* dx, float* dx32,
                                                               const float* gamma, const float* beta, const float* mean, const float* rstd,
                                                               const float* c1, const float* c2, long total8, long E, long L, int C, int G,
-                                                              int cg, int lddy, int relu) {
+                                                              int cg, int lddy, int relu, double* dbias_part) {
+  __shared__ float dbsh[256 * 8];
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (long f = blockIdx.x * 256L + threadIdx.x; f < total8; f += (long)gridDim.x * 256) {
     const long i = f * 8;
     const long n = i / E;
@@ -1366,6 +1394,7 @@ __global__ __launch_bounds__(256) void lp_gn_bwd_apply_kernel(const unsigned sho
       const float ga = gamma[idx];
       if (relu && !(xh * ga + beta[idx] > 0.f)) de = 0.f;
       o[e] = (de * ga - k1 - xh * k2) * rs;
+      cs[e] += o[e];
     }
     *reinterpret_cast<u32x4*>(dx + i) = pack8<T>(o);
     if (dx32 != nullptr) {
@@ -1373,6 +1402,8 @@ __global__ __launch_bounds__(256) void lp_gn_bwd_apply_kernel(const unsigned sho
       *reinterpret_cast<f32x4*>(dx32 + i + 4) = f32x4{o[4], o[5], o[6], o[7]};
     }
   }
+  if (dbias_part != nullptr)     // (launch-uniform; 2048 % C == 0: thread t always holds octet t mod C/8)
+    lp_dbias_block(cs, 0, C / 8, dbias_part + (long)blockIdx.x * C, dbsh);
 }
 static int lp_gnb_blocks(long L) {
   long b = L / (2048 * 16);
@@ -1383,12 +1414,12 @@ static int lp_gnb_blocks(long L) {
 extern "C" long bts_lp_gn_bwd_workspace(int N, long V, int C, int G) {
   if (N <= 0 || V <= 0 || C <= 0 || G <= 0 || C % G != 0) return -1;
   const long L = V * C / G;
-  return (long)N * G * lp_gnb_blocks(L) * (C / G) * 2 * 8 + (long)N * G * 2 * 4 + 64;
+  return (long)N * G * lp_gnb_blocks(L) * (C / G) * 2 * 8 + (long)N * G * 2 * 4 + 64 + 16384L * C * 8 + 64;   // (+ bias-gradient rows)
 }
 // x dense (N,V,C) in the storage type; dy rows of stride lddy; dx dense in the storage type, dx32 (may be NULL) the same values in fp32
 extern "C" int bts_lp_gn_bwd(int dtype, const void* x, const void* dy, void* dx, float* dx32, const float* gamma, const float* beta,
                              const float* mean, const float* rstd, float* dgamma, float* dbeta, void* workspace, long workspace_bytes, int N,
-                             long V, int C, int lddy, int G, int relu, int accumulate_params, hipStream_t stream) {
+                             long V, int C, int lddy, int G, int relu, int accumulate_params, float* dbias, hipStream_t stream) {
   if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
   if (N <= 0 || V <= 0 || C < G || C % G != 0 || C % 8 != 0 || C > 256 || (C & (C - 1)) != 0 || lddy % 8 != 0 || lddy < C) return BTS_ERR_SHAPE;
   const long E = V * C, L = E / G;
@@ -1401,6 +1432,7 @@ extern "C" int bts_lp_gn_bwd(int dtype, const void* x, const void* dy, void* dx,
   double* partial = reinterpret_cast<double*>(workspace);
   float* c1 = reinterpret_cast<float*>(partial + (long)N * G * B * cg * 2);
   float* c2 = c1 + (long)N * G;
+  double* dbp = dbias ? reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(c2 + (long)N * G) + 63) & ~(uintptr_t)63) : nullptr;
   (void)hipGetLastError();
   if (dtype == LP_F16) hipLaunchKernelGGL(lp_gn_bwd_reduce_kernel<TF16>, dim3(B, N * G), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)dy, gamma, beta, mean, rstd, partial, E, L, span, C, G, cg, lddy, relu);
   else hipLaunchKernelGGL(lp_gn_bwd_reduce_kernel<TBF16>, dim3(B, N * G), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)dy, gamma, beta, mean, rstd, partial, E, L, span, C, G, cg, lddy, relu);
@@ -1410,9 +1442,13 @@ extern "C" int bts_lp_gn_bwd(int dtype, const void* x, const void* dy, void* dx,
   const long total8 = (long)N * E / 8;
   long blocks = (total8 + 255) / 256;
   if (blocks > 16384) blocks = 16384;
-  if (dtype == LP_F16) hipLaunchKernelGGL(lp_gn_bwd_apply_kernel<TF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)dy, (unsigned short*)dx, dx32, gamma, beta, mean, rstd, c1, c2, total8, E, L, C, G, cg, lddy, relu);
-  else hipLaunchKernelGGL(lp_gn_bwd_apply_kernel<TBF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)dy, (unsigned short*)dx, dx32, gamma, beta, mean, rstd, c1, c2, total8, E, L, C, G, cg, lddy, relu);
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_gn_bwd_apply_kernel<TF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)dy, (unsigned short*)dx, dx32, gamma, beta, mean, rstd, c1, c2, total8, E, L, C, G, cg, lddy, relu, dbp);
+  else hipLaunchKernelGGL(lp_gn_bwd_apply_kernel<TBF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)dy, (unsigned short*)dx, dx32, gamma, beta, mean, rstd, c1, c2, total8, E, L, C, G, cg, lddy, relu, dbp);
   BTS_LAUNCH_CHECK();
+  if (dbias != nullptr) {      // bias gradient of the conv whose output this GroupNorm normalised (dx IS that conv's dy)
+    hipLaunchKernelGGL(lp_dbias_finalize_kernel, dim3(C), dim3(256), 0, stream, dbp, dbias, (int)blocks, C, accumulate_params);
+    BTS_LAUNCH_CHECK();
+  }
   return BTS_OK;
 }
 
@@ -2029,7 +2065,9 @@ __global__ __launch_bounds__(256) void lp_se_bwd_reduce_kernel(const unsigned sh
 template <typename T>
 __global__ __launch_bounds__(256) void lp_se_bwd_apply_kernel(const unsigned short* dout, const float* sp, const float* ds, const float* ch,
                                                               const float* wsp, const float* dgap, unsigned short* dres, long NV, long V, int F,
-                                                              int lddo) {
+                                                              int lddo, double* dbias_part) {
+  __shared__ float dbsh[256 * 8];
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int F8 = F >> 3;
   const long total = NV * F8;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -2040,9 +2078,11 @@ __global__ __launch_bounds__(256) void lp_se_bwd_apply_kernel(const unsigned sho
     unpack8<T>(*reinterpret_cast<const u32x4*>(dout + v * lddo + c), d);
     const float s = sp[v], dsv = ds[v];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = fmaf(d[e], s + ch[n * F + c + e], fmaf(dsv, wsp[c + e], dgap[n * F + c + e]));
+    for (int e = 0; e < 8; ++e) { o[e] = fmaf(d[e], s + ch[n * F + c + e], fmaf(dsv, wsp[c + e], dgap[n * F + c + e])); cs[e] += o[e]; }
     *reinterpret_cast<u32x4*>(dres + v * F + c) = pack8<T>(o);
   }
+  if (dbias_part != nullptr)     // (launch-uniform; 256 % (F/8) == 0: thread t always holds octet t mod F/8)
+    lp_dbias_block(cs, 0, F8, dbias_part + (long)blockIdx.x * F, dbsh);
 }
 static int lp_se_blocks(long V, int N, int F, long* vspan) {
   const int vpb = 256 / (F / 8);
@@ -2057,14 +2097,14 @@ extern "C" long bts_lp_se_bwd_workspace(int N, long V, int F, int R) {
   if (N <= 0 || V <= 0 || F < 8 || R <= 0) return -1;
   long vspan;
   const int B = lp_se_blocks(V, N, F, &vspan);
-  return (long)N * B * F * 2 * 8 + ((long)N * F * 3 + (long)N * R) * 8 + 128;
+  return (long)N * B * F * 2 * 8 + ((long)N * F * 3 + (long)N * R) * 8 + 128 + 16384L * F * 8 + 64;   // (+ bias-gradient rows)
 }
 // dout rows of stride lddo, res dense, both in the storage type; sp fp32 [N*V] (bts_lp_block_epilogue's sp_out); gap / h / ch from the forward.
 // Outputs: dres dense in the storage type, ds [N*V] and dgap [N*F] fp32 scratch, parameter gradients fp32 (+= when accumulate_params).
 extern "C" int bts_lp_se_bwd(int dtype, const void* dout, const void* res, const float* sp, const float* gap, const float* h, const float* ch,
                              const float* w1, const float* w2, const float* wsp, void* dres, float* ds, float* dgap, float* dw1, float* dw2,
                              float* dwsp, void* workspace, long workspace_bytes, int N, long V, int F, int R, int lddo, int accumulate_params,
-                             hipStream_t stream) {
+                             float* dbias, hipStream_t stream) {
   if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
   if (N <= 0 || V <= 0 || F < 8 || (F & (F - 1)) || F > 256 || lddo < F || lddo % 8) return BTS_ERR_SHAPE;
   if ((((uintptr_t)dout) & 15) || (((uintptr_t)res) & 15) || (((uintptr_t)dres) & 15)) return BTS_ERR_ALIGN;
@@ -2074,6 +2114,7 @@ extern "C" int bts_lp_se_bwd(int dtype, const void* dout, const void* res, const
   double* partial = reinterpret_cast<double*>(workspace);
   double* red = partial + (long)N * B * F * 2;
   double* scratch = red + (long)N * F * 2;
+  double* dbp = dbias ? reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(scratch + (long)N * F + (long)N * R) + 63) & ~(uintptr_t)63) : nullptr;
   (void)hipGetLastError();
   if (dtype == LP_F16) hipLaunchKernelGGL(lp_se_bwd_reduce_kernel<TF16>, dim3(B, N), dim3(256), 0, stream, (const unsigned short*)dout, (const unsigned short*)res, sp, ds, partial, V, F, lddo, vspan);
   else hipLaunchKernelGGL(lp_se_bwd_reduce_kernel<TBF16>, dim3(B, N), dim3(256), 0, stream, (const unsigned short*)dout, (const unsigned short*)res, sp, ds, partial, V, F, lddo, vspan);
@@ -2083,8 +2124,12 @@ extern "C" int bts_lp_se_bwd(int dtype, const void* dout, const void* res, const
   const long total = (long)N * V * (F / 8);
   long blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
-  if (dtype == LP_F16) hipLaunchKernelGGL(lp_se_bwd_apply_kernel<TF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)dout, sp, ds, ch, wsp, dgap, (unsigned short*)dres, (long)N * V, V, F, lddo);
-  else hipLaunchKernelGGL(lp_se_bwd_apply_kernel<TBF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)dout, sp, ds, ch, wsp, dgap, (unsigned short*)dres, (long)N * V, V, F, lddo);
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_se_bwd_apply_kernel<TF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)dout, sp, ds, ch, wsp, dgap, (unsigned short*)dres, (long)N * V, V, F, lddo, dbp);
+  else hipLaunchKernelGGL(lp_se_bwd_apply_kernel<TBF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)dout, sp, ds, ch, wsp, dgap, (unsigned short*)dres, (long)N * V, V, F, lddo, dbp);
   BTS_LAUNCH_CHECK();
+  if (dbias != nullptr) {      // bias gradient of the block's 1x1x1 shortcut conv (dres IS its dy)
+    hipLaunchKernelGGL(lp_dbias_finalize_kernel, dim3(F), dim3(256), 0, stream, dbp, dbias, (int)blocks, F, accumulate_params);
+    BTS_LAUNCH_CHECK();
+  }
   return BTS_OK;
 }

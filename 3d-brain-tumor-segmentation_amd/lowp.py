@@ -160,9 +160,10 @@ def gn_apply(code, x, gamma, beta, mean, rstd, groups, mode, relu, out=None):
     return out
 
 
-def gn_bwd(code, tdt, x, dy, gamma, beta, mean, rstd, dgamma, dbeta, groups, relu, want_f32=True):
+def gn_bwd(code, tdt, x, dy, gamma, beta, mean, rstd, dgamma, dbeta, groups, relu, want_f32=True, dbias=None):
     """slab-mode GroupNorm backward on 16-bit tensors -> (dx in the storage type, dx in fp32 or None); None if the shape is outside the
-    kernel's tiling (the caller then runs the fp32 kernel on widened copies)"""
+    kernel's tiling (the caller then runs the fp32 kernel on widened copies).  dbias: fp32 view that receives (+=) the column sums of
+    dx -- the bias gradient of the conv that produced x -- from the same pass"""
     n, c = x.shape[0], x.shape[4]
     v = x.shape[1] * x.shape[2] * x.shape[3]
     L = v * c // groups
@@ -173,7 +174,8 @@ def gn_bwd(code, tdt, x, dy, gamma, beta, mean, rstd, dgamma, dbeta, groups, rel
     dx = torch.empty_like(x)
     dx32 = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_f32 else None
     lib().call('bts_lp_gn_bwd', code, _p(x), _p(dy), _p(dx), _p(dx32) if dx32 is not None else None, _p(gamma), _p(beta), _p(mean), _p(rstd),
-               _p(dgamma), _p(dbeta), _p(ws), nb, n, v, c, _ld(dy), groups, 1 if relu else 0, 1, _stream())
+               _p(dgamma), _p(dbeta), _p(ws), nb, n, v, c, _ld(dy), groups, 1 if relu else 0, 1, _p(dbias) if dbias is not None else None,
+               _stream())
     return dx, dx32
 
 
@@ -207,8 +209,9 @@ def block_epilogue(code, res, c2, out, wsp, ch, gamma, beta, mean, rstd, groups,
     return out
 
 
-def se_bwd(code, tdt, dout, res, sp, gap, h, ch, w1, w2, wsp, dw1, dw2, dwsp):
-    """gate backward on 16-bit tensors -> dres (storage type, dense); parameter gradients accumulate"""
+def se_bwd(code, tdt, dout, res, sp, gap, h, ch, w1, w2, wsp, dw1, dw2, dwsp, dbias=None):
+    """gate backward on 16-bit tensors -> dres (storage type, dense); parameter gradients accumulate; dbias: fp32 view that receives
+    (+=) the column sums of dres, the shortcut conv's bias gradient"""
     n, f = res.shape[0], res.shape[4]
     v = res.shape[1] * res.shape[2] * res.shape[3]
     r = w1.shape[1]
@@ -218,7 +221,7 @@ def se_bwd(code, tdt, dout, res, sp, gap, h, ch, w1, w2, wsp, dw1, dw2, dwsp):
     ds = torch.empty(n * v, dtype=torch.float32, device=res.device)
     dgap = torch.empty((n, f), dtype=torch.float32, device=res.device)
     lib().call('bts_lp_se_bwd', code, _p(dout), _p(res), _p(sp), _p(gap), _p(h), _p(ch), _p(w1), _p(w2), _p(wsp), _p(dres), _p(ds), _p(dgap),
-               _p(dw1), _p(dw2), _p(dwsp), _p(ws), nb, n, v, f, r, _ld(dout), 1, _stream())
+               _p(dw1), _p(dw2), _p(dwsp), _p(ws), nb, n, v, f, r, _ld(dout), 1, _p(dbias) if dbias is not None else None, _stream())
     return dres
 
 

@@ -59,14 +59,17 @@ class LowPrecisionTrainer(object):
         cast(self.code, self.tdt, t, out=buf[..., :c])
         return buf
 
-    def _gn_bwd(self, norm, c, dy, mean, rstd, want_f32=True):
+    def _gn_bwd(self, norm, c, dy, mean, rstd, want_f32=True, dbias=None):
         """GroupNorm (+ReLU) backward -> (dc in the storage type with channels padded to a matrix step, dc in fp32 or None);
-        parameter gradients accumulate.  16-bit kernel where its tiling fits, else the fp32 kernel on widened copies"""
+        parameter gradients accumulate.  16-bit kernel where its tiling fits, else the fp32 kernel on widened copies.  dbias: the
+        producing conv's bias-gradient slot; self._db_done says whether the pass filled it (else the weight gradient must)"""
         r = None
+        self._db_done = False
         if norm._mode == ops.GN_SLAB:
             pad = c.shape[-1] % 16 != 0
             r = lowp.gn_bwd(self.code, self.tdt, c, dy, norm.gamma.t, norm.beta.t, mean, rstd, self._gslot(norm.gamma), self._gslot(norm.beta),
-                            norm.groups, True, want_f32=want_f32 or pad)
+                            norm.groups, True, want_f32=want_f32 or pad, dbias=dbias)
+            self._db_done = r is not None and dbias is not None
         if r is not None and r[0].shape[-1] % 16 == 0:
             return r
         if r is not None:
@@ -134,11 +137,11 @@ class LowPrecisionTrainer(object):
         lp2 = lowp.wgrad_supported(ops.K3S1, f, f)                       # conv2's weight gradient on the 16-bit kernel?
         lp1 = lowp.wgrad_supported(ops.K3S1, cin_slab, f) and cin_slab == x.shape[-1]   # conv1 / shortcut (not the padded 2-channel input)
         # conv branch: GN2 (+ReLU) -> conv2 -> GN1 (+ReLU) -> conv1
-        dc2_16, dc2 = self._gn_bwd(n2, s['c2'], dout, s['m2'], s['r2'], want_f32=not lp2)
+        dc2_16, dc2 = self._gn_bwd(n2, s['c2'], dout, s['m2'], s['r2'], want_f32=not lp2, dbias=self._gslot(blk.conv2_b) if lp2 else None)
         if lp2:
             a16 = s['a']
-            self._wg((a16, dc2_16), lambda: lowp.conv_bwd_weight(ops.K3S1, code, a16, dc2_16, self._gslot(blk.conv2_k),
-                                                                 self._gslot(blk.conv2_b), accumulate=True))
+            db2 = None if self._db_done else self._gslot(blk.conv2_b)
+            self._wg((a16, dc2_16), lambda: lowp.conv_bwd_weight(ops.K3S1, code, a16, dc2_16, self._gslot(blk.conv2_k), db2, accumulate=True))
         else:
             a32 = self._f32(s['a'])
             self._wg((a32, dc2), lambda: ops.conv_bwd_weight(ops.K3S1, a32, dc2, self._gslot(blk.conv2_k), self._gslot(blk.conv2_b),
@@ -146,18 +149,19 @@ class LowPrecisionTrainer(object):
         da = torch.empty_like(s['a'])
         conv_bwd_data(ops.K3S1, code, dc2_16, self._pk((key, 'c2b'), ops.K3S1, blk.conv2_k, f, f, role=ops.ROLE_BWD), da, False)
         del dc2, dc2_16
-        dc1_16, dc1 = self._gn_bwd(n1, s['c1'], da, s['m1'], s['r1'], want_f32=not lp1)
+        dc1_16, dc1 = self._gn_bwd(n1, s['c1'], da, s['m1'], s['r1'], want_f32=not lp1, dbias=self._gslot(blk.conv1_b) if lp1 else None)
+        db1 = None if (lp1 and self._db_done) else self._gslot(blk.conv1_b)
         del da
         # gate branch (16-bit kernels; fp32 copies only where a weight gradient still runs on the fp32 kernels)
         dres_16 = lowp.se_bwd(code, self.tdt, dout, s['res'], s['sp'], s['gap'], s['hbuf'], s['ch'], blk.se_w1.t, blk.se_w2.t,
                               blk.spatial_k.t.reshape(-1), self._gslot(blk.se_w1), self._gslot(blk.se_w2),
-                              self._gslot(blk.spatial_k).reshape(-1))
+                              self._gslot(blk.spatial_k).reshape(-1), dbias=self._gslot(blk.ptwise_b) if lp1 else None)
         dres = None if lp1 else self._f32(dres_16)
         # weight gradients of the two convolutions that read the block input
         if lp1:
             def wgrads():
-                lowp.conv_bwd_weight(ops.K3S1, code, x, dc1_16, self._gslot(blk.conv1_k), self._gslot(blk.conv1_b), dup_start, dup_shift, True)
-                lowp.conv_bwd_weight(ops.K1, code, x, dres_16, self._gslot(blk.ptwise_k), self._gslot(blk.ptwise_b), dup_start, dup_shift, True)
+                lowp.conv_bwd_weight(ops.K3S1, code, x, dc1_16, self._gslot(blk.conv1_k), db1, dup_start, dup_shift, True)
+                lowp.conv_bwd_weight(ops.K1, code, x, dres_16, self._gslot(blk.ptwise_k), None, dup_start, dup_shift, True)   # (bias: se_bwd)
             self._wg((x, dc1_16, dres_16), wgrads)
         else:   # fp32 kernels on the widened input view
             x32 = self._f32(x[..., :cin_slab])
@@ -189,11 +193,11 @@ class LowPrecisionTrainer(object):
         cout = s['c'].shape[-1]
         lp16 = cin_live is None and cout % 16 == 0 and lowp.wgrad_supported(kind, x.shape[-1], cout) and \
             not (kind == ops.K3S2 and any(v & 1 for v in x.shape[1:4]))
-        dc16, dc = self._gn_bwd(nrm, s['c'], dy, s['m'], s['r'], want_f32=not lp16)
+        dc16, dc = self._gn_bwd(nrm, s['c'], dy, s['m'], s['r'], want_f32=not lp16, dbias=self._gslot(lay.conv_b) if lp16 else None)
         if lp16 and dc16.is_contiguous():
             # 16-bit operands straight into the transposing-read weight-gradient kernel (no widened copies)
-            self._wg((x, dc16), lambda: lowp.conv_bwd_weight(kind, self.code, x, dc16, self._gslot(lay.conv_k), self._gslot(lay.conv_b),
-                                                             accumulate=True))
+            dbs = None if self._db_done else self._gslot(lay.conv_b)
+            self._wg((x, dc16), lambda: lowp.conv_bwd_weight(kind, self.code, x, dc16, self._gslot(lay.conv_k), dbs, accumulate=True))
         else:
             x32 = self._f32(x)
             if dc is None:

@@ -269,12 +269,14 @@ int bts_lp_gn_stats(int dtype, const void* x, float* mean, float* rstd, void* wo
 int bts_lp_gn_apply(int dtype, const void* x, void* y, const float* gamma, const float* beta, const float* mean, const float* rstd, int N,
                     long V, int C, int ldy, int G, int mode, int relu, bts_stream_t stream);
 /* GroupNormalization backward (slab semantics; fused ReLU mask when relu != 0): dx in the storage type and, when dx32 != NULL, the same
- * values in fp32 (the weight gradients still run on the fp32 matrix pipe); dgamma / dbeta fp32 (+= when accumulate_params).
+ * values in fp32 (for a weight gradient that still runs on the fp32 matrix pipe); dgamma / dbeta fp32 (+= when accumulate_params).
+ * dbias (may be NULL, C floats, += when accumulate_params): column sums of dx over voxels and samples = the bias gradient of the conv
+ * whose output this layer normalised (resnet.py:80-93: conv -> GroupNormalization), taken from the same pass.
  * BTS_ERR_UNSUPPORTED for shapes outside its tiling (group length not a multiple of 2048, C/G > 32): run bts_gn_bwd on widened copies */
 long bts_lp_gn_bwd_workspace(int N, long V, int C, int G);
 int bts_lp_gn_bwd(int dtype, const void* x, const void* dy, void* dx, float* dx32, const float* gamma, const float* beta, const float* mean,
                   const float* rstd, float* dgamma, float* dbeta, void* workspace, long workspace_bytes, int N, long V, int C, int lddy, int G,
-                  int relu, int accumulate_params, bts_stream_t stream);
+                  int relu, int accumulate_params, float* dbias, bts_stream_t stream);
 /* GlobalAveragePooling3D of the shortcut (resnet.py:45-46,121): out[n][c] = scale * sum_v x */
 long bts_lp_colsum_workspace(int N, long V, int C);
 int bts_lp_colsum(int dtype, const void* x, float* out, void* workspace, long workspace_bytes, int N, long V, int C, float scale,
@@ -296,11 +298,13 @@ long bts_lp_conv1_gap_workspace(int N, long V, int Cout);
 int bts_lp_conv1_gap(int dtype, const void* x, const void* wp, const float* bias, void* res, float* gap, void* workspace,
                      long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldres, bts_stream_t stream);
 /* gate backward (resnet.py:121-130 under autodiff) on 16-bit dout / res -> dres in the storage type; fp32 parameter gradients;
- * sp = the sp_out of bts_lp_block_epilogue; ds [N*V] and dgap [N*F] are fp32 scratch outputs */
+ * sp = the sp_out of bts_lp_block_epilogue; ds [N*V] and dgap [N*F] are fp32 scratch outputs; dbias (may be NULL, F floats, += when
+ * accumulate_params): column sums of dres = the bias gradient of the block's 1x1x1 shortcut conv (resnet.py:96-103) */
 long bts_lp_se_bwd_workspace(int N, long V, int F, int R);
 int bts_lp_se_bwd(int dtype, const void* dout, const void* res, const float* sp, const float* gap, const float* h, const float* ch,
                   const float* w1, const float* w2, const float* wsp, void* dres, float* ds, float* dgap, float* dw1, float* dw2, float* dwsp,
-                  void* workspace, long workspace_bytes, int N, long V, int F, int R, int lddo, int accumulate_params, bts_stream_t stream);
+                  void* workspace, long workspace_bytes, int N, long V, int F, int R, int lddo, int accumulate_params, float* dbias,
+                  bts_stream_t stream);
 /* output head (decoder.py:55-63): y = sigmoid(x . W + b), W (C, K <= 4) fp32, y fp32 (the label map is taken from it) */
 int bts_lp_head(int dtype, const void* x, const float* w, const float* bias, float* y, long nvox, int C, int ldx, int K, int sigmoid,
                 bts_stream_t stream);

@@ -476,3 +476,42 @@ def test_conv_with_fused_groupnorm_statistics(case, dtype):
     scale = float(y64.abs().mean())
     assert float((mean.double().cpu() - m_ref).abs().max()) <= U[dtype] * scale * 0.05 + 1e-5
     assert float((rstd.double().cpu() / r_ref - 1).abs().max()) <= U[dtype] * 0.05 + 1e-5
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+def test_backward_apply_passes_emit_the_producing_convs_bias_gradient(dtype):
+    """bts_lp_gn_bwd / bts_lp_se_bwd with dbias: the column sums of the tensor the pass writes (the dy of the conv in front of the
+    GroupNorm, resnet.py:80-93; of the 1x1x1 shortcut, resnet.py:96-103) leave from the same pass; they must equal the sums of the
+    fp32 values the pass computed, added to what the slot held"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    code, tdt = lowp.DTYPES[dtype]
+    g = torch.Generator().manual_seed(23)
+    n, d, h, w, c, G = 2, 8, 16, 16, 32, 8
+    x = (torch.randn((n, d, h, w, c), generator=g) * 1.5).to(tdt).to(DEV)
+    dy = torch.randn((n, d, h, w, c), generator=g).to(tdt).to(DEV)
+    gamma, beta = (1 + 0.3 * torch.randn(c, generator=g)).to(DEV), (0.2 * torch.randn(c, generator=g)).to(DEV)
+    mean, rstd = lowp.gn_stats(code, x, G, ops.GN_SLAB, 1e-5)
+    dgam, dbet = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+    db = torch.full((c,), 0.25, device=DEV)
+    dx16, dx32 = lowp.gn_bwd(code, tdt, x, dy, gamma, beta, mean, rstd, dgam, dbet, G, True, want_f32=True, dbias=db)
+    torch.cuda.synchronize()
+    want = dx32.double().sum(dim=(0, 1, 2, 3)).cpu() + 0.25
+    assert float((db.double().cpu() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    # gate backward
+    f, r = 32, 4
+    res = torch.randn((n, d, h, w, f), generator=g).to(tdt).to(DEV)
+    dout = torch.randn((n, d, h, w, f), generator=g).to(tdt).to(DEV)
+    wsp = (torch.randn(f, generator=g) * 0.3).to(DEV)
+    w1, w2 = (torch.randn((f, r), generator=g) * 0.3).to(DEV), (torch.randn((r, f), generator=g) * 0.3).to(DEV)
+    gap = res.float().mean(dim=(1, 2, 3)).contiguous()
+    hb, ch = ops.se_mlp_fwd(gap, w1, w2)
+    sp = torch.sigmoid((res.float() * wsp).sum(-1)).reshape(-1).contiguous()
+    dw1, dw2, dwsp = torch.zeros_like(w1), torch.zeros_like(w2), torch.zeros_like(wsp)
+    db2 = torch.full((f,), -0.5, device=DEV)
+    dres = lowp.se_bwd(code, tdt, dout, res, sp, gap, hb, ch, w1, w2, wsp, dw1, dw2, dwsp, dbias=db2)
+    torch.cuda.synchronize()
+    want2 = dres.double().sum(dim=(0, 1, 2, 3)).cpu() - 0.5         # (sums of the ROUNDED values: the kernel adds the unrounded ones)
+    u = U[dtype]
+    tol = u * float(dres.double().abs().sum(dim=(0, 1, 2, 3)).max()) / (n * d * h * w) ** 0.5 * 8 + 1e-4
+    assert float((db2.double().cpu() - want2).abs().max()) <= tol
