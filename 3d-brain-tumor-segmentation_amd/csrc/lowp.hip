@@ -1228,6 +1228,88 @@ extern "C" int bts_lp_head(int dtype, const void* x, const float* w, const float
   return BTS_OK;
 }
 
+__global__ __launch_bounds__(256) void lp_dbias_finalize_kernel(const double* part, float* db, int nblocks, int C, int accum);
+// ---- output head backward (decoder.py:55-63 under TF autodiff, train.py:142-151): with dpre = dL/d(x . W + b) per voxel (K <= 4 values,
+// the sigmoid's gradient already applied: bts_sigmoid_bwd), ONE pass over the 16-bit activations gives all three gradients:
+//   dx[v][c] = sum_k dpre[v][k] W[c][k]  (storage type),   dW[c][k] (+)= sum_v x[v][c] dpre[v][k],   db[k] (+)= sum_v dpre[v][k].
+// Round 2 widened x to fp32, ran the fp32 1x1x1 weight- and data-gradient kernels and narrowed dx again: five passes over a 128^3 x 32
+// tensor.  One voxel per lane; a lane keeps the C*K + K running sums of its voxels, waves reduce by shuffles, blocks through LDS, one
+// fp64 row per block; lp_dbias_finalize_kernel adds the rows in block order.
+template <typename T, int C, int K>
+__global__ __launch_bounds__(256) void lp_head_bwd_kernel(const unsigned short* x, const float* dpre, const float* w, unsigned short* dx, double* part,
+                                                          long nvox, int ldx, int lddx) {
+  constexpr int NS = C * K + K;
+  __shared__ float sh[4][NS];
+  float acc[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) acc[i] = 0.f;
+  float wr[C * K];
+#pragma unroll
+  for (int i = 0; i < C * K; ++i) wr[i] = w[i];
+  for (long v = blockIdx.x * 256L + threadIdx.x; v < nvox; v += (long)gridDim.x * 256) {
+    float d[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { d[k] = dpre[v * K + k]; acc[C * K + k] += d[k]; }
+#pragma unroll
+    for (int c0 = 0; c0 < C; c0 += 8) {
+      float t[8], o[8];
+      unpack8<T>(*reinterpret_cast<const u32x4*>(x + v * ldx + c0), t);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          s = fmaf(d[k], wr[(c0 + e) * K + k], s);
+          acc[(c0 + e) * K + k] = fmaf(t[e], d[k], acc[(c0 + e) * K + k]);
+        }
+        o[e] = s;
+      }
+      *reinterpret_cast<u32x4*>(dx + v * lddx + c0) = pack8<T>(o);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const float s = wave_sum_f32(acc[i]);
+    if (lane == 0) sh[wave][i] = s;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NS; i += 256) part[(long)blockIdx.x * NS + i] = ((double)sh[0][i] + (double)sh[1][i]) + ((double)sh[2][i] + (double)sh[3][i]);
+}
+extern "C" long bts_lp_head_bwd_workspace(int C, int K) { return (C <= 0 || K <= 0) ? -1 : 2048L * (C * K + K) * 8 + 64; }
+// x (nvox, C) 16-bit rows of ldx; dpre (nvox, K) fp32 dense; w (C, K) fp32; dx (nvox, C) 16-bit rows of lddx; dw (C, K), db (K) fp32 (+= when accumulate).
+// C in {16, 32, 64}, K in {1, 2, 3, 4}: the heads of this model (decoder.py:55-63: C = base_filters, K = out_ch)
+extern "C" int bts_lp_head_bwd(int dtype, const void* x, const float* dpre, const float* w, void* dx, float* dw, float* db, void* workspace,
+                               long workspace_bytes, long nvox, int C, int ldx, int lddx, int K, int accumulate, hipStream_t stream) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  if (nvox <= 0 || (C != 16 && C != 32 && C != 64) || K < 1 || K > 4) return BTS_ERR_UNSUPPORTED;
+  if (ldx % 8 != 0 || lddx % 8 != 0 || ldx < C || lddx < C) return BTS_ERR_SHAPE;
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)dx) & 15) || (((uintptr_t)workspace) & 15)) return BTS_ERR_ALIGN;
+  if (workspace_bytes < bts_lp_head_bwd_workspace(C, K)) return BTS_ERR_WORKSPACE;
+  long blocks = (nvox + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  double* part = reinterpret_cast<double*>(workspace);
+  (void)hipGetLastError();
+#define LP_HB(TT, C_, K_) hipLaunchKernelGGL((lp_head_bwd_kernel<TT, C_, K_>), dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)x, dpre, w, (unsigned short*)dx, part, nvox, ldx, lddx)
+#define LP_HB_K(TT, C_) do { if (K == 1) LP_HB(TT, C_, 1); else if (K == 2) LP_HB(TT, C_, 2); else if (K == 3) LP_HB(TT, C_, 3); else LP_HB(TT, C_, 4); } while (0)
+#define LP_HB_C(TT) do { if (C == 16) LP_HB_K(TT, 16); else if (C == 32) LP_HB_K(TT, 32); else LP_HB_K(TT, 64); } while (0)
+  if (dtype == LP_F16) LP_HB_C(TF16); else LP_HB_C(TBF16);
+#undef LP_HB_C
+#undef LP_HB_K
+#undef LP_HB
+  BTS_LAUNCH_CHECK();
+  const int NS = C * K + K;
+  float* tmp = nullptr; (void)tmp;
+  // rows -> dw (C*K values) and db (K values): two calls of the fixed-order row adder on the same partial rows
+  hipLaunchKernelGGL(lp_dbias_finalize_kernel, dim3(C * K), dim3(256), 0, stream, part, dw, (int)blocks, NS, accumulate);
+  BTS_LAUNCH_CHECK();
+  if (db != nullptr) {
+    hipLaunchKernelGGL(lp_dbias_finalize_kernel, dim3(K), dim3(256), 0, stream, part + C * K, db, (int)blocks, NS, accumulate);
+    BTS_LAUNCH_CHECK();
+  }
+  return BTS_OK;
+}
+
 // Bias gradient of the conv that produced the tensor a backward apply pass writes (its dy): db[c] = sum over voxels and samples.  The
 // apply kernels walk octets with a stride that is a multiple of the channel count, so a thread's channel octet never changes: it keeps
 // eight running sums, the block adds the threads of equal octet in LDS (fixed order) and leaves one fp64 partial row per block;

@@ -225,6 +225,21 @@ def se_bwd(code, tdt, dout, res, sp, gap, h, ch, w1, w2, wsp, dw1, dw2, dwsp, db
     return dres
 
 
+def head_bwd(code, tdt, x, dpre, w, dw, db, accumulate=True):
+    """output head backward in one pass over the 16-bit activations -> dx (storage type); dw (C,K) / db (K) fp32 accumulate.
+    None when the head is outside the kernel's shapes (C in {16,32,64}, K <= 4): the caller then runs the fp32 kernels"""
+    n, d, h, wd, c = x.shape
+    k = dpre.shape[-1]
+    if c not in (16, 32, 64) or k > 4 or not dpre.is_contiguous():
+        return None
+    dx = torch.empty((n, d, h, wd, c), dtype=tdt, device=x.device)
+    nb = lib().query('bts_lp_head_bwd_workspace', c, k)
+    ws = ops.workspace(nb, x.device)
+    lib().call('bts_lp_head_bwd', code, _p(x), _p(dpre), _p(w), _p(dx), _p(dw), _p(db) if db is not None else None, _p(ws), nb,
+               n * d * h * wd, c, _ld(x), c, k, 1 if accumulate else 0, _stream())
+    return dx
+
+
 def head(code, x, w, bias, sigmoid=True):
     n, d, h, wd, c = x.shape
     k = w.shape[-1]

@@ -135,7 +135,10 @@ class LowPrecisionTrainer(object):
         x = s['x']
         cin_slab = s['cin_slab']
         lp2 = lowp.wgrad_supported(ops.K3S1, f, f)                       # conv2's weight gradient on the 16-bit kernel?
-        lp1 = lowp.wgrad_supported(ops.K3S1, cin_slab, f) and cin_slab == x.shape[-1]   # conv1 / shortcut (not the padded 2-channel input)
+        # conv1 / shortcut weight gradients on the 16-bit kernel; the first block reads the 2-channel volume zero-padded to one matrix
+        # step: its gradients are taken over all 16 stored channels into a scratch tensor and the live rows added to the real slots
+        pad_in = cin_slab < x.shape[-1]
+        lp1 = lowp.wgrad_supported(ops.K3S1, x.shape[-1], f)
         # conv branch: GN2 (+ReLU) -> conv2 -> GN1 (+ReLU) -> conv1
         dc2_16, dc2 = self._gn_bwd(n2, s['c2'], dout, s['m2'], s['r2'], want_f32=not lp2, dbias=self._gslot(blk.conv2_b) if lp2 else None)
         if lp2:
@@ -158,7 +161,16 @@ class LowPrecisionTrainer(object):
                               self._gslot(blk.spatial_k).reshape(-1), dbias=self._gslot(blk.ptwise_b) if lp1 else None)
         dres = None if lp1 else self._f32(dres_16)
         # weight gradients of the two convolutions that read the block input
-        if lp1:
+        if lp1 and pad_in:
+            def wgrads():
+                tk = torch.empty((3, 3, 3, x.shape[-1], f), dtype=torch.float32, device=x.device)
+                tp = torch.empty((1, 1, 1, x.shape[-1], f), dtype=torch.float32, device=x.device)
+                lowp.conv_bwd_weight(ops.K3S1, code, x, dc1_16, tk, db1, 0, 0, False)
+                lowp.conv_bwd_weight(ops.K1, code, x, dres_16, tp, None, 0, 0, False)
+                self._gslot(blk.conv1_k).add_(tk[:, :, :, :cin_slab, :])
+                self._gslot(blk.ptwise_k).add_(tp[:, :, :, :cin_slab, :])
+            self._wg((x, dc1_16, dres_16), wgrads)
+        elif lp1:
             def wgrads():
                 lowp.conv_bwd_weight(ops.K3S1, code, x, dc1_16, self._gslot(blk.conv1_k), db1, dup_start, dup_shift, True)
                 lowp.conv_bwd_weight(ops.K1, code, x, dres_16, self._gslot(blk.ptwise_k), None, dup_start, dup_shift, True)   # (bias: se_bwd)
@@ -320,16 +332,20 @@ class LowPrecisionTrainer(object):
         ops.loss_bwd(y_pred, y, x, y_vae, proj, sums, one, dyp, dyv, dproj, through_sigmoid=False)
         # slab gradients (zero-initialised: every contribution accumulates)
         gslabs = [torch.zeros_like(slab) for slab, _, _, _ in levels]
-        # decoder head (decoder.py:55-63): sigmoid, 1x1x1 conv to out_ch -- fp32 kernels (3 output channels)
+        # decoder head (decoder.py:55-63): sigmoid, 1x1x1 conv to out_ch -- dx, dW and db from one pass over the 16-bit activations
         dpre = ops.sigmoid_bwd(y_pred, dyp)
-        ylast32 = self._f32(y_last)
-        self._wg((ylast32, dpre), lambda: ops.conv_bwd_weight(ops.K1, ylast32, dpre, self._gslot(dec.out_k), self._gslot(dec.out_b),
-                                                             accumulate=True))
-        dlast32 = torch.empty_like(ylast32)
-        wpb = dec.packed('out_b', ops.K1, ops.ROLE_BWD, dec.out_k, y_last.shape[-1], dec.out_ch)
-        ops.conv_bwd_data(ops.K1, dpre, wpb, dlast32, False)
-        dcur = self._b16(dlast32)
-        del dlast32, ylast32, dpre
+        wk2 = dec.out_k.t.reshape(dec.out_k.t.shape[-2], dec.out_k.t.shape[-1])
+        dcur = lowp.head_bwd(code, tdt, y_last, dpre, wk2, self._gslot(dec.out_k).reshape(wk2.shape), self._gslot(dec.out_b), True)
+        if dcur is None:       # head outside the fused kernel's shapes: fp32 kernels on widened copies
+            ylast32 = self._f32(y_last)
+            self._wg((ylast32, dpre), lambda: ops.conv_bwd_weight(ops.K1, ylast32, dpre, self._gslot(dec.out_k), self._gslot(dec.out_b),
+                                                                 accumulate=True))
+            dlast32 = torch.empty_like(ylast32)
+            wpb = dec.packed('out_b', ops.K1, ops.ROLE_BWD, dec.out_k, y_last.shape[-1], dec.out_ch)
+            ops.conv_bwd_data(ops.K1, dpre, wpb, dlast32, False)
+            dcur = self._b16(dlast32)
+            del dlast32, ylast32
+        del dpre
         for idx in range(len(dsaves) - 1, -1, -1):
             us, bs, li, cres, f = dsaves[idx]
             gs = gslabs[li]
@@ -339,15 +355,35 @@ class LowPrecisionTrainer(object):
             else:                                                # the others read the previous decoder block's output
                 dcur = torch.empty(us['x'].shape, dtype=tdt, device=dev)
                 self._sampler_bwd(us, gs[..., cres:cres + f], dcur, False)
-        # VAE branch backward
-        ylv32 = self._f32(yv_last)
-        self._wg((ylv32, dyv), lambda: ops.conv_bwd_weight(ops.K3S1, ylv32, dyv, self._gslot(vae.out_k), self._gslot(vae.out_b),
-                                                           accumulate=True))
-        dv32 = torch.empty_like(ylv32)
-        wpb = vae.packed('out_b', ops.K3S1, ops.ROLE_BWD, vae.out_k, yv_last.shape[-1], vae.out_ch)
-        ops.conv_bwd_data(ops.K3S1, dyv, wpb, dv32, False)
-        dv = self._b16(dv32)
-        del dv32, ylv32
+        # VAE branch backward.  Its output conv has out_ch = in_ch = 2 channels (vae.py:92-99): dy is stored zero-padded to one matrix step
+        # (16 channels, like the input volume) so that the weight gradient (padded columns dropped afterwards) and the data gradient
+        # (role-swapped image of the zero-padded kernel) run on the 16-bit kernels instead of the fp32 ones over widened copies
+        cv, co = yv_last.shape[-1], vae.out_ch
+        if cv % 16 == 0 and co <= 16 and lowp.wgrad_supported(ops.K3S1, cv, 16):
+            dyv16 = torch.zeros(tuple(dyv.shape[:4]) + (16,), dtype=tdt, device=dev)
+            cast(code, tdt, dyv, out=dyv16[..., :co])
+
+            def wg_out():
+                tk = torch.empty((3, 3, 3, cv, 16), dtype=torch.float32, device=dev)
+                lowp.conv_bwd_weight(ops.K3S1, code, yv_last, dyv16, tk, None, 0, 0, False)
+                self._gslot(vae.out_k).add_(tk[..., :co])
+                self._gslot(vae.out_b).add_(dyv.sum(dim=(0, 1, 2, 3)))
+            self._wg((yv_last, dyv16, dyv), wg_out)
+            wpad = torch.zeros((3, 3, 3, cv, 16), dtype=torch.float32, device=dev)
+            wpad[..., :co] = vae.out_k.t
+            wpb = lowp.pack(ops.K3S1, code, wpad, cv, 16, role=ops.ROLE_BWD)
+            dv = torch.empty(yv_last.shape, dtype=tdt, device=dev)
+            conv_bwd_data(ops.K3S1, code, dyv16, wpb, dv, False)
+            del dyv16
+        else:
+            ylv32 = self._f32(yv_last)
+            self._wg((ylv32, dyv), lambda: ops.conv_bwd_weight(ops.K3S1, ylv32, dyv, self._gslot(vae.out_k), self._gslot(vae.out_b),
+                                                               accumulate=True))
+            dv32 = torch.empty_like(ylv32)
+            wpb = vae.packed('out_b', ops.K3S1, ops.ROLE_BWD, vae.out_k, yv_last.shape[-1], vae.out_ch)
+            ops.conv_bwd_data(ops.K3S1, dyv, wpb, dv32, False)
+            dv = self._b16(dv32)
+            del dv32, ylv32
         for us, bs in reversed(vsaves):
             dblk_in = torch.zeros(bs['x'].shape, dtype=tdt, device=dev)
             self._block_bwd(bs, dv, dblk_in)

@@ -308,6 +308,11 @@ int bts_lp_se_bwd(int dtype, const void* dout, const void* res, const float* sp,
 /* output head (decoder.py:55-63): y = sigmoid(x . W + b), W (C, K <= 4) fp32, y fp32 (the label map is taken from it) */
 int bts_lp_head(int dtype, const void* x, const float* w, const float* bias, float* y, long nvox, int C, int ldx, int K, int sigmoid,
                 bts_stream_t stream);
+/* output head backward (decoder.py:55-63 under autodiff; train.py:142-151): dpre = dL/d(x . W + b) (nvox, K) fp32 (bts_sigmoid_bwd) ->
+ * dx (nvox, C) in the storage type, dw (C, K) and db (K) fp32 (+= when accumulate), all from ONE pass over x.  C in {16,32,64}, K <= 4 */
+long bts_lp_head_bwd_workspace(int C, int K);
+int bts_lp_head_bwd(int dtype, const void* x, const float* dpre, const float* w, void* dx, float* dw, float* db, void* workspace,
+                    long workspace_bytes, long nvox, int C, int ldx, int lddx, int K, int accumulate, bts_stream_t stream);
 
 #ifdef __cplusplus
 }
