@@ -1523,7 +1523,8 @@ extern "C" int bts_lp_gn_bwd(int dtype, const void* x, const void* dy, void* dx,
   BTS_LAUNCH_CHECK();
   const long total8 = (long)N * E / 8;
   long blocks = (total8 + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
+  const long cap = dbias ? 2048 : 16384;       // (bias rows: one per block -- 2048 blocks of 256 still fill the chip eight waves deep)
+  if (blocks > cap) blocks = cap;
   if (dtype == LP_F16) hipLaunchKernelGGL(lp_gn_bwd_apply_kernel<TF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)dy, (unsigned short*)dx, dx32, gamma, beta, mean, rstd, c1, c2, total8, E, L, C, G, cg, lddy, relu, dbp);
   else hipLaunchKernelGGL(lp_gn_bwd_apply_kernel<TBF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)dy, (unsigned short*)dx, dx32, gamma, beta, mean, rstd, c1, c2, total8, E, L, C, G, cg, lddy, relu, dbp);
   BTS_LAUNCH_CHECK();
@@ -2205,7 +2206,8 @@ extern "C" int bts_lp_se_bwd(int dtype, const void* dout, const void* res, const
   if (r != BTS_OK) return r;
   const long total = (long)N * V * (F / 8);
   long blocks = (total + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
+  const long cap = dbias ? 2048 : 16384;
+  if (blocks > cap) blocks = cap;
   if (dtype == LP_F16) hipLaunchKernelGGL(lp_se_bwd_apply_kernel<TF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)dout, sp, ds, ch, wsp, dgap, (unsigned short*)dres, (long)N * V, V, F, lddo, dbp);
   else hipLaunchKernelGGL(lp_se_bwd_apply_kernel<TBF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)dout, sp, ds, ch, wsp, dgap, (unsigned short*)dres, (long)N * V, V, F, lddo, dbp);
   BTS_LAUNCH_CHECK();
