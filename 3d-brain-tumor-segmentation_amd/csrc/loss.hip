@@ -244,7 +244,7 @@ extern "C" int bts_dice_metric_value(const double* table, float* out, int W, int
 // ---------------------------------------------------------------------------------------------
 // L2 regulariser over ranges of the flat parameter buffer: value = sum_r coef_r * sum(p[r]^2); grad += 2*coef_r*p
 // ---------------------------------------------------------------------------------------------
-#define L2_MAXR 4
+#define L2_MAXR 128   // one range per (layer group, coefficient): the flat buffer is laid out in backward-completion order (model.py)
 struct L2Ranges {
   long off[L2_MAXR], len[L2_MAXR];
   float coef[L2_MAXR];

@@ -52,33 +52,67 @@ class Model(Layer):
         self.built = True
         self._flatten_parameters()
 
+    def _backward_groups(self):
+        """The variables grouped by layer call, in the order the backward pass FINISHES their gradients: the tape replays the forward's
+        layer calls in reverse (model.py:63-68: encoder, decoder, vae -> vae, decoder, encoder level 3 .. 0).  The flat buffers follow
+        this order so that the gradient buckets of parallel.GradSync ("reverse-layer order") complete front to back while
+        the backward pass is still running, and the last bucket holds only the shallow encoder levels."""
+        enc, dec, vae = self.encoder, self.decoder, self.vae
+        own = lambda lay, names: [getattr(lay, n) for n in names if getattr(lay, n, None) is not None]
+        groups = [own(vae, ['out_k', 'out_b'])]
+        for up, blk in reversed(vae.levels):
+            groups += [blk.trainable_variables, up.trainable_variables]
+        groups += [vae.upsample.trainable_variables, own(vae, ['unproj_k', 'unproj_b', 'proj_k', 'proj_b']), vae.downsample.trainable_variables]
+        groups.append(own(dec, ['out_k', 'out_b']))
+        for up, blk in reversed(dec.levels):
+            groups += [blk.trainable_variables, up.trainable_variables]
+        for convs, down in reversed(enc.levels):
+            if down is not None:
+                groups.append(down.trainable_variables)
+            for blk in reversed(convs):
+                groups.append(blk.trainable_variables)
+        groups = [g for g in groups if g]
+        seen = [id(p) for g in groups for p in g]
+        if len(seen) != len(set(seen)) or set(seen) != set(id(p) for p in self.trainable_variables):
+            raise RuntimeError('backward grouping does not cover the variables exactly once')
+        return groups
+
     def _flatten_parameters(self):
-        """one contiguous buffer: [ l2_scale-regularised | fixed-1e-5-regularised | unregularised ]"""
-        ps = self.trainable_variables
-        coefs = sorted(set(p.l2 for p in ps if p.l2 > 0), reverse=True)
-        groups = [[p for p in ps if p.l2 == c] for c in coefs] + [[p for p in ps if p.l2 <= 0]]
-        total = sum(p.t.numel() for p in ps)
+        """one contiguous buffer in backward-completion order; inside a layer group [regularised (by coefficient) | unregularised], so
+        the regulariser touches one short list of ranges (ops.l2_reg_*: up to 128) and Adam / the all-reduce one contiguous buffer"""
+        groups = self._backward_groups()
+        total = sum(p.t.numel() for g in groups for p in g)
         pad = (-total) % 4
-        dev = ps[0].t.device
+        dev = groups[0][0].t.device
         flat = torch.empty(total + pad, dtype=torch.float32, device=dev)
         grads = torch.zeros(total + pad, dtype=torch.float32, device=dev)
         if pad:
             flat[total:] = 0
         off = 0
-        ranges = []
-        for gi, grp in enumerate(groups):
+        ranges, spans = [], []
+        for grp in groups:
             start = off
-            for p in grp:
-                n = p.t.numel()
-                flat[off:off + n].copy_(p.t.reshape(-1))
-                p.t = flat[off:off + n].view(p.t.shape)
-                p._gview = grads[off:off + n].view(p.t.shape)
-                off += n
-            if gi < len(coefs) and off > start:
-                ranges.append((start, off - start, coefs[gi]))
-        if len(ranges) > 4:
-            raise RuntimeError('more than 4 distinct L2 coefficients')
+            coefs = sorted(set(p.l2 for p in grp if p.l2 > 0), reverse=True)
+            for cls in coefs + [0.0]:
+                c0 = off
+                for p in grp:
+                    if (p.l2 if p.l2 > 0 else 0.0) != cls:
+                        continue
+                    n = p.t.numel()
+                    flat[off:off + n].copy_(p.t.reshape(-1))
+                    p.t = flat[off:off + n].view(p.t.shape)
+                    p._gview = grads[off:off + n].view(p.t.shape)
+                    off += n
+                if cls > 0 and off > c0:
+                    if ranges and ranges[-1][2] == cls and ranges[-1][0] + ranges[-1][1] == c0:
+                        ranges[-1] = (ranges[-1][0], ranges[-1][1] + off - c0, cls)       # (adjacent ranges of one coefficient merge)
+                    else:
+                        ranges.append((c0, off - c0, cls))
+            spans.append((start, off))
+        if len(ranges) > 128:
+            raise RuntimeError('more than 128 regulariser ranges')
         self.flat_params, self.flat_grads, self._l2_ranges = flat, grads, ranges
+        self._group_spans = spans          # (start, end) of every layer group, backward-completion order
         self.n_params = total
         bump_weights_epoch()
 

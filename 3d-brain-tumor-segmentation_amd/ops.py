@@ -558,7 +558,7 @@ def _ranges(ranges):
 
 
 def l2_reg_fwd(params_flat, ranges):
-    """ranges: [(offset, length, coefficient)] (<= 4) into the flat parameter buffer"""
+    """ranges: [(offset, length, coefficient)] (<= 128) into the flat parameter buffer"""
     off, ln, cf, nr = _ranges(ranges)
     out = torch.empty(1, dtype=torch.float32, device=params_flat.device)
     nb = lib().query('bts_l2_workspace')

@@ -166,7 +166,7 @@ class GradSync(object):
             self.spans[id(p_)] = (off, p_._gview.numel())
         self.buckets = []   # (start, length, [param ids])
         n = model.flat_grads.numel()
-        for off, ln in bucket_ranges(n, 4, bucket_bytes):
+        for off, ln in self._cuts(model, n, bucket_bytes):
             members = [id(p_) for p_ in ps if self.spans[id(p_)][0] < off + ln and self.spans[id(p_)][0] + self.spans[id(p_)][1] > off]
             self.buckets.append((off, ln, members))
         self.by_param = {}
@@ -174,9 +174,40 @@ class GradSync(object):
             for pid in members:
                 self.by_param.setdefault(pid, []).append(bi)
         self.params = {id(p_): p_ for p_ in ps}
+        self.launch_log = []     # per step: (bucket, tape nodes replayed when it was launched, bytes) -- tests read it
+
+    @staticmethod
+    def _cuts(model, n, bucket_bytes):
+        """Bucket boundaries.  The flat buffers are laid out in backward-completion order, one span per layer call
+        (model._group_spans): a bucket is a run of whole layer groups of at least `bucket_bytes` (few large messages: xGMI rings are
+        per-link bound), closed early so that the groups the backward pass finishes LAST -- the shallow encoder levels, a few MB --
+        form a small bucket of their own: everything before it is in flight while the 128^3 levels are still being back-propagated."""
+        spans = getattr(model, '_group_spans', None)
+        if not spans or bucket_bytes < (1 << 20):
+            return bucket_ranges(n, 4, bucket_bytes)      # (tests ask for many tiny buckets: plain equal cuts)
+        per = max(1, bucket_bytes // 4)
+        tail_elems = (4 << 20) // 4
+        # index of the first group of the small tail: trailing groups that together stay under 4 MB
+        t, acc = len(spans), 0
+        while t > 0 and acc + (spans[t - 1][1] - spans[t - 1][0]) <= tail_elems:
+            acc += spans[t - 1][1] - spans[t - 1][0]
+            t -= 1
+        cuts, start = [], 0
+        for gi, (a, b) in enumerate(spans):
+            if gi == t and a > start:
+                cuts.append((start, a - start))
+                start = a
+            if b - start >= per and gi + 1 < len(spans) and gi + 1 != t:
+                cuts.append((start, b - start))
+                start = b
+        if n > start:
+            cuts.append((start, n - start))
+        return cuts
 
     def begin(self, tape):
         self.tape = tape
+        self.launch_log = []
+        self.nodes_total = len(tape.nodes)
         self.done = set()
         self.pending = [len(m) for _, _, m in self.buckets]
         self.launched = [False] * len(self.buckets)
@@ -220,6 +251,7 @@ class GradSync(object):
             if rg:
                 ops.l2_reg_bwd(m.flat_params, m.flat_grads, rg, g)
         self.launched[bi] = True
+        self.launch_log.append((bi, getattr(self.tape, 'nodes_replayed', 0), ln * 4))
         if active():
             self.handles.append(_sum_over_ranks(m.flat_grads[off:off + ln], async_op=True))
 

@@ -230,8 +230,10 @@ class GradientTape(object):
                 grad_sync.begin(self)
             nodes = self.nodes if self.persistent else None
             seq = self.nodes
+            self.nodes_replayed = 0
             for i in range(len(seq) - 1, -1, -1):
                 seq[i]()
+                self.nodes_replayed += 1
                 if nodes is None:
                     seq[i] = None  # release saved activations as soon as they are consumed
                 if self._touched:

@@ -28,7 +28,7 @@ LOG_HEADER = ','.join(['epoch', 'lr', 'train_loss', 'train_macro_dice', 'train_m
                        'val_macro_dice', 'val_micro_dice'])                       # train.py:119-126
 CHECKPOINT_NAME = 'chkpt.safetensors'                                             # reference: chkpt.hdf5 (train.py:201)
 ARGS_NAME = 'train_args.pkl'                                                      # args.py:193-194
-FORMAT_VERSION = 1
+FORMAT_VERSION = 2      # 2: Adam moments in the backward-completion order of the flat buffers (model._flatten_parameters, round 3)
 
 
 class Mean(object):

@@ -42,10 +42,20 @@ def test_parameter_inventory(kw, count):
     for p in m.trainable_variables:
         assert tuple(p.t.shape) == tuple(P[m.oracle_name(p)].shape), p.name
         assert p.l2 == pytest.approx(P.l2[m.oracle_name(p)]), p.name
-    # flat buffer: one contiguous, 16B-aligned range; L2-regularised variables first
+    # flat buffer: one contiguous, 16B-aligned range in backward-completion order (vae, decoder, encoder level 3 .. 0: SURVEY 8e); the
+    # regulariser ranges are disjoint, carry the one coefficient of this configuration and cover exactly the regularised variables
     assert m.flat_params.numel() >= count and m.flat_params.numel() % 4 == 0
-    off, ln, coef = m._l2_ranges[0]
-    assert off == 0 and coef == 1e-5 and ln == sum(p.t.numel() for p in m.trainable_variables if p.l2 > 0)
+    rg = sorted(m._l2_ranges)
+    assert all(a[0] + a[1] <= b[0] for a, b in zip(rg, rg[1:])) and all(c == 1e-5 for _, _, c in rg) and len(rg) <= 128
+    assert sum(ln for _, ln, _ in rg) == sum(p.t.numel() for p in m.trainable_variables if p.l2 > 0)
+    base = m.flat_params.data_ptr()
+    for p in m.trainable_variables:
+        o = (p.t.data_ptr() - base) // 4
+        inside = any(a <= o and o + p.t.numel() <= a + ln for a, ln, _ in rg)
+        assert inside == (p.l2 > 0), p.name
+    first = (m.vae.out_k.t.data_ptr() - base) // 4          # the backward pass finishes the VAE's output conv first ...
+    last = max(p.t.data_ptr() for p in m.encoder.levels[0][0][0].trainable_variables)
+    assert first == 0 and last == max(p.t.data_ptr() for p in m.trainable_variables)      # ... and the first encoder block last
     # unproj is created last inside the VAE (vae.py:105)
     vnames = [p.name for p in m.vae.trainable_variables]
     assert vnames[-2:] == ['vae/unproj_k', 'vae/unproj_b']
