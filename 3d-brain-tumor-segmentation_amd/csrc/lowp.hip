@@ -1192,6 +1192,173 @@ extern "C" int bts_lp_block_epilogue(int dtype, const void* res, const void* c2,
   return BTS_OK;
 }
 
+// ---- the non-default samplers on 16-bit tensors (args.py:136-141): MaxPooling3D(2) (downsample.py:51-70) and
+// UpSampling3D(2) = nearest-neighbour repeat (upsample.py:69), with their gradients (train.py:142-151 under TF autodiff).  Eight
+// channels (one 16-byte piece) per thread; the pool keeps the window position of the FIRST maximum (scan order dz, dy, dx) like the
+// fp32 engine's bts_maxpool2_fwd, so that the gradient routing is the same; sums of the repeat's gradient run in fp32.
+template <typename T>
+__global__ __launch_bounds__(256) void lp_maxpool2_fwd_kernel(const unsigned short* x, unsigned short* y, unsigned char* idx, long total8, int Do,
+                                                              int Ho, int Wo, int C, int ldx, int ldy) {
+  const int C8 = C >> 3;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C8) * 8;
+    long v = i / C8;
+    const int ox = (int)(v % Wo); v /= Wo;
+    const int oy = (int)(v % Ho); v /= Ho;
+    const int oz = (int)(v % Do);
+    const long n = v / Do;
+    float best[8];
+    unsigned char bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const long src = (((n * (2 * Do) + 2 * oz + (t >> 2)) * (2 * Ho) + 2 * oy + ((t >> 1) & 1)) * (2L * Wo) + 2 * ox + (t & 1));
+      float f[8];
+      unpack8<T>(*reinterpret_cast<const u32x4*>(x + src * ldx + c), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (f[e] > best[e]) { best[e] = f[e]; bi[e] = (unsigned char)t; }
+    }
+    const long dst = ((n * Do + oz) * Ho + oy) * (long)Wo + ox;
+    *reinterpret_cast<u32x4*>(y + dst * ldy + c) = pack8<T>(best);
+    if (idx != nullptr) {
+      unsigned lo = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24), hi = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+      *reinterpret_cast<u32x2*>(idx + dst * C + c) = u32x2{lo, hi};
+    }
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void lp_maxpool2_bwd_kernel(const unsigned short* dy, const unsigned char* idx, unsigned short* dx, long total8,
+                                                              int Do, int Ho, int Wo, int C, int lddy, int lddx, int accum) {
+  const int C8 = C >> 3;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C8) * 8;
+    long v = i / C8;
+    const int ox = (int)(v % Wo); v /= Wo;
+    const int oy = (int)(v % Ho); v /= Ho;
+    const int oz = (int)(v % Do);
+    const long n = v / Do;
+    const long src = ((n * Do + oz) * Ho + oy) * (long)Wo + ox;
+    float g[8];
+    unpack8<T>(*reinterpret_cast<const u32x4*>(dy + src * lddy + c), g);
+    const u32x2 pk = *reinterpret_cast<const u32x2*>(idx + src * C + c);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const long dst = (((n * (2 * Do) + 2 * oz + (t >> 2)) * (2 * Ho) + 2 * oy + ((t >> 1) & 1)) * (2L * Wo) + 2 * ox + (t & 1));
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (((e < 4 ? pk[0] >> (8 * e) : pk[1] >> (8 * (e - 4))) & 0xffu) == (unsigned)t) ? g[e] : 0.f;
+      if (accum) {
+        float old[8];
+        unpack8<T>(*reinterpret_cast<const u32x4*>(dx + dst * lddx + c), old);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += old[e];
+      }
+      *reinterpret_cast<u32x4*>(dx + dst * lddx + c) = pack8<T>(o);
+    }
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void lp_upsample2_fwd_kernel(const unsigned short* x, unsigned short* y, long total8, int D, int H, int W, int C,
+                                                               int ldx, int ldy) {
+  const int C8 = C >> 3;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {      // over the FINE grid
+    const int c = (int)(i % C8) * 8;
+    long v = i / C8;
+    const int fx = (int)(v % (2 * W)); v /= 2 * W;
+    const int fy = (int)(v % (2 * H)); v /= 2 * H;
+    const int fz = (int)(v % (2 * D));
+    const long n = v / (2 * D);
+    const long src = ((n * D + (fz >> 1)) * H + (fy >> 1)) * (long)W + (fx >> 1);
+    const long dst = ((n * (2 * D) + fz) * (2 * H) + fy) * (2L * W) + fx;
+    *reinterpret_cast<u32x4*>(y + dst * ldy + c) = *reinterpret_cast<const u32x4*>(x + src * ldx + c);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void lp_upsample2_bwd_kernel(const unsigned short* dy, unsigned short* dx, long total8, int D, int H, int W, int C,
+                                                               int lddy, int lddx, int accum) {
+  const int C8 = C >> 3;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {      // over the COARSE grid
+    const int c = (int)(i % C8) * 8;
+    long v = i / C8;
+    const int ox = (int)(v % W); v /= W;
+    const int oy = (int)(v % H); v /= H;
+    const int oz = (int)(v % D);
+    const long n = v / D;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const long src = (((n * (2 * D) + 2 * oz + (t >> 2)) * (2 * H) + 2 * oy + ((t >> 1) & 1)) * (2L * W) + 2 * ox + (t & 1));
+      float f[8];
+      unpack8<T>(*reinterpret_cast<const u32x4*>(dy + src * lddy + c), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += f[e];
+    }
+    const long dst = ((n * D + oz) * H + oy) * (long)W + ox;
+    if (accum) {
+      float old[8];
+      unpack8<T>(*reinterpret_cast<const u32x4*>(dx + dst * lddx + c), old);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += old[e];
+    }
+    *reinterpret_cast<u32x4*>(dx + dst * lddx + c) = pack8<T>(s);
+  }
+}
+static int lp_sampler_check(int dtype, const void* a, const void* b, int N, int D, int H, int W, int C, int lda, int ldb) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 != 0 || lda % 8 != 0 || ldb % 8 != 0 || lda < C || ldb < C) return BTS_ERR_SHAPE;
+  if ((((uintptr_t)a) & 15) || (((uintptr_t)b) & 15)) return BTS_ERR_ALIGN;
+  return BTS_OK;
+}
+static unsigned lp_sampler_blocks(long total8) { long b = (total8 + 255) / 256; return (unsigned)(b > 16384 ? 16384 : b); }
+// (D,H,W) = INPUT dims (even); y (N,D/2,H/2,W/2,C); idx (may be NULL: inference) dense uint8 (N,D/2,H/2,W/2,C)
+extern "C" int bts_lp_maxpool2_fwd(int dtype, const void* x, void* y, uint8_t* idx, int N, int D, int H, int W, int C, int ldx, int ldy,
+                                   hipStream_t stream) {
+  const int r = lp_sampler_check(dtype, x, y, N, D, H, W, C, ldx, ldy);
+  if (r != BTS_OK) return r;
+  if ((D | H | W) & 1) return BTS_ERR_SHAPE;
+  const long total8 = (long)N * (D / 2) * (H / 2) * (W / 2) * (C / 8);
+  (void)hipGetLastError();
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_maxpool2_fwd_kernel<TF16>, dim3(lp_sampler_blocks(total8)), dim3(256), 0, stream, (const unsigned short*)x, (unsigned short*)y, idx, total8, D / 2, H / 2, W / 2, C, ldx, ldy);
+  else hipLaunchKernelGGL(lp_maxpool2_fwd_kernel<TBF16>, dim3(lp_sampler_blocks(total8)), dim3(256), 0, stream, (const unsigned short*)x, (unsigned short*)y, idx, total8, D / 2, H / 2, W / 2, C, ldx, ldy);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+extern "C" int bts_lp_maxpool2_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int N, int D, int H, int W, int C, int lddy, int lddx,
+                                   int accumulate, hipStream_t stream) {
+  const int r = lp_sampler_check(dtype, dy, dx, N, D, H, W, C, lddy, lddx);
+  if (r != BTS_OK) return r;
+  if (((D | H | W) & 1) || idx == nullptr) return BTS_ERR_SHAPE;
+  const long total8 = (long)N * (D / 2) * (H / 2) * (W / 2) * (C / 8);
+  (void)hipGetLastError();
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_maxpool2_bwd_kernel<TF16>, dim3(lp_sampler_blocks(total8)), dim3(256), 0, stream, (const unsigned short*)dy, idx, (unsigned short*)dx, total8, D / 2, H / 2, W / 2, C, lddy, lddx, accumulate);
+  else hipLaunchKernelGGL(lp_maxpool2_bwd_kernel<TBF16>, dim3(lp_sampler_blocks(total8)), dim3(256), 0, stream, (const unsigned short*)dy, idx, (unsigned short*)dx, total8, D / 2, H / 2, W / 2, C, lddy, lddx, accumulate);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+// (D,H,W) = COARSE dims in both calls
+extern "C" int bts_lp_upsample2_fwd(int dtype, const void* x, void* y, int N, int D, int H, int W, int C, int ldx, int ldy, hipStream_t stream) {
+  const int r = lp_sampler_check(dtype, x, y, N, D, H, W, C, ldx, ldy);
+  if (r != BTS_OK) return r;
+  const long total8 = 8L * N * D * H * W * (C / 8);
+  (void)hipGetLastError();
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_upsample2_fwd_kernel<TF16>, dim3(lp_sampler_blocks(total8)), dim3(256), 0, stream, (const unsigned short*)x, (unsigned short*)y, total8, D, H, W, C, ldx, ldy);
+  else hipLaunchKernelGGL(lp_upsample2_fwd_kernel<TBF16>, dim3(lp_sampler_blocks(total8)), dim3(256), 0, stream, (const unsigned short*)x, (unsigned short*)y, total8, D, H, W, C, ldx, ldy);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+extern "C" int bts_lp_upsample2_bwd(int dtype, const void* dy, void* dx, int N, int D, int H, int W, int C, int lddy, int lddx, int accumulate,
+                                    hipStream_t stream) {
+  const int r = lp_sampler_check(dtype, dy, dx, N, D, H, W, C, lddy, lddx);
+  if (r != BTS_OK) return r;
+  const long total8 = (long)N * D * H * W * (C / 8);
+  (void)hipGetLastError();
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_upsample2_bwd_kernel<TF16>, dim3(lp_sampler_blocks(total8)), dim3(256), 0, stream, (const unsigned short*)dy, (unsigned short*)dx, total8, D, H, W, C, lddy, lddx, accumulate);
+  else hipLaunchKernelGGL(lp_upsample2_bwd_kernel<TBF16>, dim3(lp_sampler_blocks(total8)), dim3(256), 0, stream, (const unsigned short*)dy, (unsigned short*)dx, total8, D, H, W, C, lddy, lddx, accumulate);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
 // ---- output head (decoder.py:55-63): y = sigmoid(x . W + b), 1x1x1 conv to out_ch <= 4 channels, fp32 result (the label map
 // is taken from it, so it is never rounded to 16 bits).  One voxel per lane, weights in registers via scalar loads.
 template <typename T>

@@ -240,6 +240,42 @@ def head_bwd(code, tdt, x, dpre, w, dw, db, accumulate=True):
     return dx
 
 
+def maxpool2(code, x, want_idx=True):
+    """MaxPooling3D(2) on a 16-bit view (downsample.py:51-70) -> (y dense, idx uint8 or None)"""
+    n, d, h, w, c = x.shape
+    if (d | h | w) & 1:
+        raise ValueError('MaxDownsample needs even spatial sizes, got %s' % (tuple(x.shape),))
+    y = torch.empty((n, d // 2, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
+    idx = torch.empty(y.shape, dtype=torch.uint8, device=x.device) if want_idx else None
+    lib().call('bts_lp_maxpool2_fwd', code, _p(x), _p(y), _p(idx) if want_idx else None, n, d, h, w, c, _ld(x), _ld(y), _stream())
+    return y, idx
+
+
+def maxpool2_bwd(code, dy, idx, dx, accumulate):
+    n, d, h, w, c = dx.shape
+    lib().call('bts_lp_maxpool2_bwd', code, _p(dy), _p(idx), _p(dx), n, d, h, w, c, _ld(dy), _ld(dx), 1 if accumulate else 0, _stream())
+    return dx
+
+
+def upsample2(code, x, out=None):
+    """UpSampling3D(2) (nearest-neighbour repeat, upsample.py:69) of a 16-bit view into `out` (a view is fine)"""
+    n, d, h, w, c = x.shape
+    if out is None:
+        out = torch.empty((n, 2 * d, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
+    lib().call('bts_lp_upsample2_fwd', code, _p(x), _p(out), n, d, h, w, c, _ld(x), _ld(out), _stream())
+    return out
+
+
+def upsample2_bwd(code, dy, dx=None, accumulate=False):
+    """gradient of the repeat: sums of the 8 fine voxels of each coarse one (fp32 sums) -> dx (dense unless given)"""
+    n, d2, h2, w2, c = dy.shape
+    if dx is None:
+        dx = torch.empty((n, d2 // 2, h2 // 2, w2 // 2, c), dtype=dy.dtype, device=dy.device)
+    lib().call('bts_lp_upsample2_bwd', code, _p(dy), _p(dx), n, d2 // 2, h2 // 2, w2 // 2, c, _ld(dy), _ld(dx), 1 if accumulate else 0,
+               _stream())
+    return dx
+
+
 def head(code, x, w, bias, sigmoid=True):
     n, d, h, wd, c = x.shape
     k = w.shape[-1]
@@ -252,7 +288,9 @@ def head(code, x, w, bias, sigmoid=True):
 # ---- the forward graph -------------------------------------------------------------------------------------------------
 class LowPrecisionForward(object):
     """model(x, training=False, inference=True) with 16-bit storage: `LowPrecisionForward(model, 'float16')(x)` -> y_pred fp32
-    [N,D,H,W,out_ch] (model.py:63-68).  Default samplers (conv down / up-sampling) and channels_last public layout only."""
+    [N,D,H,W,out_ch] (model.py:63-68), or [N,out_ch,D,H,W] from NCDHW volumes for a model built with
+    data_format='channels_first' (args.py:121-123: memory stays NDHWC, GroupNorm takes its channel-group form).  Both sampler
+    families of args.py:136-141 (conv | max, conv | linear)."""
 
     def __init__(self, model, dtype='float16'):
         if dtype not in DTYPES:
@@ -260,16 +298,16 @@ class LowPrecisionForward(object):
         self.model = model
         self.code, self.tdt = DTYPES[dtype]
         self._packs = {}
-        from .layers.downsample import ConvDownsample
-        from .layers.upsample import ConvUpsample
+        from .layers.downsample import ConvDownsample, MaxDownsample
+        from .layers.upsample import ConvUpsample, LinearUpsample
+        self._max, self._linear = MaxDownsample, LinearUpsample
         for convs, down in model.encoder.levels:
-            if down is not None and not isinstance(down, ConvDownsample):
-                raise NotImplementedError('the 16-bit forward covers the default conv down-sampling only')
+            if down is not None and not isinstance(down, (ConvDownsample, MaxDownsample)):
+                raise NotImplementedError('unknown down-sampling layer %r' % type(down).__name__)
         for up, _ in model.decoder.levels:
-            if not isinstance(up, ConvUpsample):
-                raise NotImplementedError('the 16-bit forward covers the default conv up-sampling only')
-        if model.data_format != 'channels_last':
-            raise NotImplementedError('the 16-bit forward takes channels_last volumes')
+            if not isinstance(up, (ConvUpsample, LinearUpsample)):
+                raise NotImplementedError('unknown up-sampling layer %r' % type(up).__name__)
+        self.channels_first = model.data_format == 'channels_first'
 
     def _packed(self, key, kind, param, cin_ref, cout, cin_slab=None, dup_start=0, dup_shift=0):
         ent = self._packs.get(key)
@@ -312,11 +350,17 @@ class LowPrecisionForward(object):
                               blk.norm2._mode)
 
     def _down(self, lay, x):
+        if isinstance(lay, self._max):                                                   # downsample.py:51-70
+            return maxpool2(self.code, x, want_idx=False)[0]
         wp = self._packed((id(lay), 'f'), ops.K3S2, lay.conv_k, lay.cin, lay.filters)
         c = conv(ops.K3S2, self.code, self.tdt, x, wp, lay.conv_b.t, lay.filters)
         return self._gn(lay.norm, c, True)
 
     def _up(self, lay, x, out):
+        if isinstance(lay, self._linear):                                                # upsample.py:49-79: 1x1x1 conv, then repeat
+            wp = self._packed((id(lay), 'f'), ops.K1, lay.ptwise_k, lay.cin, lay.filters)
+            c = conv(ops.K1, self.code, self.tdt, x, wp, lay.ptwise_b.t, lay.filters)
+            return upsample2(self.code, c, out=out)
         wp = self._packed((id(lay), 'f'), ops.K3S2T, lay.conv_k, lay.cin, lay.filters)
         c = conv(ops.K3S2T, self.code, self.tdt, x, wp, lay.conv_b.t, lay.filters)
         return self._gn(lay.norm, c, True, out=out)
@@ -331,7 +375,10 @@ class LowPrecisionForward(object):
             if not torch.cuda.is_available():
                 raise RuntimeError('no MI355X visible: the engine has no CPU execution path')
             x = x.cuda()
-        x = x.float().contiguous()
+        x = x.float()
+        if self.channels_first:                       # raw NCDHW in (tape.as_tensor does the same for the fp32 engine)
+            x = x.permute(0, 2, 3, 4, 1)
+        x = x.contiguous()
         if any(s % (2 ** (m.encoder.depth - 1)) for s in x.shape[1:4]):
             raise ValueError('spatial sizes must be multiples of %d (test.py:164-178 pads to that)' % 2 ** (m.encoder.depth - 1))
         # the input volume in the storage type, zero-padded to one 16-channel matrix step (in_ch = 2: model.py:18)
@@ -364,4 +411,5 @@ class LowPrecisionForward(object):
             f = up.filters
             self._up(up, y, slab[..., cres:cres + f])                                     # decoder.py:72
             y = self._block(blk, slab[..., :cres + f], None)                              # decoder.py:75-78
-        return head(self.code, y, dec.out_k.t.reshape(dec.out_k.t.shape[-2], dec.out_k.t.shape[-1]), dec.out_b.t, True)
+        yp = head(self.code, y, dec.out_k.t.reshape(dec.out_k.t.shape[-2], dec.out_k.t.shape[-1]), dec.out_b.t, True)
+        return yp.permute(0, 4, 1, 2, 3) if self.channels_first else yp      # the public layout (a view, like Tensor.public())

@@ -190,6 +190,14 @@ class LowPrecisionTrainer(object):
             conv_bwd_data(ops.K1, code, dres_16, wpbp, dx, True)
 
     def _sampler_fwd(self, lay, kind, x, out=None):
+        if isinstance(lay, self.fwd._max):                   # MaxPooling3D(2) (downsample.py:51-70): no parameters, channels kept
+            y, idx = lowp.maxpool2(self.code, x)
+            return y, dict(lay=lay, kind='max', idx=idx)
+        if isinstance(lay, self.fwd._linear):                # 1x1x1 conv, then nearest-neighbour repeat (upsample.py:49-79)
+            wp = self._pk((id(lay), 'f'), ops.K1, lay.ptwise_k, lay.cin, lay.filters)
+            c = conv(ops.K1, self.code, self.tdt, x, wp, lay.ptwise_b.t, lay.filters)
+            y = lowp.upsample2(self.code, c, out=out)
+            return y, dict(lay=lay, kind='linear', x=x)
         wp = self._pk((id(lay), 'f'), kind, lay.conv_k, lay.cin, lay.filters)
         c = conv(kind, self.code, self.tdt, x, wp, lay.conv_b.t, lay.filters)
         m, r = gn_stats(self.code, c, lay.norm.groups, lay.norm._mode, lay.norm.epsilon)
@@ -200,6 +208,12 @@ class LowPrecisionTrainer(object):
         """ConvDownsample / ConvUpsample backward (downsample.py:41-45, upsample.py:39-43): GN(+ReLU) gradient, weight gradient,
         data gradient into dx (None: not needed).  cin_live: real input channels when the input was zero-padded to 16"""
         lay, kind = s['lay'], s['kind']
+        if kind == 'max':
+            if dx is not None:
+                lowp.maxpool2_bwd(self.code, dy, s['idx'], dx, accumulate)
+            return
+        if kind == 'linear':
+            return self._linear_bwd(s, dy, dx, accumulate, cin_live)
         nrm = lay.norm
         x = s['x'] if cin_live is None else s['x'][..., :cin_live]
         cout = s['c'].shape[-1]
@@ -226,6 +240,27 @@ class LowPrecisionTrainer(object):
             wpb = self._pk((id(lay), 'b'), kind, lay.conv_k, lay.cin, lay.filters, role=ops.ROLE_BWD)
             conv_bwd_data(kind, self.code, dc16, wpb, dx, accumulate)
 
+    def _linear_bwd(self, s, dy, dx, accumulate, cin_live):
+        """LinearUpsample backward (upsample.py:49-79 under autodiff): the repeat's gradient (sums of 8 fine voxels, fp32 sums),
+        then the 1x1x1 conv's weight, bias and data gradients"""
+        lay = s['lay']
+        f = lay.filters
+        fp = (f + 15) // 16 * 16                              # (the contraction of the data gradient steps over 16 channels)
+        x = s['x'] if cin_live is None else s['x'][..., :cin_live]
+        n, d2, h2, w2 = dy.shape[:4]
+        buf = (torch.zeros if fp != f else torch.empty)((n, d2 // 2, h2 // 2, w2 // 2, fp), dtype=self.tdt, device=dy.device)
+        dc16 = lowp.upsample2_bwd(self.code, dy, dx=buf[..., :f])
+        if cin_live is None and fp == f and lowp.wgrad_supported(ops.K1, x.shape[-1], f):
+            self._wg((x, dc16), lambda: lowp.conv_bwd_weight(ops.K1, self.code, x, dc16, self._gslot(lay.ptwise_k), self._gslot(lay.ptwise_b),
+                                                             accumulate=True))
+        else:
+            x32, dc = self._f32(x), self._f32(dc16)
+            self._wg((x32, dc), lambda: ops.conv_bwd_weight(ops.K1, x32, dc, self._gslot(lay.ptwise_k), self._gslot(lay.ptwise_b),
+                                                            accumulate=True))
+        if dx is not None:
+            wpb = self._pk((id(lay), 'b'), ops.K1, lay.ptwise_k, lay.cin, f, role=ops.ROLE_BWD)
+            conv_bwd_data(ops.K1, self.code, buf, wpb, dx, accumulate)
+
     # ================================================================================================================
     # the step
     # ================================================================================================================
@@ -239,15 +274,21 @@ class LowPrecisionTrainer(object):
         if not torch.is_tensor(y):
             y = torch.as_tensor(y)
         dev = torch.device('cuda', torch.cuda.current_device())
-        x = x.to(dev).float().contiguous()
-        y = y.to(dev).float().contiguous()
+        x, y = x.to(dev).float(), y.to(dev).float()
+        cf = m.data_format == 'channels_first'
+        if cf:          # raw NCDHW volumes -> the engine's NDHWC memory (tape.as_tensor does the same for the fp32 step)
+            x, y = x.permute(0, 2, 3, 4, 1), y.permute(0, 2, 3, 4, 1)
+        x, y = x.contiguous(), y.contiguous()
         n = x.shape[0]
         ops.fill(m.flat_grads, 0.0)
         # ------------------------------------------------ forward ------------------------------------------------
         xin = x
         if enc.dropout_rate > 0:                                                      # encoder.py:39,71
             if enc._mask is not None:
-                msk = (torch.as_tensor(enc._mask) != 0).to(torch.uint8).to(dev).contiguous()
+                msk = torch.as_tensor(enc._mask)
+                if cf and msk.dim() == 5:                                             # (an injected mask is in the public layout)
+                    msk = msk.permute(0, 2, 3, 4, 1)
+                msk = (msk != 0).to(torch.uint8).to(dev).contiguous()
                 enc._mask = None
             else:
                 enc._seed += 1
@@ -322,7 +363,7 @@ class LowPrecisionTrainer(object):
         lt, _ = ops.loss_value(sums, c, True)
         l2v = ops.l2_reg_fwd(m.flat_params, m._l2_ranges) if m._l2_ranges else None
         loss_t = ops.scalar_lincomb(lt, l2v, 1.0, 1.0) if l2v is not None else lt
-        macro, micro = dice_fn(y, Tensor(y_pred, requires_grad=False))
+        macro, micro = dice_fn(Tensor(y, requires_grad=False), Tensor(y_pred, requires_grad=False))     # (engine layout already)
         self.last_labels = dice_fn.last_labels
         # ------------------------------------------------ backward ------------------------------------------------
         one = torch.ones(1, dtype=torch.float32, device=dev)

@@ -305,6 +305,16 @@ int bts_lp_se_bwd(int dtype, const void* dout, const void* res, const float* sp,
                   const float* w1, const float* w2, const float* wsp, void* dres, float* ds, float* dgap, float* dw1, float* dw2, float* dwsp,
                   void* workspace, long workspace_bytes, int N, long V, int F, int R, int lddo, int accumulate_params, float* dbias,
                   bts_stream_t stream);
+/* the non-default samplers on 16-bit tensors (args.py:136-141): MaxPooling3D(2) (downsample.py:51-70; (D,H,W) = INPUT dims, idx the
+ * window position of the first maximum per output element, NULL when no gradient is wanted) and UpSampling3D(2) (upsample.py:69;
+ * (D,H,W) = COARSE dims), with their gradients; C % 8 == 0, channel-slice views allowed */
+int bts_lp_maxpool2_fwd(int dtype, const void* x, void* y, uint8_t* idx, int N, int D, int H, int W, int C, int ldx, int ldy,
+                        bts_stream_t stream);
+int bts_lp_maxpool2_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int N, int D, int H, int W, int C, int lddy, int lddx,
+                        int accumulate, bts_stream_t stream);
+int bts_lp_upsample2_fwd(int dtype, const void* x, void* y, int N, int D, int H, int W, int C, int ldx, int ldy, bts_stream_t stream);
+int bts_lp_upsample2_bwd(int dtype, const void* dy, void* dx, int N, int D, int H, int W, int C, int lddy, int lddx, int accumulate,
+                         bts_stream_t stream);
 /* output head (decoder.py:55-63): y = sigmoid(x . W + b), W (C, K <= 4) fp32, y fp32 (the label map is taken from it) */
 int bts_lp_head(int dtype, const void* x, const float* w, const float* bias, float* y, long nvox, int C, int ldx, int K, int sigmoid,
                 bts_stream_t stream);

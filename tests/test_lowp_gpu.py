@@ -515,3 +515,53 @@ def test_backward_apply_passes_emit_the_producing_convs_bias_gradient(dtype):
     u = U[dtype]
     tol = u * float(dres.double().abs().sum(dim=(0, 1, 2, 3)).max()) / (n * d * h * w) ** 0.5 * 8 + 1e-4
     assert float((db2.double().cpu() - want2).abs().max()) <= tol
+
+
+# ---- the non-default samplers on 16-bit tensors (args.py:136-141) ---------------------------------------------------------------
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('shape,view', [((2, 8, 12, 20, 32), None), ((1, 4, 6, 10, 24), (8, 16)), ((1, 16, 16, 16, 8), None)])
+def test_maxpool2_and_its_gradient_are_exact(dtype, shape, view):
+    """MaxPooling3D(2) selects stored values: bit-exact against torch on the same 16-bit tensor, ties included (values drawn from a
+    small set); the gradient lands on the first maximum in scan order like the fp32 engine's kernel"""
+    from bts_amd import lowp, ops
+    code, tdt = lowp.DTYPES[dtype]
+    g = torch.Generator().manual_seed(5)
+    n, d, h, w, c = shape
+    full = (torch.randint(-6, 7, shape, generator=g).float() * 0.25).to(tdt).cuda()
+    x = full if view is None else full[..., view[0]:view[0] + view[1]]
+    y, idx = lowp.maxpool2(code, x)
+    ref = torch.nn.functional.max_pool3d(x.float().permute(0, 4, 1, 2, 3), 2).permute(0, 2, 3, 4, 1)
+    assert torch.equal(y.float(), ref)
+    y2, none = lowp.maxpool2(code, x, want_idx=False)
+    assert none is None and torch.equal(y2, y)
+    # against the fp32 engine's kernel (same first-maximum rule)
+    y32, idx32 = ops.maxpool2_fwd(x.float().contiguous())
+    assert torch.equal(idx, idx32) and torch.equal(y.float(), y32)
+    dy = (torch.randint(-8, 9, tuple(y.shape), generator=g).float() * 0.125).to(tdt).cuda()
+    dx = torch.full(tuple(x.shape), 1.0, dtype=tdt, device='cuda')
+    lowp.maxpool2_bwd(code, dy, idx, dx, True)
+    dref = torch.zeros(tuple(x.shape), dtype=torch.float32, device='cuda')
+    ops.maxpool2_bwd(dy.float(), idx32, dref, False)
+    assert torch.equal(dx.float(), dref + 1.0)
+    lowp.maxpool2_bwd(code, dy, idx, dx, False)
+    assert torch.equal(dx.float(), dref)
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+def test_upsample2_and_its_gradient(dtype):
+    from bts_amd import lowp
+    code, tdt = lowp.DTYPES[dtype]
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn((2, 4, 6, 10, 24), generator=g).to(tdt).cuda()
+    slab = torch.zeros((2, 8, 12, 20, 64), dtype=tdt, device='cuda')
+    lowp.upsample2(code, x, out=slab[..., 16:40])
+    ref = x.repeat_interleave(2, 1).repeat_interleave(2, 2).repeat_interleave(2, 3)
+    assert torch.equal(slab[..., 16:40], ref) and float(slab[..., :16].abs().max()) == 0 and float(slab[..., 40:].abs().max()) == 0
+    dy = torch.randn((2, 8, 12, 20, 64), generator=g).to(tdt).cuda()
+    dx = lowp.upsample2_bwd(code, dy[..., 16:40])
+    r = dy[..., 16:40].float().reshape(2, 4, 2, 6, 2, 10, 2, 24).sum(dim=(2, 4, 6))
+    assert torch.equal(dx, r.to(tdt))           # fp32 sum of 8 stored values, rounded once
+    old = torch.randn(tuple(dx.shape), generator=g).to(tdt).cuda()
+    acc = old.clone()
+    lowp.upsample2_bwd(code, dy[..., 16:40], dx=acc, accumulate=True)
+    assert float((acc.float() - (r + old.float())).abs().max()) <= 2.0 ** (-7 if dtype == 'bfloat16' else -10) * float(r.abs().max() + 3)

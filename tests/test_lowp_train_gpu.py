@@ -12,14 +12,14 @@ CROP = (32, 32, 32)
 N = 2
 
 
-def _setup(seed=3):
+def _setup(seed=3, **model_kw):
     import bts_amd  # noqa: F401
     from bts_amd.data import synthetic_batch
     from bts_amd.layers import _base
     from bts_amd.model import Model
     from bts_amd.tape import bump_weights_epoch
     _base.set_seed(seed)
-    m = Model(**KW)
+    m = Model(**dict(KW, **model_kw))
     m.build((N,) + CROP + (2,))
     g = torch.Generator().manual_seed(seed + 1)
     for p in m.trainable_variables:
@@ -120,3 +120,106 @@ def test_bf16_training_tracks_the_fp32_trajectory():
     # (lr 1e-3, ten times the default: Adam's early steps are ~lr*sign(g), so rounding noise in small gradients moves the two runs
     #  apart by up to ~1 % of the loss on the way down; measured: 1.64430/1.64448 ... 1.19224/1.18136 ... 1.02990/1.02862)
     assert all(abs(a - b) <= 2e-2 * abs(b) for a, b in zip(runs['bf16'], runs['fp32']))
+
+
+# ---- the non-default options of args.py:121-141 on the 16-bit step ---------------------------------------------------
+OPTIONS = [dict(data_format='channels_first'), dict(downsampling='max', upsampling='linear'),
+           dict(data_format='channels_first', downsampling='max', upsampling='linear')]
+
+
+def _public(t, cf):
+    return t.permute(0, 4, 1, 2, 3).contiguous() if cf else t
+
+
+# fp16 storage pins the GRAPH of every option (the same bounds as the default graph's fp16 case).  bf16 storage is bounded like the
+# default graph where the activations stay normalised (channels_first; the linear up-sampler).  Max pooling is followed by no
+# normalisation: the untrained net's encoder activations grow to ~2e2 by the top level (scripts/lp_opts_debug.py prints them), bf16's 8
+# bits leave ~3 % of that at single voxels, and the gradient of that ill-conditioned net moves accordingly -- measured rel L2 0.10
+# (max + linear) and 1.1-1.7 (channels_first + max), against 0.02 in fp16 on the same graph: stated, bounded only where it is small.
+STEP_LIMITS = {'float16': dict(loss=5e-4, l2=0.04, cos=0.999, var_cos=0.99, labels=1e-2),
+               'float16-max': dict(loss=5e-4, l2=0.07, cos=0.998, var_cos=0.9, labels=1e-2),
+               'bfloat16': dict(loss=5e-3, l2=0.12, cos=0.99, var_cos=0.97, labels=1e-2),
+               'bfloat16-max': dict(loss=5e-3, l2=0.15, cos=0.99, var_cos=0.90, labels=2e-2),
+               'bfloat16-cf-max': dict(loss=5e-3, l2=None, cos=None, var_cos=None, labels=2e-2)}
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('opts', OPTIONS, ids=lambda o: '-'.join('%s' % v for v in o.values()))
+def test_options_step_against_the_fp32_engine(opts, dtype):
+    """channels_first (NCDHW volumes in, GroupNorm over true channel groups, per-class Dice), MaxPooling3D down-sampling and
+    1x1x1-conv + repeat up-sampling through the 16-bit-storage step"""
+    key = dtype
+    if opts.get('downsampling') == 'max':
+        key = dtype + ('-cf-max' if (dtype == 'bfloat16' and opts.get('data_format') == 'channels_first') else '-max')
+    lim = STEP_LIMITS[key]
+    from bts_amd.lowp_train import LowPrecisionTrainer
+    from bts_amd.tape import bump_weights_epoch
+    from bts_amd.util import DiceCoefficient, DiceVAELoss, ScheduledOptim, train_step
+    m, x, y, mask, eps = _setup(seed=5, **opts)
+    df = opts.get('data_format', 'channels_last')
+    cf = df == 'channels_first'
+    x, y, mask = _public(x, cf), _public(y, cf), _public(mask, cf)
+    start = m.flat_params.clone()
+    opt = ScheduledOptim(1e-4)
+    opt(epoch=0)
+    m.encoder.set_dropout_mask(mask)
+    m.vae.set_eps(eps)
+    d32 = DiceCoefficient(data_format=df)
+    loss32, macro32, micro32 = train_step(m, opt, DiceVAELoss(data_format=df), d32, x, y)
+    torch.cuda.synchronize()
+    g32, p32, lab32 = m.flat_grads.clone(), m.flat_params.clone(), d32.last_labels.clone()
+    m.flat_params.copy_(start)
+    bump_weights_epoch()
+    opt2 = ScheduledOptim(1e-4)
+    opt2(epoch=0)
+    m.encoder.set_dropout_mask(mask)
+    m.vae.set_eps(eps)
+    tr = LowPrecisionTrainer(m, dtype)
+    d16 = DiceCoefficient(data_format=df)
+    loss16, macro16, micro16 = tr.step(opt2, d16, x, y)
+    torch.cuda.synchronize()
+    g16, p16 = m.flat_grads.clone(), m.flat_params.clone()
+    dl = abs(float(loss16) - float(loss32)) / abs(float(loss32))
+    rel = float((g16 - g32).norm() / g32.norm())
+    cos = float(torch.dot(g16, g32) / (g16.norm() * g32.norm()))
+    mism = float((d16.last_labels != lab32).float().mean())
+    worst = (2.0, '')
+    tot = float(g32.norm())
+    for p in m.trainable_variables:
+        off = (p._gview.data_ptr() - m.flat_grads.data_ptr()) // 4
+        a, b = g16[off:off + p._gview.numel()], g32[off:off + p._gview.numel()]
+        if float(b.norm()) >= 0.02 * tot:
+            worst = min(worst, (float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)), p.name))
+    moved = float((p32 - start).abs().max())
+    dpar = float((p16 - p32).abs().max())
+    print('%s %s: loss %.6f vs %.6f (rel %.2e), macro Dice %.5f vs %.5f, micro %.5f vs %.5f, label changes %.3f %%; gradient rel L2 %.3e '
+          'cosine %.6f; worst heavy variable cosine %.4f (%s)' % (opts, dtype, float(loss16), float(loss32), dl, float(macro16), float(macro32),
+                                                                  float(micro16), float(micro32), 100 * mism, rel, cos, worst[0], worst[1]))
+    assert dl <= lim['loss'] and abs(float(macro16) - float(macro32)) <= 5e-3 and mism <= lim['labels']
+    if lim['l2'] is not None:
+        assert rel <= lim['l2'] and cos >= lim['cos'] and worst[0] >= lim['var_cos']
+    assert dpar <= 2.0 * moved
+    # every parameter of the optional layers received a gradient (none was skipped by the explicit backward)
+    for p in m.trainable_variables:
+        off = (p._gview.data_ptr() - m.flat_grads.data_ptr()) // 4
+        n32 = float(g32[off:off + p._gview.numel()].norm())
+        if n32 > 1e-10:
+            assert float(g16[off:off + p._gview.numel()].norm()) > 0.0, p.name
+
+
+@pytest.mark.parametrize('dtype,tol', [('float16', (2e-2, 1e-3, 0.15, 1e-3)), ('bfloat16', (1.6e-1, 4e-3, 0.9, 8e-3))])
+@pytest.mark.parametrize('opts', OPTIONS, ids=lambda o: '-'.join('%s' % v for v in o.values()))
+def test_options_forward_against_the_fp32_engine(opts, dtype, tol):
+    """inference graph (lowp.LowPrecisionForward) under the options: (max, mean) |dy_pred| bounds -- the default graph's where the
+    activations stay normalised, wider single-voxel bounds behind max pooling (see STEP_LIMITS above; the mean stays small)"""
+    from bts_amd.lowp import LowPrecisionForward
+    m, x, y, mask, eps = _setup(seed=6, **opts)
+    cf = opts.get('data_format', 'channels_last') == 'channels_first'
+    x = _public(x, cf)
+    ref = m(x, training=False, inference=True)[0].public()
+    got = LowPrecisionForward(m, dtype)(x)
+    assert tuple(got.shape) == tuple(ref.shape)
+    err, mean = float((got - ref).abs().max()), float((got - ref).abs().mean())
+    print('%s %s: |dy_pred| max %.3e mean %.3e' % (opts, dtype, err, mean))
+    mx_tol, mean_tol = tol[2:] if opts.get('downsampling') == 'max' else tol[:2]
+    assert err <= mx_tol and mean <= mean_tol
