@@ -29,18 +29,33 @@ need() {  # need <dir> <file name>: the one CSV a pass must have produced, non-e
 # than the step -- it is the evidence that the streams do overlap, not a per-kernel table.
 rm -rf "$O/prof_$TAG"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$TAG" -o bench -- \
-  python3 "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-profile --serial-streams > "$O/prof_$TAG.log" 2>&1
+  python3 "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-profile --no-also --serial-streams > "$O/prof_$TAG.log" 2>&1
 cp "$(need "$O/prof_$TAG" bench_kernel_stats.csv)" "$O/${TAG}_bench_kernel_stats.csv"
 rm -rf "$O/prof_${TAG}_ms"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_${TAG}_ms" -o bench -- \
-  python3 "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-profile > "$O/prof_${TAG}_ms.log" 2>&1
+  python3 "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-profile --no-also > "$O/prof_${TAG}_ms.log" 2>&1
 cp "$(need "$O/prof_${TAG}_ms" bench_kernel_stats.csv)" "$O/${TAG}_bench_multistream_kernel_stats.csv"
+
+# the 16-bit configurations (BASELINE configs[2]: bf16 storage, batch 8; configs[4]: fp16 full-volume inference): their own bench
+# lines and one-stream kernel tables
+python3 "$R/bench.py" --dtype bf16 --batch 8 --steps 5 --warmup 2 --no-cpu-baseline --no-also > "$O/${TAG}_train_bf16_b8.json" 2> "$O/${TAG}_train_bf16_b8.err"
+cut -c1-300 "$O/${TAG}_train_bf16_b8.json"
+python3 "$R/bench.py" --infer --dtype f16 --steps 10 --warmup 3 --no-cpu-baseline --no-also > "$O/${TAG}_infer_f16.json" 2> "$O/${TAG}_infer_f16.err"
+cut -c1-300 "$O/${TAG}_infer_f16.json"
+rm -rf "$O/prof_${TAG}_bf16"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_${TAG}_bf16" -o bench -- \
+  python3 "$R/bench.py" --dtype bf16 --batch 8 --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-also --serial-streams > "$O/prof_${TAG}_bf16.log" 2>&1
+cp "$(need "$O/prof_${TAG}_bf16" bench_kernel_stats.csv)" "$O/${TAG}_train_bf16_b8_kernel_stats.csv"
+rm -rf "$O/prof_${TAG}_inf"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_${TAG}_inf" -o bench -- \
+  python3 "$R/bench.py" --infer --dtype f16 --steps 5 --warmup 2 --no-cpu-baseline --no-profile --no-also > "$O/prof_${TAG}_inf.log" 2>&1
+cp "$(need "$O/prof_${TAG}_inf" bench_kernel_stats.csv)" "$O/${TAG}_infer_f16_kernel_stats.csv"
 
 for pass in fetch:FETCH_SIZE write:WRITE_SIZE; do
   name=${pass%%:*}; ctr=${pass##*:}
   rm -rf "$O/pmc_${TAG}_$name"
   rocprofv3 --kernel-trace --pmc "$ctr" --output-format csv -d "$O/pmc_${TAG}_$name" -o "$name" -- \
-    python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-profile --serial-streams > "$O/pmc_${TAG}_$name.log" 2>&1
+    python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-also --serial-streams > "$O/pmc_${TAG}_$name.log" 2>&1
   need "$O/pmc_${TAG}_$name" "${name}_counter_collection.csv" > /dev/null
 done
 
