@@ -1048,13 +1048,20 @@ __global__ __launch_bounds__(WGW_THREADS, 1) void wgw_kernel(const WgradParams p
       o.u2 = wgw_sub4(o.a0, o.a1);
       if (bias) bsum += (double)((o.u1[0] + o.u1[1]) + (o.u1[2] + o.u1[3]));   // wave 1: the four Q rows of this lane's own 4 x
     }
+    // window 3 and 8 (the x neighbours of the quad).  Thirty-two lanes reading ONE column of 32 channel rows with 4-byte reads hit
+    // 8 banks (the row stride is a multiple of 4 floats; 4-byte reads bank on 32): those 4-way conflicts on eight reads per step
+    // were 45 % of this kernel's LDS cycles (profiles/r02e_pmc_wino.txt).  Read the neighbouring CELLS with 16-byte reads instead
+    // (conflict-free like the middle quad's: 16 lanes x 16 bytes cover the 64 banks once) and use one element of each.
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {  // window 3 and 8 (the x neighbours of the quad)
-      const int off = e == 0 ? 3 : 8;
-      const float x0s = qb[qX + off], x1s = qb[qX + 32 * WGW_QSTR + off];
-      const float y0s = qb[(4 * 32) * WGW_QSTR + off], y1s = qb[(5 * 32) * WGW_QSTR + off];
-      o.a0s[e] = fmaf(y0s, sq, x0s);
-      o.a1s[e] = fmaf(y1s, sq, x1s);
+    for (int e = 0; e < 2; ++e) {
+      const int off = e == 0 ? 0 : 8, el = e == 0 ? 3 : 0;
+      f32x4 xs0 = *reinterpret_cast<const f32x4*>(qb + qX + off);
+      f32x4 xs1 = *reinterpret_cast<const f32x4*>(qb + qX + 32 * WGW_QSTR + off);
+      f32x4 ys0 = *reinterpret_cast<const f32x4*>(qb + (4 * 32) * WGW_QSTR + off);
+      f32x4 ys1 = *reinterpret_cast<const f32x4*>(qb + (5 * 32) * WGW_QSTR + off);
+      asm volatile("" : "+v"(xs0), "+v"(xs1), "+v"(ys0), "+v"(ys1));     // (keeps the four reads 16 bytes wide)
+      o.a0s[e] = fmaf(ys0[el], sq, xs0[el]);
+      o.a1s[e] = fmaf(ys1[el], sq, xs1[el]);
       o.u1s[e] = o.a0s[e] + o.a1s[e];
       o.u2s[e] = o.a0s[e] - o.a1s[e];
     }
