@@ -2128,6 +2128,10 @@ int bts_lp_wgrad_finalize_(const float* part, float* dw, int nwg, int ncp, int n
 long bts_lp_wgs_workspace_(int N, int Dc, int Hc, int Wc, int Cp, int Cq);
 int bts_lp_wgs_launch_(int dtype, const void* P, const void* Q, float* dw, void* ws, long ws_bytes, int N, int Df, int Hf, int Wf, int Dc, int Hc,
                        int Wc, int Cp, int ldp, int Cq, int ldq, int accum, hipStream_t stream);
+// lowp_wgd.hip: the streaming weight-gradient kernel of the stride-1 3x3x3 convolutions with Cout <= 32
+long bts_lp_wgd_workspace_(int N, int D, int H, int W, int Cp, int Cq);
+int bts_lp_wgd_launch_(int dtype, const void* x, const void* dy, float* dw, void* ws, long ws_bytes, int N, int D, int H, int W, int Cp, int ldp,
+                       int Cq, int ldq, int dup_start, int dup_shift, int accum, hipStream_t stream);
 // db[k] (+)= sum_n colsum[n][k]
 __global__ void lp_bias_grad_kernel(const float* cs, float* db, int N, int C, int accum) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2162,7 +2166,12 @@ extern "C" long bts_lp_conv3d_bwd_weight_workspace(int kind, int N, int D, int H
   int nq, nwg, ncp, ncqg; long ntiles;
   lp_wg_plan(kind, N, D, H, W, Cin, Cout, nq, nwg, ntiles, ncp, ncqg);
   const int nslot = kind == BTS_CONV_K3S1 ? 27 : 8;
-  return (long)nwg * ncp * ncqg * nslot * 32 * 32 * nq * 4 + (long)N * ((Cout + 7) / 8 * 8) * 4 + bts_lp_colsum_workspace(N, (long)D * H * W, (Cout + 7) / 8 * 8) + 256;
+  long part = (long)nwg * ncp * ncqg * nslot * 32 * 32 * nq * 4;
+  if (kind == BTS_CONV_K3S1) {          // (the streaming kernel's slabs sit in the same place; one per workgroup too)
+    const long alt = bts_lp_wgd_workspace_(N, D, H, W, Cin, Cout);
+    if (alt > part) part = alt;
+  }
+  return part + (long)N * ((Cout + 7) / 8 * 8) * 4 + bts_lp_colsum_workspace(N, (long)D * H * W, (Cout + 7) / 8 * 8) + 256;
 }
 // dw (Keras layout (kd,kh,kw,Cin_ref,Cout), fp32) (+)= the weight gradient; db (may be NULL) (+)= sum of dy over voxels and samples.
 // x (N,D,H,W,Cin) stride ldx, dy (N,D,H,W,Cout) DENSE when db is wanted; Cin, Cout multiples of 8.  K3S1 and K1 only (-3 otherwise).
@@ -2207,6 +2216,19 @@ extern "C" int bts_lp_conv3d_bwd_weight(int kind, int dtype, const void* x, cons
   LpWgParams p;
   int nq, nwg;
   lp_wg_plan(kind, N, D, H, W, Cin, Cout, nq, nwg, p.ntiles, p.ncp, p.ncqg);
+  long part_bytes = (long)nwg * p.ncp * p.ncqg * (kind == BTS_CONV_K3S1 ? 27 : 8) * 32 * 32 * nq * 4;
+  bool streamed = false;
+  if (kind == BTS_CONV_K3S1) {          // few output channels at a large volume: the streaming kernel (lowp_wgd.hip), else the general one
+    const long alt = bts_lp_wgd_workspace_(N, D, H, W, Cin, Cout);
+    if (alt > 0) {
+      const int r = bts_lp_wgd_launch_(dtype, x, dy, dw, workspace, alt > part_bytes ? alt : part_bytes, N, D, H, W, Cin, ldx, Cout, lddy, dup_start,
+                                       dup_shift, accumulate, stream);
+      if (r < 0) return r;
+      streamed = r == BTS_OK;
+      if (alt > part_bytes) part_bytes = alt;
+    }
+  }
+  if (!streamed) {
   p.p = (const unsigned short*)x; p.q = (const unsigned short*)dy; p.part = reinterpret_cast<float*>(workspace);
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cp = Cin; p.ldp = ldx; p.Cq = Cout; p.ldq = lddy; p.ntaps = kind == BTS_CONV_K3S1 ? 27 : 1;
   p.ntx = (W + LPW_TX - 1) / LPW_TX; p.nty = (H + LPW_TY - 1) / LPW_TY; p.ntz = (D + LPW_TZ - 1) / LPW_TZ;
@@ -2244,9 +2266,10 @@ extern "C" int bts_lp_conv3d_bwd_weight(int kind, int dtype, const void* x, cons
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(lp_wgrad_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, f);
   BTS_LAUNCH_CHECK();
+  }
   if (db != nullptr) {
     if (lddy != Cout) return BTS_ERR_UNSUPPORTED;
-    char* wsb = reinterpret_cast<char*>(workspace) + (long)nwg * p.ncp * p.ncqg * f.nslot * 32 * 32 * nq * 4;
+    char* wsb = reinterpret_cast<char*>(workspace) + part_bytes;
     float* cs = reinterpret_cast<float*>(wsb);
     void* cws = wsb + (((long)N * Cout * 4 + 255) & ~255L);
     const int r = bts_lp_colsum(dtype, dy, cs, cws, bts_lp_colsum_workspace(N, (long)D * H * W, Cout), N, (long)D * H * W, Cout, 1.0f, stream);

@@ -1,0 +1,374 @@
+// Weight gradient of the stride-1 3x3x3 convolutions with FEW output channels (Cout <= 32: the 128^3 level of the CLI model) on
+// 16-bit operands -- what TF autodiff derives for the Conv3D kernels of resnet.py:80-87,96-103 and vae.py:92-99 under
+// train.py:142-151:   dW[t][c][k] = sum_v P[v + off_t][c] * Q[v][k],   P = the conv's input, Q = the gradient of its output.
+//
+// At 32 x 32 channels the arithmetic intensity of this contraction (27 taps x 2 x 32 x 32 flops per 128 operand bytes = 432 flop/B)
+// sits just below the machine balance (2.5 PFLOP/s : ~5 TB/s): the layer is bound by reading P and Q ONCE.  lowp.hip's general
+// kernel (register staging with a 2-byte interleave, 16 x 8 x 4 tiles whose 18 x 10 x 6 halo re-reads P 2.1 times, two idle waves)
+// ran it at 0.79 PFLOP/s = 0.43 of that bound.  This kernel is built to stream:
+//   * a workgroup owns a 32 (x) x 8 (y) column and marches along z: every stage brings ONE plane of P (34 x 10 voxels: the x/y halo is
+//     the only re-read, 1.33x) and one plane of Q; the three z taps come from a ring of Q planes that stay in LDS.  Planes are
+//     requested TWO stages ahead (3 P buffers + 5 Q slots = 155 KB of LDS: ~76 KB per CU in flight -- with one stage ahead the
+//     kernel ran at 2.2 TB/s, bound by the bytes in flight over the memory latency);
+//   * the planes go global -> LDS by buffer_load ... lds (no registers, no staging instructions), as they lie in memory: [voxel][32
+//     channels]; out-of-range voxels ('same' padding, planes outside the item) are requests with an out-of-range offset = zeros;
+//   * the contraction runs over voxels, so both matrix operands need a transpose: ds_read_b64_tr_b16 does it on the way out of LDS (a
+//     16-lane group pointing at [4 voxels][16 channels] receives, per lane, one channel's four voxels).  The two 16-byte pieces of a
+//     voxel's channel half are swapped on every other 8-voxel block (chosen by the DMA's per-lane global address), which makes the
+//     32 lanes served per LDS cycle cover the 64 banks exactly once;
+//   * v_mfma_f32_16x16x32: a wave owns ONE 16 x 16 (cin x cout) block of all 27 taps (108 accumulation registers) for half of the
+//     column's rows -- 8 waves = 2 cin halves x 2 cout halves x 2 row halves, every SIMD equally loaded.  A P fragment (one row, one
+//     x tap) meets the 3 x 3 (z, y) neighbourhood of Q fragments: 60 transposing reads per 108 matrix instructions;
+//   * the two row halves meet in LDS at the end: one fp32 partial slab per workgroup in the layout of lowp.hip's fixed-order finalize.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+#include "bts_internal.h"
+#include "lowp_common.h"
+
+int bts_prof_on();
+void bts_prof_begin(int sym, double flops, hipStream_t stream);
+void bts_prof_end(hipStream_t stream);
+int bts_lp_wgrad_finalize_(const float* part, float* dw, int nwg, int ncp, int ncqg, int nslot, int ntaps, int NQ, int Cp, int Cq, int Cin_ref,
+                           int dup_start, int dup_shift, int accum, hipStream_t stream);
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <int V> using WgdIC = std::integral_constant<int, V>;
+
+struct LpWgdParams {
+  const unsigned short* p;   // (N, D, H, W, Cp) voxel stride ldp
+  const unsigned short* q;   // (N, D, H, W, Cq <= 32) voxel stride ldq
+  float* part;               // [workgroup][cp block][27 taps][32][32]
+  int N, D, H, W, Cp, ldp, Cq, ldq;
+  int ntx, nty, nzc, ZC;     // columns per sample (x, y), z chunks per column, planes per chunk
+  int nitems, ipw, ncp, xcd_order;
+};
+#define WGD_TX 32
+#define WGD_TY 8
+#define WGD_PROW 2560                       // bytes of a P row in LDS: 40 voxel slots x 64 B (34 in use)
+#define WGD_PPL (10 * WGD_PROW)             // a P plane: rows y0 - 1 .. y0 + 8 = 400 slots = 25 requests of 16
+#define WGD_QROW 2048
+#define WGD_QPL (WGD_TY * WGD_QROW)
+#define WGD_NPB 3                           // P planes in LDS: the stage's and the next two in flight
+#define WGD_NQS 5                           // Q planes in LDS: the stage's three and the next two in flight
+#define WGD_QBASE (WGD_NPB * WGD_PPL)
+#define WGD_SCR (WGD_QBASE + WGD_NQS * WGD_QPL)   // 1 KB that swallows the filler requests
+#define WGD_LDS (WGD_SCR + 1024)            // 159744 bytes
+
+// One LDS-DMA request (buffer_load_dwordx4 ... lds: 64 lanes x 16 bytes -> 1 KB of LDS at M0) as inline assembly.  Through the builtin the
+// compiler orders every later LDS read behind the request with s_waitcnt vmcnt(0) (it cannot tell the read from the request's
+// destination apart): the requests of a stage, meant to land two stages later, were each waited for on the spot -- transfer and
+// arithmetic ran one after the other (1.12 ms per 32->32 @128^3 x8 launch, 0.38 + 0.57 apart).  Waits are counted by hand below.
+__device__ __forceinline__ void wgd_dma16(u32x4 rsrc, unsigned lds_byte, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_byte), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ u32x4 wgd_rsrc(const void* base) {
+  const unsigned long a = (unsigned long)base;
+  return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
+}
+
+template <typename T> struct Mfma16;
+template <> struct Mfma16<TF16> {
+  static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mfma16<TBF16> {
+  static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b16x8, a), __builtin_bit_cast(b16x8, b), c, 0, 0, 0);
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (see lp_s1d_kernel: the host pass drops the launch stub of this template otherwise)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wa = wave & 1, wb = (wave >> 1) & 1, hv = wave >> 2;     // cin half, cout half, row half of this wave
+  const int cpt = blockIdx.y, cp0 = cpt * 32;
+
+  // ---- DMA side: every wave issues SIX requests per stage (a counted s_waitcnt needs equal counts): id = j * 8 + wave; ids 0..24 = the 25
+  // pieces of 16 slots of a P plane, 25..40 = Q rows x 2 segments, 41..47 = fillers (out of range: no traffic, 1 KB of scratch) ----
+  const int vi = lane >> 2, pos = lane & 3;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;      // LDS byte address of the dynamic segment
+  u32x4 pr, qr;
+  unsigned voff[6];               // this lane's byte offset inside a plane for request j of the current item (bit 31: masked = zeros)
+  unsigned pplane, qplane;        // bytes per plane
+  int zlo = 0, zhi = 0;
+  auto kind_of = [&](int j) { const int id = j * 8 + wave; return id < 25 ? 0 : id < 41 ? 1 : 2; };   // P, Q, filler (wave-uniform)
+  auto dst_of = [&](int j) {      // LDS byte offset of request j inside its plane
+    const int id = j * 8 + wave;
+    if (id < 25) return id * 1024;
+    const int qi = id - 25;
+    return (qi >> 1) * WGD_QROW + (qi & 1) * 1024;
+  };
+  auto setup = [&](int item) {
+    int b = item;
+    const int zc = b % p.nzc; b /= p.nzc;
+    const int tx = b % p.ntx; b /= p.ntx;
+    const int ty = b % p.nty;
+    const int n = b / p.nty;
+    const int x0 = tx * WGD_TX, y0 = ty * WGD_TY;
+    zlo = zc * p.ZC;
+    zhi = zlo + p.ZC;
+    if (zhi > p.D) zhi = p.D;
+    // origins: P at (x0 - 1, y0 - 1) of plane 0 -- possibly before the sample's first voxel: every lane that would reach there is masked
+    const long pvox = ((long)n * p.D * p.H + (y0 - 1)) * p.W + (x0 - 1);
+    const long qvox = ((long)n * p.D * p.H + y0) * p.W + x0;
+    pr = wgd_rsrc(p.p + pvox * p.ldp);
+    qr = wgd_rsrc(p.q + qvox * p.ldq);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int id = j * 8 + wave;
+      unsigned v = 0x80000000u;
+      if (id < 25) {
+        const int slot = id * 16 + vi;                    // slot of the plane: row * 40 + xl
+        const int row = slot / 40, xl = slot - row * 40;
+        const int oct = pos ^ (2 * ((slot >> 3) & 1));
+        if (xl < 34 && cp0 + oct * 8 < p.Cp && (unsigned)(x0 - 1 + xl) < (unsigned)p.W && (unsigned)(y0 - 1 + row) < (unsigned)p.H)
+          v = (unsigned)(((row * p.W + xl) * p.ldp + cp0 + oct * 8) * 2);
+      } else if (id < 41) {
+        const int qi = id - 25;
+        const int row = qi >> 1, xl = (qi & 1) * 16 + vi;
+        const int oct = pos ^ (2 * ((xl >> 3) & 1));
+        if (oct * 8 < p.Cq && x0 + xl < p.W && y0 + row < p.H) v = (unsigned)(((row * p.W + xl) * p.ldq + oct * 8) * 2);
+      }
+      voff[j] = v;
+    }
+  };
+  // request j of a stage's six: Q plane zq -> ring slot qslot, P plane zp -> buffer pbuf (want_p false: fillers instead).  The stage
+  // deals its six between its matrix instructions (a request costs the wave ~100 issue cycles)
+  struct StageReq { bool qok, pok, want_p; unsigned qso, pso; int qslot, pbuf; };
+  auto make_req = [&](int zq, int qslot, int zp, int pbuf, bool want_p) {
+    StageReq r;
+    r.qok = zq >= zlo && zq < zhi;
+    r.want_p = want_p;
+    r.pok = want_p && zp >= 0 && zp < p.D;
+    r.qso = r.qok ? (unsigned)zq * qplane : 0u;
+    r.pso = r.pok ? (unsigned)zp * pplane : 0u;
+    r.qslot = qslot; r.pbuf = pbuf;
+    return r;
+  };
+  auto issue1 = [&](const StageReq& r, int j) {
+#ifdef WGD_EXP_NODMA    // timing experiment (wrong results): no requests after the prologue
+    if (r.qslot >= 0) return;
+#endif
+    if (kind_of(j) == 1) {
+      wgd_dma16(qr, lds0 + (unsigned)(WGD_QBASE + r.qslot * WGD_QPL + dst_of(j)), r.qok ? voff[j] : 0x80000000u, r.qso);
+    } else {
+      const bool live = kind_of(j) == 0 && r.want_p;
+      wgd_dma16(pr, lds0 + (unsigned)(live ? r.pbuf * WGD_PPL + dst_of(j) : WGD_SCR), (live && r.pok) ? voff[j] : 0x80000000u, r.pso);
+    }
+  };
+  auto issue = [&](int zq, int qslot, int zp, int pbuf, bool want_p) {
+    const StageReq r = make_req(zq, qslot, zp, pbuf, want_p);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) issue1(r, j);
+  };
+
+  // ---- compute side ----
+  const int g = lane >> 4, rr = (lane & 15) >> 2, c4 = lane & 3;
+  unsigned poff[3][2], qoff[2];      // [x tap][k half] for even rows; odd rows: ^ 32 (row * 40 slots shifts the 8-slot block parity)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int xl = kx + 8 * g + 4 * h + rr;
+      const int ps = (2 * wa + (c4 >> 1)) ^ (2 * ((xl >> 3) & 1));
+      poff[kx][h] = (unsigned)((4 * hv) * WGD_PROW + xl * 64 + ps * 16 + (c4 & 1) * 8);
+    }
+    const int xl = 8 * g + 4 * h + rr;
+    const int ps = (2 * wb + (c4 >> 1)) ^ (2 * ((xl >> 3) & 1));
+    qoff[h] = (unsigned)(WGD_QBASE + (4 * hv) * WGD_QROW + xl * 64 + ps * 16 + (c4 & 1) * 8);
+  }
+  auto trd = [&](const unsigned char* a) -> u32x2 {
+#ifdef WGD_EXP_NOREAD   // timing experiment (wrong results): no operand reads from LDS
+    return u32x2{(unsigned)(uintptr_t)a, 1u};
+#endif
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a)));
+  };
+  f32x4 acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  pplane = (unsigned)(p.H * p.W * p.ldp * 2);
+  qplane = (unsigned)(p.H * p.W * p.ldq * 2);
+  const int w = blockIdx.x;
+  int it0 = w * p.ipw;
+  if (p.xcd_order) it0 = ((w & 7) * (gridDim.x >> 3) + (w >> 3)) * p.ipw;      // consecutive item ranges stay on one XCD (its L2 holds the halos)
+  int it1 = it0 + p.ipw;
+  if (it1 > p.nitems) it1 = p.nitems;
+  // Q fragments [plane role kz][row]: the planes zp, zp - 1 of a stage are the planes zp + 1, zp of the stage before -- their fragments
+  // stay in registers and change ROLE (physical index (kz + rot) % 3, rot steps 0 -> 2 -> 1 -> 0); only the new plane's four are read
+  u32x4 qfp[3][4];
+  u32x4 pf[3];
+  // One stage, straight-line: 18 steps (P row, x tap) of 3..9 matrix instructions; P fragments are read two steps ahead, the new Q
+  // plane's rows just before their first use, the six requests of the stage after next are dealt over the steps.
+  auto stage = [&](auto rotc, const unsigned char* pb, const unsigned char* qnew, const StageReq& rq) {
+    constexpr int R = decltype(rotc)::value;
+    auto rdp = [&](int st) -> u32x4 {
+      const int prow = st / 3, kx = st - prow * 3;
+      const unsigned sw = (prow & 1) ? 32u : 0u;
+      const u32x2 lo = trd(pb + (poff[kx][0] ^ sw) + prow * WGD_PROW), hi = trd(pb + (poff[kx][1] ^ sw) + prow * WGD_PROW);
+      return u32x4{lo[0], lo[1], hi[0], hi[1]};
+    };
+    auto rdq = [&](int qrow) {
+      const u32x2 lo = trd(qnew + qoff[0] + qrow * WGD_QROW), hi = trd(qnew + qoff[1] + qrow * WGD_QROW);
+      qfp[R % 3][qrow] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+    };
+    rdq(0);
+    pf[0] = rdp(0);
+    pf[1] = rdp(1);
+    issue1(rq, 0);
+    rdq(1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int st = 0; st < 18; ++st) {
+      const int prow = st / 3, kx = st - prow * 3;
+      if (st + 2 < 18) pf[(st + 2) % 3] = rdp(st + 2);
+      if (st == 2) rdq(2);
+      if (st == 5) rdq(3);
+      if (st == 1 || st == 4 || st == 7 || st == 10 || st == 13) issue1(rq, (st + 2) / 3);
+      const u32x4 a = pf[st % 3];
+      // resident planes first: the new plane's fragments (kz 0) have had the longest to arrive by the time they are used
+#pragma unroll
+      for (int kz = 2; kz >= 0; --kz)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int qrow = prow - ky;
+          if (qrow < 0 || qrow > 3) continue;
+#ifdef WGD_EXP_NOMFMA   // timing experiment (wrong results): one matrix instruction per step keeps the reads alive
+          if (kz != 0 || ky != (prow > 3 ? prow - 3 : 0)) continue;
+#endif
+          acc[(kz * 3 + ky) * 3 + kx] = Mfma16<T>::run(a, qfp[(kz + R) % 3][qrow], acc[(kz * 3 + ky) * 3 + kx]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  for (int item = it0; item < it1; ++item) {
+    setup(item);
+    // ring slot of Q plane z: (z - zlo + 2) % 5; P plane z: (z - zlo + 1) % 3
+    issue(zlo - 2, 0, 0, 0, false);
+    issue(zlo - 1, 1, 0, 0, false);
+    issue(zlo, 2, zlo - 1, 0, true);
+    issue(zlo + 1, 3, zlo, 1, true);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // everything but the last stage's worth has landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // the first stage's resident planes (zlo - 1, zlo - 2: outside the item = zeros): roles kz 1, 2 at rot 0
+#pragma unroll
+    for (int qrow = 0; qrow < 4; ++qrow) qfp[1][qrow] = qfp[2][qrow] = u32x4{0u, 0u, 0u, 0u};
+    int pb_i = 0, qs = 0, rot = 0;                         // P buffer of plane zp, ring slot of Q plane zp - 1, register rotation
+    for (int zp = zlo - 1; zp <= zhi; ++zp) {      // stage: P plane zp against Q planes zp + 1 (kz 0), zp (kz 1), zp - 1 (kz 2)
+      int pn = pb_i + 2; if (pn >= WGD_NPB) pn -= WGD_NPB;
+      int qn = qs + 4; if (qn >= WGD_NQS) qn -= WGD_NQS;
+      const StageReq rq = make_req(zp + 3, qn, zp + 2, pn, zp + 2 <= zhi);     // two stages ahead (past the item's end: zeros / fillers)
+      const unsigned char* pb = lds + pb_i * WGD_PPL;
+      int sl = qs + 2; if (sl >= WGD_NQS) sl -= WGD_NQS;
+      const unsigned char* qnew = lds + sl * WGD_QPL;
+      stage(WgdIC<0>{}, pb, qnew, rq);
+#pragma unroll
+      for (int qrow = 0; qrow < 4; ++qrow) { qfp[2][qrow] = qfp[1][qrow]; qfp[1][qrow] = qfp[0][qrow]; }
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // the next stage's planes have landed; this stage's requests stay in flight
+#ifndef WGD_EXP_NOBAR   // timing experiment (wrong results): no stage barrier
+      __builtin_amdgcn_s_barrier();
+#endif
+      asm volatile("" ::: "memory");
+      if (++pb_i == WGD_NPB) pb_i = 0;
+      if (++qs == WGD_NQS) qs = 0;
+      rot = rot == 0 ? 2 : rot - 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (fillers of the last stage: nothing may land after the buffers change hands)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  // ---- the two row halves meet in LDS; partial slab [tap][32 cin][32 cout] ----
+  float* xl = reinterpret_cast<float*>(lds);
+  const int row0 = wa * 16 + 4 * g, col = wb * 16 + (lane & 15);
+  if (hv == 1) {
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xl[(t * 32 + row0 + r) * 32 + col] = acc[t][r];
+  }
+  __syncthreads();
+  if (hv == 0) {
+    float* pbw = p.part + ((long)blockIdx.x * p.ncp + cpt) * (27L * 1024);
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pbw[(t * 32 + row0 + r) * 32 + col] = acc[t][r] + xl[(t * 32 + row0 + r) * 32 + col];
+  }
+#endif
+}
+
+// =====================================================================================================================
+// plan + launch (the finalize is lowp.hip's)
+// =====================================================================================================================
+struct WgdPlan { int ntx, nty, nzc, ZC, nitems, ipw, nwg, ncp, xcd; };
+static bool wgd_enabled() {   // BTS_LP_WGD=0: these layers back on lowp.hip's general weight-gradient kernel (A/B; read per call)
+  const char* e = getenv("BTS_LP_WGD");
+  return !(e && atoi(e) == 0);
+}
+static bool wgd_plan(WgdPlan& pl, int N, int D, int H, int W, int Cp, int ldp, int Cq, int ldq) {
+  if (!wgd_enabled() || Cq > 32 || Cq % 8 != 0 || Cp % 8 != 0 || W % WGD_TX != 0 || H % WGD_TY != 0 || D < 4) return false;
+  if ((long)D * H * W * (long)ldp * 2 >= 0x7fffffffL || (long)D * H * W * (long)ldq * 2 >= 0x7fffffffL) return false;
+  pl.ncp = (Cp + 31) / 32;
+  pl.ntx = W / WGD_TX; pl.nty = H / WGD_TY;
+  const long ncol = (long)N * pl.ntx * pl.nty;
+  if (ncol * D < 64) return false;      // (fewer than 64 plane stages: nothing to stream)
+  const int cus = 256 / pl.ncp;
+  int nzc = 1;
+  while (ncol * nzc < 2L * cus && (D + 2 * nzc - 1) / (2 * nzc) >= 8) nzc *= 2;
+  pl.nzc = nzc;
+  pl.ZC = (D + nzc - 1) / nzc;
+  pl.nzc = (D + pl.ZC - 1) / pl.ZC;
+  const long items = ncol * pl.nzc;
+  if (items > 0x3fffffffL) return false;
+  pl.nitems = (int)items;
+  int nwg = pl.nitems < cus ? pl.nitems : cus;
+  pl.ipw = (pl.nitems + nwg - 1) / nwg;
+  pl.nwg = (pl.nitems + pl.ipw - 1) / pl.ipw;
+  pl.xcd = (pl.nwg % 8 == 0 && pl.nwg * pl.ipw == pl.nitems) ? 1 : 0;
+  return true;
+}
+// bytes of partial slabs a call with these dimensions needs, or 0 when it is declined
+long bts_lp_wgd_workspace_(int N, int D, int H, int W, int Cp, int Cq) {
+  WgdPlan pl;
+  if (!wgd_plan(pl, N, D, H, W, Cp, Cp, Cq, Cq)) return 0;
+  return (long)pl.nwg * pl.ncp * 27 * 1024 * 4;
+}
+// BTS_OK = ran (dw written by the shared finalize), 1 = declined
+int bts_lp_wgd_launch_(int dtype, const void* x, const void* dy, float* dw, void* ws, long ws_bytes, int N, int D, int H, int W, int Cp, int ldp,
+                       int Cq, int ldq, int dup_start, int dup_shift, int accum, hipStream_t stream) {
+  WgdPlan pl;
+  if (!wgd_plan(pl, N, D, H, W, Cp, ldp, Cq, ldq)) return 1;
+  if (ws_bytes < (long)pl.nwg * pl.ncp * 27 * 1024 * 4) return 1;
+  LpWgdParams p;
+  p.p = (const unsigned short*)x; p.q = (const unsigned short*)dy; p.part = reinterpret_cast<float*>(ws);
+  p.N = N; p.D = D; p.H = H; p.W = W; p.Cp = Cp; p.ldp = ldp; p.Cq = Cq; p.ldq = ldq;
+  p.ntx = pl.ntx; p.nty = pl.nty; p.nzc = pl.nzc; p.ZC = pl.ZC; p.nitems = pl.nitems; p.ipw = pl.ipw; p.ncp = pl.ncp; p.xcd_order = pl.xcd;
+  (void)hipGetLastError();
+#define WGD_LAUNCH(TT)                                                                                                       \
+  do {                                                                                                                       \
+    auto kern = lp_wgd_kernel<TT>;                                                                                           \
+    static bool done = false;                                                                                                \
+    if (!done) {                                                                                                             \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WGD_LDS); \
+      if (e != hipSuccess) return (int)e;                                                                                    \
+      done = true;                                                                                                           \
+    }                                                                                                                        \
+    hipLaunchKernelGGL(kern, dim3(pl.nwg, pl.ncp), dim3(512), WGD_LDS, stream, p);                                           \
+  } while (0)
+  const bool prof = bts_prof_on();
+  if (prof) bts_prof_begin(37, 2.0 * 27.0 * (double)Cp * Cq * (double)N * D * H * W, stream);
+  if (dtype == LP_F16) WGD_LAUNCH(TF16); else WGD_LAUNCH(TBF16);
+#undef WGD_LAUNCH
+  if (prof) bts_prof_end(stream);
+  BTS_LAUNCH_CHECK();
+  return bts_lp_wgrad_finalize_(p.part, dw, pl.nwg, pl.ncp, 1, 27, 27, 1, Cp, Cq, Cp + dup_shift, dup_start, dup_shift, accum, stream);
+}

@@ -54,6 +54,8 @@ def kernel_symbol(sym):
         return 'lp_up_kernel'
     if sym == 36:
         return 'lp_wgs_kernel'
+    if sym == 37:
+        return 'lp_wgd_kernel'
     if sym >= 100:  # 100 + (MODE << 2 | FIXG)
         return 'wgrad_kernel<%d,%d>' % ((sym - 100) >> 2, (sym - 100) & 3)
     return 'igemm_kernel<%s,%d>' % (_CFG[sym & 7], 4 if sym & 8 else 1)
