@@ -267,9 +267,32 @@ extern "C" int bts_gn_stats(const float* x, float* mean, float* rstd, void* work
   return BTS_OK;
 }
 
+// many partials per unit (conv epilogues leave one per tile column and plane: thousands at 128^3): one WORKGROUP per (n, g), fixed order
+__global__ __launch_bounds__(256) void gn_stats_finalize_wide_kernel(const double* partial, float* mean, float* rstd, int B, double count,
+                                                                     float eps) {
+  __shared__ double sh[8];
+  const int i = blockIdx.x;
+  double s = 0.0, ss = 0.0;
+  for (int b = threadIdx.x; b < B; b += 256) { s += partial[((long)i * B + b) * 2]; ss += partial[((long)i * B + b) * 2 + 1]; }
+  const double rs = block_sum_f64(s, sh);
+  const double rss = block_sum_f64(ss, sh + 4);
+  if (threadIdx.x == 0) {
+    const double m = rs / count;
+    double var = rss / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[i] = (float)m;
+    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
 int bts_gn_finalize_partials_(const double* partial, float* mean, float* rstd, int NG, long B, double count, float eps,
                               hipStream_t stream) {
   if (NG <= 0 || B <= 0 || B > 0x7fffffffL) return BTS_ERR_SHAPE;
+  if (B >= 512) {
+    (void)hipGetLastError(); hipLaunchKernelGGL(gn_stats_finalize_wide_kernel, dim3(NG), dim3(256), 0, stream, partial, mean, rstd, (int)B, count, eps);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+  }
   (void)hipGetLastError(); hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3((NG + 3) / 4), dim3(256), 0, stream, partial, mean, rstd, NG, (int)B, 0,
                      1, BTS_GN_SLAB, count, eps);
   BTS_LAUNCH_CHECK();

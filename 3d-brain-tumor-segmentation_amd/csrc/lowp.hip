@@ -36,9 +36,9 @@ int bts_lp_s1d_pack_(int dtype, const LpPackParams& p, void* dst, hipStream_t st
 long bts_lp_s1d_workspace_(int N, int D, int H, int W, int Cin, int Cout);
 long bts_lp_s1d_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn);
 // lowp_k1.hip: streaming 1x1x1 kernel (offered first; 1 = declined); gap partials per block of bts_lp_k1_gap_block_ positions
-int bts_lp_k1_gap_block_(long npos, int Cin, int Cout);
+int bts_lp_k1_gap_block_(long npos, long V, int Cin, int Cout);
 int bts_lp_k1_launch_(int dtype, const void* x, const void* wp, const float* bias, void* y, long npos, int Cin, int ldx, int Cout, int ldy,
-                      int accum, double* gap_part, hipStream_t stream);
+                      int accum, double* gap_part, int gap_block, hipStream_t stream);
 // lowp_up.hip: transposed form, all eight output classes in one pass (offered first; 1 = declined)
 int bts_lp_up_launch_(int dtype, const void* x, const void* wp_dma, const float* bias, void* y, int N, int D, int H, int W, int Cin, int ldx,
                       int Cout, int ldy, int accum, hipStream_t stream);
@@ -728,7 +728,7 @@ static int lp_conv_run(int geo, int dtype, const void* x, const void* wp, const 
   g.gap_part = (geo == 0) ? gap_part : nullptr;
   auto run = [&](const LpGatherParams& q) { return dtype == LP_F16 ? lp_gather_launch<TF16>(q, stream) : lp_gather_launch<TBF16>(q, stream); };
   if (geo == 0 && gap_part == nullptr) {     // (the fused-pool form is offered the streaming kernel by bts_lp_conv1_gap itself)
-    const int r = bts_lp_k1_launch_(dtype, x, wp, bias, y, (long)N * D * H * W, Cin, ldx, Cout, ldy, accum, nullptr, stream);
+    const int r = bts_lp_k1_launch_(dtype, x, wp, bias, y, (long)N * D * H * W, Cin, ldx, Cout, ldy, accum, nullptr, 0, stream);
     if (r != 1) return r;
   }
   if (geo == 0) {
@@ -855,10 +855,10 @@ extern "C" int bts_lp_conv1_gap(int dtype, const void* x, const void* wp, const 
   if (workspace == nullptr || workspace_bytes < bts_lp_conv1_gap_workspace(N, V, Cout) || (((uintptr_t)workspace) & 15)) return BTS_ERR_WORKSPACE;
   const int NB = (Cout + 31) / 32;
   {   // streaming kernel: column sums per block of 256 positions
-    const int kb = bts_lp_k1_gap_block_((long)N * V, Cin, Cout);
+    const int kb = bts_lp_k1_gap_block_((long)N * V, V, Cin, Cout);
     if (kb > 0 && V % kb == 0 && ldres == Cout) {
       double* part = reinterpret_cast<double*>(workspace);
-      const int r = bts_lp_k1_launch_(dtype, x, wp, bias, res, (long)N * V, Cin, ldx, Cout, ldres, 0, part, stream);
+      const int r = bts_lp_k1_launch_(dtype, x, wp, bias, res, (long)N * V, Cin, ldx, Cout, ldres, 0, part, kb, stream);
       if (r == BTS_OK) {
         hipLaunchKernelGGL(lp_colsum_finalize_kernel, dim3((N * Cout + 3) / 4), dim3(256), 0, stream, part, gap, N, Cout, (int)(V / kb), 1.0 / (double)V);
         BTS_LAUNCH_CHECK();

@@ -30,7 +30,8 @@ struct LpK1Params {
   unsigned short* y;
   long npos;
   int ldx, ldy, Cout, KS, NB, accum;
-  double* gap_part;           // [position block of 256][Cout] column sums of the unrounded outputs, or NULL
+  int nit;                    // position blocks of 256 one workgroup walks (its column sums leave as ONE partial row)
+  double* gap_part;           // [workgroup][Cout] column sums of the unrounded outputs, or NULL
 };
 #define LPK1_POS 256   // positions per workgroup: 4 waves x 2 fragments x 32
 
@@ -44,96 +45,98 @@ __global__ __launch_bounds__(256, 3) void lp_k1_kernel(const LpK1Params p) {
   const int cg = blockIdx.y;
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7fffffff, 0x00020000);
   const unsigned wlane = (unsigned)(lane * 16);
-  long pos[VB];
-  bool live[VB];
-  const unsigned short* xb[VB];
-#pragma unroll
-  for (int v = 0; v < VB; ++v) {
-    pos[v] = blk * LPK1_POS + (wave * VB + v) * 32 + l32;
-    live[v] = pos[v] < p.npos;
-    xb[v] = p.x + (live[v] ? pos[v] : p.npos - 1) * (long)p.ldx + h * 8;     // (masked lanes re-read the last voxel: no traffic of their own)
-  }
-  f32x16 acc[VB][CB];
-#pragma unroll
-  for (int c = 0; c < CB; ++c) {
-    const int cb = cg * CB + c;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int co = cb * 32 + 8 * q + 4 * h;
-      float bq[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias != nullptr && co + 3 < p.Cout) {       // (the bias is a view into the flat parameter buffer: 4-byte aligned only)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bq[j] = p.bias[co + j];
-      }
-#pragma unroll
-      for (int v = 0; v < VB; ++v)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[v][c][4 * q + j] = bq[j];
-    }
-  }
-  u32x4 ar[RD][CB], br[RD][VB];
-  auto issue = [&](int ks, u32x4 (&a)[CB], u32x4 (&b)[VB]) {
-#pragma unroll
-    for (int c = 0; c < CB; ++c) {
-      const int cb = cg * CB + c;
-      a[c] = bload16(wr, wlane, (unsigned)((ks * p.NB + (cb < p.NB ? cb : 0)) * 1024));
-    }
-#pragma unroll
-    for (int v = 0; v < VB; ++v) b[v] = *reinterpret_cast<const u32x4*>(xb[v] + ks * 16);
-  };
-#pragma unroll
-  for (int j = 0; j < RD - 1; ++j)
-    if (j < p.KS) issue(j, ar[j], br[j]);
-  for (int k0 = 0; k0 < p.KS; k0 += RD) {
-#pragma unroll
-    for (int j = 0; j < RD; ++j) {
-      if (k0 + j < p.KS) {
-        if (k0 + j + RD - 1 < p.KS) issue(k0 + j + RD - 1, ar[(j + RD - 1) % RD], br[(j + RD - 1) % RD]);
-#pragma unroll
-        for (int v = 0; v < VB; ++v)
-#pragma unroll
-          for (int c = 0; c < CB; ++c) acc[v][c] = T::mfma(ar[j][c], br[j][v], acc[v][c]);
-      }
-    }
-  }
-  // ---- output side ----
   const bool gap_on = p.gap_part != nullptr;
   float csum[CB][16];
 #pragma unroll
   for (int c = 0; c < CB; ++c)
 #pragma unroll
     for (int r = 0; r < 16; ++r) csum[c][r] = 0.f;
-#pragma unroll
-  for (int c = 0; c < CB; ++c) {
-    const int cb = cg * CB + c;
-#pragma unroll
-    for (int qp = 0; qp < 2; ++qp) {
-      const int co = cb * 32 + 16 * qp + 8 * h;
-#pragma unroll
-      for (int v = 0; v < VB; ++v) {
-        const bool ok = live[v] && cb < p.NB && co < p.Cout;
-        unsigned short* dst = p.y + pos[v] * (long)p.ldy + co;
-        float f[4], g2[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { f[j] = acc[v][c][8 * qp + j]; g2[j] = acc[v][c][8 * qp + 4 + j]; }
-        if (p.accum) {     // old values arrive in the exchanged layout: the exchange is its own inverse
-          u32x4 e = {0u, 0u, 0u, 0u};
-          if (ok) e = *reinterpret_cast<const u32x4*>(dst);
+  for (int it = 0; it < p.nit; ++it) {
+    long pos[VB];
+    bool live[VB];
+    const unsigned short* xb[VB];
+  #pragma unroll
+    for (int v = 0; v < VB; ++v) {
+      pos[v] = (blk * p.nit + it) * LPK1_POS + (wave * VB + v) * 32 + l32;
+      live[v] = pos[v] < p.npos;
+      xb[v] = p.x + (live[v] ? pos[v] : p.npos - 1) * (long)p.ldx + h * 8;     // (masked lanes re-read the last voxel: no traffic of their own)
+    }
+    f32x16 acc[VB][CB];
+  #pragma unroll
+    for (int c = 0; c < CB; ++c) {
+      const int cb = cg * CB + c;
+  #pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = cb * 32 + 8 * q + 4 * h;
+        float bq[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr && co + 3 < p.Cout) {       // (the bias is a view into the flat parameter buffer: 4-byte aligned only)
+  #pragma unroll
+          for (int j = 0; j < 4; ++j) bq[j] = p.bias[co + j];
+        }
+  #pragma unroll
+        for (int v = 0; v < VB; ++v)
+  #pragma unroll
+          for (int j = 0; j < 4; ++j) acc[v][c][4 * q + j] = bq[j];
+      }
+    }
+    u32x4 ar[RD][CB], br[RD][VB];
+    auto issue = [&](int ks, u32x4 (&a)[CB], u32x4 (&b)[VB]) {
+  #pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        const int cb = cg * CB + c;
+        a[c] = bload16(wr, wlane, (unsigned)((ks * p.NB + (cb < p.NB ? cb : 0)) * 1024));
+      }
+  #pragma unroll
+      for (int v = 0; v < VB; ++v) b[v] = *reinterpret_cast<const u32x4*>(xb[v] + ks * 16);
+    };
+  #pragma unroll
+    for (int j = 0; j < RD - 1; ++j)
+      if (j < p.KS) issue(j, ar[j], br[j]);
+    for (int k0 = 0; k0 < p.KS; k0 += RD) {
+  #pragma unroll
+      for (int j = 0; j < RD; ++j) {
+        if (k0 + j < p.KS) {
+          if (k0 + j + RD - 1 < p.KS) issue(k0 + j + RD - 1, ar[(j + RD - 1) % RD], br[(j + RD - 1) % RD]);
+  #pragma unroll
+          for (int v = 0; v < VB; ++v)
+  #pragma unroll
+            for (int c = 0; c < CB; ++c) acc[v][c] = T::mfma(ar[j][c], br[j][v], acc[v][c]);
+        }
+      }
+    }
+    // ---- output side ----
+  #pragma unroll
+    for (int c = 0; c < CB; ++c) {
+      const int cb = cg * CB + c;
+  #pragma unroll
+      for (int qp = 0; qp < 2; ++qp) {
+        const int co = cb * 32 + 16 * qp + 8 * h;
+  #pragma unroll
+        for (int v = 0; v < VB; ++v) {
+          const bool ok = live[v] && cb < p.NB && co < p.Cout;
+          unsigned short* dst = p.y + pos[v] * (long)p.ldy + co;
+          float f[4], g2[4];
+  #pragma unroll
+          for (int j = 0; j < 4; ++j) { f[j] = acc[v][c][8 * qp + j]; g2[j] = acc[v][c][8 * qp + 4 + j]; }
+          if (p.accum) {     // old values arrive in the exchanged layout: the exchange is its own inverse
+            u32x4 e = {0u, 0u, 0u, 0u};
+            if (ok) e = *reinterpret_cast<const u32x4*>(dst);
+            asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\tv_nop"
+                         : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]));
+            float old[8];
+            unpack8<T>(e, old);
+  #pragma unroll
+            for (int j = 0; j < 4; ++j) { f[j] += old[j]; g2[j] += old[4 + j]; }
+          }
+          if (gap_on && live[v]) {
+  #pragma unroll
+            for (int j = 0; j < 4; ++j) { csum[c][8 * qp + j] += f[j]; csum[c][8 * qp + 4 + j] += g2[j]; }
+          }
+          unsigned d0 = pack2<T>(f[0], f[1]), d1 = pack2<T>(f[2], f[3]), d2 = pack2<T>(g2[0], g2[1]), d3 = pack2<T>(g2[2], g2[3]);
           asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\tv_nop"
-                       : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]));
-          float old[8];
-          unpack8<T>(e, old);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { f[j] += old[j]; g2[j] += old[4 + j]; }
+                       : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+          if (ok) *reinterpret_cast<u32x4*>(dst) = u32x4{d0, d1, d2, d3};
         }
-        if (gap_on && live[v]) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { csum[c][8 * qp + j] += f[j]; csum[c][8 * qp + 4 + j] += g2[j]; }
-        }
-        unsigned d0 = pack2<T>(f[0], f[1]), d1 = pack2<T>(f[2], f[3]), d2 = pack2<T>(g2[0], g2[1]), d3 = pack2<T>(g2[2], g2[3]);
-        asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\tv_nop"
-                     : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
-        if (ok) *reinterpret_cast<u32x4*>(dst) = u32x4{d0, d1, d2, d3};
       }
     }
   }
@@ -163,21 +166,25 @@ static bool k1_enabled() {   // BTS_LP_K1=0: 1x1x1 convs back on the general gat
   const char* e = getenv("BTS_LP_K1");
   return !(e && atoi(e) == 0);
 }
-// positions per gap partial block of the streaming kernel, or 0 when a call with these dimensions is declined
-int bts_lp_k1_gap_block_(long npos, int Cin, int Cout) {
+// positions per gap partial row of the streaming kernel for samples of V positions (a row never spans two samples: the largest of 2048
+// .. 256 that divides V; fewer, longer rows keep the finalize short), or 0 when a call with these dimensions is declined
+int bts_lp_k1_gap_block_(long npos, long V, int Cin, int Cout) {
   if (!k1_enabled() || Cin % 16 != 0 || Cout % 8 != 0 || npos < 4096) return 0;
-  return LPK1_POS;
+  for (int kb = 2048; kb >= LPK1_POS; kb >>= 1)
+    if (V % kb == 0) return kb;
+  return 0;
 }
 // BTS_OK = ran, 1 = declined.  Views: x rows of ldx elements, y rows of ldy, both 16-byte aligned with ld % 8 == 0.
 int bts_lp_k1_launch_(int dtype, const void* x, const void* wp, const float* bias, void* y, long npos, int Cin, int ldx, int Cout, int ldy,
-                      int accum, double* gap_part, hipStream_t stream) {
-  if (bts_lp_k1_gap_block_(npos, Cin, Cout) == 0) return 1;
+                      int accum, double* gap_part, int gap_block, hipStream_t stream) {
+  if (bts_lp_k1_gap_block_(npos, LPK1_POS, Cin, Cout) == 0) return 1;
+  if (gap_part != nullptr && (gap_block < LPK1_POS || gap_block % LPK1_POS != 0 || npos % gap_block != 0)) return 1;
   if (ldx % 8 != 0 || ldy % 8 != 0 || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 15)) return 1;
   LpK1Params p;
   p.x = (const unsigned short*)x; p.wp = (const unsigned short*)wp; p.bias = bias; p.y = (unsigned short*)y;
-  p.npos = npos; p.ldx = ldx; p.ldy = ldy; p.Cout = Cout; p.KS = Cin / 16; p.NB = (Cout + 31) / 32; p.accum = accum; p.gap_part = gap_part;
+  p.npos = npos; p.ldx = ldx; p.ldy = ldy; p.Cout = Cout; p.KS = Cin / 16; p.NB = (Cout + 31) / 32; p.accum = accum; p.gap_part = gap_part; p.nit = gap_part != nullptr ? gap_block / LPK1_POS : 1;
   const int cb = p.NB >= 2 ? 2 : 1;
-  const long blocks = (npos + LPK1_POS - 1) / LPK1_POS;
+  const long blocks = (npos + (long)LPK1_POS * p.nit - 1) / ((long)LPK1_POS * p.nit);
   if (blocks > 0x7fffffffL) return 1;
   const bool prof = bts_prof_on();
   if (prof) bts_prof_begin(34, 2.0 * Cin * (double)Cout * (double)npos, stream);

@@ -40,11 +40,11 @@ template <int V> using WgdIC = std::integral_constant<int, V>;
 
 struct LpWgdParams {
   const unsigned short* p;   // (N, D, H, W, Cp) voxel stride ldp
-  const unsigned short* q;   // (N, D, H, W, Cq <= 32) voxel stride ldq
-  float* part;               // [workgroup][cp block][27 taps][32][32]
+  const unsigned short* q;   // (N, D, H, W, Cq) voxel stride ldq
+  float* part;               // [workgroup][cp block][cq block][27 taps][32][32]
   int N, D, H, W, Cp, ldp, Cq, ldq;
   int ntx, nty, nzc, ZC;     // columns per sample (x, y), z chunks per column, planes per chunk
-  int nitems, ipw, ncp, xcd_order;
+  int nitems, ipw, ncp, ncq, xcd_order;
 };
 #define WGD_TX 32
 #define WGD_TY 8
@@ -90,6 +90,7 @@ __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wa = wave & 1, wb = (wave >> 1) & 1, hv = wave >> 2;     // cin half, cout half, row half of this wave
   const int cpt = blockIdx.y, cp0 = cpt * 32;
+  const int cqt = blockIdx.z, cq0 = cqt * 32;
 
   // ---- DMA side: every wave issues SIX requests per stage (a counted s_waitcnt needs equal counts): id = j * 8 + wave; ids 0..24 = the 25
   // pieces of 16 slots of a P plane, 25..40 = Q rows x 2 segments, 41..47 = fillers (out of range: no traffic, 1 KB of scratch) ----
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
         const int qi = id - 25;
         const int row = qi >> 1, xl = (qi & 1) * 16 + vi;
         const int oct = pos ^ (2 * ((xl >> 3) & 1));
-        if (oct * 8 < p.Cq && x0 + xl < p.W && y0 + row < p.H) v = (unsigned)(((row * p.W + xl) * p.ldq + oct * 8) * 2);
+        if (cq0 + oct * 8 < p.Cq && x0 + xl < p.W && y0 + row < p.H) v = (unsigned)(((row * p.W + xl) * p.ldq + cq0 + oct * 8) * 2);
       }
       voff[j] = v;
     }
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
   }
   __syncthreads();
   if (hv == 0) {
-    float* pbw = p.part + ((long)blockIdx.x * p.ncp + cpt) * (27L * 1024);
+    float* pbw = p.part + (((long)blockIdx.x * p.ncp + cpt) * p.ncq + cqt) * (27L * 1024);
 #pragma unroll
     for (int t = 0; t < 27; ++t)
 #pragma unroll
@@ -309,19 +310,21 @@ __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
 // =====================================================================================================================
 // plan + launch (the finalize is lowp.hip's)
 // =====================================================================================================================
-struct WgdPlan { int ntx, nty, nzc, ZC, nitems, ipw, nwg, ncp, xcd; };
+struct WgdPlan { int ntx, nty, nzc, ZC, nitems, ipw, nwg, ncp, ncq, xcd; };
 static bool wgd_enabled() {   // BTS_LP_WGD=0: these layers back on lowp.hip's general weight-gradient kernel (A/B; read per call)
   const char* e = getenv("BTS_LP_WGD");
   return !(e && atoi(e) == 0);
 }
 static bool wgd_plan(WgdPlan& pl, int N, int D, int H, int W, int Cp, int ldp, int Cq, int ldq) {
-  if (!wgd_enabled() || Cq > 32 || Cq % 8 != 0 || Cp % 8 != 0 || W % WGD_TX != 0 || H % WGD_TY != 0 || D < 4) return false;
+  if (!wgd_enabled() || Cq % 8 != 0 || Cp % 8 != 0 || W % WGD_TX != 0 || H % WGD_TY != 0 || D < 4) return false;
   if ((long)D * H * W * (long)ldp * 2 >= 0x7fffffffL || (long)D * H * W * (long)ldq * 2 >= 0x7fffffffL) return false;
   pl.ncp = (Cp + 31) / 32;
+  pl.ncq = (Cq + 31) / 32;
   pl.ntx = W / WGD_TX; pl.nty = H / WGD_TY;
   const long ncol = (long)N * pl.ntx * pl.nty;
   if (ncol * D < 64) return false;      // (fewer than 64 plane stages: nothing to stream)
-  const int cus = 256 / pl.ncp;
+  int cus = 256 / (pl.ncp * pl.ncq);
+  if (cus < 8) cus = 8;
   int nzc = 1;
   while (ncol * nzc < 2L * cus && (D + 2 * nzc - 1) / (2 * nzc) >= 8) nzc *= 2;
   pl.nzc = nzc;
@@ -340,18 +343,18 @@ static bool wgd_plan(WgdPlan& pl, int N, int D, int H, int W, int Cp, int ldp, i
 long bts_lp_wgd_workspace_(int N, int D, int H, int W, int Cp, int Cq) {
   WgdPlan pl;
   if (!wgd_plan(pl, N, D, H, W, Cp, Cp, Cq, Cq)) return 0;
-  return (long)pl.nwg * pl.ncp * 27 * 1024 * 4;
+  return (long)pl.nwg * pl.ncp * pl.ncq * 27 * 1024 * 4;
 }
 // BTS_OK = ran (dw written by the shared finalize), 1 = declined
 int bts_lp_wgd_launch_(int dtype, const void* x, const void* dy, float* dw, void* ws, long ws_bytes, int N, int D, int H, int W, int Cp, int ldp,
                        int Cq, int ldq, int dup_start, int dup_shift, int accum, hipStream_t stream) {
   WgdPlan pl;
   if (!wgd_plan(pl, N, D, H, W, Cp, ldp, Cq, ldq)) return 1;
-  if (ws_bytes < (long)pl.nwg * pl.ncp * 27 * 1024 * 4) return 1;
+  if (ws_bytes < (long)pl.nwg * pl.ncp * pl.ncq * 27 * 1024 * 4) return 1;
   LpWgdParams p;
   p.p = (const unsigned short*)x; p.q = (const unsigned short*)dy; p.part = reinterpret_cast<float*>(ws);
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cp = Cp; p.ldp = ldp; p.Cq = Cq; p.ldq = ldq;
-  p.ntx = pl.ntx; p.nty = pl.nty; p.nzc = pl.nzc; p.ZC = pl.ZC; p.nitems = pl.nitems; p.ipw = pl.ipw; p.ncp = pl.ncp; p.xcd_order = pl.xcd;
+  p.ntx = pl.ntx; p.nty = pl.nty; p.nzc = pl.nzc; p.ZC = pl.ZC; p.nitems = pl.nitems; p.ipw = pl.ipw; p.ncp = pl.ncp; p.ncq = pl.ncq; p.xcd_order = pl.xcd;
   (void)hipGetLastError();
 #define WGD_LAUNCH(TT)                                                                                                       \
   do {                                                                                                                       \
@@ -362,7 +365,7 @@ int bts_lp_wgd_launch_(int dtype, const void* x, const void* dy, float* dw, void
       if (e != hipSuccess) return (int)e;                                                                                    \
       done = true;                                                                                                           \
     }                                                                                                                        \
-    hipLaunchKernelGGL(kern, dim3(pl.nwg, pl.ncp), dim3(512), WGD_LDS, stream, p);                                           \
+    hipLaunchKernelGGL(kern, dim3(pl.nwg, pl.ncp, pl.ncq), dim3(512), WGD_LDS, stream, p);                                           \
   } while (0)
   const bool prof = bts_prof_on();
   if (prof) bts_prof_begin(37, 2.0 * 27.0 * (double)Cp * Cq * (double)N * D * H * W, stream);
@@ -370,5 +373,5 @@ int bts_lp_wgd_launch_(int dtype, const void* x, const void* dy, float* dw, void
 #undef WGD_LAUNCH
   if (prof) bts_prof_end(stream);
   BTS_LAUNCH_CHECK();
-  return bts_lp_wgrad_finalize_(p.part, dw, pl.nwg, pl.ncp, 1, 27, 27, 1, Cp, Cq, Cp + dup_shift, dup_start, dup_shift, accum, stream);
+  return bts_lp_wgrad_finalize_(p.part, dw, pl.nwg, pl.ncp, pl.ncq, 27, 27, 1, Cp, Cq, Cp + dup_shift, dup_start, dup_shift, accum, stream);
 }

@@ -14,7 +14,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dtype = sys.argv[2] if len(sys.argv) > 2 else 'bfloat16'
 code, tdt = lowp.DTYPES[dtype]
 D = torch.device('cuda:0')
-for d, cin, cout in ((128, 32, 32), (128, 64, 32), (128, 16, 32), (128, 32, 16), (64, 32, 32)):
+for d, cin, cout in ((128, 32, 32), (128, 64, 32), (128, 16, 32), (64, 64, 64), (64, 128, 64), (32, 128, 128), (32, 256, 128)):
     x = torch.randn((N, d, d, d, cin), device=D).to(tdt)
     dy = torch.randn((N, d, d, d, cout), device=D).to(tdt)
     dw = torch.zeros((3, 3, 3, cin, cout), device=D)

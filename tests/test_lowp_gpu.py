@@ -335,11 +335,12 @@ WG_CASES = [
     ('K3S1', (2, 4, 8, 16), 32, 16, (16, 16), True),       # folded duplicate slice: both copies of the weight get the gradient
     ('K1', (2, 8, 8, 16), 48, 32, None, True),
     ('K1', (1, 4, 8, 16), 32, 128, (16, 16), False),
-    # the streaming kernel of lowp_wgd.hip (Cout <= 32, W % 32 == 0, H % 8 == 0): several columns; z chunks with a ragged last one, two
+    # the streaming kernel of lowp_wgd.hip (W % 32 == 0, H % 8 == 0): several columns; z chunks with a ragged last one, two
     # cin blocks and a half-empty cout block on a slab view; the folded duplicate slice
     ('K3S1', (2, 8, 32, 64), 32, 32, None, False),
     ('K3S1', (1, 37, 16, 32), 64, 16, None, True),
     ('K3S1', (2, 16, 16, 32), 32, 32, (16, 16), True),
+    ('K3S1', (2, 16, 16, 32), 64, 128, None, False),        # two cin blocks x four cout blocks
 ]
 
 
@@ -373,7 +374,7 @@ def test_weight_gradient_kernel(case, dtype):
     xin = buf[..., 8:8 + cin] if slab else torch.empty((n, d, h, w, cin), dtype=tdt, device=DEV)
     xin.copy_(x.to(tdt).to(DEV))
     dw, db = dw0.to(DEV).contiguous(), db0.to(DEV).contiguous()
-    streams = name == 'K3S1' and cout <= 32 and w % 32 == 0 and h % 8 == 0 and n * (h // 8) * (w // 32) * d >= 64
+    streams = name == 'K3S1' and w % 32 == 0 and h % 8 == 0 and n * (h // 8) * (w // 32) * d >= 64
     ops.profile_enable(True)
     ok = lowp.conv_bwd_weight(kind, code, xin, dy.to(tdt).to(DEV), dw, db, dup_start, dup_shift, accumulate=True)
     assert ok
