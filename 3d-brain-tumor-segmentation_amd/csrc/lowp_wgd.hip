@@ -224,7 +224,12 @@ __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
     rdq(0);
     pf[0] = rdp(0);
     pf[1] = rdp(1);
+#ifdef WGD_EXP_DMA_FIRST   // timing experiment: all six requests at the start of the stage
+#pragma unroll
+    for (int j = 0; j < 6; ++j) issue1(rq, j);
+#else
     issue1(rq, 0);
+#endif
     rdq(1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -233,7 +238,12 @@ __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
       if (st + 2 < 18) pf[(st + 2) % 3] = rdp(st + 2);
       if (st == 2) rdq(2);
       if (st == 5) rdq(3);
+#ifdef WGD_EXP_DMA_STAGGER   // timing experiment: the two row halves (SIMD partners) issue in different thirds of the stage
+      if (hv == 0 ? (st == 1 || st == 2 || st == 3 || st == 4 || st == 5) : (st == 9 || st == 10 || st == 11 || st == 12 || st == 13))
+        issue1(rq, hv == 0 ? st : st - 8);
+#elif !defined(WGD_EXP_DMA_FIRST)
       if (st == 1 || st == 4 || st == 7 || st == 10 || st == 13) issue1(rq, (st + 2) / 3);
+#endif
       const u32x4 a = pf[st % 3];
       // resident planes first: the new plane's fragments (kz 0) have had the longest to arrive by the time they are used
 #pragma unroll
