@@ -35,6 +35,10 @@ long bts_lp_s1d_image_bytes_(int K, int N);
 int bts_lp_s1d_pack_(int dtype, const LpPackParams& p, void* dst, hipStream_t stream);
 long bts_lp_s1d_workspace_(int N, int D, int H, int W, int Cin, int Cout);
 long bts_lp_s1d_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn);
+// lowp_s1z.hip: z-marching stride-1 3x3x3 kernel for few channels (offered first; 1 = declined)
+long bts_lp_s1z_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn);
+int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bias, void* y, int N, int D, int H, int W, int Cin, int ldx,
+                       int Cout, int ldy, int accum, double* gn_part, int gn_G, hipStream_t stream);
 // lowp_k1.hip: streaming 1x1x1 kernel (offered first; 1 = declined); gap partials per block of bts_lp_k1_gap_block_ positions
 int bts_lp_k1_gap_block_(long npos, long V, int Cin, int Cout);
 int bts_lp_k1_launch_(int dtype, const void* x, const void* wp, const float* bias, void* y, long npos, int Cin, int ldx, int Cout, int ldy,
@@ -711,6 +715,11 @@ static int lp_conv_run(int geo, int dtype, const void* x, const void* wp, const 
   const int KS = Cin / 16, NB = (Cout + 31) / 32;
   if (geo == 1) {
     if (((long)(D + 2) * H * W + 64) * (long)ldx * 2 >= 0x7fffffffL) return BTS_ERR_SHAPE;   // 31-bit offsets inside one volume
+    {   // few channels on a big volume: the z-marching streaming kernel (lowp_s1z.hip); same image part as the tiled DMA kernel
+      const int r = bts_lp_s1z_launch_(dtype, x, reinterpret_cast<const char*>(wp) + lp_s1d_part_offset(Cin, Cout), bias, y, N, D, H, W, Cin, ldx,
+                                       Cout, ldy, accum, gn_part, gn_G, stream);
+      if (r != 1) return r;
+    }
     {
       const int r = bts_lp_s1d_launch_(dtype, x, reinterpret_cast<const char*>(wp) + lp_s1d_part_offset(Cin, Cout), bias, y, workspace,
                                        workspace_bytes, N, D, H, W, Cin, ldx, Cout, ldy, accum, gn_part, gn_G, stream);
@@ -798,6 +807,8 @@ extern "C" int bts_lp_conv3d_fwd(int kind, int dtype, const void* x, const void*
 // channels, z-slabs that are not whole planes (D % G != 0) and heads with Cout % 4 != 0 run the conv and bts_lp_gn_stats on the stored y.
 static bool lp_s1_gn_plan(int N, int D, int H, int W, int Cin, int Cout, int G, long* B) {
   if (Cin % 16 != 0 || Cout % 4 != 0 || G <= 0 || D % G != 0) return false;
+  *B = bts_lp_s1z_gn_B_(N, D, H, W, Cin, Cout, G);          // the streaming kernel takes this shape: its partial layout
+  if (*B > 0) return true;
   if (bts_lp_s1d_workspace_(N, D, H, W, Cin, Cout) >= 0) {      // the DMA kernel takes this shape: its partial layout
     *B = bts_lp_s1d_gn_B_(N, D, H, W, Cin, Cout, G);
     return *B > 0;

@@ -1,0 +1,359 @@
+// Stride-1 3x3x3 convolution on 16-bit storage for the layers with FEW channels (Cin 16 or 32, Cout <= 32: the 128^3 level of the CLI
+// model -- resnet.py:80-87, vae.py:92-99 and their data gradients under train.py:142-151) as a z-marching streaming kernel.
+//
+// At 32 -> 32 channels the layer moves 128 operand bytes per 55 k flops: 432 flop/B against a machine balance of ~500 -- it is bound by
+// reading the input and writing the output ONCE.  lowp_s1d.hip's tiled kernel re-reads the input 2.0x (34 x 10 x 6 halo of a 32 x 8 x 4
+// tile), re-streams the weights per tile and drains its pipeline after two k-steps: 0.46 PFLOP/s on these launches inside the batch-8
+// step.  Here
+//   * a workgroup owns a 32 (x) x 16 (y) column and marches along z: ONE input plane (34 x 18 voxels, all channels) per stage -- the
+//     x/y halo (1.2x) is the only re-read;
+//   * all 27 x Cin/16 weight fragments stay in LDS for the whole launch (27 or 54 KB);
+//   * an input plane feeds the three output planes z-1, z, z+1: three accumulator sets per wave (2 rows x 32 positions x 32 couts each)
+//     change roles every stage; the completed plane leaves after its third input plane (bias-initialised accumulators, 16-byte stores
+//     of 8 consecutive couts after a v_permlane32_swap, optional accumulate, fused GroupNorm partial sums), then restarts at the bias;
+//   * planes go global -> LDS by buffer_load ... lds one stage ahead (inline assembly: see lowp_wgd.hip for why), in lowp_s1d.hip's
+//     conflict-free [voxel][2 x 8 ch] layout; fragments are plain ds_read_b128 at immediate offsets.
+// The weight image is the DMA part of the K3S1 image (lowp_s1d.hip's pack: [k-step][dz][dy*3+dx][k-half][32 couts][8 cin]).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+#include "bts_internal.h"
+#include "lowp_common.h"
+
+int bts_prof_on();
+void bts_prof_begin(int sym, double flops, hipStream_t stream);
+void bts_prof_end(hipStream_t stream);
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+template <int V> using S1zIC = std::integral_constant<int, V>;
+
+struct LpS1zParams {
+  const unsigned short* x;
+  const unsigned short* wp;
+  const float* bias;
+  unsigned short* y;
+  int N, D, H, W, ldx, ldy, Cout;
+  int ntx, nty, nzc, ZC, nitems, ipw, xcd_order, accum;
+  double* gnp;       // fused GroupNorm partial sums (slab semantics) [N*G][gn_B][2], or NULL
+  int gn_G, gn_zt;
+  long gn_B;
+};
+#define S1Z_TX 32
+#define S1Z_TY 16
+#define S1Z_SX 34
+#define S1Z_SY 18
+#define S1Z_NCHK 20          // 1 KB chunks (32 voxels x 32 B) of one k-step of a plane: 612 voxels -> 20
+
+__device__ __forceinline__ void s1z_dma16(u32x4 rsrc, unsigned lds_byte, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_byte), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ u32x4 s1z_rsrc(const void* base) {
+  const unsigned long a = (unsigned long)base;
+  return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
+}
+
+template <typename T, int KS>
+__global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int SX = S1Z_SX, SY = S1Z_SY, NVOX = SX * SY, NCHK = S1Z_NCHK;
+  constexpr int WB = 27 * KS * 1024, PLB = NCHK * 1024 * KS;
+  constexpr int OFF_P = WB, OFF_BIAS = WB + 2 * PLB, OFF_SCR = OFF_BIAS + 256;
+#ifdef S1Z_EXP_2ISSUE   // timing experiment: two waves issue all plane requests of a stage (is request back-pressure what stalls the others?)
+  constexpr int NREQ = NCHK * KS, NR = NREQ / 2;
+#define S1Z_ID(j) ((wave < 2) ? (wave * NR + (j)) : 0x7fff)
+#else
+  constexpr int NREQ = NCHK * KS, NR = (NREQ + 7) / 8;       // plane requests per stage / per wave
+#define S1Z_ID(j) ((j) * 8 + wave)
+#endif
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l32 = lane & 31;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
+
+  // ---- DMA side ----
+  u32x4 xr;
+  unsigned voff[NR];
+  unsigned xplane;       // bytes per input plane
+  int zlo = 0, zhi = 0, cn = 0, cx0 = 0, cy0 = 0;
+  auto setup = [&](int item) {
+    int b = item;
+    const int zc = b % p.nzc; b /= p.nzc;
+    const int tx = b % p.ntx; b /= p.ntx;
+    const int ty = b % p.nty;
+    cn = b / p.nty;
+    cx0 = tx * S1Z_TX; cy0 = ty * S1Z_TY;
+    zlo = zc * p.ZC;
+    zhi = zlo + p.ZC;
+    if (zhi > p.D) zhi = p.D;
+    const long xvox = ((long)cn * p.D * p.H + (cy0 - 1)) * p.W + (cx0 - 1);     // (may lie before the sample: such lanes are masked)
+    xr = s1z_rsrc(p.x + xvox * p.ldx);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int id = S1Z_ID(j);
+      unsigned v = 0x80000000u;
+      if (id < NREQ) {
+        const int ks = id / NCHK, chunk = id - ks * NCHK;
+        const int vox = chunk * 32 + (lane >> 1);
+        const int vy = vox / SX, vx = vox - vy * SX;
+        const int hp = (lane & 1) ^ ((vx >> 3) & 1);
+        if (vox < NVOX && (unsigned)(cx0 - 1 + vx) < (unsigned)p.W && (unsigned)(cy0 - 1 + vy) < (unsigned)p.H)
+          v = (unsigned)(((vy * p.W + vx) * p.ldx + ks * 16 + hp * 8) * 2);
+      }
+      voff[j] = v;
+    }
+  };
+  auto issue1 = [&](int j, int zp, int buf) {      // request j of input plane zp -> plane buffer buf (out of the volume: zeros)
+    const int id = S1Z_ID(j);
+    const bool pok = zp >= 0 && zp < p.D;
+    if (id < NREQ) s1z_dma16(xr, lds0 + (unsigned)(OFF_P + buf * PLB + id * 1024), pok ? voff[j] : 0x80000000u, pok ? (unsigned)zp * xplane : 0u);
+    else s1z_dma16(xr, lds0 + (unsigned)OFF_SCR, 0x80000000u, 0u);
+  };
+  auto issue_filler = [&]() { s1z_dma16(xr, lds0 + (unsigned)OFF_SCR, 0x80000000u, 0u); };      // (keeps the request counts of all stages equal)
+
+  // ---- compute side ----
+  const int r0 = 2 * wave;      // this wave's two output rows inside the column
+  unsigned hbB[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) hbB[dx] = (unsigned)(OFF_P + (r0 * SX + l32 + dx) * 32 + ((h ^ (((l32 + dx) >> 3) & 1)) * 16));
+  const unsigned wbA = (unsigned)(h * 512 + l32 * 16);
+  f32x16 acc[3][2];
+  const float* bsh = reinterpret_cast<const float*>(lds + OFF_BIAS) + 4 * h;
+  auto init_set = [&](int s) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(bsh + 8 * q);
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[s][r][4 * q + j] = bq[j];
+    }
+  };
+  __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, 0x7fffffff, 0x00020000);
+  // the completed output plane z of accumulator set s leaves (and the set restarts at the bias)
+  auto store_set = [&](auto sc, int z) {
+    constexpr int s = decltype(sc)::value;
+    const bool gn_on = p.gnp != nullptr;
+    float gn_s = 0.f, gn_q = 0.f;
+#pragma unroll
+    for (int qp = 0; qp < 2; ++qp) {
+      const int co = 16 * qp + 8 * h;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const bool ok = co < p.Cout;
+        const unsigned off = ok ? (unsigned)((((z * p.H + cy0 + r0 + r) * p.W + cx0 + l32) * p.ldy + co) * 2) : 0x80000000u;
+        float f[4], g2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f[j] = acc[s][r][8 * qp + j]; g2[j] = acc[s][r][8 * qp + 4 + j]; }
+        if (p.accum) {     // old values arrive in the exchanged layout: the exchange is its own inverse
+          u32x4 e = __builtin_amdgcn_raw_buffer_load_b128(yr, off, 0, 0);
+          asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\tv_nop"
+                       : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]));
+          float old[8];
+          unpack8<T>(e, old);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { f[j] += old[j]; g2[j] += old[4 + j]; }
+        }
+        if (gn_on && ok) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            gn_s += f[j] + g2[j];
+            gn_q = fmaf(f[j], f[j], fmaf(g2[j], g2[j], gn_q));
+          }
+        }
+        unsigned d0 = pack2<T>(f[0], f[1]), d1 = pack2<T>(f[2], f[3]), d2 = pack2<T>(g2[0], g2[1]), d3 = pack2<T>(g2[2], g2[3]);
+        asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\tv_nop"
+                     : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+#ifdef S1Z_EXP_NOSTORE   // timing experiment (wrong results)
+        if (z == -12345)
+#endif
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{d0, d1, d2, d3}, yr, off, 0, 0);
+      }
+    }
+    if (gn_on) {   // one fp64 (sum, sumsq) pair per (z plane, column, wave): fixed order
+      const double ds = wave_sum_f64((double)gn_s), dq = wave_sum_f64((double)gn_q);
+      if (lane == 0) {
+        const int gg = z / p.gn_zt;
+        const long slot = ((long)(z - gg * p.gn_zt) * (p.nty * p.ntx) + (cy0 / S1Z_TY) * p.ntx + cx0 / S1Z_TX) * 8 + wave;
+        double* dst = p.gnp + (((long)cn * p.gn_G + gg) * p.gn_B + slot) * 2;
+        dst[0] = ds;
+        dst[1] = dq;
+      }
+    }
+    init_set(s);
+  };
+  // One stage: input plane zp (buffer buf) into the three accumulator sets.  Set of output plane z: (z - zlo + 1) % 3, i.e. with
+  // R = (zp - (zlo - 1)) % 3 the tap kz (output plane zp + 1 - kz) accumulates into set (R + 4 - kz) % 3.
+  // 9 * KS groups (k-step, x tap, z tap) of six matrix instructions: three weight fragments (y taps) x the wave's two rows.  The fragments
+  // of group g + 1 are read while group g multiplies (two register sets, fixed by sched_barriers: left alone the compiler reads every
+  // fragment right before its first use and waits out the LDS latency 54 times per stage: 0.93 PFLOP/s instead of ...); the input rows
+  // change every third group.  One plane request per group while there are any.
+  auto stage = [&](auto rc, int zp, int buf) {
+    constexpr int R = decltype(rc)::value;
+    constexpr int NG = 9 * KS;
+    const unsigned pbo = (unsigned)(buf * PLB);
+    const bool more = zp < zhi;
+    u32x4 A[2][3], B[2][4];
+    auto ldA = [&](u32x4 (&a)[3], int g) {
+      const int ks = g / 9, dx = (g / 3) % 3, kz = g % 3;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) a[ky] = *reinterpret_cast<const u32x4*>(lds + wbA + ((ks * 3 + kz) * 9 + ky * 3 + dx) * 1024);
+    };
+    auto ldB = [&](u32x4 (&bb)[4], int g) {
+      const int ks = g / 9, dx = (g / 3) % 3;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bb[i] = *reinterpret_cast<const u32x4*>(lds + hbB[dx] + pbo + ks * (NCHK * 1024) + i * (SX * 32));
+    };
+    ldB(B[0], 0);
+    ldA(A[0], 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int kz = g % 3;
+      const int bs = (g / 3) & 1;
+      if (g + 1 < NG) {
+        ldA(A[(g + 1) & 1], g + 1);
+        if ((g + 1) % 3 == 0) ldB(B[bs ^ 1], g + 1);
+      }
+#ifdef S1Z_EXP_NODMA     // timing experiment (wrong results)
+      if (g < NR) issue_filler();
+#else
+#ifdef S1Z_EXP_2ISSUE
+      if (g == 0 && wave < 2) {
+        for (int j = 0; j < NR; ++j) { if (more) issue1(j, zp + 1, buf ^ 1); else issue_filler(); }
+      }
+#else
+      if (g < NR) { if (more) issue1(g, zp + 1, buf ^ 1); else issue_filler(); }
+#endif
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      const int s = (R + 4 - kz) % 3;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+#ifdef S1Z_EXP_NOMFMA   // timing experiment (wrong results)
+        if (ky) { asm volatile("" ::"v"(A[g & 1][ky]), "v"(B[bs][ky + 1])); continue; }
+#endif
+        acc[s][0] = T::mfma(A[g & 1][ky], B[bs][ky], acc[s][0]);
+        acc[s][1] = T::mfma(A[g & 1][ky], B[bs][ky + 1], acc[s][1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#ifndef S1Z_EXP_2ISSUE
+    static_assert(NR <= NG, "a stage has one request slot per group");
+#endif
+  };
+
+  xplane = (unsigned)(p.H * p.W * p.ldx * 2);
+  // weights and bias: once per workgroup
+  {
+    const u32x4 wr = s1z_rsrc(p.wp);
+    for (int c = wave; c < 27 * KS; c += 8) s1z_dma16(wr, lds0 + (unsigned)(c * 1024), (unsigned)(lane * 16), (unsigned)(c * 1024));
+    if (tid < 32) reinterpret_cast<float*>(lds + OFF_BIAS)[tid] = (p.bias != nullptr && tid < p.Cout) ? p.bias[tid] : 0.f;
+  }
+  const int w = blockIdx.x;
+  int it0 = w * p.ipw;
+  if (p.xcd_order) it0 = ((w & 7) * (gridDim.x >> 3) + (w >> 3)) * p.ipw;
+  int it1 = it0 + p.ipw;
+  if (it1 > p.nitems) it1 = p.nitems;
+  for (int item = it0; item < it1; ++item) {
+    setup(item);
+    yr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long)cn * p.D * p.H * p.W * (long)p.ldy), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) issue1(j, zlo - 1, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    init_set(0); init_set(1); init_set(2);
+    int zp = zlo - 1, buf = 0;
+    // stage zp completes output plane zp - 1 (set of tap kz = 2)
+#define S1Z_STAGE(RR)                                                                        \
+    stage(S1zIC<RR>{}, zp, buf);                                                             \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
+    __builtin_amdgcn_s_barrier();                                                            \
+    asm volatile("" ::: "memory");                                                           \
+    if (zp - 1 >= zlo) store_set(S1zIC<(RR + 2) % 3>{}, zp - 1); else init_set((RR + 2) % 3);  \
+    buf ^= 1;                                                                                \
+    if (++zp > zhi) break;
+    for (;;) {
+      S1Z_STAGE(0)
+      S1Z_STAGE(1)
+      S1Z_STAGE(2)
+    }
+#undef S1Z_STAGE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the last plane's stores and fillers) before the buffers change hands
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+#endif
+}
+
+// =====================================================================================================================
+// plan + launch
+// =====================================================================================================================
+struct S1zPlan { int ntx, nty, nzc, ZC, nitems, ipw, nwg, xcd; };
+static bool s1z_enabled() {   // BTS_LP_S1Z=0: these layers back on lowp_s1d.hip's tiled kernel (A/B; read per call)
+  const char* e = getenv("BTS_LP_S1Z");
+  return !(e && atoi(e) == 0);
+}
+static bool s1z_plan(S1zPlan& pl, int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy) {
+  if (!s1z_enabled() || (Cin != 16 && Cin != 32) || Cout > 32 || Cout % 8 != 0 || W % S1Z_TX != 0 || H % S1Z_TY != 0 || D < 8) return false;
+  if (ldx % 8 != 0 || ldy % 8 != 0) return false;
+  if ((long)D * H * W * (long)ldx * 2 >= 0x7fffffffL || (long)D * H * W * (long)ldy * 2 >= 0x7fffffffL) return false;
+  pl.ntx = W / S1Z_TX; pl.nty = H / S1Z_TY;
+  const long ncol = (long)N * pl.ntx * pl.nty;
+  if (ncol * D < 96) return false;      // (small volumes: the tiled kernel)
+  int nzc = 1;
+  while (ncol * nzc < 224 && (D + 2 * nzc - 1) / (2 * nzc) >= 16) nzc *= 2;
+  pl.ZC = (D + nzc - 1) / nzc;
+  pl.nzc = (D + pl.ZC - 1) / pl.ZC;
+  const long items = ncol * pl.nzc;
+  if (items > 0x3fffffffL) return false;
+  pl.nitems = (int)items;
+  const int nwg = pl.nitems < 256 ? pl.nitems : 256;
+  pl.ipw = (pl.nitems + nwg - 1) / nwg;
+  pl.nwg = (pl.nitems + pl.ipw - 1) / pl.ipw;
+  pl.xcd = (pl.nwg % 8 == 0 && pl.nwg * pl.ipw == pl.nitems) ? 1 : 0;
+  return true;
+}
+// GroupNorm-partial slots per (n, group) when the kernel takes the shape and can emit them (whole planes per group); 0 otherwise
+long bts_lp_s1z_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn) {
+  S1zPlan pl;
+  if (Gn <= 0 || D % Gn != 0 || !s1z_plan(pl, N, D, H, W, Cin, Cin, Cout, Cout)) return 0;
+  return (long)(D / Gn) * pl.nty * pl.ntx * 8;
+}
+// BTS_OK = ran, 1 = declined.  wp = the DMA part of the K3S1 image.
+int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bias, void* y, int N, int D, int H, int W, int Cin, int ldx,
+                       int Cout, int ldy, int accum, double* gn_part, int gn_G, hipStream_t stream) {
+  S1zPlan pl;
+  if (!s1z_plan(pl, N, D, H, W, Cin, ldx, Cout, ldy)) return 1;
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)y) & 15) || (((uintptr_t)wp) & 15)) return 1;
+  if (gn_part != nullptr && (gn_G <= 0 || D % gn_G != 0)) return 1;
+  LpS1zParams p;
+  p.x = (const unsigned short*)x; p.wp = (const unsigned short*)wp; p.bias = bias; p.y = (unsigned short*)y;
+  p.N = N; p.D = D; p.H = H; p.W = W; p.ldx = ldx; p.ldy = ldy; p.Cout = Cout;
+  p.ntx = pl.ntx; p.nty = pl.nty; p.nzc = pl.nzc; p.ZC = pl.ZC; p.nitems = pl.nitems; p.ipw = pl.ipw; p.xcd_order = pl.xcd; p.accum = accum;
+  p.gnp = gn_part; p.gn_G = gn_G; p.gn_zt = gn_G > 0 ? D / gn_G : 1; p.gn_B = gn_G > 0 ? (long)(D / gn_G) * pl.nty * pl.ntx * 8 : 0;
+  const int KS = Cin / 16;
+  const size_t shmem = (size_t)(27 * KS * 1024 + 2 * S1Z_NCHK * 1024 * KS + 256 + 1024);
+  (void)hipGetLastError();
+#define S1Z_LAUNCH(TT, KS_)                                                                                                  \
+  do {                                                                                                                       \
+    auto kern = lp_s1z_kernel<TT, KS_>;                                                                                      \
+    static bool done = false;                                                                                                \
+    if (!done) {                                                                                                             \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+      if (e != hipSuccess) return (int)e;                                                                                    \
+      done = true;                                                                                                           \
+    }                                                                                                                        \
+    hipLaunchKernelGGL(kern, dim3(pl.nwg), dim3(512), shmem, stream, p);                                                     \
+  } while (0)
+  const bool prof = bts_prof_on();
+  if (prof) bts_prof_begin(38, 2.0 * 27.0 * (double)Cin * Cout * (double)N * D * H * W, stream);
+  if (dtype == LP_F16) { if (KS == 2) S1Z_LAUNCH(TF16, 2); else S1Z_LAUNCH(TF16, 1); }
+  else { if (KS == 2) S1Z_LAUNCH(TBF16, 2); else S1Z_LAUNCH(TBF16, 1); }
+#undef S1Z_LAUNCH
+  if (prof) bts_prof_end(stream);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
