@@ -237,6 +237,10 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
 #endif
         acc[s][0] = T::mfma(A[g & 1][ky], B[bs][ky], acc[s][0]);
         acc[s][1] = T::mfma(A[g & 1][ky], B[bs][ky + 1], acc[s][1]);
+#ifdef S1Z_EXP_MFMA2     // timing experiment (wrong results): twice the matrix work per stage
+        acc[s][0] = T::mfma(A[g & 1][ky], B[bs][ky], acc[s][0]);
+        acc[s][1] = T::mfma(A[g & 1][ky], B[bs][ky + 1], acc[s][1]);
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
     }
