@@ -501,7 +501,7 @@ static bool s1d_enabled() {   // BTS_LP_S1D=0: every stride-1 conv on the regist
 }
 static bool s1d_plan(int N, int D, int H, int W, int Cin, int Cout, S1dPlan& pl) {
   if (!s1d_enabled() || Cin % 16 != 0 || Cout % 8 != 0 || W < 12) return false;
-  if ((long)N * D * H * W < 12288) return false;      // (20x24x20, the deepest level of the full inference volume: the small-tile kernel wins)
+  { const char* fl = getenv("BTS_LP_S1D_FLOOR"); if ((long)N * D * H * W < (fl ? atol(fl) : 12288)) return false; }      // (20x24x20, the deepest level of the full inference volume: the small-tile kernel wins)
   const int NB = (Cout + 31) / 32, KS = Cin / 16;
   pl.mode = NB >= 2 ? 1 : 0;
   pl.txl = W >= 24 ? 5 : 4;

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""the deepest level of the full inference volume (256 -> 256 at 20x24x20): tiled LDS-DMA kernel vs the register-staged one"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bts_amd  # noqa
+from bts_amd import lowp, ops
+code, tdt = lowp.DTYPES['float16']
+D = torch.device('cuda:0')
+for shape, cin, cout in (((1, 20, 24, 20), 256, 256), ((1, 20, 24, 20), 512, 256), ((1, 40, 48, 40), 128, 128)):
+    x = torch.randn(shape + (cin,), device=D).to(tdt)
+    wt = torch.randn((3, 3, 3, cin, cout), device=D) * 0.02
+    b = torch.zeros(cout, device=D)
+    wp = lowp.pack(ops.K3S1, code, wt, cin, cout)
+    for mode in ('1', '0'):
+        os.environ['BTS_LP_S1D'] = mode
+        ops.profile_enable(True)
+        lowp.conv(ops.K3S1, code, tdt, x, wp, b, cout)
+        torch.cuda.synchronize()
+        ops.profile_enable(False)
+        syms = [r[0] for r in ops.profile_records()]
+        for _ in range(3):
+            lowp.conv(ops.K3S1, code, tdt, x, wp, b, cout)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            lowp.conv(ops.K3S1, code, tdt, x, wp, b, cout)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        fl = 2.0 * 27 * cin * cout * x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3]
+        print(shape, cin, cout, 'S1D=%s' % mode, syms, '%.1f us  %.0f TF' % (ms * 1e3, fl / ms / 1e9))
