@@ -332,6 +332,76 @@ __global__ void se_mlp_bwd_kernel(const double* partial, const float* gap, const
   }
 }
 
+// The same arithmetic for batches (N >= 2) in two launches with many workgroups: the one-block kernel above walks N*R dot products of
+// length F with four waves (64 us at N = 8, F = 256: 1.35 ms of the batch-8 16-bit step).  Per-sample part: one workgroup per sample.
+__global__ __launch_bounds__(256) void se_mlp_bwd_sample_kernel(const double* partial, const float* hbuf, const float* ch, const float* w1,
+                                                                const float* w2, float* dgap, double* scratch, int N, int F, int R, double invV) {
+  const int n = blockIdx.x;
+  double* dz2 = scratch + (long)n * F;
+  double* dz1 = scratch + (long)N * F + (long)n * R;
+  for (int c = threadIdx.x; c < F; c += 256) {
+    const double cc = (double)ch[n * F + c];
+    dz2[c] = partial[((long)n * F + c) * 2] * cc * (1.0 - cc);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = wave; k < R; k += 4) {
+    double s = 0.0;
+    for (int c = lane; c < F; c += 64) s += (double)w2[k * F + c] * dz2[c];
+    s = wave_sum_f64(s);
+    if (lane == 0) dz1[k] = (hbuf[n * R + k] > 0.f) ? s : 0.0;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < F; c += 256) {
+    double s = 0.0;
+    for (int k = 0; k < R; ++k) s += (double)w1[c * R + k] * dz1[k];
+    dgap[n * F + c] = (float)(s * invV);
+  }
+}
+// sums over the samples: dW2, dW1, dw_sp
+__global__ __launch_bounds__(256) void se_mlp_bwd_param_kernel(const double* partial, const float* gap, const float* hbuf, float* dw1, float* dw2,
+                                                               float* dwsp, const double* scratch, int N, int F, int R, int accum) {
+  const double* dz2 = scratch;
+  const double* dz1 = scratch + (long)N * F;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < R * F) {
+    {
+      const int k = i / F, c = i % F;
+      double s = 0.0;
+      for (int n = 0; n < N; ++n) s += (double)hbuf[n * R + k] * dz2[n * F + c];
+      dw2[i] = accum ? dw2[i] + (float)s : (float)s;
+    }
+    {
+      const int c = i / R, k = i % R;
+      double s = 0.0;
+      for (int n = 0; n < N; ++n) s += (double)gap[n * F + c] * dz1[n * R + k];
+      dw1[i] = accum ? dw1[i] + (float)s : (float)s;
+    }
+  }
+  if (i < F) {
+    double s = 0.0;
+    for (int n = 0; n < N; ++n) s += partial[((long)n * F + i) * 2 + 1];
+    dwsp[i] = accum ? dwsp[i] + (float)s : (float)s;
+  }
+}
+static int se_mlp_bwd_launch(const double* red, const float* gap, const float* h, const float* ch, const float* w1, const float* w2, float* dw1,
+                             float* dw2, float* dwsp, float* dgap, double* scratch, int N, int B, long V, int F, int R, int accumulate_params,
+                             hipStream_t stream) {
+  (void)hipGetLastError();
+  if (N >= 2) {
+    hipLaunchKernelGGL(se_mlp_bwd_sample_kernel, dim3(N), dim3(256), 0, stream, red, h, ch, w1, w2, dgap, scratch, N, F, R, 1.0 / (double)V);
+    BTS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(se_mlp_bwd_param_kernel, dim3((R * F + 255) / 256), dim3(256), 0, stream, red, gap, h, dw1, dw2, dwsp, scratch, N, F, R,
+                       accumulate_params);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+  }
+  hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(1), dim3(256), 0, stream, red, gap, h, ch, w1, w2, dw1, dw2, dwsp, dgap, scratch, N, B, F, R,
+                     1.0 / (double)V, accumulate_params);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
 // stage 3: dres = dout*(sp + ch) + ds*wsp + dgap/V
 __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ sp,
                                                            const float* __restrict__ ds, const float* __restrict__ ch,
@@ -361,10 +431,7 @@ int bts_se_bwd_middle_(double* partial, double* red, double* scratch, const floa
                        int accumulate_params, hipStream_t stream) {
   (void)hipGetLastError(); hipLaunchKernelGGL(se_bwd_partial_reduce_kernel, dim3((N * F + 3) / 4), dim3(256), 0, stream, partial, red, N, B, F);
   BTS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(1), dim3(256), 0, stream, red, gap, h, ch, w1, w2, dw1, dw2, dwsp, dgap, scratch, N, B, F, R,
-                     1.0 / (double)V, accumulate_params);
-  BTS_LAUNCH_CHECK();
-  return BTS_OK;
+  return se_mlp_bwd_launch(red, gap, h, ch, w1, w2, dw1, dw2, dwsp, dgap, scratch, N, B, V, F, R, accumulate_params, stream);
 }
 
 static int se_bwd_blocks(long V, int N, int F, long* vspan) {
@@ -399,9 +466,10 @@ extern "C" int bts_se_bwd(const float* dout, const float* res, const float* sp, 
   BTS_LAUNCH_CHECK();
   (void)hipGetLastError(); hipLaunchKernelGGL(se_bwd_partial_reduce_kernel, dim3((N * F + 3) / 4), dim3(256), 0, stream, partial, red, N, B, F);
   BTS_LAUNCH_CHECK();
-  (void)hipGetLastError(); hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(1), dim3(256), 0, stream, red, gap, h, ch, w1, w2, dw1, dw2, dwsp, dgap,
-                     scratch, N, B, F, R, 1.0 / (double)V, accumulate_params);
-  BTS_LAUNCH_CHECK();
+  {
+    const int r = se_mlp_bwd_launch(red, gap, h, ch, w1, w2, dw1, dw2, dwsp, dgap, scratch, N, B, V, F, R, accumulate_params, stream);
+    if (r != BTS_OK) return r;
+  }
   const long total = (long)N * V * (F / 4);
   long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
