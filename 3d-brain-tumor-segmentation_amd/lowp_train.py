@@ -123,9 +123,10 @@ class LowPrecisionTrainer(object):
         return out, dict(blk=blk, x=x, res=res, c1=c1, m1=m1, r1=r1, a=a, c2=c2, m2=m2, r2=r2, gap=gap, hbuf=hbuf, ch=ch, sp=sp,
                          fold=(dup_start, dup_shift), cin_slab=cin_slab)
 
-    def _block_bwd(self, s, dout, dx):
+    def _block_bwd(self, s, dout, dx, first=False):
         """dout: 16-bit gradient of the block output (dense or a slab-gradient view); dx: 16-bit gradient view of the block input
-        to ACCUMULATE into, or None (the input volume)"""
+        to ACCUMULATE into, or None (the input volume).  first: this call is the first writer of dx (uninitialised memory): conv1's
+        data gradient writes it, the shortcut's accumulates -- no zero fill, no read of the old values"""
         code = self.code
         blk = s['blk']
         f, g = blk.filters, blk.groups
@@ -186,7 +187,7 @@ class LowPrecisionTrainer(object):
             cin = x.shape[-1]
             wpb1 = self._pk((key, 'c1b'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin, dup_start, dup_shift, role=ops.ROLE_BWD)
             wpbp = self._pk((key, 'ptb'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin, dup_start, dup_shift, role=ops.ROLE_BWD)
-            conv_bwd_data(ops.K3S1, code, dc1_16, wpb1, dx, True)
+            conv_bwd_data(ops.K3S1, code, dc1_16, wpb1, dx, not first)
             conv_bwd_data(ops.K1, code, dres_16, wpbp, dx, True)
 
     def _sampler_fwd(self, lay, kind, x, out=None):
@@ -371,8 +372,11 @@ class LowPrecisionTrainer(object):
         dyv = torch.empty_like(y_vae)
         dproj = torch.empty_like(proj)
         ops.loss_bwd(y_pred, y, x, y_vae, proj, sums, one, dyp, dyv, dproj, through_sigmoid=False)
-        # slab gradients (zero-initialised: every contribution accumulates)
-        gslabs = [torch.zeros_like(slab) for slab, _, _, _ in levels]
+        # slab gradients: uninitialised -- the first writer of each one writes, every later contribution accumulates.  Levels below the
+        # top: the decoder block's conv1 data gradient (its view [0, cres + f) is the whole slab); the top level: the first
+        # up-sampler's data gradient (its view [0, top_used) is the whole slab, which has no spare channels)
+        gslabs = [torch.empty_like(slab) for slab, _, _, _ in levels]
+        assert levels[-1][0].shape[-1] == top_used
         # decoder head (decoder.py:55-63): sigmoid, 1x1x1 conv to out_ch -- dx, dW and db from one pass over the 16-bit activations
         dpre = ops.sigmoid_bwd(y_pred, dyp)
         wk2 = dec.out_k.t.reshape(dec.out_k.t.shape[-2], dec.out_k.t.shape[-1])
@@ -390,9 +394,10 @@ class LowPrecisionTrainer(object):
         for idx in range(len(dsaves) - 1, -1, -1):
             us, bs, li, cres, f = dsaves[idx]
             gs = gslabs[li]
-            self._block_bwd(bs, dcur, gs[..., :cres + f])        # skip part [0, cres) and the up-sampled part [cres, cres + f)
+            assert gs.shape[-1] == cres + f
+            self._block_bwd(bs, dcur, gs[..., :cres + f], first=True)        # skip part [0, cres) and the up-sampled part [cres, cres + f)
             if idx == 0:                                         # the first up layer read the top level's slab view
-                self._sampler_bwd(us, gs[..., cres:cres + f], gslabs[-1][..., :top_used], True)
+                self._sampler_bwd(us, gs[..., cres:cres + f], gslabs[-1][..., :top_used], False)
             else:                                                # the others read the previous decoder block's output
                 dcur = torch.empty(us['x'].shape, dtype=tdt, device=dev)
                 self._sampler_bwd(us, gs[..., cres:cres + f], dcur, False)
@@ -426,8 +431,8 @@ class LowPrecisionTrainer(object):
             dv = self._b16(dv32)
             del dv32, ylv32
         for us, bs in reversed(vsaves):
-            dblk_in = torch.zeros(bs['x'].shape, dtype=tdt, device=dev)
-            self._block_bwd(bs, dv, dblk_in)
+            dblk_in = torch.empty(bs['x'].shape, dtype=tdt, device=dev)
+            self._block_bwd(bs, dv, dblk_in, first=True)
             dv = torch.empty(us['x'].shape, dtype=tdt, device=dev)
             self._sampler_bwd(us, dblk_in, dv, False)
         du16 = torch.zeros_like(u16)
@@ -453,8 +458,8 @@ class LowPrecisionTrainer(object):
                 if j > 0:
                     self._block_bwd(saves[j], dout, gs[..., :j * f])
                 elif i > 0:
-                    dprev = torch.zeros(saves[0]['x'].shape, dtype=tdt, device=dev)
-                    self._block_bwd(saves[0], dout, dprev)
+                    dprev = torch.empty(saves[0]['x'].shape, dtype=tdt, device=dev)
+                    self._block_bwd(saves[0], dout, dprev, first=True)
                     pslab, pused, _, pds = levels[i - 1]
                     self._sampler_bwd(pds, dprev, gslabs[i - 1][..., :pused], True)
                 else:

@@ -107,7 +107,9 @@ def test_16bit_step_at_128_cubed_against_the_fp32_engine(dtype, lim):
               (r[0], r[1], r[2], 100 * r[2] / tot, r[3], 100 * r[3] / tot))
     import os
     if os.environ.get('BTS_LP_S1D') != '0':
-        assert counts.get('lp_s1d_kernel', 0) >= 40 and counts.get('lp_wgrad_kernel', 0) + counts.get('lp_wgd_kernel', 0) >= 30, counts
+        assert counts.get('lp_s1d_kernel', 0) + counts.get('lp_s1z_kernel', 0) >= 40 and counts.get('lp_wgrad_kernel', 0) + counts.get('lp_wgd_kernel', 0) >= 30, counts
+        if os.environ.get('BTS_LP_S1Z') != '0':      # the z-marching conv carries the 128^3 level's 32-channel layers
+            assert counts.get('lp_s1z_kernel', 0) >= 8, counts
         if os.environ.get('BTS_LP_WGD') != '0':      # the streaming weight-gradient kernel carries the 128^3 .. 32^3 levels
             assert counts.get('lp_wgd_kernel', 0) >= 20, counts
     assert dl <= lim['loss'] and abs(d16 - macro32) <= lim['dice'] and mism <= lim['lab']
