@@ -53,16 +53,18 @@ int bts_lp_s1d_launch_(int dtype, const void* x, const void* wp_dma, const float
 // weight packing: Keras layout fp32 -> [tap][k-step of 16 cin][cout block of 32][h][32 couts][8 cin] 16-bit
 // =====================================================================================================================
 template <typename T>
+__device__ __forceinline__ void lp_pack_elem(const LpPackParams& p, long i) {
+  const int e = (int)(i & 7), r = (int)((i >> 3) & 31), h = (int)((i >> 8) & 1);
+  long q = i >> 9;
+  const int cb = (int)(q % p.NB); q /= p.NB;
+  const int ks = (int)(q % p.KS);
+  const int t = (int)(q / p.KS);
+  p.wp[i] = T::st(lp_pack_src(p, t, ks * 16 + h * 8 + e, cb * 32 + r));
+}
+template <typename T>
 __global__ __launch_bounds__(256) void lp_pack_kernel(const LpPackParams p) {
   const long total = (long)p.ntaps * p.KS * p.NB * 512;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int e = (int)(i & 7), r = (int)((i >> 3) & 31), h = (int)((i >> 8) & 1);
-    long q = i >> 9;
-    const int cb = (int)(q % p.NB); q /= p.NB;
-    const int ks = (int)(q % p.KS);
-    const int t = (int)(q / p.KS);
-    p.wp[i] = T::st(lp_pack_src(p, t, ks * 16 + h * 8 + e, cb * 32 + r));
-  }
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) lp_pack_elem<T>(p, i);
 }
 
 static int lp_ntaps(int kind) { return kind == BTS_CONV_K1 ? 1 : 27; }
@@ -80,11 +82,10 @@ extern "C" long bts_lp_packed_bytes(int kind, int role, int Cin_slab, int Cout) 
 }
 // byte offset of the DMA part inside a K3S1 image with K contraction channels and N output columns
 static long lp_s1d_part_offset(int K, int N) { return 27L * ((K + 15) / 16) * ((N + 31) / 32) * 1024; }
-extern "C" int bts_lp_pack(int kind, int role, int dtype, const float* w, void* wp, int Cin_ref, int Cout, int Cin_slab, int dup_start,
-                           int dup_shift, hipStream_t stream) {
-  if (kind < 0 || kind > 3 || role < 0 || role > 1 || (dtype != LP_F16 && dtype != LP_BF16)) return BTS_ERR_UNSUPPORTED;
+static int lp_pack_params(LpPackParams& p, int kind, int role, const float* w, void* wp, int Cin_ref, int Cout, int Cin_slab, int dup_start,
+                          int dup_shift) {
+  if (kind < 0 || kind > 3 || role < 0 || role > 1) return BTS_ERR_UNSUPPORTED;
   if (Cin_slab + dup_shift != Cin_ref || dup_shift < 0 || dup_start < 0 || dup_start + dup_shift > Cin_slab) return BTS_ERR_SHAPE;
-  LpPackParams p;
   p.w = w; p.wp = reinterpret_cast<unsigned short*>(wp);
   p.ntaps = lp_ntaps(kind);
   p.shift = dup_shift;
@@ -100,6 +101,14 @@ extern "C" int bts_lp_pack(int kind, int role, int dtype, const float* w, void* 
     p.flip = (kind == BTS_CONV_K3S1) ? 1 : 0;
   }
   p.KS = (p.K + 15) / 16; p.NB = (p.N + 31) / 32;
+  return BTS_OK;
+}
+extern "C" int bts_lp_pack(int kind, int role, int dtype, const float* w, void* wp, int Cin_ref, int Cout, int Cin_slab, int dup_start,
+                           int dup_shift, hipStream_t stream) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  LpPackParams p;
+  const int r = lp_pack_params(p, kind, role, w, wp, Cin_ref, Cout, Cin_slab, dup_start, dup_shift);
+  if (r != BTS_OK) return r;
   const long total = (long)p.ntaps * p.KS * p.NB * 512;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
@@ -108,6 +117,64 @@ extern "C" int bts_lp_pack(int kind, int role, int dtype, const float* w, void* 
   else hipLaunchKernelGGL(lp_pack_kernel<TBF16>, dim3(blocks), dim3(256), 0, stream, p);
   BTS_LAUNCH_CHECK();
   if (lp_has_dma_part(kind, role)) return bts_lp_s1d_pack_(dtype, p, reinterpret_cast<char*>(wp) + lp_s1d_part_offset(p.K, p.N), stream);
+  return BTS_OK;
+}
+// All 16-bit weight images in one launch (every image goes stale together at the optimiser step, train.py:152; the batch-8 step spent
+// 1.2 ms in 194 launches of 6 us).  Host table of descriptors as bts_conv_pack_desc / bts_conv_pack_batch of the fp32 engine.
+struct LpPackDesc {
+  LpPackParams p;          // first part
+  unsigned short* wp_dma;  // second part (LDS-DMA stage order), or NULL
+  int cbw, ncg;
+  long total_main, total;  // elements of the first part / of both
+  long first_block;
+};
+#define LP_PACK_BLOCK_ELEMS 2048
+template <typename T>
+__global__ __launch_bounds__(256) void lp_pack_batch_kernel(const LpPackDesc* tab, int n) {
+  const long blk = blockIdx.x;
+  int lo = 0, hi = n - 1;       // last descriptor with first_block <= blk
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].first_block <= blk) lo = mid; else hi = mid - 1;
+  }
+  const LpPackDesc d = tab[lo];
+  const long e0 = (blk - d.first_block) * LP_PACK_BLOCK_ELEMS;
+  for (int k = 0; k < LP_PACK_BLOCK_ELEMS / 256; ++k) {
+    const long i = e0 + k * 256 + threadIdx.x;
+    if (i < d.total_main) lp_pack_elem<T>(d.p, i);
+    else if (i < d.total) {
+      LpPackParams q = d.p;
+      q.wp = d.wp_dma;
+      lp_s1d_pack_elem<T>(q, d.cbw, i - d.total_main);
+    }
+  }
+}
+extern "C" long bts_lp_pack_desc_bytes(void) { return (long)sizeof(LpPackDesc); }
+extern "C" long bts_lp_pack_desc(void* host_table, int index, long first_block, int kind, int role, const float* w, void* wp, int Cin_ref,
+                                 int Cout, int Cin_slab, int dup_start, int dup_shift) {
+  LpPackDesc d;
+  const int r = lp_pack_params(d.p, kind, role, w, wp, Cin_ref, Cout, Cin_slab, dup_start, dup_shift);
+  if (r != BTS_OK) return r;
+  d.total_main = (long)d.p.ntaps * d.p.KS * d.p.NB * 512;
+  d.total = d.total_main;
+  d.wp_dma = nullptr; d.cbw = 1; d.ncg = 1;
+  if (lp_has_dma_part(kind, role)) {
+    d.wp_dma = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(wp) + lp_s1d_part_offset(d.p.K, d.p.N));
+    d.cbw = d.p.NB >= 2 ? 2 : 1;
+    d.ncg = (d.p.NB + d.cbw - 1) / d.cbw;
+    d.total += bts_lp_s1d_image_bytes_(d.p.K, d.p.N) / 2;
+  }
+  d.first_block = first_block;
+  reinterpret_cast<LpPackDesc*>(host_table)[index] = d;
+  return (d.total + LP_PACK_BLOCK_ELEMS - 1) / LP_PACK_BLOCK_ELEMS;
+}
+extern "C" int bts_lp_pack_batch(int dtype, const void* table_dev, int n, long total_blocks, hipStream_t stream) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  if (n <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffL) return BTS_ERR_SHAPE;
+  (void)hipGetLastError();
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_pack_batch_kernel<TF16>, dim3((unsigned)total_blocks), dim3(256), 0, stream, reinterpret_cast<const LpPackDesc*>(table_dev), n);
+  else hipLaunchKernelGGL(lp_pack_batch_kernel<TBF16>, dim3((unsigned)total_blocks), dim3(256), 0, stream, reinterpret_cast<const LpPackDesc*>(table_dev), n);
+  BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
 

@@ -82,3 +82,18 @@ __device__ __forceinline__ float lp_pack_src(const LpPackParams& q, int t, int k
     v += q.w[ts * q.sT + k2 * q.sK + n2 * q.sN];
   return v;
 }
+
+// element i of the LDS-DMA stage-order part of a K3S1 image: [cout group of CBW blocks][k-step][dz][dy*3+dx][k-half][cout in group][8 cin]
+// (lowp_s1d.hip's pack kernel and lowp.hip's batched pack)
+template <typename T> __device__ __forceinline__ void lp_s1d_pack_elem(const LpPackParams& p, int CBW, long i) {
+  const int e = (int)(i & 7);
+  long q = i >> 3;
+  const int row = (int)(q % (32 * CBW)); q /= 32 * CBW;
+  const int hh = (int)(q & 1); q >>= 1;
+  const int t9 = (int)(q % 9); q /= 9;
+  const int dz = (int)(q % 3); q /= 3;
+  const int ks = (int)(q % p.KS);
+  const int cg = (int)(q / p.KS);
+  p.wp[i] = T::st(lp_pack_src(p, dz * 9 + t9, ks * 16 + hh * 8 + e, cg * CBW * 32 + row));
+}
+

@@ -429,17 +429,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void lp_s1d_pack_kernel(const LpPackParams p, int CBW, int NCG) {
   const long per_stage = 9L * CBW * 512;   // elements
   const long total = (long)NCG * p.KS * 3 * per_stage;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int e = (int)(i & 7);
-    long q = i >> 3;
-    const int row = (int)(q % (32 * CBW)); q /= 32 * CBW;
-    const int hh = (int)(q & 1); q >>= 1;
-    const int t9 = (int)(q % 9); q /= 9;
-    const int dz = (int)(q % 3); q /= 3;
-    const int ks = (int)(q % p.KS);
-    const int cg = (int)(q / p.KS);
-    p.wp[i] = T::st(lp_pack_src(p, dz * 9 + t9, ks * 16 + hh * 8 + e, cg * CBW * 32 + row));
-  }
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) lp_s1d_pack_elem<T>(p, CBW, i);
 }
 
 static int s1d_cbw(int NB) { return NB >= 2 ? 2 : 1; }

@@ -52,6 +52,40 @@ def pack(kind, code, w, cin_ref, cout, cin_slab=None, dup_start=0, dup_shift=0, 
     return wp
 
 
+class PackTable(object):
+    """Device-resident descriptor table for bts_lp_pack_batch: entries = [(kind, role, w, wp, cin_ref, cout, cin_slab, dup_start,
+    dup_shift)] with torch tensors w (reference layout, fp32) / wp (packed 16-bit image).  Rebuilt only when a pointer or the entry
+    list changes (ops.PackTable is the fp32 engine's)."""
+
+    def __init__(self):
+        self.key = None
+        self.dev = None
+        self.n = 0
+        self.blocks = 0
+
+    def run(self, code, entries):
+        if not entries:
+            return
+        import ctypes
+        key = tuple((e[0], e[1], e[2].data_ptr(), e[3].data_ptr()) + tuple(e[4:]) for e in entries)
+        if key != self.key:
+            L = lib()
+            nb = L._bts_lp_pack_desc_bytes()
+            host = (ctypes.c_char * (nb * len(entries)))()
+            first = 0
+            for i, (kind, role, w, wp, cin_ref, cout, cin_slab, dup_start, dup_shift) in enumerate(entries):
+                if not w.is_contiguous() or w.dtype != torch.float32:
+                    raise ValueError('lp_pack_batch: kernels must be contiguous fp32 tensors')
+                r = L._bts_lp_pack_desc(ctypes.cast(host, ctypes.c_void_p), i, first, kind, role, _p(w), _p(wp), cin_ref, cout, cin_slab,
+                                        dup_start, dup_shift)
+                if r <= 0:
+                    raise RuntimeError('bts_lp_pack_desc failed: %s' % ops.ERRORS.get(r, r))
+                first += r
+            self.dev = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(entries[0][3].device)
+            self.key, self.n, self.blocks = key, len(entries), first
+        lib().call('bts_lp_pack_batch', code, _p(self.dev), self.n, self.blocks, _stream())
+
+
 def conv_bwd_data(kind, code, dy, wp_bwd, dx, accumulate):
     """dx (+)= conv^T(dy); dx: (N,D,H,W,Cin) view of the forward input's gradient, dy: the forward output's"""
     n, d, h, w, cin = dx.shape

@@ -305,6 +305,13 @@ int bts_lp_se_bwd(int dtype, const void* dout, const void* res, const float* sp,
                   const float* w1, const float* w2, const float* wsp, void* dres, float* ds, float* dgap, float* dw1, float* dw2, float* dwsp,
                   void* workspace, long workspace_bytes, int N, long V, int F, int R, int lddo, int accumulate_params, float* dbias,
                   bts_stream_t stream);
+/* All 16-bit weight images in one launch (they go stale together at the optimiser step, train.py:152): host table of
+ * bts_lp_pack_desc_bytes()-sized descriptors filled by bts_lp_pack_desc (arguments as bts_lp_pack; returns the entry's block count > 0 or
+ * a negative engine code; first_block = running sum of those counts), copied to device memory by the caller. */
+long bts_lp_pack_desc_bytes(void);
+long bts_lp_pack_desc(void* host_table, int index, long first_block, int kind, int role, const float* w, void* wp, int Cin_ref, int Cout,
+                      int Cin_slab, int dup_start, int dup_shift);
+int bts_lp_pack_batch(int dtype, const void* table_dev, int n, long total_blocks, bts_stream_t stream);
 /* the non-default samplers on 16-bit tensors (args.py:136-141): MaxPooling3D(2) (downsample.py:51-70; (D,H,W) = INPUT dims, idx the
  * window position of the first maximum per output element, NULL when no gradient is wanted) and UpSampling3D(2) (upsample.py:69;
  * (D,H,W) = COARSE dims), with their gradients; C % 8 == 0, channel-slice views allowed */
