@@ -576,3 +576,37 @@ def test_upsample2_and_its_gradient(dtype):
     acc = old.clone()
     lowp.upsample2_bwd(code, dy[..., 16:40], dx=acc, accumulate=True)
     assert float((acc.float() - (r + old.float())).abs().max()) <= 2.0 ** (-7 if dtype == 'bfloat16' else -10) * float(r.abs().max() + 3)
+
+
+def test_batched_weight_packing_equals_the_single_calls():
+    """bts_lp_pack_batch (one launch for every image of the trainer) writes bit-for-bit what bts_lp_pack writes image by image: all four
+    kinds, both roles, a folded duplicate slice, a 2-channel first block (K < one matrix step), partly filled cout blocks"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    g = torch.Generator().manual_seed(77)
+    for dtype in ('float16', 'bfloat16'):
+        code, tdt = lowp.DTYPES[dtype]
+        cases = [(ops.K3S1, ops.ROLE_FWD, 32, 32, None, 0, 0), (ops.K3S1, ops.ROLE_BWD, 64, 24, None, 0, 0), (ops.K3S1, ops.ROLE_FWD, 48, 64, 32, 16, 16),
+                 (ops.K3S1, ops.ROLE_BWD, 48, 64, 32, 16, 16), (ops.K3S1, ops.ROLE_FWD, 2, 32, None, 0, 0), (ops.K1, ops.ROLE_FWD, 48, 32, 32, 16, 16),
+                 (ops.K1, ops.ROLE_BWD, 32, 8, None, 0, 0), (ops.K3S2, ops.ROLE_FWD, 32, 64, None, 0, 0), (ops.K3S2, ops.ROLE_BWD, 32, 64, None, 0, 0),
+                 (ops.K3S2T, ops.ROLE_FWD, 128, 64, None, 0, 0), (ops.K3S2T, ops.ROLE_BWD, 16, 8, None, 0, 0)]
+        entries, singles = [], []
+        for kind, role, cin_ref, cout, cin_slab, ds, dsh in cases:
+            k = 1 if kind == ops.K1 else 3
+            shape = (k, k, k, cout, cin_ref) if kind == ops.K3S2T else (k, k, k, cin_ref, cout)
+            w = torch.randn(shape, generator=g).to(DEV)
+            single = lowp.pack(kind, code, w, cin_ref, cout, cin_slab, ds, dsh, role=role)
+            wp = torch.full_like(single, 0x5a5a)
+            entries.append((kind, role, w, wp, cin_ref, cout, cin_ref if cin_slab is None else cin_slab, ds, dsh))
+            singles.append(single)
+        tab = lowp.PackTable()
+        tab.run(code, entries)
+        torch.cuda.synchronize()
+        for e, single in zip(entries, singles):
+            assert torch.equal(e[3], single), (dtype, e[0], e[1], e[4], e[5])
+        # a second run reuses the device table (same pointers) and overwrites in place
+        for e in entries:
+            e[3].fill_(0)
+        tab.run(code, entries)
+        torch.cuda.synchronize()
+        assert all(torch.equal(e[3], s) for e, s in zip(entries, singles))
