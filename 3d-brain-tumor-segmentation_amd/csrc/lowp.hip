@@ -2478,6 +2478,209 @@ __global__ __launch_bounds__(256) void lp_se_bwd_reduce_kernel(const unsigned sh
     partial[o + 1] = sb;
   }
 }
+// =====================================================================================================================
+// A ResnetBlock's gate backward and GroupNorm-2 backward in ONE pair of passes (resnet.py:121-137 under TF autodiff).  Both read the
+// gradient of the block output: the separate routes (bts_lp_se_bwd, bts_lp_gn_bwd) read it four times and launch ten kernels; here
+// the reduce pass reads dout, res, c2 once (GroupNorm class sums + gate sums + the per-voxel spatial-gate gradient) and the apply pass
+// reads dout, c2 once and writes dres and dc2 (+ both bias-gradient rows).  Thread mapping of the GroupNorm kernels: a workgroup owns a
+// span of one (n, group) unit, a thread 8 consecutive channels of a voxel, the C/8 lanes of a voxel are neighbours.
+// =====================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void lp_blk_bwd_reduce_kernel(const unsigned short* x, const unsigned short* dy, const unsigned short* res,
+                                                                const float* sp, const float* gamma, const float* beta, const float* mean,
+                                                                const float* rstd, double* partial, double* se_partial, float* ds_out, long E,
+                                                                long L, long span, int C, int G, int cg, int lddy) {
+  __shared__ double sh[4 * 4 * 16];
+  __shared__ double sh2[256 * 16];
+  const int unit = blockIdx.y, n = unit / G, g = unit % G;
+  const long lo = (long)blockIdx.x * span;
+  long hi = lo + span;
+  if (hi > L) hi = L;
+  const long ubase = (long)g * L;
+  const int cph = (int)((ubase + lo + threadIdx.x * 8L) % C);
+  const int F8 = C >> 3;
+  float gam[8], bet[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { const int idx = g * cg + ((cph + e) % cg); gam[e] = gamma[idx]; bet[e] = beta[idx]; }
+  const float m = mean[unit], rs = rstd[unit];
+  double a[8], b[8], pa[8], pb[8];
+  float fa[8], fb[8], qa[8], qb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] = b[e] = pa[e] = pb[e] = 0.0; fa[e] = fb[e] = qa[e] = qb[e] = 0.f; }
+  const unsigned short* xb = x + (long)n * E + ubase;
+  const unsigned short* rb = res + (long)n * E + ubase;
+  int cnt = 0;
+  for (long i = lo + threadIdx.x * 8L; i < hi; i += 2048) {      // (hi - lo is a multiple of 2048: the lanes of a voxel leave together)
+    float v[8], d[8], r[8];
+    unpack8<T>(*reinterpret_cast<const u32x4*>(xb + i), v);
+    unpack8<T>(*reinterpret_cast<const u32x4*>(rb + i), r);
+    const long gi = (long)n * E + ubase + i;
+    const long pix = gi / C;
+    unpack8<T>(*reinterpret_cast<const u32x4*>(dy + pix * lddy + (gi - pix * C)), d);
+    float t = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t = fmaf(d[e], r[e], t);
+    for (int o = F8 >> 1; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    const float s = sp[pix];
+    const float dsv = t * s * (1.f - s);
+    if ((threadIdx.x & (F8 - 1)) == 0) ds_out[pix] = dsv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = (v[e] - m) * rs;
+      float de = d[e];
+      if (!(xh * gam[e] + bet[e] > 0.f)) de = 0.f;
+      fa[e] = fmaf(de, xh, fa[e]);
+      fb[e] += de;
+      qa[e] = fmaf(d[e], r[e], qa[e]);
+      qb[e] = fmaf(dsv, r[e], qb[e]);
+    }
+    if (++cnt == 32) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a[e] += fa[e]; b[e] += fb[e]; pa[e] += qa[e]; pb[e] += qb[e]; fa[e] = fb[e] = qa[e] = qb[e] = 0.f; }
+      cnt = 0;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] += fa[e]; b[e] += fb[e]; pa[e] += qa[e]; pb[e] += qb[e]; }
+  // gate sums first (their LDS array is separate): threads of equal octet (t mod F8) in thread order
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sh2[threadIdx.x * 16 + e] = pa[e]; sh2[threadIdx.x * 16 + 8 + e] = pb[e]; }
+  // GroupNorm class sums exactly as lp_gn_bwd_reduce_kernel
+  const int p = cg > 8 ? cg / 8 : 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int off = 32; off >= p; off >>= 1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] += __shfl_xor(a[e], off, 64); b[e] += __shfl_xor(b[e], off, 64); }
+  }
+  if (lane < p) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sh[((wave * 4 + lane) * 8 + e) * 2] = a[e]; sh[((wave * 4 + lane) * 8 + e) * 2 + 1] = b[e]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < cg) {
+    const int j = threadIdx.x;
+    const int cph0 = (int)((ubase + lo) % C);
+    double sa = 0.0, sb = 0.0;
+    for (int w = 0; w < 4; ++w)
+      for (int q = 0; q < p; ++q)
+        for (int e = 0; e < 8; ++e)
+          if (((cph0 + 8 * q + e) % cg) == j) { sa += sh[((w * 4 + q) * 8 + e) * 2]; sb += sh[((w * 4 + q) * 8 + e) * 2 + 1]; }
+    double* o = partial + (((long)unit * gridDim.x + blockIdx.x) * cg + j) * 2;
+    o[0] = sa; o[1] = sb;
+  }
+  const int vpb = 256 / F8;
+  for (int col = threadIdx.x; col < C; col += 256) {
+    const int e = col & 7, l = col >> 3;
+    double sa = 0.0, sb = 0.0;
+    for (int k = 0; k < vpb; ++k) { sa += sh2[(k * F8 + l) * 16 + e]; sb += sh2[(k * F8 + l) * 16 + 8 + e]; }
+    const long o = ((((long)n * G + g) * gridDim.x + blockIdx.x) * C + col) * 2;      // block index inside the sample: g * B + b
+    se_partial[o] = sa;
+    se_partial[o + 1] = sb;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void lp_blk_bwd_apply_kernel(const unsigned short* x, const unsigned short* dy, unsigned short* dx, unsigned short* dres,
+                                                               const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                                               const float* c1, const float* c2, const float* sp, const float* ds, const float* ch,
+                                                               const float* wsp, const float* dgap, long total8, long E, long L, int C, int G,
+                                                               int cg, int lddy, double* dbias_c2, double* dbias_pt) {
+  __shared__ float dbsh[256 * 8];
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long f = blockIdx.x * 256L + threadIdx.x; f < total8; f += (long)gridDim.x * 256) {
+    const long i = f * 8;
+    const long n = i / E;
+    const long r = i - n * E;
+    const int c = (int)(r % C);
+    const long pix = i / C;
+    const int g = (int)(r / L);
+    const long unit = n * G + g;
+    float v[8], d[8], o[8], q[8];
+    unpack8<T>(*reinterpret_cast<const u32x4*>(x + i), v);
+    unpack8<T>(*reinterpret_cast<const u32x4*>(dy + pix * lddy + c), d);
+    const float m = mean[unit], rs = rstd[unit], k1 = c1[unit], k2 = c2[unit];
+    const float s = sp[pix], dsv = ds[pix];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int idx = g * cg + ((c + e) % cg);
+      const float xh = (v[e] - m) * rs;
+      float de = d[e];
+      const float ga = gamma[idx];
+      if (!(xh * ga + beta[idx] > 0.f)) de = 0.f;
+      o[e] = (de * ga - k1 - xh * k2) * rs;
+      cs[e] += o[e];
+      q[e] = fmaf(d[e], s + ch[n * C + c + e], fmaf(dsv, wsp[c + e], dgap[n * C + c + e]));
+      cr[e] += q[e];
+    }
+    *reinterpret_cast<u32x4*>(dx + i) = pack8<T>(o);
+    *reinterpret_cast<u32x4*>(dres + i) = pack8<T>(q);
+  }
+  if (dbias_c2 != nullptr) lp_dbias_block(cs, 0, C / 8, dbias_c2 + (long)blockIdx.x * C, dbsh);     // (launch-uniform)
+  if (dbias_pt != nullptr) lp_dbias_block(cr, 0, C / 8, dbias_pt + (long)blockIdx.x * C, dbsh);
+}
+int bts_se_bwd_middle_(double* partial, double* red, double* scratch, const float* gap, const float* h, const float* ch, const float* w1,
+                       const float* w2, float* dw1, float* dw2, float* dwsp, float* dgap, int N, int B, long V, int F, int R,
+                       int accumulate_params, hipStream_t stream);
+static int lp_gnb_blocks(long L);
+extern "C" long bts_lp_block_bwd_workspace(int N, long V, int F, int R, int G) {
+  if (N <= 0 || V <= 0 || F < 8 || R <= 0 || G <= 0 || F % G != 0) return -1;
+  const long L = V * F / G;
+  const long B = lp_gnb_blocks(L);
+  return (long)N * G * B * (F / G) * 2 * 8 + (long)N * G * 2 * 4 + 64      // GroupNorm partials, c1 / c2
+         + (long)N * G * B * F * 2 * 8 + ((long)N * F * 3 + (long)N * R) * 8 + 128      // gate partials, red, scratch
+         + 2 * (2048L * F * 8 + 64);      // two sets of bias-gradient rows
+}
+// dout (N,V,F) rows of lddo; res, c2 dense; dres, dc2 dense outputs in the storage type; ds (N*V) and dgap (N,F) fp32 scratch outputs;
+// parameter gradients accumulate (+=); dbias_pt / dbias_c2 (may be NULL): the shortcut conv's / conv2's bias gradients (+=).
+// BTS_ERR_UNSUPPORTED outside the kernels' tiling: the caller runs bts_lp_gn_bwd and bts_lp_se_bwd.
+extern "C" int bts_lp_block_bwd(int dtype, const void* dout, int lddo, const void* res, const void* c2x, const float* sp, const float* gap,
+                                const float* h, const float* ch, const float* w1, const float* w2, const float* wsp, const float* gamma,
+                                const float* beta, const float* mean, const float* rstd, void* dres, void* dc2, float* ds, float* dgap, float* dw1,
+                                float* dw2, float* dwsp, float* dgamma, float* dbeta, float* dbias_pt, float* dbias_c2, void* workspace,
+                                long workspace_bytes, int N, long V, int F, int R, int G, hipStream_t stream) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  if (N <= 0 || V <= 0 || F < 8 || F < G || F % G != 0 || (F & (F - 1)) != 0 || F > 256 || lddo % 8 != 0 || lddo < F || R <= 0) return BTS_ERR_SHAPE;
+  const long E = V * F, L = E / G;
+  const int cg = F / G;
+  if (E % G != 0 || L % 2048 != 0 || cg > 32 || 256 % cg != 0) return BTS_ERR_UNSUPPORTED;
+  if ((((uintptr_t)dout) & 15) || (((uintptr_t)res) & 15) || (((uintptr_t)c2x) & 15) || (((uintptr_t)dres) & 15) || (((uintptr_t)dc2) & 15)) return BTS_ERR_ALIGN;
+  if (workspace == nullptr || (((uintptr_t)workspace) & 15) || workspace_bytes < bts_lp_block_bwd_workspace(N, V, F, R, G)) return BTS_ERR_WORKSPACE;
+  const int B = lp_gnb_blocks(L);
+  const long span = ((L / 2048 + B - 1) / B) * 2048;
+  double* partial = reinterpret_cast<double*>(workspace);
+  float* c1 = reinterpret_cast<float*>(partial + (long)N * G * B * cg * 2);
+  float* c2 = c1 + (long)N * G;
+  double* sep = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(c2 + (long)N * G) + 63) & ~(uintptr_t)63);
+  double* red = sep + (long)N * G * B * F * 2;
+  double* scratch = red + (long)N * F * 2;
+  double* dbp1 = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(scratch + (long)N * F + (long)N * R) + 63) & ~(uintptr_t)63);
+  double* dbp2 = dbp1 + 2048L * F + 8;
+  (void)hipGetLastError();
+#define LP_BB_R(TT) hipLaunchKernelGGL(lp_blk_bwd_reduce_kernel<TT>, dim3(B, N * G), dim3(256), 0, stream, (const unsigned short*)c2x, (const unsigned short*)dout, (const unsigned short*)res, sp, gamma, beta, mean, rstd, partial, sep, ds, E, L, span, F, G, cg, lddo)
+  if (dtype == LP_F16) LP_BB_R(TF16); else LP_BB_R(TBF16);
+#undef LP_BB_R
+  BTS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(lp_gn_bwd_finalize_kernel, dim3(G), dim3(256), 0, stream, partial, gamma, dgamma, dbeta, c1, c2, N, G, B, cg, (double)L, 1);
+  BTS_LAUNCH_CHECK();
+  const int r = bts_se_bwd_middle_(sep, red, scratch, gap, h, ch, w1, w2, dw1, dw2, dwsp, dgap, N, G * B, V, F, R, 1, stream);
+  if (r != BTS_OK) return r;
+  const long total8 = (long)N * E / 8;
+  long blocks = (total8 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+#define LP_BB_A(TT) hipLaunchKernelGGL(lp_blk_bwd_apply_kernel<TT>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)c2x, (const unsigned short*)dout, (unsigned short*)dc2, (unsigned short*)dres, gamma, beta, mean, rstd, c1, c2, sp, ds, ch, wsp, dgap, total8, E, L, F, G, cg, lddo, dbias_c2 ? dbp1 : (double*)nullptr, dbias_pt ? dbp2 : (double*)nullptr)
+  if (dtype == LP_F16) LP_BB_A(TF16); else LP_BB_A(TBF16);
+#undef LP_BB_A
+  BTS_LAUNCH_CHECK();
+  if (dbias_c2 != nullptr) {
+    hipLaunchKernelGGL(lp_dbias_finalize_kernel, dim3(F), dim3(256), 0, stream, dbp1, dbias_c2, (int)blocks, F, 1);
+    BTS_LAUNCH_CHECK();
+  }
+  if (dbias_pt != nullptr) {
+    hipLaunchKernelGGL(lp_dbias_finalize_kernel, dim3(F), dim3(256), 0, stream, dbp2, dbias_pt, (int)blocks, F, 1);
+    BTS_LAUNCH_CHECK();
+  }
+  return BTS_OK;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void lp_se_bwd_apply_kernel(const unsigned short* dout, const float* sp, const float* ds, const float* ch,
                                                               const float* wsp, const float* dgap, unsigned short* dres, long NV, long V, int F,

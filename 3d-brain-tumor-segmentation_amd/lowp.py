@@ -259,6 +259,30 @@ def se_bwd(code, tdt, dout, res, sp, gap, h, ch, w1, w2, wsp, dw1, dw2, dwsp, db
     return dres
 
 
+def block_bwd(code, tdt, dout, res, c2, sp, gap, h, ch, w1, w2, wsp, gamma, beta, mean, rstd, groups, dw1, dw2, dwsp, dgamma, dbeta,
+              dbias_pt=None, dbias_c2=None):
+    """gate backward + GroupNorm-2 (+ReLU) backward of a ResnetBlock in one pair of passes -> (dres, dc2) in the storage type, or None
+    outside the fused kernels' tiling (the caller then runs se_bwd and gn_bwd).  Parameter / bias gradients accumulate."""
+    n, f = res.shape[0], res.shape[4]
+    v = res.shape[1] * res.shape[2] * res.shape[3]
+    L = v * f // groups
+    cg = f // groups
+    if (v * f) % groups or L % 2048 or cg > 32 or 256 % cg or f > 256 or f & (f - 1) or not (res.is_contiguous() and c2.is_contiguous()):
+        return None
+    r = w1.shape[1]
+    nb = lib().query('bts_lp_block_bwd_workspace', n, v, f, r, groups)
+    ws = ops.workspace(nb, res.device)
+    dres = torch.empty_like(res)
+    dc2 = torch.empty_like(c2)
+    ds = torch.empty(n * v, dtype=torch.float32, device=res.device)
+    dgap = torch.empty((n, f), dtype=torch.float32, device=res.device)
+    lib().call('bts_lp_block_bwd', code, _p(dout), _ld(dout), _p(res), _p(c2), _p(sp), _p(gap), _p(h), _p(ch), _p(w1), _p(w2), _p(wsp), _p(gamma),
+               _p(beta), _p(mean), _p(rstd), _p(dres), _p(dc2), _p(ds), _p(dgap), _p(dw1), _p(dw2), _p(dwsp), _p(dgamma), _p(dbeta),
+               _p(dbias_pt) if dbias_pt is not None else None, _p(dbias_c2) if dbias_c2 is not None else None, _p(ws), nb, n, v, f, r, groups,
+               _stream())
+    return dres, dc2
+
+
 def head_bwd(code, tdt, x, dpre, w, dw, db, accumulate=True):
     """output head backward in one pass over the 16-bit activations -> dx (storage type); dw (C,K) / db (K) fp32 accumulate.
     None when the head is outside the kernel's shapes (C in {16,32,64}, K <= 4): the caller then runs the fp32 kernels"""

@@ -19,6 +19,8 @@ reference of this path: tests/test_lowp_train_gpu.py) is not touched.  Parameter
 flat buffer; slab gradients are zero-initialised and accumulated into (a 16-bit accumulation: every partial sum is rounded
 to the storage type, which is part of what "16-bit storage" means and is bounded by the parity test).
 """
+import os
+
 import torch
 
 from . import lowp, ops, parallel
@@ -33,6 +35,10 @@ class LowPrecisionTrainer(object):
         self.code, self.tdt = DTYPES[dtype]
         self._packs = {}
         self._pack_table = lowp.PackTable()
+        # BTS_LP_FUSE_BLOCK_BWD=1: gate + GroupNorm-2 backward in one pair of passes (bts_lp_block_bwd).  Built, parity-tested and measured
+        # SLOWER than the two separate routes (94.0 vs 90.3 ms per batch-8 step: the fused reduce pass carries four fp64 sum sets and 34 KB
+        # of LDS per workgroup, and streams at a lower rate than the two light passes it replaces): off by default, DESIGN 11.4
+        self.fuse_block_bwd = os.environ.get('BTS_LP_FUSE_BLOCK_BWD', '0') == '1'
         self.last_labels = None
 
     # ---- weight images ----
@@ -163,7 +169,19 @@ class LowPrecisionTrainer(object):
         pad_in = cin_slab < x.shape[-1]
         lp1 = lowp.wgrad_supported(ops.K3S1, x.shape[-1], f)
         # conv branch: GN2 (+ReLU) -> conv2 -> GN1 (+ReLU) -> conv1
-        dc2_16, dc2 = self._gn_bwd(n2, s['c2'], dout, s['m2'], s['r2'], want_f32=not lp2, dbias=self._gslot(blk.conv2_b) if lp2 else None)
+        # gate backward and GroupNorm-2 backward both read dout: one pair of passes where the fused kernels' tiling fits
+        fused = None
+        if lp2 and lp1 and n2._mode == ops.GN_SLAB and f % 16 == 0 and self.fuse_block_bwd:
+            fused = lowp.block_bwd(code, self.tdt, dout, s['res'], s['c2'], s['sp'], s['gap'], s['hbuf'], s['ch'], blk.se_w1.t, blk.se_w2.t,
+                                   blk.spatial_k.t.reshape(-1), n2.gamma.t, n2.beta.t, s['m2'], s['r2'], n2.groups, self._gslot(blk.se_w1),
+                                   self._gslot(blk.se_w2), self._gslot(blk.spatial_k).reshape(-1), self._gslot(n2.gamma), self._gslot(n2.beta),
+                                   dbias_pt=self._gslot(blk.ptwise_b), dbias_c2=self._gslot(blk.conv2_b))
+        if fused is not None:
+            dres_fused, dc2_16 = fused
+            dc2 = None
+            self._db_done = True
+        else:
+            dc2_16, dc2 = self._gn_bwd(n2, s['c2'], dout, s['m2'], s['r2'], want_f32=not lp2, dbias=self._gslot(blk.conv2_b) if lp2 else None)
         if lp2:
             a16 = s['a']
             db2 = None if self._db_done else self._gslot(blk.conv2_b)
@@ -179,9 +197,12 @@ class LowPrecisionTrainer(object):
         db1 = None if (lp1 and self._db_done) else self._gslot(blk.conv1_b)
         del da
         # gate branch (16-bit kernels; fp32 copies only where a weight gradient still runs on the fp32 kernels)
-        dres_16 = lowp.se_bwd(code, self.tdt, dout, s['res'], s['sp'], s['gap'], s['hbuf'], s['ch'], blk.se_w1.t, blk.se_w2.t,
-                              blk.spatial_k.t.reshape(-1), self._gslot(blk.se_w1), self._gslot(blk.se_w2),
-                              self._gslot(blk.spatial_k).reshape(-1), dbias=self._gslot(blk.ptwise_b) if lp1 else None)
+        if fused is not None:
+            dres_16 = dres_fused
+        else:
+            dres_16 = lowp.se_bwd(code, self.tdt, dout, s['res'], s['sp'], s['gap'], s['hbuf'], s['ch'], blk.se_w1.t, blk.se_w2.t,
+                                  blk.spatial_k.t.reshape(-1), self._gslot(blk.se_w1), self._gslot(blk.se_w2),
+                                  self._gslot(blk.spatial_k).reshape(-1), dbias=self._gslot(blk.ptwise_b) if lp1 else None)
         dres = None if lp1 else self._f32(dres_16)
         # weight gradients of the two convolutions that read the block input
         if lp1 and pad_in:

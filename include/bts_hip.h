@@ -305,6 +305,17 @@ int bts_lp_se_bwd(int dtype, const void* dout, const void* res, const float* sp,
                   const float* w1, const float* w2, const float* wsp, void* dres, float* ds, float* dgap, float* dw1, float* dw2, float* dwsp,
                   void* workspace, long workspace_bytes, int N, long V, int F, int R, int lddo, int accumulate_params, float* dbias,
                   bts_stream_t stream);
+/* A ResnetBlock's gate backward and GroupNorm-2 (+ReLU) backward in one pair of passes (resnet.py:121-137 under TF autodiff): what
+ * bts_lp_se_bwd followed by bts_lp_gn_bwd compute, reading the block-output gradient dout (N,V,F; rows of lddo) twice instead of four
+ * times.  res, c2 dense; dres, dc2 dense outputs in the storage type; ds (N*V) / dgap (N,F) fp32 scratch outputs; parameter gradients
+ * accumulate; dbias_pt / dbias_c2 (may be NULL): bias gradients of the shortcut conv / conv2 (+=).  BTS_ERR_UNSUPPORTED outside the
+ * kernels' tiling (the caller runs the two separate entry points). */
+long bts_lp_block_bwd_workspace(int N, long V, int F, int R, int G);
+int bts_lp_block_bwd(int dtype, const void* dout, int lddo, const void* res, const void* c2, const float* sp, const float* gap, const float* h,
+                     const float* ch, const float* w1, const float* w2, const float* wsp, const float* gamma, const float* beta,
+                     const float* mean, const float* rstd, void* dres, void* dc2, float* ds, float* dgap, float* dw1, float* dw2, float* dwsp,
+                     float* dgamma, float* dbeta, float* dbias_pt, float* dbias_c2, void* workspace, long workspace_bytes, int N, long V, int F,
+                     int R, int G, bts_stream_t stream);
 /* All 16-bit weight images in one launch (they go stale together at the optimiser step, train.py:152): host table of
  * bts_lp_pack_desc_bytes()-sized descriptors filled by bts_lp_pack_desc (arguments as bts_lp_pack; returns the entry's block count > 0 or
  * a negative engine code; first_block = running sum of those counts), copied to device memory by the caller. */

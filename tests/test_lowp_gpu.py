@@ -610,3 +610,45 @@ def test_batched_weight_packing_equals_the_single_calls():
         tab.run(code, entries)
         torch.cuda.synchronize()
         assert all(torch.equal(e[3], s) for e, s in zip(entries, singles))
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('shape', [(2, 8, 16, 16, 32), (1, 16, 16, 32, 64), (2, 4, 8, 8, 256)])
+def test_fused_gate_and_groupnorm2_backward(shape, dtype):
+    """bts_lp_block_bwd (one reduce + one apply pass over dout) against bts_lp_se_bwd followed by bts_lp_gn_bwd on the same tensors: dc2 and
+    dres to one unit in the last place of the storage type; parameter and bias gradients accumulated
+    onto non-zero buffers; dout arrives as a channel slice of a wider slab"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    code, tdt = lowp.DTYPES[dtype]
+    n, d, h, w, f = shape
+    groups, r = 8, max(f // 8, 1)
+    g = torch.Generator().manual_seed(f + d)
+    res = torch.randn(shape, generator=g).to(tdt).to(DEV)
+    c2 = torch.randn(shape, generator=g).to(tdt).to(DEV)
+    slab = torch.randn((n, d, h, w, f + 16), generator=g).to(tdt).to(DEV)
+    dout = slab[..., 8:8 + f]
+    sp = torch.sigmoid(torch.randn((n, d, h, w, 1), generator=g)).to(DEV).contiguous()
+    gap = torch.randn((n, f), generator=g).to(DEV)
+    w1 = (0.3 * torch.randn((f, r), generator=g)).to(DEV)
+    w2 = (0.3 * torch.randn((r, f), generator=g)).to(DEV)
+    wsp = (0.3 * torch.randn(f, generator=g)).to(DEV)
+    gamma = (1.0 + 0.3 * torch.randn(f, generator=g)).to(DEV)
+    beta = (0.2 * torch.randn(f, generator=g)).to(DEV)
+    hbuf, ch = ops.se_mlp_fwd(gap, w1, w2)
+    mean, rstd = lowp.gn_stats(code, c2, groups, ops.GN_SLAB, 1e-5)
+    init = [torch.randn(t.shape, generator=g).to(DEV) for t in (w1, w2, wsp, gamma, beta, wsp, wsp)]      # dw1 dw2 dwsp dgamma dbeta db_pt db_c2
+    ref = [t.clone() for t in init]
+    dres_r = lowp.se_bwd(code, tdt, dout, res, sp, gap, hbuf, ch, w1, w2, wsp, ref[0], ref[1], ref[2], dbias=ref[5])
+    dc2_r, _ = lowp.gn_bwd(code, tdt, c2, dout, gamma, beta, mean, rstd, ref[3], ref[4], groups, True, want_f32=False, dbias=ref[6])
+    got = [t.clone() for t in init]
+    out = lowp.block_bwd(code, tdt, dout, res, c2, sp, gap, hbuf, ch, w1, w2, wsp, gamma, beta, mean, rstd, groups, got[0], got[1], got[2],
+                         got[3], got[4], dbias_pt=got[5], dbias_c2=got[6])
+    assert out is not None
+    dres, dc2 = out
+    torch.cuda.synchronize()
+    assert float((dc2.float() - dc2_r.float()).abs().max()) <= U[dtype] * float(dc2_r.float().abs().max()) * 1.01      # (same sums; the compiler contracts the apply formula differently)
+    scale = float(dres_r.float().abs().max())
+    assert float((dres.float() - dres_r.float()).abs().max()) <= U[dtype] * scale * 1.01
+    for a, b in zip(got, ref):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-5
