@@ -72,6 +72,8 @@ class Tensor(object):
     @property
     def grad(self):
         if self.base is not None:
+            if hasattr(self.base, 'grad_read'):
+                return self.base.grad_read(self.c0, self.c0 + self.t.shape[-1])
             g = self.base.grad_or_none()
             return None if g is None else g[..., self.c0:self.c0 + self.t.shape[-1]]
         return self._grad
@@ -79,6 +81,8 @@ class Tensor(object):
     def grad_slot(self):
         """-> (buffer, accumulate): where a consumer's backward kernel must put d(loss)/d(self)"""
         if self.base is not None:
+            if hasattr(self.base, 'grad_write'):
+                return self.base.grad_write(self.c0, self.c0 + self.t.shape[-1])
             g = self.base.grad_full()
             return g[..., self.c0:self.c0 + self.t.shape[-1]], True
         if self._grad is None:
@@ -125,19 +129,75 @@ class Slab(object):
     def __init__(self, n, d, h, w, ctot, device):
         self.t = torch.empty((n, d, h, w, ctot), dtype=torch.float32, device=device)
         self.g = None
+        self._cov = []
         self.used = 0
 
     def view(self, c0, c1, requires_grad=True):
         return Tensor(self.t[..., c0:c1], base=self, c0=c0, requires_grad=requires_grad)
 
-    def grad_full(self):
+    # The gradient buffer is NOT zero-filled: the first contribution to a channel range is written (accumulate = False), later ones
+    # accumulate; `_cov` holds the channel intervals that have been written.  A range that is only partly covered (or read before
+    # anything was written into it) has its uncovered channels zero-filled on demand.  In a training step the decoder block's input
+    # view covers a level's whole slab and is its first writer, so nothing is filled at all (round 2 filled every slab gradient and
+    # read it back in the first accumulation: ~1 GB of traffic per 128^3 step).
+    def _uncovered(self, c0, c1):
+        out, pos = [], c0
+        for a, b in self._cov:
+            if b <= pos or a >= c1:
+                continue
+            if a > pos:
+                out.append((pos, a))
+            pos = max(pos, b)
+        if pos < c1:
+            out.append((pos, c1))
+        return out
+
+    def _cover(self, c0, c1):
+        iv = sorted(self._cov + [(c0, c1)])
+        merged = [iv[0]]
+        for a, b in iv[1:]:
+            if a <= merged[-1][1]:
+                merged[-1] = (merged[-1][0], max(merged[-1][1], b))
+            else:
+                merged.append((a, b))
+        self._cov = merged
+
+    def _buffer(self):
         if self.g is None:
             self.g = torch.empty_like(self.t)
-            ops.fill(self.g, 0.0)
+            self._cov = []
         return self.g
 
+    def grad_write(self, c0, c1):
+        """-> (gradient view of channels [c0, c1), accumulate) for a backward kernel about to contribute to it"""
+        g = self._buffer()
+        gaps = self._uncovered(c0, c1)
+        if len(gaps) == 1 and gaps[0] == (c0, c1):      # untouched: this contribution is written
+            self._cover(c0, c1)
+            return g[..., c0:c1], False
+        for a, b in gaps:                               # partly covered: zero what is missing, then accumulate
+            g[..., a:b].zero_()
+        if gaps:
+            self._cover(c0, c1)
+        return g[..., c0:c1], True
+
+    def grad_read(self, c0, c1):
+        if self.g is None:
+            return None
+        for a, b in self._uncovered(c0, c1):            # (never the case in a training step)
+            self.g[..., a:b].zero_()
+        self._cover(c0, c1)
+        return self.g[..., c0:c1]
+
+    def grad_full(self):
+        g = self._buffer()
+        for a, b in self._uncovered(0, g.shape[-1]):
+            g[..., a:b].zero_()
+        self._cov = [(0, g.shape[-1])]
+        return g
+
     def grad_or_none(self):
-        return self.g
+        return self.g if self.g is None else self.grad_full()
 
 
 class Param(Tensor):
