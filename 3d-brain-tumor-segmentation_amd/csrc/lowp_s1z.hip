@@ -47,7 +47,7 @@ struct LpS1zParams {
 #define S1Z_NCHK 20          // 1 KB chunks (32 voxels x 32 B) of one k-step of a plane: 612 voxels -> 20
 
 __device__ __forceinline__ void s1z_dma16(u32x4 rsrc, unsigned lds_byte, unsigned voff, unsigned soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_byte), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_byte), "v"(voff), "s"(rsrc), "s"(soff) : "memory");   // (m0 is a reserved register: the compiler sets it right before each of its own uses, never across statements)
 }
 __device__ __forceinline__ u32x4 s1z_rsrc(const void* base) {
   const unsigned long a = (unsigned long)base;

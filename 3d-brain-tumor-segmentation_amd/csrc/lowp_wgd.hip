@@ -63,7 +63,7 @@ struct LpWgdParams {
 // destination apart): the requests of a stage, meant to land two stages later, were each waited for on the spot -- transfer and
 // arithmetic ran one after the other (1.12 ms per 32->32 @128^3 x8 launch, 0.38 + 0.57 apart).  Waits are counted by hand below.
 __device__ __forceinline__ void wgd_dma16(u32x4 rsrc, unsigned lds_byte, unsigned voff, unsigned soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_byte), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_byte), "v"(voff), "s"(rsrc), "s"(soff) : "memory");   // (m0 is a reserved register: the compiler sets it right before each of its own uses, never across statements)
 }
 __device__ __forceinline__ u32x4 wgd_rsrc(const void* base) {
   const unsigned long a = (unsigned long)base;
