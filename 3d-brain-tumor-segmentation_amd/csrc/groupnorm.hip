@@ -593,6 +593,50 @@ __global__ void gn_bwd_finalize_kernel(const float* gamma, float* dgamma, float*
   }
 }
 
+// slab mode, one launch instead of the two above: one block per group g; threads = (class j, slice of the partial blocks); for every
+// sample the class sums over the blocks -> c1, c2; the sums over the samples -> dgamma, dbeta.  (The pair cost two ~4.7 us launches per
+// GroupNorm backward on the main stream's chain: 43 of them per step.)  cg = C / G is a power of two <= 256 here.
+__global__ __launch_bounds__(256) void gn_bwd_finalize_slab_kernel(const double* partial, const float* gamma, float* dgamma, float* dbeta, float* c1,
+                                                                   float* c2, int N, int G, int B, int cg, double L, int accum) {
+  __shared__ double sh[256 * 2];
+  const int g = blockIdx.x;
+  const int j = threadIdx.x % cg, sl = threadIdx.x / cg, S = 256 / cg;
+  double ga = 0.0, gb = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const long unit = (long)n * G + g;
+    double sa = 0.0, sb = 0.0;
+    for (int b = sl; b < B; b += S) {
+      const double* o = partial + ((unit * B + b) * cg + j) * 2;
+      sa += o[0]; sb += o[1];
+    }
+    __syncthreads();
+    sh[threadIdx.x * 2] = sa; sh[threadIdx.x * 2 + 1] = sb;
+    __syncthreads();
+    if (sl == 0) {
+      sa = 0.0; sb = 0.0;
+      for (int s2 = 0; s2 < S; ++s2) { sa += sh[(s2 * cg + j) * 2]; sb += sh[(s2 * cg + j) * 2 + 1]; }
+      ga += sa; gb += sb;
+    }
+    __syncthreads();
+    if (sl == 0) {
+      sh[j * 2] = (double)gamma[g * cg + j] * sb;       // -> c1
+      sh[j * 2 + 1] = (double)gamma[g * cg + j] * sa;   // -> c2
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int q = 0; q < cg; ++q) { s1 += sh[q * 2]; s2 += sh[q * 2 + 1]; }
+      c1[unit] = (float)(s1 / L);
+      c2[unit] = (float)(s2 / L);
+    }
+  }
+  if (sl == 0) {
+    const int idx = g * cg + j;
+    if (dgamma) dgamma[idx] = accum ? dgamma[idx] + (float)ga : (float)ga;
+    if (dbeta) dbeta[idx] = accum ? dbeta[idx] + (float)gb : (float)gb;
+  }
+}
+
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            float* __restrict__ dx, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ mean,
@@ -720,11 +764,17 @@ extern "C" int bts_gn_bwd(const float* x, const float* dy, float* dx, const floa
   (void)hipGetLastError(); hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(g.B, slab ? N * G : N), dim3(256), 0, stream, x, dy, gamma, beta, mean,
                      rstd, partial, g.E, g.L, g.span, C, G, g.cg, lddy, mode, relu);
   BTS_LAUNCH_CHECK();
-  (void)hipGetLastError(); hipLaunchKernelGGL(gn_bwd_finalize_a_kernel, dim3((N * C + 3) / 4), dim3(256), 0, stream, partial, scratch, N, g.B, C, G, mode);
-  BTS_LAUNCH_CHECK();
-  (void)hipGetLastError(); hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), 0, stream, gamma, dgamma, dbeta, c1, c2, scratch, N, C, G,
-                     (double)g.L, accumulate_params);
-  BTS_LAUNCH_CHECK();
+  if (slab && g.cg <= 256 && 256 % g.cg == 0) {
+    (void)hipGetLastError(); hipLaunchKernelGGL(gn_bwd_finalize_slab_kernel, dim3(G), dim3(256), 0, stream, partial, gamma, dgamma, dbeta, c1, c2, N, G, g.B,
+                       g.cg, (double)g.L, accumulate_params);
+    BTS_LAUNCH_CHECK();
+  } else {
+    (void)hipGetLastError(); hipLaunchKernelGGL(gn_bwd_finalize_a_kernel, dim3((N * C + 3) / 4), dim3(256), 0, stream, partial, scratch, N, g.B, C, G, mode);
+    BTS_LAUNCH_CHECK();
+    (void)hipGetLastError(); hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), 0, stream, gamma, dgamma, dbeta, c1, c2, scratch, N, C, G,
+                       (double)g.L, accumulate_params);
+    BTS_LAUNCH_CHECK();
+  }
   if (slab && g.L % 1024 == 0 && 1024 % C == 0 && getenv("BTS_GN_NOSTREAM") == nullptr) {
     const long cpu = g.L / 1024;
     const int cpb = gn_stream_cpb(cpu);
