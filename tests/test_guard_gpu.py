@@ -229,7 +229,40 @@ def test_16bit_kernels_with_tiling_floors_stay_inside_slab_views(guard, dtype):
     assert lowp.conv_bwd_weight(ops.K3S2, code, yv, dyc, dw, db, accumulate=True)
     dwt = guard._alloc((3, 3, 3, 64, 32), torch.float32, dev, zero=True)
     assert lowp.conv_bwd_weight(ops.K3S2T, code, xv, yv.contiguous(), dwt, None, accumulate=False)
-    assert guard.check() > 10
+    # z-marching stride-1 conv for few channels (lowp_s1z.hip): several columns, z chunks with a ragged last one, slab views, accumulate
+    for (n, d, h, w, cin, cout) in [(1, 37, 16, 96, 32, 16), (2, 16, 32, 64, 16, 32)]:
+        xb, xv, _, _ = slab(n, d, h, w, cin)
+        yb, yv, yl, yc = slab(n, d, h, w, cout)
+        wt = (torch.randn((3, 3, 3, cin, cout), generator=gen) * 0.05).to(dev)
+        b = torch.randn(cout, generator=gen).to(dev)
+        ops.profile_enable(True)
+        lowp.conv(ops.K3S1, code, tdt, xv, lowp.pack(ops.K3S1, code, wt, cin, cout), b, cout, out=yv)
+        if cin == cout or cout % 16 == 0:
+            lowp.conv_bwd_data(ops.K3S1, code, yv, lowp.pack(ops.K3S1, code, wt, cin, cout, role=ops.ROLE_BWD), xv, True)
+        torch.cuda.synchronize()
+        ops.profile_enable(False)
+        assert 'lp_s1z_kernel' in [r[0] for r in ops.profile_records()]
+        assert untouched(yb, yl, yc) and untouched(xb, 8, cin)
+    # streaming stride-1 weight gradient (lowp_wgd.hip): x a slab view, guarded dw and an exact-size workspace
+    xb, xv, _, _ = slab(1, 37, 16, 32, 64)
+    dyc = torch.randn((1, 37, 16, 32, 16), generator=gen).to(tdt).to(dev)
+    dw3 = guard._alloc((3, 3, 3, 64, 16), torch.float32, dev, zero=True)
+    ops.profile_enable(True)
+    assert lowp.conv_bwd_weight(ops.K3S1, code, xv, dyc, dw3, None, accumulate=True)
+    torch.cuda.synchronize()
+    ops.profile_enable(False)
+    assert 'lp_wgd_kernel' in [r[0] for r in ops.profile_records()]
+    assert untouched(xb, 8, 64)
+    # all images in one launch (bts_lp_pack_batch) into guarded image buffers of exactly bts_lp_packed_bytes
+    entries = []
+    for kind, role, cin, cout in ((ops.K3S1, ops.ROLE_FWD, 32, 24), (ops.K3S1, ops.ROLE_BWD, 16, 64), (ops.K1, ops.ROLE_FWD, 48, 8), (ops.K3S2T, ops.ROLE_FWD, 32, 16)):
+        k = 1 if kind == ops.K1 else 3
+        shape = (k, k, k, cout, cin) if kind == ops.K3S2T else (k, k, k, cin, cout)
+        wsrc = torch.randn(shape, generator=gen).to(dev)
+        nbytes = lowp.lib().query('bts_lp_packed_bytes', kind, role, cin, cout)
+        entries.append((kind, role, wsrc, guard._alloc((nbytes // 2,), torch.int16, dev), cin, cout, cin, 0, 0))
+    lowp.PackTable().run(code, entries)
+    assert guard.check() > 16
 
 
 def test_the_guard_itself_notices_a_stray_store(guard):
