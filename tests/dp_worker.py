@@ -17,6 +17,11 @@ sys.path.insert(0, ROOT)
 KW = dict(base_filters=8, groups=2, reduction=2, depth=3)
 CROP = (16, 16, 16)
 GLOBAL_BATCH = 2
+# BTS_DP_TRAINER=bfloat16 | float16: the 16-bit storage step (bts_amd.lowp_train, BASELINE configs[3] = configs[2] per GPU) instead of the fp32 one
+TRAINER = os.environ.get('BTS_DP_TRAINER')
+if TRAINER:
+    KW = dict(base_filters=16, groups=8, reduction=2, depth=3)
+    CROP = (32, 32, 32)
 
 
 def main():
@@ -51,11 +56,16 @@ def main():
     opt = ScheduledOptim(1e-3)
     opt(epoch=0)
     lf, df = DiceVAELoss(), DiceCoefficient()
+    step = train_step
+    if TRAINER:
+        from bts_amd.lowp_train import LowPrecisionTrainer
+        tr = LowPrecisionTrainer(model, TRAINER)
+        step = lambda m_, o_, lf_, df_, x_, y_: tr.step(o_, df_, x_, y_)   # noqa: E731
     losses, macros, grads1 = [], [], None
     for s in range(steps):
         model.encoder.set_dropout_mask(mask)                 # one-shot injections: the same draws every step, so the
         model.vae.set_eps(eps)                               # single-process run sees exactly the ranks' samples
-        loss, macro, micro = train_step(model, opt, lf, df, x.to(dev), y.to(dev))
+        loss, macro, micro = step(model, opt, lf, df, x.to(dev), y.to(dev))
         torch.cuda.synchronize()
         losses.append(float(loss))
         macros.append(float(macro))
