@@ -2672,12 +2672,16 @@ int bts_se_bwd_middle_(double* partial, double* red, double* scratch, const floa
                        const float* w2, float* dw1, float* dw2, float* dwsp, float* dgap, int N, int B, long V, int F, int R,
                        int accumulate_params, hipStream_t stream);
 static int lp_gnb_blocks(long L);
+static int lp_se_blocks(long V, int N, int F, long* vspan);
 extern "C" long bts_lp_block_bwd_workspace(int N, long V, int F, int R, int G) {
   if (N <= 0 || V <= 0 || F < 8 || R <= 0 || G <= 0 || F % G != 0) return -1;
   const long L = V * F / G;
   const long B = lp_gnb_blocks(L);
+  long vspan;
+  long Bse = lp_se_blocks(V, N, F, &vspan);      // (the A/B route with separate reduce passes uses the gate kernel's own block count)
+  if (Bse < G * B) Bse = G * B;
   return (long)N * G * B * (F / G) * 2 * 8 + (long)N * G * 2 * 4 + 64      // GroupNorm partials, c1 / c2
-         + (long)N * G * B * F * 2 * 8 + ((long)N * F * 3 + (long)N * R) * 8 + 128      // gate partials, red, scratch
+         + (long)N * Bse * F * 2 * 8 + ((long)N * F * 3 + (long)N * R) * 8 + 128      // gate partials, red, scratch
          + 2 * (2048L * F * 8 + 64);      // two sets of bias-gradient rows
 }
 // dout (N,V,F) rows of lddo; res, c2 dense; dres, dc2 dense outputs in the storage type; ds (N*V) and dgap (N,F) fp32 scratch outputs;
@@ -2701,18 +2705,36 @@ extern "C" int bts_lp_block_bwd(int dtype, const void* dout, int lddo, const voi
   float* c1 = reinterpret_cast<float*>(partial + (long)N * G * B * cg * 2);
   float* c2 = c1 + (long)N * G;
   double* sep = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(c2 + (long)N * G) + 63) & ~(uintptr_t)63);
-  double* red = sep + (long)N * G * B * F * 2;
+  long vspan_se;
+  long Bmax = lp_se_blocks(V, N, F, &vspan_se);
+  if (Bmax < (long)G * B) Bmax = (long)G * B;
+  double* red = sep + (long)N * Bmax * F * 2;
   double* scratch = red + (long)N * F * 2;
   double* dbp1 = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(scratch + (long)N * F + (long)N * R) + 63) & ~(uintptr_t)63);
   double* dbp2 = dbp1 + 2048L * F + 8;
   (void)hipGetLastError();
+  // BTS_LP_FUSE_BLOCK_BWD_REDUCE=0 (A/B): the two light reduce passes of the separate routes, then the fused apply pass
+  const char* fr = getenv("BTS_LP_FUSE_BLOCK_BWD_REDUCE");
+  int Bse = G * B;
+  if (fr && atoi(fr) == 0) {
+    long vspan;
+    Bse = lp_se_blocks(V, N, F, &vspan);
+    if (dtype == LP_F16) {
+      hipLaunchKernelGGL(lp_gn_bwd_reduce_kernel<TF16>, dim3(B, N * G), dim3(256), 0, stream, (const unsigned short*)c2x, (const unsigned short*)dout, gamma, beta, mean, rstd, partial, E, L, span, F, G, cg, lddo, 1);
+      hipLaunchKernelGGL(lp_se_bwd_reduce_kernel<TF16>, dim3(Bse, N), dim3(256), 0, stream, (const unsigned short*)dout, (const unsigned short*)res, sp, ds, sep, V, F, lddo, vspan);
+    } else {
+      hipLaunchKernelGGL(lp_gn_bwd_reduce_kernel<TBF16>, dim3(B, N * G), dim3(256), 0, stream, (const unsigned short*)c2x, (const unsigned short*)dout, gamma, beta, mean, rstd, partial, E, L, span, F, G, cg, lddo, 1);
+      hipLaunchKernelGGL(lp_se_bwd_reduce_kernel<TBF16>, dim3(Bse, N), dim3(256), 0, stream, (const unsigned short*)dout, (const unsigned short*)res, sp, ds, sep, V, F, lddo, vspan);
+    }
+  } else {
 #define LP_BB_R(TT) hipLaunchKernelGGL(lp_blk_bwd_reduce_kernel<TT>, dim3(B, N * G), dim3(256), 0, stream, (const unsigned short*)c2x, (const unsigned short*)dout, (const unsigned short*)res, sp, gamma, beta, mean, rstd, partial, sep, ds, E, L, span, F, G, cg, lddo)
-  if (dtype == LP_F16) LP_BB_R(TF16); else LP_BB_R(TBF16);
+    if (dtype == LP_F16) LP_BB_R(TF16); else LP_BB_R(TBF16);
 #undef LP_BB_R
+  }
   BTS_LAUNCH_CHECK();
   hipLaunchKernelGGL(lp_gn_bwd_finalize_kernel, dim3(G), dim3(256), 0, stream, partial, gamma, dgamma, dbeta, c1, c2, N, G, B, cg, (double)L, 1);
   BTS_LAUNCH_CHECK();
-  const int r = bts_se_bwd_middle_(sep, red, scratch, gap, h, ch, w1, w2, dw1, dw2, dwsp, dgap, N, G * B, V, F, R, 1, stream);
+  const int r = bts_se_bwd_middle_(sep, red, scratch, gap, h, ch, w1, w2, dw1, dw2, dwsp, dgap, N, Bse, V, F, R, 1, stream);
   if (r != BTS_OK) return r;
   const long total8 = (long)N * E / 8;
   long blocks = (total8 + 255) / 256;

@@ -35,10 +35,10 @@ class LowPrecisionTrainer(object):
         self.code, self.tdt = DTYPES[dtype]
         self._packs = {}
         self._pack_table = lowp.PackTable()
-        # BTS_LP_FUSE_BLOCK_BWD=1: gate + GroupNorm-2 backward in one pair of passes (bts_lp_block_bwd).  Built, parity-tested and measured
-        # SLOWER than the two separate routes (94.0 vs 90.3 ms per batch-8 step: the fused reduce pass carries four fp64 sum sets and 34 KB
-        # of LDS per workgroup, and streams at a lower rate than the two light passes it replaces): off by default, DESIGN 11.4
-        self.fuse_block_bwd = os.environ.get('BTS_LP_FUSE_BLOCK_BWD', '0') == '1'
+        # gate + GroupNorm-2 backward of a block in one pair of passes (bts_lp_block_bwd): 89.4 -> 87.5 ms per batch-8 step measured by
+        # interleaved rounds inside one process (scripts/lp_fuse_ab.py; A/B between processes drowns in the pool's run-to-run spread).
+        # BTS_LP_FUSE_BLOCK_BWD=0: the two separate routes
+        self.fuse_block_bwd = os.environ.get('BTS_LP_FUSE_BLOCK_BWD', '1') != '0'
         self.last_labels = None
 
     # ---- weight images ----
