@@ -19,7 +19,7 @@
 //   * a three-slot weight ring and a double-buffered halo tile are filled two stages / one k-step ahead; a stage boundary is
 //     `s_waitcnt vmcnt(N)` with N counted (never 0) + one s_barrier; a workgroup walks its items (tile x cout group, XCD-aware
 //     order) as ONE stage stream, the next item's operands in flight under the current item's output side.
-// Declines (caller runs the old kernel): W < 12, fewer than 12288 voxels, Cout % 8 != 0, offsets beyond 31 bits.
+// Declines (caller runs the old kernel): W < 12, fewer than 4096 voxels, Cout % 8 != 0, offsets beyond 31 bits.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -489,29 +489,44 @@ static bool s1d_enabled() {   // BTS_LP_S1D=0: every stride-1 conv on the regist
   const char* e = getenv("BTS_LP_S1D");
   return !(e && atoi(e) == 0);
 }
-static bool s1d_plan(int N, int D, int H, int W, int Cin, int Cout, S1dPlan& pl) {
-  if (!s1d_enabled() || Cin % 16 != 0 || Cout % 8 != 0 || W < 12) return false;
-  { const char* fl = getenv("BTS_LP_S1D_FLOOR"); if ((long)N * D * H * W < (fl ? atol(fl) : 12288)) return false; }      // (20x24x20, the deepest level of the full inference volume: the small-tile kernel wins)
+// tile grid + split-K of one tile shape (TX = 1 << txl); returns the modelled cost in k-step times: rounds of the 256 CUs x (k-steps
+// per workgroup + 1.5 for an item's fill and output side)
+static double s1d_plan_shape(int N, int D, int H, int W, int Cin, int Cout, int txl, S1dPlan& pl) {
   const int NB = (Cout + 31) / 32, KS = Cin / 16;
   pl.mode = NB >= 2 ? 1 : 0;
-  pl.txl = W >= 24 ? 5 : 4;
+  pl.txl = txl;
   const int TX = 1 << pl.txl, ZP = 32 / TX, TY = pl.mode ? 4 : 8, TZ = 4 * ZP;
   pl.ntx = (W + TX - 1) / TX; pl.nty = (H + TY - 1) / TY; pl.ntz = (D + TZ - 1) / TZ;
   pl.ncg = pl.mode ? (NB + 1) / 2 : 1;
   pl.nitems = (long)N * pl.ntz * pl.nty * pl.ntx * pl.ncg;
-  if (pl.nitems > 0x7fffffffL) return false;
+  if (pl.nitems > 0x7fffffffL) return -1.0;
   s1d_block(pl.ntx, pl.nty, pl.ntz, TX, TY, TZ, pl.ncg >= 32 ? 1 : 32 / pl.ncg, pl.bx, pl.by, pl.bz);
-  // split-K: grids that cannot give most CUs an item split the input channels (>= 2 k-steps per workgroup)
+  // split-K: grids that cannot give most CUs an item split the input channels (>= 2 k-steps per workgroup); the split with the
+  // fewest (rounds x k-steps) wins, ties to the smaller split (less partial-sum traffic)
+  auto cost = [&](int per, int split) { return (double)((pl.nitems * split + 255) / 256) * (per + 1.5); };
   pl.ksplit = 1; pl.ks_per = KS;
+  double best = cost(KS, 1);
   if (pl.nitems < 160 && KS >= 4) {
-    int ks = (int)((256 + pl.nitems - 1) / pl.nitems);
-    if (ks > KS / 2) ks = KS / 2;
-    if (ks > 16) ks = 16;
-    if (ks > 1) {
-      pl.ks_per = (KS + ks - 1) / ks;
-      pl.ksplit = (KS + pl.ks_per - 1) / pl.ks_per;
+    for (int ks = 2; ks <= KS / 2 && ks <= 16; ++ks) {
+      const int per = (KS + ks - 1) / ks, split = (KS + per - 1) / per;
+      const double c = cost(per, split) + 0.5 * split;      // (+ the reduce pass grows with the split)
+      if (c < best - 1e-9) { best = c; pl.ks_per = per; pl.ksplit = split; }
     }
   }
+  return best;
+}
+static bool s1d_plan(int N, int D, int H, int W, int Cin, int Cout, S1dPlan& pl) {
+  if (!s1d_enabled() || Cin % 16 != 0 || Cout % 8 != 0 || W < 12) return false;
+  { const char* fl = getenv("BTS_LP_S1D_FLOOR"); if ((long)N * D * H * W < (fl ? atol(fl) : 4096)) return false; }
+  // x extent of a tile: 32, or 16 with two z planes per fragment -- whichever wastes less of the 256 CUs on this grid (20x24x20, the
+  // deepest level of the full inference volume: 32 wide gives 120 items = one round at split 2, 16 wide 144 items = two rounds)
+  const char* e = getenv("BTS_LP_S1D_TXL");
+  if (e) return s1d_plan_shape(N, D, H, W, Cin, Cout, atoi(e) == 4 ? 4 : 5, pl) >= 0.0;
+  S1dPlan a, b;
+  const double ca = s1d_plan_shape(N, D, H, W, Cin, Cout, 5, a), cb = s1d_plan_shape(N, D, H, W, Cin, Cout, 4, b);
+  if (ca < 0.0 && cb < 0.0) return false;
+  const bool wide = cb < 0.0 || (ca >= 0.0 && (W >= 24 || ca <= cb));     // (W >= 24: 32 wide always, as measured in round 2)
+  pl = wide ? a : b;
   return true;
 }
 long bts_lp_s1d_workspace_(int N, int D, int H, int W, int Cin, int Cout) {

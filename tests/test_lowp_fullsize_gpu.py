@@ -86,7 +86,7 @@ def test_16bit_step_at_128_cubed_against_the_fp32_engine(dtype, lim):
 
     l16, d16, g16, p16, lab16, syms = lowp_step(True)
     # the 128^3 kernels ran: the LDS-DMA conv carries the stride-1 convolutions and their data gradients of the levels above its
-    # 12288-voxel floor (levels 0-2 at batch 2), the 16-bit weight-gradient kernel the stride-1 / 1x1x1 weight gradients
+    # 4096-voxel floor (every level at batch 2), the 16-bit weight-gradient kernel the stride-1 / 1x1x1 weight gradients
     counts = {s: syms.count(s) for s in sorted(set(syms))}
     print('launches of the 16-bit step:', counts)
     dl = abs(l16 - loss32) / abs(loss32)

@@ -1,6 +1,6 @@
 """-m gpu: the LDS-DMA staged stride-1 3x3x3 convolution of the 16-bit storage path (csrc/lowp_s1d.hip; the Conv3D of
 resnet.py:80-87 and, on role-swapped images, its data gradient under train.py:142-151) at shapes it TAKES -- the small cases of
-test_lowp_gpu.py fall below its 12288-voxel floor and keep exercising the register-staged kernel.
+test_lowp_gpu.py fall below its 4096-voxel floor and keep exercising the register-staged kernel.
 
 Every case runs through the C ABI (bts_lp_conv3d_fwd / _bwd_data / _fwd_gn), is checked against the oracle's op on the same
 16-bit-rounded operands in fp64 under the stated bound  |err| <= 8 * 2^-24 * sum|a_i b_i| + u * |ref|  (u = 2^-11 fp16, 2^-8 bf16;
@@ -42,6 +42,9 @@ CASES = [
     (2, (20, 20, 20), 32, 32, True, False),      # 16-wide tiles, 32-cout items, ragged z / y / x
     (1, (36, 32, 64), 16, 128, False, False),    # 288 items on 256 workgroups: items chained, two cout groups per tile
     (1, (8, 48, 32), 48, 96, False, False),      # three cout blocks: the last group half empty
+    (1, (20, 24, 20), 128, 128, False, False),   # the deepest grid of the 160x192x160 volume: 32-wide tiles on a 20-wide grid, split-K
+    (2, (16, 16, 16), 64, 64, False, False),     # 16-wide tiles chosen by the plan's cost model (64-cout items)
+    (1, (16, 16, 16), 32, 32, True, False),      # ... 32-cout items, 4096 voxels = the floor
 ]
 
 
