@@ -9,7 +9,9 @@ code, tdt = lowp.DTYPES['float16']
 D = torch.device('cuda:0')
 VARIANTS = (('old', {'BTS_LP_S1D': '0'}), ('s1d tx16', {'BTS_LP_S1D': '1', 'BTS_LP_S1D_FLOOR': '0', 'BTS_LP_S1D_TXL': '4'}),
             ('s1d tx32', {'BTS_LP_S1D': '1', 'BTS_LP_S1D_FLOOR': '0', 'BTS_LP_S1D_TXL': '5'}))
-for shape, cin, cout in (((1, 20, 24, 20), 256, 256), ((1, 20, 24, 20), 512, 256), ((1, 16, 16, 16), 256, 256), ((2, 16, 16, 16), 256, 256)):
+import ast
+SHAPES = ast.literal_eval(sys.argv[1]) if len(sys.argv) > 1 else (((1, 20, 24, 20), 256, 256), ((1, 20, 24, 20), 512, 256), ((1, 16, 16, 16), 256, 256), ((2, 16, 16, 16), 256, 256))
+for shape, cin, cout in SHAPES:
     x = torch.randn(shape + (cin,), device=D).to(tdt)
     wt = torch.randn((3, 3, 3, cin, cout), device=D) * 0.02
     b = torch.zeros(cout, device=D)
