@@ -1124,6 +1124,63 @@ __global__ __launch_bounds__(256) void lp_gn_apply_kernel(const unsigned short* 
     *reinterpret_cast<u32x4*>(y + pix * ldy + c) = pack8<T>(o);
   }
 }
+// The same pass for tensors whose (sample, slab) units are whole multiples of 2048 elements with C | 2048 (every layer of the model):
+// a workgroup streams one contiguous chunk of one unit, so a thread's eight channels -- and with them its statistics, scales and
+// shifts -- are fixed before the loop: no division and no parameter load per 16 bytes, four loads in flight per thread.  (The
+// grid-stride form above spent 4 64-bit divisions + 16 small ones per 16 bytes and streamed 3.1 TB/s; this one is bound by HBM.)
+// Chunks of one unit: enough workgroups for ~16 per CU, at least 4 iterations each where the unit is that long.
+static long lp_chunk_per(long Lu, long units, int* B) {
+  const long steps = Lu / 2048;                 // 2048-element steps of a unit
+  long b = (4096 + units - 1) / units;
+  if (b > steps / 4) b = steps / 4;
+  if (b < 1) b = 1;
+  const long per = (steps + b - 1) / b;
+  *B = (int)((steps + per - 1) / per);
+  return per * 2048;
+}
+template <typename T, int RELU>
+__global__ __launch_bounds__(256) void lp_gn_apply_chunk_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd, long Lu,
+                                                                long per, int C, int G, int cg, int ldy, int slab, int upn) {
+  const int unit = blockIdx.y, n = unit / upn, u = unit - n * upn;
+  const long lo = (long)unit * Lu;
+  const long a = lo + (long)blockIdx.x * per;
+  const long bnd = (a + per < lo + Lu) ? a + per : lo + Lu;
+  const int t8 = threadIdx.x * 8, c = t8 % C;
+  float mu[8], sc[8], be[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int g = slab ? u : (c + e) / cg;
+    const int idx = slab ? g * cg + ((c + e) % cg) : (c + e);
+    mu[e] = mean[n * G + g];
+    sc[e] = rstd[n * G + g] * gamma[idx];
+    be[e] = beta[idx];
+  }
+  const long pstep = 2048 / C;
+  long pix = a / C + t8 / C;
+  const unsigned short* src = x + a + t8;
+  const long K = (bnd - a) / 2048;
+  auto one = [&](const u32x4 raw, long px) {
+    float v[8], o[8];
+    unpack8<T>(raw, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float t = fmaf(v[e] - mu[e], sc[e], be[e]);
+      o[e] = RELU ? fmaxf(t, 0.f) : t;
+    }
+    *reinterpret_cast<u32x4*>(y + px * ldy + c) = pack8<T>(o);
+  };
+  long k = 0;
+  for (; k + 4 <= K; k += 4) {
+    u32x4 r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = *reinterpret_cast<const u32x4*>(src + (k + j) * 2048);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) one(r[j], pix + (k + j) * pstep);
+  }
+  for (; k < K; ++k) one(*reinterpret_cast<const u32x4*>(src + k * 2048), pix + k * pstep);
+}
 extern "C" int bts_lp_gn_apply(int dtype, const void* x, void* y, const float* gamma, const float* beta, const float* mean,
                                const float* rstd, int N, long V, int C, int ldy, int G, int mode, int relu, hipStream_t stream) {
   if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
@@ -1131,10 +1188,26 @@ extern "C" int bts_lp_gn_apply(int dtype, const void* x, void* y, const float* g
   const long E = V * C, L = E / G;
   if (mode == BTS_GN_SLAB && L % 8 != 0) return BTS_ERR_UNSUPPORTED;
   if ((((uintptr_t)x) & 15) || (((uintptr_t)y) & 15)) return BTS_ERR_ALIGN;
+  (void)hipGetLastError();
+  {
+    const int slab = mode == BTS_GN_SLAB;
+    const long Lu = slab ? L : E;
+    if (2048 % C == 0 && Lu % 2048 == 0 && !getenv("BTS_LP_ELEM_OLD")) {
+      const int upn = slab ? G : 1;
+      int B;
+      const long per = lp_chunk_per(Lu, (long)N * upn, &B);
+      const dim3 grid((unsigned)B, (unsigned)(N * upn));
+#define LP_GA(T_, R_) hipLaunchKernelGGL((lp_gn_apply_chunk_kernel<T_, R_>), grid, dim3(256), 0, stream, (const unsigned short*)x, (unsigned short*)y, gamma, beta, mean, rstd, Lu, per, C, G, C / G, ldy, slab, upn)
+      if (dtype == LP_F16) { if (relu) LP_GA(TF16, 1); else LP_GA(TF16, 0); }
+      else { if (relu) LP_GA(TBF16, 1); else LP_GA(TBF16, 0); }
+#undef LP_GA
+      BTS_LAUNCH_CHECK();
+      return BTS_OK;
+    }
+  }
   const long total8 = (long)N * E / 8;
   long blocks = (total8 + 255) / 256;
   if (blocks > 16384) blocks = 16384;
-  (void)hipGetLastError();
   if (dtype == LP_F16) hipLaunchKernelGGL(lp_gn_apply_kernel<TF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)x, (unsigned short*)y, gamma, beta, mean, rstd, total8, E, L, C, G, C / G, ldy, mode, relu);
   else hipLaunchKernelGGL(lp_gn_apply_kernel<TBF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)x, (unsigned short*)y, gamma, beta, mean, rstd, total8, E, L, C, G, C / G, ldy, mode, relu);
   BTS_LAUNCH_CHECK();
@@ -1251,6 +1324,65 @@ __global__ __launch_bounds__(256) void lp_block_epilogue_kernel(const unsigned s
     *reinterpret_cast<u32x4*>(out + pix * ldo + c) = pack8<T>(o);
   }
 }
+// chunked form (see lp_gn_apply_chunk_kernel): per-thread channels fixed, gate weights / statistics / scales in registers
+template <typename T>
+__global__ __launch_bounds__(256) void lp_block_epilogue_chunk_kernel(const unsigned short* __restrict__ res, const unsigned short* __restrict__ c2,
+                                                                      unsigned short* __restrict__ out, float* __restrict__ sp_out,
+                                                                      const float* __restrict__ wsp, const float* __restrict__ ch,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                      const float* __restrict__ mean, const float* __restrict__ rstd, long Lu,
+                                                                      long per, int C, int G, int cg, int ldo, int slab, int upn) {
+  const int unit = blockIdx.y, n = unit / upn, u = unit - n * upn;
+  const long lo = (long)unit * Lu;
+  const long a = lo + (long)blockIdx.x * per;
+  const long bnd = (a + per < lo + Lu) ? a + per : lo + Lu;
+  const int t8 = threadIdx.x * 8, c = t8 % C, oct = C / 8;
+  float mu[8], sc[8], be[8], ws[8], cw[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int g = slab ? u : (c + e) / cg;
+    const int idx = slab ? g * cg + ((c + e) % cg) : (c + e);
+    mu[e] = mean[n * G + g];
+    sc[e] = rstd[n * G + g] * gamma[idx];
+    be[e] = beta[idx];
+    ws[e] = wsp[c + e];
+    cw[e] = ch[n * C + c + e];
+  }
+  const long pstep = 2048 / C;
+  const long pix = a / C + t8 / C;
+  const unsigned short* ra = res + a + t8;
+  const unsigned short* rb = c2 + a + t8;
+  const long K = (bnd - a) / 2048;
+  auto one = [&](const u32x4 r0, const u32x4 r1, long px) {
+    float va[8], vb[8], o[8];
+    unpack8<T>(r0, va);
+    unpack8<T>(r1, vb);
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dot = fmaf(va[e], ws[e], dot);
+    for (int m = 1; m < oct; m <<= 1) dot += __shfl_xor(dot, m, 64);
+    const float sp = 1.f / (1.f + __expf(-dot));
+    if (sp_out != nullptr && c == 0) sp_out[px] = sp;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float t = fmaxf(fmaf(vb[e] - mu[e], sc[e], be[e]), 0.f);
+      o[e] = fmaf(va[e], sp + cw[e], t);
+    }
+    *reinterpret_cast<u32x4*>(out + px * ldo + c) = pack8<T>(o);
+  };
+  long k = 0;
+  for (; k + 2 <= K; k += 2) {
+    u32x4 r0[2], r1[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      r0[j] = *reinterpret_cast<const u32x4*>(ra + (k + j) * 2048);
+      r1[j] = *reinterpret_cast<const u32x4*>(rb + (k + j) * 2048);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) one(r0[j], r1[j], pix + (k + j) * pstep);
+  }
+  for (; k < K; ++k) one(*reinterpret_cast<const u32x4*>(ra + k * 2048), *reinterpret_cast<const u32x4*>(rb + k * 2048), pix + k * pstep);
+}
 extern "C" int bts_lp_block_epilogue(int dtype, const void* res, const void* c2, void* out, float* sp_out, const float* wsp, const float* ch,
                                      const float* gamma, const float* beta, const float* mean, const float* rstd, int N, long V, int C,
                                      int ldo, int G, int mode, hipStream_t stream) {
@@ -1259,11 +1391,25 @@ extern "C" int bts_lp_block_epilogue(int dtype, const void* res, const void* c2,
   const long E = V * C, L = E / G;
   if (mode == BTS_GN_SLAB && L % 8 != 0) return BTS_ERR_UNSUPPORTED;
   if ((((uintptr_t)res) & 15) || (((uintptr_t)c2) & 15) || (((uintptr_t)out) & 15)) return BTS_ERR_ALIGN;
+  (void)hipGetLastError();
+  {
+    const int slab = mode == BTS_GN_SLAB;
+    const long Lu = slab ? L : E;
+    if (2048 % C == 0 && Lu % 2048 == 0 && !getenv("BTS_LP_ELEM_OLD")) {
+      const int upn = slab ? G : 1;
+      int B;
+      const long per = lp_chunk_per(Lu, (long)N * upn, &B);
+      const dim3 grid((unsigned)B, (unsigned)(N * upn));
+      if (dtype == LP_F16) hipLaunchKernelGGL(lp_block_epilogue_chunk_kernel<TF16>, grid, dim3(256), 0, stream, (const unsigned short*)res, (const unsigned short*)c2, (unsigned short*)out, sp_out, wsp, ch, gamma, beta, mean, rstd, Lu, per, C, G, C / G, ldo, slab, upn);
+      else hipLaunchKernelGGL(lp_block_epilogue_chunk_kernel<TBF16>, grid, dim3(256), 0, stream, (const unsigned short*)res, (const unsigned short*)c2, (unsigned short*)out, sp_out, wsp, ch, gamma, beta, mean, rstd, Lu, per, C, G, C / G, ldo, slab, upn);
+      BTS_LAUNCH_CHECK();
+      return BTS_OK;
+    }
+  }
   const long total8 = (long)N * E / 8;
   // (the C/8 lanes of a voxel are adjacent and aligned inside a wave, so they enter and leave the loop together)
   long blocks = (total8 + 255) / 256;
   if (blocks > 16384) blocks = 16384;
-  (void)hipGetLastError();
   if (dtype == LP_F16) hipLaunchKernelGGL(lp_block_epilogue_kernel<TF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)res, (const unsigned short*)c2, (unsigned short*)out, sp_out, wsp, ch, gamma, beta, mean, rstd, total8, E, L, C, G, C / G, ldo, mode);
   else hipLaunchKernelGGL(lp_block_epilogue_kernel<TBF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)res, (const unsigned short*)c2, (unsigned short*)out, sp_out, wsp, ch, gamma, beta, mean, rstd, total8, E, L, C, G, C / G, ldo, mode);
   BTS_LAUNCH_CHECK();
