@@ -1129,9 +1129,9 @@ __global__ __launch_bounds__(256) void lp_gn_apply_kernel(const unsigned short* 
 // shifts -- are fixed before the loop: no division and no parameter load per 16 bytes, four loads in flight per thread.  (The
 // grid-stride form above spent 4 64-bit divisions + 16 small ones per 16 bytes and streamed 3.1 TB/s; this one is bound by HBM.)
 // Chunks of one unit: enough workgroups for ~16 per CU, at least 4 iterations each where the unit is that long.
-static long lp_chunk_per(long Lu, long units, int* B) {
+static long lp_chunk_per(long Lu, long units, int* B, long target = 4096) {
   const long steps = Lu / 2048;                 // 2048-element steps of a unit
-  long b = (4096 + units - 1) / units;
+  long b = target / units;
   if (b > steps / 4) b = steps / 4;
   if (b < 1) b = 1;
   const long per = (steps + b - 1) / b;
@@ -1820,13 +1820,13 @@ __global__ __launch_bounds__(256) void lp_gn_bwd_reduce_kernel(const unsigned sh
 #pragma unroll
   for (int e = 0; e < 8; ++e) { a[e] = b[e] = 0.0; fa[e] = fb[e] = 0.f; }
   const unsigned short* xb = x + (long)n * E + ubase;
+  const long pstep = 2048 / C, pix0 = ((long)n * E + ubase + lo + threadIdx.x * 8L) / C;
   int cnt = 0;
   for (long i = lo + threadIdx.x * 8L; i < hi; i += 2048) {
     float v[8], d[8];
     unpack8<T>(*reinterpret_cast<const u32x4*>(xb + i), v);
-    const long gi = (long)n * E + ubase + i;          // global element index -> voxel, channel of the (possibly strided) dy
-    const long pix = gi / C;
-    unpack8<T>(*reinterpret_cast<const u32x4*>(dy + pix * lddy + (gi - pix * C)), d);
+    const long pix = pix0 + (i - lo) / 2048 * pstep;      // (voxel of the possibly strided dy; 2048 / C voxels per step)
+    unpack8<T>(*reinterpret_cast<const u32x4*>(dy + pix * lddy + cph), d);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float xh = (v[e] - m) * rs;
@@ -1905,33 +1905,38 @@ __global__ __launch_bounds__(256) void lp_gn_bwd_finalize_kernel(const double* p
     dbeta[idx] = accum ? dbeta[idx] + (float)gb : (float)gb;
   }
 }
+// apply pass, chunked like lp_gn_apply_chunk_kernel: a workgroup streams one contiguous piece of one (n, group) unit, a thread's
+// channels / statistics / c1, c2 are loop constants (the grid-stride form did 5 64-bit divisions per 16 bytes: 3.9 TB/s)
 template <typename T>
-__global__ __launch_bounds__(256) void lp_gn_bwd_apply_kernel(const unsigned short* x, const unsigned short* dy, unsigned short* dx, float* dx32,
-                                                              const float* gamma, const float* beta, const float* mean, const float* rstd,
-                                                              const float* c1, const float* c2, long total8, long E, long L, int C, int G,
-                                                              int cg, int lddy, int relu, double* dbias_part) {
+__global__ __launch_bounds__(256) void lp_gn_bwd_apply_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy,
+                                                              unsigned short* __restrict__ dx, float* __restrict__ dx32,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ c1, const float* __restrict__ c2, long L, long per, int C,
+                                                              int G, int cg, int lddy, int relu, double* dbias_part) {
   __shared__ float dbsh[256 * 8];
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (long f = blockIdx.x * 256L + threadIdx.x; f < total8; f += (long)gridDim.x * 256) {
-    const long i = f * 8;
-    const long n = i / E;
-    const long r = i - n * E;
-    const int c = (int)(r % C);
-    const long pix = i / C;
-    const int g = (int)(r / L);
-    const long unit = n * G + g;
+  const int unit = blockIdx.y, g = unit % G;
+  const long lo = (long)unit * L;                      // (= n * E + g * L)
+  const long a = lo + (long)blockIdx.x * per;
+  const long bnd = (a + per < lo + L) ? a + per : lo + L;
+  const int t8 = threadIdx.x * 8, c = t8 % C;
+  float gam[8], bet[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { const int idx = g * cg + ((c + e) % cg); gam[e] = gamma[idx]; bet[e] = beta[idx]; }
+  const float m = mean[unit], rs = rstd[unit], k1 = c1[unit], k2 = c2[unit];
+  const long pstep = 2048 / C, pix = a / C + t8 / C;
+  const long K = (bnd - a) / 2048;
+  auto one = [&](const u32x4 rx, const u32x4 rd, long i) {
     float v[8], d[8], o[8];
-    unpack8<T>(*reinterpret_cast<const u32x4*>(x + i), v);
-    unpack8<T>(*reinterpret_cast<const u32x4*>(dy + pix * lddy + c), d);
-    const float m = mean[unit], rs = rstd[unit], k1 = c1[unit], k2 = c2[unit];
+    unpack8<T>(rx, v);
+    unpack8<T>(rd, d);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int idx = g * cg + ((c + e) % cg);
       const float xh = (v[e] - m) * rs;
       float de = d[e];
-      const float ga = gamma[idx];
-      if (relu && !(xh * ga + beta[idx] > 0.f)) de = 0.f;
-      o[e] = (de * ga - k1 - xh * k2) * rs;
+      if (relu && !(xh * gam[e] + bet[e] > 0.f)) de = 0.f;
+      o[e] = (de * gam[e] - k1 - xh * k2) * rs;
       cs[e] += o[e];
     }
     *reinterpret_cast<u32x4*>(dx + i) = pack8<T>(o);
@@ -1939,9 +1944,22 @@ __global__ __launch_bounds__(256) void lp_gn_bwd_apply_kernel(const unsigned sho
       *reinterpret_cast<f32x4*>(dx32 + i) = f32x4{o[0], o[1], o[2], o[3]};
       *reinterpret_cast<f32x4*>(dx32 + i + 4) = f32x4{o[4], o[5], o[6], o[7]};
     }
+  };
+  long k = 0;
+  for (; k + 2 <= K; k += 2) {
+    u32x4 rx[2], rd[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      rx[j] = *reinterpret_cast<const u32x4*>(x + a + t8 + (k + j) * 2048);
+      rd[j] = *reinterpret_cast<const u32x4*>(dy + (pix + (k + j) * pstep) * lddy + c);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) one(rx[j], rd[j], a + t8 + (k + j) * 2048);
   }
+  for (; k < K; ++k)
+    one(*reinterpret_cast<const u32x4*>(x + a + t8 + k * 2048), *reinterpret_cast<const u32x4*>(dy + (pix + k * pstep) * lddy + c), a + t8 + k * 2048);
   if (dbias_part != nullptr)     // (launch-uniform; 2048 % C == 0: thread t always holds octet t mod C/8)
-    lp_dbias_block(cs, 0, C / 8, dbias_part + (long)blockIdx.x * C, dbsh);
+    lp_dbias_block(cs, 0, C / 8, dbias_part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * C, dbsh);
 }
 static int lp_gnb_blocks(long L) {
   long b = L / (2048 * 16);
@@ -1977,12 +1995,12 @@ extern "C" int bts_lp_gn_bwd(int dtype, const void* x, const void* dy, void* dx,
   BTS_LAUNCH_CHECK();
   hipLaunchKernelGGL(lp_gn_bwd_finalize_kernel, dim3(G), dim3(256), 0, stream, partial, gamma, dgamma, dbeta, c1, c2, N, G, B, cg, (double)L, accumulate_params);
   BTS_LAUNCH_CHECK();
-  const long total8 = (long)N * E / 8;
-  long blocks = (total8 + 255) / 256;
-  const long cap = dbias ? 2048 : 16384;       // (bias rows: one per block -- 2048 blocks of 256 still fill the chip eight waves deep)
-  if (blocks > cap) blocks = cap;
-  if (dtype == LP_F16) hipLaunchKernelGGL(lp_gn_bwd_apply_kernel<TF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)dy, (unsigned short*)dx, dx32, gamma, beta, mean, rstd, c1, c2, total8, E, L, C, G, cg, lddy, relu, dbp);
-  else hipLaunchKernelGGL(lp_gn_bwd_apply_kernel<TBF16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)dy, (unsigned short*)dx, dx32, gamma, beta, mean, rstd, c1, c2, total8, E, L, C, G, cg, lddy, relu, dbp);
+  int Ba;
+  const long per = lp_chunk_per(L, (long)N * G, &Ba, dbias ? 2048 : 4096);   // (bias rows: one per block -- 2048 blocks of 256 fill the chip eight waves deep)
+  const long blocks = (long)N * G * Ba;
+  if (blocks > 16384) return BTS_ERR_SHAPE;       // (the bias rows of the workspace)
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_gn_bwd_apply_kernel<TF16>, dim3((unsigned)Ba, (unsigned)(N * G)), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)dy, (unsigned short*)dx, dx32, gamma, beta, mean, rstd, c1, c2, L, per, C, G, cg, lddy, relu, dbp);
+  else hipLaunchKernelGGL(lp_gn_bwd_apply_kernel<TBF16>, dim3((unsigned)Ba, (unsigned)(N * G)), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)dy, (unsigned short*)dx, dx32, gamma, beta, mean, rstd, c1, c2, L, per, C, G, cg, lddy, relu, dbp);
   BTS_LAUNCH_CHECK();
   if (dbias != nullptr) {      // bias gradient of the conv whose output this GroupNorm normalised (dx IS that conv's dy)
     hipLaunchKernelGGL(lp_dbias_finalize_kernel, dim3(C), dim3(256), 0, stream, dbp, dbias, (int)blocks, C, accumulate_params);
@@ -2706,14 +2724,14 @@ __global__ __launch_bounds__(256) void lp_blk_bwd_reduce_kernel(const unsigned s
   for (int e = 0; e < 8; ++e) { a[e] = b[e] = pa[e] = pb[e] = 0.0; fa[e] = fb[e] = qa[e] = qb[e] = 0.f; }
   const unsigned short* xb = x + (long)n * E + ubase;
   const unsigned short* rb = res + (long)n * E + ubase;
+  const long pstep = 2048 / C, pix0 = ((long)n * E + ubase + lo + threadIdx.x * 8L) / C;
   int cnt = 0;
   for (long i = lo + threadIdx.x * 8L; i < hi; i += 2048) {      // (hi - lo is a multiple of 2048: the lanes of a voxel leave together)
     float v[8], d[8], r[8];
     unpack8<T>(*reinterpret_cast<const u32x4*>(xb + i), v);
     unpack8<T>(*reinterpret_cast<const u32x4*>(rb + i), r);
-    const long gi = (long)n * E + ubase + i;
-    const long pix = gi / C;
-    unpack8<T>(*reinterpret_cast<const u32x4*>(dy + pix * lddy + (gi - pix * C)), d);
+    const long pix = pix0 + (i - lo) / 2048 * pstep;
+    unpack8<T>(*reinterpret_cast<const u32x4*>(dy + pix * lddy + cph), d);
     float t = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) t = fmaf(d[e], r[e], t);
@@ -2776,43 +2794,70 @@ __global__ __launch_bounds__(256) void lp_blk_bwd_reduce_kernel(const unsigned s
   }
 }
 template <typename T>
-__global__ __launch_bounds__(256) void lp_blk_bwd_apply_kernel(const unsigned short* x, const unsigned short* dy, unsigned short* dx, unsigned short* dres,
-                                                               const float* gamma, const float* beta, const float* mean, const float* rstd,
-                                                               const float* c1, const float* c2, const float* sp, const float* ds, const float* ch,
-                                                               const float* wsp, const float* dgap, long total8, long E, long L, int C, int G,
-                                                               int cg, int lddy, double* dbias_c2, double* dbias_pt) {
+__global__ __launch_bounds__(256) void lp_blk_bwd_apply_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy,
+                                                               unsigned short* __restrict__ dx, unsigned short* __restrict__ dres,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ c1, const float* __restrict__ c2,
+                                                               const float* __restrict__ sp, const float* __restrict__ ds,
+                                                               const float* __restrict__ ch, const float* __restrict__ wsp,
+                                                               const float* __restrict__ dgap, long L, long per, int C, int G, int cg, int lddy,
+                                                               double* dbias_c2, double* dbias_pt) {
   __shared__ float dbsh[256 * 8];
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (long f = blockIdx.x * 256L + threadIdx.x; f < total8; f += (long)gridDim.x * 256) {
-    const long i = f * 8;
-    const long n = i / E;
-    const long r = i - n * E;
-    const int c = (int)(r % C);
-    const long pix = i / C;
-    const int g = (int)(r / L);
-    const long unit = n * G + g;
+  const int unit = blockIdx.y, n = unit / G, g = unit - n * G;
+  const long lo = (long)unit * L;
+  const long a = lo + (long)blockIdx.x * per;
+  const long bnd = (a + per < lo + L) ? a + per : lo + L;
+  const int t8 = threadIdx.x * 8, c = t8 % C;
+  float gam[8], bet[8], chv[8], wsv[8], dgv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int idx = g * cg + ((c + e) % cg);
+    gam[e] = gamma[idx]; bet[e] = beta[idx];
+    chv[e] = ch[n * C + c + e]; wsv[e] = wsp[c + e]; dgv[e] = dgap[n * C + c + e];
+  }
+  const float m = mean[unit], rs = rstd[unit], k1 = c1[unit], k2 = c2[unit];
+  const long pstep = 2048 / C, pix = a / C + t8 / C;
+  const long K = (bnd - a) / 2048;
+  auto one = [&](const u32x4 rx, const u32x4 rd, float s, float dsv, long i) {
     float v[8], d[8], o[8], q[8];
-    unpack8<T>(*reinterpret_cast<const u32x4*>(x + i), v);
-    unpack8<T>(*reinterpret_cast<const u32x4*>(dy + pix * lddy + c), d);
-    const float m = mean[unit], rs = rstd[unit], k1 = c1[unit], k2 = c2[unit];
-    const float s = sp[pix], dsv = ds[pix];
+    unpack8<T>(rx, v);
+    unpack8<T>(rd, d);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int idx = g * cg + ((c + e) % cg);
       const float xh = (v[e] - m) * rs;
       float de = d[e];
-      const float ga = gamma[idx];
-      if (!(xh * ga + beta[idx] > 0.f)) de = 0.f;
-      o[e] = (de * ga - k1 - xh * k2) * rs;
+      if (!(xh * gam[e] + bet[e] > 0.f)) de = 0.f;
+      o[e] = (de * gam[e] - k1 - xh * k2) * rs;
       cs[e] += o[e];
-      q[e] = fmaf(d[e], s + ch[n * C + c + e], fmaf(dsv, wsp[c + e], dgap[n * C + c + e]));
+      q[e] = fmaf(d[e], s + chv[e], fmaf(dsv, wsv[e], dgv[e]));
       cr[e] += q[e];
     }
     *reinterpret_cast<u32x4*>(dx + i) = pack8<T>(o);
     *reinterpret_cast<u32x4*>(dres + i) = pack8<T>(q);
+  };
+  long k = 0;
+  for (; k + 2 <= K; k += 2) {
+    u32x4 rx[2], rd[2];
+    float s[2], dv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long px = pix + (k + j) * pstep;
+      rx[j] = *reinterpret_cast<const u32x4*>(x + a + t8 + (k + j) * 2048);
+      rd[j] = *reinterpret_cast<const u32x4*>(dy + px * lddy + c);
+      s[j] = sp[px]; dv[j] = ds[px];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) one(rx[j], rd[j], s[j], dv[j], a + t8 + (k + j) * 2048);
   }
-  if (dbias_c2 != nullptr) lp_dbias_block(cs, 0, C / 8, dbias_c2 + (long)blockIdx.x * C, dbsh);     // (launch-uniform)
-  if (dbias_pt != nullptr) lp_dbias_block(cr, 0, C / 8, dbias_pt + (long)blockIdx.x * C, dbsh);
+  for (; k < K; ++k) {
+    const long px = pix + k * pstep;
+    one(*reinterpret_cast<const u32x4*>(x + a + t8 + k * 2048), *reinterpret_cast<const u32x4*>(dy + px * lddy + c), sp[px], ds[px], a + t8 + k * 2048);
+  }
+  const long row = (long)blockIdx.y * gridDim.x + blockIdx.x;
+  if (dbias_c2 != nullptr) lp_dbias_block(cs, 0, C / 8, dbias_c2 + row * C, dbsh);     // (launch-uniform)
+  if (dbias_pt != nullptr) lp_dbias_block(cr, 0, C / 8, dbias_pt + row * C, dbsh);
 }
 int bts_se_bwd_middle_(double* partial, double* red, double* scratch, const float* gap, const float* h, const float* ch, const float* w1,
                        const float* w2, float* dw1, float* dw2, float* dwsp, float* dgap, int N, int B, long V, int F, int R,
@@ -2828,7 +2873,7 @@ extern "C" long bts_lp_block_bwd_workspace(int N, long V, int F, int R, int G) {
   if (Bse < G * B) Bse = G * B;
   return (long)N * G * B * (F / G) * 2 * 8 + (long)N * G * 2 * 4 + 64      // GroupNorm partials, c1 / c2
          + (long)N * Bse * F * 2 * 8 + ((long)N * F * 3 + (long)N * R) * 8 + 128      // gate partials, red, scratch
-         + 2 * (2048L * F * 8 + 64);      // two sets of bias-gradient rows
+         + 2 * ((N * (long)G > 2048 ? N * (long)G : 2048L) * F * 8 + 64);      // two sets of bias-gradient rows (one per apply workgroup)
 }
 // dout (N,V,F) rows of lddo; res, c2 dense; dres, dc2 dense outputs in the storage type; ds (N*V) and dgap (N,F) fp32 scratch outputs;
 // parameter gradients accumulate (+=); dbias_pt / dbias_c2 (may be NULL): the shortcut conv's / conv2's bias gradients (+=).
@@ -2857,7 +2902,7 @@ extern "C" int bts_lp_block_bwd(int dtype, const void* dout, int lddo, const voi
   double* red = sep + (long)N * Bmax * F * 2;
   double* scratch = red + (long)N * F * 2;
   double* dbp1 = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(scratch + (long)N * F + (long)N * R) + 63) & ~(uintptr_t)63);
-  double* dbp2 = dbp1 + 2048L * F + 8;
+  double* dbp2 = dbp1 + (N * (long)G > 2048 ? N * (long)G : 2048L) * F + 8;
   (void)hipGetLastError();
   // BTS_LP_FUSE_BLOCK_BWD_REDUCE=0 (A/B): the two light reduce passes of the separate routes, then the fused apply pass
   const char* fr = getenv("BTS_LP_FUSE_BLOCK_BWD_REDUCE");
@@ -2882,10 +2927,10 @@ extern "C" int bts_lp_block_bwd(int dtype, const void* dout, int lddo, const voi
   BTS_LAUNCH_CHECK();
   const int r = bts_se_bwd_middle_(sep, red, scratch, gap, h, ch, w1, w2, dw1, dw2, dwsp, dgap, N, Bse, V, F, R, 1, stream);
   if (r != BTS_OK) return r;
-  const long total8 = (long)N * E / 8;
-  long blocks = (total8 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-#define LP_BB_A(TT) hipLaunchKernelGGL(lp_blk_bwd_apply_kernel<TT>, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)c2x, (const unsigned short*)dout, (unsigned short*)dc2, (unsigned short*)dres, gamma, beta, mean, rstd, c1, c2, sp, ds, ch, wsp, dgap, total8, E, L, F, G, cg, lddo, dbias_c2 ? dbp1 : (double*)nullptr, dbias_pt ? dbp2 : (double*)nullptr)
+  int Ba;
+  const long per = lp_chunk_per(L, (long)N * G, &Ba, 2048);
+  const long blocks = (long)N * G * Ba;
+#define LP_BB_A(TT) hipLaunchKernelGGL(lp_blk_bwd_apply_kernel<TT>, dim3((unsigned)Ba, (unsigned)(N * G)), dim3(256), 0, stream, (const unsigned short*)c2x, (const unsigned short*)dout, (unsigned short*)dc2, (unsigned short*)dres, gamma, beta, mean, rstd, c1, c2, sp, ds, ch, wsp, dgap, L, per, F, G, cg, lddo, dbias_c2 ? dbp1 : (double*)nullptr, dbias_pt ? dbp2 : (double*)nullptr)
   if (dtype == LP_F16) LP_BB_A(TF16); else LP_BB_A(TBF16);
 #undef LP_BB_A
   BTS_LAUNCH_CHECK();
