@@ -2726,17 +2726,16 @@ __global__ __launch_bounds__(256) void lp_blk_bwd_reduce_kernel(const unsigned s
   const unsigned short* rb = res + (long)n * E + ubase;
   const long pstep = 2048 / C, pix0 = ((long)n * E + ubase + lo + threadIdx.x * 8L) / C;
   int cnt = 0;
-  for (long i = lo + threadIdx.x * 8L; i < hi; i += 2048) {      // (hi - lo is a multiple of 2048: the lanes of a voxel leave together)
+  // (hi - lo is a multiple of 2048: the lanes of a voxel leave together.)  Two steps per trip, their six loads issued first.
+  auto one = [&](const u32x4 rv, const u32x4 rr, const u32x4 rd, float s, long pix) {
     float v[8], d[8], r[8];
-    unpack8<T>(*reinterpret_cast<const u32x4*>(xb + i), v);
-    unpack8<T>(*reinterpret_cast<const u32x4*>(rb + i), r);
-    const long pix = pix0 + (i - lo) / 2048 * pstep;
-    unpack8<T>(*reinterpret_cast<const u32x4*>(dy + pix * lddy + cph), d);
+    unpack8<T>(rv, v);
+    unpack8<T>(rr, r);
+    unpack8<T>(rd, d);
     float t = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) t = fmaf(d[e], r[e], t);
     for (int o = F8 >> 1; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-    const float s = sp[pix];
     const float dsv = t * s * (1.f - s);
     if ((threadIdx.x & (F8 - 1)) == 0) ds_out[pix] = dsv;
 #pragma unroll
@@ -2753,6 +2752,29 @@ __global__ __launch_bounds__(256) void lp_blk_bwd_reduce_kernel(const unsigned s
 #pragma unroll
       for (int e = 0; e < 8; ++e) { a[e] += fa[e]; b[e] += fb[e]; pa[e] += qa[e]; pb[e] += qb[e]; fa[e] = fb[e] = qa[e] = qb[e] = 0.f; }
       cnt = 0;
+    }
+  };
+  {
+    const long K = (hi - lo) / 2048;
+    const long i0 = lo + threadIdx.x * 8L;
+    long k = 0;
+    for (; k + 2 <= K; k += 2) {
+      u32x4 rv[2], rr[2], rd[2];
+      float s[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const long i = i0 + (k + j) * 2048, pix = pix0 + (k + j) * pstep;
+        rv[j] = *reinterpret_cast<const u32x4*>(xb + i);
+        rr[j] = *reinterpret_cast<const u32x4*>(rb + i);
+        rd[j] = *reinterpret_cast<const u32x4*>(dy + pix * lddy + cph);
+        s[j] = sp[pix];
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) one(rv[j], rr[j], rd[j], s[j], pix0 + (k + j) * pstep);
+    }
+    for (; k < K; ++k) {
+      const long i = i0 + k * 2048, pix = pix0 + k * pstep;
+      one(*reinterpret_cast<const u32x4*>(xb + i), *reinterpret_cast<const u32x4*>(rb + i), *reinterpret_cast<const u32x4*>(dy + pix * lddy + cph), sp[pix], pix);
     }
   }
 #pragma unroll

@@ -30,6 +30,7 @@ struct LpK1Params {
   unsigned short* y;
   long npos;
   int ldx, ldy, Cout, KS, NB, accum;
+  int ncg;                    // cout groups (of CB blocks of 32)
   int nit;                    // position blocks of 256 one workgroup walks (its column sums leave as ONE partial row)
   double* gap_part;           // [workgroup][Cout] column sums of the unrounded outputs, or NULL
 };
@@ -41,8 +42,10 @@ __global__ __launch_bounds__(256, 3) void lp_k1_kernel(const LpK1Params p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = tid >> 6;
   const int h = lane >> 5, l32 = lane & 31;
-  const long blk = blockIdx.x;
-  const int cg = blockIdx.y;
+  // cout group fastest: the groups of one position block run side by side and find its voxels in L2 (as the slow grid dimension the
+  // groups were whole passes apart: 64 -> 192 channels read its input three times from HBM)
+  const long blk = blockIdx.x / p.ncg;
+  const int cg = (int)(blockIdx.x - blk * p.ncg);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7fffffff, 0x00020000);
   const unsigned wlane = (unsigned)(lane * 16);
   const bool gap_on = p.gap_part != nullptr;
@@ -189,7 +192,9 @@ int bts_lp_k1_launch_(int dtype, const void* x, const void* wp, const float* bia
   const bool prof = bts_prof_on();
   if (prof) bts_prof_begin(34, 2.0 * Cin * (double)Cout * (double)npos, stream);
   (void)hipGetLastError();
-  const dim3 grid((unsigned)blocks, (unsigned)((p.NB + cb - 1) / cb));
+  p.ncg = (p.NB + cb - 1) / cb;
+  if (blocks * p.ncg > 0x7fffffffL) return 1;
+  const dim3 grid((unsigned)(blocks * p.ncg));
   if (dtype == LP_F16) {
     if (cb == 2) hipLaunchKernelGGL((lp_k1_kernel<TF16, 2>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((lp_k1_kernel<TF16, 1>), grid, dim3(256), 0, stream, p);
