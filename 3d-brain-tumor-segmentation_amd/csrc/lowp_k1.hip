@@ -36,8 +36,134 @@ struct LpK1Params {
 };
 #define LPK1_POS 256   // positions per workgroup: 4 waves x 2 fragments x 32
 
-template <typename T, int CB>
-__global__ __launch_bounds__(256, 3) void lp_k1_kernel(const LpK1Params p) {
+// 4 x 4 transpose of 16-byte pieces between the four lanes of a quad (lane bits 0-1) and four registers: afterwards register j of quad
+// lane b holds what register b of quad lane j held.  Two butterfly stages of quad-permute DPP moves; its own inverse.
+// What it is for: NDHWC rows of 64 channels are 128 bytes = 8 pieces.  The matrix instruction wants lane (voxel, k-half h) to hold piece
+// 2 ks + h of ITS voxel in the register of k-step ks -- loaded that way, one instruction touches 32 bytes of each of 32 rows, four
+// instructions per cache line, and the L1 request rate (not HBM) bounds the kernel at ~4 TB/s.  Loaded transposed -- instruction i:
+// quad lane b fetches piece 2 b + h of voxel (quad base + i) -- an instruction covers 8 whole rows; the transpose then hands every lane
+// its own voxel.  The same on the way out for 64-cout groups.
+__device__ __forceinline__ void k1_quad_transpose(u32x4 (&r)[4], int b) {
+  u32x4 s[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    u32x4 t;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) t[d] = (unsigned)__builtin_amdgcn_mov_dpp((int)r[j ^ 1][d], 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    const bool keep = ((b ^ j) & 1) == 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) s[j][d] = keep ? r[j][d] : t[d];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    u32x4 t;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) t[d] = (unsigned)__builtin_amdgcn_mov_dpp((int)s[j ^ 2][d], 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    const bool keep = ((b ^ j) & 2) == 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) r[j][d] = keep ? s[j][d] : t[d];
+  }
+}
+
+// Output side of a wave's VB fragments: (+ old values), column sums for the fused pool, rounding, stores.  32-cout items: 16-byte
+// stores of 8 consecutive couts (v_permlane32_swap between the two lanes of a voxel).  64-cout items: the four 16-byte pieces of a
+// lane are quad-transposed first, so that a store instruction writes whole 128-byte rows (and reads them whole when accumulating).
+template <typename T, int CB, int VB>
+__device__ __forceinline__ void k1_output(const LpK1Params& p, f32x16 (&acc)[VB][CB], const long (&pos)[VB], const bool (&live)[VB], int cg, int h,
+                                          int l32, bool gap_on, float (&csum)[CB][16]) {
+  if constexpr (CB == 2) {
+    const int b = l32 & 3;
+#pragma unroll
+    for (int v = 0; v < VB; ++v) {
+      // row j of this store set: voxel (quad base + j), this lane's piece 2 b + h of the 64-cout group
+      const long qpos = pos[v] - b;
+      const int co_t = cg * 64 + (2 * b + h) * 8;
+      bool okt[4];
+      unsigned short* dstt[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        okt[j] = (qpos + j) < p.npos && co_t < p.Cout;
+        dstt[j] = p.y + (qpos + j) * (long)p.ldy + co_t;
+      }
+      u32x4 e[4];
+      if (p.accum) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          e[j] = u32x4{0u, 0u, 0u, 0u};
+          if (okt[j]) e[j] = *reinterpret_cast<const u32x4*>(dstt[j]);
+        }
+        k1_quad_transpose(e, b);      // -> own voxel, piece 2 j + h (the exchanged layout the 32-cout path loads directly)
+      }
+      u32x4 dq[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {      // j = 2 c + qp
+        const int c = j >> 1, qp = j & 1;
+        float f[4], g2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f[i] = acc[v][c][8 * qp + i]; g2[i] = acc[v][c][8 * qp + 4 + i]; }
+        if (p.accum) {
+          u32x4 o = e[j];
+          asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\tv_nop"
+                       : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+          float old[8];
+          unpack8<T>(o, old);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { f[i] += old[i]; g2[i] += old[4 + i]; }
+        }
+        if (gap_on && live[v]) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { csum[c][8 * qp + i] += f[i]; csum[c][8 * qp + 4 + i] += g2[i]; }
+        }
+        unsigned d0 = pack2<T>(f[0], f[1]), d1 = pack2<T>(f[2], f[3]), d2 = pack2<T>(g2[0], g2[1]), d3 = pack2<T>(g2[2], g2[3]);
+        asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\tv_nop"
+                     : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+        dq[j] = u32x4{d0, d1, d2, d3};
+      }
+      k1_quad_transpose(dq, b);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (okt[j]) *reinterpret_cast<u32x4*>(dstt[j]) = dq[j];
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+      const int cb = cg * CB + c;
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp) {
+        const int co = cb * 32 + 16 * qp + 8 * h;
+#pragma unroll
+        for (int v = 0; v < VB; ++v) {
+          const bool ok = live[v] && cb < p.NB && co < p.Cout;
+          unsigned short* dst = p.y + pos[v] * (long)p.ldy + co;
+          float f[4], g2[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { f[j] = acc[v][c][8 * qp + j]; g2[j] = acc[v][c][8 * qp + 4 + j]; }
+          if (p.accum) {     // old values arrive in the exchanged layout: the exchange is its own inverse
+            u32x4 e = {0u, 0u, 0u, 0u};
+            if (ok) e = *reinterpret_cast<const u32x4*>(dst);
+            asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\tv_nop"
+                         : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]));
+            float old[8];
+            unpack8<T>(e, old);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { f[j] += old[j]; g2[j] += old[4 + j]; }
+          }
+          if (gap_on && live[v]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { csum[c][8 * qp + j] += f[j]; csum[c][8 * qp + 4 + j] += g2[j]; }
+          }
+          unsigned d0 = pack2<T>(f[0], f[1]), d1 = pack2<T>(f[2], f[3]), d2 = pack2<T>(g2[0], g2[1]), d3 = pack2<T>(g2[2], g2[3]);
+          asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\tv_nop"
+                       : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+          if (ok) *reinterpret_cast<u32x4*>(dst) = u32x4{d0, d1, d2, d3};
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int CB, bool GAP>
+__global__ __launch_bounds__(256, (CB == 2 && GAP) ? 2 : 3) void lp_k1_kernel(const LpK1Params p) {
   constexpr int VB = 2, RD = 3;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = tid >> 6;
@@ -48,7 +174,7 @@ __global__ __launch_bounds__(256, 3) void lp_k1_kernel(const LpK1Params p) {
   const int cg = (int)(blockIdx.x - blk * p.ncg);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7fffffff, 0x00020000);
   const unsigned wlane = (unsigned)(lane * 16);
-  const bool gap_on = p.gap_part != nullptr;
+  constexpr bool gap_on = GAP;          // (p.gap_part != nullptr; a template parameter so that the 16-32 sum registers exist only there)
   float csum[CB][16];
 #pragma unroll
   for (int c = 0; c < CB; ++c)
@@ -108,45 +234,108 @@ __global__ __launch_bounds__(256, 3) void lp_k1_kernel(const LpK1Params p) {
       }
     }
     // ---- output side ----
-  #pragma unroll
-    for (int c = 0; c < CB; ++c) {
-      const int cb = cg * CB + c;
-  #pragma unroll
-      for (int qp = 0; qp < 2; ++qp) {
-        const int co = cb * 32 + 16 * qp + 8 * h;
-  #pragma unroll
-        for (int v = 0; v < VB; ++v) {
-          const bool ok = live[v] && cb < p.NB && co < p.Cout;
-          unsigned short* dst = p.y + pos[v] * (long)p.ldy + co;
-          float f[4], g2[4];
-  #pragma unroll
-          for (int j = 0; j < 4; ++j) { f[j] = acc[v][c][8 * qp + j]; g2[j] = acc[v][c][8 * qp + 4 + j]; }
-          if (p.accum) {     // old values arrive in the exchanged layout: the exchange is its own inverse
-            u32x4 e = {0u, 0u, 0u, 0u};
-            if (ok) e = *reinterpret_cast<const u32x4*>(dst);
-            asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\tv_nop"
-                         : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]));
-            float old[8];
-            unpack8<T>(e, old);
-  #pragma unroll
-            for (int j = 0; j < 4; ++j) { f[j] += old[j]; g2[j] += old[4 + j]; }
-          }
-          if (gap_on && live[v]) {
-  #pragma unroll
-            for (int j = 0; j < 4; ++j) { csum[c][8 * qp + j] += f[j]; csum[c][8 * qp + 4 + j] += g2[j]; }
-          }
-          unsigned d0 = pack2<T>(f[0], f[1]), d1 = pack2<T>(f[2], f[3]), d2 = pack2<T>(g2[0], g2[1]), d3 = pack2<T>(g2[2], g2[3]);
-          asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\tv_nop"
-                       : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
-          if (ok) *reinterpret_cast<u32x4*>(dst) = u32x4{d0, d1, d2, d3};
-        }
-      }
-    }
+    k1_output<T, CB, VB>(p, acc, pos, live, cg, h, l32, gap_on, csum);
   }
   // Fused global average pool (resnet.py:121: the squeeze of the shortcut output): column sums of this block's 256 positions --
   // lanes by xor shuffles over the 32 positions of a fragment, the 4 waves through LDS in fixed order, one fp64 partial per
   // (position block, cout); the caller's finalize adds the blocks of a sample
   if (gap_on) {   // (launch-uniform)
+    __shared__ float csh[4][CB * 32];
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float s = csum[c][r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (l32 == 0) csh[wave][c * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = s;
+      }
+    __syncthreads();
+    if (tid < CB * 32) {
+      const int co = cg * CB * 32 + tid;
+      if (co < p.Cout) p.gap_part[blk * p.Cout + co] = ((double)csh[0][tid] + (double)csh[1][tid]) + ((double)csh[2][tid] + (double)csh[3][tid]);
+    }
+  }
+}
+
+// Whole-row form for inputs of 64 x m channels: the k-steps go in groups of four (one 128-byte row piece per voxel and group), each
+// group loaded transposed (see k1_quad_transpose) and handed to the matrix instructions after the quad exchange.  One register set
+// (a second one for the next group spilled at three waves per SIMD): the overlap comes from the other waves and workgroups of the CU.
+template <typename T, int CB, bool GAP>
+__global__ __launch_bounds__(256, (CB == 2 && GAP) ? 2 : 3) void lp_k1f_kernel(const LpK1Params p) {
+  constexpr int VB = 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = tid >> 6;
+  const int h = lane >> 5, l32 = lane & 31, b = l32 & 3;
+  const long blk = blockIdx.x / p.ncg;
+  const int cg = (int)(blockIdx.x - blk * p.ncg);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7fffffff, 0x00020000);
+  const unsigned wlane = (unsigned)(lane * 16);
+  constexpr bool gap_on = GAP;          // (p.gap_part != nullptr; a template parameter so that the 16-32 sum registers exist only there)
+  const int NG = p.KS >> 2;
+  float csum[CB][16];
+#pragma unroll
+  for (int c = 0; c < CB; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) csum[c][r] = 0.f;
+  for (int it = 0; it < p.nit; ++it) {
+    long pos[VB];
+    bool live[VB];
+    const unsigned short* xq[VB][4];     // row of quad voxel i, at this lane's piece 2 b + h
+#pragma unroll
+    for (int v = 0; v < VB; ++v) {
+      pos[v] = (blk * p.nit + it) * LPK1_POS + (wave * VB + v) * 32 + l32;
+      live[v] = pos[v] < p.npos;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        long q = pos[v] - b + i;
+        if (q >= p.npos) q = p.npos - 1;                  // (masked voxels re-read the last one: no traffic of their own)
+        xq[v][i] = p.x + q * (long)p.ldx + (2 * b + h) * 8;
+      }
+    }
+    f32x16 acc[VB][CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+      const int cb = cg * CB + c;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = cb * 32 + 8 * q + 4 * h;
+        float bq[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr && co + 3 < p.Cout) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bq[j] = p.bias[co + j];
+        }
+#pragma unroll
+        for (int v = 0; v < VB; ++v)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[v][c][4 * q + j] = bq[j];
+      }
+    }
+    for (int g = 0; g < NG; ++g) {
+      u32x4 a[4][CB], bb[VB][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+          const int cb = cg * CB + c;
+          a[j][c] = bload16(wr, wlane, (unsigned)(((4 * g + j) * p.NB + (cb < p.NB ? cb : 0)) * 1024));
+        }
+#pragma unroll
+      for (int v = 0; v < VB; ++v)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bb[v][i] = *reinterpret_cast<const u32x4*>(xq[v][i] + g * 64);
+#pragma unroll
+      for (int v = 0; v < VB; ++v) k1_quad_transpose(bb[v], b);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int v = 0; v < VB; ++v)
+#pragma unroll
+          for (int c = 0; c < CB; ++c) acc[v][c] = T::mfma(a[j][c], bb[v][j], acc[v][c]);
+    }
+    k1_output<T, CB, VB>(p, acc, pos, live, cg, h, l32, gap_on, csum);
+  }
+  if (gap_on) {   // (launch-uniform; as lp_k1_kernel)
     __shared__ float csh[4][CB * 32];
 #pragma unroll
     for (int c = 0; c < CB; ++c)
@@ -195,13 +384,16 @@ int bts_lp_k1_launch_(int dtype, const void* x, const void* wp, const float* bia
   p.ncg = (p.NB + cb - 1) / cb;
   if (blocks * p.ncg > 0x7fffffffL) return 1;
   const dim3 grid((unsigned)(blocks * p.ncg));
-  if (dtype == LP_F16) {
-    if (cb == 2) hipLaunchKernelGGL((lp_k1_kernel<TF16, 2>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((lp_k1_kernel<TF16, 1>), grid, dim3(256), 0, stream, p);
-  } else {
-    if (cb == 2) hipLaunchKernelGGL((lp_k1_kernel<TBF16, 2>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((lp_k1_kernel<TBF16, 1>), grid, dim3(256), 0, stream, p);
-  }
+  static const bool lf_on = !(getenv("BTS_LP_K1F") && atoi(getenv("BTS_LP_K1F")) == 0);
+  const bool lf = lf_on && Cin % 64 == 0;      // whole 128-byte row pieces per load instruction
+  const bool gp = gap_part != nullptr;
+#define K1_GO(KERN, T_) do {                                                                                                          \
+    if (cb == 2) { if (gp) hipLaunchKernelGGL((KERN<T_, 2, true>), grid, dim3(256), 0, stream, p); else hipLaunchKernelGGL((KERN<T_, 2, false>), grid, dim3(256), 0, stream, p); } \
+    else { if (gp) hipLaunchKernelGGL((KERN<T_, 1, true>), grid, dim3(256), 0, stream, p); else hipLaunchKernelGGL((KERN<T_, 1, false>), grid, dim3(256), 0, stream, p); }        \
+  } while (0)
+  if (lf) { if (dtype == LP_F16) K1_GO(lp_k1f_kernel, TF16); else K1_GO(lp_k1f_kernel, TBF16); }
+  else { if (dtype == LP_F16) K1_GO(lp_k1_kernel, TF16); else K1_GO(lp_k1_kernel, TBF16); }
+#undef K1_GO
   if (prof) bts_prof_end(stream);
   BTS_LAUNCH_CHECK();
   return BTS_OK;

@@ -117,22 +117,43 @@ extern "C" int bts_colsum(const float* x, float* out, void* workspace, long work
 // ---------------------------------------------------------------------------------------------
 // channel-SE MLP forward: one block per sample (resnet.py:47-58,122-124; Dense kernels are (in,out), no bias)
 // ---------------------------------------------------------------------------------------------
-__global__ void se_mlp_fwd_kernel(const float* gap, const float* w1, const float* w2, float* hbuf, float* ch, int F, int R) {
-  extern __shared__ float shf[];  // gap[F] + h[R]
+// (the first layer's F-long sums are split over 256 / R slices of the block and combined in fixed order: with one thread per hidden
+// unit the kernel was a chain of F dependent loads -- 11 us at F = 256, on the critical path of every block)
+__global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* gap, const float* w1, const float* w2, float* hbuf, float* ch, int F, int R) {
+  extern __shared__ float shf[];  // gap[F] + h[R] + partial[256]
+  float* hs = shf + F;
+  float* part = hs + R;
   const int n = blockIdx.x;
-  for (int c = threadIdx.x; c < F; c += blockDim.x) shf[c] = gap[n * F + c];
+  for (int c = threadIdx.x; c < F; c += 256) shf[c] = gap[n * F + c];
   __syncthreads();
-  for (int k = threadIdx.x; k < R; k += blockDim.x) {
+  if (R <= 256) {
+    const int P = 256 / R;                  // slices
+    const int k = threadIdx.x % R, sl = threadIdx.x / R;
     float s = 0.f;
-    for (int c = 0; c < F; ++c) s = fmaf(shf[c], w1[c * R + k], s);
-    s = fmaxf(s, 0.f);
-    shf[F + k] = s;
-    hbuf[n * R + k] = s;
+    if (sl < P)
+      for (int c = sl; c < F; c += P) s = fmaf(shf[c], w1[c * R + k], s);
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if ((int)threadIdx.x < R) {
+      float t = 0.f;
+      for (int q = 0; q < P; ++q) t += part[q * R + threadIdx.x];
+      t = fmaxf(t, 0.f);
+      hs[threadIdx.x] = t;
+      hbuf[n * R + threadIdx.x] = t;
+    }
+  } else {
+    for (int k = threadIdx.x; k < R; k += 256) {
+      float s = 0.f;
+      for (int c = 0; c < F; ++c) s = fmaf(shf[c], w1[c * R + k], s);
+      s = fmaxf(s, 0.f);
+      hs[k] = s;
+      hbuf[n * R + k] = s;
+    }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < F; c += blockDim.x) {
+  for (int c = threadIdx.x; c < F; c += 256) {
     float s = 0.f;
-    for (int k = 0; k < R; ++k) s = fmaf(shf[F + k], w2[k * F + c], s);
+    for (int k = 0; k < R; ++k) s = fmaf(hs[k], w2[k * F + c], s);
     ch[n * F + c] = sigmoidf_(s);
   }
 }
@@ -140,7 +161,7 @@ __global__ void se_mlp_fwd_kernel(const float* gap, const float* w1, const float
 extern "C" int bts_se_mlp_fwd(const float* gap, const float* w1, const float* w2, float* h, float* ch, int N, int F, int R,
                               hipStream_t stream) {
   if (N <= 0 || F <= 0 || R <= 0) return BTS_ERR_SHAPE;
-  (void)hipGetLastError(); hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(N), dim3(256), (F + R) * sizeof(float), stream, gap, w1, w2, h, ch, F, R);
+  (void)hipGetLastError(); hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(N), dim3(256), (F + R + 256) * sizeof(float), stream, gap, w1, w2, h, ch, F, R);
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }

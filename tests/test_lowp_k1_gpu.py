@@ -32,6 +32,8 @@ CASES = [
     (1, (16, 16, 16), 16, 96, False, False),     # one k-step, three cout blocks (two launch columns, the second half empty)
     (2, (9, 13, 20), 64, 64, False, True),       # 4680 positions: the last workgroup ragged
     (1, (16, 24, 32), 192, 64, True, False),     # twelve k-steps
+    (1, (17, 15, 17), 64, 64, False, True),      # 4335 positions: the last quad of voxels ragged (whole-row loads / stores by quads)
+    (1, (16, 16, 17), 128, 96, True, True),      # two groups of four k-steps, the second cout group half empty
 ]
 
 
