@@ -742,6 +742,120 @@ __global__ __launch_bounds__(256, 2) void lp_conv_gather_kernel(const LpGatherPa
   }
 }
 
+// Stride-2 gather with whole-row loads.  In the kernel above a B operand is 16 bytes of each of 32 voxels that sit two rows apart:
+// an instruction touches 32 cache lines and uses 32 bytes of each, every line comes back for the other k-steps, and the L2 -> L1 fill
+// rate bounds the launch (0.09 of the matrix peak at 32 channels).  Here the k-steps of a tap go in groups of GK = 2 | 4 (64 | 128
+// bytes of a voxel's row): load instruction i has the GK lanes of a quad fetch the GK * 32 contiguous bytes of output voxel
+// (quad base + i), the quad transpose (lowp_common.h) hands every lane its own voxel's pieces, one per k-step.  Two register sets:
+// the next group's rows and weight fragments are in flight while the current group multiplies.  Needs Wg % GK == 0 (a quad never
+// leaves its output row).
+template <typename T, int CB, int GK>
+__global__ __launch_bounds__(256, 2) void lp_conv_gatherq_kernel(const LpGatherParams p) {
+  constexpr int VB = 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = tid >> 6;
+  const int h = lane >> 5, l32 = lane & 31, b = l32 & (GK - 1);
+  const int cg = blockIdx.x % p.ncg;
+  const long blk = blockIdx.x / p.ncg;
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7fffffff, 0x00020000);
+  const unsigned wlane = (unsigned)((h * 32 + l32) * 16);
+  int gz[VB], gy[VB], gx[VB], gn[VB];
+  bool live[VB];
+  const unsigned short* base[VB];     // own voxel's quad base (n, s gz, s gy, s (gx - b)), this lane's piece of a chunk
+#pragma unroll
+  for (int v = 0; v < VB; ++v) {
+    long pos = ((blk * 4 + wave) * VB + v) * 32 + l32;
+    live[v] = pos < p.npos;           // (npos is a multiple of Wg, Wg of GK: the lanes of a quad are live together)
+    if (!live[v]) pos = 0;
+    gx[v] = (int)(pos % p.Wg); pos /= p.Wg;
+    gy[v] = (int)(pos % p.Hg); pos /= p.Hg;
+    gz[v] = (int)(pos % p.Dg);
+    gn[v] = (int)(pos / p.Dg);
+    base[v] = p.x + ((((long)gn[v] * p.Di + gz[v] * p.s) * p.Hi + gy[v] * p.s) * p.Wi + (long)(gx[v] - b) * p.s) * (long)p.ldx + (2 * b + h) * 8;
+  }
+  f32x16 acc[VB][CB];
+#pragma unroll
+  for (int v = 0; v < VB; ++v)
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[v][c][r] = 0.f;
+  const int NQ = p.KS / GK;                 // chunks per tap
+  const int total = p.ntaps * NQ;
+  int rt = 0, rq = 0, issued = 0;
+  u32x4 a0[GK][CB], a1[GK][CB], b0[VB][GK], b1[VB][GK];
+  auto issue = [&](u32x4 (&a)[GK][CB], u32x4 (&bb)[VB][GK]) {
+    if (issued >= total) return;
+    const LpTap tp = p.taps[rt];
+#pragma unroll
+    for (int j = 0; j < GK; ++j)
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        const int cb = cg * CB + c;
+        a[j][c] = bload16(wr, wlane, (unsigned)((((tp.w * p.KS + rq * GK + j) * p.NB) + (cb < p.NB ? cb : 0)) * 1024));
+      }
+    const long off = (((long)tp.dz * p.Hi + tp.dy) * p.Wi + tp.dx) * (long)p.ldx + rq * (GK * 16);
+#pragma unroll
+    for (int v = 0; v < VB; ++v) {
+      const int iz = gz[v] * p.s + tp.dz, iy = gy[v] * p.s + tp.dy;
+      const bool okzy = live[v] && (unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi;
+#pragma unroll
+      for (int i = 0; i < GK; ++i) {
+        const int ix = (gx[v] - b + i) * p.s + tp.dx;
+        bb[v][i] = u32x4{0u, 0u, 0u, 0u};
+        if (okzy && (unsigned)ix < (unsigned)p.Wi) bb[v][i] = *reinterpret_cast<const u32x4*>(base[v] + off + (long)i * p.s * p.ldx);
+      }
+    }
+    ++issued;
+    if (++rq == NQ) { rq = 0; ++rt; }
+  };
+  auto compute = [&](u32x4 (&a)[GK][CB], u32x4 (&bb)[VB][GK]) {
+#pragma unroll
+    for (int v = 0; v < VB; ++v) {
+      if constexpr (GK == 4) k1_quad_transpose(bb[v], b); else k1_pair_transpose(bb[v], b);
+    }
+#pragma unroll
+    for (int j = 0; j < GK; ++j)
+#pragma unroll
+      for (int v = 0; v < VB; ++v)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) acc[v][c] = T::mfma(a[j][c], bb[v][j], acc[v][c]);
+  };
+  issue(a0, b0);
+  for (int g = 0; g < total; g += 2) {
+    issue(a1, b1);
+    compute(a0, b0);
+    if (g + 1 < total) {
+      issue(a0, b0);
+      compute(a1, b1);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CB; ++c) {
+    const int cb = cg * CB + c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = cb * 32 + 8 * q + 4 * h;
+      float bq[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && cb < p.NB) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (co + j < p.Cout) bq[j] = p.bias[co + j];
+      }
+#pragma unroll
+      for (int v = 0; v < VB; ++v) {
+        if (live[v] && cb < p.NB && co < p.Cout) {
+          const int oz = gz[v] * p.os + p.ooz, oy = gy[v] * p.os + p.ooy, ox = gx[v] * p.os + p.oox;
+          if (oz < p.Do && oy < p.Ho && ox < p.Wo) {
+            unsigned short* dst = p.y + ((((long)gn[v] * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * (long)p.ldy + co;
+            lp_store_quad<T>(dst, acc[v][c][4 * q] + bq[0], acc[v][c][4 * q + 1] + bq[1], acc[v][c][4 * q + 2] + bq[2], acc[v][c][4 * q + 3] + bq[3],
+                             p.Cout - co, p.accum);
+          }
+        }
+      }
+    }
+  }
+}
+
 // positions per workgroup of a gather launch (4 waves x VB x 32)
 static int lp_gather_vb(long npos, int NB) {
   const int cb = NB >= 2 ? 2 : 1;
@@ -753,12 +867,32 @@ static int lp_gather_launch(LpGatherParams p, hipStream_t stream) {
   p.npos = (long)p.N * p.Dg * p.Hg * p.Wg;
   const int cb = p.NB >= 2 ? 2 : 1;
   p.ncg = (p.NB + cb - 1) / cb;
-  const int vb = lp_gather_vb(p.npos, p.NB);
+  int vb = lp_gather_vb(p.npos, p.NB);
+  // whole-row loads for the stride-2 forms on grids that fill the chip (BTS_LP_GATHERQ=0: the plain kernel, for A/B)
+  int gk = 0;
+  {
+    const char* e = getenv("BTS_LP_GATHERQ");
+    if (!(e && atoi(e) == 0) && p.s == 2 && p.gap_part == nullptr && vb >= 2 && p.KS % 2 == 0) {
+      if (p.KS % 4 == 0 && p.Wg % 4 == 0) gk = 4;
+      else if (p.Wg % 2 == 0) gk = 2;
+    }
+    if (gk && ((p.npos + 255) / 256) * p.ncg < 1024) gk = 0;     // (grids that do not fill the chip four workgroups deep: the plain kernel's smaller tiles win)
+    if (gk) vb = 2;
+  }
   const long blocks = ((p.npos + 128L * vb - 1) / (128L * vb)) * p.ncg;
   if (blocks > 0x7fffffffL) return BTS_ERR_SHAPE;
   const bool prof = bts_prof_on();
   if (prof) bts_prof_begin(31, 2.0 * p.ntaps * 16.0 * p.KS * p.Cout * (double)p.npos, stream);
   (void)hipGetLastError();
+  if (gk) {
+#define LP_GQ(CB_, GK_) hipLaunchKernelGGL((lp_conv_gatherq_kernel<T, CB_, GK_>), dim3((unsigned)blocks), dim3(256), 0, stream, p)
+    if (cb == 2) { if (gk == 4) LP_GQ(2, 4); else LP_GQ(2, 2); }
+    else { if (gk == 4) LP_GQ(1, 4); else LP_GQ(1, 2); }
+#undef LP_GQ
+    if (prof) bts_prof_end(stream);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+  }
 #define LP_G_CASE(VB_, CB_) if (vb == VB_ && cb == CB_) hipLaunchKernelGGL((lp_conv_gather_kernel<T, VB_, CB_>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
   LP_G_CASE(4, 1) LP_G_CASE(4, 2) LP_G_CASE(2, 1) LP_G_CASE(2, 2) LP_G_CASE(1, 1) LP_G_CASE(1, 2)
 #undef LP_G_CASE

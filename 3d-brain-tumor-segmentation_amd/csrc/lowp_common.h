@@ -97,3 +97,47 @@ template <typename T> __device__ __forceinline__ void lp_s1d_pack_elem(const LpP
   p.wp[i] = T::st(lp_pack_src(p, dz * 9 + t9, ks * 16 + hh * 8 + e, cg * CBW * 32 + row));
 }
 
+
+// 4 x 4 transpose of 16-byte pieces between the four lanes of a quad (lane bits 0-1) and four registers: afterwards register j of quad
+// lane b holds what register b of quad lane j held.  Two butterfly stages of quad-permute DPP moves; its own inverse.
+// What it is for: NDHWC rows of 64 channels are 128 bytes = 8 pieces.  The matrix instruction wants lane (voxel, k-half h) to hold piece
+// 2 ks + h of ITS voxel in the register of k-step ks -- loaded that way, one instruction touches 32 bytes of each of 32 rows, four
+// instructions per cache line, and the L1 request rate (not HBM) bounds the kernel at ~4 TB/s.  Loaded transposed -- instruction i:
+// quad lane b fetches piece 2 b + h of voxel (quad base + i) -- an instruction covers 8 whole rows; the transpose then hands every lane
+// its own voxel.  The same on the way out for 64-cout groups.
+__device__ __forceinline__ void k1_quad_transpose(u32x4 (&r)[4], int b) {
+  u32x4 s[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    u32x4 t;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) t[d] = (unsigned)__builtin_amdgcn_mov_dpp((int)r[j ^ 1][d], 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    const bool keep = ((b ^ j) & 1) == 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) s[j][d] = keep ? r[j][d] : t[d];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    u32x4 t;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) t[d] = (unsigned)__builtin_amdgcn_mov_dpp((int)s[j ^ 2][d], 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    const bool keep = ((b ^ j) & 2) == 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) r[j][d] = keep ? s[j][d] : t[d];
+  }
+}
+
+// the 2 x 2 form: register j of pair lane b <-> register b of pair lane j (64-byte row chunks: two k-steps)
+__device__ __forceinline__ void k1_pair_transpose(u32x4 (&r)[2], int b) {
+  u32x4 s[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    u32x4 t;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) t[d] = (unsigned)__builtin_amdgcn_mov_dpp((int)r[j ^ 1][d], 0xB1, 0xf, 0xf, true);
+    const bool keep = ((b ^ j) & 1) == 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) s[j][d] = keep ? r[j][d] : t[d];
+  }
+  r[0] = s[0]; r[1] = s[1];
+}

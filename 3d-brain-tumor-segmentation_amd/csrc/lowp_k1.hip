@@ -36,35 +36,6 @@ struct LpK1Params {
 };
 #define LPK1_POS 256   // positions per workgroup: 4 waves x 2 fragments x 32
 
-// 4 x 4 transpose of 16-byte pieces between the four lanes of a quad (lane bits 0-1) and four registers: afterwards register j of quad
-// lane b holds what register b of quad lane j held.  Two butterfly stages of quad-permute DPP moves; its own inverse.
-// What it is for: NDHWC rows of 64 channels are 128 bytes = 8 pieces.  The matrix instruction wants lane (voxel, k-half h) to hold piece
-// 2 ks + h of ITS voxel in the register of k-step ks -- loaded that way, one instruction touches 32 bytes of each of 32 rows, four
-// instructions per cache line, and the L1 request rate (not HBM) bounds the kernel at ~4 TB/s.  Loaded transposed -- instruction i:
-// quad lane b fetches piece 2 b + h of voxel (quad base + i) -- an instruction covers 8 whole rows; the transpose then hands every lane
-// its own voxel.  The same on the way out for 64-cout groups.
-__device__ __forceinline__ void k1_quad_transpose(u32x4 (&r)[4], int b) {
-  u32x4 s[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    u32x4 t;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) t[d] = (unsigned)__builtin_amdgcn_mov_dpp((int)r[j ^ 1][d], 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-    const bool keep = ((b ^ j) & 1) == 0;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) s[j][d] = keep ? r[j][d] : t[d];
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    u32x4 t;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) t[d] = (unsigned)__builtin_amdgcn_mov_dpp((int)s[j ^ 2][d], 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
-    const bool keep = ((b ^ j) & 2) == 0;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) r[j][d] = keep ? s[j][d] : t[d];
-  }
-}
-
 // Output side of a wave's VB fragments: (+ old values), column sums for the fused pool, rounding, stores.  32-cout items: 16-byte
 // stores of 8 consecutive couts (v_permlane32_swap between the two lanes of a voxel).  64-cout items: the four 16-byte pieces of a
 // lane are quad-transposed first, so that a store instruction writes whole 128-byte rows (and reads them whole when accumulating).

@@ -433,6 +433,7 @@ class LowPrecisionForward(object):
             if not torch.cuda.is_available():
                 raise RuntimeError('no MI355X visible: the engine has no CPU execution path')
             x = x.cuda()
+        fence = ops.step_fence('infer', depth=3)
         x = x.float()
         if self.channels_first:                       # raw NCDHW in (tape.as_tensor does the same for the fp32 engine)
             x = x.permute(0, 2, 3, 4, 1)
@@ -470,4 +471,5 @@ class LowPrecisionForward(object):
             self._up(up, y, slab[..., cres:cres + f])                                     # decoder.py:72
             y = self._block(blk, slab[..., :cres + f], None)                              # decoder.py:75-78
         yp = head(self.code, y, dec.out_k.t.reshape(dec.out_k.t.shape[-2], dec.out_k.t.shape[-1]), dec.out_b.t, True)
+        ops.step_fence_done(fence)
         return yp.permute(0, 4, 1, 2, 3) if self.channels_first else yp      # the public layout (a view, like Tensor.public())

@@ -318,6 +318,7 @@ class LowPrecisionTrainer(object):
         if not torch.is_tensor(y):
             y = torch.as_tensor(y)
         dev = torch.device('cuda', torch.cuda.current_device())
+        fence = ops.step_fence('train')          # at most two steps in flight (see ops.step_fence)
         x, y = x.to(dev).float(), y.to(dev).float()
         cf = m.data_format == 'channels_first'
         if cf:          # raw NCDHW volumes -> the engine's NDHWC memory (tape.as_tensor does the same for the fp32 step)
@@ -515,4 +516,5 @@ class LowPrecisionTrainer(object):
         scale = parallel.all_reduce_gradients(m)
         grads = [p._gview for p in m.trainable_variables]
         optimizer.apply_gradients(zip(grads, m.trainable_variables), model=m, grad_scale=scale)
+        ops.step_fence_done(fence)
         return Tensor(loss_t, requires_grad=False), macro, micro

@@ -137,6 +137,7 @@ def reduce_sum(terms):
 
 def train_step(model, optimizer, loss_fn, dice_fn, x, y):
     """One iteration of the reference's training loop, train.py:140-152.  Returns (loss, macro_dice, micro_dice)."""
+    fence = ops.step_fence('train')          # at most two steps in flight (see ops.step_fence)
     with GradientTape() as tape:
         y_pred, y_vae, z_mean, z_logvar = model(x, training=True, inference=False)     # :143
         loss = loss_fn(x, y, y_pred, y_vae, z_mean, z_logvar)                          # :145
@@ -146,4 +147,5 @@ def train_step(model, optimizer, loss_fn, dice_fn, x, y):
     grads = tape.gradient(loss, model.trainable_variables, grad_sync=sync)             # :151
     scale = 1.0 if sync is not None else parallel.all_reduce_gradients(model)          # C1 (no-op on one rank)
     optimizer.apply_gradients(zip(grads, model.trainable_variables), model=model, grad_scale=scale)  # :152
+    ops.step_fence_done(fence)
     return loss, macro_dice, micro_dice

@@ -366,6 +366,11 @@ def measure_train(args, world, rank, dev, overrides, dtype=None, batch=None, ste
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if os.environ.get('BTS_BENCH_MEMSTATS'):       # allocator state of the timed region, to stderr (diagnostics; not part of the line)
+        ms_ = torch.cuda.memory_stats()
+        print('memstats: reserved peak %.1f GB, allocated peak %.1f GB, hipMalloc retries %d, segments %d' %
+              (ms_['reserved_bytes.all.peak'] / 1e9, ms_['allocated_bytes.all.peak'] / 1e9, ms_['num_alloc_retries'],
+               ms_['segment.all.current']), file=sys.stderr, flush=True)
     ranks_seen = 1
     if parallel.active():
         tt = torch.tensor([dt], dtype=torch.float64)
