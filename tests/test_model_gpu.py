@@ -218,12 +218,16 @@ def test_channels_first_public_layout_parity(name):
     assert torch.equal(lab[~ambiguous], labels_r.long()[~ambiguous]), 'argmax label map differs'
     print('voxels within 2e-4 of a decision boundary:', int(ambiguous.sum()), 'of', ambiguous.numel())
     gdev = max(maxerr(grads_32[k], grads_r[k]) / (float(grads_r[k].abs().max()) + 1e-12) for k in grads_r)
+    # A conv bias in front of a GroupNormalization has the exact gradient 0 (2.7e-15 in fp64 here): what any fp32 evaluation returns is
+    # the rounding residue of ~256 gradient values of the layer that cancel -- 2e-8 or 6e-5 depending on the last bits upstream (the
+    # layer's kernel gradient is 12.6).  Such entries are held to 1e-5 of the model's largest gradient instead of to their own size.
+    gmax = max(float(grads_r[k].abs().max()) for k in grads_r)
     for p, g in zip(model.trainable_variables, grads):
         gr = grads_r[model.oracle_name(p)]
         scale = float(gr.abs().max()) + 1e-12
         err = maxerr(g, gr) / scale
         dev32 = maxerr(grads_32[model.oracle_name(p)], gr) / scale
-        assert err <= max(1e-3, 4 * dev32, gdev) or maxerr(g, gr) <= 1e-9, \
+        assert err <= max(1e-3, 4 * dev32, gdev) or maxerr(g, gr) <= max(1e-9, 1e-5 * gmax if scale < 1e-9 * gmax else 0.0), \
             'grad %s rel err %.3e (fp32-torch deviates %.3e)' % (p.name, err, dev32)
 
 
