@@ -876,7 +876,8 @@ static int lp_gather_launch(LpGatherParams p, hipStream_t stream) {
       if (p.KS % 4 == 0 && p.Wg % 4 == 0) gk = 4;
       else if (p.Wg % 2 == 0) gk = 2;
     }
-    if (gk && ((p.npos + 255) / 256) * p.ncg < 1024) gk = 0;     // (grids that do not fill the chip four workgroups deep: the plain kernel's smaller tiles win)
+    // (below ~300 workgroups the plain kernel's smaller tiles win: 128 -> 128 at 8 x 32^3, 256 workgroups, 77 against 90 us)
+    { const char* m = getenv("BTS_LP_GATHERQ_MIN"); if (gk && ((p.npos + 255) / 256) * p.ncg < (m ? atol(m) : 288)) gk = 0; }
     if (gk) vb = 2;
   }
   const long blocks = ((p.npos + 128L * vb - 1) / (128L * vb)) * p.ncg;
@@ -1067,12 +1068,15 @@ extern "C" int bts_lp_conv1_gap(int dtype, const void* x, const void* wp, const 
   if (workspace == nullptr || workspace_bytes < bts_lp_conv1_gap_workspace(N, V, Cout) || (((uintptr_t)workspace) & 15)) return BTS_ERR_WORKSPACE;
   const int NB = (Cout + 31) / 32;
   {   // streaming kernel: column sums per block of 256 positions
-    const int kb = bts_lp_k1_gap_block_((long)N * V, V, Cin, Cout);
-    if (kb > 0 && V % kb == 0 && ldres == Cout) {
+    // (one sample: a partial row can never span two samples, so the last position block may be ragged -- 20x24x20 = 9600 positions,
+    // the deepest level of the full inference volume, is not a multiple of 256)
+    int kb = bts_lp_k1_gap_block_((long)N * V, V, Cin, Cout);
+    if (kb == 0 && N == 1 && bts_lp_k1_gap_block_(V, 256, Cin, Cout) > 0) kb = 256;
+    if (kb > 0 && (V % kb == 0 || N == 1) && ldres == Cout) {
       double* part = reinterpret_cast<double*>(workspace);
       const int r = bts_lp_k1_launch_(dtype, x, wp, bias, res, (long)N * V, Cin, ldx, Cout, ldres, 0, part, kb, stream);
       if (r == BTS_OK) {
-        hipLaunchKernelGGL(lp_colsum_finalize_kernel, dim3((N * Cout + 3) / 4), dim3(256), 0, stream, part, gap, N, Cout, (int)(V / kb), 1.0 / (double)V);
+        hipLaunchKernelGGL(lp_colsum_finalize_kernel, dim3((N * Cout + 3) / 4), dim3(256), 0, stream, part, gap, N, Cout, (int)((V + kb - 1) / kb), 1.0 / (double)V);
         BTS_LAUNCH_CHECK();
         return BTS_OK;
       }

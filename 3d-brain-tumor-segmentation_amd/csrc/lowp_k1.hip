@@ -341,7 +341,8 @@ int bts_lp_k1_gap_block_(long npos, long V, int Cin, int Cout) {
 int bts_lp_k1_launch_(int dtype, const void* x, const void* wp, const float* bias, void* y, long npos, int Cin, int ldx, int Cout, int ldy,
                       int accum, double* gap_part, int gap_block, hipStream_t stream) {
   if (bts_lp_k1_gap_block_(npos, LPK1_POS, Cin, Cout) == 0) return 1;
-  if (gap_part != nullptr && (gap_block < LPK1_POS || gap_block % LPK1_POS != 0 || npos % gap_block != 0)) return 1;
+  // (npos % gap_block != 0: the caller vouches that the ragged last row belongs to the only sample)
+  if (gap_part != nullptr && (gap_block < LPK1_POS || gap_block % LPK1_POS != 0)) return 1;
   if (ldx % 8 != 0 || ldy % 8 != 0 || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 15)) return 1;
   LpK1Params p;
   p.x = (const unsigned short*)x; p.wp = (const unsigned short*)wp; p.bias = bias; p.y = (unsigned short*)y;

@@ -6,9 +6,10 @@ import bts_amd  # noqa
 from bts_amd import lowp, ops
 DEV = torch.device('cuda', 0)
 code, tdt = lowp.DTYPES['bfloat16']
-CASES = [(8, 128, 32, 32, 64), (8, 128, 32, 32, 32), (8, 128, 32, 64, 64), (8, 64, 64, 64, 128), (8, 64, 64, 64, 64), (8, 32, 128, 128, 256), (1, 160, 32, 32, 64)]
+CASES = [(1, (80, 96, 80), 64, 64, 128), (1, (40, 48, 40), 128, 128, 256), (1, (160, 192, 160), 32, 32, 64), (8, 128, 32, 32, 64), (8, 128, 32, 32, 32), (8, 128, 32, 64, 64), (8, 64, 64, 64, 128), (8, 64, 64, 64, 64), (8, 32, 128, 128, 256), (1, 160, 32, 32, 64)]
 for (n, d, cin, cout, ldx) in CASES:
-    slab = torch.randn((n, d, d, d, ldx), device=DEV).to(tdt)
+    dims = d if isinstance(d, tuple) else (d, d, d)
+    slab = torch.randn((n,) + dims + (ldx,), device=DEV).to(tdt)
     x = slab[..., :cin]
     wt = torch.randn((3, 3, 3, cin, cout), device=DEV) * 0.05
     b = torch.zeros(cout, device=DEV)
@@ -27,7 +28,8 @@ for (n, d, cin, cout, ldx) in CASES:
         e1.record(); torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) / 5 * 1e3)
         outs.append(y.float())
-    fl = 2.0 * 27 * cin * cout * n * (d // 2) ** 3
-    gb = (n * d ** 3 * cin + n * (d // 2) ** 3 * cout) * 2 / 1e9
-    print('s2 n%d %3d^3 %3d->%3d ldx %3d: plain %7.1f us (%4.0f TF) | whole rows %7.1f us (%4.0f TF, %.2f TB/s)  maxdiff %.3g' %
-          (n, d, cin, cout, ldx, res[0], fl / res[0] / 1e6, res[1], fl / res[1] / 1e6, gb / res[1] * 1e3, float((outs[0] - outs[1]).abs().max())), flush=True)
+    vin = dims[0] * dims[1] * dims[2]
+    fl = 2.0 * 27 * cin * cout * n * vin / 8
+    gb = (n * vin * cin + n * vin // 8 * cout) * 2 / 1e9
+    print('s2 n%d %s %3d->%3d ldx %3d: plain %7.1f us (%4.0f TF) | whole rows %7.1f us (%4.0f TF, %.2f TB/s)  maxdiff %.3g' %
+          (n, 'x'.join(map(str, dims)), cin, cout, ldx, res[0], fl / res[0] / 1e6, res[1], fl / res[1] / 1e6, gb / res[1] * 1e3, float((outs[0] - outs[1]).abs().max())), flush=True)

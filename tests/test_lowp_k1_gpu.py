@@ -98,13 +98,16 @@ def test_data_gradient(dtype, accumulate):
 
 
 @pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
-def test_fused_global_average_pool(dtype):
-    """bts_lp_conv1_gap: the shortcut conv and the squeeze of its output (resnet.py:118-121) in one pass"""
+@pytest.mark.parametrize('shape', [(2, 16, 16, 16, 32, 64), (1, 20, 24, 20, 128, 64), (1, 17, 15, 17, 64, 32)],
+                         ids=['n2-16x16x16', 'n1-20x24x20-ragged-rows', 'n1-17x15x17-ragged-quad'])
+def test_fused_global_average_pool(dtype, shape):
+    """bts_lp_conv1_gap: the shortcut conv and the squeeze of its output (resnet.py:118-121) in one pass; a single sample's volume
+    need not be whole 256-position blocks (the 20x24x20 level of the full inference volume)"""
     import bts_amd  # noqa: F401
     from bts_amd import lowp, ops
     code, tdt = lowp.DTYPES[dtype]
     g = torch.Generator().manual_seed(4)
-    n, d, h, w, cin, cout = 2, 16, 16, 16, 32, 64
+    n, d, h, w, cin, cout = shape
     x = torch.randn((n, d, h, w, cin), generator=g)
     wt = torch.randn((1, 1, 1, cin, cout), generator=g) * (2.0 / cin) ** 0.5
     b = torch.randn(cout, generator=g) * 0.3
