@@ -333,20 +333,10 @@ static bool k1_enabled() {   // BTS_LP_K1=0: 1x1x1 convs back on the general gat
 // .. 256 that divides V; fewer, longer rows keep the finalize short), or 0 when a call with these dimensions is declined
 int bts_lp_k1_gap_block_(long npos, long V, int Cin, int Cout) {
   if (!k1_enabled() || Cin % 16 != 0 || Cout % 8 != 0 || npos < 4096) return 0;
-  // ... but a workgroup walks a whole row: rows this long must still give the chip a thousand workgroups or more (160x192x160 at 2048
-  // positions per row = 2400 workgroups = 3.1 rounds of the 768 resident ones: a quarter of the launch was tail)
-  const char* e = getenv("BTS_LP_K1_ROWS");
-  const long want = e ? atol(e) : 1024;
-  int first = 0;
+  // (shorter rows = more workgroups were tried for the 160x192x160 volume, 2400 workgroups at 2048 positions per row: within the
+  // run-to-run noise at full resolution, 10-25 % slower at the 80x96x80 level where a workgroup's fixed costs stop amortising)
   for (int kb = 2048; kb >= LPK1_POS; kb >>= 1)
-    if (V % kb == 0) {
-      if (!first) first = kb;
-      if (npos / kb >= want) return kb;
-    }
-  if (first) {      // none long enough: the shortest row that divides V
-    for (int kb = LPK1_POS; kb <= first; kb <<= 1)
-      if (V % kb == 0) return kb;
-  }
+    if (V % kb == 0) return kb;
   return 0;
 }
 // BTS_OK = ran, 1 = declined.  Views: x rows of ldx elements, y rows of ldy, both 16-byte aligned with ld % 8 == 0.
