@@ -399,8 +399,21 @@ class LowPrecisionTrainer(object):
             yv, bs = self._block_fwd(blk, yv, None)
             vsaves.append((us, bs))
         yv_last = yv
-        wp_vo = self._pk((id(vae), 'out'), ops.K3S1, vae.out_k, yv_last.shape[-1], vae.out_ch)
-        y_vae = self._f32(conv(ops.K3S1, code, tdt, yv_last, wp_vo, vae.out_b.t, vae.out_ch))
+        if vae.out_ch < 8 and yv_last.shape[-1] % 16 == 0:
+            # out_ch = in_ch = 2 (vae.py:92-99): fewer than the 8 couts a 16-byte store carries, which left this 128^3 layer to the
+            # register-staged kernel (0.97 ms of the batch-8 step).  Kernel and bias zero-padded to 8 output channels -> the streaming
+            # kernels take it (the pad columns multiply zeros; only the live ones are read back)
+            cvv = yv_last.shape[-1]
+            wpad = torch.zeros((3, 3, 3, cvv, 8), dtype=torch.float32, device=dev)
+            wpad[..., :vae.out_ch] = vae.out_k.t
+            bpad = torch.zeros(8, dtype=torch.float32, device=dev)
+            bpad[:vae.out_ch] = vae.out_b.t
+            y8 = conv(ops.K3S1, code, tdt, yv_last, lowp.pack(ops.K3S1, code, wpad, cvv, 8), bpad, 8)
+            y_vae = self._f32(y8[..., :vae.out_ch])
+            del y8, wpad
+        else:
+            wp_vo = self._pk((id(vae), 'out'), ops.K3S1, vae.out_k, yv_last.shape[-1], vae.out_ch)
+            y_vae = self._f32(conv(ops.K3S1, code, tdt, yv_last, wp_vo, vae.out_b.t, vae.out_ch))
         # ------------------------------------------------ loss, metric (fp32: util.py:13-24,35-57, train.py:145-148) -------------
         c = y_pred.shape[-1]
         sums = ops.loss_sums(y_pred, y, x, y_vae, proj)
