@@ -41,6 +41,8 @@ int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bi
                        int Cout, int ldy, int accum, double* gn_part, int gn_G, hipStream_t stream);
 // lowp_k1.hip: streaming 1x1x1 kernel (offered first; 1 = declined); gap partials per block of bts_lp_k1_gap_block_ positions
 int bts_lp_k1_gap_block_(long npos, long V, int Cin, int Cout);
+int bts_lp_s2t_launch_(int dtype, const void* x, const void* wp, const float* bias, void* y, int N, int D, int H, int W, int Cin, int ldx,
+                       int Cout, int ldy, int accum, hipStream_t stream);
 int bts_lp_k1_launch_(int dtype, const void* x, const void* wp, const float* bias, void* y, long npos, int Cin, int ldx, int Cout, int ldy,
                       int accum, double* gap_part, int gap_block, hipStream_t stream);
 // lowp_up.hip: transposed form, all eight output classes in one pass (offered first; 1 = declined)
@@ -948,6 +950,10 @@ static int lp_conv_run(int geo, int dtype, const void* x, const void* wp, const 
     return run(g);
   }
   if (geo == 2) {   // TF 'same', stride 2: out = ceil(in/2), pad_before = max((out-1)*2+3-in, 0) / 2
+    {   // 32 -> <= 32 channels on a big even grid: the LDS-tiled kernel (lowp_s2t.hip)
+      const int r = bts_lp_s2t_launch_(dtype, x, wp, bias, y, N, D, H, W, Cin, ldx, Cout, ldy, accum, stream);
+      if (r != 1) return r;
+    }
     g.Do = (D + 1) / 2; g.Ho = (H + 1) / 2; g.Wo = (W + 1) / 2;
     g.Dg = g.Do; g.Hg = g.Ho; g.Wg = g.Wo; g.s = 2; g.os = 1; g.ooz = g.ooy = g.oox = 0; g.ntaps = 27;
     auto padb = [](int in, int out) { const int t = (out - 1) * 2 + 3 - in; return t > 0 ? t / 2 : 0; };

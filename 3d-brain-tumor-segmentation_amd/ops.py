@@ -58,6 +58,8 @@ def kernel_symbol(sym):
         return 'lp_wgd_kernel'
     if sym == 38:
         return 'lp_s1z_kernel'
+    if sym == 39:
+        return 'lp_s2t_kernel'
     if sym >= 100:  # 100 + (MODE << 2 | FIXG)
         return 'wgrad_kernel<%d,%d>' % ((sym - 100) >> 2, (sym - 100) & 3)
     return 'igemm_kernel<%s,%d>' % (_CFG[sym & 7], 4 if sym & 8 else 1)
