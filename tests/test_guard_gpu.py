@@ -243,6 +243,19 @@ def test_16bit_kernels_with_tiling_floors_stay_inside_slab_views(guard, dtype):
         ops.profile_enable(False)
         assert 'lp_s1z_kernel' in [r[0] for r in ops.profile_records()]
         assert untouched(yb, yl, yc) and untouched(xb, 8, cin)
+    # LDS-tiled stride-2 conv of the 32-channel top level (lowp_s2t.hip): ragged tiles on every axis, slab views on both sides; and the
+    # whole-row-load gather (64 -> 64: quads of voxels per load instruction) on a grid whose last quad row ends the tensor
+    for (n, d, h, w, cin, cout, sym) in [(2, 60, 44, 72, 32, 24, 'lp_s2t_kernel'), (1, 48, 40, 72, 64, 64, 'lp_conv_gather_kernel')]:
+        xb, xv, _, _ = slab(n, d, h, w, cin)
+        yb, yv, yl, yc = slab(n, d // 2, h // 2, w // 2, cout)
+        wt = (torch.randn((3, 3, 3, cin, cout), generator=gen) * 0.05).to(dev)
+        b = torch.randn(cout, generator=gen).to(dev)
+        ops.profile_enable(True)
+        lowp.conv(ops.K3S2, code, tdt, xv, lowp.pack(ops.K3S2, code, wt, cin, cout), b, cout, out=yv)
+        torch.cuda.synchronize()
+        ops.profile_enable(False)
+        assert sym in [r[0] for r in ops.profile_records()]
+        assert untouched(yb, yl, yc) and untouched(xb, 8, cin)
     # streaming stride-1 weight gradient (lowp_wgd.hip): x a slab view, guarded dw and an exact-size workspace
     xb, xv, _, _ = slab(1, 37, 16, 32, 64)
     dyc = torch.randn((1, 37, 16, 32, 16), generator=gen).to(tdt).to(dev)
