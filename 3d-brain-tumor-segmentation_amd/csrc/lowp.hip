@@ -2011,40 +2011,54 @@ __global__ __launch_bounds__(256) void lp_gn_bwd_reduce_kernel(const unsigned sh
     o[0] = sa; o[1] = sb;
   }
 }
-// one block per group g: for every sample the class sums over the blocks -> c1, c2; the sums over the samples -> dgamma, dbeta
+// one block per group g: for every sample the class sums over the blocks -> c1, c2; the sums over the samples -> dgamma, dbeta.
+// Up to 256 / cg samples side by side (thread = (slice of the blocks, sample, class)): the loop over the samples of a batch of 8 was
+// eight dependent rounds, 15 us on the critical path between the reduce and the apply pass of every GroupNorm backward.
 __global__ __launch_bounds__(256) void lp_gn_bwd_finalize_kernel(const double* partial, const float* gamma, float* dgamma, float* dbeta, float* c1,
                                                                  float* c2, int N, int G, int B, int cg, double L, int accum) {
   __shared__ double sh[256 * 2];
-  const int g = blockIdx.x;
-  const int j = threadIdx.x % cg, sl = threadIdx.x / cg, S = 256 / cg;
-  double ga = 0.0, gb = 0.0;     // running dgamma / dbeta of class j (slice 0 holds the result)
-  for (int n = 0; n < N; ++n) {
-    const long unit = (long)n * G + g;
+  __shared__ double tot[256 * 2];      // [sample slot][class] totals of the current round
+  const int g = blockIdx.x, t = threadIdx.x;
+  int Np = 1;
+  while (Np * 2 <= N && cg * Np * 2 <= 256) Np *= 2;
+  const int S = 256 / (cg * Np);
+  const int j = t % cg, nl = (t / cg) % Np, sl = t / (cg * Np);
+  double ga = 0.0, gb = 0.0;     // running dgamma / dbeta of class t (threads t < cg)
+  for (int n0 = 0; n0 < N; n0 += Np) {
+    const int n = n0 + nl;
     double sa = 0.0, sb = 0.0;
-    for (int b = sl; b < B; b += S) {
-      const double* o = partial + ((unit * B + b) * cg + j) * 2;
-      sa += o[0]; sb += o[1];
+    if (n < N) {
+      const long unit = (long)n * G + g;
+      for (int b = sl; b < B; b += S) {
+        const double* o = partial + ((unit * B + b) * cg + j) * 2;
+        sa += o[0]; sb += o[1];
+      }
     }
     __syncthreads();
-    sh[threadIdx.x * 2] = sa; sh[threadIdx.x * 2 + 1] = sb;
+    sh[t * 2] = sa; sh[t * 2 + 1] = sb;
     __syncthreads();
-    if (sl == 0) {
+    if (sl == 0) {      // slices in fixed order
       sa = 0.0; sb = 0.0;
-      for (int s2 = 0; s2 < S; ++s2) { sa += sh[(s2 * cg + j) * 2]; sb += sh[(s2 * cg + j) * 2 + 1]; }
-      ga += sa; gb += sb;
-      sh[j * 2] = (double)gamma[g * cg + j] * sb;       // -> c1
-      sh[j * 2 + 1] = (double)gamma[g * cg + j] * sa;   // -> c2
+      for (int s2 = 0; s2 < S; ++s2) { sa += sh[((s2 * Np + nl) * cg + j) * 2]; sb += sh[((s2 * Np + nl) * cg + j) * 2 + 1]; }
+      tot[(nl * cg + j) * 2] = sa; tot[(nl * cg + j) * 2 + 1] = sb;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (t < Np && n0 + t < N) {      // c1, c2 of sample n0 + t
       double s1 = 0.0, s2 = 0.0;
-      for (int q = 0; q < cg; ++q) { s1 += sh[q * 2]; s2 += sh[q * 2 + 1]; }
+      for (int q = 0; q < cg; ++q) {
+        s1 += (double)gamma[g * cg + q] * tot[(t * cg + q) * 2 + 1];
+        s2 += (double)gamma[g * cg + q] * tot[(t * cg + q) * 2];
+      }
+      const long unit = (long)(n0 + t) * G + g;
       c1[unit] = (float)(s1 / L);
       c2[unit] = (float)(s2 / L);
     }
+    if (t < cg) {                    // samples in fixed order
+      for (int q = 0; q < Np && n0 + q < N; ++q) { ga += tot[(q * cg + t) * 2]; gb += tot[(q * cg + t) * 2 + 1]; }
+    }
   }
-  if (sl == 0) {
-    const int idx = g * cg + j;
+  if (t < cg) {
+    const int idx = g * cg + t;
     dgamma[idx] = accum ? dgamma[idx] + (float)ga : (float)ga;
     dbeta[idx] = accum ? dbeta[idx] + (float)gb : (float)gb;
   }
