@@ -15,6 +15,10 @@
 //     voxels of a fragment row read consecutive slots for every x tap; piece p of slot s sits at p ^ ((s >> 2) & 3) -- 16 consecutive
 //     slots x one piece cover all 64 banks once;
 //   * wave = (fragment of 16 x 2 outputs, k-step): 27 matrix instructions each, the two k-steps of a fragment summed through LDS.
+// Where it stands: 8 x 128^3 from a 64-channel slab in 0.49 ms.  The tile loads move 1.45x the input (halo) in half-used 128-byte lines:
+// 3.1 GB = 6.3 TB/s of line traffic -- the HBM roofline of this layout (a dense 32-channel input: 0.37 ms).  A second register set that
+// puts the loads two tiles ahead changed nothing (tried: 254 VGPRs, same time).  What would: an XCD-aware tile order, so that the
+// neighbouring tiles an XCD works on together find each other's halo rows in its L2.
 // Declines everything else (the caller keeps the gather kernels): Cin != 32, Cout > 32 or not a multiple of 4, odd input extents.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
