@@ -17,8 +17,8 @@
 //   * wave = (fragment of 16 x 2 outputs, k-step): 27 matrix instructions each, the two k-steps of a fragment summed through LDS.
 // Where it stands: 8 x 128^3 from a 64-channel slab in 0.49 ms.  The tile loads move 1.45x the input (halo) in half-used 128-byte lines:
 // 3.1 GB = 6.3 TB/s of line traffic -- the HBM roofline of this layout (a dense 32-channel input: 0.37 ms).  A second register set that
-// puts the loads two tiles ahead changed nothing (tried: 254 VGPRs, same time).  What would: an XCD-aware tile order, so that the
-// neighbouring tiles an XCD works on together find each other's halo rows in its L2.
+// puts the loads two tiles ahead changed nothing (tried: 254 VGPRs, same time), and neither did an XCD-aware tile order (each XCD a
+// contiguous eighth of the tile list, so that neighbouring tiles meet in one L2: 0.52 ms, 5 % slower).
 // Declines everything else (the caller keeps the gather kernels): Cin != 32, Cout > 32 or not a multiple of 4, odd input extents.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
