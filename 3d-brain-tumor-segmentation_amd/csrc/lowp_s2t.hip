@@ -15,10 +15,14 @@
 //     voxels of a fragment row read consecutive slots for every x tap; piece p of slot s sits at p ^ ((s >> 2) & 3) -- 16 consecutive
 //     slots x one piece cover all 64 banks once;
 //   * wave = (fragment of 16 x 2 outputs, k-step): 27 matrix instructions each, the two k-steps of a fragment summed through LDS.
-// Where it stands: 8 x 128^3 from a 64-channel slab in 0.49 ms.  The tile loads move 1.45x the input (halo) in half-used 128-byte lines:
-// 3.1 GB = 6.3 TB/s of line traffic -- the HBM roofline of this layout (a dense 32-channel input: 0.37 ms).  A second register set that
-// puts the loads two tiles ahead changed nothing (tried: 254 VGPRs, same time), and neither did an XCD-aware tile order (each XCD a
-// contiguous eighth of the tile list, so that neighbouring tiles meet in one L2: 0.52 ms, 5 % slower).
+// Where it stands: 8 x 128^3 from a 64-channel slab in 0.44 ms (0.30 from a dense 32-channel input), 160x192x160 in 0.14 ms -- 2.3x the
+// gather kernel.  Counters (profiles/r03_pmc_lp_s2t.txt): HBM reads 1.24 GB = 1.16x the input (the halo rows are L2 hits), so it is
+// NOT at the HBM roofline (2.8 TB/s); matrix pipe busy 0.10; 15 vector + 9 scalar instructions per matrix instruction before the
+// per-thread offsets / per-lane tap addresses / bias were hoisted out of the tile loop (0.50 -> 0.44 ms); LDS bank conflicts 40 % of the
+// LDS-active cycles (the swizzle below is conflict-free for 16 CONSECUTIVE lanes; ds_read_b128's lane groups are not consecutive) at 6 %
+// LDS utilisation.  Tried without effect: loads two tiles ahead (254 VGPRs, same time), an XCD-aware tile order (5 % slower).  What is
+// left is the serial chain per tile -- store, barrier, 27 dependent matrix instructions, barrier, reduce, barrier -- of one workgroup per
+// CU with nothing to overlap it with.
 // Declines everything else (the caller keeps the gather kernels): Cin != 32, Cout > 32 or not a multiple of 4, odd input extents.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -89,20 +93,52 @@ __global__ __launch_bounds__(512, 1) void lp_s2t_kernel(const LpS2tParams p) {
     n = (int)(t / p.ntz);
     ox0 = tx * S2T_TX; oy0 = ty * S2T_TY; oz0 = tz * S2T_TZ;
   };
+  // element offset of every piece relative to the tile's first input voxel (fixed per thread; < 2^31 inside one sample)
+  int goff[S2T_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < S2T_ROUNDS; ++r) {
+    const int vz = vzyx[r] & 0xff, vy = (vzyx[r] >> 8) & 0xff, vx = (vzyx[r] >> 16) & 0xff, gp = vzyx[r] >> 24;
+    goff[r] = ((vz * p.H + vy) * p.W + vx) * p.ldx + gp * 8;
+  }
   u32x4 pre[S2T_ROUNDS];
   auto prefetch = [&](long t) {
     int n, oz0, oy0, ox0;
     tile_origin(t, n, oz0, oy0, ox0);
-    const unsigned short* org = p.x + (long)n * p.D * p.H * p.W * (long)p.ldx;
+    const unsigned short* org = p.x + ((((long)n * p.D + 2 * oz0) * p.H + 2 * oy0) * p.W + 2 * ox0) * (long)p.ldx;
+    // (even extents: TF 'same' pads at the far end only.)  A tile whose 33x9x5 input box lies inside the volume -- all but the last
+    // tile of each axis -- needs no per-piece test: one add per load
+    const bool inside = 2 * oz0 + S2T_SZ <= p.D && 2 * oy0 + S2T_SY <= p.H && 2 * ox0 + S2T_SX <= p.W;      // (workgroup-uniform)
+    if (inside) {
 #pragma unroll
-    for (int r = 0; r < S2T_ROUNDS; ++r) {
-      const int vz = vzyx[r] & 0xff, vy = (vzyx[r] >> 8) & 0xff, vx = (vzyx[r] >> 16) & 0xff, gp = vzyx[r] >> 24;
-      const int iz = 2 * oz0 + vz, iy = 2 * oy0 + vy, ix = 2 * ox0 + vx;       // (even extents: TF 'same' pads at the far end only)
-      pre[r] = u32x4{0u, 0u, 0u, 0u};
-      if (ldst[r] >= 0 && iz < p.D && iy < p.H && ix < p.W)
-        pre[r] = *reinterpret_cast<const u32x4*>(org + (((long)iz * p.H + iy) * p.W + ix) * (long)p.ldx + gp * 8);
+      for (int r = 0; r < S2T_ROUNDS; ++r) {
+        pre[r] = u32x4{0u, 0u, 0u, 0u};
+        if (ldst[r] >= 0) pre[r] = *reinterpret_cast<const u32x4*>(org + goff[r]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < S2T_ROUNDS; ++r) {
+        const int vz = vzyx[r] & 0xff, vy = (vzyx[r] >> 8) & 0xff, vx = (vzyx[r] >> 16) & 0xff;
+        pre[r] = u32x4{0u, 0u, 0u, 0u};
+        if (ldst[r] >= 0 && 2 * oz0 + vz < p.D && 2 * oy0 + vy < p.H && 2 * ox0 + vx < p.W) pre[r] = *reinterpret_cast<const u32x4*>(org + goff[r]);
+      }
     }
   };
+  // operand addresses of the 27 taps and the bias: fixed per lane
+  int boff[27];
+#pragma unroll
+  for (int tap = 0; tap < 27; ++tap) {
+    const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+    const int slot = base_slot + (dz * S2T_SY + dy) * S2T_SX + (dx == 1 ? S2T_TX + 1 : (dx >> 1));
+    boff[tap] = slot * 64 + ((piece ^ ((slot >> 2) & 3)) * 16);
+  }
+  f32x16 acc0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int co = 8 * q + 4 * h + j;
+      acc0[4 * q + j] = (ks == 0 && p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+    }
   long t = blockIdx.x;
   if (t >= p.ntiles) return;
   prefetch(t);
@@ -114,19 +150,10 @@ __global__ __launch_bounds__(512, 1) void lp_s2t_kernel(const LpS2tParams p) {
     __syncthreads();
     const long tn = t + gridDim.x;
     if (tn < p.ntiles) prefetch(tn);       // in flight while this tile multiplies
-    f32x16 acc;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int co = 8 * q + 4 * h + j;
-        acc[4 * q + j] = (ks == 0 && p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
-      }
+    f32x16 acc = acc0;
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
-      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-      const int slot = base_slot + (dz * S2T_SY + dy) * S2T_SX + (dx == 1 ? S2T_TX + 1 : (dx >> 1));
-      const u32x4 b = *reinterpret_cast<const u32x4*>(lds + slot * 64 + ((piece ^ ((slot >> 2) & 3)) * 16));
+      const u32x4 b = *reinterpret_cast<const u32x4*>(lds + boff[tap]);
       const u32x4 a = *reinterpret_cast<const u32x4*>(wbase + tap * 2048);
       acc = T::mfma(a, b, acc);
     }
