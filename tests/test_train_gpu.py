@@ -160,3 +160,32 @@ def test_gradient_buckets_follow_the_backward_pass():
         assert [b for b, _, _ in log] == sorted(b for b, _, _ in log)             # front to back: the order the backward pass finishes them
     finally:
         dist.destroy_process_group()
+
+
+def test_step_fence_bounds_the_run_ahead(monkeypatch):
+    """ops.step_fence: however many steps the host enqueues without reading a value back, at most two are in flight (every step holds
+    its activations; unbounded run-ahead made the caching allocator grow inside timed regions) -- and the fence only
+    waits: the parameters after 6 fenced steps equal those after 6 unfenced ones bit for bit."""
+    import bts_amd  # noqa: F401
+    from bts_amd import ops
+    from bts_amd.util import train_step
+    data = _data(6, 500)
+    finals = []
+    for fenced in (True, False):
+        if fenced:
+            monkeypatch.delenv('BTS_STEP_FENCE', raising=False)
+        else:
+            monkeypatch.setenv('BTS_STEP_FENCE', '0')
+        ops._fence.clear()
+        m, opt, lf, df = _setup()
+        opt(epoch=0)
+        for x, y in data:
+            train_step(m, opt, lf, df, x, y)          # no synchronize, no .item() in between
+            q = ops._fence.get((torch.cuda.current_device(), 'train'), [])
+            assert len(q) <= 2
+            assert (len(q) > 0) == fenced
+            for ev in q[:-2]:
+                assert ev.query()
+        torch.cuda.synchronize()
+        finals.append(m.flat_params.clone())
+    assert torch.equal(finals[0], finals[1])
