@@ -1140,12 +1140,39 @@ __global__ __launch_bounds__(256) void lp_cast_kernel(const float* src, long lds
     dst[r * ldd + c] = T::st(src[r * lds_ + c]);
   }
 }
+// rows of a few channels (the 2-channel volume into its 16-channel matrix step, the 1- and 2-channel VAE tensors): a thread per row --
+// the element form spends a 64-bit division per 2 bytes
+template <typename T, int C>
+__global__ __launch_bounds__(256) void lp_cast_rows_kernel(const float* __restrict__ src, long lds_, unsigned short* __restrict__ dst, long ldd, long rows) {
+  for (long r = blockIdx.x * 256L + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+    float v[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c] = src[r * lds_ + c];
+    if constexpr (C % 2 == 0) {
+#pragma unroll
+      for (int c = 0; c < C; c += 2) *reinterpret_cast<unsigned*>(dst + r * ldd + c) = pack2<T>(v[c], v[c + 1]);      // (ldd and the view's first channel even)
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; ++c) dst[r * ldd + c] = T::st(v[c]);
+    }
+  }
+}
 extern "C" int bts_lp_cast(int dtype, const float* src, long ld_src, void* dst, long ld_dst, long rows, int C, hipStream_t stream) {
   if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
   if (rows <= 0 || C <= 0) return BTS_ERR_SHAPE;
+  (void)hipGetLastError();
+  if (C <= 4 && (C % 2 != 0 || (ld_dst % 2 == 0 && (((uintptr_t)dst) & 3) == 0))) {
+    long rb = (rows + 255) / 256;
+    if (rb > 65536) rb = 65536;
+#define LP_CR(T_, C_) hipLaunchKernelGGL((lp_cast_rows_kernel<T_, C_>), dim3((unsigned)rb), dim3(256), 0, stream, src, ld_src, (unsigned short*)dst, ld_dst, rows)
+    if (dtype == LP_F16) { if (C == 1) LP_CR(TF16, 1); else if (C == 2) LP_CR(TF16, 2); else if (C == 3) LP_CR(TF16, 3); else LP_CR(TF16, 4); }
+    else { if (C == 1) LP_CR(TBF16, 1); else if (C == 2) LP_CR(TBF16, 2); else if (C == 3) LP_CR(TBF16, 3); else LP_CR(TBF16, 4); }
+#undef LP_CR
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+  }
   long blocks = (rows * C + 255) / 256;
   if (blocks > 65536) blocks = 65536;
-  (void)hipGetLastError();
   if (dtype == LP_F16) hipLaunchKernelGGL(lp_cast_kernel<TF16>, dim3((unsigned)blocks), dim3(256), 0, stream, src, ld_src, (unsigned short*)dst, ld_dst, rows, C);
   else hipLaunchKernelGGL(lp_cast_kernel<TBF16>, dim3((unsigned)blocks), dim3(256), 0, stream, src, ld_src, (unsigned short*)dst, ld_dst, rows, C);
   BTS_LAUNCH_CHECK();

@@ -652,3 +652,24 @@ def test_fused_gate_and_groupnorm2_backward(shape, dtype):
     assert float((dres.float() - dres_r.float()).abs().max()) <= U[dtype] * scale * 1.01
     for a, b in zip(got, ref):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-5
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('c', [1, 2, 3, 4, 5, 16])
+def test_cast_into_a_padded_view(c, dtype):
+    """bts_lp_cast: fp32 rows of c channels -> the storage type inside rows of 16 (how the 2-channel volume becomes one matrix step);
+    round-to-nearest-even like torch's own conversion, the pad columns untouched"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp
+    code, tdt = lowp.DTYPES[dtype]
+    g = torch.Generator().manual_seed(c)
+    x = (torch.randn((2, 5, 7, 9, c), generator=g) * 3).cuda()
+    for first in (0, 2, 3):
+        if first + c > 24:
+            continue
+        buf = torch.full((2, 5, 7, 9, 24), 7.0, dtype=tdt, device=x.device)
+        out = buf[..., first:first + c]
+        lowp.cast(code, tdt, x, out=out)
+        torch.cuda.synchronize()
+        assert torch.equal(out, x.to(tdt))
+        assert bool((buf[..., :first] == 7.0).all()) and bool((buf[..., first + c:] == 7.0).all())
