@@ -1790,12 +1790,12 @@ __global__ __launch_bounds__(256) void lp_head_oct_kernel(const unsigned short* 
     for (int k = 0; k < K; ++k) wr[e][k] = w[(o * 8 + e) * K + k];
   const long total = nvox * C8;
   const long stride = (long)gridDim.x * 256;
-  for (long i0 = blockIdx.x * 256L; i0 < total; i0 += stride) {      // (whole waves stay in the loop: the shuffles need every lane)
-    const long i = i0 + threadIdx.x;
-    const bool live = i < total;
-    const long v = live ? i / C8 : 0;
+  // (the host launches this kernel with 256 % C8 == 0: a thread's voxel advances by whole steps, no division per 16 bytes)
+  const long vpb = 256 / C8, vstride = (long)gridDim.x * vpb;
+  long v = blockIdx.x * vpb + threadIdx.x / C8;
+  auto one = [&](const u32x4 raw, long vv, bool live) {
     float t[8], acc[K];
-    unpack8<T>(live ? *reinterpret_cast<const u32x4*>(x + v * ldx + o * 8) : u32x4{0u, 0u, 0u, 0u}, t);
+    unpack8<T>(raw, t);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       float s = 0.f;
@@ -1809,9 +1809,22 @@ __global__ __launch_bounds__(256) void lp_head_oct_kernel(const unsigned short* 
       for (int k = 0; k < K; ++k) {
         float r = acc[k] + (bias ? bias[k] : 0.f);
         if (sigmoid) r = 1.f / (1.f + __expf(-r));
-        y[v * K + k] = r;
+        y[vv * K + k] = r;
       }
     }
+  };
+  // (whole waves stay in the loop: the shuffles need every lane.)  Four steps per trip, their loads issued first.
+  for (long i0 = blockIdx.x * 256L; i0 < total; i0 += 4 * stride, v += 4 * vstride) {
+    u32x4 raw[4];
+    bool live[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long vv = v + j * vstride;
+      live[j] = vv < nvox;
+      raw[j] = live[j] ? *reinterpret_cast<const u32x4*>(x + vv * ldx + o * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) one(raw[j], v + j * vstride, live[j]);
   }
 }
 extern "C" int bts_lp_head(int dtype, const void* x, const float* w, const float* bias, float* y, long nvox, int C, int ldx, int K, int sigmoid,
@@ -1824,8 +1837,9 @@ extern "C" int bts_lp_head(int dtype, const void* x, const float* w, const float
   (void)hipGetLastError();
   const int C8 = C / 8;
   if (C8 >= 2 && C8 <= 32 && (C8 & (C8 - 1)) == 0 && nvox >= 4096) {
-    long ob = (nvox * C8 + 255) / 256;
-    if (ob > 16384) ob = 16384;
+    long ob = ((nvox * C8 + 255) / 256 + 3) / 4;      // (four steps per trip of the kernel's loop)
+    if (ob > 32768) ob = 32768;
+    if (ob < 1) ob = 1;
 #define LP_HO(TT, K_) hipLaunchKernelGGL((lp_head_oct_kernel<TT, K_>), dim3((unsigned)ob), dim3(256), 0, stream, (const unsigned short*)x, w, bias, y, nvox, C8, ldx, sigmoid)
 #define LP_HO_K(TT) do { if (K == 1) LP_HO(TT, 1); else if (K == 2) LP_HO(TT, 2); else if (K == 3) LP_HO(TT, 3); else LP_HO(TT, 4); } while (0)
     if (dtype == LP_F16) LP_HO_K(TF16); else LP_HO_K(TBF16);
