@@ -43,7 +43,8 @@ def pmc_traffic(symbol):
     coalesced reads at 64 bytes, so it is doubled; WRITE_SIZE is taken as is.  The raw counter values and the file they
     come from are reported next to the corrected figure -- it belongs to that capture, not to this run."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), key=os.path.getmtime)
+    # newest = last by NAME (r01_ < r01c < ... < r03g): modification times mean nothing after a fresh checkout
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), key=os.path.basename)
     if not files:
         return None
     tab = json.load(open(files[-1]))
