@@ -359,14 +359,18 @@ def measure_train(args, world, rank, dev, overrides, dtype=None, batch=None, ste
     if parallel.active():
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]      # per-step GPU time (an event record each: no wait)
     t0 = time.perf_counter()
-    for _ in range(steps):
+    marks[0].record()
+    for k_ in range(steps):
         loss, macro, micro = train_step(model, opt, loss_fn, dice_fn, x, y)
+        marks[k_ + 1].record()
     torch.cuda.synchronize()
     if parallel.active():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[k_].elapsed_time(marks[k_ + 1]) for k_ in range(steps))
     if os.environ.get('BTS_BENCH_MEMSTATS'):       # allocator state of the timed region, to stderr (diagnostics; not part of the line)
         ms_ = torch.cuda.memory_stats()
         print('memstats: reserved peak %.1f GB, allocated peak %.1f GB, hipMalloc retries %d, segments %d' %
@@ -414,6 +418,8 @@ def measure_train(args, world, rank, dev, overrides, dtype=None, batch=None, ste
         'metric': 'training volumes/sec (2ch x %d^3)' % args.crop, 'value': volumes / dt, 'unit': 'volumes/s',
         'n_gpus': n_gpus, 'ranks_seen': ranks_seen, 'steps': steps, 'warmup': warmup,
         'ms_per_step': 1e3 * dt / steps,
+        # (diagnostic: the median and the slowest single step by events on the main stream -- `value` stays total work / total time)
+        'ms_per_step_median': per_step[len(per_step) // 2], 'ms_per_step_max': per_step[-1],
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': tdt, 'data': 'synthetic',
         'config': {'workload': ('BASELINE configs[1]: 2ch x %d^3, batch %d per GPU, fp32, full fwd+bwd with '
                                 'Dice+KL+L2 VAE loss + Dice metric + TF-form Adam; CLI-default model '
