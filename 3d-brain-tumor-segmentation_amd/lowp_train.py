@@ -28,6 +28,25 @@ from .lowp import DTYPES, block_epilogue, cast, colsum, conv, conv1_gap, conv_bw
 from .tape import Tensor, bump_weights_epoch, weights_epoch
 
 
+def _wgrad16(kind, code, x, dy, dw, *a, **kw):
+    """lowp.conv_bwd_weight where the caller has already checked the shape: a declined launch would leave `dw` unwritten (scratch
+    tensors are uninitialised memory), so it is an error here, never a silent skip"""
+    cout = dw.shape[-2] if kind == ops.K3S2T else dw.shape[-1]           # (Conv3DTranspose kernels are (kd, kh, kw, Cout, Cin))
+    if dy.shape[-1] != cout or not lowp.conv_bwd_weight(kind, code, x, dy, dw, *a, **kw):
+        raise RuntimeError('16-bit weight gradient declined: kind %d, x %s, dy %s, dw %s' % (kind, tuple(x.shape), tuple(dy.shape), tuple(dw.shape)))
+
+
+class _Progress(object):
+    """what parallel.GradSync asks of a tape: a generation, the number of backward stages and how many of them have run"""
+
+    def __init__(self, sync, stages):
+        from .tape import _generation_of_last_tape
+        self.sync = sync
+        self.gen = _generation_of_last_tape()
+        self.nodes = [None] * stages
+        self.nodes_replayed = 0
+
+
 class LowPrecisionTrainer(object):
     def __init__(self, model, dtype='bfloat16'):
         self.fwd = lowp.LowPrecisionForward(model, dtype)      # checks samplers / layout, owns the forward weight images
@@ -40,6 +59,7 @@ class LowPrecisionTrainer(object):
         # BTS_LP_FUSE_BLOCK_BWD=0: the two separate routes
         self.fuse_block_bwd = os.environ.get('BTS_LP_FUSE_BLOCK_BWD', '1') != '0'
         self.last_labels = None
+        self._clock = None
 
     # ---- weight images ----
     def _pk(self, key, kind, param, cin_ref, cout, cin_slab=None, dup_start=0, dup_shift=0, role=ops.ROLE_FWD):
@@ -119,6 +139,22 @@ class LowPrecisionTrainer(object):
         for t in tensors:
             t.record_stream(side)
 
+    def _written(self, params):
+        """one backward stage finished writing these parameters' gradients (the weight-gradient launches may still sit on the side
+        stream: GradSync orders a bucket behind that stream's events, not behind the stream).  Data parallel: a bucket of the flat
+        gradient buffer whose last member this was gets the regulariser term and is all-reduced while the backward goes on"""
+        clock = self._clock
+        if clock is None:
+            return
+        clock.nodes_replayed += 1
+        clock.sync.params_written(params)
+
+    @staticmethod
+    def _backward_stages(n_vae, n_dec, blocks_per_level):
+        """stages of the explicit backward that report parameters: vae.out, (block, up) per VAE level, vae.upsample, the dense pair,
+        vae.downsample; decoder.out, (block, up) per decoder level; every encoder block and down-sampler"""
+        return 1 + 2 * n_vae + 3 + 1 + 2 * n_dec + sum(blocks_per_level) + len(blocks_per_level) - 1
+
     @staticmethod
     def _gslot(p):
         """fp32 gradient view of a parameter inside the model's flat gradient buffer (zeroed at the start of the step)"""
@@ -163,11 +199,13 @@ class LowPrecisionTrainer(object):
         key = id(blk)
         x = s['x']
         cin_slab = s['cin_slab']
-        lp2 = lowp.wgrad_supported(ops.K3S1, f, f)                       # conv2's weight gradient on the 16-bit kernel?
+        # conv2's weight gradient on the 16-bit kernel?  (f % 16: the GroupNorm backward hands dc over zero-padded to whole matrix steps
+        # of 16 channels; with 8 filters the padded gradient is wider than the kernel's slot -- those blocks stay on the fp32 kernels)
+        lp2 = f % 16 == 0 and lowp.wgrad_supported(ops.K3S1, f, f)
         # conv1 / shortcut weight gradients on the 16-bit kernel; the first block reads the 2-channel volume zero-padded to one matrix
         # step: its gradients are taken over all 16 stored channels into a scratch tensor and the live rows added to the real slots
         pad_in = cin_slab < x.shape[-1]
-        lp1 = lowp.wgrad_supported(ops.K3S1, x.shape[-1], f)
+        lp1 = f % 16 == 0 and lowp.wgrad_supported(ops.K3S1, x.shape[-1], f)
         # conv branch: GN2 (+ReLU) -> conv2 -> GN1 (+ReLU) -> conv1
         # gate backward and GroupNorm-2 backward both read dout: one pair of passes where the fused kernels' tiling fits
         fused = None
@@ -185,7 +223,7 @@ class LowPrecisionTrainer(object):
         if lp2:
             a16 = s['a']
             db2 = None if self._db_done else self._gslot(blk.conv2_b)
-            self._wg((a16, dc2_16), lambda: lowp.conv_bwd_weight(ops.K3S1, code, a16, dc2_16, self._gslot(blk.conv2_k), db2, accumulate=True))
+            self._wg((a16, dc2_16), lambda: _wgrad16(ops.K3S1, code, a16, dc2_16, self._gslot(blk.conv2_k), db2, accumulate=True))
         else:
             a32 = self._f32(s['a'])
             self._wg((a32, dc2), lambda: ops.conv_bwd_weight(ops.K3S1, a32, dc2, self._gslot(blk.conv2_k), self._gslot(blk.conv2_b),
@@ -209,15 +247,15 @@ class LowPrecisionTrainer(object):
             def wgrads():
                 tk = torch.empty((3, 3, 3, x.shape[-1], f), dtype=torch.float32, device=x.device)
                 tp = torch.empty((1, 1, 1, x.shape[-1], f), dtype=torch.float32, device=x.device)
-                lowp.conv_bwd_weight(ops.K3S1, code, x, dc1_16, tk, db1, 0, 0, False)
-                lowp.conv_bwd_weight(ops.K1, code, x, dres_16, tp, None, 0, 0, False)
+                _wgrad16(ops.K3S1, code, x, dc1_16, tk, db1, 0, 0, False)
+                _wgrad16(ops.K1, code, x, dres_16, tp, None, 0, 0, False)
                 self._gslot(blk.conv1_k).add_(tk[:, :, :, :cin_slab, :])
                 self._gslot(blk.ptwise_k).add_(tp[:, :, :, :cin_slab, :])
             self._wg((x, dc1_16, dres_16), wgrads)
         elif lp1:
             def wgrads():
-                lowp.conv_bwd_weight(ops.K3S1, code, x, dc1_16, self._gslot(blk.conv1_k), db1, dup_start, dup_shift, True)
-                lowp.conv_bwd_weight(ops.K1, code, x, dres_16, self._gslot(blk.ptwise_k), None, dup_start, dup_shift, True)   # (bias: se_bwd)
+                _wgrad16(ops.K3S1, code, x, dc1_16, self._gslot(blk.conv1_k), db1, dup_start, dup_shift, True)
+                _wgrad16(ops.K1, code, x, dres_16, self._gslot(blk.ptwise_k), None, dup_start, dup_shift, True)   # (bias: se_bwd)
             self._wg((x, dc1_16, dres_16), wgrads)
         else:   # fp32 kernels on the widened input view
             x32 = self._f32(x[..., :cin_slab])
@@ -232,6 +270,7 @@ class LowPrecisionTrainer(object):
             wpbp = self._pk((key, 'ptb'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin, dup_start, dup_shift, role=ops.ROLE_BWD)
             conv_bwd_data(ops.K3S1, code, dc1_16, wpb1, dx, not first)
             conv_bwd_data(ops.K1, code, dres_16, wpbp, dx, True)
+        self._written(blk.trainable_variables)
 
     def _sampler_fwd(self, lay, kind, x, out=None):
         if isinstance(lay, self.fwd._max):                   # MaxPooling3D(2) (downsample.py:51-70): no parameters, channels kept
@@ -255,9 +294,10 @@ class LowPrecisionTrainer(object):
         if kind == 'max':
             if dx is not None:
                 lowp.maxpool2_bwd(self.code, dy, s['idx'], dx, accumulate)
-            return
+            return self._written([])
         if kind == 'linear':
-            return self._linear_bwd(s, dy, dx, accumulate, cin_live)
+            self._linear_bwd(s, dy, dx, accumulate, cin_live)
+            return self._written(lay.trainable_variables)
         nrm = lay.norm
         x = s['x'] if cin_live is None else s['x'][..., :cin_live]
         cout = s['c'].shape[-1]
@@ -267,7 +307,7 @@ class LowPrecisionTrainer(object):
         if lp16 and dc16.is_contiguous():
             # 16-bit operands straight into the transposing-read weight-gradient kernel (no widened copies)
             dbs = None if self._db_done else self._gslot(lay.conv_b)
-            self._wg((x, dc16), lambda: lowp.conv_bwd_weight(kind, self.code, x, dc16, self._gslot(lay.conv_k), dbs, accumulate=True))
+            self._wg((x, dc16), lambda: _wgrad16(kind, self.code, x, dc16, self._gslot(lay.conv_k), dbs, accumulate=True))
         else:
             x32 = self._f32(x)
             if dc is None:
@@ -283,6 +323,7 @@ class LowPrecisionTrainer(object):
         if dx is not None:
             wpb = self._pk((id(lay), 'b'), kind, lay.conv_k, lay.cin, lay.filters, role=ops.ROLE_BWD)
             conv_bwd_data(kind, self.code, dc16, wpb, dx, accumulate)
+        self._written(lay.trainable_variables)
 
     def _linear_bwd(self, s, dy, dx, accumulate, cin_live):
         """LinearUpsample backward (upsample.py:49-79 under autodiff): the repeat's gradient (sums of 8 fine voxels, fp32 sums),
@@ -295,7 +336,7 @@ class LowPrecisionTrainer(object):
         buf = (torch.zeros if fp != f else torch.empty)((n, d2 // 2, h2 // 2, w2 // 2, fp), dtype=self.tdt, device=dy.device)
         dc16 = lowp.upsample2_bwd(self.code, dy, dx=buf[..., :f])
         if cin_live is None and fp == f and lowp.wgrad_supported(ops.K1, x.shape[-1], f):
-            self._wg((x, dc16), lambda: lowp.conv_bwd_weight(ops.K1, self.code, x, dc16, self._gslot(lay.ptwise_k), self._gslot(lay.ptwise_b),
+            self._wg((x, dc16), lambda: _wgrad16(ops.K1, self.code, x, dc16, self._gslot(lay.ptwise_k), self._gslot(lay.ptwise_b),
                                                              accumulate=True))
         else:
             x32, dc = self._f32(x), self._f32(dc16)
@@ -319,6 +360,7 @@ class LowPrecisionTrainer(object):
             y = torch.as_tensor(y)
         dev = torch.device('cuda', torch.cuda.current_device())
         fence = ops.step_fence('train')          # at most two steps in flight (see ops.step_fence)
+        self._clock = None
         x, y = x.to(dev).float(), y.to(dev).float()
         cf = m.data_format == 'channels_first'
         if cf:          # raw NCDHW volumes -> the engine's NDHWC memory (tape.as_tensor does the same for the fp32 step)
@@ -430,34 +472,17 @@ class LowPrecisionTrainer(object):
         dproj = torch.empty_like(proj)
         ops.loss_bwd(y_pred, y, x, y_vae, proj, sums, one, dyp, dyv, dproj, through_sigmoid=False)
         # slab gradients: uninitialised -- the first writer of each one writes, every later contribution accumulates.  Levels below the
-        # top: the decoder block's conv1 data gradient (its view [0, cres + f) is the whole slab); the top level: the first
-        # up-sampler's data gradient (its view [0, top_used) is the whole slab, which has no spare channels)
+        # top: the decoder block's conv1 data gradient (its view [0, cres + f) is the whole slab); the top level: the VAE's
+        # down-sampling conv's data gradient (its view [0, top_used) is the whole slab, which has no spare channels)
         gslabs = [torch.empty_like(slab) for slab, _, _, _ in levels]
         assert levels[-1][0].shape[-1] == top_used
-        # decoder head (decoder.py:55-63): sigmoid, 1x1x1 conv to out_ch -- dx, dW and db from one pass over the 16-bit activations
-        dpre = ops.sigmoid_bwd(y_pred, dyp)
-        wk2 = dec.out_k.t.reshape(dec.out_k.t.shape[-2], dec.out_k.t.shape[-1])
-        dcur = lowp.head_bwd(code, tdt, y_last, dpre, wk2, self._gslot(dec.out_k).reshape(wk2.shape), self._gslot(dec.out_b), True)
-        if dcur is None:       # head outside the fused kernel's shapes: fp32 kernels on widened copies
-            ylast32 = self._f32(y_last)
-            self._wg((ylast32, dpre), lambda: ops.conv_bwd_weight(ops.K1, ylast32, dpre, self._gslot(dec.out_k), self._gslot(dec.out_b),
-                                                                 accumulate=True))
-            dlast32 = torch.empty_like(ylast32)
-            wpb = dec.packed('out_b', ops.K1, ops.ROLE_BWD, dec.out_k, y_last.shape[-1], dec.out_ch)
-            ops.conv_bwd_data(ops.K1, dpre, wpb, dlast32, False)
-            dcur = self._b16(dlast32)
-            del dlast32, ylast32
-        del dpre
-        for idx in range(len(dsaves) - 1, -1, -1):
-            us, bs, li, cres, f = dsaves[idx]
-            gs = gslabs[li]
-            assert gs.shape[-1] == cres + f
-            self._block_bwd(bs, dcur, gs[..., :cres + f], first=True)        # skip part [0, cres) and the up-sampled part [cres, cres + f)
-            if idx == 0:                                         # the first up layer read the top level's slab view
-                self._sampler_bwd(us, gs[..., cres:cres + f], gslabs[-1][..., :top_used], False)
-            else:                                                # the others read the previous decoder block's output
-                dcur = torch.empty(us['x'].shape, dtype=tdt, device=dev)
-                self._sampler_bwd(us, gs[..., cres:cres + f], dcur, False)
+        # The backward walks vae -> decoder -> encoder level 3 .. 0: the order of the model's flat gradient buffer (model._backward_groups),
+        # so that with a process group finished buckets are all-reduced from inside the backward pass, as the fp32
+        # tape does (parallel.GradSync); the regulariser term goes into each bucket just before its exchange
+        sync = parallel.grad_sync(m)
+        if sync is not None:
+            self._clock = _Progress(sync, self._backward_stages(len(vsaves), len(dsaves), [len(lv[2]) for lv in levels]))
+            sync.begin(self._clock, l2_grad=one if l2v is not None else None, prefilled=True)
         # VAE branch backward.  Its output conv has out_ch = in_ch = 2 channels (vae.py:92-99): dy is stored zero-padded to one matrix step
         # (16 channels, like the input volume) so that the weight gradient (padded columns dropped afterwards) and the data gradient
         # (role-swapped image of the zero-padded kernel) run on the 16-bit kernels instead of the fp32 ones over widened copies
@@ -468,7 +493,7 @@ class LowPrecisionTrainer(object):
 
             def wg_out():
                 tk = torch.empty((3, 3, 3, cv, 16), dtype=torch.float32, device=dev)
-                lowp.conv_bwd_weight(ops.K3S1, code, yv_last, dyv16, tk, None, 0, 0, False)
+                _wgrad16(ops.K3S1, code, yv_last, dyv16, tk, None, 0, 0, False)
                 self._gslot(vae.out_k).add_(tk[..., :co])
                 self._gslot(vae.out_b).add_(dyv.sum(dim=(0, 1, 2, 3)))
             self._wg((yv_last, dyv16, dyv), wg_out)
@@ -487,6 +512,7 @@ class LowPrecisionTrainer(object):
             ops.conv_bwd_data(ops.K3S1, dyv, wpb, dv32, False)
             dv = self._b16(dv32)
             del dv32, ylv32
+        self._written([vae.out_k, vae.out_b])
         for us, bs in reversed(vsaves):
             dblk_in = torch.empty(bs['x'].shape, dtype=tdt, device=dev)
             self._block_bwd(bs, dv, dblk_in, first=True)
@@ -503,8 +529,34 @@ class LowPrecisionTrainer(object):
         dflat = torch.empty_like(flat)
         ops.dense_bwd(flat, vae.proj_k.t, dproj, dflat, self._gslot(vae.proj_k), self._gslot(vae.proj_b), accumulate_dx=False,
                       accumulate_params=True)
+        self._written([vae.unproj_k, vae.unproj_b, vae.proj_k, vae.proj_b])
         dhdn = self._b16(dflat.reshape(hdn.shape))
-        self._sampler_bwd(vds, dhdn, gslabs[-1][..., :top_used], True)
+        self._sampler_bwd(vds, dhdn, gslabs[-1][..., :top_used], False)           # first writer of the top level's slab gradient
+        # decoder head (decoder.py:55-63): sigmoid, 1x1x1 conv to out_ch -- dx, dW and db from one pass over the 16-bit activations
+        dpre = ops.sigmoid_bwd(y_pred, dyp)
+        wk2 = dec.out_k.t.reshape(dec.out_k.t.shape[-2], dec.out_k.t.shape[-1])
+        dcur = lowp.head_bwd(code, tdt, y_last, dpre, wk2, self._gslot(dec.out_k).reshape(wk2.shape), self._gslot(dec.out_b), True)
+        if dcur is None:       # head outside the fused kernel's shapes: fp32 kernels on widened copies
+            ylast32 = self._f32(y_last)
+            self._wg((ylast32, dpre), lambda: ops.conv_bwd_weight(ops.K1, ylast32, dpre, self._gslot(dec.out_k), self._gslot(dec.out_b),
+                                                                 accumulate=True))
+            dlast32 = torch.empty_like(ylast32)
+            wpb = dec.packed('out_b', ops.K1, ops.ROLE_BWD, dec.out_k, y_last.shape[-1], dec.out_ch)
+            ops.conv_bwd_data(ops.K1, dpre, wpb, dlast32, False)
+            dcur = self._b16(dlast32)
+            del dlast32, ylast32
+        del dpre
+        self._written([dec.out_k, dec.out_b])
+        for idx in range(len(dsaves) - 1, -1, -1):
+            us, bs, li, cres, f = dsaves[idx]
+            gs = gslabs[li]
+            assert gs.shape[-1] == cres + f
+            self._block_bwd(bs, dcur, gs[..., :cres + f], first=True)        # skip part [0, cres) and the up-sampled part [cres, cres + f)
+            if idx == 0:                                         # the first up layer read the top level's slab view
+                self._sampler_bwd(us, gs[..., cres:cres + f], gslabs[-1][..., :top_used], True)
+            else:                                                # the others read the previous decoder block's output
+                dcur = torch.empty(us['x'].shape, dtype=tdt, device=dev)
+                self._sampler_bwd(us, gs[..., cres:cres + f], dcur, False)
         # encoder backward (encoder.py:69-101 in reverse)
         for i in range(len(levels) - 1, -1, -1):
             slab, used, saves, dsave = levels[i]
@@ -523,10 +575,15 @@ class LowPrecisionTrainer(object):
                     self._block_bwd(saves[0], dout, None)
         # regulariser (train.py:146), exchange, optimiser (train.py:151-152)
         ops.join_side_stream()
-        if l2v is not None:
-            k = parallel.l2_grad_scale()
-            ops.l2_reg_bwd(m.flat_params, m.flat_grads, [(o, ln, cf * k) for o, ln, cf in m._l2_ranges], one)
-        scale = parallel.all_reduce_gradients(m)
+        if sync is not None:
+            self._clock = None
+            sync.finish()              # parameters no stage reported (none in this graph) and pad-only buckets; waits for the handles
+            scale = 1.0
+        else:
+            if l2v is not None:
+                k = parallel.l2_grad_scale()
+                ops.l2_reg_bwd(m.flat_params, m.flat_grads, [(o, ln, cf * k) for o, ln, cf in m._l2_ranges], one)
+            scale = parallel.all_reduce_gradients(m)
         grads = [p._gview for p in m.trainable_variables]
         optimizer.apply_gradients(zip(grads, m.trainable_variables), model=m, grad_scale=scale)
         ops.step_fence_done(fence)

@@ -204,8 +204,13 @@ class GradSync(object):
             cuts.append((start, n - start))
         return cuts
 
-    def begin(self, tape):
+    def begin(self, tape, l2_grad=None, prefilled=False):
+        """tape: anything with .gen, .nodes and .nodes_replayed (tape.GradientTape; the explicit 16-bit step of lowp_train passes its own
+        progress record).  l2_grad: the regulariser's upstream gradient (1-element tensor) when the caller, not the tape's L2 node, owns
+        it.  prefilled: the flat gradient buffer was zeroed before the backward, parameters no node wrote need no fill"""
         self.tape = tape
+        self.l2_grad = l2_grad
+        self.prefilled = prefilled
         self.launch_log = []
         self.nodes_total = len(tape.nodes)
         self.done = set()
@@ -239,8 +244,11 @@ class GradSync(object):
         ops.wait_side_stream_event('wgrad')
         off, ln, _ = self.buckets[bi]
         m = self.model
-        fresh = getattr(m, '_l2_val', None) is not None and getattr(m, '_l2_val_gen', None) == self.tape.gen
-        g = m._l2_val.grad if fresh else None   # (no regulariser term was added to this step's loss otherwise)
+        if self.l2_grad is not None:
+            g = self.l2_grad
+        else:
+            fresh = getattr(m, '_l2_val', None) is not None and getattr(m, '_l2_val_gen', None) == self.tape.gen
+            g = m._l2_val.grad if fresh else None   # (no regulariser term was added to this step's loss otherwise)
         if g is not None and m._l2_ranges:
             k = l2_grad_scale()
             rg = []
@@ -260,7 +268,7 @@ class GradSync(object):
         gen = self.tape.gen
         for pid, p_ in self.params.items():
             if pid not in self.done:
-                if p_._gen != gen:              # never written this step: its gradient is exactly the regulariser's
+                if not self.prefilled and p_._gen != gen:   # never written this step: its gradient is exactly the regulariser's
                     ops.fill(p_._gview, 0.0)
                     p_._gen = gen
                 self.done.discard(pid)

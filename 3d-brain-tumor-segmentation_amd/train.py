@@ -174,8 +174,9 @@ def save_checkpoint(folder, model, optimizer=None, completed=False, tracker=None
 def load_checkpoint(folder, model, optimizer=None):
     """inverse of save_checkpoint; the model must be built (same architecture).  Returns the stored meta dict."""
     tensors, meta = read_container(os.path.join(folder, CHECKPOINT_NAME))
-    if meta.get('format') != FORMAT_VERSION:
-        raise ValueError('unknown checkpoint format %r' % (meta.get('format'),))
+    fmt = meta.get('format')
+    if fmt not in (1, FORMAT_VERSION):
+        raise ValueError('unknown checkpoint format %r' % (fmt,))
     missing = [p.name for p in model.trainable_variables if 'var/' + p.name not in tensors]
     if missing:
         raise KeyError('checkpoint lacks %d variables, e.g. %s' % (len(missing), missing[:3]))
@@ -208,7 +209,14 @@ def load_checkpoint(folder, model, optimizer=None):
         o = meta['optimizer']
         optimizer.iterations = int(o['iterations'])
         optimizer.learning_rate = float(o['learning_rate'])
-        if 'adam/m' in tensors:
+        if 'adam/m' in tensors and fmt != FORMAT_VERSION:
+            # format 1 stored the Adam moments in the flat order of that build (reference variable order); variables are keyed by name and
+            # load fine, the moments cannot be mapped without that order: they restart at zero (and the bias correction with them)
+            import warnings
+            warnings.warn('checkpoint format %r: weights, epoch and random state restored; Adam moments dropped (flat order changed in '
+                          'format %d)' % (fmt, FORMAT_VERSION))
+            optimizer.iterations = 0
+        elif 'adam/m' in tensors:
             dev = model.flat_params.device
             optimizer._state[id(model.flat_params)] = (tensors['adam/m'].to(dev).contiguous(),
                                                        tensors['adam/v'].to(dev).contiguous())
@@ -245,7 +253,8 @@ def fit(model, optimizer, loss_fn, dice_fn, train_data, val_data, n_epochs, pati
 
     train_data / val_data: re-iterable collections of (x, y) batches (NDHWC tensors on the device).
     Resumes at `model.epoch` (train.py:133).  Returns the list of per-epoch rows (dicts).  On data-parallel runs every
-    rank iterates its own shard; rank 0 alone writes files."""
+    rank must call fit() (with the same n_epochs / patience; equally long shards) and iterates its own shard; rank 0 alone writes
+    files, and rank 0's validation Dice drives the save / stop decision of all ranks."""
     tstep = train_step_fn or (lambda x, y: train_step(model, optimizer, loss_fn, dice_fn, x, y))
     estep = eval_step_fn or (lambda x, y: eval_step(model, loss_fn, dice_fn, x, y))
     writer = save_folder is not None and parallel.rank() == 0
@@ -290,9 +299,17 @@ def fit(model, optimizer, loss_fn, dice_fn, train_data, val_data, n_epochs, pati
         if writer:
             with open(os.path.join(save_folder, 'train.log'), 'a') as f:
                 f.write(log_row(epoch, row['lr'], *[row[k] for k in names]) + '\n')
-        action = tracker.update(float(row['val_macro_dice']))
+        # The save / stop decision must be the same on every rank: save_checkpoint is a collective (it gathers the per-rank random
+        # state) and a rank that stops alone leaves the others in the next gradient exchange.  The built-in DiceCoefficient all-reduces
+        # its sums, a custom eval_step_fn / metric need not -- so rank 0's validation Dice decides for all, and whether files are
+        # wanted is agreed on as well (a save_folder on rank 0 only is fine)
+        val_dice, want_files = float(row['val_macro_dice']), save_folder is not None
+        if parallel.active():
+            got = parallel.gather_objects((val_dice, want_files))
+            val_dice, want_files = got[0][0], any(w for _, w in got)
+        action = tracker.update(val_dice)
         if action == 'save':
-            if save_folder is not None:          # every rank: the per-rank random state is gathered; rank 0 writes
+            if want_files:                       # every rank: the per-rank random state is gathered; rank 0 writes
                 save_checkpoint(save_folder, model, optimizer, completed=True, tracker=tracker,
                                 datasets={'train': train_data, 'val': val_data}, write=writer)
             log('Saved model weights.')

@@ -106,6 +106,19 @@ def test_overlapped_exchange_is_bitwise_the_plain_one(tmp_path):
     assert torch.equal(a[0]['params'], b[0]['params']) and torch.equal(a[1]['params'], b[1]['params'])
 
 
+def test_overlapped_exchange_of_the_16bit_step_is_bitwise_the_plain_one(tmp_path):
+    """lowp_train.LowPrecisionTrainer.step launches finished gradient buckets from inside its explicit backward (GradSync, as the fp32
+    tape does); BTS_DP_NO_OVERLAP=1 restores join -> regulariser -> one blocking exchange.  Same kernels on the same values: bitwise"""
+    d = str(tmp_path)
+    env = {'BTS_DP_TRAINER': 'bfloat16'}
+    a = _run(2, d, 'ovl16', env)
+    b = _run(2, d, 'plain16', dict(env, BTS_DP_NO_OVERLAP='1'))
+    assert a[0]['overlap'] and not b[0]['overlap']
+    assert a[0]['loss'] == b[0]['loss']
+    assert torch.equal(a[0]['grads'], b[0]['grads'])
+    assert torch.equal(a[0]['params'], b[0]['params']) and torch.equal(a[1]['params'], b[1]['params'])
+
+
 def test_bench_launcher_starts_the_ranks(tmp_path):
     """`python bench.py --gpus 2` with no WORLD_SIZE must START two ranks (here sharing the box's single GPU) and say so"""
     import json

@@ -153,15 +153,18 @@ def test_fp32_train_step_stays_inside_its_buffers(guard, monkeypatch, kw, shape,
     assert n > 200, n          # (the step allocated: saved activations, gradients, scratch)
 
 
+@pytest.mark.parametrize('filters', [16, 8])
 @pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
-def test_16bit_forward_and_train_step_stay_inside_their_buffers(guard, dtype):
+def test_16bit_forward_and_train_step_stay_inside_their_buffers(guard, dtype, filters):
+    """filters = 8: blocks whose GroupNorm gradients come back zero-padded to a 16-channel matrix step -- their weight gradients must
+    stay on the fp32 kernels (the padded gradient is wider than the 16-bit kernel's slot; round-3 advisor finding)"""
     from bts_amd import lowp
     from bts_amd.data import synthetic_batch
     from bts_amd.lowp_train import LowPrecisionTrainer
     from bts_amd.util import DiceCoefficient, ScheduledOptim
-    kw, shape = dict(base_filters=16, groups=8, reduction=2, depth=3), (2, 32, 32, 48)
+    kw, shape = dict(base_filters=filters, groups=8 if filters == 16 else 4, reduction=2, depth=3), (2, 32, 32, 48)
     m = _fresh_model(kw, shape)
-    x, y, _, _ = synthetic_batch(shape[0], shape[1:], latent=32, seed=7)
+    x, y, _, _ = synthetic_batch(shape[0], shape[1:], latent=2 * filters, seed=7)
     yp = lowp.LowPrecisionForward(m, dtype)(x[:1, :24, :, :40].contiguous())          # ragged forward-only volume
     assert yp.dtype == torch.float32
     opt = ScheduledOptim(1e-4)
@@ -170,6 +173,8 @@ def test_16bit_forward_and_train_step_stay_inside_their_buffers(guard, dtype):
     for _ in range(2):
         loss, _, _ = tr.step(opt, DiceCoefficient(), x, y)
     assert float(loss) == float(loss)
+    g = m.flat_grads
+    assert bool(torch.isfinite(g).all()) and float(g.abs().max()) < 1e3, float(g.abs().max())     # (no uninitialised scratch added in)
     assert guard.check() > 200
 
 

@@ -128,3 +128,55 @@ def test_checkpoint_keeps_per_rank_random_state(tmp_path):
         assert p.exitcode == 0
     assert res[0][1] and res[1][1], res
     assert res[0][2] != res[1][2]                      # the ranks' counters differ, and each got its own back
+
+
+def _fit_worker(rank, world, port, folder, q):
+    """fit() with a metric that is NOT all-reduced (rank 1 sees a worse validation Dice) and a save_folder on rank 0 only: the
+    round-3 advisor's hang.  Both ranks must take rank 0's save / stop decisions and finish"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import bts_amd  # noqa: F401
+    from bts_amd import parallel, train as T
+    from bts_amd.model import Model
+    from bts_amd.util import ScheduledOptim
+    parallel.init_from_env('gloo')
+    m = Model(base_filters=8, reduction=2, depth=2, groups=2)
+    m.build((1, 8, 8, 8, 2))
+    opt = ScheduledOptim(1e-4)
+    dice = {0: [0.5, 0.4, 0.6, 0.3, 0.2, 0.1], 1: [0.1, 0.7, 0.2, 0.8, 0.9, 0.95]}[rank]     # rank 1 disagrees at every epoch
+    ep = [0]
+
+    def estep(x, y):
+        return 1.0, dice[ep[0]], dice[ep[0]]
+
+    def tstep(x, y):
+        torch.distributed.all_reduce(torch.zeros(1))       # stands for the gradient exchange: a rank that left would hang the other
+        return 1.0, 0.5, 0.5
+    msgs = []
+
+    def log(s):
+        msgs.append(s)
+        if s.startswith('Validation.'):
+            ep[0] += 1
+    hist = T.fit(m, opt, None, None, [(None, None)], [(None, None)], 6, patience=2, save_folder=folder if rank == 0 else None,
+                 train_step_fn=tstep, eval_step_fn=estep, log=log)
+    q.put((rank, len(hist), sum(1 for s in msgs if s.startswith('Saved')), any('Stopped' in s for s in msgs)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_fit_takes_rank_identical_save_and_stop_decisions(tmp_path):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_fit_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    # rank 0's curve 0.5 0.4 0.6 0.3 0.2 0.1 (patience 2): saves at epochs 0 and 2, stops at epoch 5 -- on BOTH ranks
+    assert res[0][1:] == res[1][1:], res
+    assert res[0][2] == 2 and res[0][3] and res[0][1] == 6, res
+    assert os.path.exists(os.path.join(str(tmp_path), 'checkpoint.safetensors')) or len(os.listdir(str(tmp_path))) > 0

@@ -162,6 +162,62 @@ def test_gradient_buckets_follow_the_backward_pass():
         dist.destroy_process_group()
 
 
+def test_gradient_buckets_follow_the_backward_pass_of_the_16bit_step():
+    """The same contract for lowp_train.LowPrecisionTrainer.step (BASELINE configs[3] runs configs[2]'s step on every GPU): its explicit
+    backward walks vae -> decoder -> encoder and reports each stage's parameters; on a 1-rank RCCL group at least 80 % of the gradient
+    bytes are in flight before the last 10 % of the stages, every bucket is exchanged once, front to back, and the gradient equals the
+    post-backward exchange's bit for bit."""
+    import bts_amd  # noqa: F401
+    from bts_amd import parallel
+    from bts_amd.data import synthetic_batch
+    from bts_amd.lowp_train import LowPrecisionTrainer
+    from bts_amd.model import Model
+    from bts_amd.util import DiceCoefficient, ScheduledOptim
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip('a process group already exists in this process')
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29643', rank=0, world_size=1)
+    try:
+        os.environ.pop('BTS_DP_NO_OVERLAP', None)
+        m = Model(base_filters=32, reduction=8, depth=4, groups=8)
+        crop = (32, 32, 32)
+        m.build((2,) + crop + (2,))
+        x, y, mask, eps = synthetic_batch(2, crop, latent=128, seed=5)
+        start = m.flat_params.clone()
+        tr = LowPrecisionTrainer(m, 'bfloat16')
+        grads = []
+        for plain in (False, True):
+            if plain:
+                os.environ['BTS_DP_NO_OVERLAP'] = '1'
+            m.flat_params.copy_(start)
+            from bts_amd.tape import bump_weights_epoch
+            bump_weights_epoch()
+            m.encoder.set_dropout_mask(mask)
+            m.vae.set_eps(eps)
+            opt = ScheduledOptim(1e-4)
+            opt(epoch=0)
+            tr.step(opt, DiceCoefficient(), x.cuda(), y.cuda())
+            torch.cuda.synchronize()
+            grads.append(m.flat_grads.clone())
+            if not plain:
+                gs = parallel.grad_sync(m)
+                assert gs is not None
+                sizes = [ln * 4 for _, ln, _ in gs.buckets]
+                log, total = list(gs.launch_log), gs.nodes_total
+                assert gs.tape.nodes_replayed == total, (gs.tape.nodes_replayed, total)      # every stage reported
+                assert sorted(b for b, _, _ in log) == list(range(len(sizes)))
+                early = sum(nbytes for _, at, nbytes in log if at <= 0.9 * total)
+                print('16-bit step: buckets (MB):', ['%.1f' % (v / 1e6) for v in sizes], '; launched after stage',
+                      ['%d/%d' % (at, total) for _, at, _ in sorted(log)], '; %.1f %% of the bytes in flight before the last 10 %%'
+                      % (100.0 * early / sum(sizes)))
+                assert early >= 0.8 * sum(sizes)
+                assert [b for b, _, _ in log] == sorted(b for b, _, _ in log)
+        assert torch.equal(grads[0], grads[1])
+    finally:
+        os.environ.pop('BTS_DP_NO_OVERLAP', None)
+        dist.destroy_process_group()
+
+
 def test_step_fence_bounds_the_run_ahead(monkeypatch):
     """ops.step_fence: however many steps the host enqueues without reading a value back, at most two are in flight (every step holds
     its activations; unbounded run-ahead made the caching allocator grow inside timed regions) -- and the fence only
