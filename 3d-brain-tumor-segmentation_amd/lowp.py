@@ -366,6 +366,11 @@ class LowPrecisionForward(object):
             if not isinstance(up, (ConvUpsample, LinearUpsample)):
                 raise NotImplementedError('unknown up-sampling layer %r' % type(up).__name__)
         self.channels_first = model.data_format == 'channels_first'
+        bf = getattr(model.encoder, 'base_filters', 16)
+        if bf % 16 != 0:
+            # every 16-bit convolution contracts over whole matrix steps of 16 input channels (v_mfma_f32_32x32x16): an 8-filter level
+            # cannot feed its own second conv.  Refused here, by name, rather than by an alignment status from the first launch
+            raise ValueError('the 16-bit engine needs base_filters to be a multiple of 16 (got %d); use the fp32 engine for such models' % bf)
 
     def _packed(self, key, kind, param, cin_ref, cout, cin_slab=None, dup_start=0, dup_shift=0):
         ent = self._packs.get(key)

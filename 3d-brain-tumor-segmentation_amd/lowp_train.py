@@ -19,6 +19,7 @@ reference of this path: tests/test_lowp_train_gpu.py) is not touched.  Parameter
 flat buffer; slab gradients are zero-initialised and accumulated into (a 16-bit accumulation: every partial sum is rounded
 to the storage type, which is part of what "16-bit storage" means and is bounded by the parity test).
 """
+import math
 import os
 
 import torch
@@ -48,10 +49,28 @@ class _Progress(object):
 
 
 class LowPrecisionTrainer(object):
-    def __init__(self, model, dtype='bfloat16'):
+    """dtype 'bfloat16' (BASELINE configs[2]) or 'float16'.
+
+    float16 stores activation GRADIENTS in a type whose normal range ends at 6e-5: the gradients of a mean-reduced loss over N x 128^3
+    voxels (~1e-7) would be subnormal and lose most of their bits (tests/test_lowp_fullsize_gpu.py measured it in round 3).  The float16
+    trainer therefore always runs with dynamic loss scaling: the backward is seeded with `loss_scale` (a power of two: exact) instead
+    of 1, the summed flat fp32 gradient is checked for overflow (one host read per step -- float16 is the inference type, not a
+    benchmark configuration) and un-scaled; on overflow the step is skipped and the scale halved, after `growth_interval` clean steps it
+    doubles.  bfloat16 has fp32's exponent range and runs unscaled (loss_scale = 1, no check) unless a scale is asked for."""
+
+    def __init__(self, model, dtype='bfloat16', loss_scale=None, growth_interval=200):
         self.fwd = lowp.LowPrecisionForward(model, dtype)      # checks samplers / layout, owns the forward weight images
         self.model = model
         self.code, self.tdt = DTYPES[dtype]
+        if loss_scale is None:
+            loss_scale = 2.0 ** 16 if self.tdt == torch.float16 else 1.0
+        if loss_scale <= 0 or 2.0 ** round(math.log2(loss_scale)) != loss_scale:
+            raise ValueError('loss_scale must be a power of two, got %r' % (loss_scale,))
+        self.loss_scale = float(loss_scale)
+        self.dynamic_scale = self.tdt == torch.float16 or self.loss_scale != 1.0
+        self.growth_interval = int(growth_interval)
+        self._clean_steps = 0
+        self.skipped_steps = 0
         self._packs = {}
         self._pack_table = lowp.PackTable()
         # gate + GroupNorm-2 backward of a block in one pair of passes (bts_lp_block_bwd): 89.4 -> 87.5 ms per batch-8 step measured by
@@ -466,7 +485,8 @@ class LowPrecisionTrainer(object):
         macro, micro = dice_fn(Tensor(y, requires_grad=False), Tensor(y_pred, requires_grad=False))     # (engine layout already)
         self.last_labels = dice_fn.last_labels
         # ------------------------------------------------ backward ------------------------------------------------
-        one = torch.ones(1, dtype=torch.float32, device=dev)
+        # `one` seeds the backward: d loss / d loss, times the loss scale (float16: see the class docstring)
+        one = torch.full((1,), self.loss_scale, dtype=torch.float32, device=dev)
         dyp = torch.empty_like(y_pred)
         dyv = torch.empty_like(y_vae)
         dproj = torch.empty_like(proj)
@@ -585,6 +605,22 @@ class LowPrecisionTrainer(object):
                 ops.l2_reg_bwd(m.flat_params, m.flat_grads, [(o, ln, cf * k) for o, ln, cf in m._l2_ranges], one)
             scale = parallel.all_reduce_gradients(m)
         grads = [p._gview for p in m.trainable_variables]
+        if self.dynamic_scale:
+            # after the exchange every rank holds the same summed gradient, so every rank takes the same decision
+            finite = bool(torch.isfinite(m.flat_grads).all())
+            if finite:
+                if self.loss_scale != 1.0:
+                    m.flat_grads.mul_(1.0 / self.loss_scale)        # (a power of two: exact)
+                self._clean_steps += 1
+                if self._clean_steps >= self.growth_interval and self.loss_scale < 2.0 ** 24:
+                    self.loss_scale *= 2.0
+                    self._clean_steps = 0
+            else:
+                self.skipped_steps += 1
+                self._clean_steps = 0
+                self.loss_scale = max(1.0, self.loss_scale * 0.5)
+                ops.step_fence_done(fence)
+                return Tensor(loss_t, requires_grad=False), macro, micro      # no optimiser step on an overflowed gradient
         optimizer.apply_gradients(zip(grads, m.trainable_variables), model=m, grad_scale=scale)
         ops.step_fence_done(fence)
         return Tensor(loss_t, requires_grad=False), macro, micro

@@ -36,33 +36,104 @@ PEAK_HBM_TBS = 8.0             # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achie
 WINOGRAD_EXECUTED = {'wino_kernel': 12.0 / 27.0, 'wgw_kernel': 12.0 / 27.0, 'w3_kernel': 8.0 / 27.0}
 
 
-def pmc_traffic(symbol):
-    """HBM bytes per launch of `symbol` from the newest COMMITTED rocprofv3 PMC capture (scripts/pmc_traffic.sh ->
-    profiles/rNN*_pmc_traffic.json; two separate --pmc passes, FETCH_SIZE and WRITE_SIZE).  Corrected as
-    MI355X_MICROARCH.md's HBM section prescribes for gfx950: FETCH_SIZE tallies the 128-byte requests of wide (16 B/lane)
-    coalesced reads at 64 bytes, so it is doubled; WRITE_SIZE is taken as is.  The raw counter values and the file they
-    come from are reported next to the corrected figure -- it belongs to that capture, not to this run."""
+def _traffic_table(suffix=''):
+    """the newest COMMITTED rocprofv3 PMC capture of one configuration (scripts/round_profile.sh -> profiles/rNN*_pmc_traffic<suffix>.json:
+    separate --pmc passes for FETCH_SIZE, WRITE_SIZE and the fabric read-request counters), or (None, None).  suffix '' = the fp32
+    step, '_bf16_b8' = BASELINE configs[2], '_infer_f16' = configs[4]."""
     import glob
-    # newest = last by NAME (r01_ < r01c < ... < r03g): modification times mean nothing after a fresh checkout
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), key=os.path.basename)
+    import re
+    # newest = last by NAME (r01_ < r01c < ... < r04a): modification times mean nothing after a fresh checkout
+    files = [f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic%s.json' % suffix))
+             if re.match(r'r\d+[a-z]?_pmc_traffic%s\.json$' % re.escape(suffix), os.path.basename(f))]
     if not files:
+        return None, None
+    f = sorted(files, key=os.path.basename)[-1]
+    return json.load(open(f)), 'profiles/' + os.path.basename(f)
+
+
+def _kernel_bytes(v):
+    """HBM-side bytes of one launch from a kernel's counter means -> (read bytes, write bytes, how the read side was derived).
+    MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE = TCC_EA0_RDREQ x 64 B whatever the request size, so a kernel whose reads
+    are 128-byte requests reports half its bytes.  Per-kernel calibration from the request counters of the same capture: 32-byte
+    requests (TCC_EA0_RDREQ_32B) at 32 B, 128-byte ones (TCC_BUBBLE, where this rocprofv3 exposes it) at 128 B, the rest at 64 B.
+    Without TCC_BUBBLE the request SIZE is unknown: the guide's blanket rule (2 x FETCH_SIZE) is an upper bound, FETCH_SIZE itself the
+    lower one -- both are reported and the upper one is used, so `wasted traffic` is never understated."""
+    fetch = v.get('FETCH_SIZE_KiB_mean')
+    write = v.get('WRITE_SIZE_KiB_mean')
+    if fetch is None or write is None:
         return None
-    tab = json.load(open(files[-1]))
+    rd, r32, r64, r128 = (v.get('TCC_EA0_RDREQ%s_sum_mean' % k) for k in ('', '_32B', '_64B', '_128B'))
+    if rd is not None and r32 is not None and r128 is not None:
+        if r64 is None:
+            r64 = max(rd - r32 - r128, 0.0)
+        read = 32.0 * r32 + 64.0 * r64 + 128.0 * r128
+        how = 'request counters: 32 B x RDREQ_32B + 64 B x RDREQ_64B + 128 B x RDREQ_128B'
+    else:
+        read = 2.0 * fetch * 1024.0
+        how = '2 x FETCH_SIZE (guide rule for wide reads on gfx950: an upper bound; FETCH_SIZE itself = RDREQ x 64 B is the lower one)'
+    return read, write * 1024.0, how
+
+
+def pmc_traffic(symbol, suffix=''):
+    """HBM bytes per launch of `symbol` from the committed capture of this configuration.  The raw counter values and the file they
+    come from are reported next to the figure -- it belongs to that capture, not to this run."""
+    tab, src = _traffic_table(suffix)
+    if tab is None:
+        return None
     norm = lambda n: n.replace('void ', '').replace(' ', '')
     key = norm(symbol)
     best = None
     for k, v in tab.items():
+        if k.startswith('_'):
+            continue
         nk = norm(k)
-        if (nk == key or (('<' not in key) and nk.split('<')[0] == key)) and 'FETCH_SIZE_KiB_mean' in v \
-                and 'WRITE_SIZE_KiB_mean' in v:
+        if (nk == key or (('<' not in key) and nk.split('<')[0] == key)) and _kernel_bytes(v) is not None:
             if best is None or v['launches'] > best['launches']:
                 best = v
     if best is None:
         return None
-    return {'bytes': (2.0 * best['FETCH_SIZE_KiB_mean'] + best['WRITE_SIZE_KiB_mean']) * 1024.0,
+    read, write, how = _kernel_bytes(best)
+    return {'bytes': read + write, 'read_bytes': read, 'write_bytes': write, 'read_side': how,
             'fetch_size_kib_raw': best['FETCH_SIZE_KiB_mean'], 'write_size_kib_raw': best['WRITE_SIZE_KiB_mean'],
-            'correction': '2*FETCH_SIZE + WRITE_SIZE (gfx950 wide-read undercount)',
-            'source': 'committed capture profiles/' + os.path.basename(files[-1])}
+            'rdreq_raw': best.get('TCC_EA0_RDREQ_sum_mean'), 'rdreq_32b_raw': best.get('TCC_EA0_RDREQ_32B_sum_mean'),
+            'rdreq_64b_raw': best.get('TCC_EA0_RDREQ_64B_sum_mean'), 'rdreq_128b_raw': best.get('TCC_EA0_RDREQ_128B_sum_mean'), 'launches_in_capture': best['launches'], 'source': 'committed capture ' + src}
+
+
+# SURVEY 8(d): algorithmic work per unit (CLI-default model).  Training volume 2ch x 128^3: 6.517 TFLOP (fwd 2,172.2 GFLOP, bwd 2x);
+# compulsory HBM bytes 32.2 GB fp32 at batch 1, 15.9 GB per volume with 16-bit storage at batch 8
+TRAIN_ALGORITHMIC_TFLOP_PER_VOLUME = 6.517
+TRAIN_ALGORITHMIC_GB_PER_VOLUME = {'f32': 32.2, 'bf16': 15.9, 'f16': 15.9}
+
+
+def step_rooflines(alg_tflop, alg_gb, sec, dt, suffix):
+    """whole-step rooflines: SURVEY 8(d)'s algorithmic FLOPs and compulsory bytes of one step over the measured step time, against
+    the matrix peak of the type and the HBM peak; and, from the committed PMC capture of this configuration, the HBM bytes ALL kernels
+    of a step moved (sum over kernels of launches x per-launch bytes / steps in the capture) over the algorithmic bytes = the
+    wasted-traffic ratio of the step"""
+    peak = PEAK_F32_MFMA_TFLOPS if dt == 'f32' else PEAK_F16_MFMA_TFLOPS
+    out = {'algorithmic_tflop_per_step': alg_tflop, 'algorithmic_gb_per_step': alg_gb,
+           'mfma_frac': alg_tflop / sec / peak, 'mfma_peak_tflops': peak,
+           'hbm_frac': alg_gb / 1e3 / sec / PEAK_HBM_TBS, 'hbm_peak_tbs': PEAK_HBM_TBS,
+           'note': 'direct-form FLOPs: the fp32 engine\'s Winograd kernels execute 8/27 (12/27) of them, so mfma_frac may exceed 1 there'}
+    tab, src = _traffic_table(suffix)
+    if tab is not None and tab.get('_meta', {}).get('steps_in_capture'):
+        nsteps = float(tab['_meta']['steps_in_capture'])
+        rd = wr = 0.0
+        hows = set()
+        for k, v in tab.items():
+            if k.startswith('_'):
+                continue
+            b = _kernel_bytes(v)
+            if b is None:
+                continue
+            rd += b[0] * v['launches']
+            wr += b[1] * v['launches']
+            hows.add(b[2].split(':')[0].split(' (')[0])
+        out.update({'measured_hbm_gb_per_step': (rd + wr) / nsteps / 1e9, 'measured_read_gb_per_step': rd / nsteps / 1e9,
+                    'measured_write_gb_per_step': wr / nsteps / 1e9, 'wasted_traffic_ratio': (rd + wr) / nsteps / 1e9 / alg_gb,
+                    'measured_hbm_frac_of_step': (rd + wr) / nsteps / sec / (PEAK_HBM_TBS * 1e12),
+                    'read_side': sorted(hows), 'source': 'committed capture ' + src + ' (all kernels, %d steps)' % nsteps})
+    return out
 
 
 CPU_BASELINE_THREADS = 16   # torch-CPU conv3d stops scaling (and thrashes badly) far below the GPU box's 256 hardware threads
@@ -274,10 +345,13 @@ def measure_infer(args, world, rank, dev, overrides, dtype=None, shape=None, bat
             'algorithmic_gflop': INFER_ALGORITHMIC_GFLOP, 'algorithmic_gb': INFER_ALGORITHMIC_GB[dt],
             'mfma_frac': INFER_ALGORITHMIC_GFLOP / 1e3 / sec / (PEAK_F32_MFMA_TFLOPS if dt == 'f32' else PEAK_F16_MFMA_TFLOPS),
             'hbm_frac': INFER_ALGORITHMIC_GB[dt] / 1e3 / sec / PEAK_HBM_TBS}
+        out['step_rooflines'] = step_rooflines(INFER_ALGORITHMIC_GFLOP / 1e3, INFER_ALGORITHMIC_GB[dt], sec, dt,
+                                               '_infer_f16' if dt == 'f16' else '_infer_' + dt)
     if overrides:
         out['overrides'] = overrides
     if prof:
-        out.update(_roofline_from_records(prof, prof_steps, dt_prof, None,
+        sfx = '_infer_f16' if dt == 'f16' else '_infer_' + dt
+        out.update(_roofline_from_records(prof, prof_steps, dt_prof, (lambda sym: pmc_traffic(sym, sfx)) if canonical else None,
                                           'HIP events on the launch stream over %d further forwards right after the timed region' % prof_steps))
     del model
     return out
@@ -424,7 +498,10 @@ def measure_train(args, world, rank, dev, overrides, dtype=None, batch=None, ste
         'config': {'workload': ('BASELINE configs[1]: 2ch x %d^3, batch %d per GPU, fp32, full fwd+bwd with '
                                 'Dice+KL+L2 VAE loss + Dice metric + TF-form Adam; CLI-default model '
                                 '(base_filters=32, depth=4, groups=8, reduction=8; 42,174,773 params)' % (args.crop, nb)) if tdt == 'f32' else
-                               ('BASELINE configs[2] (when batch = 8, bf16): 2ch x %d^3, batch %d per GPU, %s STORAGE of activations / their '
+                               (('BASELINE configs[3] (configs[2]\'s step on each of %d GPUs, RCCL gradient all-reduce launched in buckets from '
+                                 'inside the backward): ' % world if (world > 1 and nb == 8 and tdt == 'bf16') else
+                                 'BASELINE configs[2] (when batch = 8, bf16): ') +
+                                '2ch x %d^3, batch %d per GPU, %s STORAGE of activations / their '
                                 'gradients / weight images, fp32 sums, fp32 master weights and Adam; full train step (forward, data, '
                                 'weight, GroupNorm and gate gradients on the 16-bit kernels; loss, metric, regulariser, Adam and the '
                                 'dense VAE head in fp32); CLI-default model' % (args.crop, nb, tdt)),
@@ -436,9 +513,13 @@ def measure_train(args, world, rank, dev, overrides, dtype=None, batch=None, ste
         out['config']['note'] = '%d ranks sharing %s device(s) over gloo: functional check of the N>1 path' % (world, shared)
     if overrides:
         out['overrides'] = overrides
+    sfx = '' if (tdt == 'f32' and nb == 1) else ('_%s_b%d' % (tdt, nb))
+    if args.crop == 128:
+        out['step_rooflines'] = step_rooflines(TRAIN_ALGORITHMIC_TFLOP_PER_VOLUME * nb, TRAIN_ALGORITHMIC_GB_PER_VOLUME[tdt] * nb,
+                                               dt / steps, tdt, sfx)
     if do_prof and prof:
         out.update(_roofline_from_records(
-            prof, prof_steps, dt_prof, pmc_traffic,
+            prof, prof_steps, dt_prof, (lambda sym: pmc_traffic(sym, sfx)) if args.crop == 128 else None,
             'HIP events on the launch stream over %d one-stream steps run right after the timed region (%.2f ms per step that way): in the '
             'timed region the kernel shares the chip with the weight-gradient / gate streams and has no launch duration of its own'
             % (prof_steps, 1e3 * dt_prof / prof_steps)))

@@ -2,8 +2,10 @@
 # Per-round evidence for bench.py (run ON the GPU box: `gpurun -- 'bash scripts/round_profile.sh r02a'`):
 #   gpurun_out/<tag>_bench.json               the bench line (un-profiled, HIP-event hooks on)
 #   gpurun_out/<tag>_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the same command
-#   gpurun_out/<tag>_pmc_traffic.json         FETCH_SIZE / WRITE_SIZE per-launch means (two separate --pmc passes: the TCC
-#                                             slots cannot hold both; kernel-trace only, as the MI355X guide prescribes)
+#   gpurun_out/<tag>_pmc_traffic{,_bf16_b8,_infer_f16}.json
+#                                             FETCH_SIZE / WRITE_SIZE / fabric read-request per-launch means of every kernel of the fp32
+#                                             step, the bf16 batch-8 step and the fp16 forward (separate --pmc passes: the TCC slots
+#                                             cannot hold them together; kernel-trace only, as the MI355X guide prescribes)
 # Every pass writes into a directory removed beforehand, keeps its log next to the outputs, and the script stops at the
 # first pass that fails or leaves no CSV -- nothing stale can be published.  The program sits directly after `--`.
 set -euo pipefail
@@ -51,30 +53,47 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_${TAG}_inf" -o 
   python3 "$R/bench.py" --infer --dtype f16 --steps 5 --warmup 2 --no-cpu-baseline --no-profile --no-also > "$O/prof_${TAG}_inf.log" 2>&1
 cp "$(need "$O/prof_${TAG}_inf" bench_kernel_stats.csv)" "$O/${TAG}_infer_f16_kernel_stats.csv"
 
-for pass in fetch:FETCH_SIZE write:WRITE_SIZE; do
-  name=${pass%%:*}; ctr=${pass##*:}
-  rm -rf "$O/pmc_${TAG}_$name"
-  rocprofv3 --kernel-trace --pmc "$ctr" --output-format csv -d "$O/pmc_${TAG}_$name" -o "$name" -- \
-    python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-also --serial-streams > "$O/pmc_${TAG}_$name.log" 2>&1
-  need "$O/pmc_${TAG}_$name" "${name}_counter_collection.csv" > /dev/null
-done
+# HBM-side counters, one rocprofv3 pass per counter group (the TCC block has 4 slots: FETCH_SIZE takes 3, WRITE_SIZE 2), for each of the
+# three configurations of the default bench line.  Third pass: the raw fabric request counters FETCH_SIZE is derived from
+# (TCC_EA0_RDREQ: all read requests; _32B / _64B / _128B: by request size) -- bench.py takes the read bytes of every kernel as
+# 32 x R32 + 64 x R64 + 128 x R128 instead of doubling FETCH_SIZE (= RDREQ x 64 B on gfx950) across the board.
+REQ="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"   # (all four exist on gfx950: rocprofv3 -L, round 4)
+traffic_passes() {   # traffic_passes <suffix> <bench args...>
+  local sfx=$1; shift
+  for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "req:$REQ"; do
+    local name=${pass%%:*} ctr=${pass#*:}
+    rm -rf "$O/pmc_${TAG}${sfx}_$name"
+    # shellcheck disable=SC2086
+    rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$O/pmc_${TAG}${sfx}_$name" -o "$name" -- \
+      python3 "$R/bench.py" "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-also --serial-streams > "$O/pmc_${TAG}${sfx}_$name.log" 2>&1
+    need "$O/pmc_${TAG}${sfx}_$name" "${name}_counter_collection.csv" > /dev/null
+  done
+}
+traffic_passes ""
+traffic_passes "_bf16_b8" --dtype bf16 --batch 8
+traffic_passes "_infer_f16" --infer --dtype f16
 
 python3 - "$O" "$TAG" <<'PY'
 import collections, csv, glob, json, sys
 O, TAG = sys.argv[1], sys.argv[2]
-out = {}
-for name, ctr in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
-    files = glob.glob('%s/pmc_%s_%s/**/%s_counter_collection.csv' % (O, TAG, name, name), recursive=True)
-    assert len(files) == 1, files
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(files[0])):
-        if r['Counter_Name'] == ctr:
-            agg[r['Kernel_Name'].split('(')[0]].append(float(r['Counter_Value']))
-    assert agg, 'no %s rows in %s' % (ctr, files[0])
-    for k, v in agg.items():
-        out.setdefault(k, {})[ctr + '_KiB_mean'] = sum(v) / len(v)
-        out[k]['launches'] = len(v)
-json.dump(out, open('%s/%s_pmc_traffic.json' % (O, TAG), 'w'), indent=1, sort_keys=True)
+for sfx in ('', '_bf16_b8', '_infer_f16'):
+    out = {}
+    for name in ('fetch', 'write', 'req'):
+        files = glob.glob('%s/pmc_%s%s_%s/**/%s_counter_collection.csv' % (O, TAG, sfx, name, name), recursive=True)
+        assert len(files) == 1, files
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(files[0])):
+            agg[r['Kernel_Name'].split('(')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
+        assert agg, 'no rows in %s' % files[0]
+        for k, cs in agg.items():
+            for ctr, v in cs.items():
+                key = ctr + ('_KiB' if ctr in ('FETCH_SIZE', 'WRITE_SIZE') else '')
+                out.setdefault(k, {})[key + '_mean'] = sum(v) / len(v)
+                out[k]['launches'] = len(v)
+    # 3 steps per capture (1 warm-up + 2 timed; --no-profile: no further ones); one-time construction kernels are in there too
+    out['_meta'] = {'steps_in_capture': 3, 'command': 'bench.py%s --steps 2 --warmup 1 --serial-streams under rocprofv3 --kernel-trace --pmc <group>'
+                    % {'': '', '_bf16_b8': ' --dtype bf16 --batch 8', '_infer_f16': ' --infer --dtype f16'}[sfx]}
+    json.dump(out, open('%s/%s_pmc_traffic%s.json' % (O, TAG, sfx), 'w'), indent=1, sort_keys=True)
 rows = list(csv.DictReader(open('%s/%s_bench_kernel_stats.csv' % (O, TAG))))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 print('kernel time per step (7 steps in the trace): %.2f ms' % (tot / 7e6))

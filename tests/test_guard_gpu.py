@@ -156,14 +156,21 @@ def test_fp32_train_step_stays_inside_its_buffers(guard, monkeypatch, kw, shape,
 @pytest.mark.parametrize('filters', [16, 8])
 @pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
 def test_16bit_forward_and_train_step_stay_inside_their_buffers(guard, dtype, filters):
-    """filters = 8: blocks whose GroupNorm gradients come back zero-padded to a 16-channel matrix step -- their weight gradients must
-    stay on the fp32 kernels (the padded gradient is wider than the 16-bit kernel's slot; round-3 advisor finding)"""
+    """filters = 8 (round-3 advisor finding: a GroupNorm gradient zero-padded to a 16-channel matrix step is wider than an 8-filter
+    weight-gradient slot): the 16-bit engine contracts over whole 16-channel steps and refuses such a model BY NAME at construction;
+    the trainer's weight-gradient helper additionally raises on any declined or mis-sized launch instead of leaving scratch unwritten"""
     from bts_amd import lowp
     from bts_amd.data import synthetic_batch
     from bts_amd.lowp_train import LowPrecisionTrainer
     from bts_amd.util import DiceCoefficient, ScheduledOptim
     kw, shape = dict(base_filters=filters, groups=8 if filters == 16 else 4, reduction=2, depth=3), (2, 32, 32, 48)
     m = _fresh_model(kw, shape)
+    if filters % 16:
+        with pytest.raises(ValueError, match='multiple of 16'):
+            LowPrecisionTrainer(m, dtype)
+        with pytest.raises(ValueError, match='multiple of 16'):
+            lowp.LowPrecisionForward(m, dtype)
+        return
     x, y, _, _ = synthetic_batch(shape[0], shape[1:], latent=2 * filters, seed=7)
     yp = lowp.LowPrecisionForward(m, dtype)(x[:1, :24, :, :40].contiguous())          # ragged forward-only volume
     assert yp.dtype == torch.float32

@@ -1,6 +1,8 @@
 """-m gpu: BASELINE configs[2] at its stated shape -- the CLI-default model (42,174,773 parameters) at 2ch x 128^3 with bf16
-STORAGE (bts_amd.lowp_train; the step itself is train.py:142-152), batch 2 per GPU (batch 8 is the same code with four times
-the voxels; 2 keeps the fp32 comparison step inside the test budget).  tests/test_lowp_train_gpu.py runs a 16-filter, depth-3
+STORAGE (bts_amd.lowp_train; the step itself is train.py:142-152), at batch 2 (bf16 and fp16) AND at the stated batch 8 (bf16: the
+plan is not the same -- the stride-1 conv's cost model picks tile width / split-K from the item count, the streaming 1x1x1 kernel's
+pool rows and the batched SE-MLP backward change form with N; the fp32 comparison step at batch 8 holds ~80 GB of the 288).
+tests/test_lowp_train_gpu.py runs a 16-filter, depth-3
 model at 32^3: at 128^3 the dispatcher picks tile geometries that test never reaches (the LDS-DMA stride-1 kernel on 32-wide
 tiles with chained items, the 128^3 weight-gradient tilings, the fused GroupNorm partials per whole z plane).
 
@@ -22,10 +24,9 @@ pytestmark = pytest.mark.gpu
 
 CLI = dict(base_filters=32, reduction=8, depth=4, groups=8)
 CROP = (128, 128, 128)
-N = 2
 
 
-def _setup(seed=11):
+def _setup(N, seed=11):
     import bts_amd  # noqa: F401
     from bts_amd.data import synthetic_batch
     from bts_amd.layers import _base
@@ -46,14 +47,16 @@ def _setup(seed=11):
     return m, x, y, mask, eps
 
 
-@pytest.mark.parametrize('dtype,lim', [('bfloat16', dict(loss=5e-3, dice=5e-3, lab=1e-2, l2=0.2, cos=0.98)),
-                                       ('float16', dict(loss=5e-4, dice=1e-3, lab=2e-3, l2=None, cos=None))])
-def test_16bit_step_at_128_cubed_against_the_fp32_engine(dtype, lim):
+@pytest.mark.parametrize('dtype,N,lim', [('bfloat16', 2, dict(loss=5e-3, dice=5e-3, lab=1e-2, l2=0.2, cos=0.98)),
+                                         ('float16', 2, dict(loss=5e-4, dice=1e-3, lab=2e-3, l2=None, cos=None)),
+                                         ('bfloat16', 8, dict(loss=5e-3, dice=5e-3, lab=1e-2, l2=0.2, cos=0.98))],
+                         ids=['bfloat16-n2', 'float16-n2', 'bfloat16-n8-configs2'])
+def test_16bit_step_at_128_cubed_against_the_fp32_engine(dtype, N, lim):
     from bts_amd import ops
     from bts_amd.lowp_train import LowPrecisionTrainer
     from bts_amd.tape import bump_weights_epoch
     from bts_amd.util import DiceCoefficient, DiceVAELoss, ScheduledOptim, train_step
-    m, x, y, mask, eps = _setup()
+    m, x, y, mask, eps = _setup(N)
     start = m.flat_params.clone()
     opt = ScheduledOptim(1e-4)
     opt(epoch=0)
@@ -64,6 +67,8 @@ def test_16bit_step_at_128_cubed_against_the_fp32_engine(dtype, lim):
     torch.cuda.synchronize()
     g32, lab32 = m.flat_grads.clone(), df32.last_labels.clone()
     loss32, macro32 = float(loss32), float(macro32)
+    del df32
+    torch.cuda.empty_cache()          # (the fp32 step's ~10 GB per sample goes back before the 16-bit steps allocate)
 
     def lowp_step(record):
         m.flat_params.copy_(start)
@@ -112,6 +117,15 @@ def test_16bit_step_at_128_cubed_against_the_fp32_engine(dtype, lim):
             assert counts.get('lp_s1z_kernel', 0) >= 8, counts
         if os.environ.get('BTS_LP_WGD') != '0':      # the streaming weight-gradient kernel carries the 128^3 .. 32^3 levels
             assert counts.get('lp_wgd_kernel', 0) >= 20, counts
+        # the rest of the plan at this batch: streaming 1x1x1 kernel (shortcuts, their data gradients), the LDS-tiled stride-2 conv of
+        # the 32-channel level, the merged transposed form, the transposing-read weight gradients of the samplers
+        if os.environ.get('BTS_LP_K1') != '0':
+            assert counts.get('lp_k1_kernel', 0) >= 20, counts
+        if os.environ.get('BTS_LP_S2T') != '0':
+            assert counts.get('lp_s2t_kernel', 0) >= 1, counts
+        if os.environ.get('BTS_LP_UP') != '0':
+            assert counts.get('lp_up_kernel', 0) >= 6, counts
+        assert counts.get('lp_wgs_kernel', 0) >= 6, counts
     assert dl <= lim['loss'] and abs(d16 - macro32) <= lim['dice'] and mism <= lim['lab']
     if lim['l2'] is not None:
         assert rel <= lim['l2'] and cos >= lim['cos']
