@@ -38,7 +38,8 @@ long bts_lp_s1d_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn);
 // lowp_s1z.hip: z-marching stride-1 3x3x3 kernel for few channels (offered first; 1 = declined)
 long bts_lp_s1z_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn);
 int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bias, void* y, int N, int D, int H, int W, int Cin, int ldx,
-                       int Cout, int ldy, int accum, double* gn_part, int gn_G, hipStream_t stream);
+                       int Cout, int ldy, int accum, double* gn_part, int gn_G, hipStream_t stream, const LpGnbFuse* gb = nullptr);
+long bts_lp_s1z_gnb_B_(int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, int Gn);
 // lowp_k1.hip: streaming 1x1x1 kernel (offered first; 1 = declined); gap partials per block of bts_lp_k1_gap_block_ positions
 int bts_lp_k1_gap_block_(long npos, long V, int Cin, int Cout);
 int bts_lp_s2t_launch_(int dtype, const void* x, const void* wp, const float* bias, void* y, int N, int D, int H, int W, int Cin, int ldx,

@@ -141,3 +141,19 @@ __device__ __forceinline__ void k1_pair_transpose(u32x4 (&r)[2], int b) {
   }
   r[0] = s[0]; r[1] = s[1];
 }
+
+// GroupNorm-backward class sums from the epilogue of the data-gradient conv that PRODUCES the GroupNorm output's gradient (resnet.py:80-93
+// under train.py:151: conv2^T(dc2) = da, then GN1 backward needs A_j = sum da_E * xh and B_j = sum da_E per (sample, group, class
+// j = channel mod cg) before anything else -- lp_gn_bwd_reduce_kernel's pass over da and c1).  The epilogue holds da in registers; it
+// reads the matching 16 bytes of the GroupNorm INPUT x per stored 16 bytes and leaves the class sums as per-(unit, slot) partial rows
+// in lp_gn_bwd_finalize_kernel's layout [N*G][B][cg][2] (fp64).  Slab semantics (whole z planes per group: D % G == 0).
+struct LpGnbFuse {
+  const unsigned short* x;   // GroupNorm input, dense (N, D, H, W, C) with C = the conv's output channels here
+  const float* gamma;
+  const float* beta;
+  const float* mean;         // [N*G]
+  const float* rstd;
+  double* part;              // [N*G][B][cg][2]
+  int G, cg, relu;
+  long B;
+};

@@ -39,6 +39,8 @@ struct LpS1zParams {
   double* gnp;       // fused GroupNorm partial sums (slab semantics) [N*G][gn_B][2], or NULL
   int gn_G, gn_zt;
   long gn_B;
+  LpGnbFuse gb;      // GNB kernels: GroupNorm-backward class sums of the stored output against the GroupNorm input gb.x (lowp_common.h)
+  int gb_zt;         // planes per group
 };
 #define S1Z_TX 32
 #define S1Z_TY 16
@@ -54,7 +56,7 @@ __device__ __forceinline__ u32x4 s1z_rsrc(const void* base) {
   return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
 }
 
-template <typename T, int KS>
+template <typename T, int KS, bool GNB = false>
 __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int SX = S1Z_SX, SY = S1Z_SY, NVOX = SX * SY, NCHK = S1Z_NCHK;
@@ -132,11 +134,37 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
     }
   };
   __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, 0x7fffffff, 0x00020000);
+  // GNB: per-lane class sums of the current (sample, group) run -- element e of a lane's stored 8 couts is channel co + e with co a
+  // multiple of 8, so its class (channel mod cg, cg | 8) is e mod cg for every lane; flushed (wave sum in fp64, one partial row per
+  // wave) where the march leaves a group or the item
+  __amdgpu_buffer_rsrc_t cr = yr;
+  float gba[8], gbb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) gba[e] = gbb[e] = 0.f;
   // the completed output plane z of accumulator set s leaves (and the set restarts at the bias)
   auto store_set = [&](auto sc, int z) {
     constexpr int s = decltype(sc)::value;
     const bool gn_on = p.gnp != nullptr;
     float gn_s = 0.f, gn_q = 0.f;
+    float gam[8], bet[8], gm = 0.f, grs = 0.f;
+    if constexpr (GNB) {
+      const int gg = z / p.gb_zt;
+      gm = p.gb.mean[cn * p.gb.G + gg];
+      grs = p.gb.rstd[cn * p.gb.G + gg];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { gam[e] = p.gb.gamma[gg * p.gb.cg + (e & (p.gb.cg - 1))]; bet[e] = p.gb.beta[gg * p.gb.cg + (e & (p.gb.cg - 1))]; }
+    }
+    u32x4 cxs[2][2];      // GNB: the GroupNorm-input rows of this plane's four stores, requested before the first store is issued
+    if constexpr (GNB) {
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int co = 16 * qp + 8 * h;
+          const unsigned offc = co < p.Cout ? (unsigned)((((z * p.H + cy0 + r0 + r) * p.W + cx0 + l32) * p.Cout + co) * 2) : 0x80000000u;
+          cxs[qp][r] = __builtin_amdgcn_raw_buffer_load_b128(cr, offc, 0, 0);
+        }
+    }
 #pragma unroll
     for (int qp = 0; qp < 2; ++qp) {
       const int co = 16 * qp + 8 * h;
@@ -170,6 +198,42 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
         if (z == -12345)
 #endif
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{d0, d1, d2, d3}, yr, off, 0, 0);
+        if constexpr (GNB) {      // (after the exchange: this lane holds the STORED couts co .. co + 7 of voxel l32, as the reduce pass would read them)
+          float cv[8], dv[8];
+          unpack8<T>(cxs[qp][r], cv);
+          unpack8<T>(u32x4{d0, d1, d2, d3}, dv);
+          if (ok) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float xh = (cv[e] - gm) * grs;
+              float de = dv[e];
+              if (p.gb.relu && !(xh * gam[e] + bet[e] > 0.f)) de = 0.f;
+              gba[e] = fmaf(de, xh, gba[e]);
+              gbb[e] += de;
+            }
+          }
+        }
+      }
+    }
+    if constexpr (GNB) {
+      if ((z + 1) % p.gb_zt == 0 || z == zhi - 1) {      // the run of planes of one (sample, group) ends here
+        double ra[8], rb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ra[e] = wave_sum_f64((double)gba[e]); rb[e] = wave_sum_f64((double)gbb[e]); gba[e] = gbb[e] = 0.f; }
+        if (lane == 0) {
+          const int gg = z / p.gb_zt;
+          const int run = p.ZC < p.gb_zt ? (zlo - gg * p.gb_zt) / p.ZC : 0;
+          const long slot = ((long)run * (p.nty * p.ntx) + (cy0 / S1Z_TY) * p.ntx + cx0 / S1Z_TX) * 8 + wave;
+          double* dst = p.gb.part + (((long)cn * p.gb.G + gg) * p.gb.B + slot) * (p.gb.cg * 2);
+          for (int j = 0; j < p.gb.cg; ++j) {
+            double sa = 0.0, sb = 0.0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if ((e & (p.gb.cg - 1)) == j) { sa += ra[e]; sb += rb[e]; }
+            dst[2 * j] = sa;
+            dst[2 * j + 1] = sb;
+          }
+        }
       }
     }
     if (gn_on) {   // one fp64 (sum, sumsq) pair per (z plane, column, wave): fixed order
@@ -264,6 +328,7 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
   for (int item = it0; item < it1; ++item) {
     setup(item);
     yr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long)cn * p.D * p.H * p.W * (long)p.ldy), 0, 0x7fffffff, 0x00020000);
+    if constexpr (GNB) cr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.gb.x + (long)cn * p.D * p.H * p.W * (long)p.Cout), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int j = 0; j < NR; ++j) issue1(j, zlo - 1, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -326,24 +391,39 @@ long bts_lp_s1z_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn) {
   if (Gn <= 0 || D % Gn != 0 || !s1z_plan(pl, N, D, H, W, Cin, Cin, Cout, Cout)) return 0;
   return (long)(D / Gn) * pl.nty * pl.ntx * 8;
 }
-// BTS_OK = ran, 1 = declined.  wp = the DMA part of the K3S1 image.
+// partial rows per (n, group) of the fused GroupNorm-BACKWARD class sums (LpGnbFuse) when the kernel takes the shape and can emit them:
+// whole planes per group, z chunks that nest with the groups, classes that divide a lane's 8 couts; 0 otherwise
+long bts_lp_s1z_gnb_B_(int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, int Gn) {
+  S1zPlan pl;
+  if (Gn <= 0 || D % Gn != 0 || Cout % Gn != 0 || !s1z_plan(pl, N, D, H, W, Cin, ldx, Cout, ldy)) return 0;
+  const int cg = Cout / Gn, zt = D / Gn;
+  if (cg > 8 || (8 % cg) != 0) return 0;
+  if (pl.ZC % zt != 0 && zt % pl.ZC != 0) return 0;
+  return (long)(pl.ZC < zt ? zt / pl.ZC : 1) * pl.nty * pl.ntx * 8;
+}
+// BTS_OK = ran, 1 = declined.  wp = the DMA part of the K3S1 image.  gb (may be NULL): see LpGnbFuse; its B must be bts_lp_s1z_gnb_B_'s
 int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bias, void* y, int N, int D, int H, int W, int Cin, int ldx,
-                       int Cout, int ldy, int accum, double* gn_part, int gn_G, hipStream_t stream) {
+                       int Cout, int ldy, int accum, double* gn_part, int gn_G, hipStream_t stream, const LpGnbFuse* gb) {
   S1zPlan pl;
   if (!s1z_plan(pl, N, D, H, W, Cin, ldx, Cout, ldy)) return 1;
   if ((((uintptr_t)x) & 15) || (((uintptr_t)y) & 15) || (((uintptr_t)wp) & 15)) return 1;
   if (gn_part != nullptr && (gn_G <= 0 || D % gn_G != 0)) return 1;
+  if (gb != nullptr && (gn_part != nullptr || gb->B != bts_lp_s1z_gnb_B_(N, D, H, W, Cin, ldx, Cout, ldy, gb->G) || gb->B <= 0 ||
+                        (((uintptr_t)gb->x) & 15)))
+    return 1;
   LpS1zParams p;
   p.x = (const unsigned short*)x; p.wp = (const unsigned short*)wp; p.bias = bias; p.y = (unsigned short*)y;
   p.N = N; p.D = D; p.H = H; p.W = W; p.ldx = ldx; p.ldy = ldy; p.Cout = Cout;
   p.ntx = pl.ntx; p.nty = pl.nty; p.nzc = pl.nzc; p.ZC = pl.ZC; p.nitems = pl.nitems; p.ipw = pl.ipw; p.xcd_order = pl.xcd; p.accum = accum;
   p.gnp = gn_part; p.gn_G = gn_G; p.gn_zt = gn_G > 0 ? D / gn_G : 1; p.gn_B = gn_G > 0 ? (long)(D / gn_G) * pl.nty * pl.ntx * 8 : 0;
+  if (gb != nullptr) { p.gb = *gb; p.gb_zt = D / gb->G; } else { p.gb = LpGnbFuse{}; p.gb_zt = 1; }
   const int KS = Cin / 16;
   const size_t shmem = (size_t)(27 * KS * 1024 + 2 * S1Z_NCHK * 1024 * KS + 256 + 1024);
   (void)hipGetLastError();
-#define S1Z_LAUNCH(TT, KS_)                                                                                                  \
+#define S1Z_LAUNCH(TT, KS_) do { if (gb != nullptr) S1Z_LAUNCH_(TT, KS_, true); else S1Z_LAUNCH_(TT, KS_, false); } while (0)
+#define S1Z_LAUNCH_(TT, KS_, GB_)                                                                                            \
   do {                                                                                                                       \
-    auto kern = lp_s1z_kernel<TT, KS_>;                                                                                      \
+    auto kern = lp_s1z_kernel<TT, KS_, GB_>;                                                                                 \
     static bool done = false;                                                                                                \
     if (!done) {                                                                                                             \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
@@ -357,6 +437,7 @@ int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bi
   if (dtype == LP_F16) { if (KS == 2) S1Z_LAUNCH(TF16, 2); else S1Z_LAUNCH(TF16, 1); }
   else { if (KS == 2) S1Z_LAUNCH(TBF16, 2); else S1Z_LAUNCH(TBF16, 1); }
 #undef S1Z_LAUNCH
+#undef S1Z_LAUNCH_
   if (prof) bts_prof_end(stream);
   BTS_LAUNCH_CHECK();
   return BTS_OK;

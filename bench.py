@@ -113,8 +113,9 @@ def step_rooflines(alg_tflop, alg_gb, sec, dt, suffix):
     peak = PEAK_F32_MFMA_TFLOPS if dt == 'f32' else PEAK_F16_MFMA_TFLOPS
     out = {'algorithmic_tflop_per_step': alg_tflop, 'algorithmic_gb_per_step': alg_gb,
            'mfma_frac': alg_tflop / sec / peak, 'mfma_peak_tflops': peak,
-           'hbm_frac': alg_gb / 1e3 / sec / PEAK_HBM_TBS, 'hbm_peak_tbs': PEAK_HBM_TBS,
-           'note': 'direct-form FLOPs: the fp32 engine\'s Winograd kernels execute 8/27 (12/27) of them, so mfma_frac may exceed 1 there'}
+           'hbm_frac': alg_gb / 1e3 / sec / PEAK_HBM_TBS, 'hbm_peak_tbs': PEAK_HBM_TBS}
+    if dt == 'f32':
+        out['note'] = 'direct-form FLOPs: the fp32 engine\'s Winograd kernels execute 8/27 (12/27) of them, so mfma_frac may exceed 1'
     tab, src = _traffic_table(suffix)
     if tab is not None and tab.get('_meta', {}).get('steps_in_capture'):
         nsteps = float(tab['_meta']['steps_in_capture'])

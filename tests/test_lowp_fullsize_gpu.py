@@ -13,9 +13,10 @@ evenly over the conv kernels of every level -- the per-variable table the test p
 mantissa bits, which is what separates rounding from a kernel fault): bf16 loss <= 5e-3 relative, macro Dice <= 5e-3, <= 1 % label
 changes, whole-gradient cosine >= 0.98 and relative L2 <= 0.2 (measured 0.989 / 0.146 -- and 0.989 / 0.152 with the register-staged
 conv kernel, BTS_LP_S1D=0: the figure belongs to the storage type, not to a kernel).  fp16: loss <= 5e-4, Dice <= 1e-3, <= 0.2 % label
-changes (measured 5.8e-5, 4e-5, 0.05 %); its GRADIENT is not bounded at this size: without loss scaling the activation gradients of a
-mean-reduced loss over 2 x 128^3 voxels (~1e-7) sit in fp16's subnormal range and lose most of their bits -- fp16 is the inference
-type (BASELINE configs[4]), bf16 the training type (configs[2]).
+changes (measured 5.8e-5, 4e-5, 0.05 %); its GRADIENT was unbounded at this size in round 3: without loss scaling the activation
+gradients of a mean-reduced loss over 2 x 128^3 voxels (~1e-7) sit in fp16's subnormal range.  The float16 trainer now always scales
+its loss (dynamic, 2^16 to start: lowp_train.LowPrecisionTrainer) and the gradient is bounded like bf16's, tighter: relative L2 <= 0.1,
+cosine >= 0.99.  At batch 8 (bf16, configs[2] as stated): measured relative L2 0.0997, cosine 0.9950, loss 2.3e-4, 0.39 % label changes.
 Also: two 16-bit steps from the same state are bitwise identical, and the launch records show which kernels ran."""
 import pytest
 import torch
@@ -48,7 +49,7 @@ def _setup(N, seed=11):
 
 
 @pytest.mark.parametrize('dtype,N,lim', [('bfloat16', 2, dict(loss=5e-3, dice=5e-3, lab=1e-2, l2=0.2, cos=0.98)),
-                                         ('float16', 2, dict(loss=5e-4, dice=1e-3, lab=2e-3, l2=None, cos=None)),
+                                         ('float16', 2, dict(loss=5e-4, dice=1e-3, lab=2e-3, l2=0.1, cos=0.99)),
                                          ('bfloat16', 8, dict(loss=5e-3, dice=5e-3, lab=1e-2, l2=0.2, cos=0.98))],
                          ids=['bfloat16-n2', 'float16-n2', 'bfloat16-n8-configs2'])
 def test_16bit_step_at_128_cubed_against_the_fp32_engine(dtype, N, lim):
