@@ -910,7 +910,7 @@ static int lp_gather_launch(LpGatherParams p, hipStream_t stream) {
 // odd ones (i, k=1)).  (D,H,W) are the dims of `x`, the tensor the taps read; Cin its channels (the contraction).
 static int lp_conv_run(int geo, int dtype, const void* x, const void* wp, const float* bias, void* y, void* workspace, long workspace_bytes,
                        int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, int accum, hipStream_t stream,
-                       double* gap_part = nullptr, double* gn_part = nullptr, int gn_G = 0) {
+                       double* gap_part = nullptr, double* gn_part = nullptr, int gn_G = 0, const LpGnbFuse* gnb = nullptr) {
   if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return BTS_ERR_SHAPE;
   // (results are stored four couts = 8 bytes at a time; a head with fewer than four output channels stores them one by one)
@@ -922,9 +922,10 @@ static int lp_conv_run(int geo, int dtype, const void* x, const void* wp, const 
     if (((long)(D + 2) * H * W + 64) * (long)ldx * 2 >= 0x7fffffffL) return BTS_ERR_SHAPE;   // 31-bit offsets inside one volume
     {   // few channels on a big volume: the z-marching streaming kernel (lowp_s1z.hip); same image part as the tiled DMA kernel
       const int r = bts_lp_s1z_launch_(dtype, x, reinterpret_cast<const char*>(wp) + lp_s1d_part_offset(Cin, Cout), bias, y, N, D, H, W, Cin, ldx,
-                                       Cout, ldy, accum, gn_part, gn_G, stream);
+                                       Cout, ldy, accum, gn_part, gn_G, stream, gnb);
       if (r != 1) return r;
     }
+    if (gnb != nullptr) return 1;      // (only the streaming kernel emits the GroupNorm-backward class sums: nothing was launched)
     {
       const int r = bts_lp_s1d_launch_(dtype, x, reinterpret_cast<const char*>(wp) + lp_s1d_part_offset(Cin, Cout), bias, y, workspace,
                                        workspace_bytes, N, D, H, W, Cin, ldx, Cout, ldy, accum, gn_part, gn_G, stream);
@@ -2173,26 +2174,15 @@ extern "C" long bts_lp_gn_bwd_workspace(int N, long V, int C, int G) {
   return (long)N * G * lp_gnb_blocks(L) * (C / G) * 2 * 8 + (long)N * G * 2 * 4 + 64 + 16384L * C * 8 + 64;   // (+ bias-gradient rows)
 }
 // x dense (N,V,C) in the storage type; dy rows of stride lddy; dx dense in the storage type, dx32 (may be NULL) the same values in fp32
-extern "C" int bts_lp_gn_bwd(int dtype, const void* x, const void* dy, void* dx, float* dx32, const float* gamma, const float* beta,
-                             const float* mean, const float* rstd, float* dgamma, float* dbeta, void* workspace, long workspace_bytes, int N,
-                             long V, int C, int lddy, int G, int relu, int accumulate_params, float* dbias, hipStream_t stream) {
-  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
-  if (N <= 0 || V <= 0 || C < G || C % G != 0 || C % 8 != 0 || C > 256 || (C & (C - 1)) != 0 || lddy % 8 != 0 || lddy < C) return BTS_ERR_SHAPE;
-  const long E = V * C, L = E / G;
+// finalize + apply (+ bias-gradient finalize) on class-sum partial rows [N*G][B][cg][2] -- lp_gn_bwd_reduce_kernel's, or the ones a
+// data-gradient conv left from its epilogue (LpGnbFuse).  tail: c1, c2 ([N*G] floats each), then the 64-byte aligned bias rows
+static int lp_gn_bwd_tail(int dtype, const void* x, const void* dy, void* dx, float* dx32, const float* gamma, const float* beta, const float* mean,
+                          const float* rstd, float* dgamma, float* dbeta, const double* partial, int B, float* tail, int N, long L, int C, int lddy,
+                          int G, int relu, int accumulate_params, float* dbias, hipStream_t stream) {
   const int cg = C / G;
-  if (E % G != 0 || L % 2048 != 0 || cg > 32 || 256 % cg != 0) return BTS_ERR_UNSUPPORTED;   // (the caller falls back to the fp32 kernels)
-  if ((((uintptr_t)x) & 15) || (((uintptr_t)dy) & 15) || (((uintptr_t)dx) & 15) || (dx32 && (((uintptr_t)dx32) & 15))) return BTS_ERR_ALIGN;
-  if (workspace_bytes < bts_lp_gn_bwd_workspace(N, V, C, G)) return BTS_ERR_WORKSPACE;
-  const int B = lp_gnb_blocks(L);
-  const long span = ((L / 2048 + B - 1) / B) * 2048;
-  double* partial = reinterpret_cast<double*>(workspace);
-  float* c1 = reinterpret_cast<float*>(partial + (long)N * G * B * cg * 2);
+  float* c1 = tail;
   float* c2 = c1 + (long)N * G;
   double* dbp = dbias ? reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(c2 + (long)N * G) + 63) & ~(uintptr_t)63) : nullptr;
-  (void)hipGetLastError();
-  if (dtype == LP_F16) hipLaunchKernelGGL(lp_gn_bwd_reduce_kernel<TF16>, dim3(B, N * G), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)dy, gamma, beta, mean, rstd, partial, E, L, span, C, G, cg, lddy, relu);
-  else hipLaunchKernelGGL(lp_gn_bwd_reduce_kernel<TBF16>, dim3(B, N * G), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)dy, gamma, beta, mean, rstd, partial, E, L, span, C, G, cg, lddy, relu);
-  BTS_LAUNCH_CHECK();
   hipLaunchKernelGGL(lp_gn_bwd_finalize_kernel, dim3(G), dim3(256), 0, stream, partial, gamma, dgamma, dbeta, c1, c2, N, G, B, cg, (double)L, accumulate_params);
   BTS_LAUNCH_CHECK();
   int Ba;
@@ -2207,6 +2197,85 @@ extern "C" int bts_lp_gn_bwd(int dtype, const void* x, const void* dy, void* dx,
     BTS_LAUNCH_CHECK();
   }
   return BTS_OK;
+}
+static int lp_gn_bwd_check(int dtype, const void* x, const void* dy, const void* dx, const float* dx32, int N, long V, int C, int lddy, int G) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  if (N <= 0 || V <= 0 || C < G || C % G != 0 || C % 8 != 0 || C > 256 || (C & (C - 1)) != 0 || lddy % 8 != 0 || lddy < C) return BTS_ERR_SHAPE;
+  const long E = V * C, L = E / G;
+  const int cg = C / G;
+  if (E % G != 0 || L % 2048 != 0 || cg > 32 || 256 % cg != 0) return BTS_ERR_UNSUPPORTED;   // (the caller falls back to the fp32 kernels)
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)dy) & 15) || (((uintptr_t)dx) & 15) || (dx32 && (((uintptr_t)dx32) & 15))) return BTS_ERR_ALIGN;
+  return BTS_OK;
+}
+extern "C" int bts_lp_gn_bwd(int dtype, const void* x, const void* dy, void* dx, float* dx32, const float* gamma, const float* beta,
+                             const float* mean, const float* rstd, float* dgamma, float* dbeta, void* workspace, long workspace_bytes, int N,
+                             long V, int C, int lddy, int G, int relu, int accumulate_params, float* dbias, hipStream_t stream) {
+  const int chk = lp_gn_bwd_check(dtype, x, dy, dx, dx32, N, V, C, lddy, G);
+  if (chk != BTS_OK) return chk;
+  const long E = V * C, L = E / G;
+  const int cg = C / G;
+  if (workspace_bytes < bts_lp_gn_bwd_workspace(N, V, C, G)) return BTS_ERR_WORKSPACE;
+  const int B = lp_gnb_blocks(L);
+  const long span = ((L / 2048 + B - 1) / B) * 2048;
+  double* partial = reinterpret_cast<double*>(workspace);
+  (void)hipGetLastError();
+  if (dtype == LP_F16) hipLaunchKernelGGL(lp_gn_bwd_reduce_kernel<TF16>, dim3(B, N * G), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)dy, gamma, beta, mean, rstd, partial, E, L, span, C, G, cg, lddy, relu);
+  else hipLaunchKernelGGL(lp_gn_bwd_reduce_kernel<TBF16>, dim3(B, N * G), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)dy, gamma, beta, mean, rstd, partial, E, L, span, C, G, cg, lddy, relu);
+  BTS_LAUNCH_CHECK();
+  return lp_gn_bwd_tail(dtype, x, dy, dx, dx32, gamma, beta, mean, rstd, dgamma, dbeta, partial, B, reinterpret_cast<float*>(partial + (long)N * G * B * cg * 2),
+                        N, L, C, lddy, G, relu, accumulate_params, dbias, stream);
+}
+
+// da = conv3x3x3^T(dy) (stride 1; stored dense in the storage type) and the backward of the GroupNormalization (+ReLU) that da is the
+// output gradient of -- resnet.py:80-93 in reverse under train.py:151: conv2's data gradient, then norm1 -- as ONE entry point, so that
+// the class sums GroupNorm's backward needs first (A_j, B_j above) leave the conv's epilogue instead of costing a reduce pass over da
+// and c (2 of the 5 tensor passes of a GroupNorm backward).  Fused where the z-marching kernel takes the layer (lowp_s1z.hip: the
+// data-gradient contraction over 16 | 32 channels, <= 32 GroupNorm channels, whole planes per group); otherwise the conv and
+// bts_lp_gn_bwd run back to back: same results up to the order of the fp32 class sums.  (D,H,W): the grid; Cg = GroupNorm channels =
+// the forward conv's INPUT channels, Cdy = dy's channels (row stride lddy); wp_bwd = bts_lp_pack(BTS_CONV_K3S1, BTS_ROLE_BWD_DATA, ...).
+// *fused_out (may be NULL) <- 1 when the epilogue form ran, 0 otherwise.
+extern "C" long bts_lp_conv3d_bwd_data_gn_bwd_workspace(int N, int D, int H, int W, int Cg, int Cdy, int G) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cg <= 0 || Cdy <= 0 || G <= 0 || Cg % G != 0) return -1;
+  const long V = (long)D * H * W;
+  const long conv = ((lp_s1_workspace(N, D, H, W, Cdy, Cg) + 63) / 64) * 64;
+  const long plain = bts_lp_gn_bwd_workspace(N, V, Cg, G);
+  const long B = bts_lp_s1z_gnb_B_(N, D, H, W, Cdy, Cdy, Cg, Cg, G);
+  const long fused = B > 0 ? (long)N * G * B * (Cg / G) * 2 * 8 + (long)N * G * 2 * 4 + 64 + 16384L * Cg * 8 + 64 : 0;
+  return conv + (fused > plain ? fused : plain) + 64;
+}
+extern "C" int bts_lp_conv3d_bwd_data_gn_bwd(int dtype, const void* dy, const void* wp_bwd, void* da, const void* c, void* dc, float* dc32,
+                                             const float* gamma, const float* beta, const float* mean, const float* rstd, float* dgamma,
+                                             float* dbeta, void* workspace, long workspace_bytes, int N, int D, int H, int W, int Cg, int Cdy,
+                                             int lddy, int G, int relu, int accumulate_params, float* dbias, int* fused_out,
+                                             hipStream_t stream) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cg <= 0 || Cdy <= 0 || G <= 0 || Cg % G != 0) return BTS_ERR_SHAPE;
+  const long V = (long)D * H * W;
+  const int chk = lp_gn_bwd_check(dtype, c, da, dc, dc32, N, V, Cg, Cg, G);
+  if (chk != BTS_OK) return chk;
+  if (workspace == nullptr || workspace_bytes < bts_lp_conv3d_bwd_data_gn_bwd_workspace(N, D, H, W, Cg, Cdy, G) || (((uintptr_t)workspace) & 15))
+    return BTS_ERR_WORKSPACE;
+  const long conv_ws = ((lp_s1_workspace(N, D, H, W, Cdy, Cg) + 63) / 64) * 64;
+  char* tail = reinterpret_cast<char*>(workspace) + conv_ws;
+  const long L = V * Cg / G;
+  const int cg = Cg / G;
+  if (fused_out) *fused_out = 0;
+  const long B = bts_lp_s1z_gnb_B_(N, D, H, W, Cdy, lddy, Cg, Cg, G);
+  if (B > 0 && B <= 0x7fffffffL && B == bts_lp_s1z_gnb_B_(N, D, H, W, Cdy, Cdy, Cg, Cg, G)) {     // (the workspace was sized for dense dy)
+    LpGnbFuse f;
+    f.x = (const unsigned short*)c; f.gamma = gamma; f.beta = beta; f.mean = mean; f.rstd = rstd;
+    f.part = reinterpret_cast<double*>(tail); f.G = G; f.cg = cg; f.relu = relu; f.B = B;
+    const int r = lp_conv_run(1, dtype, dy, wp_bwd, nullptr, da, nullptr, 0, N, D, H, W, Cdy, lddy, Cg, Cg, 0, stream, nullptr, nullptr, 0, &f);
+    if (r == BTS_OK) {
+      if (fused_out) *fused_out = 1;
+      return lp_gn_bwd_tail(dtype, c, da, dc, dc32, gamma, beta, mean, rstd, dgamma, dbeta, f.part, (int)B,
+                            reinterpret_cast<float*>(f.part + (long)N * G * B * cg * 2), N, L, Cg, Cg, G, relu, accumulate_params, dbias, stream);
+    }
+    if (r != 1) return r;
+  }
+  const int r = lp_conv_run(1, dtype, dy, wp_bwd, nullptr, da, workspace, conv_ws, N, D, H, W, Cdy, lddy, Cg, Cg, 0, stream);
+  if (r != BTS_OK) return r;
+  return bts_lp_gn_bwd(dtype, c, da, dc, dc32, gamma, beta, mean, rstd, dgamma, dbeta, tail, workspace_bytes - conv_ws, N, V, Cg, Cg, G, relu,
+                       accumulate_params, dbias, stream);
 }
 
 // =====================================================================================================================

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
   constexpr int SX = S1Z_SX, SY = S1Z_SY, NVOX = SX * SY, NCHK = S1Z_NCHK;
   constexpr int WB = 27 * KS * 1024, PLB = NCHK * 1024 * KS;
   constexpr int OFF_P = WB, OFF_BIAS = WB + 2 * PLB, OFF_SCR = OFF_BIAS + 256;
+  constexpr int OFF_GB = OFF_SCR + 1024;      // GNB: gamma[32] | beta[32] | mean[32] | rstd[32] of the current sample (floats)
 #ifdef S1Z_EXP_2ISSUE   // timing experiment: two waves issue all plane requests of a stage (is request back-pressure what stalls the others?)
   constexpr int NREQ = NCHK * KS, NR = NREQ / 2;
 #define S1Z_ID(j) ((wave < 2) ? (wave * NR + (j)) : 0x7fff)
@@ -134,37 +135,86 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
     }
   };
   __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, 0x7fffffff, 0x00020000);
-  // GNB: per-lane class sums of the current (sample, group) run -- element e of a lane's stored 8 couts is channel co + e with co a
-  // multiple of 8, so its class (channel mod cg, cg | 8) is e mod cg for every lane; flushed (wave sum in fp64, one partial row per
-  // wave) where the march leaves a group or the item
+  // GNB (GroupNorm-backward class sums, LpGnbFuse).  Element e of a lane's stored 8 couts is channel co + e with co a multiple of 8, so
+  // its class (channel mod cg, cg | 4) is e mod cg for every lane.  With t = c * g' + b' (g' = rstd * gamma_j, b' = beta_j - mean * g':
+  // per sample and channel, in LDS) the masked gradient is dE = [t > 0] da and the class sums are B_j = S0_j, A_j = rstd * (S1_j - mean *
+  // S0_j) with S0 = sum dE, S1 = sum dE * c: five vector instructions per element, run right after each 16-byte store.  The
+  // GroupNorm-input rows of the plane a stage completes are requested from INSIDE that stage (after its plane requests), so they have
+  // arrived when it ends: requested at the store they cost the HBM latency once per plane with the matrix pipe idle (0.60 -> 0.95 ms
+  // per launch; 0.83 ms this way).  What is left is the arithmetic itself, eight waves between two stages (~1.5 us per plane).  Moving
+  // it into the next stage's matrix-instruction shadow needs the four stored rows + the four input rows live across the stage: 32
+  // registers the kernel does not have (256 with scratch spills of 0.9-2 KB per lane; built, measured in the compiler's report, dropped).
+  // Per-lane fp32 sums are flushed (wave sum in fp64, one partial row per wave) where the march leaves a group or the item.
   __amdgpu_buffer_rsrc_t cr = yr;
-  float gba[8], gbb[8];
+  float gs0[4], gs1[4];           // (cg <= 4: elements e and e + 4 of a row share a class)
 #pragma unroll
-  for (int e = 0; e < 8; ++e) gba[e] = gbb[e] = 0.f;
+  for (int e = 0; e < 4; ++e) gs0[e] = gs1[e] = 0.f;
+  u32x4 cxs[2][2], dst_;
+  int zst = -1;                    // plane of the row in dst_
+  auto gnb_request = [&](int z) {
+#pragma unroll
+    for (int qp = 0; qp < 2; ++qp)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int co = 16 * qp + 8 * h;
+        const unsigned offc = (co < p.Cout && z >= zlo) ? (unsigned)((((z * p.H + cy0 + r0 + r) * p.W + cx0 + l32) * p.Cout + co) * 2) : 0x80000000u;
+        cxs[qp][r] = __builtin_amdgcn_raw_buffer_load_b128(cr, offc, 0, 0);
+      }
+  };
+  float gpr[4], bpr[4];            // g', b' of the four element classes of the plane being stored (one batch of LDS reads per plane:
+                                   // read where they are used, every one of them cost its own lgkmcnt wait -- 75 per plane)
+  auto gnb_params = [&](int z) {
+    const float* gsh = reinterpret_cast<const float*>(lds + OFF_GB) + (z / p.gb_zt) * p.gb.cg;
+    const int cmask = p.gb.cg - 1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { gpr[e] = gsh[e & cmask]; bpr[e] = gsh[32 + (e & cmask)]; }
+  };
+  auto gnb_math = [&](const u32x4& crow, bool live) {      // the row just stored (dst_) against its GroupNorm-input row
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned cw = crow[i], dw = dst_[i];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int e = (2 * i + k) & 3;      // elements e and e + 4 share a class (cg | 4)
+          const float c = T::ld((unsigned short)(k ? cw >> 16 : cw & 0xffffu)), d = T::ld((unsigned short)(k ? dw >> 16 : dw & 0xffffu));
+          const float t = fmaf(c, gpr[e], bpr[e]);
+          const float de = (!p.gb.relu || t > 0.f) ? d : 0.f;
+          gs1[e] = fmaf(de, c, gs1[e]);
+          gs0[e] += de;
+        }
+      }
+    }
+  };
+  auto gnb_flush = [&]() {          // after the last row of plane zst: the run of planes of one (sample, group) may end here
+    if ((zst + 1) % p.gb_zt == 0 || zst == zhi - 1) {
+      const float* gsh = reinterpret_cast<const float*>(lds + OFF_GB);
+      const int gg = zst / p.gb_zt;
+      const double gm = (double)gsh[64 + gg], grs = (double)gsh[96 + gg];
+      double ra[4], rb[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ra[e] = wave_sum_f64((double)gs1[e]); rb[e] = wave_sum_f64((double)gs0[e]); gs0[e] = gs1[e] = 0.f; }
+      if (lane == 0) {
+        const int run = p.ZC < p.gb_zt ? (zlo - gg * p.gb_zt) / p.ZC : 0;
+        const long slot = ((long)run * (p.nty * p.ntx) + (cy0 / S1Z_TY) * p.ntx + cx0 / S1Z_TX) * 8 + wave;
+        double* dst = p.gb.part + (((long)cn * p.gb.G + gg) * p.gb.B + slot) * (p.gb.cg * 2);
+        for (int j = 0; j < p.gb.cg; ++j) {
+          double s1 = 0.0, s0 = 0.0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if ((e & (p.gb.cg - 1)) == j) { s1 += ra[e]; s0 += rb[e]; }
+          dst[2 * j] = grs * (s1 - gm * s0);
+          dst[2 * j + 1] = s0;
+        }
+      }
+    }
+  };
   // the completed output plane z of accumulator set s leaves (and the set restarts at the bias)
   auto store_set = [&](auto sc, int z) {
     constexpr int s = decltype(sc)::value;
     const bool gn_on = p.gnp != nullptr;
     float gn_s = 0.f, gn_q = 0.f;
-    float gam[8], bet[8], gm = 0.f, grs = 0.f;
-    if constexpr (GNB) {
-      const int gg = z / p.gb_zt;
-      gm = p.gb.mean[cn * p.gb.G + gg];
-      grs = p.gb.rstd[cn * p.gb.G + gg];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { gam[e] = p.gb.gamma[gg * p.gb.cg + (e & (p.gb.cg - 1))]; bet[e] = p.gb.beta[gg * p.gb.cg + (e & (p.gb.cg - 1))]; }
-    }
-    u32x4 cxs[2][2];      // GNB: the GroupNorm-input rows of this plane's four stores, requested before the first store is issued
-    if constexpr (GNB) {
-#pragma unroll
-      for (int qp = 0; qp < 2; ++qp)
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const int co = 16 * qp + 8 * h;
-          const unsigned offc = co < p.Cout ? (unsigned)((((z * p.H + cy0 + r0 + r) * p.W + cx0 + l32) * p.Cout + co) * 2) : 0x80000000u;
-          cxs[qp][r] = __builtin_amdgcn_raw_buffer_load_b128(cr, offc, 0, 0);
-        }
-    }
+    if constexpr (GNB) gnb_params(z);
 #pragma unroll
     for (int qp = 0; qp < 2; ++qp) {
       const int co = 16 * qp + 8 * h;
@@ -198,44 +248,14 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
         if (z == -12345)
 #endif
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{d0, d1, d2, d3}, yr, off, 0, 0);
-        if constexpr (GNB) {      // (after the exchange: this lane holds the STORED couts co .. co + 7 of voxel l32, as the reduce pass would read them)
-          float cv[8], dv[8];
-          unpack8<T>(cxs[qp][r], cv);
-          unpack8<T>(u32x4{d0, d1, d2, d3}, dv);
-          if (ok) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float xh = (cv[e] - gm) * grs;
-              float de = dv[e];
-              if (p.gb.relu && !(xh * gam[e] + bet[e] > 0.f)) de = 0.f;
-              gba[e] = fmaf(de, xh, gba[e]);
-              gbb[e] += de;
-            }
-          }
+        if constexpr (GNB) {      // (after the exchange: the STORED couts co .. co + 7 of voxel l32, as a reduce pass would read them)
+          dst_ = u32x4{d0, d1, d2, d3};
+          zst = z;
+          gnb_math(cxs[qp][r], 16 * qp + 8 * h < p.Cout);
         }
       }
     }
-    if constexpr (GNB) {
-      if ((z + 1) % p.gb_zt == 0 || z == zhi - 1) {      // the run of planes of one (sample, group) ends here
-        double ra[8], rb[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { ra[e] = wave_sum_f64((double)gba[e]); rb[e] = wave_sum_f64((double)gbb[e]); gba[e] = gbb[e] = 0.f; }
-        if (lane == 0) {
-          const int gg = z / p.gb_zt;
-          const int run = p.ZC < p.gb_zt ? (zlo - gg * p.gb_zt) / p.ZC : 0;
-          const long slot = ((long)run * (p.nty * p.ntx) + (cy0 / S1Z_TY) * p.ntx + cx0 / S1Z_TX) * 8 + wave;
-          double* dst = p.gb.part + (((long)cn * p.gb.G + gg) * p.gb.B + slot) * (p.gb.cg * 2);
-          for (int j = 0; j < p.gb.cg; ++j) {
-            double sa = 0.0, sb = 0.0;
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-              if ((e & (p.gb.cg - 1)) == j) { sa += ra[e]; sb += rb[e]; }
-            dst[2 * j] = sa;
-            dst[2 * j + 1] = sb;
-          }
-        }
-      }
-    }
+    if constexpr (GNB) gnb_flush();
     if (gn_on) {   // one fp64 (sum, sumsq) pair per (z plane, column, wave): fixed order
       const double ds = wave_sum_f64((double)gn_s), dq = wave_sum_f64((double)gn_q);
       if (lane == 0) {
@@ -292,6 +312,9 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
       if (g < NR) { if (more) issue1(g, zp + 1, buf ^ 1); else issue_filler(); }
 #endif
 #endif
+      if constexpr (GNB) {
+        if (g == (NR < NG ? NR : NG - 1)) gnb_request(zp - 1);       // (after this stage's plane requests)
+      }
       __builtin_amdgcn_sched_barrier(0);
       const int s = (R + 4 - kz) % 3;
 #pragma unroll
@@ -328,7 +351,21 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
   for (int item = it0; item < it1; ++item) {
     setup(item);
     yr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long)cn * p.D * p.H * p.W * (long)p.ldy), 0, 0x7fffffff, 0x00020000);
-    if constexpr (GNB) cr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.gb.x + (long)cn * p.D * p.H * p.W * (long)p.Cout), 0, 0x7fffffff, 0x00020000);
+    if constexpr (GNB) {
+      cr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.gb.x + (long)cn * p.D * p.H * p.W * (long)p.Cout), 0, 0x7fffffff, 0x00020000);
+      // (the previous item's last reads lie behind its closing barrier; the barrier below publishes these)
+      float* gsh = reinterpret_cast<float*>(lds + OFF_GB);
+      if (tid < p.gb.G) {
+        gsh[64 + tid] = p.gb.mean[cn * p.gb.G + tid];
+        gsh[96 + tid] = p.gb.rstd[cn * p.gb.G + tid];
+      }
+      if (tid >= 64 && tid < 64 + p.Cout) {      // channel c = g * cg + j of the affine parameters: g' = rstd gamma, b' = beta - mean g'
+        const int c = tid - 64, gq = c / p.gb.cg;
+        const float gp = p.gb.rstd[cn * p.gb.G + gq] * p.gb.gamma[c];
+        gsh[c] = gp;
+        gsh[32 + c] = p.gb.beta[c] - p.gb.mean[cn * p.gb.G + gq] * gp;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NR; ++j) issue1(j, zlo - 1, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -397,7 +434,7 @@ long bts_lp_s1z_gnb_B_(int N, int D, int H, int W, int Cin, int ldx, int Cout, i
   S1zPlan pl;
   if (Gn <= 0 || D % Gn != 0 || Cout % Gn != 0 || !s1z_plan(pl, N, D, H, W, Cin, ldx, Cout, ldy)) return 0;
   const int cg = Cout / Gn, zt = D / Gn;
-  if (cg > 8 || (8 % cg) != 0) return 0;
+  if (cg > 4 || (4 % cg) != 0 || Gn > 32 || Cout > 32) return 0;
   if (pl.ZC % zt != 0 && zt % pl.ZC != 0) return 0;
   return (long)(pl.ZC < zt ? zt / pl.ZC : 1) * pl.nty * pl.ntx * 8;
 }
@@ -418,7 +455,7 @@ int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bi
   p.gnp = gn_part; p.gn_G = gn_G; p.gn_zt = gn_G > 0 ? D / gn_G : 1; p.gn_B = gn_G > 0 ? (long)(D / gn_G) * pl.nty * pl.ntx * 8 : 0;
   if (gb != nullptr) { p.gb = *gb; p.gb_zt = D / gb->G; } else { p.gb = LpGnbFuse{}; p.gb_zt = 1; }
   const int KS = Cin / 16;
-  const size_t shmem = (size_t)(27 * KS * 1024 + 2 * S1Z_NCHK * 1024 * KS + 256 + 1024);
+  const size_t shmem = (size_t)(27 * KS * 1024 + 2 * S1Z_NCHK * 1024 * KS + 256 + 1024 + 512);
   (void)hipGetLastError();
 #define S1Z_LAUNCH(TT, KS_) do { if (gb != nullptr) S1Z_LAUNCH_(TT, KS_, true); else S1Z_LAUNCH_(TT, KS_, false); } while (0)
 #define S1Z_LAUNCH_(TT, KS_, GB_)                                                                                            \

@@ -213,6 +213,29 @@ def gn_bwd(code, tdt, x, dy, gamma, beta, mean, rstd, dgamma, dbeta, groups, rel
     return dx, dx32
 
 
+def conv_bwd_data_gn_bwd(code, tdt, dy, wp_bwd, c, gamma, beta, mean, rstd, dgamma, dbeta, groups, relu, want_f32=True, dbias=None):
+    """conv2's data gradient followed by GroupNorm-1's backward (resnet.py:80-93 in reverse) as one library call -> (da, dc, dc32 | None,
+    fused): da = conv3x3x3^T(dy) stored in the storage type, dc the gradient of the GroupNorm input c; where the z-marching conv kernel
+    takes the layer, GroupNorm's class sums come out of its epilogue (no reduce pass over da and c).  None when the GroupNorm kernels'
+    tiling does not fit (gn_bwd's conditions): the caller runs the two steps itself"""
+    n, d, h, w, cg = c.shape
+    v = d * h * w
+    L = v * cg // groups
+    if (v * cg) % groups or L % 2048 or cg // groups > 32 or 256 % (cg // groups) or cg > 256 or cg & (cg - 1) or not c.is_contiguous():
+        return None
+    cdy = dy.shape[-1]
+    nb = lib().query('bts_lp_conv3d_bwd_data_gn_bwd_workspace', n, d, h, w, cg, cdy, groups)
+    ws = ops.workspace(nb, c.device)
+    da = torch.empty_like(c)
+    dc = torch.empty_like(c)
+    dc32 = torch.empty(c.shape, dtype=torch.float32, device=c.device) if want_f32 else None
+    fused = ctypes.c_int(0)
+    lib().call('bts_lp_conv3d_bwd_data_gn_bwd', code, _p(dy), _p(wp_bwd), _p(da), _p(c), _p(dc), _p(dc32) if dc32 is not None else None,
+               _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dgamma), _p(dbeta), _p(ws), nb, n, d, h, w, cg, cdy, _ld(dy), groups,
+               1 if relu else 0, 1, _p(dbias) if dbias is not None else None, ctypes.byref(fused), _stream())
+    return da, dc, dc32, bool(fused.value)
+
+
 def conv1_gap(code, x, wp, bias, cout, tdt):
     """(res, gap): the block's 1x1x1 shortcut conv and the mean over voxels of its output (the gate's squeeze) in one pass"""
     n, d, h, w, cin = x.shape

@@ -77,6 +77,9 @@ class LowPrecisionTrainer(object):
         # interleaved rounds inside one process (scripts/lp_fuse_ab.py; A/B between processes drowns in the pool's run-to-run spread).
         # BTS_LP_FUSE_BLOCK_BWD=0: the two separate routes
         self.fuse_block_bwd = os.environ.get('BTS_LP_FUSE_BLOCK_BWD', '1') != '0'
+        # conv2's data gradient + GroupNorm-1's backward through bts_lp_conv3d_bwd_data_gn_bwd (class sums from the conv's epilogue where
+        # the streaming kernel runs the layer); BTS_LP_FUSE_GN1_BWD=0: the two separate calls (A/B)
+        self.fuse_gn1_bwd = os.environ.get('BTS_LP_FUSE_GN1_BWD', '1') != '0'
         self.last_labels = None
         self._clock = None
 
@@ -247,10 +250,23 @@ class LowPrecisionTrainer(object):
             a32 = self._f32(s['a'])
             self._wg((a32, dc2), lambda: ops.conv_bwd_weight(ops.K3S1, a32, dc2, self._gslot(blk.conv2_k), self._gslot(blk.conv2_b),
                                                              accumulate=True))
-        da = torch.empty_like(s['a'])
-        conv_bwd_data(ops.K3S1, code, dc2_16, self._pk((key, 'c2b'), ops.K3S1, blk.conv2_k, f, f, role=ops.ROLE_BWD), da, False)
-        del dc2, dc2_16
-        dc1_16, dc1 = self._gn_bwd(n1, s['c1'], da, s['m1'], s['r1'], want_f32=not lp1, dbias=self._gslot(blk.conv1_b) if lp1 else None)
+        wp_c2b = self._pk((key, 'c2b'), ops.K3S1, blk.conv2_k, f, f, role=ops.ROLE_BWD)
+        both = None
+        if self.fuse_gn1_bwd and n1._mode == ops.GN_SLAB and f % 16 == 0 and dc2_16.shape[-1] == f:
+            # conv2's data gradient and GroupNorm-1's backward as one library call: on the layers the z-marching conv takes, the class
+            # sums of GroupNorm's backward leave the conv's epilogue (no reduce pass over da and c1)
+            both = lowp.conv_bwd_data_gn_bwd(code, self.tdt, dc2_16, wp_c2b, s['c1'], n1.gamma.t, n1.beta.t, s['m1'], s['r1'], self._gslot(n1.gamma),
+                                             self._gslot(n1.beta), n1.groups, True, want_f32=not lp1,
+                                             dbias=self._gslot(blk.conv1_b) if lp1 else None)
+        if both is not None:
+            da, dc1_16, dc1, _ = both
+            self._db_done = lp1
+            del dc2, dc2_16
+        else:
+            da = torch.empty_like(s['a'])
+            conv_bwd_data(ops.K3S1, code, dc2_16, wp_c2b, da, False)
+            del dc2, dc2_16
+            dc1_16, dc1 = self._gn_bwd(n1, s['c1'], da, s['m1'], s['r1'], want_f32=not lp1, dbias=self._gslot(blk.conv1_b) if lp1 else None)
         db1 = None if (lp1 and self._db_done) else self._gslot(blk.conv1_b)
         del da
         # gate branch (16-bit kernels; fp32 copies only where a weight gradient still runs on the fp32 kernels)

@@ -277,6 +277,18 @@ long bts_lp_gn_bwd_workspace(int N, long V, int C, int G);
 int bts_lp_gn_bwd(int dtype, const void* x, const void* dy, void* dx, float* dx32, const float* gamma, const float* beta, const float* mean,
                   const float* rstd, float* dgamma, float* dbeta, void* workspace, long workspace_bytes, int N, long V, int C, int lddy, int G,
                   int relu, int accumulate_params, float* dbias, bts_stream_t stream);
+/* A ResnetBlock's conv2 data gradient and its GroupNorm-1 (+ReLU) backward as one entry point (resnet.py:80-93 in reverse under
+ * train.py:151; replaces bts_lp_conv3d_bwd_data followed by bts_lp_gn_bwd): da = conv3x3x3^T(dy) is stored dense (N,D,H,W,Cg) in the
+ * storage type, dc / dc32 / dgamma / dbeta / dbias are bts_lp_gn_bwd's outputs for x = c, dy = da.  Where the z-marching kernel takes
+ * the layer the class sums GroupNorm's backward starts from leave the conv's epilogue (one read of c per stored row) instead of a
+ * reduce pass over da and c; elsewhere the two run back to back -- same results up to the order of the fp32 class sums.
+ * Cg = GroupNorm channels = the forward conv's input channels, Cdy = dy's channels (rows of lddy); wp_bwd = bts_lp_pack(BTS_CONV_K3S1,
+ * BTS_ROLE_BWD_DATA, ...); *fused_out (may be NULL) <- 1 | 0: which form ran.  Error codes as bts_lp_gn_bwd. */
+long bts_lp_conv3d_bwd_data_gn_bwd_workspace(int N, int D, int H, int W, int Cg, int Cdy, int G);
+int bts_lp_conv3d_bwd_data_gn_bwd(int dtype, const void* dy, const void* wp_bwd, void* da, const void* c, void* dc, float* dc32,
+                                  const float* gamma, const float* beta, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                                  void* workspace, long workspace_bytes, int N, int D, int H, int W, int Cg, int Cdy, int lddy, int G, int relu,
+                                  int accumulate_params, float* dbias, int* fused_out, bts_stream_t stream);
 /* GlobalAveragePooling3D of the shortcut (resnet.py:45-46,121): out[n][c] = scale * sum_v x */
 long bts_lp_colsum_workspace(int N, long V, int C);
 int bts_lp_colsum(int dtype, const void* x, float* out, void* workspace, long workspace_bytes, int N, long V, int C, float scale,

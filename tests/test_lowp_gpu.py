@@ -673,3 +673,61 @@ def test_cast_into_a_padded_view(c, dtype):
         torch.cuda.synchronize()
         assert torch.equal(out, x.to(tdt))
         assert bool((buf[..., :first] == 7.0).all()) and bool((buf[..., first + c:] == 7.0).all())
+
+
+GNB_CASES = [
+    # (N, D, H, W), GroupNorm channels (= conv2 input channels), dy channels, groups, dy is a slab view, fused form expected
+    ((2, 32, 32, 64), 32, 32, 8, False, True),       # z chunks of 16 planes over groups of 4: flushed at every group boundary
+    ((2, 128, 32, 64), 16, 32, 4, True, True),       # z chunks of 16 planes inside groups of 32: several runs per (sample, group)
+    ((2, 64, 32, 64), 16, 32, 2, True, False),       # 8 classes per group: more than the epilogue form folds (4)
+    ((1, 16, 16, 32), 32, 32, 8, False, False),      # too small for the streaming kernel: the two steps back to back
+    ((2, 8, 16, 16), 64, 64, 8, False, False),       # 64 channels: the tiled kernel, no epilogue form (yet)
+]
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('case', GNB_CASES, ids=lambda c: '%s-%d-%d-g%d-%s' % ('x'.join(map(str, c[0])), c[1], c[2], c[3], 'fused' if c[5] else 'plain'))
+def test_conv2_data_gradient_with_groupnorm1_backward(case, dtype):
+    """bts_lp_conv3d_bwd_data_gn_bwd (conv2's data gradient + GroupNorm-1 (+ReLU) backward, class sums from the conv's epilogue where
+    the z-marching kernel runs the layer) against bts_lp_conv3d_bwd_data followed by bts_lp_gn_bwd on the same tensors: da identical
+    (same kernel, same stores), dc / dc32 / dgamma / dbeta / dbias equal up to the order of the fp32 class sums; and against the fp32
+    engine's GroupNorm backward on the stored da (the oracle-pinned kernel of tests/test_kernels_gpu.py)"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    (n, d, h, w), cg, cdy, G, slab, want_fused = case
+    code, tdt = lowp.DTYPES[dtype]
+    g = torch.Generator().manual_seed(cg * 3 + cdy + d)
+    k = torch.randn((3, 3, 3, cg, cdy), generator=g) * (2.0 / (27 * cg)) ** 0.5
+    wpb = lowp.pack(ops.K3S1, code, k.to(DEV), cg, cdy, role=ops.ROLE_BWD)
+    c = (torch.randn((n, d, h, w, cg), generator=g) * 1.5 + 0.3).to(tdt).to(DEV)
+    if slab:
+        dys = torch.randn((n, d, h, w, cdy + 16), generator=g).to(tdt).to(DEV)
+        dy = dys[..., 8:8 + cdy]
+    else:
+        dy = torch.randn((n, d, h, w, cdy), generator=g).to(tdt).to(DEV)
+    gamma = (1 + 0.3 * torch.randn(cg, generator=g)).to(DEV)
+    beta = (0.2 * torch.randn(cg, generator=g)).to(DEV)
+    mean, rstd = lowp.gn_stats(code, c, G, ops.GN_SLAB, 1e-5)
+    # reference: the two entry points
+    da_r = torch.empty_like(c)
+    lowp.conv_bwd_data(ops.K3S1, code, dy, wpb, da_r, False)
+    dg_r, db_r, dbias_r = torch.full((cg,), 0.5, device=DEV), torch.full((cg,), -0.25, device=DEV), torch.full((cg,), 0.125, device=DEV)
+    dc_r, dc32_r = lowp.gn_bwd(code, tdt, c, da_r, gamma, beta, mean, rstd, dg_r, db_r, G, True, want_f32=True, dbias=dbias_r)
+    dg, db, dbias = torch.full((cg,), 0.5, device=DEV), torch.full((cg,), -0.25, device=DEV), torch.full((cg,), 0.125, device=DEV)
+    out = lowp.conv_bwd_data_gn_bwd(code, tdt, dy, wpb, c, gamma, beta, mean, rstd, dg, db, G, True, want_f32=True, dbias=dbias)
+    assert out is not None
+    da, dc, dc32, fused = out
+    torch.cuda.synchronize()
+    assert fused == want_fused, (fused, want_fused)
+    assert torch.equal(da, da_r)
+    scale = float(dc32_r.abs().max())
+    assert float((dc32 - dc32_r).abs().max()) <= 2e-5 * scale + 1e-6
+    assert float((dc.float() - dc_r.float()).abs().max()) <= U[dtype] * scale * 1.01
+    for a, b in ((dg, dg_r), (db, db_r), (dbias, dbias_r)):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-5, (a, b)
+    # and the fp32 engine's kernel on the stored da
+    dg32, db32 = torch.full((cg,), 0.5, device=DEV), torch.full((cg,), -0.25, device=DEV)
+    dx32 = ops.gn_bwd(lowp.uncast(code, c), lowp.uncast(code, da), gamma, beta, mean, rstd, dg32, db32, G, ops.GN_SLAB, True, accumulate_params=True)
+    assert float((dc32 - dx32).abs().max()) <= 2e-5 * float(dx32.abs().max()) + 1e-6
+    for a, b in ((dg, dg32), (db, db32)):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-5
