@@ -37,6 +37,13 @@ def _wgrad16(kind, code, x, dy, dw, *a, **kw):
         raise RuntimeError('16-bit weight gradient declined: kind %d, x %s, dy %s, dw %s' % (kind, tuple(x.shape), tuple(dy.shape), tuple(dw.shape)))
 
 
+class _Holder(object):
+    """what _pk needs of a parameter: .t"""
+
+    def __init__(self, t):
+        self.t = t
+
+
 class _Progress(object):
     """what parallel.GradSync asks of a tape: a generation, the number of backward stages and how many of them have run"""
 
@@ -72,6 +79,7 @@ class LowPrecisionTrainer(object):
         self._clean_steps = 0
         self.skipped_steps = 0
         self._packs = {}
+        self._pads = {}
         self._pack_table = lowp.PackTable()
         # gate + GroupNorm-2 backward of a block in one pair of passes (bts_lp_block_bwd): 89.4 -> 87.5 ms per batch-8 step measured by
         # interleaved rounds inside one process (scripts/lp_fuse_ab.py; A/B between processes drowns in the pool's run-to-run spread).
@@ -98,8 +106,30 @@ class LowPrecisionTrainer(object):
             self._repack_all()
         return ent[2]
 
+    def _padded(self, key, param, width):
+        """persistent fp32 copy of `param` zero-padded along its LAST axis to `width` (a kernel's output channels or a bias), as an
+        object _pk accepts; the live columns are refreshed by _repack_all, i.e. before any image is packed from it (round 3 rebuilt
+        the padded kernels with zeros + slice copy + a pack launch of their own on every step, in both directions)"""
+        ent = self._pads.get(key)
+        if ent is None or ent[1] is not param:
+            buf = torch.zeros(tuple(param.t.shape[:-1]) + (width,), dtype=torch.float32, device=param.t.device)
+            buf[..., :param.t.shape[-1]].copy_(param.t)
+            ent = (_Holder(buf), param, [weights_epoch()])
+            self._pads[key] = ent
+        elif ent[2][0] != weights_epoch():
+            self._refresh_pads()
+        return ent[0]
+
+    def _refresh_pads(self):
+        ep = weights_epoch()
+        for holder, param, stamp in self._pads.values():
+            if stamp[0] != ep:
+                holder.t[..., :param.t.shape[-1]].copy_(param.t)
+                stamp[0] = ep
+
     def _repack_all(self):
         ep = weights_epoch()
+        self._refresh_pads()
         batch = []
         for ent in self._packs.values():
             if ent[0] == ep:
@@ -481,13 +511,11 @@ class LowPrecisionTrainer(object):
             # register-staged kernel (0.97 ms of the batch-8 step).  Kernel and bias zero-padded to 8 output channels -> the streaming
             # kernels take it (the pad columns multiply zeros; only the live ones are read back)
             cvv = yv_last.shape[-1]
-            wpad = torch.zeros((3, 3, 3, cvv, 8), dtype=torch.float32, device=dev)
-            wpad[..., :vae.out_ch] = vae.out_k.t
-            bpad = torch.zeros(8, dtype=torch.float32, device=dev)
-            bpad[:vae.out_ch] = vae.out_b.t
-            y8 = conv(ops.K3S1, code, tdt, yv_last, lowp.pack(ops.K3S1, code, wpad, cvv, 8), bpad, 8)
+            wpad = self._padded((id(vae), 'out_k8'), vae.out_k, 8)
+            bpad = self._padded((id(vae), 'out_b8'), vae.out_b, 8)
+            y8 = conv(ops.K3S1, code, tdt, yv_last, self._pk((id(vae), 'out8'), ops.K3S1, wpad, cvv, 8), bpad.t, 8)
             y_vae = self._f32(y8[..., :vae.out_ch])
-            del y8, wpad
+            del y8
         else:
             wp_vo = self._pk((id(vae), 'out'), ops.K3S1, vae.out_k, yv_last.shape[-1], vae.out_ch)
             y_vae = self._f32(conv(ops.K3S1, code, tdt, yv_last, wp_vo, vae.out_b.t, vae.out_ch))
@@ -533,9 +561,7 @@ class LowPrecisionTrainer(object):
                 self._gslot(vae.out_k).add_(tk[..., :co])
                 self._gslot(vae.out_b).add_(dyv.sum(dim=(0, 1, 2, 3)))
             self._wg((yv_last, dyv16, dyv), wg_out)
-            wpad = torch.zeros((3, 3, 3, cv, 16), dtype=torch.float32, device=dev)
-            wpad[..., :co] = vae.out_k.t
-            wpb = lowp.pack(ops.K3S1, code, wpad, cv, 16, role=ops.ROLE_BWD)
+            wpb = self._pk((id(vae), 'out16b'), ops.K3S1, self._padded((id(vae), 'out_k16'), vae.out_k, 16), cv, 16, role=ops.ROLE_BWD)
             dv = torch.empty(yv_last.shape, dtype=tdt, device=dev)
             conv_bwd_data(ops.K3S1, code, dyv16, wpb, dv, False)
             del dyv16

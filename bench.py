@@ -15,8 +15,12 @@ N>1: one process per GPU, one sample per rank (weak scaling), RCCL all-reduce of
     RCCL, which refuses two ranks on one device): a functional check of the N>1 path, not a scaling number.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  "roofline":     dominant kernel (by summed time in the timed region), measured live with HIP events on the launch stream
-  "cpu_baseline": the oracle's identical 128^3 step on the host cores (rank 0, N=1 only)
+  "roofline":       dominant kernel (by summed time in the timed region), measured live with HIP events on the launch stream; its
+                    `traffic` from the newest committed PMC capture of the same configuration (scripts/round_profile.sh ->
+                    profiles/rNN*_pmc_traffic{,_bf16_b8,_infer_f16}.json), read bytes from the request-size counters
+  "step_rooflines": SURVEY 8(d)'s algorithmic FLOPs / bytes of the whole step over the measured step time, and the HBM bytes all
+                    kernels of a step moved in that capture over the algorithmic bytes (wasted-traffic ratio)
+  "cpu_baseline":   the oracle's identical 128^3 step on the host cores (rank 0, N=1 only)
 """
 import argparse
 import json
