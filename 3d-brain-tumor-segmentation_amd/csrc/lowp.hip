@@ -2877,7 +2877,7 @@ extern "C" int bts_lp_conv3d_bwd_weight(int kind, int dtype, const void* x, cons
   } while (0)
   const bool k3 = kind == BTS_CONV_K3S1;
   const bool prof = bts_prof_on();
-  if (prof) bts_prof_begin(32, 2.0 * p.ntaps * (double)Cin * Cout * (double)N * D * H * W, stream);
+  if (prof) bts_prof_begin(32 | ((k3 ? 1 : 2) << 16), 2.0 * p.ntaps * (double)Cin * Cout * (double)N * D * H * W, stream);   // (variant 2: 1x1x1 -- 2 FLOP per operand byte, HBM-bound)
   if (dtype == LP_F16) {
     if (k3) { if (nq == 2) LPW_LAUNCH(TF16, 2, true); else LPW_LAUNCH(TF16, 1, true); }
     else { if (nq == 2) LPW_LAUNCH(TF16, 2, false); else LPW_LAUNCH(TF16, 1, false); }

@@ -593,7 +593,7 @@ int bts_lp_s1d_launch_(int dtype, const void* x, const void* wp_dma, const float
   p.gn_B = gn_G > 0 ? (long)p.gn_zt * pl.nty * pl.ntx * pl.ncg * 2 : 0;
   if (gnp != nullptr && p.ksplit > 1) return BTS_ERR_UNSUPPORTED;
   const bool prof = bts_prof_on();
-  if (prof) bts_prof_begin(33, 2.0 * 27.0 * Cin * (double)Cout * (double)nvox, stream);
+  if (prof) bts_prof_begin(33 | ((1 + pl.mode * 2 + (pl.txl == 4 ? 1 : 0)) << 16), 2.0 * 27.0 * Cin * (double)Cout * (double)nvox, stream);   // (bits 16+: the variant, for bench.py's per-variant table)
   int r;
 #define S1D_CASE(M_, X_)                                                                                                  \
   if (pl.mode == M_ && pl.txl == X_)                                                                                      \

@@ -23,7 +23,16 @@ _workspaces = {}
 _CFG = {0: '2,1,4,1', 1: '2,2,4,1', 2: '1,2,2,2', 3: '1,1,2,2', 4: '1,1,4,1', 5: '4,1,4,1'}
 
 
-def kernel_symbol(sym):
+_VARIANTS = {33: {1: '<0,5>', 2: '<0,4>', 3: '<1,5>', 4: '<1,4>'},          # lp_s1d_kernel<MODE, TXL>
+             32: {1: '<3x3x3>', 2: '<1x1x1>'}}                                 # lp_wgrad_kernel by kernel size
+
+
+def kernel_symbol(sym, detail=False):
+    """name of a profiled launch; bits 16+ of `sym` carry a kernel-specific variant, shown only with detail=True (tests count launches
+    by the plain name, bench.py's kernel_breakdown tells the variants apart)"""
+    var, sym = sym >> 16, sym & 0xffff
+    if var and detail and sym in _VARIANTS:
+        return kernel_symbol(sym) + _VARIANTS[sym].get(var, '<%d>' % var)
     if sym == 20:
         return 'upm_kernel'
     if sym == 21:
@@ -69,14 +78,14 @@ def profile_enable(on):
     lib().call('bts_profile_enable', 1 if on else 0)
 
 
-def profile_records():
-    """-> [(symbol, algorithmic_flops, ms)] ; synchronise the device first"""
+def profile_records(detail=False):
+    """-> [(symbol, algorithmic_flops, ms)] ; synchronise the device first.  detail: kernel variants in the symbol names"""
     L = lib()
     out = []
     sym, fl, ms = ctypes.c_int(), ctypes.c_double(), ctypes.c_float()
     for i in range(L._bts_profile_count()):
         L.call('bts_profile_get', i, ctypes.byref(sym), ctypes.byref(fl), ctypes.byref(ms))
-        out.append((kernel_symbol(sym.value), fl.value, ms.value))
+        out.append((kernel_symbol(sym.value, detail), fl.value, ms.value))
     return out
 
 

@@ -84,13 +84,19 @@ def pmc_traffic(symbol, suffix=''):
     tab, src = _traffic_table(suffix)
     if tab is None:
         return None
-    norm = lambda n: n.replace('void ', '').replace(' ', '')
+    norm = lambda n: n.replace('void ', '').replace(' ', '').replace('TBF16,', '').replace('TF16,', '')
     key = norm(symbol)
+    want_tail = None
+    if key.endswith('<3x3x3>') or key.endswith('<1x1x1>'):      # lp_wgrad_kernel<T, NQ, K3>: the kernel size is its last template argument
+        want_tail = 'true>' if key.endswith('<3x3x3>') else 'false>'
+        key = key.split('<')[0]
     best = None
     for k, v in tab.items():
         if k.startswith('_'):
             continue
         nk = norm(k)
+        if want_tail is not None and not nk.endswith(want_tail):
+            continue
         if (nk == key or (('<' not in key) and nk.split('<')[0] == key)) and _kernel_bytes(v) is not None:
             if best is None or v['launches'] > best['launches']:
                 best = v
@@ -328,7 +334,7 @@ def measure_infer(args, world, rank, dev, overrides, dtype=None, shape=None, bat
         torch.cuda.synchronize()
         dt_prof = time.perf_counter() - t1
         ops.profile_enable(False)
-        prof = ops.profile_records()
+        prof = ops.profile_records(detail=True)
     if rank != 0:
         return None
     sec = dts / steps
@@ -396,9 +402,18 @@ def _roofline_from_records(prof, steps_p, dt_p, traffic_of, measured):
                         'F(2x2,3x3) x direct: 12 per 27; executed/algorithmic = %.4f here): ' % WINOGRAD_EXECUTED[sym] +
                         '`achieved`/`frac` are the EXECUTED rate (what is left to gain); *_algorithmic is '
                         'direct-form FLOPs / time and may exceed the peak')
-    return {'roofline': roof,
-            'kernel_breakdown': {k: {'ms_per_step': 1e3 * v[0] / steps_p, 'tflops': v[1] / v[0] / 1e12,
-                                     'launches_per_step': v[2] / steps_p} for k, v in sorted(agg.items())}}
+    brk = {}
+    for k, v in sorted(agg.items()):
+        pk = PEAK_F16_MFMA_TFLOPS if k.startswith('lp_') else PEAK_F32_MFMA_TFLOPS
+        e = {'ms_per_step': 1e3 * v[0] / steps_p, 'tflops': v[1] / v[0] / 1e12, 'launches_per_step': v[2] / steps_p,
+             'mfma_frac': v[1] * WINOGRAD_EXECUTED.get(k, 1.0) / v[0] / 1e12 / pk}
+        tr = traffic_of(k) if traffic_of else None
+        if tr:        # HBM side of the same kernel (bytes per launch from the committed capture over this run's launch time)
+            e['hbm_tbs'] = tr['bytes'] / (v[0] / v[2]) / 1e12
+            e['hbm_frac'] = e['hbm_tbs'] / PEAK_HBM_TBS
+            e['bound'] = 'hbm' if e['hbm_frac'] > e['mfma_frac'] else 'mfma'
+        brk[k] = e
+    return {'roofline': roof, 'kernel_breakdown': brk}
 
 
 def measure_train(args, world, rank, dev, overrides, dtype=None, batch=None, steps=None, warmup=None, shared=None):
@@ -487,7 +502,7 @@ def measure_train(args, world, rank, dev, overrides, dtype=None, batch=None, ste
         torch.cuda.synchronize()
         dt_prof = time.perf_counter() - t1
         ops.profile_enable(False)
-        prof = ops.profile_records()
+        prof = ops.profile_records(detail=True)
         ops.enable_side_streams(not args.serial_streams)
     if rank != 0:
         return None
