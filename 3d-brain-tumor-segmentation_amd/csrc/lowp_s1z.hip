@@ -146,9 +146,10 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
   // registers the kernel does not have (256 with scratch spills of 0.9-2 KB per lane; built, measured in the compiler's report, dropped).
   // Per-lane fp32 sums are flushed (wave sum in fp64, one partial row per wave) where the march leaves a group or the item.
   __amdgpu_buffer_rsrc_t cr = yr;
-  float gs0[4], gs1[4];           // (cg <= 4: elements e and e + 4 of a row share a class)
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+  f32x2v gs0[2], gs1[2];          // per-lane sums of the element pairs (0,1) and (2,3) (cg <= 4: elements e and e + 4 of a row share a class)
 #pragma unroll
-  for (int e = 0; e < 4; ++e) gs0[e] = gs1[e] = 0.f;
+  for (int e = 0; e < 2; ++e) gs0[e] = gs1[e] = f32x2v{0.f, 0.f};
   u32x4 cxs[2][2], dst_;
   int zst = -1;                    // plane of the row in dst_
   auto gnb_request = [&](int z) {
@@ -161,28 +162,30 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
         cxs[qp][r] = __builtin_amdgcn_raw_buffer_load_b128(cr, offc, 0, 0);
       }
   };
-  float gpr[4], bpr[4];            // g', b' of the four element classes of the plane being stored (one batch of LDS reads per plane:
-                                   // read where they are used, every one of them cost its own lgkmcnt wait -- 75 per plane)
+  f32x2v gpr[2], bpr[2];           // g', b' of the element pairs of the plane being stored (one batch of LDS reads per plane: read where
+                                   // they are used, every one of them cost its own lgkmcnt wait -- 75 per plane)
   auto gnb_params = [&](int z) {
     const float* gsh = reinterpret_cast<const float*>(lds + OFF_GB) + (z / p.gb_zt) * p.gb.cg;
     const int cmask = p.gb.cg - 1;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { gpr[e] = gsh[e & cmask]; bpr[e] = gsh[32 + (e & cmask)]; }
+    for (int e = 0; e < 2; ++e) {
+      gpr[e] = f32x2v{gsh[(2 * e) & cmask], gsh[(2 * e + 1) & cmask]};
+      bpr[e] = f32x2v{gsh[32 + ((2 * e) & cmask)], gsh[32 + ((2 * e + 1) & cmask)]};
+    }
   };
-  auto gnb_math = [&](const u32x4& crow, bool live) {      // the row just stored (dst_) against its GroupNorm-input row
+  // the row just stored (dst_) against its GroupNorm-input row, two elements (one dword of each) at a time on the packed fp32
+  // instructions: t = c g' + b', dE = [t > 0] d, S1 += dE c, S0 += dE -- 3 packed + 2 selects + 4 unpacks per pair
+  auto gnb_math = [&](const u32x4& crow, bool live) {
     if (live) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const unsigned cw = crow[i], dw = dst_[i];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int e = (2 * i + k) & 3;      // elements e and e + 4 share a class (cg | 4)
-          const float c = T::ld((unsigned short)(k ? cw >> 16 : cw & 0xffffu)), d = T::ld((unsigned short)(k ? dw >> 16 : dw & 0xffffu));
-          const float t = fmaf(c, gpr[e], bpr[e]);
-          const float de = (!p.gb.relu || t > 0.f) ? d : 0.f;
-          gs1[e] = fmaf(de, c, gs1[e]);
-          gs0[e] += de;
-        }
+        const f32x2v c = {T::ld((unsigned short)(cw & 0xffffu)), T::ld((unsigned short)(cw >> 16))};
+        const f32x2v d = {T::ld((unsigned short)(dw & 0xffffu)), T::ld((unsigned short)(dw >> 16))};
+        const f32x2v t = c * gpr[i & 1] + bpr[i & 1];
+        const f32x2v de = {(!p.gb.relu || t[0] > 0.f) ? d[0] : 0.f, (!p.gb.relu || t[1] > 0.f) ? d[1] : 0.f};
+        gs1[i & 1] = de * c + gs1[i & 1];
+        gs0[i & 1] = gs0[i & 1] + de;
       }
     }
   };
@@ -193,7 +196,9 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
       const double gm = (double)gsh[64 + gg], grs = (double)gsh[96 + gg];
       double ra[4], rb[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { ra[e] = wave_sum_f64((double)gs1[e]); rb[e] = wave_sum_f64((double)gs0[e]); gs0[e] = gs1[e] = 0.f; }
+      for (int e = 0; e < 4; ++e) { ra[e] = wave_sum_f64((double)gs1[e >> 1][e & 1]); rb[e] = wave_sum_f64((double)gs0[e >> 1][e & 1]); }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) gs0[e] = gs1[e] = f32x2v{0.f, 0.f};
       if (lane == 0) {
         const int run = p.ZC < p.gb_zt ? (zlo - gg * p.gb_zt) / p.ZC : 0;
         const long slot = ((long)run * (p.nty * p.ntx) + (cy0 / S1Z_TY) * p.ntx + cx0 / S1Z_TX) * 8 + wave;
