@@ -225,15 +225,17 @@ class LowPrecisionTrainer(object):
         key = id(blk)
         wp_pt = self._pk((key, 'pt'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
         wp_c1 = self._pk((key, 'c1'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
-        res, gap = conv1_gap(code, x, wp_pt, blk.ptwise_b.t, f, tdt)      # shortcut conv + the gate's squeeze in one pass
+        # shortcut conv + the gate's squeeze in one pass, then the SE-MLP (main stream: see lowp.gate_branch)
+        res, gap, (hbuf, ch), gate = lowp.gate_branch(code, tdt, x, wp_pt, blk.ptwise_b.t, f, blk.se_w1.t, blk.se_w2.t, side=False)
         c1, m1, r1 = conv_gn(code, tdt, x, wp_c1, blk.conv1_b.t, f, blk.norm1)      # conv + the statistics of its output
-        hbuf, ch = ops.se_mlp_fwd(gap, blk.se_w1.t, blk.se_w2.t)
         a = gn_apply(code, c1, blk.norm1.gamma.t, blk.norm1.beta.t, m1, r1, g, blk.norm1._mode, True)
         wp_c2 = self._pk((key, 'c2'), ops.K3S1, blk.conv2_k, f, f)
         c2, m2, r2 = conv_gn(code, tdt, a, wp_c2, blk.conv2_b.t, f, blk.norm2)
         if out is None:
             out = torch.empty((n, d, h, w, f), dtype=tdt, device=x.device)
         sp = torch.empty(n * v, dtype=torch.float32, device=x.device)
+        if gate is not None:
+            torch.cuda.current_stream().wait_stream(gate)       # the epilogue is where the two branches meet (resnet.py:130,137)
         block_epilogue(code, res, c2, out, blk.spatial_k.t.reshape(-1), ch, blk.norm2.gamma.t, blk.norm2.beta.t, m2, r2, g,
                        blk.norm2._mode, sp_out=sp)
         return out, dict(blk=blk, x=x, res=res, c1=c1, m1=m1, r1=r1, a=a, c2=c2, m2=m2, r2=r2, gap=gap, hbuf=hbuf, ch=ch, sp=sp,

@@ -301,6 +301,8 @@ def measure_infer(args, world, rank, dev, overrides, dtype=None, shape=None, bat
     else:
         run = lowp.LowPrecisionForward(model, {'f16': 'float16', 'bf16': 'bfloat16'}[dt])
         fwd = lambda: run(x)
+    if args.serial_streams:
+        ops.enable_side_streams(False)
     for _ in range(warmup):
         y = fwd()
     torch.cuda.synchronize()
@@ -327,6 +329,9 @@ def measure_infer(args, world, rank, dev, overrides, dtype=None, shape=None, bat
     prof = None
     prof_steps = min(steps, 5)
     if not args.no_profile and rank == 0:
+        ops.enable_side_streams(False)      # (one stream: a launch that shares the chip with the gate stream has no duration of its own)
+        y = fwd()
+        torch.cuda.synchronize()
         ops.profile_enable(True)
         t1 = time.perf_counter()
         for _ in range(prof_steps):
@@ -335,6 +340,7 @@ def measure_infer(args, world, rank, dev, overrides, dtype=None, shape=None, bat
         dt_prof = time.perf_counter() - t1
         ops.profile_enable(False)
         prof = ops.profile_records(detail=True)
+        ops.enable_side_streams(not args.serial_streams)
     if rank != 0:
         return None
     sec = dts / steps
@@ -363,7 +369,7 @@ def measure_infer(args, world, rank, dev, overrides, dtype=None, shape=None, bat
     if prof:
         sfx = '_infer_f16' if dt == 'f16' else '_infer_' + dt
         out.update(_roofline_from_records(prof, prof_steps, dt_prof, (lambda sym: pmc_traffic(sym, sfx)) if canonical else None,
-                                          'HIP events on the launch stream over %d further forwards right after the timed region' % prof_steps))
+                                          'HIP events on the launch stream over %d further one-stream forwards right after the timed region' % prof_steps))
     del model
     return out
 
