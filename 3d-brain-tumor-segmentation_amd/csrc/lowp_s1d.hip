@@ -507,13 +507,13 @@ static double s1d_plan_shape(int N, int D, int H, int W, int Cin, int Cout, int 
   auto cost = [&](int per, int split) { return ((double)((pl.nitems * split + 255) / 256) + 0.1 * (double)(pl.nitems * split) / 256.0) * (per + 1.5); };
   pl.ksplit = 1; pl.ks_per = KS;
   double best = cost(KS, 1);
-  if (pl.nitems < 160 && KS >= 4) {
+  { const char* e = getenv("BTS_LP_S1D_SPLIT_ITEMS"); if (pl.nitems < (e ? atol(e) : 160) && KS >= 4) {
     for (int ks = 2; ks <= KS / 2 && ks <= 16; ++ks) {
       const int per = (KS + ks - 1) / ks, split = (KS + per - 1) / per;
       const double c = cost(per, split) + 0.5 * split;      // (+ the reduce pass grows with the split)
       if (c < best - 1e-9) { best = c; pl.ks_per = per; pl.ksplit = split; }
     }
-  }
+  } }
   return best;
 }
 static bool s1d_plan(int N, int D, int H, int W, int Cin, int Cout, S1dPlan& pl) {

@@ -90,23 +90,31 @@ def pmc_traffic(symbol, suffix=''):
     if key.endswith('<3x3x3>') or key.endswith('<1x1x1>'):      # lp_wgrad_kernel<T, NQ, K3>: the kernel size is its last template argument
         want_tail = 'true>' if key.endswith('<3x3x3>') else 'false>'
         key = key.split('<')[0]
-    best = None
+    # every capture entry the symbol covers: one template instantiation for a full name, all of them for a bare one (the library's
+    # launch records lump e.g. lp_k1_kernel / lp_k1f_kernel<...> under one name) -- launch-weighted means over those
+    hits = []
     for k, v in tab.items():
         if k.startswith('_'):
             continue
         nk = norm(k)
         if want_tail is not None and not nk.endswith(want_tail):
             continue
-        if (nk == key or (('<' not in key) and nk.split('<')[0] == key)) and _kernel_bytes(v) is not None:
-            if best is None or v['launches'] > best['launches']:
-                best = v
-    if best is None:
+        base = nk.split('<')[0]
+        fam = base == key or (key == 'lp_k1_kernel' and base == 'lp_k1f_kernel') or (key == 'lp_conv_gather_kernel' and base == 'lp_conv_gatherq_kernel')
+        if (nk == key or (('<' not in key) and fam)) and _kernel_bytes(v) is not None:
+            hits.append(v)
+    if not hits:
         return None
-    read, write, how = _kernel_bytes(best)
+    n = float(sum(v['launches'] for v in hits))
+    wmean = lambda f: sum(f(v) * v['launches'] for v in hits) / n
+    read, write = wmean(lambda v: _kernel_bytes(v)[0]), wmean(lambda v: _kernel_bytes(v)[1])
+    how = _kernel_bytes(hits[0])[2]
+    opt = lambda name: (wmean(lambda v: v.get(name, 0.0)) if all(name in v for v in hits) else None)
     return {'bytes': read + write, 'read_bytes': read, 'write_bytes': write, 'read_side': how,
-            'fetch_size_kib_raw': best['FETCH_SIZE_KiB_mean'], 'write_size_kib_raw': best['WRITE_SIZE_KiB_mean'],
-            'rdreq_raw': best.get('TCC_EA0_RDREQ_sum_mean'), 'rdreq_32b_raw': best.get('TCC_EA0_RDREQ_32B_sum_mean'),
-            'rdreq_64b_raw': best.get('TCC_EA0_RDREQ_64B_sum_mean'), 'rdreq_128b_raw': best.get('TCC_EA0_RDREQ_128B_sum_mean'), 'launches_in_capture': best['launches'], 'source': 'committed capture ' + src}
+            'fetch_size_kib_raw': opt('FETCH_SIZE_KiB_mean'), 'write_size_kib_raw': opt('WRITE_SIZE_KiB_mean'),
+            'rdreq_raw': opt('TCC_EA0_RDREQ_sum_mean'), 'rdreq_32b_raw': opt('TCC_EA0_RDREQ_32B_sum_mean'),
+            'rdreq_64b_raw': opt('TCC_EA0_RDREQ_64B_sum_mean'), 'rdreq_128b_raw': opt('TCC_EA0_RDREQ_128B_sum_mean'),
+            'launches_in_capture': int(n), 'variants_in_capture': len(hits), 'source': 'committed capture ' + src}
 
 
 # algorithmic work per unit (CLI-default model).  Training volume 2ch x 128^3: 6.517 TFLOP (fwd 2,172.2 GFLOP, bwd 2x);
