@@ -47,7 +47,8 @@ struct LpS1dParams {
   // item order: cout group fastest, then the tiles of a block of bx x by x bz tiles (x fastest), then the blocks (x fastest), then
   // the samples -- a block is what the 32 workgroups of an XCD hold at a time, so the halo voxels its tiles share are fetched from
   // HBM once and found in that XCD's L2 by the neighbours.  Divisions by run-time constants as multiply-high + shift.
-  int dbg;          // timing experiments (builds with -DBTS_TIMING_EXPERIMENTS only): 1 no output stores, 2 no halo traffic, 4 no matrix instructions
+  int dbg;          // timing experiments (builds with -DBTS_TIMING_EXPERIMENTS only): 1 no output stores, 2 no halo traffic, 4 no matrix instructions,
+                    // 8 no fragment reads from LDS, 16 no weight traffic
   int bx, by, bz_;
   unsigned bvol_, nbx_, nby_, nbz_;
   unsigned dv_mul[7], dv_sh[7];    // divisors: ncg, bx*by*bz, bx, by, ntx/bx, nty/by, ntz/bz
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
     wdst[r] = c < G::NWC ? G::OFF_W + c * 1024 : G::OFF_SCR;
   }
   auto w_soff = [&](int cg, int ks, int dz, bool live) -> unsigned {
+    if (BTS_DBG(p) & 16) return 0x80000000u;
     return live ? (unsigned)((((cg * p.KS + ks) * 3) + dz) * G::WSTAGE) : 0x80000000u;    // (no next item: nothing to fetch)
   };
   auto issue_w1 = [&](int r, unsigned soff, int dz) {
@@ -220,11 +222,13 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
   u32x4 Bc[6], Ac[3], Bn[6], An[3];
   auto ldB = [&](u32x4 (&B)[6], const unsigned char* hb, auto dzc, auto dxc) {     // hb = the halo buffer of this k-step
     constexpr int DZ = decltype(dzc)::value, DX = decltype(dxc)::value;
+    if (BTS_DBG(p) & 8) { asm volatile("" : "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]), "+v"(B[4]), "+v"(B[5])); return; }
 #pragma unroll
     for (int j = 0; j < 6; ++j) B[j] = *reinterpret_cast<const u32x4*>(hb + hbB[DX] + ((DZ * PS) + j * SX) * 32);
   };
   auto ldA = [&](u32x4 (&A)[3], auto dzc, auto dxc) {
     constexpr int DZ = decltype(dzc)::value, DX = decltype(dxc)::value;
+    if (BTS_DBG(p) & 8) { asm volatile("" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2])); return; }
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) A[dy] = *reinterpret_cast<const u32x4*>(lds + wbA + DZ * G::WSTAGE + (dy * 3 + DX) * G::WTAP);
   };

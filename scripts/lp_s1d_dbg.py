@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """lp_s1d under its timing switches (a -DBTS_TIMING_EXPERIMENTS build, BTS_HIP_LIB=...): BTS_S1D_DBG 0 = normal, 1 = no output stores,
-2 = no halo traffic, 4 = no matrix instructions"""
+2 = no halo traffic, 4 = no matrix instructions, 8 = no fragment reads from LDS, 16 = no weight traffic (sums combine)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bts_amd  # noqa
@@ -13,7 +13,7 @@ for shape, cin, cout in (((8, 64, 64, 64), 64, 64), ((8, 128, 128, 128), 64, 32)
     b = torch.zeros(cout, device=D)
     wp = lowp.pack(ops.K3S1, code, wt, cin, cout)
     os.environ['BTS_LP_S1Z'] = '0'
-    for dbg in ('0', '1', '2', '4', '3'):
+    for dbg in ('0', '1', '2', '4', '3', '8', '12', '16', '18', '19', '27', '31'):
         os.environ['BTS_S1D_DBG'] = dbg
         for _ in range(3):
             lowp.conv(ops.K3S1, code, tdt, x, wp, b, cout)
