@@ -48,7 +48,8 @@ int bts_lp_k1_launch_(int dtype, const void* x, const void* wp, const float* bia
                       int accum, double* gap_part, int gap_block, hipStream_t stream);
 // lowp_up.hip: transposed form, all eight output classes in one pass (offered first; 1 = declined)
 int bts_lp_up_launch_(int dtype, const void* x, const void* wp_dma, const float* bias, void* y, int N, int D, int H, int W, int Cin, int ldx,
-                      int Cout, int ldy, int accum, hipStream_t stream);
+                      int Cout, int ldy, int accum, hipStream_t stream, double* gnp = nullptr, int gn_G = 0);
+long bts_lp_up_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn);
 int bts_lp_s1d_launch_(int dtype, const void* x, const void* wp_dma, const float* bias, void* y, void* ws, long ws_bytes, int N, int D, int H,
                        int W, int Cin, int ldx, int Cout, int ldy, int accum, double* gnp, int gn_G, hipStream_t stream);
 
@@ -966,9 +967,10 @@ static int lp_conv_run(int geo, int dtype, const void* x, const void* wp, const 
   if (geo == 3) {  // y[2i+k] += x[i] w[k], cropped to [0, 2n): 8 output-parity classes, every output written once
     {
       const int r = bts_lp_up_launch_(dtype, x, reinterpret_cast<const char*>(wp) + lp_s1d_part_offset(Cin, Cout), bias, y, N, D, H, W, Cin, ldx,
-                                      Cout, ldy, accum, stream);
+                                      Cout, ldy, accum, stream, gn_part, gn_G);
       if (r != 1) return r;
     }
+    if (gn_part != nullptr) return 1;      // (only the merged kernel emits the statistics: nothing was launched)
     g.Do = 2 * D; g.Ho = 2 * H; g.Wo = 2 * W; g.Dg = D; g.Hg = H; g.Wg = W; g.s = 1; g.os = 2;
     for (int cls = 0; cls < 8; ++cls) {
       const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
@@ -1058,6 +1060,35 @@ extern "C" int bts_lp_conv3d_fwd_gn(int dtype, const void* x, const void* wp, co
   const int r = lp_conv_run(1, dtype, x, wp, bias, y, workspace, conv_ws, N, D, H, W, Cin, ldx, Cout, Cout, 0, stream);
   if (r != BTS_OK) return r;
   return bts_lp_gn_stats(dtype, y, mean, rstd, tail, workspace_bytes - conv_ws, N, V, Cout, G, BTS_GN_SLAB, eps, stream);
+}
+// y = Conv3DTranspose(k3, s2, 'same')(x) + bias (dense fine tensor, storage type) AND the slab-mode GroupNorm statistics of y -- ConvUpsample
+// (upsample.py:28-43: conv -> GroupNormalization) without the statistics pass over the fine tensor: (sum, sumsq) partials leave the
+// merged transposed-conv kernel's epilogue per fine plane.  (D,H,W) = the COARSE grid.  Shapes that kernel declines, or fine z-slabs
+// that are not whole planes, run the conv and bts_lp_gn_stats on the stored y.
+extern "C" long bts_lp_convT3d_fwd_gn_workspace(int N, int D, int H, int W, int Cin, int Cout, int G) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || G <= 0 || Cout % G != 0) return -1;
+  const long B = bts_lp_up_gn_B_(N, D, H, W, Cin, Cout, G);
+  const long fused = B > 0 ? (long)N * G * B * 16 + 64 : 0;
+  const long stats = bts_lp_gn_workspace(N, 8L * D * H * W, Cout, G);
+  return (fused > stats ? fused : stats) + 64;
+}
+extern "C" int bts_lp_convT3d_fwd_gn(int dtype, const void* x, const void* wp, const float* bias, void* y, float* mean, float* rstd,
+                                     void* workspace, long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int G,
+                                     float eps, hipStream_t stream) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || G <= 0 || Cout % G != 0) return BTS_ERR_SHAPE;
+  if (workspace == nullptr || workspace_bytes < bts_lp_convT3d_fwd_gn_workspace(N, D, H, W, Cin, Cout, G) || (((uintptr_t)workspace) & 15))
+    return BTS_ERR_WORKSPACE;
+  const long Vf = 8L * D * H * W;
+  const long B = (Cin % 16 == 0) ? bts_lp_up_gn_B_(N, D, H, W, Cin, Cout, G) : 0;
+  if (B > 0) {
+    double* part = reinterpret_cast<double*>(workspace);
+    const int r = lp_conv_run(3, dtype, x, wp, bias, y, nullptr, 0, N, D, H, W, Cin, ldx, Cout, Cout, 0, stream, nullptr, part, G);
+    if (r == BTS_OK) return bts_gn_finalize_partials_(part, mean, rstd, N * G, B, (double)(Vf * Cout / G), eps, stream);
+    if (r != 1) return r;
+  }
+  const int r = lp_conv_run(3, dtype, x, wp, bias, y, nullptr, 0, N, D, H, W, Cin, ldx, Cout, Cout, 0, stream);
+  if (r != BTS_OK) return r;
+  return bts_lp_gn_stats(dtype, y, mean, rstd, workspace, workspace_bytes, N, Vf, Cout, G, BTS_GN_SLAB, eps, stream);
 }
 __global__ __launch_bounds__(256) void lp_colsum_finalize_kernel(const double* partial, float* out, int N, int C, int B, double scale);
 // res = conv1x1x1(x) + bias in the storage type AND gap[n][c] = mean over the voxels of (the unrounded) res -- the block's shortcut

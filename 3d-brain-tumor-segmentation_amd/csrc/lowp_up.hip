@@ -40,6 +40,11 @@ struct LpUpParams {
   int ntx, nty, ntz, ncg;
   long nitems;
   int accum;
+  // fused GroupNorm partial sums of the fine tensor (slab semantics: whole fine planes per group) [N*G][gn_B][2] fp64, or NULL.
+  // One (sum, sumsq) pair per (fine z plane, tile row, tile column, cout group, wave sharing that plane): fixed order
+  double* gnp;
+  int gn_G, gn_zt;
+  long gn_B;
 };
 
 template <int MODE, int TXL>
@@ -240,6 +245,8 @@ __global__ __launch_bounds__(512, 2) void lp_up_kernel(const LpUpParams p) {
       const __amdgpu_buffer_rsrc_t yr =
           __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long)ci.n * 8L * p.D * p.H * p.W * (long)p.ldy), 0, 0x7fffffff, 0x00020000);
       const bool inb = gz < p.D && gy < p.H && gx < p.W;
+      const bool gn_on = p.gnp != nullptr;
+      float gn_s[2] = {0.f, 0.f}, gn_q[2] = {0.f, 0.f};      // per fine plane 2 gz + pz of this lane
 #pragma unroll
       for (int cls = 0; cls < 8; ++cls) {
         const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
@@ -261,11 +268,39 @@ __global__ __launch_bounds__(512, 2) void lp_up_kernel(const LpUpParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { f[j] += old[j]; g2[j] += old[4 + j]; }
           }
+          if (gn_on && ok) {      // (own values, before the exchange: the sums run over all lanes anyway)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              gn_s[pz] += f[j] + g2[j];
+              gn_q[pz] = fmaf(f[j], f[j], fmaf(g2[j], g2[j], gn_q[pz]));
+            }
+          }
           unsigned d0 = pack2<T>(f[0], f[1]), d1 = pack2<T>(f[2], f[3]), d2 = pack2<T>(g2[0], g2[1]), d3 = pack2<T>(g2[2], g2[3]);
           asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\tv_nop"
                        : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
           __builtin_amdgcn_raw_buffer_store_b128(u32x4{d0, d1, d2, d3}, yr, off, 0, 0);
         }
+      }
+      if (gn_on) {
+        constexpr int WPZ = 8 / G::RZ;                       // waves of an item that share a coarse z unit
+        const int wsub = MODE ? wave : (wave & 3);           // this wave's index among them
+        const int ty = ci.gy0 / G::TY, tx = ci.gx0 / TX;
+#pragma unroll
+        for (int zl = 0; zl < ZP; ++zl)
+#pragma unroll
+          for (int pz = 0; pz < 2; ++pz) {
+            const bool mine = (ZP == 1) || lz == zl;
+            const double ds = wave_sum_f64(mine ? (double)gn_s[pz] : 0.0), dq = wave_sum_f64(mine ? (double)gn_q[pz] : 0.0);
+            const int gzc = ci.gz0 + wz * ZP + zl;          // coarse plane
+            const int zf = 2 * gzc + pz;                    // fine plane
+            if (lane == 0 && gzc < p.D) {
+              const int gg = zf / p.gn_zt;
+              const long slot = (((((long)(zf - gg * p.gn_zt) * p.nty + ty) * p.ntx + tx) * p.ncg + ci.cg) * WPZ) + wsub;
+              double* dst = p.gnp + (((long)ci.n * p.gn_G + gg) * p.gn_B + slot) * 2;
+              dst[0] = ds;
+              dst[1] = dq;
+            }
+          }
       }
     }
     after_out = true;
@@ -320,11 +355,20 @@ static int up_launch_t(const LpUpParams& p, hipStream_t stream) {
   return BTS_OK;
 }
 
+// GroupNorm-partial slots per (n, group) of the FINE tensor when the kernel takes the shape and can emit them (whole fine planes per
+// group); 0 otherwise
+long bts_lp_up_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn) {
+  UpPlan pl;
+  if (Gn <= 0 || (2 * D) % Gn != 0 || !up_plan(N, D, H, W, Cin, Cout, pl)) return 0;
+  return (long)(2 * D / Gn) * pl.nty * pl.ntx * pl.ncg * (pl.mode ? 8 : 4);
+}
 // BTS_OK = ran, 1 = declined.  x: coarse (N,D,H,W,Cin); y: fine (N,2D,2H,2W,Cout); wp_dma: the DMA part of the image.
+// gnp (may be NULL): fused GroupNorm partial sums of y, [N*gn_G][bts_lp_up_gn_B_][2]
 int bts_lp_up_launch_(int dtype, const void* x, const void* wp_dma, const float* bias, void* y, int N, int D, int H, int W, int Cin, int ldx,
-                      int Cout, int ldy, int accum, hipStream_t stream) {
+                      int Cout, int ldy, int accum, hipStream_t stream, double* gnp, int gn_G) {
   UpPlan pl;
   if (!up_plan(N, D, H, W, Cin, Cout, pl)) return 1;
+  if (gnp != nullptr && (gn_G <= 0 || (2 * D) % gn_G != 0)) return 1;
   if (ldx % 8 != 0 || ldy % 8 != 0 || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 15) || (((uintptr_t)wp_dma) & 15)) return 1;
   if (((long)(D + 2) * H * W + 64) * (long)ldx * 2 >= 0x7fffffffL) return 1;
   if ((8L * D * H * W + 64) * (long)ldy * 2 >= 0x7fffff00L) return 1;
@@ -332,6 +376,8 @@ int bts_lp_up_launch_(int dtype, const void* x, const void* wp_dma, const float*
   p.x = (const unsigned short*)x; p.wp = (const unsigned short*)wp_dma; p.bias = bias; p.y = (unsigned short*)y;
   p.N = N; p.D = D; p.H = H; p.W = W; p.ldx = ldx; p.ldy = ldy; p.Cout = Cout; p.KS = Cin / 16; p.NB = (Cout + 31) / 32;
   p.ntx = pl.ntx; p.nty = pl.nty; p.ntz = pl.ntz; p.ncg = pl.ncg; p.nitems = pl.nitems; p.accum = accum;
+  p.gnp = gnp; p.gn_G = gn_G; p.gn_zt = gn_G > 0 ? 2 * D / gn_G : 1;
+  p.gn_B = gn_G > 0 ? (long)p.gn_zt * pl.nty * pl.ntx * pl.ncg * (pl.mode ? 8 : 4) : 0;
   const bool prof = bts_prof_on();
   if (prof) bts_prof_begin(35, 2.0 * 27.0 * Cin * (double)Cout * (double)N * D * H * W, stream);
   int r;

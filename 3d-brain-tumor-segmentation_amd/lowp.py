@@ -213,6 +213,23 @@ def gn_bwd(code, tdt, x, dy, gamma, beta, mean, rstd, dgamma, dbeta, groups, rel
     return dx, dx32
 
 
+def convT_gn(code, tdt, x, wp, bias, cout, norm):
+    """(y, mean, rstd): y = Conv3DTranspose(k3, s2, 'same')(x) + bias (dense fine tensor, storage type) and GroupNorm `norm`'s statistics
+    of y -- from the merged transposed-conv kernel's epilogue where the library can (slab mode, whole fine planes per group)"""
+    n, d, h, w, cin = x.shape
+    if norm._mode != ops.GN_SLAB:
+        y = conv(ops.K3S2T, code, tdt, x, wp, bias, cout)
+        return (y,) + tuple(gn_stats(code, y, norm.groups, norm._mode, norm.epsilon))
+    y = torch.empty((n, 2 * d, 2 * h, 2 * w, cout), dtype=tdt, device=x.device)
+    mean = torch.empty(n * norm.groups, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(n * norm.groups, dtype=torch.float32, device=x.device)
+    nb = lib().query('bts_lp_convT3d_fwd_gn_workspace', n, d, h, w, cin, cout, norm.groups)
+    ws = ops.workspace(nb, x.device)
+    lib().call('bts_lp_convT3d_fwd_gn', code, _p(x), _p(wp), _p(bias), _p(y), _p(mean), _p(rstd), _p(ws), nb, n, d, h, w, cin, _ld(x), cout,
+               norm.groups, float(norm.epsilon), _stream())
+    return y, mean, rstd
+
+
 def conv_bwd_data_gn_bwd(code, tdt, dy, wp_bwd, c, gamma, beta, mean, rstd, dgamma, dbeta, groups, relu, want_f32=True, dbias=None):
     """conv2's data gradient followed by GroupNorm-1's backward (resnet.py:80-93 in reverse) as one library call -> (da, dc, dc32 | None,
     fused): da = conv3x3x3^T(dy) stored in the storage type, dc the gradient of the GroupNorm input c; where the z-marching conv kernel
@@ -472,8 +489,8 @@ class LowPrecisionForward(object):
             c = conv(ops.K1, self.code, self.tdt, x, wp, lay.ptwise_b.t, lay.filters)
             return upsample2(self.code, c, out=out)
         wp = self._packed((id(lay), 'f'), ops.K3S2T, lay.conv_k, lay.cin, lay.filters)
-        c = conv(ops.K3S2T, self.code, self.tdt, x, wp, lay.conv_b.t, lay.filters)
-        return self._gn(lay.norm, c, True, out=out)
+        c, m_, r_ = convT_gn(self.code, self.tdt, x, wp, lay.conv_b.t, lay.filters, lay.norm)      # conv + the statistics of its output
+        return gn_apply(self.code, c, lay.norm.gamma.t, lay.norm.beta.t, m_, r_, lay.norm.groups, lay.norm._mode, True, out=out)
 
     def __call__(self, x):
         m = self.model

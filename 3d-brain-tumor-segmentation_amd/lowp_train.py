@@ -349,8 +349,11 @@ class LowPrecisionTrainer(object):
             y = lowp.upsample2(self.code, c, out=out)
             return y, dict(lay=lay, kind='linear', x=x)
         wp = self._pk((id(lay), 'f'), kind, lay.conv_k, lay.cin, lay.filters)
-        c = conv(kind, self.code, self.tdt, x, wp, lay.conv_b.t, lay.filters)
-        m, r = gn_stats(self.code, c, lay.norm.groups, lay.norm._mode, lay.norm.epsilon)
+        if kind == ops.K3S2T:       # transposed conv with the statistics of its (fine) output from its epilogue
+            c, m, r = lowp.convT_gn(self.code, self.tdt, x, wp, lay.conv_b.t, lay.filters, lay.norm)
+        else:
+            c = conv(kind, self.code, self.tdt, x, wp, lay.conv_b.t, lay.filters)
+            m, r = gn_stats(self.code, c, lay.norm.groups, lay.norm._mode, lay.norm.epsilon)
         y = gn_apply(self.code, c, lay.norm.gamma.t, lay.norm.beta.t, m, r, lay.norm.groups, lay.norm._mode, True, out=out)
         return y, dict(lay=lay, kind=kind, x=x, c=c, m=m, r=r)
 

@@ -304,6 +304,14 @@ long bts_lp_conv3d_fwd_gn_workspace(int N, int D, int H, int W, int Cin, int Cou
 int bts_lp_conv3d_fwd_gn(int dtype, const void* x, const void* wp, const float* bias, void* y, float* mean, float* rstd, void* workspace,
                          long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int G, float eps,
                          bts_stream_t stream);
+/* y = Conv3DTranspose(k3, s2, 'same')(x) + bias (dense fine tensor (N,2D,2H,2W,Cout), storage type) and the slab-mode GroupNorm
+ * statistics of y in one pass: ConvUpsample (upsample.py:28-43: conv -> GroupNormalization) without a statistics pass over the fine
+ * tensor.  (D,H,W): the COARSE grid; wp = bts_lp_pack(BTS_CONV_K3S2T, BTS_ROLE_FWD, ...).  Falls back to the conv + bts_lp_gn_stats
+ * where the merged transposed-conv kernel declines the shape or a group is not whole fine planes. */
+long bts_lp_convT3d_fwd_gn_workspace(int N, int D, int H, int W, int Cin, int Cout, int G);
+int bts_lp_convT3d_fwd_gn(int dtype, const void* x, const void* wp, const float* bias, void* y, float* mean, float* rstd, void* workspace,
+                          long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int G, float eps,
+                          bts_stream_t stream);
 /* res = conv1x1x1(x) + bias in the storage type (dense, ldres == Cout) and gap[n][c] = mean over voxels of res: the block's
  * shortcut and the squeeze of its gate (resnet.py:118-121) in one pass (column sums from the conv epilogue + a small finalize) */
 long bts_lp_conv1_gap_workspace(int N, long V, int Cout);

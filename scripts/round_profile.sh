@@ -60,7 +60,9 @@ cp "$(need "$O/prof_${TAG}_inf" bench_kernel_stats.csv)" "$O/${TAG}_infer_f16_ke
 REQ="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"   # (all four exist on gfx950: rocprofv3 -L, round 4)
 traffic_passes() {   # traffic_passes <suffix> <bench args...>
   local sfx=$1; shift
-  for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "req:$REQ"; do
+  # (GRBM_GUI_ACTIVE rides on the WRITE_SIZE pass -- the GRBM block has its own slots: busy cycles summed over the 8 XCDs, which over
+  # the launch's duration in the same pass is the clock the part held under that kernel)
+  for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE GRBM_GUI_ACTIVE" "req:$REQ"; do
     local name=${pass%%:*} ctr=${pass#*:}
     rm -rf "$O/pmc_${TAG}${sfx}_$name"
     # shellcheck disable=SC2086
@@ -84,6 +86,8 @@ for sfx in ('', '_bf16_b8', '_infer_f16'):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(files[0])):
             agg[r['Kernel_Name'].split('(')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
+            if r['Counter_Name'] == 'GRBM_GUI_ACTIVE':       # duration of the same dispatch, for the clock
+                agg[r['Kernel_Name'].split('(')[0]]['duration_ns'].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
         assert agg, 'no rows in %s' % files[0]
         for k, cs in agg.items():
             for ctr, v in cs.items():

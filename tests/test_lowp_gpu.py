@@ -490,6 +490,40 @@ def test_conv_with_fused_groupnorm_statistics(case, dtype):
 
 
 @pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('case', [((1, 16, 16, 32), 32, 32, 8), ((2, 8, 8, 16), 64, 64, 8), ((1, 12, 10, 24), 32, 16, 4), ((1, 6, 8, 16), 16, 32, 8),
+                                  ((1, 4, 4, 8), 32, 32, 8)],
+                         ids=['32-32-g8', 'batch2-64-64-two-cout-blocks', 'ragged-16-couts-g4', 'slab-not-whole-planes', 'too-small-for-the-merged-kernel'])
+def test_transposed_conv_with_fused_groupnorm_statistics(case, dtype):
+    """bts_lp_convT3d_fwd_gn (ConvUpsample's conv -> GroupNormalization, upsample.py:28-43): y bit-equal to the plain 16-bit transposed
+    conv's, (mean, rstd) against the fp64 slab statistics of the oracle's transposed conv on the rounded operands; cases where the
+    merged kernel declines or a group is not whole fine planes take the two-pass route inside the same entry point"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    (n, d, h, w), cin, cout, G = case
+    code, tdt = lowp.DTYPES[dtype]
+    g = torch.Generator().manual_seed(cin * 5 + cout + d)
+    x = torch.randn((n, d, h, w, cin), generator=g)
+    wt = torch.randn((3, 3, 3, cout, cin), generator=g) * (2.0 / (27 * cin / 8)) ** 0.5
+    b = torch.randn(cout, generator=g)
+    xin = x.to(tdt).to(DEV)
+    wp = lowp.pack(ops.K3S2T, code, wt.to(DEV), cin, cout)
+
+    class _Norm(object):
+        groups, epsilon, _mode = G, 1e-5, ops.GN_SLAB
+    y, mean, rstd = lowp.convT_gn(code, tdt, xin, wp, b.to(DEV), cout, _Norm)
+    y_ref = lowp.conv(ops.K3S2T, code, tdt, xin, wp, b.to(DEV), cout)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == (n, 2 * d, 2 * h, 2 * w, cout) and torch.equal(y, y_ref)
+    y64 = R.conv3d_transpose(_round(x, tdt), _round(wt, tdt), b.double())
+    slabs = y64.reshape(n, G, -1)
+    m_ref = slabs.mean(dim=2).reshape(-1)
+    r_ref = 1.0 / torch.sqrt(slabs.var(dim=2, unbiased=False) + 1e-5).reshape(-1)
+    scale = float(y64.abs().mean())
+    assert float((mean.double().cpu() - m_ref).abs().max()) <= U[dtype] * scale * 0.05 + 1e-5
+    assert float((rstd.double().cpu() / r_ref - 1).abs().max()) <= U[dtype] * 0.05 + 1e-5
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
 def test_backward_apply_passes_emit_the_producing_convs_bias_gradient(dtype):
     """bts_lp_gn_bwd / bts_lp_se_bwd with dbias: the column sums of the tensor the pass writes (the dy of the conv in front of the
     GroupNorm, resnet.py:80-93; of the 1x1x1 shortcut, resnet.py:96-103) leave from the same pass; they must equal the sums of the
