@@ -1220,6 +1220,34 @@ __global__ __launch_bounds__(256) void lp_uncast_kernel(const unsigned short* sr
     dst[r * ldd + c] = T::ld(src[r * lds_ + c]);
   }
 }
+// fp32 rows of C (<= 4) channels -> storage-type rows of 16 channels, the tail zero: the 2-channel volume / VAE-output gradient and
+// the 1-channel VAE tensor as whole matrix steps in ONE pass (a zero fill of the 16-channel tensor + bts_lp_cast into its first
+// channels wrote every row twice: 0.28 ms per 8 x 128^3 tensor)
+template <typename T, int C>
+__global__ __launch_bounds__(256) void lp_cast_pad16_kernel(const float* __restrict__ src, long lds_, unsigned short* __restrict__ dst, long rows) {
+  for (long r = blockIdx.x * 256L + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c] = src[r * lds_ + c];
+    u32x4* o = reinterpret_cast<u32x4*>(dst + r * 16);
+    o[0] = u32x4{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), 0u, 0u};
+    o[1] = u32x4{0u, 0u, 0u, 0u};
+  }
+}
+extern "C" int bts_lp_cast_pad16(int dtype, const float* src, long ld_src, void* dst, long rows, int C, hipStream_t stream) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  if (rows <= 0 || C <= 0 || C > 4 || ld_src < C) return BTS_ERR_SHAPE;
+  if (((uintptr_t)dst) & 15) return BTS_ERR_ALIGN;
+  long blocks = (rows + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  (void)hipGetLastError();
+#define LP_CP(TT, C_) hipLaunchKernelGGL((lp_cast_pad16_kernel<TT, C_>), dim3((unsigned)blocks), dim3(256), 0, stream, src, ld_src, (unsigned short*)dst, rows)
+  if (dtype == LP_F16) { if (C == 1) LP_CP(TF16, 1); else if (C == 2) LP_CP(TF16, 2); else if (C == 3) LP_CP(TF16, 3); else LP_CP(TF16, 4); }
+  else { if (C == 1) LP_CP(TBF16, 1); else if (C == 2) LP_CP(TBF16, 2); else if (C == 3) LP_CP(TBF16, 3); else LP_CP(TBF16, 4); }
+#undef LP_CP
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
 extern "C" int bts_lp_uncast(int dtype, const void* src, long ld_src, float* dst, long ld_dst, long rows, int C, hipStream_t stream) {
   if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
   if (rows <= 0 || C <= 0) return BTS_ERR_SHAPE;

@@ -146,6 +146,15 @@ def cast(code, tdt, src, out=None):
     return out
 
 
+def cast_pad16(code, tdt, src):
+    """fp32 (..., C <= 4) -> storage type (..., 16) with a zero tail, one pass (the 2- / 1-channel tensors as whole matrix steps)"""
+    c = src.shape[-1]
+    rows = src.numel() // c
+    out = torch.empty(tuple(src.shape[:-1]) + (16,), dtype=tdt, device=src.device)
+    lib().call('bts_lp_cast_pad16', code, _p(src), src.stride(-2), _p(out), rows, c, _stream())
+    return out
+
+
 def uncast(code, src):
     c = src.shape[-1]
     rows = src.numel() // c
@@ -510,10 +519,13 @@ class LowPrecisionForward(object):
         if any(s % (2 ** (m.encoder.depth - 1)) for s in x.shape[1:4]):
             raise ValueError('spatial sizes must be multiples of %d (test.py:164-178 pads to that)' % 2 ** (m.encoder.depth - 1))
         # the input volume in the storage type, zero-padded to one 16-channel matrix step (in_ch = 2: model.py:18)
-        cpad = (x.shape[-1] + 15) // 16 * 16
-        xin = torch.zeros(tuple(x.shape[:4]) + (cpad,), dtype=self.tdt, device=x.device)
-        cast(self.code, self.tdt, x, out=xin[..., :x.shape[-1]])
-        x = xin
+        if x.shape[-1] <= 4:
+            x = cast_pad16(self.code, self.tdt, x)
+        else:
+            cpad = (x.shape[-1] + 15) // 16 * 16
+            xin = torch.zeros(tuple(x.shape[:4]) + (cpad,), dtype=self.tdt, device=x.device)
+            cast(self.code, self.tdt, x, out=xin[..., :x.shape[-1]])
+            x = xin
         enc, dec = m.encoder, m.decoder
         n = x.shape[0]
         residuals = []

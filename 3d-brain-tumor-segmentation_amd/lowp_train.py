@@ -451,9 +451,12 @@ class LowPrecisionTrainer(object):
                 enc._seed += 1
                 msk = ops.dropout_mask(x.shape, enc.dropout_rate, enc._seed, dev)
             xin = ops.dropout_apply(x, msk, enc.dropout_rate)
-        cpad = (x.shape[-1] + 15) // 16 * 16
-        cur = torch.zeros(tuple(x.shape[:4]) + (cpad,), dtype=tdt, device=dev)
-        cast(code, tdt, xin, out=cur[..., :x.shape[-1]])
+        if x.shape[-1] <= 4 and xin.is_contiguous():      # in_ch = 2 (model.py:18): one pass writes the whole 16-channel matrix step
+            cur = lowp.cast_pad16(code, tdt, xin)
+        else:
+            cpad = (x.shape[-1] + 15) // 16 * 16
+            cur = torch.zeros(tuple(x.shape[:4]) + (cpad,), dtype=tdt, device=dev)
+            cast(code, tdt, xin, out=cur[..., :x.shape[-1]])
         del xin
         levels = []                     # per encoder level: (slab, used, [block saves], down save or None)
         for i, (convs, down) in enumerate(enc.levels):
@@ -502,8 +505,7 @@ class LowPrecisionTrainer(object):
         z = ops.vae_sample_fwd(proj, eps)
         u = ops.dense_fwd(z, vae.unproj_k.t, vae.unproj_b.t, True)
         u5 = u.reshape((n,) + tuple(vae._unflat))
-        u16 = torch.zeros(tuple(u5.shape[:4]) + (16,), dtype=tdt, device=dev)     # 1 channel, zero-padded to a matrix step
-        cast(code, tdt, u5, out=u16[..., :1])
+        u16 = lowp.cast_pad16(code, tdt, u5.contiguous())      # 1 channel, zero-padded to a matrix step
         yv, vus = self._sampler_fwd(vae.upsample, ops.K3S2T, u16)
         vsaves = []
         for up, blk in vae.levels:
@@ -539,7 +541,8 @@ class LowPrecisionTrainer(object):
         dyp = torch.empty_like(y_pred)
         dyv = torch.empty_like(y_vae)
         dproj = torch.empty_like(proj)
-        ops.loss_bwd(y_pred, y, x, y_vae, proj, sums, one, dyp, dyv, dproj, through_sigmoid=False)
+        # (through the decoder's sigmoid, decoder.py:60, in the same pass: dyp IS the gradient of the head's pre-activation)
+        ops.loss_bwd(y_pred, y, x, y_vae, proj, sums, one, dyp, dyv, dproj, through_sigmoid=True)
         # slab gradients: uninitialised -- the first writer of each one writes, every later contribution accumulates.  Levels below the
         # top: the decoder block's conv1 data gradient (its view [0, cres + f) is the whole slab); the top level: the VAE's
         # down-sampling conv's data gradient (its view [0, top_used) is the whole slab, which has no spare channels)
@@ -557,8 +560,11 @@ class LowPrecisionTrainer(object):
         # (role-swapped image of the zero-padded kernel) run on the 16-bit kernels instead of the fp32 ones over widened copies
         cv, co = yv_last.shape[-1], vae.out_ch
         if cv % 16 == 0 and co <= 16 and lowp.wgrad_supported(ops.K3S1, cv, 16):
-            dyv16 = torch.zeros(tuple(dyv.shape[:4]) + (16,), dtype=tdt, device=dev)
-            cast(code, tdt, dyv, out=dyv16[..., :co])
+            if co <= 4 and dyv.is_contiguous():
+                dyv16 = lowp.cast_pad16(code, tdt, dyv)
+            else:
+                dyv16 = torch.zeros(tuple(dyv.shape[:4]) + (16,), dtype=tdt, device=dev)
+                cast(code, tdt, dyv, out=dyv16[..., :co])
 
             def wg_out():
                 tk = torch.empty((3, 3, 3, cv, 16), dtype=torch.float32, device=dev)
@@ -600,7 +606,7 @@ class LowPrecisionTrainer(object):
         dhdn = self._b16(dflat.reshape(hdn.shape))
         self._sampler_bwd(vds, dhdn, gslabs[-1][..., :top_used], False)           # first writer of the top level's slab gradient
         # decoder head (decoder.py:55-63): sigmoid, 1x1x1 conv to out_ch -- dx, dW and db from one pass over the 16-bit activations
-        dpre = ops.sigmoid_bwd(y_pred, dyp)
+        dpre = dyp
         wk2 = dec.out_k.t.reshape(dec.out_k.t.shape[-2], dec.out_k.t.shape[-1])
         dcur = lowp.head_bwd(code, tdt, y_last, dpre, wk2, self._gslot(dec.out_k).reshape(wk2.shape), self._gslot(dec.out_b), True)
         if dcur is None:       # head outside the fused kernel's shapes: fp32 kernels on widened copies

@@ -262,6 +262,10 @@ int bts_lp_conv3d_bwd_weight(int kind, int dtype, const void* x, const void* dy,
 /* fp32 <-> storage type, `rows` rows of C elements with row strides (the 2-channel input block runs in fp32: K = 16 is its floor) */
 int bts_lp_cast(int dtype, const float* src, long ld_src, void* dst, long ld_dst, long rows, int C, bts_stream_t stream);
 int bts_lp_uncast(int dtype, const void* src, long ld_src, float* dst, long ld_dst, long rows, int C, bts_stream_t stream);
+/* fp32 rows of C <= 4 channels -> dense storage-type rows of 16 channels with a zero tail, in one pass: the 2-channel input volume
+ * (model.py:58, after encoder.py:71's dropout), the 2-channel VAE-output gradient and the 1-channel VAE tensor (vae.py:110-111) as
+ * whole 16-channel matrix steps */
+int bts_lp_cast_pad16(int dtype, const float* src, long ld_src, void* dst, long rows, int C, bts_stream_t stream);
 /* GroupNormalization (group_norm.py:83-124), both semantics; x dense */
 long bts_lp_gn_workspace(int N, long V, int C, int G);
 int bts_lp_gn_stats(int dtype, const void* x, float* mean, float* rstd, void* workspace, long workspace_bytes, int N, long V, int C, int G,

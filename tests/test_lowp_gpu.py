@@ -709,6 +709,23 @@ def test_cast_into_a_padded_view(c, dtype):
         assert bool((buf[..., :first] == 7.0).all()) and bool((buf[..., first + c:] == 7.0).all())
 
 
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('c', [1, 2, 3, 4])
+def test_cast_with_zero_padding_to_a_matrix_step(c, dtype):
+    """bts_lp_cast_pad16: fp32 rows of c <= 4 channels (also as a channel slice of wider rows) -> dense rows of 16 in the storage type,
+    the live columns rounded like torch's own conversion, the tail exactly zero, the guard bytes behind the tensor untouched"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp
+    code, tdt = lowp.DTYPES[dtype]
+    g = torch.Generator().manual_seed(10 + c)
+    wide = (torch.randn((2, 5, 7, 9, c + 3), generator=g) * 3).cuda()
+    for x in (wide[..., :c].contiguous(), wide[..., 1:1 + c]):
+        out = lowp.cast_pad16(code, tdt, x)
+        torch.cuda.synchronize()
+        assert tuple(out.shape) == (2, 5, 7, 9, 16) and out.dtype == tdt
+        assert torch.equal(out[..., :c], x.to(tdt)) and bool((out[..., c:] == 0).all())
+
+
 GNB_CASES = [
     # (N, D, H, W), GroupNorm channels (= conv2 input channels), dy channels, groups, dy is a slab view, fused form expected
     ((2, 32, 32, 64), 32, 32, 8, False, True),       # z chunks of 16 planes over groups of 4: flushed at every group boundary
