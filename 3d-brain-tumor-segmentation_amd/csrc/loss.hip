@@ -224,15 +224,20 @@ extern "C" int bts_dice_metric_sums(const float* y_true, const float* y_pred, ui
 }
 // out[0] = macro, out[1] = micro   (micro has no smoothing: NaN when both empty, as in the reference)
 __global__ void dice_metric_value_kernel(const double* table, float* out, int cells, int C) {
-  if (threadIdx.x || blockIdx.x) return;
+  // one wave: lane l takes the entries l, l + 64, ... (independent loads in flight: the single-thread loop spent 65 us on 384 dependent
+  // L2 round trips), then a fixed-order tree over the lanes
+  if (blockIdx.x || threadIdx.x >= 64) return;
   double macro = 0.0, si = 0.0, sp = 0.0, st = 0.0;
-  for (int i = 0; i < cells * C; ++i) {
+  for (int i = threadIdx.x; i < cells * C; i += 64) {
     const double I = table[i * 3], P = table[i * 3 + 1], T = table[i * 3 + 2];
     macro += (2.0 * I + 1.0) / (P + T + 1.0);
     si += I; sp += P; st += T;
   }
-  out[0] = (float)(macro / (cells * C));
-  out[1] = (float)(si / (sp + st));
+  macro = wave_sum_f64(macro); si = wave_sum_f64(si); sp = wave_sum_f64(sp); st = wave_sum_f64(st);
+  if (threadIdx.x == 0) {
+    out[0] = (float)(macro / (cells * C));
+    out[1] = (float)(si / (sp + st));
+  }
 }
 extern "C" int bts_dice_metric_value(const double* table, float* out, int W, int C, int channels_last_axes,
                                      hipStream_t stream) {
