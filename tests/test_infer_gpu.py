@@ -83,6 +83,10 @@ def test_segment_volume_matches_oracle(kw, vol, res):
     m.set_weights_from(P)
     y, lab = infer.segment_volume(m, x.to(dev()), mask.to(dev()), mean, std, res)
     torch.cuda.synchronize()
+    # the augmented copies as batches of 3 (8 = 3 + 3 + 2: a ragged last chunk) give the same map as one by one
+    yb, labb = infer.segment_volume(m, x.to(dev()), mask.to(dev()), mean, std, res, tta_batch=3)
+    torch.cuda.synchronize()
+    assert float((yb - y).abs().max()) <= 2e-6 and float((labb != lab).float().mean()) <= 1e-3
     assert tuple(y.shape) == vol + (3,) and tuple(lab.shape) == vol and lab.dtype == torch.uint8
     err = float((y.double().cpu() - y_ref).abs().max())
     assert err <= 1e-4, 'TTA probabilities: max abs err %.3e' % err
