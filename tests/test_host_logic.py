@@ -210,3 +210,29 @@ def test_keras_order_weight_list_round_trip(tmp_path):
         m2.set_weights(bad)
     with pytest.raises(ValueError):
         m2.set_weights(w[:5])
+
+
+def test_bench_line_helpers_on_the_committed_captures():
+    """bench.py's roofline / kernel_breakdown / step_rooflines helpers against the committed PMC captures (no GPU): every configuration
+    of the default line has a traffic table with request-size counters, the dominant kernels resolve to a per-launch byte count, the
+    read side is derived from the request sizes (not the blanket 2 x FETCH_SIZE), and the wasted-traffic ratio is a finite number > 1"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for sfx, sym in (('', 'w3_kernel'), ('_bf16_b8', 'lp_s1d_kernel<1,5>'), ('_infer_f16', 'lp_s1d_kernel<1,4>')):
+        tab, src = bench._traffic_table(sfx)
+        assert tab is not None and tab.get('_meta', {}).get('steps_in_capture'), (sfx, src)
+        tr = bench.pmc_traffic(sym, sfx)
+        assert tr is not None and tr['bytes'] > 0 and tr['read_side'].startswith('request counters'), (sfx, sym, tr)
+        assert abs(tr['read_bytes'] - 2.0 * tr['fetch_size_kib_raw'] * 1024.0) <= 0.01 * tr['read_bytes']      # all requests are 128-byte ones
+    # records of two fake launches -> the contract's objects
+    rec = [('lp_s1d_kernel<1,5>', 4.0e11, 0.30), ('lp_s1d_kernel<1,5>', 4.0e11, 0.34), ('lp_k1_kernel', 1.0e9, 0.10)]
+    out = bench._roofline_from_records(rec, 1, 1e-3, lambda s: bench.pmc_traffic(s, '_bf16_b8'), 'test')
+    r = out['roofline']
+    assert r['kernel'] == 'lp_s1d_kernel<1,5>' and r['peak'] == bench.PEAK_F16_MFMA_TFLOPS and 0.4 < r['frac'] < 0.6 and r['traffic'] > 0
+    assert out['kernel_breakdown']['lp_k1_kernel']['bound'] == 'hbm' and out['kernel_breakdown']['lp_s1d_kernel<1,5>']['bound'] == 'mfma'
+    sr = bench.step_rooflines(52.136, 127.2, 0.0765, 'bf16', '_bf16_b8')
+    assert 1.0 < sr['wasted_traffic_ratio'] < 4.0 and 0.2 < sr['mfma_frac'] < 0.35 and sr['read_side'] == ['request counters']
