@@ -69,6 +69,7 @@ class LowPrecisionTrainer(object):
         self.fwd = lowp.LowPrecisionForward(model, dtype)      # checks samplers / layout, owns the forward weight images
         self.model = model
         self.code, self.tdt = DTYPES[dtype]
+        self.dtype_name = dtype
         if loss_scale is None:
             loss_scale = 2.0 ** 16 if self.tdt == torch.float16 else 1.0
         if loss_scale <= 0 or 2.0 ** round(math.log2(loss_scale)) != loss_scale:

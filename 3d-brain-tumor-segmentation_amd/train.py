@@ -144,6 +144,10 @@ def save_checkpoint(folder, model, optimizer=None, completed=False, tracker=None
         meta['next_epoch'] = meta['epoch'] + 1
     if tracker is not None:
         meta['tracker'] = {'best': float(tracker.best), 'patience': int(tracker.patience)}
+    tr16 = getattr(model, '_trainer16', None)          # fit(compute_dtype=...): the dynamic loss scale is training state too
+    if tr16 is not None:
+        meta['loss_scale'] = {'dtype': tr16.dtype_name, 'scale': float(tr16.loss_scale), 'clean_steps': int(tr16._clean_steps),
+                              'skipped_steps': int(tr16.skipped_steps)}
     local = {}
     for key, ds in (datasets or {}).items():
         if hasattr(ds, 'state_dict'):
@@ -197,7 +201,7 @@ def load_checkpoint(folder, model, optimizer=None):
                 data[k[len('data/'):-len(mine)]] = v
         else:
             data.setdefault(k[len('data/'):], v)
-    model._resume = {'tracker': meta.get('tracker'), 'data': data}
+    model._resume = {'tracker': meta.get('tracker'), 'data': data, 'loss_scale': meta.get('loss_scale')}
     for k, lay in _rng_layers(model).items():
         if k in meta.get('rng', {}):
             lay._seed = int(meta['rng'][k])
@@ -248,13 +252,28 @@ def eval_step(model, loss_fn, dice_fn, x, y):
 
 
 def fit(model, optimizer, loss_fn, dice_fn, train_data, val_data, n_epochs, patience=10, save_folder=None,
-        train_step_fn=None, eval_step_fn=None, log=print):
+        train_step_fn=None, eval_step_fn=None, log=print, compute_dtype=None):
     """The reference's `train(args)` from the logging set-up on (train.py:116-216).
+
+    compute_dtype: None / 'float32' = the fp32 engine (util.train_step); 'bfloat16' / 'float16' = the 16-bit-storage engine
+    (lowp_train.LowPrecisionTrainer.step: fp32 master weights, fp32 statistics, fp16 with dynamic loss scaling) for the training
+    iterations (its loss is util.DiceVAELoss, like train.py:143-147; loss_fn is then used by validation only) -- validation
+    stays on the fp32 engine.
 
     train_data / val_data: re-iterable collections of (x, y) batches (NDHWC tensors on the device).
     Resumes at `model.epoch` (train.py:133).  Returns the list of per-epoch rows (dicts).  On data-parallel runs every
     rank must call fit() (with the same n_epochs / patience; equally long shards) and iterates its own shard; rank 0 alone writes
     files, and rank 0's validation Dice drives the save / stop decision of all ranks."""
+    if train_step_fn is None and compute_dtype not in (None, 'float32'):
+        from .lowp_train import LowPrecisionTrainer
+        trainer = getattr(model, '_trainer16', None)
+        if trainer is None or trainer.dtype_name != compute_dtype:
+            trainer = model._trainer16 = LowPrecisionTrainer(model, compute_dtype)
+        saved = (getattr(model, '_resume', None) or {}).get('loss_scale')
+        if saved and saved.get('dtype') == compute_dtype:
+            trainer.loss_scale, trainer._clean_steps = float(saved['scale']), int(saved['clean_steps'])
+            trainer.skipped_steps = int(saved.get('skipped_steps', 0))
+        train_step_fn = lambda x, y: trainer.step(optimizer, dice_fn, x, y)     # noqa: E731
     tstep = train_step_fn or (lambda x, y: train_step(model, optimizer, loss_fn, dice_fn, x, y))
     estep = eval_step_fn or (lambda x, y: eval_step(model, loss_fn, dice_fn, x, y))
     writer = save_folder is not None and parallel.rank() == 0

@@ -77,6 +77,52 @@ def test_resume_is_bit_exact(tmp_path):
     assert torch.equal(sA[0], sB[0]) and torch.equal(sA[1], sB[1]) and oA.iterations == oB.iterations == 6
 
 
+KW16 = dict(base_filters=16, groups=4, reduction=4, depth=3)
+
+
+def _setup16(seed=0):
+    import bts_amd  # noqa: F401
+    from bts_amd.layers import _base
+    from bts_amd.model import Model
+    from bts_amd.util import DiceCoefficient, DiceVAELoss, ScheduledOptim
+    _base.set_seed(7)
+    m = Model(**KW16)
+    m.build((1,) + CROP + (2,))
+    return m, ScheduledOptim(1e-3, n_epochs=4), DiceVAELoss(), DiceCoefficient()
+
+
+def _data16(n, seed):
+    dev = torch.device('cuda', 0)
+    latent = KW16['base_filters'] * 2 ** (KW16['depth'] - 2)
+    return [tuple(t.to(dev) for t in R.synthetic_batch(1, CROP, latent=latent, seed=seed + i)[:2]) for i in range(n)]
+
+
+@pytest.mark.parametrize('dtype', ['bfloat16', 'float16'])
+def test_fit_with_the_16bit_step_learns_and_resumes_bit_exactly(tmp_path, dtype):
+    """fit(compute_dtype=...) runs the training iterations through lowp_train.LowPrecisionTrainer (validation stays fp32); the
+    container holds everything that step needs too (fp32 master weights, Adam moments, RNG counters), so a resumed run is bit-exact."""
+    from bts_amd import train as T
+    train, val = _data16(3, 100), _data16(1, 200)
+    mA, oA, lf, df = _setup16()
+    hA = T.fit(mA, oA, lf, df, train, val, n_epochs=1, patience=5, log=lambda s: None, compute_dtype=dtype)
+    mA.epoch.assign(1)
+    if dtype == 'float16':                   # as if two overflows had halved it: the resumed run must continue at this scale
+        mA._trainer16.loss_scale, mA._trainer16._clean_steps = 2.0 ** 14, 1
+    T.save_checkpoint(str(tmp_path), mA, oA)
+    hA += T.fit(mA, oA, lf, df, train, val, n_epochs=3, patience=5, log=lambda s: None, compute_dtype=dtype)
+    assert [h['epoch'] for h in hA] == [0, 1, 2] and oA.iterations == 9
+    assert float(hA[2]['train_loss']) < float(hA[0]['train_loss'])
+    mB, oB, lf2, df2 = _setup16()
+    for p in mB.trainable_variables:
+        p.t.zero_()
+    T.load_checkpoint(str(tmp_path), mB, oB)
+    T.fit(mB, oB, lf2, df2, train, val, n_epochs=3, patience=5, log=lambda s: None, compute_dtype=dtype)
+    torch.cuda.synchronize()
+    assert torch.equal(mA.flat_params, mB.flat_params), 'max |d| %.3e' % float((mA.flat_params - mB.flat_params).abs().max())
+    assert (mB._trainer16.loss_scale, mB._trainer16._clean_steps) == (mA._trainer16.loss_scale, mA._trainer16._clean_steps)
+    assert mA._trainer16.loss_scale == (2.0 ** 14 if dtype == 'float16' else 1.0) and mA._trainer16.skipped_steps == 0
+
+
 def test_overlapped_gradient_sync_is_bit_identical(monkeypatch):
     """parallel.GradSync (bucketed all-reduce issued from inside the backward pass, L2 term applied per bucket) against
     the plain path (backward, then all_reduce_gradients) on a 1-rank RCCL group: identical parameters after 3 steps."""
