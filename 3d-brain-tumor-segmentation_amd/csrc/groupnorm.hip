@@ -267,16 +267,32 @@ extern "C" int bts_gn_stats(const float* x, float* mean, float* rstd, void* work
   return BTS_OK;
 }
 
-// many partials per unit (conv epilogues leave one per tile column and plane: thousands at 128^3): one WORKGROUP per (n, g), fixed order
-__global__ __launch_bounds__(256) void gn_stats_finalize_wide_kernel(const double* partial, float* mean, float* rstd, int B, double count,
-                                                                     float eps) {
-  __shared__ double sh[8];
+// many partials per unit (conv epilogues leave one per tile column, plane and wave: 5-10 k at 128^3): one 1024-thread WORKGROUP per (n, g),
+// fixed order.  Four loads in flight per thread: walking the pairs one by one with 256 threads was a chain of ~40 dependent-latency
+// loads, 11 us per launch on the critical path of every GroupNorm.
+__global__ __launch_bounds__(1024) void gn_stats_finalize_wide_kernel(const double* partial, float* mean, float* rstd, int B, double count,
+                                                                      float eps) {
+  __shared__ double sh[32];
   const int i = blockIdx.x;
   double s = 0.0, ss = 0.0;
-  for (int b = threadIdx.x; b < B; b += 256) { s += partial[((long)i * B + b) * 2]; ss += partial[((long)i * B + b) * 2 + 1]; }
-  const double rs = block_sum_f64(s, sh);
-  const double rss = block_sum_f64(ss, sh + 4);
+  const double2* pp = reinterpret_cast<const double2*>(partial) + (long)i * B;
+  int b = threadIdx.x;
+  for (; b + 3 * 1024 < B; b += 4 * 1024) {
+    double2 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = pp[b + j * 1024];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s += v[j].x; ss += v[j].y; }
+  }
+  for (; b < B; b += 1024) { const double2 v = pp[b]; s += v.x; ss += v.y; }
+  s = wave_sum_f64(s);
+  ss = wave_sum_f64(ss);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { sh[w] = s; sh[16 + w] = ss; }
+  __syncthreads();
   if (threadIdx.x == 0) {
+    double rs = 0.0, rss = 0.0;
+    for (int k = 0; k < 16; ++k) { rs += sh[k]; rss += sh[16 + k]; }
     const double m = rs / count;
     double var = rss / count - m * m;
     if (var < 0.0) var = 0.0;
@@ -288,8 +304,9 @@ __global__ __launch_bounds__(256) void gn_stats_finalize_wide_kernel(const doubl
 int bts_gn_finalize_partials_(const double* partial, float* mean, float* rstd, int NG, long B, double count, float eps,
                               hipStream_t stream) {
   if (NG <= 0 || B <= 0 || B > 0x7fffffffL) return BTS_ERR_SHAPE;
+  if (((uintptr_t)partial) & 15) return BTS_ERR_ALIGN;
   if (B >= 512) {
-    (void)hipGetLastError(); hipLaunchKernelGGL(gn_stats_finalize_wide_kernel, dim3(NG), dim3(256), 0, stream, partial, mean, rstd, (int)B, count, eps);
+    (void)hipGetLastError(); hipLaunchKernelGGL(gn_stats_finalize_wide_kernel, dim3(NG), dim3(1024), 0, stream, partial, mean, rstd, (int)B, count, eps);
     BTS_LAUNCH_CHECK();
     return BTS_OK;
   }

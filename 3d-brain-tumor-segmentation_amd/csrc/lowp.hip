@@ -494,6 +494,77 @@ __global__ __launch_bounds__(256) void lp_splitk_reduce_kernel(const float* part
   }
 }
 
+// The same finish for a conv whose output goes into a slab-mode GroupNorm (dense y, Cout % 32 == 0): the workgroups walk the (sample, slab)
+// units the way lp_gn_stats_kernel does and leave (sum, sumsq) partials of the ROUNDED values, like that kernel -- the statistics pass over
+// the stored tensor and its launch go away (the deepest level of the inference volume runs eight such layers).
+template <typename T>
+__global__ __launch_bounds__(256) void lp_splitk_reduce_gn_kernel(const float* part, const float* bias, unsigned short* y, double* gn_partial,
+                                                                  long nvox, long E, long L, int C, int G, int ksplit, int B) {
+  __shared__ double sh[8];
+  const int unit = blockIdx.y, n = unit / G, g = unit % G;
+  const long lo = (long)n * E + (long)g * L;
+  const long per = ((L / 8 + B - 1) / B) * 8;
+  const long a = lo + (long)blockIdx.x * per, bnd = (a + per < lo + L) ? a + per : lo + L;
+  const long tot = nvox * C;
+  double s = 0.0, q = 0.0;
+  float fs = 0.f, fq = 0.f;
+  long cnt = 0;
+  for (long i = a + threadIdx.x * 8L; i < bnd; i += 256 * 8) {
+    const int c = (int)(i % C);
+    f32x4 u0 = *reinterpret_cast<const f32x4*>(part + i), u1 = *reinterpret_cast<const f32x4*>(part + i + 4);
+    for (int z = 1; z < ksplit; ++z) {
+      u0 += *reinterpret_cast<const f32x4*>(part + (long)z * tot + i);
+      u1 += *reinterpret_cast<const f32x4*>(part + (long)z * tot + i + 4);
+    }
+    float o[8], v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = u0[e]; o[4 + e] = u1[e]; }
+    if (bias) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += bias[c + e];
+    }
+    const u32x4 r = pack8<T>(o);
+    *reinterpret_cast<u32x4*>(y + i) = r;
+    unpack8<T>(r, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { fs += v[e]; fq = fmaf(v[e], v[e], fq); }
+    if (++cnt == 64) { s += fs; q += fq; fs = fq = 0.f; cnt = 0; }
+  }
+  s += fs; q += fq;
+  s = block_sum_f64(s, sh);
+  q = block_sum_f64(q, sh + 4);
+  if (threadIdx.x == 0) {
+    double* o = gn_partial + ((long)unit * B + blockIdx.x) * 2;
+    o[0] = s; o[1] = q;
+  }
+}
+// partial slots per (n, group) the kernel above leaves (0 = it does not take the shape)
+long bts_lp_splitk_gn_B_(int N, long V, int Cout, int G) {
+  if (G <= 0 || Cout % 32 != 0 || Cout % G != 0 || (V * Cout) % G != 0 || ((V * Cout) / G) % 8 != 0) return 0;
+  static const bool off = [] { const char* e = getenv("BTS_LP_SPLIT_GN"); return e && atoi(e) == 0; }();      // A/B: the separate statistics pass
+  if (off) return 0;
+  // (many short workgroups -- one or two 2048-element steps each: the tensor is small and the pass is latency-bound; < 512 partials per
+  // unit keeps the finalize on its one-wave-per-unit form)
+  long b = (V * Cout / G + 2047) / 2048;
+  if (b > 448) b = 448;
+  return b;
+}
+int bts_lp_splitk_reduce_gn_(int dtype, const float* part, const float* bias, void* y, double* gn_partial, int N, long V, int Cout, int G,
+                             int ksplit, hipStream_t stream) {
+  const long B = bts_lp_splitk_gn_B_(N, V, Cout, G);
+  if (B <= 0 || (((uintptr_t)y) & 15)) return BTS_ERR_UNSUPPORTED;
+  const long E = V * Cout, L = E / G;
+  (void)hipGetLastError();
+  if (dtype == LP_F16)
+    hipLaunchKernelGGL(lp_splitk_reduce_gn_kernel<TF16>, dim3((unsigned)B, (unsigned)(N * G)), dim3(256), 0, stream, part, bias, (unsigned short*)y,
+                       gn_partial, (long)N * V, E, L, Cout, G, ksplit, (int)B);
+  else
+    hipLaunchKernelGGL(lp_splitk_reduce_gn_kernel<TBF16>, dim3((unsigned)B, (unsigned)(N * G)), dim3(256), 0, stream, part, bias, (unsigned short*)y,
+                       gn_partial, (long)N * V, E, L, Cout, G, ksplit, (int)B);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
 int bts_lp_splitk_reduce_(int dtype, const float* part, const float* bias, void* y, long nvox, int Cout, int Npad, int ldy, int ksplit,
                           int accum, hipStream_t stream) {
   long blocks = (nvox * (Npad / 4) + 255) / 256;
@@ -1018,7 +1089,13 @@ extern "C" int bts_lp_conv3d_fwd(int kind, int dtype, const void* x, const void*
 // conv's epilogue per (z plane, tile column), bts_gn_finalize_partials_ turns them into mean / rstd.  Grids that split the input
 // channels, z-slabs that are not whole planes (D % G != 0) and heads with Cout % 4 != 0 run the conv and bts_lp_gn_stats on the stored y.
 static bool lp_s1_gn_plan(int N, int D, int H, int W, int Cin, int Cout, int G, long* B) {
-  if (Cin % 16 != 0 || Cout % 4 != 0 || G <= 0 || D % G != 0) return false;
+  if (Cin % 16 != 0 || Cout % 4 != 0 || G <= 0) return false;
+  if (D % G != 0) {      // slabs that are not whole planes: only the split-K finish of the DMA kernel counts them
+    const bool s1z_takes_it = bts_lp_s1z_gn_B_(N, D, H, W, Cin, Cout, 1) > 0;      // (offered first by lp_conv_run)
+    const bool splits = bts_lp_s1d_workspace_(N, D, H, W, Cin, Cout) > 0;
+    *B = (!s1z_takes_it && splits) ? bts_lp_s1d_gn_B_(N, D, H, W, Cin, Cout, G) : 0;
+    return *B > 0;
+  }
   *B = bts_lp_s1z_gn_B_(N, D, H, W, Cin, Cout, G);          // the streaming kernel takes this shape: its partial layout
   if (*B > 0) return true;
   if (bts_lp_s1d_workspace_(N, D, H, W, Cin, Cout) >= 0) {      // the DMA kernel takes this shape: its partial layout
@@ -1053,7 +1130,7 @@ extern "C" int bts_lp_conv3d_fwd_gn(int dtype, const void* x, const void* wp, co
   long B = 0;
   if (lp_s1_gn_plan(N, D, H, W, Cin, Cout, G, &B)) {
     double* part = reinterpret_cast<double*>(tail);
-    const int r = lp_conv_run(1, dtype, x, wp, bias, y, nullptr, 0, N, D, H, W, Cin, ldx, Cout, Cout, 0, stream, nullptr, part, G);
+    const int r = lp_conv_run(1, dtype, x, wp, bias, y, workspace, conv_ws, N, D, H, W, Cin, ldx, Cout, Cout, 0, stream, nullptr, part, G);
     if (r != BTS_OK) return r;
     return bts_gn_finalize_partials_(part, mean, rstd, N * G, B, (double)(V * Cout / G), eps, stream);
   }

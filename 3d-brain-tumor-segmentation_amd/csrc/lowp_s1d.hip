@@ -31,6 +31,9 @@
 int bts_prof_on();
 void bts_prof_begin(int sym, double flops, hipStream_t stream);
 void bts_prof_end(hipStream_t stream);
+long bts_lp_splitk_gn_B_(int N, long V, int Cout, int G);
+int bts_lp_splitk_reduce_gn_(int dtype, const float* part, const float* bias, void* y, double* gn_partial, int N, long V, int Cout, int G,
+                             int ksplit, hipStream_t stream);
 int bts_lp_splitk_reduce_(int dtype, const float* part, const float* bias, void* y, long nvox, int Cout, int Npad, int ldy, int ksplit,
                           int accum, hipStream_t stream);
 
@@ -543,7 +546,10 @@ long bts_lp_s1d_workspace_(int N, int D, int H, int W, int Cin, int Cout) {
 // GroupNorm-partial slots per (n, group) when the conv can emit them (no split-K, whole planes per group); 0 otherwise
 long bts_lp_s1d_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn) {
   S1dPlan pl;
-  if (Gn <= 0 || D % Gn != 0 || !s1d_plan(N, D, H, W, Cin, Cout, pl) || pl.ksplit > 1) return 0;
+  if (Gn <= 0 || !s1d_plan(N, D, H, W, Cin, Cout, pl)) return 0;
+  // (the split-K finish leaves the partials, in its own layout: slabs need not be whole planes there)
+  if (pl.ksplit > 1) return bts_lp_splitk_gn_B_(N, (long)D * H * W, Cout, Gn);
+  if (D % Gn != 0) return 0;
   return (long)(D / Gn) * pl.nty * pl.ntx * pl.ncg * 2;
 }
 
@@ -587,6 +593,7 @@ int bts_lp_s1d_launch_(int dtype, const void* x, const void* wp_dma, const float
   p.part = reinterpret_cast<float*>(ws);
   const long nvox = (long)N * D * H * W;
   if (p.ksplit > 1 && (ws == nullptr || ws_bytes < (long)p.ksplit * nvox * p.NB * 32 * 4 || (((uintptr_t)ws) & 15))) {
+    if (gnp != nullptr) return BTS_ERR_WORKSPACE;      // (the caller sized the partial array for the split plan)
     p.ksplit = 1; p.ks_per = p.KS;
   }
   p.dbg = 0;
@@ -595,7 +602,11 @@ int bts_lp_s1d_launch_(int dtype, const void* x, const void* wp_dma, const float
 #endif
   p.gnp = gnp; p.gn_G = gn_G; p.gn_zt = gn_G > 0 ? D / gn_G : 1;
   p.gn_B = gn_G > 0 ? (long)p.gn_zt * pl.nty * pl.ntx * pl.ncg * 2 : 0;
-  if (gnp != nullptr && p.ksplit > 1) return BTS_ERR_UNSUPPORTED;
+  const bool split_gn = gnp != nullptr && p.ksplit > 1;      // statistics from the split-K finish (dense y, whole 32-cout blocks)
+  if (split_gn) {
+    if (accum || ldy != Cout || bts_lp_splitk_gn_B_(N, (long)D * H * W, Cout, gn_G) <= 0) return BTS_ERR_UNSUPPORTED;
+    p.gnp = nullptr; p.gn_G = 0; p.gn_zt = 1; p.gn_B = 0;
+  }
   const bool prof = bts_prof_on();
   if (prof) bts_prof_begin(33 | ((1 + pl.mode * 2 + (pl.txl == 4 ? 1 : 0)) << 16), 2.0 * 27.0 * Cin * (double)Cout * (double)nvox, stream);   // (bits 16+: the variant, for bench.py's per-variant table)
   int r;
@@ -606,6 +617,7 @@ int bts_lp_s1d_launch_(int dtype, const void* x, const void* wp_dma, const float
 #undef S1D_CASE
   if (prof) bts_prof_end(stream);
   if (r != BTS_OK) return r;
+  if (split_gn) return bts_lp_splitk_reduce_gn_(dtype, p.part, bias, y, gnp, N, (long)D * H * W, Cout, gn_G, p.ksplit, stream);
   if (p.ksplit > 1) return bts_lp_splitk_reduce_(dtype, p.part, bias, y, nvox, Cout, p.NB * 32, ldy, p.ksplit, accum, stream);
   return BTS_OK;
 }

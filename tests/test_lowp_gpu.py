@@ -490,6 +490,36 @@ def test_conv_with_fused_groupnorm_statistics(case, dtype):
 
 
 @pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('case', [((1, 20, 24, 20), 256, 256, 8), ((1, 8, 12, 20), 128, 128, 8), ((2, 8, 8, 8), 256, 64, 4)],
+                         ids=['deepest-inference-level', '128-128', 'batch2-256-64-g4'])
+def test_split_channel_conv_leaves_the_groupnorm_statistics_of_its_stored_output(case, dtype):
+    """Layers whose grid splits the input channels (few voxels, many channels: the 20x24x20 level of the full inference volume) get
+    their GroupNorm statistics from the split's finish (lp_splitk_reduce_gn_kernel): the sums are those of the STORED values, as in
+    the statistics pass: y bit-equal, mean and rstd equal to conv + bts_lp_gn_stats up to the order of the fp64 partial sums."""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    (n, d, h, w), cin, cout, G = case
+    code, tdt = lowp.DTYPES[dtype]
+    g = torch.Generator().manual_seed(cin + cout + d)
+    xin = torch.randn((n, d, h, w, cin), generator=g).to(tdt).to(DEV)
+    wt = torch.randn((3, 3, 3, cin, cout), generator=g) * (2.0 / (27 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g).to(DEV)
+    wp = lowp.pack(ops.K3S1, code, wt.to(DEV), cin, cout)
+
+    class _Norm(object):
+        groups, epsilon, _mode = G, 1e-5, ops.GN_SLAB
+    y, mean, rstd = lowp.conv_gn(code, tdt, xin, wp, b, cout, _Norm)
+    y_ref = lowp.conv(ops.K3S1, code, tdt, xin, wp, b, cout)
+    m_ref, r_ref = lowp.gn_stats(code, y_ref, G, ops.GN_SLAB, 1e-5)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref)
+    assert float((mean - m_ref).abs().max()) <= 1e-6 and float((rstd / r_ref - 1).abs().max()) <= 1e-6      # (same values, other partial sums)
+    sl = y_ref.double().reshape(n, G, -1)
+    assert float((mean.double() - sl.mean(dim=2).reshape(-1)).abs().max()) <= 1e-5
+    assert float((rstd.double() * torch.sqrt(sl.var(dim=2, unbiased=False) + 1e-5).reshape(-1) - 1).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
 @pytest.mark.parametrize('case', [((1, 16, 16, 32), 32, 32, 8), ((2, 8, 8, 16), 64, 64, 8), ((1, 12, 10, 24), 32, 16, 4), ((1, 6, 8, 16), 16, 32, 8),
                                   ((1, 4, 4, 8), 32, 32, 8)],
                          ids=['32-32-g8', 'batch2-64-64-two-cout-blocks', 'ragged-16-couts-g4', 'slab-not-whole-planes', 'too-small-for-the-merged-kernel'])
