@@ -628,11 +628,14 @@ def main():
             # The two secondary BASELINE configurations, measured in this same process right after the (untouched) headline and
             # nested under "also": driver-witnessed numbers for the 16-bit engine.  Each is its own workload with its own timed
             # region (warm-up, then steps bracketed by synchronize); none of it is inside the headline's timed region.
-            torch.cuda.empty_cache()
+            import gc
+            gc.collect()                 # the headline's model and tape are garbage now: collect them here, not inside the next timed region
+            torch.cuda.empty_cache()     # (a collection that frees ~20 GB of device memory mid-step stalls that step by tens of ms)
             also = {}
             try:
                 # (5 warm-up + 10 timed steps: with 3 + 5 a single host or allocator hiccup inside the 0.4-s window moved the line by 15 %)
                 also['configs[2]'] = measure_train(args, world, rank, dev, overrides, dtype='bf16', batch=8, steps=10, warmup=5)
+                gc.collect()
                 torch.cuda.empty_cache()
                 also['configs[4]'] = measure_infer(args, world, rank, dev, overrides, dtype='f16', shape='160,192,160', batch=1,
                                                    steps=10, warmup=3)
