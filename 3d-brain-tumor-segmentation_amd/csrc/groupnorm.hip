@@ -690,6 +690,23 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// for block_bwd.hip (the fused gate + GroupNorm-2 backward): the slab-mode block geometry of this file and the finalize above
+bool bts_gn_slab_blocks_(int N, long V, int C, int G, int* B, long* span) {
+  GnGeom g;
+  if (gn_geom(g, N, V, C, G, BTS_GN_SLAB) != BTS_OK || g.generic) return false;
+  *B = g.B;
+  *span = g.span;
+  return true;
+}
+int bts_gn_bwd_finalize_slab_(const double* partial, const float* gamma, float* dgamma, float* dbeta, float* c1, float* c2, int N, int G, int B,
+                              int cg, double L, int accum, hipStream_t stream) {
+  if (cg > 256 || 256 % cg != 0) return BTS_ERR_UNSUPPORTED;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(gn_bwd_finalize_slab_kernel, dim3(G), dim3(256), 0, stream, partial, gamma, dgamma, dbeta, c1, c2, N, G, B, cg, L, accum);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
 // streaming form of gn_bwd_apply_kernel for slab mode with dense dy (see gn_apply_slab_stream_kernel); same arithmetic, element
 // for element, as the general kernel
 __global__ __launch_bounds__(256) void gn_bwd_apply_slab_stream_kernel(const float* __restrict__ x, const float* __restrict__ dy,

@@ -12,6 +12,8 @@ One layer call = one tape node: forward launches ~12 HIP kernels, backward ~20 (
 block that the reference would have seen [o_{j-1}, slab...] (encoder.py:83-87) so its weights carry dup_shift extra
 input channels that are folded at pack time.
 """
+import os
+
 import torch
 
 from .. import ops
@@ -164,6 +166,11 @@ class ResnetBlock(Layer):
         gws, a3 = self.spatial_k.grad_slot()
         main = torch.cuda.current_stream()
         gate = ops.side_stream('gate')
+        # gate + GroupNorm-2 backward in one pair of passes where the library takes the shape (slab mode: the layout the reference's
+        # channels_last GroupNormalization reduces over); BTS_FUSE_BLOCK_BWD=0: the two separate routes (A/B)
+        fused = None
+        if n2._mode == ops.GN_SLAB and n2.gamma is not None and n2.beta is not None and os.environ.get('BTS_FUSE_BLOCK_BWD', '1') != '0':
+            fused = self._fused_gate_gn2_backward(dout, res, c2, sp, gap, hbuf, ch, m2, r2, (gw1, a1), (gw2, a2), (gws, a3))
 
         def gate_backward():
             acc_ = a1
@@ -175,7 +182,10 @@ class ResnetBlock(Layer):
             return ops.se_bwd(dout, res, sp, gap, hbuf, ch, self.se_w1.t, self.se_w2.t, self.spatial_k.t.reshape(-1), gw1, gw2,
                               gws.reshape(-1), accumulate_params=acc_)
 
-        if gate is not None:
+        if fused is not None:
+            dres, dc2 = fused
+            gate = None
+        elif gate is not None:
             gate.wait_stream(main)                     # dout is complete once the main stream gets here
             with torch.cuda.stream(gate):
                 dres = gate_backward()
@@ -183,7 +193,8 @@ class ResnetBlock(Layer):
                 t.record_stream(gate)
             dres.record_stream(main)
         # ---- conv branch: GN2 -> conv2 -> GN1 -> conv1
-        dc2 = group_norm_backward(n2, c2, dout, n2.gamma.t, n2.beta.t, m2, r2, True)
+        if fused is None:
+            dc2 = group_norm_backward(n2, c2, dout, n2.gamma.t, n2.beta.t, m2, r2, True)
         wpb2 = self.packed('c2_b', K3, ops.ROLE_BWD, self.conv2_k, f, f)
         da = torch.empty_like(a)
         ops.conv_bwd_data(K3, dc2, wpb2, da, False)
@@ -192,7 +203,9 @@ class ResnetBlock(Layer):
         dc1 = group_norm_backward(n1, c1, da, n1.gamma.t, n1.beta.t, m1, r1, True)
         del da
         need_dx = x.requires_grad
-        if gate is None:
+        if fused is not None:
+            pass
+        elif gate is None:
             dres = gate_backward()
         else:
             main.wait_stream(gate)                     # both gradients into x leave in one pass below
@@ -204,6 +217,30 @@ class ResnetBlock(Layer):
         _wgrad(K3, x.t, dc1, self.conv1_k, self.conv1_b, dup_start, dup_shift)
         del dc1
         _wgrad(K1, x.t, dres, self.ptwise_k, self.ptwise_b, dup_start, dup_shift)
+
+    def _fused_gate_gn2_backward(self, dout, res, c2, sp, gap, hbuf, ch, m2, r2, s1, s2, s3):
+        """(dres, dc2) through ops.block_bwd, or None where it declines; parameter gradients go into the grad slots"""
+        n2 = self.norm2
+        (gw1, a1), (gw2, a2), (gws, a3) = s1, s2, s3
+        if not (torch.is_tensor(dout) and dout.shape[-1] == self.filters):
+            return None
+        if ops.block_bwd_takes(res, self.se_w1.t.shape[1], n2.groups, dout) is False:
+            return None
+        dg, ag = n2.gamma.grad_slot()
+        db, ab = n2.beta.grad_slot()
+        if not (a1 == a2 == a3):
+            for buf, ac in ((gw1, a1), (gw2, a2), (gws, a3)):
+                if not ac:
+                    ops.fill(buf, 0.0)
+            a1 = True
+        if ag != ab:
+            if not ag:
+                ops.fill(dg, 0.0)
+            if not ab:
+                ops.fill(db, 0.0)
+            ag = True
+        return ops.block_bwd(dout, res, c2, sp, gap, hbuf, ch, self.se_w1.t, self.se_w2.t, self.spatial_k.t.reshape(-1), n2.gamma.t, n2.beta.t,
+                             m2, r2, n2.groups, gw1, gw2, gws.reshape(-1), dg, db, accumulate_gate_params=a1, accumulate_norm_params=ag)
 
     def get_config(self):
         return self.config

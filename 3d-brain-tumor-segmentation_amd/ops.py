@@ -459,6 +459,34 @@ def se_bwd(dout, res, sp, gap, h, ch, w1, w2, wsp, dw1, dw2, dwsp, accumulate_pa
     return dres
 
 
+def block_bwd_takes(res, r, groups, dout):
+    """does the fused gate + GroupNorm-2 backward take this block?  (asked before the grad slots are claimed)"""
+    n, f = res.shape[0], res.shape[4]
+    v = res.shape[1] * res.shape[2] * res.shape[3]
+    return getattr(lib(), '_bts_block_bwd_workspace')(n, v, f, r, groups) >= 0 and ld_of(dout) % 4 == 0 and res.is_contiguous()
+
+
+def block_bwd(dout, res, c2, sp, gap, h, ch, w1, w2, wsp, gamma, beta, mean, rstd, groups, dw1, dw2, dwsp, dgamma, dbeta,
+              accumulate_gate_params=False, accumulate_norm_params=False):
+    """gate backward + GroupNorm-2 backward (slab mode, ReLU) of a ResnetBlock in one pair of passes -> (dres, dc2), or None where
+    the fused kernels do not take the shape (the caller runs se_bwd and gn_bwd)"""
+    n, f = res.shape[0], res.shape[4]
+    v = res.shape[1] * res.shape[2] * res.shape[3]
+    r = w1.shape[1]
+    nb = getattr(lib(), '_bts_block_bwd_workspace')(n, v, f, r, groups)      # (-1: outside the fused kernels' tiling, not an error)
+    if nb < 0 or ld_of(dout) % 4 != 0 or not (res.is_contiguous() and c2.is_contiguous()):
+        return None
+    ws = workspace(nb, res.device)
+    dres = torch.empty_like(res)
+    dc2 = torch.empty_like(c2)
+    ds = torch.empty(n * v, dtype=torch.float32, device=res.device)
+    dgap = torch.empty((n, f), dtype=torch.float32, device=res.device)
+    lib().call('bts_block_bwd', _p(dout), ld_of(dout), _p(res), _p(c2), _p(sp), _p(gap), _p(h), _p(ch), _p(w1), _p(w2), _p(wsp), _p(gamma), _p(beta),
+               _p(mean), _p(rstd), _p(dres), _p(dc2), _p(ds), _p(dgap), _p(dw1), _p(dw2), _p(dwsp), _p(dgamma), _p(dbeta), _p(ws), nb, n, v, f, r,
+               groups, 1 if accumulate_gate_params else 0, 1 if accumulate_norm_params else 0, _stream())
+    return dres, dc2
+
+
 def dropout_mask(shape, rate, seed, device):
     m = torch.empty(shape, dtype=torch.uint8, device=device)
     lib().call('bts_dropout_mask', _p(m), m.numel(), float(rate), int(seed) & (2 ** 64 - 1), _stream())

@@ -113,6 +113,17 @@ int bts_se_bwd(const float* dout, const float* res, const float* sp, const float
                float* dw2, float* dwsp, void* workspace, long workspace_bytes, int N, long V, int F, int R, int lddo,
                int accumulate_params, bts_stream_t stream);
 
+/* A ResnetBlock's gate backward (bts_se_bwd) and GroupNorm-2 backward (bts_gn_bwd, slab mode, ReLU) in one pair of passes: what
+ * tf.GradientTape (train.py:142,151) derives for layers/resnet.py:121-137 from the gradient of the block output.  dout (N,V,F) rows of
+ * lddo floats; res, c2 dense; outputs dres, dc2 dense, ds (N*V) and dgap (N,F) scratch.  accumulate_*: += into the parameter gradients.
+ * The workspace query returns -1 and the call BTS_ERR_UNSUPPORTED outside the kernels' tiling (the caller runs the two separate calls). */
+long bts_block_bwd_workspace(int N, long V, int F, int R, int G);
+int bts_block_bwd(const float* dout, int lddo, const float* res, const float* c2, const float* sp, const float* gap, const float* h,
+                  const float* ch, const float* w1, const float* w2, const float* wsp, const float* gamma, const float* beta,
+                  const float* mean, const float* rstd, float* dres, float* dc2, float* ds, float* dgap, float* dw1, float* dw2,
+                  float* dwsp, float* dgamma, float* dbeta, void* workspace, long workspace_bytes, int N, long V, int F, int R, int G,
+                  int accumulate_gate_params, int accumulate_norm_params, bts_stream_t stream);
+
 /* ===== element-wise (layers/encoder.py:39,71; layers/vae.py:9-13) ===== */
 int bts_dropout_mask(uint8_t* mask, long n, float rate, uint64_t seed, bts_stream_t stream);
 int bts_dropout_apply(const float* x, const uint8_t* mask, float* y, long n, float rate, bts_stream_t stream);

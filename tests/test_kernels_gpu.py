@@ -421,6 +421,55 @@ def test_se_gate_epilogue_fwd_bwd(n, dims, f, r, g):
         check_close(got, want, nm, rtol=1e-4, atol=1e-5 * (float(want.abs().max()) + 1))
 
 
+@pytest.mark.parametrize('accumulate', [False, True])
+@pytest.mark.parametrize('shape', [(2, 8, 16, 16, 32), (1, 16, 16, 32, 64), (2, 4, 8, 8, 256), (1, 8, 8, 16, 8)])
+def test_fused_gate_and_groupnorm2_backward(shape, accumulate):
+    """bts_block_bwd (one reduce + one apply pass over dout; resnet.py:121-137 under autodiff) against bts_se_bwd followed by bts_gn_bwd
+    on the same tensors: same arithmetic element for element, the fp64 partial sums grouped differently -- dc2 / dres and the parameter
+    gradients to a few fp32 units; dout arrives as a channel slice of a wider slab; first-write and accumulate into non-zero buffers"""
+    from bts_amd import ops
+    D = dev()
+    n, d, h, w, f = shape
+    groups, r = (8 if f >= 8 else f), max(f // 8, 1)
+    g = torch.Generator().manual_seed(f + d)
+    res = torch.randn(shape, generator=g).to(D)
+    c2 = torch.randn(shape, generator=g).to(D)
+    slab = torch.randn((n, d, h, w, f + 16), generator=g).to(D)
+    dout = slab[..., 8:8 + f]
+    sp = torch.sigmoid(torch.randn((n, d, h, w, 1), generator=g)).to(D).contiguous()
+    gap = torch.randn((n, f), generator=g).to(D)
+    w1 = (0.3 * torch.randn((f, r), generator=g)).to(D)
+    w2 = (0.3 * torch.randn((r, f), generator=g)).to(D)
+    wsp = (0.3 * torch.randn(f, generator=g)).to(D)
+    gamma = (1.0 + 0.3 * torch.randn(f, generator=g)).to(D)
+    beta = (0.2 * torch.randn(f, generator=g)).to(D)
+    hbuf, ch = ops.se_mlp_fwd(gap, w1, w2)
+    mean, rstd = ops.gn_stats(c2, groups, ops.GN_SLAB)
+    init = [torch.randn(t.shape, generator=g).to(D) for t in (w1, w2, wsp, gamma, beta)]      # dw1 dw2 dwsp dgamma dbeta
+    ref = [t.clone() for t in init]
+    dres_r = ops.se_bwd(dout, res, sp, gap, hbuf, ch, w1, w2, wsp, ref[0], ref[1], ref[2], accumulate_params=accumulate)
+    dc2_r = ops.gn_bwd(c2, dout, gamma, beta, mean, rstd, ref[3], ref[4], groups, ops.GN_SLAB, True, accumulate_params=accumulate)
+    got = [t.clone() for t in init]
+    assert ops.block_bwd_takes(res, r, groups, dout)
+    dres, dc2 = ops.block_bwd(dout, res, c2, sp, gap, hbuf, ch, w1, w2, wsp, gamma, beta, mean, rstd, groups, got[0], got[1], got[2], got[3], got[4],
+                              accumulate_gate_params=accumulate, accumulate_norm_params=accumulate)
+    torch.cuda.synchronize()
+    for a, b, nm in ((dc2, dc2_r, 'dc2'), (dres, dres_r, 'dres')):
+        assert float((a - b).abs().max()) <= 4e-7 * float(b.abs().max()) + 1e-7, (nm, float((a - b).abs().max()), float(b.abs().max()))
+    for a, b, nm in zip(got, ref, ('dw1', 'dw2', 'dwsp', 'dgamma', 'dbeta')):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-6, (nm, float((a - b).abs().max()), float(b.abs().max()))
+
+
+def test_fused_block_backward_declines_what_it_cannot_tile():
+    """units that are not whole 1024-element chunks / channel counts that do not divide a chunk: the query says so and the layer keeps
+    the two separate calls (tests/test_model_gpu.py runs such models)"""
+    from bts_amd import ops
+    D = dev()
+    for shape, groups in (((1, 4, 4, 4, 8), 4), ((1, 6, 10, 10, 16), 8), ((1, 8, 8, 8, 24), 8)):
+        res = torch.zeros(shape, device=D)
+        assert not ops.block_bwd_takes(res, 2, groups, res), shape
+
+
 def test_dropout_sample_dense():
     from bts_amd import ops
     D = dev()

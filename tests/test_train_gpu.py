@@ -123,6 +123,41 @@ def test_fit_with_the_16bit_step_learns_and_resumes_bit_exactly(tmp_path, dtype)
     assert mA._trainer16.loss_scale == (2.0 ** 14 if dtype == 'float16' else 1.0) and mA._trainer16.skipped_steps == 0
 
 
+def test_fused_block_backward_gives_the_gradients_of_the_separate_routes(monkeypatch):
+    """a whole fp32 step with the gate + GroupNorm-2 backward of every block fused (bts_block_bwd, the default) against the same step
+    with BTS_FUSE_BLOCK_BWD=0: the same arithmetic with other partial-sum groupings -- gradients equal to fp32 rounding of the sums"""
+    import bts_amd  # noqa: F401
+    from bts_amd import tape as T
+    from bts_amd.util import reduce_sum
+    x, y = _data16(1, 300)[0]
+
+    def grads(switch):
+        monkeypatch.setenv('BTS_FUSE_BLOCK_BWD', switch)
+        m, opt, lf, df = _setup16()
+        for blk_norm in [p for p in m.trainable_variables if (p.name or '').endswith('gn2/gamma')]:
+            blk_norm.t.fill_(0.7)                       # (the reference initialises GN2's gamma to zero: give the conv branch a gradient)
+        T.bump_weights_epoch()
+        m.encoder._seed = m.vae._seed = 5
+        with T.GradientTape() as tape:
+            yp, yv, zm, zl = m(x, training=True, inference=False)
+            loss = lf(x, y, yp, yv, zm, zl) + reduce_sum(m.losses)
+        tape.gradient(loss, m.trainable_variables)
+        torch.cuda.synchronize()
+        return m.flat_grads.clone(), m
+
+    g1, m = grads('1')
+    g0, _ = grads('0')
+    assert float(g0.abs().max()) > 0
+    worst = 0.0
+    off = 0
+    for p in m.trainable_variables:              # (flat_grads holds the parameters in trainable_variables order)
+        k = p.t.numel()
+        a, b = g1[off:off + k], g0[off:off + k]
+        off += k
+        worst = max(worst, float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12))
+    assert g1.numel() - 8 < off <= g1.numel() and worst <= 2e-5, worst        # (the flat buffer is padded to a vector width)
+
+
 def test_overlapped_gradient_sync_is_bit_identical(monkeypatch):
     """parallel.GradSync (bucketed all-reduce issued from inside the backward pass, L2 term applied per bucket) against
     the plain path (backward, then all_reduce_gradients) on a 1-rank RCCL group: identical parameters after 3 steps."""
