@@ -409,7 +409,9 @@ static int se_mlp_bwd_launch(const double* red, const float* gap, const float* h
                              float* dw2, float* dwsp, float* dgap, double* scratch, int N, int B, long V, int F, int R, int accumulate_params,
                              hipStream_t stream) {
   (void)hipGetLastError();
-  if (N >= 2) {
+  // (also for one sample of a wide block: the one-block kernel takes 20 / 41 us at F = 128 / 256 -- R*F products on 256 threads -- on the
+  // critical path of the block's backward; the pair below 13 us)
+  if (N >= 2 || (long)F * R >= 2048) {
     hipLaunchKernelGGL(se_mlp_bwd_sample_kernel, dim3(N), dim3(256), 0, stream, red, h, ch, w1, w2, dgap, scratch, N, F, R, 1.0 / (double)V);
     BTS_LAUNCH_CHECK();
     hipLaunchKernelGGL(se_mlp_bwd_param_kernel, dim3((R * F + 255) / 256), dim3(256), 0, stream, red, gap, h, dw1, dw2, dwsp, scratch, N, F, R,
