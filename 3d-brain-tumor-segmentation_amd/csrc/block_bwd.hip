@@ -2,7 +2,7 @@
 // train.py:142-151).  Both read the gradient of the block output.  The separate routes (bts_se_bwd on the gate stream, bts_gn_bwd on the
 // main one) stream nine tensor-sized passes -- reduce: (dout, res) and (dout, c2); apply: dout -> dres and (dout, c2) -> dc2 -- and launch
 // nine kernels; here the reduce pass reads dout, res, c2 once (GroupNorm class sums + gate sums + the per-voxel spatial-gate gradient)
-// and the apply pass reads dout, c2 once and writes dres and dc2: seven passes, six kernels.  The 16-bit engine's bts_lp_block_bwd is the
+// and the apply pass reads dout, c2 once and writes dres and dc2: seven passes, five kernels (reduce, one middle launch for both finalizes, SE-MLP backward, apply).  The 16-bit engine's bts_lp_block_bwd is the
 // same idea on 16-bit tensors (lowp.hip).
 //
 //   gate (SURVEY Appendix A'):  g = dout * res per element;  t_v = sum_c g;  ds_v = t_v sp_v (1 - sp_v)
@@ -14,6 +14,7 @@
 // a thread four consecutive channels of a voxel, the C/4 lanes of a voxel are neighbours (so the per-voxel sum is a shuffle tree).
 #include "common.h"
 #include "bts_internal.h"
+#include "finalize_parts.h"
 
 __global__ __launch_bounds__(256) void blk_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                              const float* __restrict__ res, const float* __restrict__ sp,
@@ -174,6 +175,17 @@ __global__ __launch_bounds__(256) void blk_bwd_apply_kernel(const float* __restr
   }
 }
 
+// Between the two passes, one launch for the two finalizes that only need the reduce pass's partials: workgroups [0, G) turn the
+// GroupNorm class sums into dgamma / dbeta / c1 / c2 (gn_bwd_finalize_slab_kernel's work), the rest sum the gate partials per (n, c)
+// (se_bwd_partial_reduce_kernel's).
+__global__ __launch_bounds__(256) void blk_bwd_middle_kernel(const double* partial, const float* gamma, float* dgamma, float* dbeta, float* c1,
+                                                             float* c2, const double* se_partial, double* red, int N, int G, int B, int cg,
+                                                             double L, int accum, int F) {
+  __shared__ double sh[256 * 2];
+  if ((int)blockIdx.x < G) gn_bwd_finalize_slab_body(partial, gamma, dgamma, dbeta, c1, c2, N, G, B, cg, L, accum, blockIdx.x, sh);
+  else se_bwd_partial_reduce_body(se_partial, red, N, G * B, F, (int)blockIdx.x - G);
+}
+
 // the shapes the pair of kernels takes: slab units of whole 1024-element chunks with C | 1024, classes that tile a workgroup
 static bool blk_bwd_plan(int N, long V, int F, int R, int G, int* B, long* span) {
   if (N <= 0 || V <= 0 || R <= 0 || G <= 0 || F < 4 || F > 256 || (F & (F - 1)) != 0 || F % G != 0) return false;
@@ -221,9 +233,10 @@ extern "C" int bts_block_bwd(const float* dout, int lddo, const float* res, cons
   hipLaunchKernelGGL(blk_bwd_reduce_kernel, dim3(B, N * G), dim3(256), 0, stream, c2x, dout, res, sp, gamma, beta, mean, rstd, partial, sep, ds, E, L,
                      span, F, G, cg, lddo);
   BTS_LAUNCH_CHECK();
-  int r = bts_gn_bwd_finalize_slab_(partial, gamma, dgamma, dbeta, c1, c2, N, G, B, cg, (double)L, accumulate_norm_params, stream);
-  if (r != BTS_OK) return r;
-  r = bts_se_bwd_middle_(sep, red, scratch, gap, h, ch, w1, w2, dw1, dw2, dwsp, dgap, N, G * B, V, F, R, accumulate_gate_params, stream);
+  hipLaunchKernelGGL(blk_bwd_middle_kernel, dim3(G + (N * F + 3) / 4), dim3(256), 0, stream, partial, gamma, dgamma, dbeta, c1, c2, sep, red, N, G, B, cg,
+                     (double)L, accumulate_norm_params, F);
+  BTS_LAUNCH_CHECK();
+  const int r = bts_se_mlp_bwd_(red, scratch, gap, h, ch, w1, w2, dw1, dw2, dwsp, dgap, N, G * B, V, F, R, accumulate_gate_params, stream);
   if (r != BTS_OK) return r;
   const long cpu = L / 1024;
   int cpb = 8;

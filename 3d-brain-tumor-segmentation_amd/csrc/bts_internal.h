@@ -6,11 +6,13 @@
 int bts_gn_finalize_partials_(const double* partial, float* mean, float* rstd, int NG, long B, double count, float eps,
                               hipStream_t stream);
 
-// groupnorm.hip, for block_bwd.hip: blocks per (sample, slab) unit / elements per block of the vectorised slab kernels (false: generic
-// shape), and the slab finalize of the backward class sums partial[((unit*B + b)*cg + j)*2 + {A, B}] -> dgamma, dbeta, c1, c2
+// groupnorm.hip, for block_bwd.hip: blocks per (sample, slab) unit / elements per block of the vectorised slab kernels (false: generic shape)
 bool bts_gn_slab_blocks_(int N, long V, int C, int G, int* B, long* span);
-int bts_gn_bwd_finalize_slab_(const double* partial, const float* gamma, float* dgamma, float* dbeta, float* c1, float* c2, int N, int G, int B,
-                              int cg, double L, int accum, hipStream_t stream);
+
+// se.hip: stage 2 of the gate backward alone (SE-MLP backward from the summed partials red[(n*F+c)*2 + {ch, w}])
+int bts_se_mlp_bwd_(const double* red, double* scratch, const float* gap, const float* h, const float* ch, const float* w1, const float* w2,
+                    float* dw1, float* dw2, float* dwsp, float* dgap, int N, int B, long V, int F, int R, int accumulate_params,
+                    hipStream_t stream);
 
 // conv_wino.hip: 3x3x3 stride-1 conv in Winograd F(2x2,3x3) x direct form; BTS_OK = taken, 1 = declined (run the implicit GEMM)
 int bts_wino_launch_(const float* x, const float* up, const float* bias, float* y, int N, int D, int H, int W, int Cin, int ldx,

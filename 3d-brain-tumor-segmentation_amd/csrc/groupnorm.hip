@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include "common.h"
 #include "bts_internal.h"
+#include "finalize_parts.h"
 
 #define GN_BLOCKS_MAX 256
 
@@ -616,42 +617,7 @@ __global__ void gn_bwd_finalize_kernel(const float* gamma, float* dgamma, float*
 __global__ __launch_bounds__(256) void gn_bwd_finalize_slab_kernel(const double* partial, const float* gamma, float* dgamma, float* dbeta, float* c1,
                                                                    float* c2, int N, int G, int B, int cg, double L, int accum) {
   __shared__ double sh[256 * 2];
-  const int g = blockIdx.x;
-  const int j = threadIdx.x % cg, sl = threadIdx.x / cg, S = 256 / cg;
-  double ga = 0.0, gb = 0.0;
-  for (int n = 0; n < N; ++n) {
-    const long unit = (long)n * G + g;
-    double sa = 0.0, sb = 0.0;
-    for (int b = sl; b < B; b += S) {
-      const double* o = partial + ((unit * B + b) * cg + j) * 2;
-      sa += o[0]; sb += o[1];
-    }
-    __syncthreads();
-    sh[threadIdx.x * 2] = sa; sh[threadIdx.x * 2 + 1] = sb;
-    __syncthreads();
-    if (sl == 0) {
-      sa = 0.0; sb = 0.0;
-      for (int s2 = 0; s2 < S; ++s2) { sa += sh[(s2 * cg + j) * 2]; sb += sh[(s2 * cg + j) * 2 + 1]; }
-      ga += sa; gb += sb;
-    }
-    __syncthreads();
-    if (sl == 0) {
-      sh[j * 2] = (double)gamma[g * cg + j] * sb;       // -> c1
-      sh[j * 2 + 1] = (double)gamma[g * cg + j] * sa;   // -> c2
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double s1 = 0.0, s2 = 0.0;
-      for (int q = 0; q < cg; ++q) { s1 += sh[q * 2]; s2 += sh[q * 2 + 1]; }
-      c1[unit] = (float)(s1 / L);
-      c2[unit] = (float)(s2 / L);
-    }
-  }
-  if (sl == 0) {
-    const int idx = g * cg + j;
-    if (dgamma) dgamma[idx] = accum ? dgamma[idx] + (float)ga : (float)ga;
-    if (dbeta) dbeta[idx] = accum ? dbeta[idx] + (float)gb : (float)gb;
-  }
+  gn_bwd_finalize_slab_body(partial, gamma, dgamma, dbeta, c1, c2, N, G, B, cg, L, accum, blockIdx.x, sh);
 }
 
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -690,7 +656,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   }
 }
 
-// for block_bwd.hip (the fused gate + GroupNorm-2 backward): the slab-mode block geometry of this file and the finalize above
+// for block_bwd.hip (the fused gate + GroupNorm-2 backward): the slab-mode block geometry of this file
 bool bts_gn_slab_blocks_(int N, long V, int C, int G, int* B, long* span) {
   GnGeom g;
   if (gn_geom(g, N, V, C, G, BTS_GN_SLAB) != BTS_OK || g.generic) return false;
@@ -698,15 +664,6 @@ bool bts_gn_slab_blocks_(int N, long V, int C, int G, int* B, long* span) {
   *span = g.span;
   return true;
 }
-int bts_gn_bwd_finalize_slab_(const double* partial, const float* gamma, float* dgamma, float* dbeta, float* c1, float* c2, int N, int G, int B,
-                              int cg, double L, int accum, hipStream_t stream) {
-  if (cg > 256 || 256 % cg != 0) return BTS_ERR_UNSUPPORTED;
-  (void)hipGetLastError();
-  hipLaunchKernelGGL(gn_bwd_finalize_slab_kernel, dim3(G), dim3(256), 0, stream, partial, gamma, dgamma, dbeta, c1, c2, N, G, B, cg, L, accum);
-  BTS_LAUNCH_CHECK();
-  return BTS_OK;
-}
-
 // streaming form of gn_bwd_apply_kernel for slab mode with dense dy (see gn_apply_slab_stream_kernel); same arithmetic, element
 // for element, as the general kernel
 __global__ __launch_bounds__(256) void gn_bwd_apply_slab_stream_kernel(const float* __restrict__ x, const float* __restrict__ dy,

@@ -8,6 +8,7 @@
 // caller-supplied workspace and are combined in a fixed order (bitwise reproducible).
 #include "common.h"
 #include "bts_internal.h"
+#include "finalize_parts.h"
 
 #define SE_BLOCKS_MAX 512
 
@@ -289,19 +290,7 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float* __restr
 
 // stage 2a: one wave per (n,c): sum the per-block partials -> red[(n*F+c)*2 + {ch, w}]
 __global__ __launch_bounds__(256) void se_bwd_partial_reduce_kernel(const double* partial, double* red, int N, int B, int F) {
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= N * F) return;
-  const int n = i / F, c = i % F;
-  double a = 0.0, b = 0.0;
-  for (int k = lane; k < B; k += 64) {
-    const long o = (((long)n * B + k) * F + c) * 2;
-    a += partial[o];
-    b += partial[o + 1];
-  }
-  a = wave_sum_f64(a);
-  b = wave_sum_f64(b);
-  if (lane == 0) { red[i * 2] = a; red[i * 2 + 1] = b; }
+  se_bwd_partial_reduce_body(partial, red, N, B, F, blockIdx.x);
 }
 
 // stage 2 (one block): finish the sums, SE-MLP backward, emit dgap (already divided by V) for stage 3
@@ -448,6 +437,12 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const float* __restri
   }
 }
 
+// stage 2 alone (block_bwd.hip sums the partials in its own middle launch)
+int bts_se_mlp_bwd_(const double* red, double* scratch, const float* gap, const float* h, const float* ch, const float* w1, const float* w2,
+                    float* dw1, float* dw2, float* dwsp, float* dgap, int N, int B, long V, int F, int R, int accumulate_params,
+                    hipStream_t stream) {
+  return se_mlp_bwd_launch(red, gap, h, ch, w1, w2, dw1, dw2, dwsp, dgap, scratch, N, B, V, F, R, accumulate_params, stream);
+}
 // stages 2a + 2 for callers that produced the per-block partials themselves (lowp.hip: 16-bit dout / res), same layouts as above
 int bts_se_bwd_middle_(double* partial, double* red, double* scratch, const float* gap, const float* h, const float* ch, const float* w1,
                        const float* w2, float* dw1, float* dw2, float* dwsp, float* dgap, int N, int B, long V, int F, int R,
