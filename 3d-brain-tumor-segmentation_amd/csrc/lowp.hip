@@ -38,7 +38,9 @@ long bts_lp_s1d_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn);
 // lowp_s1z.hip: z-marching stride-1 3x3x3 kernel for few channels (offered first; 1 = declined)
 long bts_lp_s1z_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn);
 int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bias, void* y, int N, int D, int H, int W, int Cin, int ldx,
-                       int Cout, int ldy, int accum, double* gn_part, int gn_G, hipStream_t stream, const LpGnbFuse* gb = nullptr);
+                       int Cout, int ldy, int accum, double* gn_part, int gn_G, hipStream_t stream, const LpGnbFuse* gb = nullptr,
+                       const LpGnaFuse* ga = nullptr);
+bool bts_lp_s1z_gna_ok_(int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, int in_G);
 long bts_lp_s1z_gnb_B_(int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, int Gn);
 // lowp_k1.hip: streaming 1x1x1 kernel (offered first; 1 = declined); gap partials per block of bts_lp_k1_gap_block_ positions
 int bts_lp_k1_gap_block_(long npos, long V, int Cin, int Cout);
@@ -982,7 +984,8 @@ static int lp_gather_launch(LpGatherParams p, hipStream_t stream) {
 // odd ones (i, k=1)).  (D,H,W) are the dims of `x`, the tensor the taps read; Cin its channels (the contraction).
 static int lp_conv_run(int geo, int dtype, const void* x, const void* wp, const float* bias, void* y, void* workspace, long workspace_bytes,
                        int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, int accum, hipStream_t stream,
-                       double* gap_part = nullptr, double* gn_part = nullptr, int gn_G = 0, const LpGnbFuse* gnb = nullptr) {
+                       double* gap_part = nullptr, double* gn_part = nullptr, int gn_G = 0, const LpGnbFuse* gnb = nullptr,
+                       const LpGnaFuse* gna = nullptr) {
   if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return BTS_ERR_SHAPE;
   // (results are stored four couts = 8 bytes at a time; a head with fewer than four output channels stores them one by one)
@@ -994,10 +997,10 @@ static int lp_conv_run(int geo, int dtype, const void* x, const void* wp, const 
     if (((long)(D + 2) * H * W + 64) * (long)ldx * 2 >= 0x7fffffffL) return BTS_ERR_SHAPE;   // 31-bit offsets inside one volume
     {   // few channels on a big volume: the z-marching streaming kernel (lowp_s1z.hip); same image part as the tiled DMA kernel
       const int r = bts_lp_s1z_launch_(dtype, x, reinterpret_cast<const char*>(wp) + lp_s1d_part_offset(Cin, Cout), bias, y, N, D, H, W, Cin, ldx,
-                                       Cout, ldy, accum, gn_part, gn_G, stream, gnb);
+                                       Cout, ldy, accum, gn_part, gn_G, stream, gnb, gna);
       if (r != 1) return r;
     }
-    if (gnb != nullptr) return 1;      // (only the streaming kernel emits the GroupNorm-backward class sums: nothing was launched)
+    if (gnb != nullptr || gna != nullptr) return 1;      // (only the streaming kernel has these epilogue / prologue forms: nothing was launched)
     {
       const int r = bts_lp_s1d_launch_(dtype, x, reinterpret_cast<const char*>(wp) + lp_s1d_part_offset(Cin, Cout), bias, y, workspace,
                                        workspace_bytes, N, D, H, W, Cin, ldx, Cout, ldy, accum, gn_part, gn_G, stream);
@@ -1137,6 +1140,33 @@ extern "C" int bts_lp_conv3d_fwd_gn(int dtype, const void* x, const void* wp, co
   const int r = lp_conv_run(1, dtype, x, wp, bias, y, workspace, conv_ws, N, D, H, W, Cin, ldx, Cout, Cout, 0, stream);
   if (r != BTS_OK) return r;
   return bts_lp_gn_stats(dtype, y, mean, rstd, tail, workspace_bytes - conv_ws, N, V, Cout, G, BTS_GN_SLAB, eps, stream);
+}
+// The same with GroupNorm + ReLU of the INPUT applied on the way in (in_relu must be 1): y = conv3x3x3(relu(GN_in(x))) + bias and the statistics of y --
+// conv2 of a ResnetBlock reading conv1's raw output (resnet.py:133-136: conv -> GroupNormalization -> relu -> conv) where no backward
+// needs the normalised tensor (inference, test.py:128-151 via Model.call(inference=True)).  The workspace query returns -1 where the
+// streaming kernel does not take the shape in this form (the caller runs bts_lp_gn_apply + bts_lp_conv3d_fwd_gn).
+extern "C" long bts_lp_conv3d_gnin_fwd_gn_workspace(int N, int D, int H, int W, int Cin, int Cout, int in_G, int G) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || G <= 0 || Cout % G != 0 || in_G <= 0 || Cin % in_G != 0) return -1;
+  static const bool off = [] { const char* e = getenv("BTS_LP_GNA"); return e && atoi(e) == 0; }();      // A/B: the separate apply pass
+  if (off || !bts_lp_s1z_gna_ok_(N, D, H, W, Cin, Cin, Cout, Cout, in_G)) return -1;
+  const long B = bts_lp_s1z_gn_B_(N, D, H, W, Cin, Cout, G);
+  if (B <= 0) return -1;
+  return (long)N * G * B * 16 + 128;
+}
+extern "C" int bts_lp_conv3d_gnin_fwd_gn(int dtype, const void* x, const float* in_gamma, const float* in_beta, const float* in_mean,
+                                         const float* in_rstd, int in_G, int in_relu, const void* wp, const float* bias, void* y, float* mean,
+                                         float* rstd, void* workspace, long workspace_bytes, int N, int D, int H, int W, int Cin, int Cout, int G,
+                                         float eps, hipStream_t stream) {
+  const long need = bts_lp_conv3d_gnin_fwd_gn_workspace(N, D, H, W, Cin, Cout, in_G, G);
+  if (need < 0 || !in_relu) return BTS_ERR_UNSUPPORTED;      // (the kernel form that exists applies GroupNorm + ReLU)
+  if (workspace == nullptr || workspace_bytes < need || (((uintptr_t)workspace) & 15)) return BTS_ERR_WORKSPACE;
+  const long B = bts_lp_s1z_gn_B_(N, D, H, W, Cin, Cout, G);
+  double* part = reinterpret_cast<double*>(workspace);
+  LpGnaFuse ga{in_gamma, in_beta, in_mean, in_rstd, in_G, Cin / in_G};
+  const int r = lp_conv_run(1, dtype, x, wp, bias, y, nullptr, 0, N, D, H, W, Cin, Cin, Cout, Cout, 0, stream, nullptr, part, G, nullptr, &ga);
+  if (r == 1) return BTS_ERR_UNSUPPORTED;
+  if (r != BTS_OK) return r;
+  return bts_gn_finalize_partials_(part, mean, rstd, N * G, B, (double)((long)D * H * W * Cout / G), eps, stream);
 }
 // y = Conv3DTranspose(k3, s2, 'same')(x) + bias (dense fine tensor, storage type) AND the slab-mode GroupNorm statistics of y -- ConvUpsample
 // (upsample.py:28-43: conv -> GroupNormalization) without the statistics pass over the fine tensor: (sum, sumsq) partials leave the

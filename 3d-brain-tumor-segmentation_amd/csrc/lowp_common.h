@@ -142,6 +142,19 @@ __device__ __forceinline__ void k1_pair_transpose(u32x4 (&r)[2], int b) {
   r[0] = s[0]; r[1] = s[1];
 }
 
+// GroupNorm-apply on the way IN: the conv reads the RAW output c of the previous conv and applies a = relu((c - mean) rstd gamma + beta)
+// (group_norm.py:110-122 + the ReLU of resnet.py:133-136) to each input plane after it has landed in LDS -- inference only, where no
+// backward needs the applied tensor: the 1 read + 1 write pass of bts_lp_gn_apply goes away.  Slab semantics with whole z planes per
+// group (D % G == 0) and classes that tile a 16-byte slot (cg | 8): a slot's eight channels then have classes e mod cg whatever the slot.
+// The arithmetic is bts_lp_gn_apply's, element for element (max(fmaf(v - mean, rstd * gamma, beta), 0), rounded to the storage type).
+struct LpGnaFuse {
+  const float* gamma;
+  const float* beta;
+  const float* mean;   // (N*G)
+  const float* rstd;
+  int G, cg;
+};
+
 // GroupNorm-backward class sums from the epilogue of the data-gradient conv that PRODUCES the GroupNorm output's gradient (resnet.py:80-93
 // under train.py:151: conv2^T(dc2) = da, then GN1 backward needs A_j = sum da_E * xh and B_j = sum da_E per (sample, group, class
 // j = channel mod cg) before anything else -- lp_gn_bwd_reduce_kernel's pass over da and c1).  The epilogue holds da in registers; it

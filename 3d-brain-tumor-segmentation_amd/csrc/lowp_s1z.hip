@@ -41,6 +41,8 @@ struct LpS1zParams {
   long gn_B;
   LpGnbFuse gb;      // GNB kernels: GroupNorm-backward class sums of the stored output against the GroupNorm input gb.x (lowp_common.h)
   int gb_zt;         // planes per group
+  LpGnaFuse ga;      // GNA kernels: GroupNorm (+ReLU) applied to the input planes in LDS (lowp_common.h)
+  int ga_zt;         // planes per group of the input's GroupNorm
 };
 #define S1Z_TX 32
 #define S1Z_TY 16
@@ -56,13 +58,13 @@ __device__ __forceinline__ u32x4 s1z_rsrc(const void* base) {
   return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
 }
 
-template <typename T, int KS, bool GNB = false>
+template <typename T, int KS, bool GNB = false, bool GNA = false>
 __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int SX = S1Z_SX, SY = S1Z_SY, NVOX = SX * SY, NCHK = S1Z_NCHK;
   constexpr int WB = 27 * KS * 1024, PLB = NCHK * 1024 * KS;
   constexpr int OFF_P = WB, OFF_BIAS = WB + 2 * PLB, OFF_SCR = OFF_BIAS + 256;
-  constexpr int OFF_GB = OFF_SCR + 1024;      // GNB: gamma[32] | beta[32] | mean[32] | rstd[32] of the current sample (floats)
+  constexpr int OFF_GB = OFF_SCR + 1024;      // GNB: gamma'[32] | beta'[32] | mean[32] | rstd[32] of the current sample (floats); GNA: gamma | beta | mean | rstd
 #ifdef S1Z_EXP_2ISSUE   // timing experiment: two waves issue all plane requests of a stage (is request back-pressure what stalls the others?)
   constexpr int NREQ = NCHK * KS, NR = NREQ / 2;
 #define S1Z_ID(j) ((wave < 2) ? (wave * NR + (j)) : 0x7fff)
@@ -106,6 +108,64 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
           v = (unsigned)(((vy * p.W + vx) * p.ldx + ks * 16 + hp * 8) * 2);
       }
       voff[j] = v;
+    }
+  };
+  // GNA: the 16-byte slots of a plane buffer this thread transforms (slot tid + 512 i) and which of them hold a voxel of the image (the
+  // others were zero-filled by the DMA and must stay zero: 'same' padding is applied AFTER the normalisation)
+  constexpr int NSLOT = KS * NCHK * 64, NSL = (NSLOT + 511) / 512;
+  unsigned ga_ok = 0;
+  int ga_g = -1;                 // group whose parameters sit in the registers below
+  float ga_mu = 0.f, ga_sc[8], ga_be[8];
+  auto ga_setup = [&]() {
+    ga_ok = 0;
+    ga_g = -1;
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+      const int id = tid + 512 * i;
+      const int chunk = (id >> 6) % NCHK, vox = chunk * 32 + ((id & 63) >> 1);
+      const int vy = vox / SX, vx = vox - vy * SX;
+      if (id < NSLOT && vox < NVOX && (unsigned)(cx0 - 1 + vx) < (unsigned)p.W && (unsigned)(cy0 - 1 + vy) < (unsigned)p.H) ga_ok |= 1u << i;
+    }
+  };
+  auto ga_apply = [&](int buf, int z) {      // plane z has landed in buffer buf and nobody reads it yet
+    if (z < 0 || z >= p.D) return;           // (a zero plane outside the volume)
+    const int gq = z / p.ga_zt;
+    if (gq != ga_g) {                        // (uniform: the march entered another group)
+      const float* gsh = reinterpret_cast<const float*>(lds + OFF_GB);
+      const int cm = p.ga.cg - 1;
+      ga_g = gq;
+      ga_mu = gsh[64 + gq];
+      const float rs = gsh[96 + gq];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        ga_sc[e] = rs * gsh[gq * p.ga.cg + (e & cm)];
+        ga_be[e] = gsh[32 + gq * p.ga.cg + (e & cm)];
+      }
+    }
+    const float mu = ga_mu;
+    const float (&sc)[8] = ga_sc;
+    const float (&be)[8] = ga_be;
+    // all loads first (one LDS latency), the arithmetic of bts_lp_gn_apply, slots outside the image written back as the zeros they were
+    u32x4 raw[NSL];
+#pragma unroll
+    for (int i = 0; i < NSL; ++i)
+      if (tid + 512 * i < NSLOT) raw[i] = *reinterpret_cast<const u32x4*>(lds + OFF_P + buf * PLB + (tid + 512 * i) * 16);
+#ifdef S1Z_EXP_GNA_NOLDS      // timing experiment (wrong results): the transform without its arithmetic and stores
+    return;
+#endif
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+      if (tid + 512 * i < NSLOT) {
+        float v[8], o[8];
+        unpack8<T>(raw[i], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = fmaxf(fmaf(v[e] - mu, sc[e], be[e]), 0.f);
+        u32x4 r = pack8<T>(o);
+        const bool ok = (ga_ok >> i) & 1u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = ok ? r[k] : 0u;
+        *reinterpret_cast<u32x4*>(lds + OFF_P + buf * PLB + (tid + 512 * i) * 16) = r;
+      }
     }
   };
   auto issue1 = [&](int j, int zp, int buf) {      // request j of input plane zp -> plane buffer buf (out of the volume: zeros)
@@ -371,10 +431,26 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
         gsh[32 + c] = p.gb.beta[c] - p.gb.mean[cn * p.gb.G + gq] * gp;
       }
     }
+    if constexpr (GNA) {
+      ga_setup();
+      float* gsh = reinterpret_cast<float*>(lds + OFF_GB);
+      const int C = 16 * KS;
+      if (tid < C) { gsh[tid] = p.ga.gamma[tid]; gsh[32 + tid] = p.ga.beta[tid]; }
+      if (tid >= 64 && tid < 64 + p.ga.G) {
+        gsh[64 + tid - 64] = p.ga.mean[cn * p.ga.G + tid - 64];
+        gsh[96 + tid - 64] = p.ga.rstd[cn * p.ga.G + tid - 64];
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NR; ++j) issue1(j, zlo - 1, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if constexpr (GNA) {
+      ga_apply(0, zlo - 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
     init_set(0); init_set(1); init_set(2);
     int zp = zlo - 1, buf = 0;
     // stage zp completes output plane zp - 1 (set of tap kz = 2)
@@ -383,6 +459,12 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
     __builtin_amdgcn_s_barrier();                                                            \
     asm volatile("" ::: "memory");                                                           \
+    if constexpr (GNA) {      /* the next plane has landed: normalise it in place; visible to every wave before the next stage reads it */ \
+      if (zp < zhi) ga_apply(buf ^ 1, zp + 1);                                               \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
+      __builtin_amdgcn_s_barrier();                                                          \
+      asm volatile("" ::: "memory");                                                         \
+    }                                                                                        \
     if (zp - 1 >= zlo) store_set(S1zIC<(RR + 2) % 3>{}, zp - 1); else init_set((RR + 2) % 3);  \
     buf ^= 1;                                                                                \
     if (++zp > zhi) break;
@@ -444,10 +526,18 @@ long bts_lp_s1z_gnb_B_(int N, int D, int H, int W, int Cin, int ldx, int Cout, i
   return (long)(pl.ZC < zt ? zt / pl.ZC : 1) * pl.nty * pl.ntx * 8;
 }
 // BTS_OK = ran, 1 = declined.  wp = the DMA part of the K3S1 image.  gb (may be NULL): see LpGnbFuse; its B must be bts_lp_s1z_gnb_B_'s
+// does the kernel take the shape with GroupNorm `in_G` applied to its input planes (LpGnaFuse)?
+bool bts_lp_s1z_gna_ok_(int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, int in_G) {
+  S1zPlan pl;
+  if (in_G <= 0 || in_G > 32 || D % in_G != 0 || Cin % in_G != 0 || ldx != Cin || !s1z_plan(pl, N, D, H, W, Cin, ldx, Cout, ldy)) return false;
+  const int cg = Cin / in_G;
+  return cg <= 8 && 8 % cg == 0;
+}
 int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bias, void* y, int N, int D, int H, int W, int Cin, int ldx,
-                       int Cout, int ldy, int accum, double* gn_part, int gn_G, hipStream_t stream, const LpGnbFuse* gb) {
+                       int Cout, int ldy, int accum, double* gn_part, int gn_G, hipStream_t stream, const LpGnbFuse* gb, const LpGnaFuse* ga) {
   S1zPlan pl;
   if (!s1z_plan(pl, N, D, H, W, Cin, ldx, Cout, ldy)) return 1;
+  if (ga != nullptr && (gb != nullptr || !bts_lp_s1z_gna_ok_(N, D, H, W, Cin, ldx, Cout, ldy, ga->G) || ga->cg != Cin / ga->G)) return 1;
   if ((((uintptr_t)x) & 15) || (((uintptr_t)y) & 15) || (((uintptr_t)wp) & 15)) return 1;
   if (gn_part != nullptr && (gn_G <= 0 || D % gn_G != 0)) return 1;
   if (gb != nullptr && (gn_part != nullptr || gb->B != bts_lp_s1z_gnb_B_(N, D, H, W, Cin, ldx, Cout, ldy, gb->G) || gb->B <= 0 ||
@@ -459,13 +549,14 @@ int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bi
   p.ntx = pl.ntx; p.nty = pl.nty; p.nzc = pl.nzc; p.ZC = pl.ZC; p.nitems = pl.nitems; p.ipw = pl.ipw; p.xcd_order = pl.xcd; p.accum = accum;
   p.gnp = gn_part; p.gn_G = gn_G; p.gn_zt = gn_G > 0 ? D / gn_G : 1; p.gn_B = gn_G > 0 ? (long)(D / gn_G) * pl.nty * pl.ntx * 8 : 0;
   if (gb != nullptr) { p.gb = *gb; p.gb_zt = D / gb->G; } else { p.gb = LpGnbFuse{}; p.gb_zt = 1; }
+  if (ga != nullptr) { p.ga = *ga; p.ga_zt = D / ga->G; } else { p.ga = LpGnaFuse{}; p.ga_zt = 1; }
   const int KS = Cin / 16;
   const size_t shmem = (size_t)(27 * KS * 1024 + 2 * S1Z_NCHK * 1024 * KS + 256 + 1024 + 512);
   (void)hipGetLastError();
-#define S1Z_LAUNCH(TT, KS_) do { if (gb != nullptr) S1Z_LAUNCH_(TT, KS_, true); else S1Z_LAUNCH_(TT, KS_, false); } while (0)
-#define S1Z_LAUNCH_(TT, KS_, GB_)                                                                                            \
+#define S1Z_LAUNCH(TT, KS_) do { if (gb != nullptr) S1Z_LAUNCH_(TT, KS_, true, false); else if (ga != nullptr) S1Z_LAUNCH_(TT, KS_, false, true); else S1Z_LAUNCH_(TT, KS_, false, false); } while (0)
+#define S1Z_LAUNCH_(TT, KS_, GB_, GA_)                                                                                       \
   do {                                                                                                                       \
-    auto kern = lp_s1z_kernel<TT, KS_, GB_>;                                                                                 \
+    auto kern = lp_s1z_kernel<TT, KS_, GB_, GA_>;                                                                            \
     static bool done = false;                                                                                                \
     if (!done) {                                                                                                             \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \

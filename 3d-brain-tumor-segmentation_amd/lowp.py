@@ -180,6 +180,26 @@ def conv_gn(code, tdt, x, wp, bias, cout, norm):
     return y, mean, rstd
 
 
+def conv_gn_normed_input(code, tdt, x, norm_in, mean_in, rstd_in, relu_in, wp, bias, cout, norm):
+    """(y, mean, rstd) with y = conv3x3x3([relu](norm_in(x))) + bias and `norm`'s statistics of y: the GroupNorm of the conv's INPUT is
+    applied to each input plane inside the conv kernel (bts_lp_conv3d_gnin_fwd_gn) -- for forwards whose normalised tensor nobody else
+    reads (inference).  None where the library does not take the shape in this form: the caller runs gn_apply + conv_gn."""
+    if norm._mode != ops.GN_SLAB or norm_in._mode != ops.GN_SLAB or not x.is_contiguous() or not relu_in:
+        return None
+    n, d, h, w, cin = x.shape
+    nb = getattr(lib(), '_bts_lp_conv3d_gnin_fwd_gn_workspace')(n, d, h, w, cin, cout, norm_in.groups, norm.groups)
+    if nb < 0:
+        return None
+    y = torch.empty((n, d, h, w, cout), dtype=tdt, device=x.device)
+    mean = torch.empty(n * norm.groups, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(n * norm.groups, dtype=torch.float32, device=x.device)
+    ws = ops.workspace(nb, x.device)
+    lib().call('bts_lp_conv3d_gnin_fwd_gn', code, _p(x), _p(norm_in.gamma.t), _p(norm_in.beta.t), _p(mean_in), _p(rstd_in), norm_in.groups,
+               1 if relu_in else 0, _p(wp), _p(bias), _p(y), _p(mean), _p(rstd), _p(ws), nb, n, d, h, w, cin, cout, norm.groups,
+               float(norm.epsilon), _stream())
+    return y, mean, rstd
+
+
 def gn_stats(code, x, groups, mode, eps):
     n, c = x.shape[0], x.shape[4]
     v = x.shape[1] * x.shape[2] * x.shape[3]
@@ -473,11 +493,17 @@ class LowPrecisionForward(object):
         wp_c1 = self._packed((key, 'c1'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
         res, gap, (_, ch), gate = gate_branch(code, tdt, x, wp_pt, blk.ptwise_b.t, f, blk.se_w1.t, blk.se_w2.t)
         c1, m1, r1 = conv_gn(code, tdt, x, wp_c1, blk.conv1_b.t, f, blk.norm1)      # conv + the statistics of its output
-        a = gn_apply(code, c1, blk.norm1.gamma.t, blk.norm1.beta.t, m1, r1, g, blk.norm1._mode, True)
-        del c1
         wp_c2 = self._packed((id(blk), 'c2'), ops.K3S1, blk.conv2_k, f, f)
-        c2, m2, r2 = conv_gn(code, tdt, a, wp_c2, blk.conv2_b.t, f, blk.norm2)
-        del a
+        # conv2 reads relu(GN1(c1)); nobody else does in a forward without a backward: where the library can, GN1 + ReLU are applied to
+        # conv2's input planes inside the conv kernel and the apply pass (1 read + 1 write of the tensor) goes away
+        fused = conv_gn_normed_input(code, tdt, c1, blk.norm1, m1, r1, True, wp_c2, blk.conv2_b.t, f, blk.norm2)
+        if fused is not None:
+            c2, m2, r2 = fused
+        else:
+            a = gn_apply(code, c1, blk.norm1.gamma.t, blk.norm1.beta.t, m1, r1, g, blk.norm1._mode, True)
+            c2, m2, r2 = conv_gn(code, tdt, a, wp_c2, blk.conv2_b.t, f, blk.norm2)
+            del a
+        del c1
         if out is None:
             out = torch.empty((n, d, h, w, f), dtype=tdt, device=res.device)
         if gate is not None:

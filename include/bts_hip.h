@@ -319,6 +319,16 @@ long bts_lp_conv3d_fwd_gn_workspace(int N, int D, int H, int W, int Cin, int Cou
 int bts_lp_conv3d_fwd_gn(int dtype, const void* x, const void* wp, const float* bias, void* y, float* mean, float* rstd, void* workspace,
                          long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int G, float eps,
                          bts_stream_t stream);
+/* The same with the GroupNorm + ReLU of the INPUT applied on the way in (in_relu = 1): y = conv3x3x3(relu(GN_in(x))) + bias and the statistics of y.
+ * conv2 of a ResnetBlock reading conv1's raw output (layers/resnet.py:133-136: conv -> GroupNormalization -> relu -> conv) in a forward
+ * whose normalised tensor nobody else reads (Model.call(inference=True), model.py:58-71; test.py:128-151): the separate apply pass of
+ * layers/group_norm.py:110-122 goes away.  x dense (N,D,H,W,Cin); in_* = that GroupNorm's parameters and statistics (slab mode).
+ * The workspace query returns -1 and the call BTS_ERR_UNSUPPORTED where no kernel takes the shape in this form. */
+long bts_lp_conv3d_gnin_fwd_gn_workspace(int N, int D, int H, int W, int Cin, int Cout, int in_G, int G);
+int bts_lp_conv3d_gnin_fwd_gn(int dtype, const void* x, const float* in_gamma, const float* in_beta, const float* in_mean,
+                              const float* in_rstd, int in_G, int in_relu, const void* wp, const float* bias, void* y, float* mean,
+                              float* rstd, void* workspace, long workspace_bytes, int N, int D, int H, int W, int Cin, int Cout, int G,
+                              float eps, bts_stream_t stream);
 /* y = Conv3DTranspose(k3, s2, 'same')(x) + bias (dense fine tensor (N,2D,2H,2W,Cout), storage type) and the slab-mode GroupNorm
  * statistics of y in one pass: ConvUpsample (upsample.py:28-43: conv -> GroupNormalization) without a statistics pass over the fine
  * tensor.  (D,H,W): the COARSE grid; wp = bts_lp_pack(BTS_CONV_K3S2T, BTS_ROLE_FWD, ...).  Falls back to the conv + bts_lp_gn_stats

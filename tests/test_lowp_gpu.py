@@ -490,6 +490,49 @@ def test_conv_with_fused_groupnorm_statistics(case, dtype):
 
 
 @pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('case', [((1, 16, 64, 64), 32, 32, 8, 8), ((2, 8, 64, 64), 16, 32, 4, 8), ((1, 24, 48, 96), 32, 16, 8, 4), ((1, 64, 32, 32), 32, 32, 8, 8),
+                                  ((1, 16, 64, 64), 32, 32, 2, 8)],
+                         ids=['32-32-g8', 'batch2-16-32-g4', '16-couts-three-columns', 'z-chunks', 'classes-of-16-declined'])
+def test_conv_with_groupnorm_applied_to_its_input_planes(case, dtype):
+    """bts_lp_conv3d_gnin_fwd_gn (conv2 of a block reading conv1's RAW output in a forward without a backward, resnet.py:133-136): the
+    arithmetic of bts_lp_gn_apply on the planes in LDS, zero padding after the normalisation -- y, mean, rstd bit-equal to
+    gn_apply + conv_gn; shapes / class counts the kernel does not take in this form are declined (None)"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    (n, d, h, w), cin, cout, gin, gout = case
+    code, tdt = lowp.DTYPES[dtype]
+    g = torch.Generator().manual_seed(cin * 7 + cout + d)
+    c1 = (torch.randn((n, d, h, w, cin), generator=g) * 1.5 + 0.3).to(tdt).to(DEV)
+    wt = torch.randn((3, 3, 3, cin, cout), generator=g) * (2.0 / (27 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g).to(DEV)
+    wp = lowp.pack(ops.K3S1, code, wt.to(DEV), cin, cout)
+
+    class _P(object):
+        def __init__(self, t):
+            self.t = t
+
+    class _NormIn(object):
+        groups, epsilon, _mode = gin, 1e-5, ops.GN_SLAB
+        gamma = _P((1.0 + 0.3 * torch.randn(cin, generator=g)).to(DEV))
+        beta = _P((0.3 * torch.randn(cin, generator=g)).to(DEV))
+
+    class _NormOut(object):
+        groups, epsilon, _mode = gout, 1e-5, ops.GN_SLAB
+    m1, r1 = lowp.gn_stats(code, c1, gin, ops.GN_SLAB, 1e-5)
+    got = lowp.conv_gn_normed_input(code, tdt, c1, _NormIn, m1, r1, True, wp, b, cout, _NormOut)
+    if cin // gin > 8:
+        assert got is None
+        return
+    assert got is not None
+    a = lowp.gn_apply(code, c1, _NormIn.gamma.t, _NormIn.beta.t, m1, r1, gin, ops.GN_SLAB, True)
+    y_ref, m_ref, r_ref = lowp.conv_gn(code, tdt, a, wp, b, cout, _NormOut)
+    torch.cuda.synchronize()
+    assert float(a.float().abs().max()) > 0 and float((a == 0).float().mean()) > 0.05       # (the ReLU bites)
+    assert torch.equal(got[0], y_ref)
+    assert torch.equal(got[1], m_ref) and torch.equal(got[2], r_ref)
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
 @pytest.mark.parametrize('case', [((1, 20, 24, 20), 256, 256, 8), ((1, 8, 12, 20), 128, 128, 8), ((2, 8, 8, 8), 256, 64, 4)],
                          ids=['deepest-inference-level', '128-128', 'batch2-256-64-g4'])
 def test_split_channel_conv_leaves_the_groupnorm_statistics_of_its_stored_output(case, dtype):
