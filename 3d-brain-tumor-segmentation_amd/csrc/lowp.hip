@@ -2927,7 +2927,8 @@ int bts_lp_wgs_launch_(int dtype, const void* P, const void* Q, float* dw, void*
 // lowp_wgd.hip: the streaming weight-gradient kernel of the stride-1 3x3x3 convolutions with Cout <= 32
 long bts_lp_wgd_workspace_(int N, int D, int H, int W, int Cp, int Cq);
 int bts_lp_wgd_launch_(int dtype, const void* x, const void* dy, float* dw, void* ws, long ws_bytes, int N, int D, int H, int W, int Cp, int ldp,
-                       int Cq, int ldq, int dup_start, int dup_shift, int accum, hipStream_t stream);
+                       int Cq, int ldq, int dup_start, int dup_shift, int accum, hipStream_t stream, const LpGnaFuse* ga = nullptr);
+bool bts_lp_wgd_gna_ok_(int N, int D, int H, int W, int Cp, int Cq, int in_G);
 // db[k] (+)= sum_n colsum[n][k]
 __global__ void lp_bias_grad_kernel(const float* cs, float* db, int N, int C, int accum) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3067,6 +3068,44 @@ extern "C" int bts_lp_conv3d_bwd_weight(int kind, int dtype, const void* x, cons
     void* cws = wsb + (((long)N * Cout * 4 + 255) & ~255L);
     const int r = bts_lp_colsum(dtype, dy, cs, cws, bts_lp_colsum_workspace(N, (long)D * H * W, Cout), N, (long)D * H * W, Cout, 1.0f, stream);
     if (r != BTS_OK) return r;
+    hipLaunchKernelGGL(lp_bias_grad_kernel, dim3((Cout + 255) / 256), dim3(256), 0, stream, cs, db, N, Cout, accumulate);
+    BTS_LAUNCH_CHECK();
+  }
+  return BTS_OK;
+}
+// conv2 of a ResnetBlock in TRAINING without the normalised tensor: conv2's forward reads conv1's raw output through
+// bts_lp_conv3d_gnin_fwd_gn, and its weight gradient dW[t][c][k] = sum_v a[v + off_t][c] dy[v][k] with a = relu(GN1(x)) is taken from the
+// raw x the same way -- the streaming weight-gradient kernel normalises its P planes in LDS (lowp_wgd.hip, GNA).  a = relu(GN1(c1))
+// (resnet.py:133-134) is then never written: one 1 read + 1 write pass and one activation-sized tensor per block less.
+// bts_lp_conv3d_gnin_train_ok: 1 when BOTH kernels take the shape in this form (ask before the forward), else 0.
+extern "C" int bts_lp_conv3d_gnin_train_ok(int N, int D, int H, int W, int Cin, int Cout, int in_G, int G) {
+  if (bts_lp_conv3d_gnin_fwd_gn_workspace(N, D, H, W, Cin, Cout, in_G, G) < 0) return 0;
+  return bts_lp_wgd_gna_ok_(N, D, H, W, Cin, Cout, in_G) ? 1 : 0;
+}
+// x: the RAW GroupNorm input, dense (N,D,H,W,Cin); in_*: that GroupNorm's parameters and statistics (slab mode; ReLU follows it);
+// dy (N,D,H,W,Cout) rows of lddy; dw (3,3,3,Cin,Cout) fp32 (+)=; db (may be NULL) (+)= column sums of dy (dense dy then).  Workspace:
+// bts_lp_conv3d_bwd_weight_workspace(BTS_CONV_K3S1, ...).  BTS_ERR_UNSUPPORTED where bts_lp_conv3d_gnin_train_ok says 0.
+extern "C" int bts_lp_conv3d_gnin_bwd_weight(int dtype, const void* x, const float* in_gamma, const float* in_beta, const float* in_mean,
+                                             const float* in_rstd, int in_G, const void* dy, float* dw, float* db, void* workspace,
+                                             long workspace_bytes, int N, int D, int H, int W, int Cin, int Cout, int lddy, int accumulate,
+                                             hipStream_t stream) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin % 8 != 0 || Cout % 8 != 0 || lddy % 8 != 0 || lddy < Cout) return BTS_ERR_SHAPE;
+  if (!bts_lp_wgd_gna_ok_(N, D, H, W, Cin, Cout, in_G)) return BTS_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)dy) & 15) || (((uintptr_t)workspace) & 15)) return BTS_ERR_ALIGN;
+  if (workspace_bytes < bts_lp_conv3d_bwd_weight_workspace(BTS_CONV_K3S1, N, D, H, W, Cin, Cout)) return BTS_ERR_WORKSPACE;
+  const long part_bytes = bts_lp_wgd_workspace_(N, D, H, W, Cin, Cout);
+  LpGnaFuse ga{in_gamma, in_beta, in_mean, in_rstd, in_G, Cin / in_G};
+  const int r = bts_lp_wgd_launch_(dtype, x, dy, dw, workspace, part_bytes, N, D, H, W, Cin, Cin, Cout, lddy, 0, 0, accumulate, stream, &ga);
+  if (r == 1) return BTS_ERR_UNSUPPORTED;
+  if (r != BTS_OK) return r;
+  if (db != nullptr) {
+    if (lddy != Cout) return BTS_ERR_UNSUPPORTED;
+    char* wsb = reinterpret_cast<char*>(workspace) + ((part_bytes + 255) & ~255L);
+    float* cs = reinterpret_cast<float*>(wsb);
+    void* cws = wsb + (((long)N * Cout * 4 + 255) & ~255L);
+    const int r2 = bts_lp_colsum(dtype, dy, cs, cws, bts_lp_colsum_workspace(N, (long)D * H * W, Cout), N, (long)D * H * W, Cout, 1.0f, stream);
+    if (r2 != BTS_OK) return r2;
     hipLaunchKernelGGL(lp_bias_grad_kernel, dim3((Cout + 255) / 256), dim3(256), 0, stream, cs, db, N, Cout, accumulate);
     BTS_LAUNCH_CHECK();
   }

@@ -45,6 +45,8 @@ struct LpWgdParams {
   int N, D, H, W, Cp, ldp, Cq, ldq;
   int ntx, nty, nzc, ZC;     // columns per sample (x, y), z chunks per column, planes per chunk
   int nitems, ipw, ncp, ncq, xcd_order;
+  LpGnaFuse ga;              // GNA kernels: P is the RAW GroupNorm input; relu(GroupNorm(P)) is formed on the planes in LDS (lowp_common.h)
+  int ga_zt;                 // planes per group
 };
 #define WGD_TX 32
 #define WGD_TY 8
@@ -56,7 +58,8 @@ struct LpWgdParams {
 #define WGD_NQS 5                           // Q planes in LDS: the stage's three and the next two in flight
 #define WGD_QBASE (WGD_NPB * WGD_PPL)
 #define WGD_SCR (WGD_QBASE + WGD_NQS * WGD_QPL)   // 1 KB that swallows the filler requests
-#define WGD_LDS (WGD_SCR + 1024)            // 159744 bytes
+#define WGD_GA (WGD_SCR + 1024)             // GNA: gamma[32] | beta[32] | mean[32] | rstd[32] of the item's sample (floats)
+#define WGD_LDS (WGD_GA + 512)              // 160256 bytes
 
 // One LDS-DMA request (buffer_load_dwordx4 ... lds: 64 lanes x 16 bytes -> 1 KB of LDS at M0) as inline assembly.  Through the builtin the
 // compiler orders every later LDS read behind the request with s_waitcnt vmcnt(0) (it cannot tell the read from the request's
@@ -82,7 +85,7 @@ template <> struct Mfma16<TBF16> {
   }
 };
 
-template <typename T>
+template <typename T, bool GNA = false>
 __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // (see lp_s1d_kernel: the host pass drops the launch stub of this template otherwise)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -100,6 +103,9 @@ __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
   unsigned voff[6];               // this lane's byte offset inside a plane for request j of the current item (bit 31: masked = zeros)
   unsigned pplane, qplane;        // bytes per plane
   int zlo = 0, zhi = 0;
+  unsigned ga_ok = 0;
+  int ga_n = 0, ga_g = -1;
+  float ga_mu = 0.f, ga_sc[8], ga_be[8];
   auto kind_of = [&](int j) { const int id = j * 8 + wave; return id < 25 ? 0 : id < 41 ? 1 : 2; };   // P, Q, filler (wave-uniform)
   auto dst_of = [&](int j) {      // LDS byte offset of request j inside its plane
     const int id = j * 8 + wave;
@@ -140,6 +146,61 @@ __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
       }
       voff[j] = v;
     }
+    if constexpr (GNA) {      // which of this thread's 16-byte pieces of a P plane (piece tid + 512 i of 25 x 64) hold image voxels
+      ga_n = n;
+      ga_ok = 0;
+      ga_g = -1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int id = tid + 512 * i;
+        const int slot = (id >> 6) * 16 + ((id & 63) >> 2), ps = id & 3;
+        const int row = slot / 40, xl = slot - row * 40;
+        const int oct = ps ^ (2 * ((slot >> 3) & 1));
+        if (id < 1600 && xl < 34 && cp0 + oct * 8 < p.Cp && (unsigned)(x0 - 1 + xl) < (unsigned)p.W && (unsigned)(y0 - 1 + row) < (unsigned)p.H)
+          ga_ok |= 1u << i;
+      }
+    }
+  };
+  // GNA: P plane z has landed in buffer pbuf and nobody reads it yet: a = relu(fmaf(v - mean, rstd * gamma, beta)) in place, the arithmetic
+  // of bts_lp_gn_apply element for element; pieces outside the image stay the zeros the DMA wrote ('same' padding applies to a)
+  auto ga_apply = [&](int pbuf, int z) {
+    if (z < 0 || z >= p.D) return;
+    const int gq = z / p.ga_zt;
+    if (gq != ga_g) {
+      const float* gsh = reinterpret_cast<const float*>(lds + WGD_GA);
+      const int cm = p.ga.cg - 1;
+      ga_g = gq;
+      ga_mu = gsh[64 + gq];
+      const float rs = gsh[96 + gq];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        ga_sc[e] = rs * gsh[gq * p.ga.cg + (e & cm)];
+        ga_be[e] = gsh[32 + gq * p.ga.cg + (e & cm)];
+      }
+    }
+    u32x4 raw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (tid + 512 * i < 1600) raw[i] = *reinterpret_cast<const u32x4*>(lds + pbuf * WGD_PPL + (tid + 512 * i) * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (tid + 512 * i < 1600) {
+        float v[8], o[8];
+        unpack8<T>(raw[i], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = fmaxf(fmaf(v[e] - ga_mu, ga_sc[e], ga_be[e]), 0.f);
+        u32x4 r = pack8<T>(o);
+        const bool ok = (ga_ok >> i) & 1u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = ok ? r[k] : 0u;
+        *reinterpret_cast<u32x4*>(lds + pbuf * WGD_PPL + (tid + 512 * i) * 16) = r;
+      }
+    }
+  };
+  auto ga_fence = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   };
   // request j of a stage's six: Q plane zq -> ring slot qslot, P plane zp -> buffer pbuf (want_p false: fillers instead).  The stage
   // deals its six between its matrix instructions (a request costs the wave ~100 issue cycles)
@@ -267,9 +328,18 @@ __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
     issue(zlo - 1, 1, 0, 0, false);
     issue(zlo, 2, zlo - 1, 0, true);
     issue(zlo + 1, 3, zlo, 1, true);
+    if constexpr (GNA) {      // (the previous item's last table reads lie behind its closing barrier; the barrier below publishes these)
+      float* gsh = reinterpret_cast<float*>(lds + WGD_GA);
+      if (tid < p.Cp && tid < 32) { gsh[tid] = p.ga.gamma[tid]; gsh[32 + tid] = p.ga.beta[tid]; }
+      if (tid >= 64 && tid < 64 + p.ga.G) {
+        gsh[tid] = p.ga.mean[ga_n * p.ga.G + tid - 64];
+        gsh[32 + tid] = p.ga.rstd[ga_n * p.ga.G + tid - 64];
+      }
+    }
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // everything but the last stage's worth has landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if constexpr (GNA) { ga_apply(0, zlo - 1); ga_fence(); }
     // the first stage's resident planes (zlo - 1, zlo - 2: outside the item = zeros): roles kz 1, 2 at rot 0
 #pragma unroll
     for (int qrow = 0; qrow < 4; ++qrow) qfp[1][qrow] = qfp[2][qrow] = u32x4{0u, 0u, 0u, 0u};
@@ -289,6 +359,10 @@ __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
       __builtin_amdgcn_s_barrier();
 #endif
       asm volatile("" ::: "memory");
+      if constexpr (GNA) {      // the next stage's P plane (zp + 1) has landed: normalise it before anyone reads it
+        if (zp < zhi) { ga_apply(pb_i + 1 == WGD_NPB ? 0 : pb_i + 1, zp + 1); }
+        ga_fence();
+      }
       if (++pb_i == WGD_NPB) pb_i = 0;
       if (++qs == WGD_NQS) qs = 0;
       rot = rot == 0 ? 2 : rot - 1;
@@ -355,20 +429,30 @@ long bts_lp_wgd_workspace_(int N, int D, int H, int W, int Cp, int Cq) {
   if (!wgd_plan(pl, N, D, H, W, Cp, Cp, Cq, Cq)) return 0;
   return (long)pl.nwg * pl.ncp * pl.ncq * 27 * 1024 * 4;
 }
+// does the kernel take the shape with GroupNorm `in_G` (+ReLU) applied to its P planes (LpGnaFuse)?
+bool bts_lp_wgd_gna_ok_(int N, int D, int H, int W, int Cp, int Cq, int in_G) {
+  WgdPlan pl;
+  if (in_G <= 0 || in_G > 32 || D % in_G != 0 || Cp % in_G != 0 || Cp > 32 || !wgd_plan(pl, N, D, H, W, Cp, Cp, Cq, Cq)) return false;
+  const int cg = Cp / in_G;
+  return cg <= 8 && 8 % cg == 0;
+}
 // BTS_OK = ran (dw written by the shared finalize), 1 = declined
 int bts_lp_wgd_launch_(int dtype, const void* x, const void* dy, float* dw, void* ws, long ws_bytes, int N, int D, int H, int W, int Cp, int ldp,
-                       int Cq, int ldq, int dup_start, int dup_shift, int accum, hipStream_t stream) {
+                       int Cq, int ldq, int dup_start, int dup_shift, int accum, hipStream_t stream, const LpGnaFuse* ga) {
   WgdPlan pl;
   if (!wgd_plan(pl, N, D, H, W, Cp, ldp, Cq, ldq)) return 1;
+  if (ga != nullptr && (ldp != Cp || dup_shift != 0 || !bts_lp_wgd_gna_ok_(N, D, H, W, Cp, Cq, ga->G) || ga->cg != Cp / ga->G)) return 1;
   if (ws_bytes < (long)pl.nwg * pl.ncp * pl.ncq * 27 * 1024 * 4) return 1;
   LpWgdParams p;
   p.p = (const unsigned short*)x; p.q = (const unsigned short*)dy; p.part = reinterpret_cast<float*>(ws);
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cp = Cp; p.ldp = ldp; p.Cq = Cq; p.ldq = ldq;
   p.ntx = pl.ntx; p.nty = pl.nty; p.nzc = pl.nzc; p.ZC = pl.ZC; p.nitems = pl.nitems; p.ipw = pl.ipw; p.ncp = pl.ncp; p.ncq = pl.ncq; p.xcd_order = pl.xcd;
+  if (ga != nullptr) { p.ga = *ga; p.ga_zt = D / ga->G; } else { p.ga = LpGnaFuse{}; p.ga_zt = 1; }
   (void)hipGetLastError();
-#define WGD_LAUNCH(TT)                                                                                                       \
+#define WGD_LAUNCH(TT) do { if (ga != nullptr) WGD_LAUNCH_(TT, true); else WGD_LAUNCH_(TT, false); } while (0)
+#define WGD_LAUNCH_(TT, GA_)                                                                                                 \
   do {                                                                                                                       \
-    auto kern = lp_wgd_kernel<TT>;                                                                                           \
+    auto kern = lp_wgd_kernel<TT, GA_>;                                                                                      \
     static bool done = false;                                                                                                \
     if (!done) {                                                                                                             \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WGD_LDS); \
@@ -381,6 +465,7 @@ int bts_lp_wgd_launch_(int dtype, const void* x, const void* dy, float* dw, void
   if (prof) bts_prof_begin(37, 2.0 * 27.0 * (double)Cp * Cq * (double)N * D * H * W, stream);
   if (dtype == LP_F16) WGD_LAUNCH(TF16); else WGD_LAUNCH(TBF16);
 #undef WGD_LAUNCH
+#undef WGD_LAUNCH_
   if (prof) bts_prof_end(stream);
   BTS_LAUNCH_CHECK();
   return bts_lp_wgrad_finalize_(p.part, dw, pl.nwg, pl.ncp, pl.ncq, 27, 27, 1, Cp, Cq, Cp + dup_shift, dup_start, dup_shift, accum, stream);

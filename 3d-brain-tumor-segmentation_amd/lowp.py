@@ -200,6 +200,28 @@ def conv_gn_normed_input(code, tdt, x, norm_in, mean_in, rstd_in, relu_in, wp, b
     return y, mean, rstd
 
 
+def gnin_train_ok(x, cout, norm_in, norm):
+    """can conv2 of a block run WITHOUT the normalised tensor in training -- forward through conv_gn_normed_input, weight gradient through
+    conv_bwd_weight_normed_input -- for raw input x (dense (N,D,H,W,Cin)) of GroupNorm `norm_in`?"""
+    if norm._mode != ops.GN_SLAB or norm_in._mode != ops.GN_SLAB or not x.is_contiguous():
+        return False
+    n, d, h, w, cin = x.shape
+    return getattr(lib(), '_bts_lp_conv3d_gnin_train_ok')(n, d, h, w, cin, cout, norm_in.groups, norm.groups) == 1
+
+
+def conv_bwd_weight_normed_input(code, x, norm_in, mean_in, rstd_in, dy, dw, db=None, accumulate=True):
+    """dw (+)= the 3x3x3 weight gradient of a conv whose input was relu(norm_in(x)), from the RAW x (bts_lp_conv3d_gnin_bwd_weight); db
+    (+)= the column sums of dy.  Raises where gnin_train_ok said no."""
+    n, d, h, w, cin = x.shape
+    cout = dy.shape[-1]
+    if dw.shape[-2] != cin or dw.shape[-1] != cout or not x.is_contiguous():
+        raise RuntimeError('conv_bwd_weight_normed_input: dw %s does not match x %s / dy %s' % (tuple(dw.shape), tuple(x.shape), tuple(dy.shape)))
+    nb = lib().query('bts_lp_conv3d_bwd_weight_workspace', ops.K3S1, n, d, h, w, cin, cout)
+    ws = ops.workspace(nb, x.device)
+    lib().call('bts_lp_conv3d_gnin_bwd_weight', code, _p(x), _p(norm_in.gamma.t), _p(norm_in.beta.t), _p(mean_in), _p(rstd_in), norm_in.groups,
+               _p(dy), _p(dw), _p(db) if db is not None else None, _p(ws), nb, n, d, h, w, cin, cout, _ld(dy), 1 if accumulate else 0, _stream())
+
+
 def gn_stats(code, x, groups, mode, eps):
     n, c = x.shape[0], x.shape[4]
     v = x.shape[1] * x.shape[2] * x.shape[3]

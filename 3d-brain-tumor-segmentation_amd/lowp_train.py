@@ -89,6 +89,9 @@ class LowPrecisionTrainer(object):
         # conv2's data gradient + GroupNorm-1's backward through bts_lp_conv3d_bwd_data_gn_bwd (class sums from the conv's epilogue where
         # the streaming kernel runs the layer); BTS_LP_FUSE_GN1_BWD=0: the two separate calls (A/B)
         self.fuse_gn1_bwd = os.environ.get('BTS_LP_FUSE_GN1_BWD', '1') != '0'
+        # GroupNorm-1 + ReLU applied inside conv2's forward and weight-gradient kernels where both can (the normalised tensor is never
+        # written); BTS_LP_FUSE_GN1_APPLY=0: the separate apply pass everywhere (A/B)
+        self.fuse_gn1_apply = os.environ.get('BTS_LP_FUSE_GN1_APPLY', '1') != '0'
         self.last_labels = None
         self._clock = None
 
@@ -229,9 +232,15 @@ class LowPrecisionTrainer(object):
         # shortcut conv + the gate's squeeze in one pass, then the SE-MLP (main stream: see lowp.gate_branch)
         res, gap, (hbuf, ch), gate = lowp.gate_branch(code, tdt, x, wp_pt, blk.ptwise_b.t, f, blk.se_w1.t, blk.se_w2.t, side=False)
         c1, m1, r1 = conv_gn(code, tdt, x, wp_c1, blk.conv1_b.t, f, blk.norm1)      # conv + the statistics of its output
-        a = gn_apply(code, c1, blk.norm1.gamma.t, blk.norm1.beta.t, m1, r1, g, blk.norm1._mode, True)
         wp_c2 = self._pk((key, 'c2'), ops.K3S1, blk.conv2_k, f, f)
-        c2, m2, r2 = conv_gn(code, tdt, a, wp_c2, blk.conv2_b.t, f, blk.norm2)
+        # relu(GN1(c1)) has two readers, conv2's forward and conv2's weight gradient: where both kernels can normalise their input planes
+        # themselves (the streaming kernels of the 128^3 level), the tensor is never written (a = None: the backward knows)
+        a = None
+        if self.fuse_gn1_apply and f % 16 == 0 and lowp.wgrad_supported(ops.K3S1, f, f) and lowp.gnin_train_ok(c1, f, blk.norm1, blk.norm2):
+            c2, m2, r2 = lowp.conv_gn_normed_input(code, tdt, c1, blk.norm1, m1, r1, True, wp_c2, blk.conv2_b.t, f, blk.norm2)
+        else:
+            a = gn_apply(code, c1, blk.norm1.gamma.t, blk.norm1.beta.t, m1, r1, g, blk.norm1._mode, True)
+            c2, m2, r2 = conv_gn(code, tdt, a, wp_c2, blk.conv2_b.t, f, blk.norm2)
         if out is None:
             out = torch.empty((n, d, h, w, f), dtype=tdt, device=x.device)
         sp = torch.empty(n * v, dtype=torch.float32, device=x.device)
@@ -275,7 +284,12 @@ class LowPrecisionTrainer(object):
             self._db_done = True
         else:
             dc2_16, dc2 = self._gn_bwd(n2, s['c2'], dout, s['m2'], s['r2'], want_f32=not lp2, dbias=self._gslot(blk.conv2_b) if lp2 else None)
-        if lp2:
+        if lp2 and s['a'] is None:      # the forward never wrote relu(GN1(c1)): the weight-gradient kernel forms it from c1 on the way in
+            db2 = None if self._db_done else self._gslot(blk.conv2_b)
+            c1_, m1_, r1_ = s['c1'], s['m1'], s['r1']
+            self._wg((c1_, dc2_16), lambda: lowp.conv_bwd_weight_normed_input(code, c1_, n1, m1_, r1_, dc2_16, self._gslot(blk.conv2_k), db2,
+                                                                              accumulate=True))
+        elif lp2:
             a16 = s['a']
             db2 = None if self._db_done else self._gslot(blk.conv2_b)
             self._wg((a16, dc2_16), lambda: _wgrad16(ops.K3S1, code, a16, dc2_16, self._gslot(blk.conv2_k), db2, accumulate=True))
@@ -296,7 +310,7 @@ class LowPrecisionTrainer(object):
             self._db_done = lp1
             del dc2, dc2_16
         else:
-            da = torch.empty_like(s['a'])
+            da = torch.empty_like(s['c1'])
             conv_bwd_data(ops.K3S1, code, dc2_16, wp_c2b, da, False)
             del dc2, dc2_16
             dc1_16, dc1 = self._gn_bwd(n1, s['c1'], da, s['m1'], s['r1'], want_f32=not lp1, dbias=self._gslot(blk.conv1_b) if lp1 else None)

@@ -329,6 +329,17 @@ int bts_lp_conv3d_gnin_fwd_gn(int dtype, const void* x, const float* in_gamma, c
                               const float* in_rstd, int in_G, int in_relu, const void* wp, const float* bias, void* y, float* mean,
                               float* rstd, void* workspace, long workspace_bytes, int N, int D, int H, int W, int Cin, int Cout, int G,
                               float eps, bts_stream_t stream);
+/* The same idea for TRAINING: conv2's weight gradient dW[t][c][k] = sum_v a[v + off_t][c] dy[v][k], a = relu(GN_in(x)), taken from the RAW x
+ * (the streaming weight-gradient kernel normalises its planes in LDS) -- with bts_lp_conv3d_gnin_fwd_gn in the forward, relu(GN1(c1)) of
+ * layers/resnet.py:133-134 is never written (what tf.GradientTape keeps alive for train.py:151 is c1 alone).
+ * bts_lp_conv3d_gnin_train_ok: 1 when both kernels take the shape in this form (ask before the forward), 0 otherwise (not a status).
+ * bts_lp_conv3d_gnin_bwd_weight: x dense (N,D,H,W,Cin) raw; dy rows of lddy; dw (3,3,3,Cin,Cout) fp32 (+)=; db (may be NULL) (+)=;
+ * workspace of bts_lp_conv3d_bwd_weight_workspace(BTS_CONV_K3S1, ...). */
+int bts_lp_conv3d_gnin_train_ok(int N, int D, int H, int W, int Cin, int Cout, int in_G, int G);
+int bts_lp_conv3d_gnin_bwd_weight(int dtype, const void* x, const float* in_gamma, const float* in_beta, const float* in_mean,
+                                  const float* in_rstd, int in_G, const void* dy, float* dw, float* db, void* workspace,
+                                  long workspace_bytes, int N, int D, int H, int W, int Cin, int Cout, int lddy, int accumulate,
+                                  bts_stream_t stream);
 /* y = Conv3DTranspose(k3, s2, 'same')(x) + bias (dense fine tensor (N,2D,2H,2W,Cout), storage type) and the slab-mode GroupNorm
  * statistics of y in one pass: ConvUpsample (upsample.py:28-43: conv -> GroupNormalization) without a statistics pass over the fine
  * tensor.  (D,H,W): the COARSE grid; wp = bts_lp_pack(BTS_CONV_K3S2T, BTS_ROLE_FWD, ...).  Falls back to the conv + bts_lp_gn_stats

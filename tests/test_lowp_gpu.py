@@ -533,6 +533,47 @@ def test_conv_with_groupnorm_applied_to_its_input_planes(case, dtype):
 
 
 @pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('case', [((1, 16, 64, 64), 32, 32, 8), ((2, 8, 64, 64), 16, 32, 4), ((1, 64, 32, 32), 32, 16, 8)],
+                         ids=['32-32-g8', 'batch2-16-32-g4', 'z-chunks-16-couts'])
+def test_weight_gradient_with_groupnorm_applied_to_its_input_planes(case, dtype):
+    """bts_lp_conv3d_gnin_bwd_weight (conv2's weight gradient from conv1's RAW output: the streaming kernel normalises its planes in LDS
+    with bts_lp_gn_apply's arithmetic) against the same kernel on the materialised relu(GN(x)): dw and db bit-equal, first write and
+    accumulate"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    (n, d, h, w), cin, cout, gin = case
+    code, tdt = lowp.DTYPES[dtype]
+    g = torch.Generator().manual_seed(cin * 11 + cout + d)
+    c1 = (torch.randn((n, d, h, w, cin), generator=g) * 1.5 + 0.3).to(tdt).to(DEV)
+    dy = torch.randn((n, d, h, w, cout), generator=g).to(tdt).to(DEV)
+
+    class _P(object):
+        def __init__(self, t):
+            self.t = t
+
+    class _NormIn(object):
+        groups, epsilon, _mode = gin, 1e-5, ops.GN_SLAB
+        gamma = _P((1.0 + 0.3 * torch.randn(cin, generator=g)).to(DEV))
+        beta = _P((0.3 * torch.randn(cin, generator=g)).to(DEV))
+
+    class _NormOut(object):
+        groups, epsilon, _mode = 8, 1e-5, ops.GN_SLAB
+    assert lowp.gnin_train_ok(c1, cout, _NormIn, _NormOut)
+    m1, r1 = lowp.gn_stats(code, c1, gin, ops.GN_SLAB, 1e-5)
+    a = lowp.gn_apply(code, c1, _NormIn.gamma.t, _NormIn.beta.t, m1, r1, gin, ops.GN_SLAB, True)
+    for accumulate in (False, True):
+        init_w = torch.randn((3, 3, 3, cin, cout), generator=g).to(DEV)
+        init_b = torch.randn(cout, generator=g).to(DEV)
+        dw_ref, db_ref = init_w.clone(), init_b.clone()
+        assert lowp.conv_bwd_weight(ops.K3S1, code, a, dy, dw_ref, db_ref, accumulate=accumulate) is not False
+        dw, db = init_w.clone(), init_b.clone()
+        lowp.conv_bwd_weight_normed_input(code, c1, _NormIn, m1, r1, dy, dw, db, accumulate=accumulate)
+        torch.cuda.synchronize()
+        assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+        assert float((dw - init_w).abs().max()) > 0
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
 @pytest.mark.parametrize('case', [((1, 20, 24, 20), 256, 256, 8), ((1, 8, 12, 20), 128, 128, 8), ((2, 8, 8, 8), 256, 64, 4)],
                          ids=['deepest-inference-level', '128-128', 'batch2-256-64-g4'])
 def test_split_channel_conv_leaves_the_groupnorm_statistics_of_its_stored_output(case, dtype):

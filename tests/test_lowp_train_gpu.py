@@ -270,3 +270,54 @@ def test_options_forward_against_the_fp32_engine(opts, dtype, tol):
     print('%s %s: |dy_pred| max %.3e mean %.3e' % (opts, dtype, err, mean))
     mx_tol, mean_tol = tol[2:] if opts.get('downsampling') == 'max' else tol[:2]
     assert err <= mx_tol and mean <= mean_tol
+
+
+@pytest.mark.parametrize('dtype', ['bfloat16', 'float16'])
+def test_step_without_the_normalised_tensor_is_the_same_step(dtype, monkeypatch):
+    """at the levels the streaming kernels take (here: all of a 64^3 crop's first level), conv2's forward and weight gradient normalise
+    conv1's raw output themselves and relu(GN1(c1)) is never written (lowp_train fuse_gn1_apply): same arithmetic element for element --
+    loss, label map and EVERY gradient bit-equal to the step with the separate apply pass (BTS_LP_FUSE_GN1_APPLY=0)"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp
+    from bts_amd.data import synthetic_batch
+    from bts_amd.layers import _base
+    from bts_amd.lowp_train import LowPrecisionTrainer
+    from bts_amd.model import Model
+    from bts_amd.tape import bump_weights_epoch
+    from bts_amd.util import DiceCoefficient, ScheduledOptim
+    crop = (64, 64, 64)
+    x, y, mask, eps = synthetic_batch(1, crop, latent=KW['base_filters'] * 2 ** (KW['depth'] - 2), seed=7)
+    taken = []
+    real = lowp.conv_bwd_weight_normed_input
+
+    def spy(*a, **k):
+        taken.append(1)
+        return real(*a, **k)
+    monkeypatch.setattr(lowp, 'conv_bwd_weight_normed_input', spy)
+
+    def run(switch):
+        monkeypatch.setenv('BTS_LP_FUSE_GN1_APPLY', switch)
+        _base.set_seed(5)
+        m = Model(**KW)
+        m.build((1,) + crop + (2,))
+        g = torch.Generator().manual_seed(6)
+        for p in m.trainable_variables:
+            if p.name.endswith('gamma'):
+                p.t.copy_((1.0 + 0.3 * torch.randn(p.t.shape, generator=g)).to(p.t.device))
+        bump_weights_epoch()
+        opt = ScheduledOptim(1e-4)
+        opt(epoch=0)
+        m.encoder.set_dropout_mask(mask)
+        m.vae.set_eps(eps)
+        tr = LowPrecisionTrainer(m, dtype)
+        df = DiceCoefficient()
+        loss, _, _ = tr.step(opt, df, x, y)
+        torch.cuda.synchronize()
+        return float(loss), m.flat_grads.clone(), df.last_labels.clone()
+    l1, g1, lab1 = run('1')
+    assert len(taken) >= 3, 'the fused route was not taken by the first-level blocks'
+    n_taken = len(taken)
+    l0, g0, lab0 = run('0')
+    assert len(taken) == n_taken
+    assert l1 == l0 and torch.equal(lab1, lab0)
+    assert torch.equal(g1, g0), float((g1 - g0).abs().max())
