@@ -74,6 +74,11 @@ class _Lib:
             raise RuntimeError('%s: unsupported shape' % name)
         return r
 
+    def probe(self, name, *args):
+        """unchecked value of a query whose negative / zero answer means "this form does not take the shape" (the caller then runs the
+        general route), not an error"""
+        return getattr(self, '_' + name)(*args)
+
 
 _lib = None
 

@@ -187,7 +187,7 @@ def conv_gn_normed_input(code, tdt, x, norm_in, mean_in, rstd_in, relu_in, wp, b
     if norm._mode != ops.GN_SLAB or norm_in._mode != ops.GN_SLAB or not x.is_contiguous() or not relu_in:
         return None
     n, d, h, w, cin = x.shape
-    nb = getattr(lib(), '_bts_lp_conv3d_gnin_fwd_gn_workspace')(n, d, h, w, cin, cout, norm_in.groups, norm.groups)
+    nb = lib().probe('bts_lp_conv3d_gnin_fwd_gn_workspace', n, d, h, w, cin, cout, norm_in.groups, norm.groups)
     if nb < 0:
         return None
     y = torch.empty((n, d, h, w, cout), dtype=tdt, device=x.device)
@@ -206,7 +206,7 @@ def gnin_train_ok(x, cout, norm_in, norm):
     if norm._mode != ops.GN_SLAB or norm_in._mode != ops.GN_SLAB or not x.is_contiguous():
         return False
     n, d, h, w, cin = x.shape
-    return getattr(lib(), '_bts_lp_conv3d_gnin_train_ok')(n, d, h, w, cin, cout, norm_in.groups, norm.groups) == 1
+    return lib().probe('bts_lp_conv3d_gnin_train_ok', n, d, h, w, cin, cout, norm_in.groups, norm.groups) == 1
 
 
 def conv_bwd_weight_normed_input(code, x, norm_in, mean_in, rstd_in, dy, dw, db=None, accumulate=True):

@@ -463,7 +463,7 @@ def block_bwd_takes(res, r, groups, dout):
     """does the fused gate + GroupNorm-2 backward take this block?  (asked before the grad slots are claimed)"""
     n, f = res.shape[0], res.shape[4]
     v = res.shape[1] * res.shape[2] * res.shape[3]
-    return getattr(lib(), '_bts_block_bwd_workspace')(n, v, f, r, groups) >= 0 and ld_of(dout) % 4 == 0 and res.is_contiguous()
+    return lib().probe('bts_block_bwd_workspace', n, v, f, r, groups) >= 0 and ld_of(dout) % 4 == 0 and res.is_contiguous()
 
 
 def block_bwd(dout, res, c2, sp, gap, h, ch, w1, w2, wsp, gamma, beta, mean, rstd, groups, dw1, dw2, dwsp, dgamma, dbeta,
@@ -473,7 +473,7 @@ def block_bwd(dout, res, c2, sp, gap, h, ch, w1, w2, wsp, gamma, beta, mean, rst
     n, f = res.shape[0], res.shape[4]
     v = res.shape[1] * res.shape[2] * res.shape[3]
     r = w1.shape[1]
-    nb = getattr(lib(), '_bts_block_bwd_workspace')(n, v, f, r, groups)      # (-1: outside the fused kernels' tiling, not an error)
+    nb = lib().probe('bts_block_bwd_workspace', n, v, f, r, groups)      # (-1: outside the fused kernels' tiling, not an error)
     if nb < 0 or ld_of(dout) % 4 != 0 or not (res.is_contiguous() and c2.is_contiguous()):
         return None
     ws = workspace(nb, res.device)
