@@ -155,6 +155,20 @@ struct LpGnaFuse {
   int G, cg;
 };
 
+// the arithmetic of the GNA transforms on one 16-byte slot: o = max(fmaf(v - mu, sc, be), 0) per element, rounded to the storage type --
+// on the packed fp32 instructions (v_pk_add_f32 / v_pk_fma_f32: the same IEEE results as the scalar forms bts_lp_gn_apply uses)
+template <typename T> __device__ __forceinline__ u32x4 lp_gna_slot(u32x4 raw, float mu, const float (&sc)[8], const float (&be)[8]) {
+  const f32x2_ m2 = {mu, mu};
+  u32x4 r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f32x2_ v = {T::ld((unsigned short)(raw[k] & 0xffffu)), T::ld((unsigned short)(raw[k] >> 16))};
+    const f32x2_ t = __builtin_elementwise_fma(v - m2, f32x2_{sc[2 * k], sc[2 * k + 1]}, f32x2_{be[2 * k], be[2 * k + 1]});
+    r[k] = pack2<T>(fmaxf(t[0], 0.f), fmaxf(t[1], 0.f));
+  }
+  return r;
+}
+
 // GroupNorm-backward class sums from the epilogue of the data-gradient conv that PRODUCES the GroupNorm output's gradient (resnet.py:80-93
 // under train.py:151: conv2^T(dc2) = da, then GN1 backward needs A_j = sum da_E * xh and B_j = sum da_E per (sample, group, class
 // j = channel mod cg) before anything else -- lp_gn_bwd_reduce_kernel's pass over da and c1).  The epilogue holds da in registers; it

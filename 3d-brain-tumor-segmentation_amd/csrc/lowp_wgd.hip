@@ -185,11 +185,7 @@ __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (tid + 512 * i < 1600) {
-        float v[8], o[8];
-        unpack8<T>(raw[i], v);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = fmaxf(fmaf(v[e] - ga_mu, ga_sc[e], ga_be[e]), 0.f);
-        u32x4 r = pack8<T>(o);
+        u32x4 r = lp_gna_slot<T>(raw[i], ga_mu, ga_sc, ga_be);
         const bool ok = (ga_ok >> i) & 1u;
 #pragma unroll
         for (int k = 0; k < 4; ++k) r[k] = ok ? r[k] : 0u;
