@@ -67,3 +67,30 @@ for name, mm, nm in (('lp_wgd 64->64 @8x64^3', mm_wgd, 6), ('lp_s1d 64->64 @8x64
     tab = timed(mm, nm, hbm, 2)
     print('%s x%d alone %.2f ms | GroupNorm backward 8x128^3x32 x2 alone %.2f ms | together on two streams %.2f ms (sum %.2f, max %.2f)' %
           (name, nm, ta, tb, tab, ta + tb, max(ta, tb)))
+
+
+# other tenants: torch's own element-wise kernels (no LDS, few registers, several loads in flight per thread) on a tensor pair of the same
+# size -- is it THIS engine's pass that cannot overlap, or any HBM-bound kernel next to these matrix kernels?
+src = torch.randn((8, 128, 128, 128, 32), device=D).to(tdt)
+dst = torch.empty_like(src)
+
+
+def t_copy():
+    dst.copy_(src)
+    dst.copy_(src)
+    dst.copy_(src)
+
+
+def t_add():
+    torch.add(src, xe, out=dst)
+    torch.add(src, xe, out=dst)
+
+
+for tname, ten in (('torch copy x3 (3.2 GB r + 3.2 GB w)', t_copy), ('torch add x2 (4.3 GB r + 2.1 GB w)', t_add)):
+    for name, mm, nm in (('lp_wgd', mm_wgd, 6), ('lp_s1d', mm_conv, 4)):
+        for _ in range(2):
+            mm(); ten()
+        ta = timed(mm, nm, lambda: None, 0)
+        tb = timed(lambda: None, 0, ten, 1)
+        tab = timed(mm, nm, ten, 1)
+        print('%s x%d alone %.2f ms | %s alone %.2f ms | together %.2f ms (sum %.2f, max %.2f)' % (name, nm, ta, tname, tb, tab, ta + tb, max(ta, tb)))
