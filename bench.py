@@ -637,8 +637,9 @@ def main():
                 also['configs[2]'] = measure_train(args, world, rank, dev, overrides, dtype='bf16', batch=8, steps=10, warmup=5)
                 gc.collect()
                 torch.cuda.empty_cache()
+                # (a forward is 6.5 ms: 10 warm-up + 30 timed cost 0.3 s and take the first-launch / clock-ramp noise of 3 + 10 out of the line)
                 also['configs[4]'] = measure_infer(args, world, rank, dev, overrides, dtype='f16', shape='160,192,160', batch=1,
-                                                   steps=10, warmup=3)
+                                                   steps=30, warmup=10)
             except Exception as e:   # the headline stands on its own; a failure here is reported, not hidden
                 also['error'] = '%s: %s' % (type(e).__name__, str(e)[:300])
             out['also'] = also
