@@ -38,6 +38,7 @@ struct LpS1zParams {
   int ntx, nty, nzc, ZC, nitems, ipw, xcd_order, accum;
   double* gnp;       // fused GroupNorm partial sums (slab semantics) [N*G][gn_B][2], or NULL
   int gn_G, gn_zt;
+  int gn_run;        // 1: a wave's sums run over all planes of a (group, item) before they leave (z chunks nest with the groups); 0: one pair per plane
   long gn_B;
   LpGnbFuse gb;      // GNB kernels: GroupNorm-backward class sums of the stored output against the GroupNorm input gb.x (lowp_common.h)
   int gb_zt;         // planes per group
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
   f32x2v gs0[2], gs1[2];          // per-lane sums of the element pairs (0,1) and (2,3) (cg <= 4: elements e and e + 4 of a row share a class)
 #pragma unroll
   for (int e = 0; e < 2; ++e) gs0[e] = gs1[e] = f32x2v{0.f, 0.f};
+  double gn_ds = 0.0, gn_dq = 0.0;      // (gn_run) this lane's sums over the planes of the current group
   u32x4 cxs[2][2], dst_;
   int zst = -1;                    // plane of the row in dst_
   auto gnb_request = [&](int z) {
@@ -317,7 +319,25 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
       }
     }
     if constexpr (GNB) gnb_flush();
-    if (gn_on) {   // one fp64 (sum, sumsq) pair per (z plane, column, wave): fixed order
+    if (gn_on && p.gn_run) {
+      // the planes of a group this item covers, one after the other: per-lane fp64 running sums of the per-plane fp32 sums; ONE pair per
+      // (group, item, column, wave) leaves where the march leaves the group or the item (a pair per plane made the finalize walk 9600
+      // pairs per unit at 160 x 192 x 160: 38 us per launch on the critical path of every top-level GroupNorm)
+      gn_ds += (double)gn_s;
+      gn_dq += (double)gn_q;
+      if ((z + 1) % p.gn_zt == 0 || z == zhi - 1) {
+        const double ds = wave_sum_f64(gn_ds), dq = wave_sum_f64(gn_dq);
+        gn_ds = gn_dq = 0.0;
+        if (lane == 0) {
+          const int gg = z / p.gn_zt;
+          const int run = p.ZC < p.gn_zt ? (zlo - gg * p.gn_zt) / p.ZC : 0;
+          const long slot = ((long)run * (p.nty * p.ntx) + (cy0 / S1Z_TY) * p.ntx + cx0 / S1Z_TX) * 8 + wave;
+          double* dst = p.gnp + (((long)cn * p.gn_G + gg) * p.gn_B + slot) * 2;
+          dst[0] = ds;
+          dst[1] = dq;
+        }
+      }
+    } else if (gn_on) {   // one fp64 (sum, sumsq) pair per (z plane, column, wave): fixed order
       const double ds = wave_sum_f64((double)gn_s), dq = wave_sum_f64((double)gn_q);
       if (lane == 0) {
         const int gg = z / p.gn_zt;
@@ -506,10 +526,15 @@ static bool s1z_plan(S1zPlan& pl, int N, int D, int H, int W, int Cin, int ldx, 
   return true;
 }
 // GroupNorm-partial slots per (n, group) when the kernel takes the shape and can emit them (whole planes per group); 0 otherwise
+static bool s1z_gn_runs(const S1zPlan& pl, int zt) { return pl.ZC % zt == 0 || zt % pl.ZC == 0; }      // z chunks nest with the groups
+static long s1z_gn_B(const S1zPlan& pl, int zt) {
+  if (s1z_gn_runs(pl, zt)) return (long)(pl.ZC < zt ? zt / pl.ZC : 1) * pl.nty * pl.ntx * 8;      // a pair per (run, column, wave)
+  return (long)zt * pl.nty * pl.ntx * 8;                                                             // a pair per (plane, column, wave)
+}
 long bts_lp_s1z_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn) {
   S1zPlan pl;
   if (Gn <= 0 || D % Gn != 0 || !s1z_plan(pl, N, D, H, W, Cin, Cin, Cout, Cout)) return 0;
-  return (long)(D / Gn) * pl.nty * pl.ntx * 8;
+  return s1z_gn_B(pl, D / Gn);
 }
 // partial rows per (n, group) of the fused GroupNorm-BACKWARD class sums (LpGnbFuse) when the kernel takes the shape and can emit them:
 // whole planes per group, z chunks that nest with the groups, classes that divide a lane's 8 couts; 0 otherwise
@@ -543,7 +568,9 @@ int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bi
   p.x = (const unsigned short*)x; p.wp = (const unsigned short*)wp; p.bias = bias; p.y = (unsigned short*)y;
   p.N = N; p.D = D; p.H = H; p.W = W; p.ldx = ldx; p.ldy = ldy; p.Cout = Cout;
   p.ntx = pl.ntx; p.nty = pl.nty; p.nzc = pl.nzc; p.ZC = pl.ZC; p.nitems = pl.nitems; p.ipw = pl.ipw; p.xcd_order = pl.xcd; p.accum = accum;
-  p.gnp = gn_part; p.gn_G = gn_G; p.gn_zt = gn_G > 0 ? D / gn_G : 1; p.gn_B = gn_G > 0 ? (long)(D / gn_G) * pl.nty * pl.ntx * 8 : 0;
+  p.gnp = gn_part; p.gn_G = gn_G; p.gn_zt = gn_G > 0 ? D / gn_G : 1;
+  p.gn_run = (gn_G > 0 && s1z_gn_runs(pl, p.gn_zt)) ? 1 : 0;
+  p.gn_B = gn_G > 0 ? s1z_gn_B(pl, p.gn_zt) : 0;
   if (gb != nullptr) { p.gb = *gb; p.gb_zt = D / gb->G; } else { p.gb = LpGnbFuse{}; p.gb_zt = 1; }
   if (ga != nullptr) { p.ga = *ga; p.ga_zt = D / ga->G; } else { p.ga = LpGnaFuse{}; p.ga_zt = 1; }
   const int KS = Cin / 16;
