@@ -250,7 +250,7 @@ def oracle_agreement(first, cpu, agreement_dir):
     lab_o, yp_o = z['labels'], z['y_pred']
     lab = first['labels'].reshape(lab_o.shape)
     top2 = np.sort(yp_o, axis=-1)[..., -2:]
-    near = (np.abs(top2[..., 1] - 0.5) < 1e-5) | (np.abs(top2[..., 1] - top2[..., 0]) < 1e-5)
+    near = (np.abs(top2[..., 1] - 0.5) < 1e-4) | (np.abs(top2[..., 1] - top2[..., 0]) < 1e-4)     # (the band the y_pred tolerance implies)
     differ = lab != lab_o
     dpar = 0.0
     for name, arr in first['params'].items():
@@ -267,7 +267,7 @@ def oracle_agreement(first, cpu, agreement_dir):
                                       and int((differ & ~near).sum()) == 0),
             'what': 'first train step of this run (initial weights, seed-1234 volume, injected dropout mask / eps) vs oracle/torch_ref.py '
                     'in fp32 from the same weights and draws (the cpu_baseline child); tolerance |dDice| <= 1e-4, label map identical '
-                    'outside near-ties (|p-0.5| or top-2 gap < 1e-5)'}
+                    'outside near-ties (|p-0.5| or top-2 gap < 1e-4, the y_pred tolerance)'}
 
 
 def active_overrides():

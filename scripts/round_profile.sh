@@ -1,6 +1,6 @@
 #!/bin/bash
 # Per-round evidence for bench.py (run ON the GPU box: `gpurun -- 'bash scripts/round_profile.sh r02a'`):
-#   gpurun_out/<tag>_bench.json               the bench line (un-profiled, HIP-event hooks on)
+#   gpurun_out/<tag>_bench.json               the bench line as the driver sees it (compact, `summary` last); <tag>_bench_detail.json = the complete record
 #   gpurun_out/<tag>_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the same command
 #   gpurun_out/<tag>_pmc_traffic{,_bf16_b8,_infer_f16}.json
 #                                             FETCH_SIZE / WRITE_SIZE / fabric read-request per-launch means of every kernel of the fp32
@@ -18,6 +18,7 @@ cd /tmp && export TMPDIR=/tmp
 python3 "$R/bench.py" --steps 10 --warmup 3 > "$O/${TAG}_bench.json" 2> "$O/${TAG}_bench.err"
 test -s "$O/${TAG}_bench.json" || { echo "bench.py printed nothing"; tail -5 "$O/${TAG}_bench.err"; exit 1; }
 cut -c1-400 "$O/${TAG}_bench.json"
+cp "$O/bench_detail.json" "$O/${TAG}_bench_detail.json"     # the complete record behind the compact line (every kernel, counter read-outs)
 
 need() {  # need <dir> <file name>: the one CSV a pass must have produced, non-empty
   local f
@@ -50,7 +51,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_${TAG}_bf16" -o
 cp "$(need "$O/prof_${TAG}_bf16" bench_kernel_stats.csv)" "$O/${TAG}_train_bf16_b8_kernel_stats.csv"
 rm -rf "$O/prof_${TAG}_inf"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_${TAG}_inf" -o bench -- \
-  python3 "$R/bench.py" --infer --dtype f16 --steps 5 --warmup 2 --no-cpu-baseline --no-profile --no-also > "$O/prof_${TAG}_inf.log" 2>&1
+  python3 "$R/bench.py" --infer --dtype f16 --steps 5 --warmup 2 --no-cpu-baseline --no-profile --no-also --serial-streams > "$O/prof_${TAG}_inf.log" 2>&1
 cp "$(need "$O/prof_${TAG}_inf" bench_kernel_stats.csv)" "$O/${TAG}_infer_f16_kernel_stats.csv"
 
 # HBM-side counters, one rocprofv3 pass per counter group (the TCC block has 4 slots: FETCH_SIZE takes 3, WRITE_SIZE 2), for each of the

@@ -14,7 +14,8 @@ Synthetic batch seed 1234, injected dropout mask and eps, every gamma / beta / b
 the conv branch of every block: SURVEY F6).  The oracle evaluations are shared by the tests of this module.
 
 Tolerances (SURVEY 8c / DESIGN 4), fp32 engine: y_pred max-abs <= 1e-4; loss <= 1e-5 relative; macro / micro Dice <= 1e-4; label
-map identical outside counted near-ties (|p - 0.5| < 1e-5 or top-2 gap < 1e-5); every variable's gradient <= 1e-3 of its max-abs,
+map identical outside the margin band the y_pred tolerance implies (|p - 0.5| < 1e-4 or top-2 gap < 1e-4), differing voxels counted
+and <= 1e-3 of the volume; every variable's gradient <= 1e-3 of its max-abs,
 or 4x what torch-fp32 deviates from fp64 on that variable, or the worst such deviation over all variables, when those are larger;
 whole gradient in relative L2 <= max(1e-4, 2x torch-fp32's); parameters after Adam from the engine's own gradient in fp64.
 16-bit engines: the bounds their small-size oracle tests use (tests/test_lowp_gpu.py, tests/test_lowp_train_gpu.py), stated in
@@ -87,9 +88,11 @@ def train_case():
                 macro=float(macro), micro=float(micro), labels=labels)
 
 
-def _ambiguous(yp):
+def _ambiguous(yp, width=1e-4):
+    """voxels whose label the stated y_pred tolerance (1e-4) cannot pin: winning probability within `width` of the 0.5 threshold, or
+    the top two classes within `width` of each other (util.py:36-44: argmax, then the > 0.5 cut)"""
     top2 = yp.topk(2, dim=-1).values
-    return ((yp.max(dim=-1).values - 0.5).abs() < 1e-5) | ((top2[..., 0] - top2[..., 1]).abs() < 1e-5)
+    return ((yp.max(dim=-1).values - 0.5).abs() < width) | ((top2[..., 0] - top2[..., 1]).abs() < width)
 
 
 def _maxerr(a, b):
@@ -131,13 +134,16 @@ def test_fp32_train_step_at_128_against_the_fp64_oracle(train_case):
     assert ev <= 1e-4 * max(1.0, float(yv_r.abs().max())), 'y_vae err %.3e' % ev
     assert _maxerr(z_mean.t, zm_r) <= 1e-4 and _maxerr(z_logvar.t, zl_r) <= 1e-4
     assert abs(float(loss) - c['loss']) <= 1e-5 * max(1.0, abs(c['loss'])), (float(loss), c['loss'])
+    # label map: identical wherever the oracle's own margin exceeds the y_pred tolerance; the voxels that differ are counted (an
+    # untrained net with randomised affines puts ~4 % of this volume within 1e-4 of a decision boundary)
     amb = _ambiguous(yp_r)
-    n_amb = int(amb.sum())
     lab = dice_fn.last_labels.cpu().long()
-    n_diff = int((lab != c['labels'].long()).sum())
-    print('label map: %d of %d voxels differ from the oracle\'s; near-threshold voxels %d' % (n_diff, amb.numel(), n_amb))
-    assert n_amb <= 1e-3 * amb.numel()
+    differ = lab != c['labels'].long()
+    n_diff = int(differ.sum())
+    print('label map: %d of %d voxels differ from the oracle\'s (all inside the 1e-4 margin band: %s); voxels in the band %d, in a 1e-5 band %d'
+          % (n_diff, amb.numel(), bool((differ & ~amb).sum() == 0), int(amb.sum()), int(_ambiguous(yp_r, 1e-5).sum())))
     assert torch.equal(lab[~amb], c['labels'].long()[~amb]), 'argmax label map differs from the oracle outside near-ties'
+    assert n_diff <= 1e-3 * amb.numel()
     assert abs(float(macro) - c['macro']) <= 1e-4 and abs(float(micro) - c['micro']) <= 1e-4
     # gradients: the rule of tests/test_model_gpu.py, with the oracle's own fp32 evaluation as the yardstick
     g64, g32 = c['g64'], c['g32']
@@ -268,7 +274,7 @@ def test_fp32_full_volume_forward_against_the_fp64_oracle(infer_case):
     print('160x192x160 fp32 engine vs fp64 oracle: y_pred max |d| %.2e; argmax differs at %d voxels, threshold at %d, near-ties %d of %d' %
           (e, n_arg, n_thr, int(amb.sum()), amb.numel()))
     assert e <= 1e-4
-    assert int(amb.sum()) <= 1e-3 * amb.numel()
+    assert n_arg + n_thr <= 1e-3 * amb.numel()
     assert torch.equal(yh.argmax(-1)[~amb], yp.argmax(-1)[~amb])
     assert torch.equal((yh.max(-1).values > 0.5)[~amb], (yp.max(-1).values > 0.5)[~amb])
 
