@@ -29,3 +29,7 @@ int bts_igemm_reduce_(const float* part, const float* bias, float* y, long nvox,
 int bts_se_bwd_middle_(double* partial, double* red, double* scratch, const float* gap, const float* h, const float* ch, const float* w1,
                        const float* w2, float* dw1, float* dw2, float* dwsp, float* dgap, int N, int B, long V, int F, int R,
                        int accumulate_params, hipStream_t stream);
+
+// conv_igemm.hip: a kernel is about to read part `bit` (1 implicit-GEMM, 2 F(2x2,3x3) x direct, 4 F(2x2x2,3x3x3)) of the K3S1 weight image
+// that starts at `base`: recorded (re-packs then write the parts in use only), and packed on the spot where the last re-pack left it out
+void bts_img_note_use_(const float* base, unsigned bit, hipStream_t stream);

@@ -541,8 +541,19 @@ struct PackParams {
   long w3_item0;    // K3S1 images: first work item of the 3-D Winograd part (conv_wino3.hip); its floats start at w3_off
   long w3_off;
   long total;       // floats of the whole image
-  long items;       // work items (pack_item): implicit-GEMM floats + Winograd positions (16 floats each)
+  long items;       // work items (pack_item): implicit-GEMM floats + Winograd positions (16 floats each), of the parts in `parts` only
+  unsigned parts;   // K3S1 images: which of the three parts this pack writes (bit 0 implicit-GEMM, 1 F(2x2,3x3) x direct, 2 F(2x2x2,3x3x3)); 7 = all
 };
+// index into the items of the enabled parts -> work item of the whole image
+__device__ __forceinline__ long pack_map(const PackParams& q, long j) {
+  if (q.parts == 7u) return j;
+  const long n0 = (q.parts & 1u) ? q.wino_off : 0;
+  if (j < n0) return j;
+  j -= n0;
+  const long n1 = (q.parts & 2u) ? (q.w3_item0 - q.wino_off) : 0;
+  if (j < n1) return q.wino_off + j;
+  return q.w3_item0 + (j - n1);
+}
 
 // source value of packed position (tap t, contraction index k, column n), with the tap flip of the data-gradient role and
 // the encoder's duplicated input slice folded in
@@ -652,7 +663,7 @@ __device__ __forceinline__ void pack_item(const PackParams& q, long i) {
 __global__ void pack_kernel(const PackParams q) {
   const long total = q.items;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
-    pack_item(q, i);
+    pack_item(q, pack_map(q, i));
 }
 
 // All layers' weight images in one launch (the optimiser step invalidates every image at once; 120 separate 5 us
@@ -674,7 +685,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restr
 #pragma unroll
   for (int u = 0; u < PACK_BLOCK_ELEMS / 256; ++u) {
     const long i = i0 + threadIdx.x + u * 256;
-    if (i < d.total) pack_item(d.q, i);
+    if (i < d.total) pack_item(d.q, pack_map(d.q, i));
   }
 }
 
@@ -689,7 +700,7 @@ extern "C" long bts_conv_packed_floats(int kind, int role, int Cin, int Cout) {
 }
 
 static int pack_params(PackParams& q, int kind, int role, const float* w, float* wp, int Cin_ref, int Cout, int Cin_slab,
-                       int dup_start, int dup_shift) {
+                       int dup_start, int dup_shift, unsigned parts = 7u) {
   if (kind < 0 || kind > 3 || role < 0 || role > 1) return BTS_ERR_UNSUPPORTED;
   if (dup_shift > 0 && (kind == BTS_CONV_K3S2 || kind == BTS_CONV_K3S2T)) return BTS_ERR_UNSUPPORTED;
   if (Cin_slab + dup_shift != Cin_ref) return BTS_ERR_SHAPE;
@@ -714,10 +725,75 @@ static int pack_params(PackParams& q, int kind, int role, const float* w, float*
   q.wino_off = (kind == BTS_CONV_K3S1) ? ig : (1L << 62);
   const long pairs = (long)q.KG * 2 * q.Npad * 4;   // (contraction index, column) pairs of the padded image
   q.total = ig + ((kind == BTS_CONV_K3S1) ? (48L + 64L) * pairs : 0L);
-  q.items = ig + ((kind == BTS_CONV_K3S1) ? (3L + 1L) * pairs : 0L);
   q.w3_item0 = (kind == BTS_CONV_K3S1) ? ig + 3L * pairs : (1L << 62);
   q.w3_off = ig + 48L * pairs;
+  q.parts = 7u;
+  q.items = ig + ((kind == BTS_CONV_K3S1) ? (3L + 1L) * pairs : 0L);
+  if (kind == BTS_CONV_K3S1 && (parts & 7u) != 7u && (parts & 7u) != 0u) {
+    q.parts = parts & 7u;
+    q.items = ((q.parts & 1u) ? ig : 0L) + ((q.parts & 2u) ? 3L * pairs : 0L) + ((q.parts & 4u) ? pairs : 0L);
+  }
   return BTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Which parts of a K3S1 image are READ.  An image carries three forms of the same weights (139 floats per (cin, cout) pair: 27 + 48 +
+// 64) and a layer uses ONE of them at a given geometry -- re-packing all three after every optimiser step wrote ~1.6 GB per fp32
+// training step (pack_batch_kernel 0.67-0.77 ms, round-4 review).  The library therefore keeps, per image (keyed by its base address),
+// the parts the dispatcher has picked so far (`used`, recorded right before each launch), and descriptor tables are built for those
+// parts only (`table_mask`).  A launch that picks a part no table covers packs it on the spot, on its own stream, from the recorded
+// source (`fresh_extra` remembers that until the next batch pack, i.e. the next weight change), and bumps the generation counter so that
+// the host rebuilds its table (ops.PackTable) at the next re-pack.  bts_conv_pack (single image, all parts) is how images are born.
+// ---------------------------------------------------------------------------------------------
+#include <mutex>
+#include <unordered_map>
+struct ImgState {
+  int kind, role, Cin_ref, Cout, Cin_slab, dup_start, dup_shift;
+  const float* w;
+  unsigned used, table_mask, fresh_extra;
+};
+static std::mutex g_img_mu;
+static std::unordered_map<const void*, ImgState> g_img;
+static long g_img_gen = 0;
+static bool img_masks_enabled() {   // BTS_PACK_USED=0: every pack writes all three parts (A/B; read per call)
+  const char* e = getenv("BTS_PACK_USED");
+  return !(e && atoi(e) == 0);
+}
+// (re)register an image; returns the parts a table built now should pack
+static unsigned img_register(const float* wp, int kind, int role, const float* w, int Cin_ref, int Cout, int Cin_slab, int dup_start,
+                             int dup_shift, bool all_parts) {
+  std::lock_guard<std::mutex> lk(g_img_mu);
+  ImgState& e = g_img[wp];
+  const bool same = e.w == w && e.kind == kind && e.role == role && e.Cin_ref == Cin_ref && e.Cout == Cout && e.Cin_slab == Cin_slab &&
+                    e.dup_start == dup_start && e.dup_shift == dup_shift;
+  if (!same) { e = ImgState{kind, role, Cin_ref, Cout, Cin_slab, dup_start, dup_shift, w, 0u, 7u, 0u}; }
+  unsigned m = 7u;
+  if (!all_parts && kind == BTS_CONV_K3S1 && e.used != 0u && img_masks_enabled()) m = e.used;
+  e.table_mask = m;
+  e.fresh_extra = 0u;
+  return m;
+}
+extern "C" long bts_conv_pack_generation(void) {
+  std::lock_guard<std::mutex> lk(g_img_mu);
+  return g_img_gen;
+}
+__global__ void pack_kernel(const PackParams q);
+// called right before a kernel reads part `bit` of the K3S1 image at `base`
+void bts_img_note_use_(const float* base, unsigned bit, hipStream_t stream) {
+  PackParams q;
+  {
+    std::lock_guard<std::mutex> lk(g_img_mu);
+    auto it = g_img.find(base);
+    if (it == g_img.end() || it->second.kind != BTS_CONV_K3S1) return;      // (an image this registry never saw: packed whole by its owner)
+    ImgState& e = it->second;
+    if (!(e.used & bit)) { e.used |= bit; ++g_img_gen; }
+    if ((e.table_mask | e.fresh_extra) & bit) return;
+    e.fresh_extra |= bit;
+    if (pack_params(q, e.kind, e.role, e.w, const_cast<float*>(base), e.Cin_ref, e.Cout, e.Cin_slab, e.dup_start, e.dup_shift, bit) != BTS_OK) return;
+  }
+  long blocks = (q.items + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, q);
 }
 
 extern "C" int bts_conv_pack(int kind, int role, const float* w, float* wp, int Cin_ref, int Cout, int Cin_slab,
@@ -725,6 +801,7 @@ extern "C" int bts_conv_pack(int kind, int role, const float* w, float* wp, int 
   PackParams q;
   const int r = pack_params(q, kind, role, w, wp, Cin_ref, Cout, Cin_slab, dup_start, dup_shift);
   if (r != BTS_OK) return r;
+  if (w != nullptr && wp != nullptr) img_register(wp, kind, role, w, Cin_ref, Cout, Cin_slab, dup_start, dup_shift, true);
   const long total = q.items;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
@@ -740,7 +817,10 @@ extern "C" long bts_conv_pack_desc_bytes(void) { return (long)sizeof(PackDesc); 
 extern "C" long bts_conv_pack_desc(void* host_table, int index, long first_block, int kind, int role, const float* w, float* wp,
                                    int Cin_ref, int Cout, int Cin_slab, int dup_start, int dup_shift) {
   PackDesc d;
-  const int r = pack_params(d.q, kind, role, w, wp, Cin_ref, Cout, Cin_slab, dup_start, dup_shift);
+  int r = pack_params(d.q, kind, role, w, wp, Cin_ref, Cout, Cin_slab, dup_start, dup_shift);
+  if (r != BTS_OK) return r;
+  const unsigned parts = img_register(wp, kind, role, w, Cin_ref, Cout, Cin_slab, dup_start, dup_shift, false);   // (the parts read so far; all when none yet)
+  if (parts != 7u) r = pack_params(d.q, kind, role, w, wp, Cin_ref, Cout, Cin_slab, dup_start, dup_shift, parts);
   if (r != BTS_OK) return r;
   d.total = d.q.items;
   d.first_block = first_block;
@@ -751,6 +831,10 @@ extern "C" long bts_conv_pack_desc(void* host_table, int index, long first_block
 // table_dev: the host table copied to device memory by the caller; total_blocks = sum of all block counts
 extern "C" int bts_conv_pack_batch(const void* table_dev, int n, long total_blocks, hipStream_t stream) {
   if (n <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffL) return BTS_ERR_SHAPE;
+  {   // a batch pack follows a weight change: parts packed on demand since the last one are stale again
+    std::lock_guard<std::mutex> lk(g_img_mu);
+    for (auto& kv : g_img) kv.second.fresh_extra = 0u;
+  }
   (void)hipGetLastError(); hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream,
                      reinterpret_cast<const PackDesc*>(table_dev), n);
   BTS_LAUNCH_CHECK();
@@ -1536,10 +1620,12 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
                         const float* x2 = nullptr, int ldx2 = 0) {
   if (gn_B) *gn_B = 0;  // stays 0 unless the tiled kernel took the launch and emitted the GroupNorm partials
   if (geo == GEO_S1 && wp2 == nullptr && need_out == nullptr && Cout <= 4) {
+    bts_img_note_use_(wp, 1u, stream);
     const int r = launch_dsc(x, wp, bias, y, N, Di, Hi, Wi, Cin, ldx, Cout, ldy, flags, stream);
     if (r != 1) return r;
   }
   if (geo == GEO_S1 && need_out == nullptr && Cin == 2 && x2 == nullptr && (wp2 == nullptr) == (y2 == nullptr)) {
+    bts_img_note_use_(wp, 1u, stream);
     const int r = launch_c2(x, wp, bias, y, N, Di, Hi, Wi, Cin, ldx, Cout, ldy, flags, wp2, bias2, y2, ldy2, gnp, gnG, gn_B, stream);
     if (r != 1) return r;
   }
@@ -1581,6 +1667,7 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
       if (r != 1) return r;
     }
   }
+  if (geo == GEO_S1 && need_out == nullptr) bts_img_note_use_(wp, 1u, stream);      // the implicit-GEMM form reads the first part
   IgemmParams p;
   p.wp2 = wp2; p.bias2 = bias2; p.y2 = y2; p.ldy2 = ldy2;
   p.x2 = x2; p.ldx2 = ldx2;   // second input (x2 + wp2 without y2): see IgemmParams
@@ -1916,6 +2003,7 @@ extern "C" int bts_conv3d_fwd_gn(int kind, const float* x, const float* wp_fwd, 
                                  long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int G, float eps,
                                  float* mean, float* rstd, hipStream_t stream) {
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin) return BTS_ERR_SHAPE;
+  if (((uintptr_t)workspace) & 15) return BTS_ERR_ALIGN;     // (the GroupNorm partials in it are read as double2: refuse before y is written)
   return conv_fwd_gn_impl(kind, x, wp_fwd, bias, y, nullptr, nullptr, nullptr, 0, workspace, workspace_bytes, N, D, H, W, Cin, ldx,
                           Cout, G, eps, mean, rstd, stream);
 }
@@ -1924,6 +2012,7 @@ extern "C" int bts_conv3d_fwd_fused2_gn(const float* x, const float* wp_fwd, con
                                         int W, int Cin, int ldx, int Cout, int ldy2, int G, float eps, float* mean, float* rstd,
                                         hipStream_t stream) {
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldy2 < Cout || !wp2 || !y2) return BTS_ERR_SHAPE;
+  if (((uintptr_t)workspace) & 15) return BTS_ERR_ALIGN;
   return conv_fwd_gn_impl(BTS_CONV_K3S1, x, wp_fwd, bias, y, wp2, bias2, y2, ldy2, workspace, workspace_bytes, N, D, H, W, Cin, ldx,
                           Cout, G, eps, mean, rstd, stream);
 }

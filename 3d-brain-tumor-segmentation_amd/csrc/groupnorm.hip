@@ -305,8 +305,8 @@ __global__ __launch_bounds__(1024) void gn_stats_finalize_wide_kernel(const doub
 int bts_gn_finalize_partials_(const double* partial, float* mean, float* rstd, int NG, long B, double count, float eps,
                               hipStream_t stream) {
   if (NG <= 0 || B <= 0 || B > 0x7fffffffL) return BTS_ERR_SHAPE;
-  if (((uintptr_t)partial) & 15) return BTS_ERR_ALIGN;
   if (B >= 512) {
+    if (((uintptr_t)partial) & 15) return BTS_ERR_ALIGN;     // (only the wide kernel loads double2; the public entry points check their workspace up front)
     (void)hipGetLastError(); hipLaunchKernelGGL(gn_stats_finalize_wide_kernel, dim3(NG), dim3(1024), 0, stream, partial, mean, rstd, (int)B, count, eps);
     BTS_LAUNCH_CHECK();
     return BTS_OK;

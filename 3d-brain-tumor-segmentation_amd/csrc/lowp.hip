@@ -1427,7 +1427,7 @@ extern "C" int bts_lp_gn_stats(int dtype, const void* x, float* mean, float* rst
   if (N <= 0 || V <= 0 || C < G || C % G != 0) return BTS_ERR_SHAPE;
   const long E = V * C, L = E / G;
   if (mode == BTS_GN_SLAB && (E % G != 0 || L % 8 != 0)) return BTS_ERR_UNSUPPORTED;
-  if (((uintptr_t)x) & 15) return BTS_ERR_ALIGN;
+  if ((((uintptr_t)x) | ((uintptr_t)workspace)) & 15) return BTS_ERR_ALIGN;
   const int B = lp_gn_blocks(L);
   if (workspace_bytes < bts_lp_gn_workspace(N, V, C, G)) return BTS_ERR_WORKSPACE;
   double* partial = reinterpret_cast<double*>(workspace);

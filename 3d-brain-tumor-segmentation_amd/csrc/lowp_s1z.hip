@@ -505,7 +505,17 @@ static bool s1z_enabled() {   // BTS_LP_S1Z=0: these layers back on lowp_s1d.hip
   const char* e = getenv("BTS_LP_S1Z");
   return !(e && atoi(e) == 0);
 }
+// Cin = 64 (the decoder's top block reading [skip, up-sampled]: 64 -> 32 at 128^3, decoder.py:55-63 / resnet.py:80-87): TWO passes of the
+// 32-channel kernel over the two channel halves of the input slab, the second accumulating into the first's output.  The tiled kernel
+// (lowp_s1d.hip) it replaces there re-reads its input 2.7x (34 x 10 x 6 halo of a 32 x 8 x 4 tile, a block's footprint beyond one XCD's
+// L2) and is HBM-bound at 0.35 of the matrix peak; the two marches read the input 1.2x and pay one extra read of the 32-channel output.
+// BTS_LP_S1Z_PAIR=0: back on the tiled kernel (A/B; read per call).
+static bool s1z_pair_enabled() {
+  const char* e = getenv("BTS_LP_S1Z_PAIR");
+  return !(e && atoi(e) == 0);
+}
 static bool s1z_plan(S1zPlan& pl, int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy) {
+  if (Cin == 64 && s1z_pair_enabled()) Cin = 32;       // (the geometry of both passes: the plan does not depend on the channel half)
   if (!s1z_enabled() || (Cin != 16 && Cin != 32) || Cout > 32 || Cout % 8 != 0 || W % S1Z_TX != 0 || H % S1Z_TY != 0 || D < 8) return false;
   if (ldx % 8 != 0 || ldy % 8 != 0) return false;
   if ((long)D * H * W * (long)ldx * 2 >= 0x7fffffffL || (long)D * H * W * (long)ldy * 2 >= 0x7fffffffL) return false;
@@ -540,6 +550,7 @@ long bts_lp_s1z_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn) {
 // whole planes per group, z chunks that nest with the groups, classes that divide a lane's 8 couts; 0 otherwise
 long bts_lp_s1z_gnb_B_(int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, int Gn) {
   S1zPlan pl;
+  if (Cin == 64) return 0;      // (two-pass shape: the epilogue forms belong to single launches)
   if (Gn <= 0 || D % Gn != 0 || Cout % Gn != 0 || !s1z_plan(pl, N, D, H, W, Cin, ldx, Cout, ldy)) return 0;
   const int cg = Cout / Gn, zt = D / Gn;
   if (cg > 4 || (4 % cg) != 0 || Gn > 32 || Cout > 32) return 0;
@@ -550,6 +561,7 @@ long bts_lp_s1z_gnb_B_(int N, int D, int H, int W, int Cin, int ldx, int Cout, i
 // does the kernel take the shape with GroupNorm `in_G` applied to its input planes (LpGnaFuse)?
 bool bts_lp_s1z_gna_ok_(int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, int in_G) {
   S1zPlan pl;
+  if (Cin == 64) return false;
   if (in_G <= 0 || in_G > 32 || D % in_G != 0 || Cin % in_G != 0 || ldx != Cin || !s1z_plan(pl, N, D, H, W, Cin, ldx, Cout, ldy)) return false;
   const int cg = Cin / in_G;
   return cg <= 8 && 8 % cg == 0;
@@ -558,6 +570,14 @@ int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bi
                        int Cout, int ldy, int accum, double* gn_part, int gn_G, hipStream_t stream, const LpGnbFuse* gb, const LpGnaFuse* ga) {
   S1zPlan pl;
   if (!s1z_plan(pl, N, D, H, W, Cin, ldx, Cout, ldy)) return 1;
+  if (Cin == 64) {      // two 32-channel passes (see s1z_plan): channels [0, 32) write (or accumulate, as asked), [32, 64) accumulate and count
+    if (gb != nullptr || ga != nullptr) return 1;
+    const int r = bts_lp_s1z_launch_(dtype, x, wp, bias, y, N, D, H, W, 32, ldx, Cout, ldy, accum, nullptr, 0, stream, nullptr, nullptr);
+    if (r != BTS_OK) return r;
+    // (image: [k-step][dz][tap][k-half][32 couts][8 cin], 27 KB per k-step: the second half starts two k-steps in)
+    return bts_lp_s1z_launch_(dtype, reinterpret_cast<const unsigned short*>(x) + 32, reinterpret_cast<const char*>(wp) + 2 * 27 * 1024, nullptr, y,
+                              N, D, H, W, 32, ldx, Cout, ldy, 1, gn_part, gn_G, stream, nullptr, nullptr);
+  }
   if (ga != nullptr && (gb != nullptr || !bts_lp_s1z_gna_ok_(N, D, H, W, Cin, ldx, Cout, ldy, ga->G) || ga->cg != Cin / ga->G)) return 1;
   if ((((uintptr_t)x) & 15) || (((uintptr_t)y) & 15) || (((uintptr_t)wp) & 15)) return 1;
   if (gn_part != nullptr && (gn_G <= 0 || D % gn_G != 0)) return 1;

@@ -475,6 +475,7 @@ extern "C" int bts_se_bwd(const float* dout, const float* res, const float* sp, 
                           long V, int F, int R, int lddo, int accumulate_params, hipStream_t stream) {
   if (N <= 0 || V <= 0 || F < 4 || (F & (F - 1)) || F > 256 || lddo < F || lddo % 4) return BTS_ERR_SHAPE;
   if (workspace_bytes < bts_se_bwd_workspace(N, V, F, R)) return BTS_ERR_WORKSPACE;
+  if (((uintptr_t)workspace) & 15) return BTS_ERR_ALIGN;     // (the partial reduce reads double2)
   long vspan;
   const int B = se_bwd_blocks(V, N, F, &vspan);
   double* partial = reinterpret_cast<double*>(workspace);

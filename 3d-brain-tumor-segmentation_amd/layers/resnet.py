@@ -224,7 +224,7 @@ class ResnetBlock(Layer):
         (gw1, a1), (gw2, a2), (gws, a3) = s1, s2, s3
         if not (torch.is_tensor(dout) and dout.shape[-1] == self.filters):
             return None
-        if ops.block_bwd_takes(res, self.se_w1.t.shape[1], n2.groups, dout) is False:
+        if not ops.block_bwd_takes(res, self.se_w1.t.shape[1], n2.groups, dout, c2):
             return None
         dg, ag = n2.gamma.grad_slot()
         db, ab = n2.beta.grad_slot()
@@ -239,8 +239,11 @@ class ResnetBlock(Layer):
             if not ab:
                 ops.fill(db, 0.0)
             ag = True
-        return ops.block_bwd(dout, res, c2, sp, gap, hbuf, ch, self.se_w1.t, self.se_w2.t, self.spatial_k.t.reshape(-1), n2.gamma.t, n2.beta.t,
-                             m2, r2, n2.groups, gw1, gw2, gws.reshape(-1), dg, db, accumulate_gate_params=a1, accumulate_norm_params=ag)
+        out = ops.block_bwd(dout, res, c2, sp, gap, hbuf, ch, self.se_w1.t, self.se_w2.t, self.spatial_k.t.reshape(-1), n2.gamma.t, n2.beta.t,
+                            m2, r2, n2.groups, gw1, gw2, gws.reshape(-1), dg, db, accumulate_gate_params=a1, accumulate_norm_params=ag)
+        if out is None:     # the grad slots are claimed: a fallback would accumulate into memory nothing wrote
+            raise RuntimeError('ops.block_bwd declined a block ops.block_bwd_takes accepted')
+        return out
 
     def get_config(self):
         return self.config

@@ -61,9 +61,13 @@ class LowPrecisionTrainer(object):
     float16 stores activation GRADIENTS in a type whose normal range ends at 6e-5: the gradients of a mean-reduced loss over N x 128^3
     voxels (~1e-7) would be subnormal and lose most of their bits (tests/test_lowp_fullsize_gpu.py measured it in round 3).  The float16
     trainer therefore always runs with dynamic loss scaling: the backward is seeded with `loss_scale` (a power of two: exact) instead
-    of 1, the summed flat fp32 gradient is checked for overflow (one host read per step -- float16 is the inference type, not a
-    benchmark configuration) and un-scaled; on overflow the step is skipped and the scale halved, after `growth_interval` clean steps it
-    doubles.  bfloat16 has fp32's exponent range and runs unscaled (loss_scale = 1, no check) unless a scale is asked for."""
+    of 1 and the summed flat fp32 gradient is checked for overflow ON THE DEVICE (ops.grad_nonfinite: one read pass into a flag word);
+    Adam un-scales the gradient as it reads it and drops the whole update when the flag is set (ops.adam_tf_step(skip=flag)) -- no host
+    round trip between the gradient exchange and the optimiser on any rank.  The host reads the flag ONE STEP LATER (settle(): the copy
+    finished long before): a skipped step is then counted, the optimiser's `iterations` taken back by one and the scale halved; after
+    `growth_interval` clean steps it doubles.  So the scale of step k+1 still is step k's: an overflow costs two skipped steps, not one.
+    State readers (checkpoints, tests) call settle() first.  bfloat16 has fp32's exponent range and runs unscaled (loss_scale = 1, no
+    check) unless a scale is asked for."""
 
     def __init__(self, model, dtype='bfloat16', loss_scale=None, growth_interval=200):
         self.fwd = lowp.LowPrecisionForward(model, dtype)      # checks samplers / layout, owns the forward weight images
@@ -79,6 +83,10 @@ class LowPrecisionTrainer(object):
         self.growth_interval = int(growth_interval)
         self._clean_steps = 0
         self.skipped_steps = 0
+        self._consecutive_skips = 0
+        self.last_grad_scale = 1.0  # what model.flat_grads still carries after step(): the loss scale (Adam un-scales as it reads)
+        self._pending = None        # (event, pinned host flag, optimiser, scale of that step): the overflow decision not yet read
+        self._flags = None          # two device flag words + pinned host mirrors, used alternately
         self._packs = {}
         self._pads = {}
         self._pack_table = lowp.PackTable()
@@ -92,6 +100,9 @@ class LowPrecisionTrainer(object):
         # GroupNorm-1 + ReLU applied inside conv2's forward and weight-gradient kernels where both can (the normalised tensor is never
         # written); BTS_LP_FUSE_GN1_APPLY=0: the separate apply pass everywhere (A/B)
         self.fuse_gn1_apply = os.environ.get('BTS_LP_FUSE_GN1_APPLY', '1') != '0'
+        # a block that is the first writer of its input gradient: shortcut gradient first (plain write), conv1's data gradient accumulates;
+        # BTS_LP_K1_FIRST=0: the other order (A/B)
+        self.k1_first = os.environ.get('BTS_LP_K1_FIRST', '1') != '0'
         self.last_labels = None
         self._clock = None
 
@@ -350,8 +361,14 @@ class LowPrecisionTrainer(object):
             cin = x.shape[-1]
             wpb1 = self._pk((key, 'c1b'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin, dup_start, dup_shift, role=ops.ROLE_BWD)
             wpbp = self._pk((key, 'ptb'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin, dup_start, dup_shift, role=ops.ROLE_BWD)
-            conv_bwd_data(ops.K3S1, code, dc1_16, wpb1, dx, not first)
-            conv_bwd_data(ops.K1, code, dres_16, wpbp, dx, True)
+            if first and self.k1_first:
+                # first writer of dx: the HBM-bound 1x1x1 gradient WRITES (no read of the old values), the matrix-bound 3x3x3 gradient
+                # accumulates -- the read-modify-write traffic moves under the kernel that has HBM time to spare
+                conv_bwd_data(ops.K1, code, dres_16, wpbp, dx, False)
+                conv_bwd_data(ops.K3S1, code, dc1_16, wpb1, dx, True)
+            else:
+                conv_bwd_data(ops.K3S1, code, dc1_16, wpb1, dx, not first)
+                conv_bwd_data(ops.K1, code, dres_16, wpbp, dx, True)
         self._written(blk.trainable_variables)
 
     def _sampler_fwd(self, lay, kind, x, out=None):
@@ -674,21 +691,51 @@ class LowPrecisionTrainer(object):
             scale = parallel.all_reduce_gradients(m)
         grads = [p._gview for p in m.trainable_variables]
         if self.dynamic_scale:
-            # after the exchange every rank holds the same summed gradient, so every rank takes the same decision
-            finite = bool(torch.isfinite(m.flat_grads).all())
-            if finite:
-                if self.loss_scale != 1.0:
-                    m.flat_grads.mul_(1.0 / self.loss_scale)        # (a power of two: exact)
-                self._clean_steps += 1
-                if self._clean_steps >= self.growth_interval and self.loss_scale < 2.0 ** 24:
-                    self.loss_scale *= 2.0
-                    self._clean_steps = 0
-            else:
-                self.skipped_steps += 1
-                self._clean_steps = 0
-                self.loss_scale = max(1.0, self.loss_scale * 0.5)
-                ops.step_fence_done(fence)
-                return Tensor(loss_t, requires_grad=False), macro, micro      # no optimiser step on an overflowed gradient
+            # after the exchange every rank holds the same summed gradient, so every rank's flag -- and later decision -- is the same
+            if self._flags is None:
+                self._flags = [(torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32).pin_memory()) for _ in range(2)]
+                self._flag_turn = 0
+            flag, mirror = self._flags[self._flag_turn]
+            self._flag_turn ^= 1
+            used = self.last_grad_scale = self.loss_scale          # the scale this step's backward was seeded with
+            ops.grad_nonfinite(m.flat_grads, flag)
+            self.settle()                               # the PREVIOUS step's decision (its copy is long done): may change loss_scale / iterations
+            mirror.copy_(flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending = (ev, mirror, optimizer, used)
+            # un-scaling rides on Adam's gradient read (1 / scale: a power of two, exact); the update is dropped on the device on overflow
+            optimizer.apply_gradients(zip(grads, m.trainable_variables), model=m, grad_scale=scale / used, skip_flag=flag)
+            ops.step_fence_done(fence)
+            return Tensor(loss_t, requires_grad=False), macro, micro
         optimizer.apply_gradients(zip(grads, m.trainable_variables), model=m, grad_scale=scale)
         ops.step_fence_done(fence)
         return Tensor(loss_t, requires_grad=False), macro, micro
+
+    def settle(self):
+        """read the overflow flag of the last dynamic-scale step (if it has not been read yet) and apply its consequences: skipped
+        steps are counted, the optimiser's step counter taken back, the loss scale halved / doubled.  Called by step() for the step
+        before, and by whoever reads loss_scale / skipped_steps / the optimiser state (checkpoints, tests)."""
+        if self._pending is None:
+            return
+        ev, mirror, optimizer, used = self._pending
+        self._pending = None
+        ev.synchronize()
+        if int(mirror[0]) == 0:
+            self._consecutive_skips = 0
+            self._clean_steps += 1
+            if self._clean_steps >= self.growth_interval and self.loss_scale < 2.0 ** 24:
+                self.loss_scale *= 2.0
+                self._clean_steps = 0
+            return
+        self.skipped_steps += 1
+        self._consecutive_skips += 1
+        self._clean_steps = 0
+        optimizer.iterations -= 1                       # the device dropped that update: Adam's bias correction must not count it
+        if used <= 1.0 or self._consecutive_skips >= 8:
+            # nothing left to halve (or halving does not help): the gradient itself is not finite -- a NaN in the data or the weights.
+            # Training would otherwise stall silently, every later step skipped.
+            import warnings
+            warnings.warn('LowPrecisionTrainer: step skipped on a non-finite gradient with loss_scale %g (%d in a row, %d in total); '
+                          'the weights or the data hold Inf / NaN' % (used, self._consecutive_skips, self.skipped_steps), RuntimeWarning)
+        self.loss_scale = max(1.0, min(self.loss_scale, used * 0.5))

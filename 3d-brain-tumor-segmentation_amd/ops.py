@@ -265,7 +265,9 @@ class PackTable(object):
     def run(self, entries):
         if not entries:
             return
-        key = tuple((e[0], e[1], e[2].data_ptr(), e[3].data_ptr()) + tuple(e[4:]) for e in entries)
+        # (+ the library's form-usage generation: images are re-packed in the forms their layers read; a table built before a new form
+        # was first read is rebuilt here, once)
+        key = (lib().query('bts_conv_pack_generation'),) + tuple((e[0], e[1], e[2].data_ptr(), e[3].data_ptr()) + tuple(e[4:]) for e in entries)
         if key != self.key:
             L = lib()
             nb = L._bts_conv_pack_desc_bytes()
@@ -459,11 +461,14 @@ def se_bwd(dout, res, sp, gap, h, ch, w1, w2, wsp, dw1, dw2, dwsp, accumulate_pa
     return dres
 
 
-def block_bwd_takes(res, r, groups, dout):
-    """does the fused gate + GroupNorm-2 backward take this block?  (asked before the grad slots are claimed)"""
+def block_bwd_takes(res, r, groups, dout, c2):
+    """does the fused gate + GroupNorm-2 backward take this block?  Asked BEFORE the grad slots are claimed, so it checks everything
+    block_bwd and bts_block_bwd check (tiling, row stride, contiguity, 16-byte alignment of the three streamed tensors): once this
+    says yes, block_bwd does not decline."""
     n, f = res.shape[0], res.shape[4]
     v = res.shape[1] * res.shape[2] * res.shape[3]
-    return lib().probe('bts_block_bwd_workspace', n, v, f, r, groups) >= 0 and ld_of(dout) % 4 == 0 and res.is_contiguous()
+    return (lib().probe('bts_block_bwd_workspace', n, v, f, r, groups) >= 0 and ld_of(dout) % 4 == 0 and res.is_contiguous()
+            and c2.is_contiguous() and all(t.data_ptr() % 16 == 0 for t in (dout, res, c2)))
 
 
 def block_bwd(dout, res, c2, sp, gap, h, ch, w1, w2, wsp, gamma, beta, mean, rstd, groups, dw1, dw2, dwsp, dgamma, dbeta,
@@ -474,7 +479,7 @@ def block_bwd(dout, res, c2, sp, gap, h, ch, w1, w2, wsp, gamma, beta, mean, rst
     v = res.shape[1] * res.shape[2] * res.shape[3]
     r = w1.shape[1]
     nb = lib().probe('bts_block_bwd_workspace', n, v, f, r, groups)      # (-1: outside the fused kernels' tiling, not an error)
-    if nb < 0 or ld_of(dout) % 4 != 0 or not (res.is_contiguous() and c2.is_contiguous()):
+    if not block_bwd_takes(res, r, groups, dout, c2):
         return None
     ws = workspace(nb, res.device)
     dres = torch.empty_like(res)
@@ -646,9 +651,19 @@ def l2_reg_bwd(params_flat, grads_flat, ranges, gscale=None):
                ctypes.cast(ln, ctypes.c_void_p), ctypes.cast(cf, ctypes.c_void_p), nr, _p(gscale), _stream())
 
 
-def adam_tf_step(p, g, m, v, lr_t, beta1, beta2, eps, gmul=1.0):
+def adam_tf_step(p, g, m, v, lr_t, beta1, beta2, eps, gmul=1.0, skip=None):
+    """skip: device int32[1]; the whole update is dropped on the device when it is non-zero (grad_nonfinite below)"""
+    if skip is not None:
+        lib().call('bts_adam_tf_step_guarded', _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr_t), float(beta1), float(beta2),
+                   float(eps), float(gmul), _p(skip), _stream())
+        return
     lib().call('bts_adam_tf_step', _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr_t), float(beta1), float(beta2),
                float(eps), float(gmul), _stream())
+
+
+def grad_nonfinite(g, flag):
+    """flag[0] (device int32) = 1 iff any element of the flat fp32 gradient is Inf / NaN"""
+    lib().call('bts_grad_nonfinite', _p(g), g.numel(), _p(flag), _stream())
 
 
 # ---- full-volume inference helpers (SURVEY 8 f-2) ----

@@ -146,6 +146,7 @@ def save_checkpoint(folder, model, optimizer=None, completed=False, tracker=None
         meta['tracker'] = {'best': float(tracker.best), 'patience': int(tracker.patience)}
     tr16 = getattr(model, '_trainer16', None)          # fit(compute_dtype=...): the dynamic loss scale is training state too
     if tr16 is not None:
+        tr16.settle()           # the last step's overflow decision belongs to the state that is saved
         meta['loss_scale'] = {'dtype': tr16.dtype_name, 'scale': float(tr16.loss_scale), 'clean_steps': int(tr16._clean_steps),
                               'skipped_steps': int(tr16.skipped_steps)}
     local = {}

@@ -100,7 +100,9 @@ class ScheduledOptim(object):
         t = self.iterations
         return self.learning_rate * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
 
-    def apply_gradients(self, grads_and_vars, model=None, grad_scale=1.0):
+    def apply_gradients(self, grads_and_vars, model=None, grad_scale=1.0, skip_flag=None):
+        """skip_flag (device int32[1], fused path only): the update is dropped on the device when it is non-zero; the caller
+        takes `iterations` back by one when it learns of the skip (lowp_train.LowPrecisionTrainer.settle)"""
         gv = list(grads_and_vars)
         self.iterations += 1
         lr_t = self._lr_t()
@@ -111,8 +113,10 @@ class ScheduledOptim(object):
                 st = (torch.zeros_like(model.flat_params), torch.zeros_like(model.flat_params))
                 self._state[key] = st
             ops.adam_tf_step(model.flat_params, model.flat_grads, st[0], st[1], lr_t, self.beta_1, self.beta_2,
-                             self.epsilon, grad_scale)
+                             self.epsilon, grad_scale, skip=skip_flag)
         else:
+            if skip_flag is not None:
+                raise ValueError('skip_flag needs the fused update over a Model\'s flat buffers')
             for g, p in gv:
                 if g is None:
                     continue

@@ -57,6 +57,12 @@ long bts_conv_pack_desc_bytes(void);
 long bts_conv_pack_desc(void* host_table, int index, long first_block, int kind, int role, const float* w, float* wp,
                         int Cin_ref, int Cout, int Cin_slab, int dup_start, int dup_shift);
 int bts_conv_pack_batch(const void* table_dev, int n, long total_blocks, bts_stream_t stream);
+/* A BTS_CONV_K3S1 image holds three forms of the same weights (implicit GEMM, F(2x2,3x3) x direct, F(2x2x2,3x3x3)); a layer reads the one
+ * its geometry selects.  The library records which forms each image has been read in and bts_conv_pack_desc describes those only (all
+ * three for an image never read); a form a launch selects although the last re-pack left it out is packed on the spot on the launch's
+ * stream.  The counter below grows whenever an image is read in a form it had not been read in before: a host table built at an older
+ * value should be rebuilt at the next re-pack (it stays CORRECT either way). */
+long bts_conv_pack_generation(void);
 /* y = act(conv(x) + bias). x (N,D,H,W,Cin) stride ldx; y (N,D',H',W',Cout) stride ldy; D' = D | D/2 | 2D. */
 /* workspace (may be NULL / 0) lets grids too small to fill the chip split the contraction over workgroups (deterministic
  * two-stage reduction); size from bts_conv3d_fwd_workspace (0 when the shape does not need it). */
@@ -168,6 +174,12 @@ int bts_l2_reg_bwd(const float* params, float* grads, const long* off, const lon
 /* ===== optimiser (util.py:60-84; Keras Adam, epsilon un-corrected) ===== */
 int bts_adam_tf_step(float* p, const float* g, float* m, float* v, long n, float lr_t, float beta1, float beta2, float eps,
                      float gmul, bts_stream_t stream);
+/* Dynamic loss scaling of the fp16-storage trainer without a host round trip (no reference counterpart: the reference trains in
+ * fp32, train.py:140-152): flag[0] = 1 iff any gradient element is Inf / NaN; the guarded step is bts_adam_tf_step unless *skip != 0,
+ * in which case nothing is written (the step is skipped on the device; the host learns of it one step later). */
+int bts_grad_nonfinite(const float* g, long n, int* flag, bts_stream_t stream);
+int bts_adam_tf_step_guarded(float* p, const float* g, float* m, float* v, long n, float lr_t, float beta1, float beta2, float eps,
+                             float gmul, const int* skip, bts_stream_t stream);
 
 /* ===== the two data-gradient paths into a ResNet block's input in one pass (resnet.py:118,134: x feeds conv1 and the
  * 1x1x1 shortcut) ===== */

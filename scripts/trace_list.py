@@ -5,12 +5,16 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
 n = len(names)
 period = None
-for p in range(8, n // 2):
-    if names[n - p:] == names[n - 2 * p:n - p]:
-        period = p
+for tail in range(0, 65):           # launches after the last step (result read-outs) do not belong to it
+    m = n - tail
+    for p in range(8, m // 2):
+        if names[m - p:m] == names[m - 2 * p:m - p]:
+            period = p
+            break
+    if period:
         break
 assert period, 'no repeating step found in %d dispatches' % n
-last = rows[n - period:]
+last = rows[m - period:m]
 short = lambda s: re.sub(r'\(.*', '', s.replace('void ', '')).replace('(anonymous namespace)::', '')[:70]
 t0 = int(last[0]['Start_Timestamp'])
 tot = 0.0

@@ -450,7 +450,7 @@ def test_fused_gate_and_groupnorm2_backward(shape, accumulate):
     dres_r = ops.se_bwd(dout, res, sp, gap, hbuf, ch, w1, w2, wsp, ref[0], ref[1], ref[2], accumulate_params=accumulate)
     dc2_r = ops.gn_bwd(c2, dout, gamma, beta, mean, rstd, ref[3], ref[4], groups, ops.GN_SLAB, True, accumulate_params=accumulate)
     got = [t.clone() for t in init]
-    assert ops.block_bwd_takes(res, r, groups, dout)
+    assert ops.block_bwd_takes(res, r, groups, dout, c2)
     dres, dc2 = ops.block_bwd(dout, res, c2, sp, gap, hbuf, ch, w1, w2, wsp, gamma, beta, mean, rstd, groups, got[0], got[1], got[2], got[3], got[4],
                               accumulate_gate_params=accumulate, accumulate_norm_params=accumulate)
     torch.cuda.synchronize()
@@ -467,7 +467,7 @@ def test_fused_block_backward_declines_what_it_cannot_tile():
     D = dev()
     for shape, groups in (((1, 4, 4, 4, 8), 4), ((1, 6, 10, 10, 16), 8), ((1, 8, 8, 8, 24), 8)):
         res = torch.zeros(shape, device=D)
-        assert not ops.block_bwd_takes(res, 2, groups, res), shape
+        assert not ops.block_bwd_takes(res, 2, groups, res, res), shape
 
 
 def test_dropout_sample_dense():

@@ -88,7 +88,7 @@ def test_16bit_step_at_128_cubed_against_the_fp32_engine(dtype, N, lim):
         if record:
             ops.profile_enable(False)
             syms = [s for s, _, _ in ops.profile_records()]
-        return float(loss), float(macro), m.flat_grads.clone(), m.flat_params.clone(), df.last_labels.clone(), syms
+        return float(loss), float(macro), m.flat_grads.clone() / tr.last_grad_scale, m.flat_params.clone(), df.last_labels.clone(), syms
 
     l16, d16, g16, p16, lab16, syms = lowp_step(True)
     # the 128^3 kernels ran: the LDS-DMA conv carries the stride-1 convolutions and their data gradients of the levels above its

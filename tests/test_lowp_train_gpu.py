@@ -60,7 +60,7 @@ def test_step_against_the_fp32_engine(dtype, lim):
     df16 = DiceCoefficient()
     loss16, macro16, _ = tr.step(opt2, df16, x, y)
     torch.cuda.synchronize()
-    g16, p16 = m.flat_grads.clone(), m.flat_params.clone()
+    g16, p16 = m.flat_grads.clone() / tr.last_grad_scale, m.flat_params.clone()      # (fp16: the buffer keeps the loss scale, Adam un-scales)
     dl = abs(float(loss16) - float(loss32)) / abs(float(loss32))
     rel = float((g16 - g32).norm() / g32.norm())
     cos = float(torch.dot(g16, g32) / (g16.norm() * g32.norm()))
@@ -178,7 +178,7 @@ def test_options_step_against_the_fp32_engine(opts, dtype):
     d16 = DiceCoefficient(data_format=df)
     loss16, macro16, micro16 = tr.step(opt2, d16, x, y)
     torch.cuda.synchronize()
-    g16, p16 = m.flat_grads.clone(), m.flat_params.clone()
+    g16, p16 = m.flat_grads.clone() / tr.last_grad_scale, m.flat_params.clone()      # (fp16: the buffer keeps the loss scale, Adam un-scales)
     dl = abs(float(loss16) - float(loss32)) / abs(float(loss32))
     rel = float((g16 - g32).norm() / g32.norm())
     cos = float(torch.dot(g16, g32) / (g16.norm() * g32.norm()))
@@ -235,10 +235,12 @@ def test_bf16_channels_first_max_pooling_gradient_on_a_conditioned_net():
         d = DiceCoefficient(data_format='channels_first')
         if dtype is None:
             train_step(m, opt, DiceVAELoss(data_format='channels_first'), d, x, y)
+            grads.append(m.flat_grads.clone())
         else:
-            LowPrecisionTrainer(m, dtype).step(opt, d, x, y)
+            tr = LowPrecisionTrainer(m, dtype)
+            tr.step(opt, d, x, y)
+            grads.append(m.flat_grads.clone() / tr.last_grad_scale)
         torch.cuda.synchronize()
-        grads.append(m.flat_grads.clone())
     g32, g16 = grads
     rel = float((g16 - g32).norm() / g32.norm())
     cos = float(torch.dot(g16, g32) / (g16.norm() * g32.norm()))
@@ -313,7 +315,7 @@ def test_step_without_the_normalised_tensor_is_the_same_step(dtype, monkeypatch)
         df = DiceCoefficient()
         loss, _, _ = tr.step(opt, df, x, y)
         torch.cuda.synchronize()
-        return float(loss), m.flat_grads.clone(), df.last_labels.clone()
+        return float(loss), m.flat_grads.clone() / tr.last_grad_scale, df.last_labels.clone()
     l1, g1, lab1 = run('1')
     assert len(taken) >= 3, 'the fused route was not taken by the first-level blocks'
     n_taken = len(taken)
