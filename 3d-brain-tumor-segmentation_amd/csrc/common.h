@@ -30,10 +30,29 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int bts_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Sum over the 64 lanes of a wave, fixed order, the total returned in EVERY lane.  Cross-lane moves by DPP (quad permutes, row rotates,
+// row_bcast15 / row_bcast31: register-to-register, a few cycles each) instead of __shfl_down's ds_bpermute round trips through the LDS
+// crossbar (two per step for a double, ~100 cycles each, and the conv kernels' epilogues take four of these sums per item with the
+// matrix pipe idle).
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_move_f64(double x) {      // lanes the control leaves out (masked rows) receive 0
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROWS, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROWS, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum_f64(double v) {
+#ifdef BTS_WAVE_SUM_SHFL      // A/B builds only (make alt NAME=shfl EXTRA=-DBTS_WAVE_SUM_SHFL): the ds_bpermute form
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
+  return __shfl(v, 0, 64);
+#endif
+  v += dpp_move_f64<0xB1, 0xf>(v);       // quad_perm [1,0,3,2]
+  v += dpp_move_f64<0x4E, 0xf>(v);       // quad_perm [2,3,0,1]: every lane holds its quad's sum
+  v += dpp_move_f64<0x124, 0xf>(v);      // row_ror:4
+  v += dpp_move_f64<0x128, 0xf>(v);      // row_ror:8: every lane holds its row's (16 lanes) sum
+  v += dpp_move_f64<0x142, 0xa>(v);      // row_bcast15 into rows 1 and 3
+  v += dpp_move_f64<0x143, 0xc>(v);      // row_bcast31 into rows 2 and 3: lane 63 holds the total
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 __device__ __forceinline__ float wave_sum_f32(float v) {
 #pragma unroll

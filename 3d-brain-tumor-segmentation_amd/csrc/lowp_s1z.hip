@@ -509,13 +509,16 @@ static bool s1z_enabled() {   // BTS_LP_S1Z=0: these layers back on lowp_s1d.hip
 // 32-channel kernel over the two channel halves of the input slab, the second accumulating into the first's output.  The tiled kernel
 // (lowp_s1d.hip) it replaces there re-reads its input 2.7x (34 x 10 x 6 halo of a 32 x 8 x 4 tile, a block's footprint beyond one XCD's
 // L2) and is HBM-bound at 0.35 of the matrix peak; the two marches read the input 1.2x and pay one extra read of the 32-channel output.
-// BTS_LP_S1Z_PAIR=0: back on the tiled kernel (A/B; read per call).
-static bool s1z_pair_enabled() {
+// Measured (round 5, profiles/r05_ab_e1.txt): the batch-8 training step gains 0.3 ms (8 x 128^3 voxels: 2 x ~0.72 ms against 2.09 ms), the
+// single 160 x 192 x 160 inference volume LOSES 0.07 ms (2 x 285 us against 506 us: the tiled kernel's re-reads still fit that grid's
+// caches) -- so the pair takes launches of at least 8 M voxels only.  BTS_LP_S1Z_PAIR=0: never, =1: always (A/B; read per call).
+static bool s1z_pair_takes(long voxels) {
   const char* e = getenv("BTS_LP_S1Z_PAIR");
-  return !(e && atoi(e) == 0);
+  if (e) return atoi(e) != 0;
+  return voxels >= (8L << 20);
 }
 static bool s1z_plan(S1zPlan& pl, int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy) {
-  if (Cin == 64 && s1z_pair_enabled()) Cin = 32;       // (the geometry of both passes: the plan does not depend on the channel half)
+  if (Cin == 64 && s1z_pair_takes((long)N * D * H * W)) Cin = 32;       // (the geometry of both passes: the plan does not depend on the channel half)
   if (!s1z_enabled() || (Cin != 16 && Cin != 32) || Cout > 32 || Cout % 8 != 0 || W % S1Z_TX != 0 || H % S1Z_TY != 0 || D < 8) return false;
   if (ldx % 8 != 0 || ldy % 8 != 0) return false;
   if ((long)D * H * W * (long)ldx * 2 >= 0x7fffffffL || (long)D * H * W * (long)ldy * 2 >= 0x7fffffffL) return false;

@@ -100,9 +100,6 @@ class LowPrecisionTrainer(object):
         # GroupNorm-1 + ReLU applied inside conv2's forward and weight-gradient kernels where both can (the normalised tensor is never
         # written); BTS_LP_FUSE_GN1_APPLY=0: the separate apply pass everywhere (A/B)
         self.fuse_gn1_apply = os.environ.get('BTS_LP_FUSE_GN1_APPLY', '1') != '0'
-        # a block that is the first writer of its input gradient: shortcut gradient first (plain write), conv1's data gradient accumulates;
-        # BTS_LP_K1_FIRST=0: the other order (A/B)
-        self.k1_first = os.environ.get('BTS_LP_K1_FIRST', '1') != '0'
         self.last_labels = None
         self._clock = None
 
@@ -342,8 +339,9 @@ class LowPrecisionTrainer(object):
                 tp = torch.empty((1, 1, 1, x.shape[-1], f), dtype=torch.float32, device=x.device)
                 _wgrad16(ops.K3S1, code, x, dc1_16, tk, db1, 0, 0, False)
                 _wgrad16(ops.K1, code, x, dres_16, tp, None, 0, 0, False)
-                self._gslot(blk.conv1_k).add_(tk[:, :, :, :cin_slab, :])
-                self._gslot(blk.ptwise_k).add_(tp[:, :, :, :cin_slab, :])
+                # live rows of the padded gradients into the real slots (library kernel: rows = taps, columns = the cin_slab x f prefix)
+                ops.add_strided(self._gslot(blk.conv1_k).view(27, cin_slab * f), tk.view(27, -1)[:, :cin_slab * f], True)
+                ops.add_strided(self._gslot(blk.ptwise_k).view(1, cin_slab * f), tp.view(1, -1)[:, :cin_slab * f], True)
             self._wg((x, dc1_16, dres_16), wgrads)
         elif lp1:
             def wgrads():
@@ -361,14 +359,10 @@ class LowPrecisionTrainer(object):
             cin = x.shape[-1]
             wpb1 = self._pk((key, 'c1b'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin, dup_start, dup_shift, role=ops.ROLE_BWD)
             wpbp = self._pk((key, 'ptb'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin, dup_start, dup_shift, role=ops.ROLE_BWD)
-            if first and self.k1_first:
-                # first writer of dx: the HBM-bound 1x1x1 gradient WRITES (no read of the old values), the matrix-bound 3x3x3 gradient
-                # accumulates -- the read-modify-write traffic moves under the kernel that has HBM time to spare
-                conv_bwd_data(ops.K1, code, dres_16, wpbp, dx, False)
-                conv_bwd_data(ops.K3S1, code, dc1_16, wpb1, dx, True)
-            else:
-                conv_bwd_data(ops.K3S1, code, dc1_16, wpb1, dx, not first)
-                conv_bwd_data(ops.K1, code, dres_16, wpbp, dx, True)
+            # (the other order where this block is the first writer -- shortcut gradient as a plain write, the matrix-bound 3x3x3 gradient
+            # accumulating -- was measured in round 5: 74.69-74.90 against 74.84-74.97 ms per batch-8 step, inside the noise; not kept)
+            conv_bwd_data(ops.K3S1, code, dc1_16, wpb1, dx, not first)
+            conv_bwd_data(ops.K1, code, dres_16, wpbp, dx, True)
         self._written(blk.trainable_variables)
 
     def _sampler_fwd(self, lay, kind, x, out=None):
@@ -601,8 +595,8 @@ class LowPrecisionTrainer(object):
             def wg_out():
                 tk = torch.empty((3, 3, 3, cv, 16), dtype=torch.float32, device=dev)
                 _wgrad16(ops.K3S1, code, yv_last, dyv16, tk, None, 0, 0, False)
-                self._gslot(vae.out_k).add_(tk[..., :co])
-                self._gslot(vae.out_b).add_(dyv.sum(dim=(0, 1, 2, 3)))
+                ops.add_strided(self._gslot(vae.out_k).view(-1, co), tk.view(-1, 16)[:, :co], True)      # the co live columns of the padded gradient
+                ops.colsum(dyv, sum_over_n=True, out=self._gslot(vae.out_b), accumulate=True)
             self._wg((yv_last, dyv16, dyv), wg_out)
             wpb = self._pk((id(vae), 'out16b'), ops.K3S1, self._padded((id(vae), 'out_k16'), vae.out_k, 16), cv, 16, role=ops.ROLE_BWD)
             dv = torch.empty(yv_last.shape, dtype=tdt, device=dev)

@@ -14,7 +14,19 @@ import os
 
 import torch
 
-BUCKET_BYTES = 64 << 20
+# C1 bucket size.  64 MB: three buckets for the 168.7 MB fp32 gradient of the CLI model.  What to expect on a full-mesh xGMI node
+# (7 links x ~153 GB/s per GPU, point to point): a RING all-reduce moves 2 (N-1)/N x bytes over ONE link pair per hop -- 168.7 MB on 8
+# GPUs = 295 MB per link at <= 153 GB/s = 1.9 ms; a direct / mesh (one-shot reduce-scatter + all-gather over all 7 links) needs the same
+# bytes over 7 links = 0.3 ms.  RCCL picks by message size and topology; NCCL_ALGO / RCCL's channel count are the
+# knobs to A/B on the first 8-GPU run (bench.py prints per-bucket times and the exposed wait for that), the bucket size is this one:
+# `bench.py --bucket-mb`, BTS_DP_BUCKET_MB, or set_bucket_bytes().
+BUCKET_BYTES = int(float(os.environ.get('BTS_DP_BUCKET_MB', '64')) * (1 << 20))
+
+
+def set_bucket_bytes(n):
+    """C1 bucket size for GradSync objects built from now on (and for all_reduce_flat's default)"""
+    global BUCKET_BYTES
+    BUCKET_BYTES = int(n)
 
 
 def world():
@@ -92,12 +104,13 @@ def gather_objects(obj):
     return out
 
 
-def bucket_ranges(n, elem_bytes=4, bucket_bytes=BUCKET_BYTES):
+def bucket_ranges(n, elem_bytes=4, bucket_bytes=None):
+    bucket_bytes = BUCKET_BYTES if bucket_bytes is None else bucket_bytes
     per = max(1, bucket_bytes // elem_bytes)
     return [(o, min(per, n - o)) for o in range(0, n, per)]
 
 
-def all_reduce_flat(flat, bucket_bytes=BUCKET_BYTES):
+def all_reduce_flat(flat, bucket_bytes=None):
     """bucketed in-place sum of a flat buffer (C1)"""
     if not active():
         return flat
@@ -156,7 +169,12 @@ class GradSync(object):
     this step) are zero-filled at the end, exactly like the non-overlapped path.  Results are bit-identical to
     all_reduce_gradients() after a plain backward (same kernels on the same values, only earlier)."""
 
-    def __init__(self, model, bucket_bytes=BUCKET_BYTES):
+    def __init__(self, model, bucket_bytes=None):
+        self.default_sized = bucket_bytes is None      # (grad_sync() rebuilds those when the default changes; explicit sizes are kept)
+        bucket_bytes = BUCKET_BYTES if bucket_bytes is None else bucket_bytes
+        self.bucket_bytes = bucket_bytes
+        self.timing = False          # bench.py: events around finish()'s waits -> how long the compute stream stood still for the exchange
+        self.exposed_ms = []
         self.model = model
         ps = model.trainable_variables
         base = model.flat_grads.data_ptr()
@@ -276,9 +294,24 @@ class GradSync(object):
         for bi in range(len(self.buckets)):    # (pad-only tail buckets have no members)
             if not self.launched[bi]:
                 self._launch(bi)
-        for h in self.handles:
-            h.wait()
+        if self.timing and active() and self.model.flat_grads.is_cuda:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for h in self.handles:
+                h.wait()
+            b.record()
+            self._timing_events = getattr(self, '_timing_events', []) + [(a, b)]
+        else:
+            for h in self.handles:
+                h.wait()
         self.handles = []
+
+    def exposed_wait_ms(self):
+        """per step since timing was switched on: milliseconds the compute stream waited in finish() for buckets still in flight
+        (call after a device synchronize)"""
+        ev = getattr(self, '_timing_events', [])
+        self._timing_events = []
+        return [a.elapsed_time(b) for a, b in ev]
 
 
 def grad_sync(model):
@@ -286,7 +319,7 @@ def grad_sync(model):
     if not active() or os.environ.get('BTS_DP_NO_OVERLAP') or model.flat_grads is None:
         return None
     gs = getattr(model, '_grad_sync', None)
-    if gs is None or gs.model.flat_grads.data_ptr() != model.flat_grads.data_ptr():
+    if gs is None or gs.model.flat_grads.data_ptr() != model.flat_grads.data_ptr() or (gs.default_sized and gs.bucket_bytes != BUCKET_BYTES):
         gs = GradSync(model)
         model._grad_sync = gs
     return gs

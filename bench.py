@@ -550,6 +550,10 @@ def measure_train(args, world, rank, dev, overrides, dtype=None, batch=None, ste
     if parallel.active():
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    gsync = parallel.grad_sync(model) if parallel.active() else None
+    if gsync is not None:      # two event records per step around the final waits of the exchange: what the compute stream stood still for
+        gsync.timing = True
+        gsync.exposed_wait_ms()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]      # per-step GPU time (an event record each: no wait)
     t0 = time.perf_counter()
     marks[0].record()
@@ -562,6 +566,11 @@ def measure_train(args, world, rank, dev, overrides, dtype=None, batch=None, ste
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     per_step = sorted(marks[k_].elapsed_time(marks[k_ + 1]) for k_ in range(steps))
+    exchange = None
+    if gsync is not None:
+        waits = gsync.exposed_wait_ms()
+        gsync.timing = False
+        exchange = _exchange_diagnostics(model, gsync, waits, dev)
     if os.environ.get('BTS_BENCH_MEMSTATS'):       # allocator state of the timed region, to stderr (diagnostics; not part of the line)
         ms_ = torch.cuda.memory_stats()
         print('memstats: reserved peak %.1f GB, allocated peak %.1f GB, hipMalloc retries %d, segments %d' %
@@ -626,6 +635,8 @@ def measure_train(args, world, rank, dev, overrides, dtype=None, batch=None, ste
         'loss': loss_v, 'macro_dice': macro_v,
         'streams': 'serial (one HIP stream)' if args.serial_streams else 'main + weight-gradient + gate streams',
     }
+    if exchange is not None:
+        out['exchange'] = exchange
     if shared:
         out['config']['note'] = '%d ranks sharing %s device(s) over gloo: functional check of the N>1 path' % (world, shared)
     if overrides:
@@ -644,6 +655,41 @@ def measure_train(args, world, rank, dev, overrides, dtype=None, batch=None, ste
         out['_first_step'] = first      # (host arrays for main(): popped before the line is printed)
     del model, opt
     return out
+
+
+def _exchange_diagnostics(model, gsync, waits, dev):
+    """N > 1, after the timed region: what the gradient exchange (C1) costs, so that the first multi-GPU run explains itself --
+    the buckets GradSync cut (MB, in launch order), each bucket's all-reduce run ALONE (5 repeats, HIP events on the compute stream around
+    a blocking all-reduce; bus bandwidth = 2 (N-1)/N x bytes / time, the figure to hold against xGMI's ~153 GB/s per link x 7 links), and
+    the time the compute stream waited at the end of the backward for buckets still in flight inside the timed steps (exposed = not
+    overlapped).  All ranks run the collectives; the numbers are this rank's."""
+    import torch
+    from bts_amd import parallel
+    d = torch.distributed
+    w = parallel.world()
+    sizes = [ln * 4 for _, ln, _ in gsync.buckets]
+    alone, bw = [], []
+    scratch = torch.zeros(max(ln for _, ln, _ in gsync.buckets), dtype=torch.float32, device=dev)
+    on_device = d.get_backend() != 'gloo'
+    for _, ln, _ in gsync.buckets:
+        t = []
+        for rep in range(6):
+            torch.cuda.synchronize()
+            d.barrier()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            parallel._sum_over_ranks(scratch[:ln])
+            b.record()
+            torch.cuda.synchronize()
+            if rep:
+                t.append(a.elapsed_time(b))
+        ms = sorted(t)[len(t) // 2]
+        alone.append(ms)
+        bw.append(2.0 * (w - 1) / w * ln * 4 / (ms * 1e-3) / 1e9 if ms > 0 else None)
+    return {'buckets': len(sizes), 'bucket_mb': [v / 1e6 for v in sizes], 'bucket_bytes_arg_mb': gsync.bucket_bytes / float(1 << 20),
+            'allreduce_alone_ms': alone, 'busbw_gbs': bw, 'backend': d.get_backend(), 'on_device_buffers': on_device,
+            'exposed_wait_ms_per_step': (sum(waits) / len(waits)) if waits else None, 'exposed_wait_ms_max': max(waits) if waits else None,
+            'algo_env': {k: os.environ[k] for k in ('NCCL_ALGO', 'NCCL_PROTO', 'NCCL_MIN_NCHANNELS', 'NCCL_MAX_NCHANNELS', 'RCCL_MSCCL_ENABLE') if k in os.environ}}
 
 
 def _sig(v, n=5):
@@ -693,6 +739,8 @@ def main():
     ap.add_argument('--crop', type=int, default=128)
     ap.add_argument('--batch', type=int, default=1, help='samples per GPU')
     ap.add_argument('--share-gpu', action='store_true', help='let ranks share devices (gloo); functional check only')
+    ap.add_argument('--bucket-mb', type=float, default=None,
+                    help='N > 1: size of the gradient all-reduce buckets in MB (default 64: parallel.BUCKET_BYTES / BTS_DP_BUCKET_MB)')
     ap.add_argument('--allow-overrides', action='store_true', help='run although BTS_* A/B switches are set')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-crop', type=int, default=128)
@@ -737,6 +785,8 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     shared = os.environ.get('BTS_BENCH_SHARED_DEVICES')
     torch.cuda.set_device(local)
+    if args.bucket_mb:
+        parallel.set_bucket_bytes(int(args.bucket_mb * (1 << 20)))
     if world > 1 or os.environ.get('BTS_FORCE_PG'):   # BTS_FORCE_PG=1: 1-rank RCCL group, smoke-tests the N>1 code path
         parallel.init_from_env('gloo' if shared else 'nccl')
     dev = torch.device('cuda', local)

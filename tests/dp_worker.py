@@ -6,7 +6,8 @@ usage: dp_worker.py RANK WORLD PORT OUT.pt [steps]
   WORLD == 0  -> single process, no process group, the WHOLE global batch (the reference every DP run must reproduce:
                  the reference itself is single-device, train.py:138)
   WORLD >= 1  -> one sample per rank; all ranks on cuda:0 over gloo (RCCL refuses two ranks on one device; with gloo the
-                 exchanges go through parallel._sum_over_ranks' host bounce, everything else is the production code)
+                 exchanges go through parallel._sum_over_ranks' host bounce, everything else is the production code), or -- with
+                 BTS_DP_BACKEND=nccl on a box with >= WORLD GPUs -- rank r on cuda:r over RCCL on device buffers
 """
 import os
 import sys
@@ -34,13 +35,18 @@ def main():
     from bts_amd.model import Model
     from bts_amd.tape import bump_weights_epoch
     from bts_amd.util import DiceCoefficient, DiceVAELoss, ScheduledOptim, train_step
-    torch.cuda.set_device(0)
-    dev = torch.device('cuda', 0)
+    # BTS_DP_BACKEND=nccl: one DEVICE per rank and RCCL on device buffers (the production path; needs >= WORLD GPUs) instead of ranks
+    # sharing cuda:0 over gloo's host bounce
+    backend = os.environ.get('BTS_DP_BACKEND', 'gloo')
+    didx = rank if (backend == 'nccl' and world >= 1) else 0
+    torch.cuda.set_device(didx)
+    dev = torch.device('cuda', didx)
     if world >= 1:
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                          LOCAL_RANK='0', BTS_FORCE_PG='1')
-        parallel.init_from_env('gloo')
+                          LOCAL_RANK=str(didx), BTS_FORCE_PG='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+        parallel.init_from_env(backend)
         assert parallel.world() == world and parallel.rank() == rank
+        assert torch.distributed.get_backend() == backend
     latent = KW['base_filters'] * 2 ** (KW['depth'] - 2)
     x, y, mask, eps = synthetic_batch(GLOBAL_BATCH, CROP, latent=latent, seed=77)
     sl = slice(0, GLOBAL_BATCH) if world == 0 else slice(rank, GLOBAL_BATCH, world)

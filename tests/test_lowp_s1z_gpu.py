@@ -135,3 +135,73 @@ def test_fused_groupnorm_statistics(dtype):
     # (the fused sums see the unrounded outputs, the stand-alone pass the stored ones: the difference is the storage rounding's mean)
     assert float((mean - m2).abs().max()) <= 4 * U[dtype] * float(y2.float().abs().mean()) + 1e-6
     assert float((rstd / r2 - 1).abs().max()) <= 4 * U[dtype]
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('accumulate', [False, True])
+def test_sixty_four_input_channels_as_two_passes(dtype, accumulate, monkeypatch):
+    """Cin = 64 -> Cout <= 32 (the decoder's top block, decoder.py:55-63: 64 -> 32 at 128^3): two marches of the 32-channel kernel over the
+    channel halves of the input slab, the second accumulating (BTS_LP_S1Z_PAIR=1 forces the form below its 8 M-voxel threshold).  The
+    first pass's result passes through the storage type once: the bound carries one more rounding of the partial result."""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    monkeypatch.setenv('BTS_LP_S1Z_PAIR', '1')
+    code, tdt = lowp.DTYPES[dtype]
+    u = U[dtype]
+    g = torch.Generator().manual_seed(41)
+    n, d, h, w, cin, cout = 2, 12, 32, 64, 64, 24
+    x = torch.randn((n, d, h, w, cin), generator=g)
+    wt = torch.randn((3, 3, 3, cin, cout), generator=g) * (2.0 / (27 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.3
+    old = torch.randn((n, d, h, w, cout), generator=g)
+    xr, wr, oldr = _round(x, tdt), _round(wt, tdt), _round(old, tdt)
+    start = oldr if accumulate else b.double()           # what the first pass adds its half of the contraction to
+    first = R.conv3d(xr[..., :32], wr[:, :, :, :32], None) + start          # ... and stores, rounded to the storage type
+    ref = R.conv3d(xr, wr, None) + start
+    # fp32 sums of the two passes + the two storage roundings (of the first pass's result and of the final one)
+    bound = 8 * 2.0 ** -24 * (R.conv3d(xr.abs(), wr.abs(), None) + start.abs()) + 1.01 * u * (ref.abs() + first.abs()) + 1e-30
+    slab = torch.zeros((n, d, h, w, cin + 16), dtype=tdt, device=DEV)
+    slab[..., 8:8 + cin] = x.to(tdt).to(DEV)
+    xin = slab[..., 8:8 + cin]
+    wp = lowp.pack(ops.K3S1, code, wt.to(DEV), cin, cout)
+    if accumulate:      # through the data-gradient entry point (it is the one with an accumulate flag): the same image, forward role
+        y = old.to(tdt).to(DEV).clone()
+        wt_b = wt.permute(0, 1, 2, 4, 3).flip(0, 1, 2).contiguous()      # conv^T with this kernel == the forward conv with wt
+        wpb = lowp.pack(ops.K3S1, code, wt_b.to(DEV), cout, cin, role=ops.ROLE_BWD)
+        _, syms = _ran(lambda: lowp.conv_bwd_data(ops.K3S1, code, xin, wpb, y, True))
+    else:
+        y, syms = _ran(lambda: lowp.conv(ops.K3S1, code, tdt, xin, wp, b.to(DEV), cout))
+    assert syms == ['lp_s1z_kernel', 'lp_s1z_kernel'], syms
+    err = (y.double().cpu() - ref).abs()
+    worst = float((err / bound).max())
+    assert worst <= 1.0, '%s: error %.3e is %.2fx the stated bound' % (dtype, float(err.max()), worst)
+    # and the tiled kernel agrees up to the roundings
+    monkeypatch.setenv('BTS_LP_S1Z_PAIR', '0')
+    if not accumulate:
+        y2, syms2 = _ran(lambda: lowp.conv(ops.K3S1, code, tdt, xin, wp, b.to(DEV), cout))
+        assert 'lp_s1z_kernel' not in syms2
+        assert float(((y2.double() - y.double()).cpu().abs() / bound).max()) <= 2.0
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+def test_two_pass_form_with_fused_groupnorm_statistics(dtype, monkeypatch):
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    from bts_amd.layers.group_norm import GroupNormalization
+    monkeypatch.setenv('BTS_LP_S1Z_PAIR', '1')
+    code, tdt = lowp.DTYPES[dtype]
+    g = torch.Generator().manual_seed(6)
+    n, d, h, w, cin, cout, groups = 1, 16, 32, 64, 64, 32, 8
+    x = torch.randn((n, d, h, w, cin), generator=g).to(tdt).to(DEV)
+    wt = (torch.randn((3, 3, 3, cin, cout), generator=g) * (2.0 / (27 * cin)) ** 0.5).to(DEV)
+    b = (torch.randn(cout, generator=g) * 0.3).to(DEV)
+    wp = lowp.pack(ops.K3S1, code, wt, cin, cout)
+    norm = GroupNormalization(groups=groups, axis=-1)
+    norm.build((None, None, None, None, cout))
+    (y, mean, rstd), syms = _ran(lambda: lowp.conv_gn(code, tdt, x, wp, b, cout, norm))
+    assert syms.count('lp_s1z_kernel') == 2, syms
+    m2, r2 = lowp.gn_stats(code, y, groups, norm._mode, norm.epsilon)
+    assert float((mean - m2).abs().max()) <= 4 * U[dtype] * float(y.float().abs().mean()) + 1e-6
+    assert float((rstd / r2 - 1).abs().max()) <= 4 * U[dtype]
+    ref = R.conv3d(x.double().cpu(), wt.to(tdt).double().cpu(), b.double().cpu())
+    assert float((y.double().cpu() - ref).abs().max()) <= 4 * U[dtype] * float(ref.abs().max())
