@@ -191,7 +191,7 @@ def test_two_pass_form_with_fused_groupnorm_statistics(dtype, monkeypatch):
     monkeypatch.setenv('BTS_LP_S1Z_PAIR', '1')
     code, tdt = lowp.DTYPES[dtype]
     g = torch.Generator().manual_seed(6)
-    n, d, h, w, cin, cout, groups = 1, 16, 32, 64, 64, 32, 8
+    n, d, h, w, cin, cout, groups = 2, 16, 32, 64, 64, 32, 8      # (8 columns x 16 planes: above the streaming kernel's 96-plane floor)
     x = torch.randn((n, d, h, w, cin), generator=g).to(tdt).to(DEV)
     wt = (torch.randn((3, 3, 3, cin, cout), generator=g) * (2.0 / (27 * cin)) ** 0.5).to(DEV)
     b = (torch.randn(cout, generator=g) * 0.3).to(DEV)
