@@ -1755,6 +1755,112 @@ extern "C" int bts_lp_block_epilogue(int dtype, const void* res, const void* c2,
   return BTS_OK;
 }
 
+// ---- the LAST block's epilogue with the output head in it (inference: decoder.py:55-63 after the top decoder block, model.py:63-68) ----
+// y_head[v][k] = sigmoid( sum_c out[v][c] * W[c][k] + b[k] ),  out = res * (sigmoid(res . w_sp) + ch) + relu(GN2(c2)) as above -- `out` has ONE
+// reader in a forward without a backward, the 1x1x1 head (32 -> 3 at the CLI defaults), so it is never written: the separate pair costs a
+// write and a read of the 32-channel tensor plus a launch (160 x 192 x 160: 177 + 101 us; fused: one pass over res and c2).  The head sees the
+// fp32 values of `out`, not their 16-bit roundings.  Chunked form only (its conditions as in bts_lp_block_epilogue); K <= 4.
+template <typename T, int K>
+__global__ __launch_bounds__(256) void lp_block_epilogue_head_kernel(const unsigned short* __restrict__ res, const unsigned short* __restrict__ c2,
+                                                                     float* __restrict__ yh, const float* __restrict__ wsp, const float* __restrict__ ch,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                     const float* __restrict__ hw, const float* __restrict__ hb, long Lu, long per,
+                                                                     int C, int G, int cg, int slab, int upn, int sigmoid) {
+  const int unit = blockIdx.y, n = unit / upn, u = unit - n * upn;
+  const long lo = (long)unit * Lu;
+  const long a = lo + (long)blockIdx.x * per;
+  const long bnd = (a + per < lo + Lu) ? a + per : lo + Lu;
+  const int t8 = threadIdx.x * 8, c = t8 % C, oct = C / 8;
+  float mu[8], sc[8], be[8], ws[8], cw[8], wr[8][K], hbk[K];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int g = slab ? u : (c + e) / cg;
+    const int idx = slab ? g * cg + ((c + e) % cg) : (c + e);
+    mu[e] = mean[n * G + g];
+    sc[e] = rstd[n * G + g] * gamma[idx];
+    be[e] = beta[idx];
+    ws[e] = wsp[c + e];
+    cw[e] = ch[n * C + c + e];
+#pragma unroll
+    for (int k = 0; k < K; ++k) wr[e][k] = hw[(c + e) * K + k];
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) hbk[k] = hb ? hb[k] : 0.f;
+  const long pstep = 2048 / C;
+  const long pix = a / C + t8 / C;
+  const unsigned short* ra = res + a + t8;
+  const unsigned short* rb = c2 + a + t8;
+  const long Kc = (bnd - a) / 2048;
+  auto one = [&](const u32x4 r0, const u32x4 r1, long px) {
+    float va[8], vb[8];
+    unpack8<T>(r0, va);
+    unpack8<T>(r1, vb);
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dot = fmaf(va[e], ws[e], dot);
+    for (int m = 1; m < oct; m <<= 1) dot += __shfl_xor(dot, m, 64);
+    const float sp = 1.f / (1.f + __expf(-dot));
+    float hk[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) hk[k] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float t = fmaxf(fmaf(vb[e] - mu[e], sc[e], be[e]), 0.f);
+      const float o = fmaf(va[e], sp + cw[e], t);
+#pragma unroll
+      for (int k = 0; k < K; ++k) hk[k] = fmaf(o, wr[e][k], hk[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      for (int m = 1; m < oct; m <<= 1) hk[k] += __shfl_xor(hk[k], m, 64);
+    if (c == 0) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        float r = hk[k] + hbk[k];
+        if (sigmoid) r = 1.f / (1.f + __expf(-r));
+        yh[px * K + k] = r;
+      }
+    }
+  };
+  long k = 0;
+  for (; k + 2 <= Kc; k += 2) {
+    u32x4 r0[2], r1[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      r0[j] = *reinterpret_cast<const u32x4*>(ra + (k + j) * 2048);
+      r1[j] = *reinterpret_cast<const u32x4*>(rb + (k + j) * 2048);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) one(r0[j], r1[j], pix + (k + j) * pstep);
+  }
+  for (; k < Kc; ++k) one(*reinterpret_cast<const u32x4*>(ra + k * 2048), *reinterpret_cast<const u32x4*>(rb + k * 2048), pix + k * pstep);
+}
+extern "C" int bts_lp_block_epilogue_head(int dtype, const void* res, const void* c2, float* y_head, const float* wsp, const float* ch,
+                                          const float* gamma, const float* beta, const float* mean, const float* rstd, const float* head_w,
+                                          const float* head_b, int N, long V, int C, int G, int mode, int K, int sigmoid, hipStream_t stream) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  if (N <= 0 || V <= 0 || C % 8 != 0 || C > 256 || ((C / 8) & (C / 8 - 1)) != 0 || C % G != 0 || K < 1) return BTS_ERR_SHAPE;
+  const long E = V * C, L = E / G;
+  const int slab = mode == BTS_GN_SLAB;
+  const long Lu = slab ? L : E;
+  // (per-thread state: 8 x K head weights on top of the epilogue's 40 registers -- wide blocks and heads stay on the two-kernel route)
+  if (K > 4 || C > 64 || (slab && L % 8 != 0) || 2048 % C != 0 || Lu % 2048 != 0) return BTS_ERR_UNSUPPORTED;
+  if ((((uintptr_t)res) & 15) || (((uintptr_t)c2) & 15) || (((uintptr_t)y_head) & 3)) return BTS_ERR_ALIGN;
+  const int upn = slab ? G : 1;
+  int B;
+  const long per = lp_chunk_per(Lu, (long)N * upn, &B);
+  const dim3 grid((unsigned)B, (unsigned)(N * upn));
+  (void)hipGetLastError();
+#define LP_EH(TT, K_) hipLaunchKernelGGL((lp_block_epilogue_head_kernel<TT, K_>), grid, dim3(256), 0, stream, (const unsigned short*)res, (const unsigned short*)c2, y_head, wsp, ch, gamma, beta, mean, rstd, head_w, head_b, Lu, per, C, G, C / G, slab, upn, sigmoid)
+#define LP_EH_K(TT) do { if (K == 1) LP_EH(TT, 1); else if (K == 2) LP_EH(TT, 2); else if (K == 3) LP_EH(TT, 3); else LP_EH(TT, 4); } while (0)
+  if (dtype == LP_F16) LP_EH_K(TF16); else LP_EH_K(TBF16);
+#undef LP_EH_K
+#undef LP_EH
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
+
 // ---- the non-default samplers on 16-bit tensors (args.py:136-141): MaxPooling3D(2) (downsample.py:51-70) and
 // UpSampling3D(2) = nearest-neighbour repeat (upsample.py:69), with their gradients (train.py:142-151 under TF autodiff).  Eight
 // channels (one 16-byte piece) per thread; the pool keeps the window position of the FIRST maximum (scan order dz, dy, dx) like the

@@ -12,11 +12,12 @@ level slabs.  The first block reads the 2-channel input volume: a 16-channel mat
 so the volume is stored zero-padded to 16 channels (the pad multiplies zeros on both sides).
 """
 import ctypes
+import os
 
 import torch
 
 from . import ops
-from ._lib import lib
+from ._lib import ERRORS, lib
 from .tape import weights_epoch
 
 DTYPES = {'float16': (1, torch.float16), 'bfloat16': (2, torch.bfloat16), 'fp16': (1, torch.float16),
@@ -334,6 +335,21 @@ def block_epilogue(code, res, c2, out, wsp, ch, gamma, beta, mean, rstd, groups,
     return out
 
 
+def block_epilogue_head(code, res, c2, wsp, ch, gamma, beta, mean, rstd, groups, mode, head_w, head_b, sigmoid=True):
+    """the last block's epilogue and the 1x1x1 output head in one pass (the block output is never written) -> y (N,D,H,W,K) fp32, or None
+    where the fused kernel does not take the shape (the caller runs block_epilogue + head)"""
+    n, d, h, w, f = res.shape
+    k = head_w.shape[-1]
+    y = torch.empty((n, d, h, w, k), dtype=torch.float32, device=res.device)
+    r = lib().probe('bts_lp_block_epilogue_head', code, _p(res), _p(c2), _p(y), _p(wsp), _p(ch), _p(gamma), _p(beta), _p(mean), _p(rstd),
+                    _p(head_w), _p(head_b) if head_b is not None else None, n, d * h * w, f, groups, mode, k, 1 if sigmoid else 0, _stream())
+    if r == -3:          # BTS_ERR_UNSUPPORTED: outside the fused kernel's shapes
+        return None
+    if r != 0:
+        raise RuntimeError('bts_lp_block_epilogue_head failed: %s' % ERRORS.get(r, 'hipError %d' % r))
+    return y
+
+
 def se_bwd(code, tdt, dout, res, sp, gap, h, ch, w1, w2, wsp, dw1, dw2, dwsp, dbias=None):
     """gate backward on 16-bit tensors -> dres (storage type, dense); parameter gradients accumulate; dbias: fp32 view that receives
     (+=) the column sums of dres, the shortcut conv's bias gradient"""
@@ -480,6 +496,7 @@ class LowPrecisionForward(object):
             if not isinstance(up, (ConvUpsample, LinearUpsample)):
                 raise NotImplementedError('unknown up-sampling layer %r' % type(up).__name__)
         self.channels_first = model.data_format == 'channels_first'
+        self.fuse_head = os.environ.get('BTS_LP_FUSE_HEAD', '1') != '0'      # (=0: block epilogue and output head as two launches; A/B)
         bf = getattr(model.encoder, 'base_filters', 16)
         if bf % 16 != 0:
             # every 16-bit convolution contracts over whole matrix steps of 16 input channels (v_mfma_f32_32x32x16): an 8-filter level
@@ -498,8 +515,9 @@ class LowPrecisionForward(object):
         m, r = gn_stats(self.code, c, norm.groups, norm._mode, norm.epsilon)
         return gn_apply(self.code, c, norm.gamma.t, norm.beta.t, m, r, norm.groups, norm._mode, relu, out=out)
 
-    def _block(self, blk, x, out, fold=None):
-        """ResnetBlock.call (resnet.py:116-138); x: 16-bit view, out: 16-bit view or None"""
+    def _block(self, blk, x, out, fold=None, head=None):
+        """ResnetBlock.call (resnet.py:116-138); x: 16-bit view, out: 16-bit view or None.  head = (W (C,K), b (K)): this is the last block
+        and its only reader is the sigmoid output head -- returns ('head', y_pred) where the fused epilogue takes the shape"""
         code, tdt = self.code, self.tdt
         f, g = blk.filters, blk.groups
         n, d, h, w, cin = x.shape
@@ -526,10 +544,15 @@ class LowPrecisionForward(object):
             c2, m2, r2 = conv_gn(code, tdt, a, wp_c2, blk.conv2_b.t, f, blk.norm2)
             del a
         del c1
-        if out is None:
-            out = torch.empty((n, d, h, w, f), dtype=tdt, device=res.device)
         if gate is not None:
             torch.cuda.current_stream().wait_stream(gate)       # the epilogue is where the two branches meet (resnet.py:130,137)
+        if head is not None and out is None and self.fuse_head:
+            yh = block_epilogue_head(code, res, c2, blk.spatial_k.t.reshape(-1), ch, blk.norm2.gamma.t, blk.norm2.beta.t, m2, r2, g,
+                                     blk.norm2._mode, head[0], head[1], True)
+            if yh is not None:
+                return ('head', yh)
+        if out is None:
+            out = torch.empty((n, d, h, w, f), dtype=tdt, device=res.device)
         return block_epilogue(code, res, c2, out, blk.spatial_k.t.reshape(-1), ch, blk.norm2.gamma.t, blk.norm2.beta.t, m2, r2, g,
                               blk.norm2._mode)
 
@@ -595,10 +618,16 @@ class LowPrecisionForward(object):
                 cur = self._down(down, slab[..., :nb * f])                                # encoder.py:97-98
         slab, used = residuals[-1]
         y = slab[..., :used]
-        for (up, blk), (slab, cres) in zip(dec.levels, residuals[-2::-1]):
+        hw = dec.out_k.t.reshape(dec.out_k.t.shape[-2], dec.out_k.t.shape[-1])
+        nlev = len(dec.levels)
+        for li, ((up, blk), (slab, cres)) in enumerate(zip(dec.levels, residuals[-2::-1])):
             f = up.filters
             self._up(up, y, slab[..., cres:cres + f])                                     # decoder.py:72
-            y = self._block(blk, slab[..., :cres + f], None)                              # decoder.py:75-78
-        yp = head(self.code, y, dec.out_k.t.reshape(dec.out_k.t.shape[-2], dec.out_k.t.shape[-1]), dec.out_b.t, True)
+            # (the top block's output has one reader, the output head: folded into its epilogue where the library can)
+            y = self._block(blk, slab[..., :cres + f], None, head=(hw, dec.out_b.t) if li == nlev - 1 else None)   # decoder.py:75-78
+        if isinstance(y, tuple):
+            yp = y[1]
+        else:
+            yp = head(self.code, y, hw, dec.out_b.t, True)
         ops.step_fence_done(fence)
         return yp.permute(0, 4, 1, 2, 3) if self.channels_first else yp      # the public layout (a view, like Tensor.public())

@@ -325,6 +325,13 @@ int bts_lp_colsum(int dtype, const void* x, float* out, void* workspace, long wo
 int bts_lp_block_epilogue(int dtype, const void* res, const void* c2, void* out, float* sp_out, const float* wsp, const float* ch, const float* gamma,
                           const float* beta, const float* mean, const float* rstd, int N, long V, int C, int ldo, int G, int mode,
                           bts_stream_t stream);
+/* The last decoder block's epilogue with the output head in it (decoder.py:55-63: Conv3D 1x1x1 -> out_ch, sigmoid; model.py:63-68 in a
+ * forward without a backward): y_head [N*V][K] fp32 = sigmoid?(out . head_w + head_b) with `out` as bts_lp_block_epilogue forms it, never
+ * written.  head_w (C, K) fp32 row-major, head_b (K) or NULL.  BTS_ERR_UNSUPPORTED outside the fused kernel's shapes (K <= 4, C <= 64,
+ * whole 2048-element chunks per unit): call bts_lp_block_epilogue and bts_lp_head. */
+int bts_lp_block_epilogue_head(int dtype, const void* res, const void* c2, float* y_head, const float* wsp, const float* ch, const float* gamma,
+                               const float* beta, const float* mean, const float* rstd, const float* head_w, const float* head_b, int N,
+                               long V, int C, int G, int mode, int K, int sigmoid, bts_stream_t stream);
 /* y = conv3x3x3(x) + bias in the storage type (dense) and the BTS_GN_SLAB statistics of y (resnet.py:80-93 conv -> GroupNormalization)
  * in one pass where the tiled kernel can emit the partial sums from its epilogue; the 16-bit counterpart of bts_conv3d_fwd_gn */
 long bts_lp_conv3d_fwd_gn_workspace(int N, int D, int H, int W, int Cin, int Cout, int G);

@@ -896,3 +896,65 @@ def test_conv2_data_gradient_with_groupnorm1_backward(case, dtype):
     assert float((dc32 - dx32).abs().max()) <= 2e-5 * float(dx32.abs().max()) + 1e-6
     for a, b in ((dg, dg32), (db, db32)):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-5
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('mode', ['slab', 'channel'])
+def test_last_block_epilogue_with_the_output_head_in_it(dtype, mode):
+    """bts_lp_block_epilogue_head (inference tail: decoder.py:55-63 after the top block): y = sigmoid(out . W + b) with `out` never written,
+    against the fp64 formula on the stored 16-bit operands (the fused kernel keeps `out` in fp32, so it is held to an fp32 bound, tighter
+    than the two-kernel route that rounds `out` to the storage type in between); shapes outside its tiling are declined, not mangled"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    code, tdt = lowp.DTYPES[dtype]
+    gmode = ops.GN_SLAB if mode == 'slab' else ops.GN_CHANNEL
+    g = torch.Generator().manual_seed(17)
+    n, d, h, w, c, G = 2, 8, 8, 16, 32, 8
+    x = torch.randn((n, d, h, w, c), generator=g) * 1.7 + 0.4
+    res = torch.randn((n, d, h, w, c), generator=g)
+    gamma, beta = 1 + 0.3 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g)
+    wsp = torch.randn(c, generator=g) * 0.3
+    ch = torch.rand((n, c), generator=g)
+    wk, bk = torch.randn((c, 3), generator=g) * 0.2, torch.randn(3, generator=g) * 0.1
+    xr, rr = _round(x, tdt), _round(res, tdt)
+    axis = -1 if mode == 'slab' else 1
+    xx = xr if mode == 'slab' else xr.permute(0, 4, 1, 2, 3)
+    gn = R.group_norm(xx, gamma.double(), beta.double(), G, axis)
+    gn = torch.relu(gn if mode == 'slab' else gn.permute(0, 2, 3, 4, 1))
+    sp = torch.sigmoid((rr * wsp.double()).sum(-1, keepdim=True))
+    out_ref = rr * (sp + ch.double().reshape(n, 1, 1, 1, c)) + gn
+    ref = torch.sigmoid(out_ref @ wk.double() + bk.double())
+    xd, rd = x.to(tdt).to(DEV), res.to(tdt).to(DEV)
+    mean, rstd = lowp.gn_stats(code, xd, G, gmode, 1e-5)
+    args = (wsp.to(DEV), ch.to(DEV), gamma.to(DEV), beta.to(DEV), mean, rstd, G, gmode)
+    y = lowp.block_epilogue_head(code, rd, xd, *args, wk.to(DEV), bk.to(DEV), True)
+    torch.cuda.synchronize()
+    assert y is not None and y.dtype == torch.float32 and tuple(y.shape) == (n, d, h, w, 3)
+    err = float((y.double().cpu() - ref).abs().max())
+    assert err <= 2e-5, err                     # (fp32 arithmetic on the stored operands; the statistics come from the 16-bit kernel's fp32 sums)
+    # the two-kernel route rounds `out` to the storage type before the head reads it: it agrees within that rounding
+    out = lowp.block_epilogue(code, rd, xd, torch.empty((n, d, h, w, c), dtype=tdt, device=DEV), *args)
+    y2 = lowp.head(code, out, wk.to(DEV), bk.to(DEV), True)
+    torch.cuda.synchronize()
+    bound = 0.25 * U[dtype] * (out_ref.abs() @ wk.double().abs()) + 2e-5       # (sigmoid is 1/4-Lipschitz)
+    assert bool(((y2.double().cpu() - y.double().cpu()).abs() <= bound).all())
+    # outside the tiling (units that are not whole 2048-element chunks): declined
+    assert lowp.block_epilogue_head(code, rd[:, :, :3, :4].contiguous(), xd[:, :, :3, :4].contiguous(), *args, wk.to(DEV), bk.to(DEV), True) is None
+
+
+def test_inference_forward_with_and_without_the_fused_head(monkeypatch):
+    """LowPrecisionForward: the top decoder block's epilogue carries the output head by default; BTS_LP_FUSE_HEAD=0 restores the two
+    launches.  Same labels, probabilities within the storage rounding of the block output."""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    m = _model(dict(base_filters=16, groups=8, reduction=2, depth=3), (32, 32, 32), 5)
+    x = torch.randn((1, 32, 32, 32, 2), generator=torch.Generator().manual_seed(9)).to(DEV)
+    ops.profile_enable(False)
+    y1 = lowp.LowPrecisionForward(m, 'float16')(x)
+    monkeypatch.setenv('BTS_LP_FUSE_HEAD', '0')
+    y0 = lowp.LowPrecisionForward(m, 'float16')(x)
+    torch.cuda.synchronize()
+    assert y1.shape == y0.shape == (1, 32, 32, 32, 3)
+    d = (y1 - y0).abs()
+    assert 0.0 < float(d.max()) <= 2e-3, float(d.max())        # (different roundings: not bitwise equal, and not far apart)
+    assert float((y1.argmax(-1) != y0.argmax(-1)).float().mean()) <= 1e-3
