@@ -3,8 +3,8 @@ fixed seed" on 2ch x 128^3, bit-exact argmax label map), not against itself:
 
   * BASELINE configs[1]: one full train step of the CLI-default model on one 2ch x 128^3 volume (train.py:140-152: forward
     with training=True, Dice + 0.1*MSE + 0.1*KL + L2 loss, Dice metric, gradients, TF-form Adam) -- fp32 engine vs
-    oracle/torch_ref.py evaluated in FP64 on the GPU box's host cores (measured there: 145 s on 64 threads, 82 GB), with the
-    oracle's own fp32 evaluation (20-33 s) as the conditioning yardstick, exactly as tests/test_model_gpu.py does at <= 64^3;
+    oracle/torch_ref.py evaluated in FP64 on the GPU box's host cores (measured there: 121 s on 16 threads, 82 GB), with the
+    oracle's own fp32 evaluation (20 s) as the conditioning yardstick, exactly as tests/test_model_gpu.py does at <= 64^3;
   * BASELINE configs[2]'s engine (bf16 storage) at the same size and on the same oracle evaluation, batch 1 (the batch-8 plan
     is held to the fp32 engine in tests/test_lowp_fullsize_gpu.py): what 16-bit storage costs against the REFERENCE arithmetic;
   * BASELINE configs[4]: the 155x190x147 volume zero-padded to 160x192x160 (test.py:164-178), inference=True (model.py:63-68)
@@ -32,7 +32,9 @@ from oracle import torch_ref as R  # noqa: E402
 
 CLI = dict(base_filters=32, groups=8, reduction=8, depth=4)
 CROP = (128, 128, 128)
-ORACLE_THREADS = int(os.environ.get('BTS_TEST_ORACLE_THREADS', '64'))
+# torch-CPU threads for the oracle: measured on the GPU box (EPYC 9575F, 256 hardware threads) for the 128^3 train step --
+# 16 threads: fp32 20.5 s / fp64 121 s; 32: 21 / 132; 64: 26 / 150; 128: 46 / 199 (the fp64 convs have no oneDNN path and stop scaling early)
+ORACLE_THREADS = int(os.environ.get('BTS_TEST_ORACLE_THREADS', '16'))
 
 
 def _randomised_params(cfg, crop, seed):
