@@ -826,9 +826,11 @@ __global__ __launch_bounds__(256, 2) void lp_conv_gather_kernel(const LpGatherPa
 // (quad base + i), the quad transpose (lowp_common.h) hands every lane its own voxel's pieces, one per k-step.  Two register sets:
 // the next group's rows and weight fragments are in flight while the current group multiplies.  Needs Wg % GK == 0 (a quad never
 // leaves its output row).
-template <typename T, int CB, int GK>
-__global__ __launch_bounds__(256, 2) void lp_conv_gatherq_kernel(const LpGatherParams p) {
-  constexpr int VB = 2;
+// VB = 4 (round 5): four position groups per wave share every weight fragment -- a wave's weight re-streaming from L2 (one fragment per
+// two matrix instructions at VB = 2, as much traffic as the activations) halves; GK = 2 only (register budget: 128 accumulators + two
+// operand sets).
+template <typename T, int CB, int GK, int VB = 2>
+__global__ __launch_bounds__(256, VB == 4 ? 1 : 2) void lp_conv_gatherq_kernel(const LpGatherParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = tid >> 6;
   const int h = lane >> 5, l32 = lane & 31, b = l32 & (GK - 1);
@@ -955,7 +957,15 @@ static int lp_gather_launch(LpGatherParams p, hipStream_t stream) {
     }
     // (below ~300 workgroups the plain kernel's smaller tiles win: 128 -> 128 at 8 x 32^3, 256 workgroups, 77 against 90 us)
     { const char* m = getenv("BTS_LP_GATHERQ_MIN"); if (gk && ((p.npos + 255) / 256) * p.ncg < (m ? atol(m) : 288)) gk = 0; }
-    if (gk) vb = 2;
+    if (gk) {
+      // four position groups per wave: OFF by default -- measured in round 5 (profiles/r05_ab_e6_gatherq_vb4.txt): the 128 accumulators
+      // + two operand sets need 442 registers, i.e. one wave per SIMD, and the batch-8 step loses 1.7 ms (76.6 against 74.9), the
+      // inference forward nothing / 0.1 ms.  BTS_LP_GATHERQ_VB4=<n> (n > 1) takes grids of at least n double-size workgroups (tests, A/B)
+      const char* v4 = getenv("BTS_LP_GATHERQ_VB4");
+      const bool vb4 = v4 && atoi(v4) > 1 && cb == 2 && p.Wg % 2 == 0 && ((p.npos + 511) / 512) * p.ncg >= atol(v4);
+      vb = vb4 ? 4 : 2;
+      if (vb4) gk = 2;
+    }
   }
   const long blocks = ((p.npos + 128L * vb - 1) / (128L * vb)) * p.ncg;
   if (blocks > 0x7fffffffL) return BTS_ERR_SHAPE;
@@ -964,7 +974,8 @@ static int lp_gather_launch(LpGatherParams p, hipStream_t stream) {
   (void)hipGetLastError();
   if (gk) {
 #define LP_GQ(CB_, GK_) hipLaunchKernelGGL((lp_conv_gatherq_kernel<T, CB_, GK_>), dim3((unsigned)blocks), dim3(256), 0, stream, p)
-    if (cb == 2) { if (gk == 4) LP_GQ(2, 4); else LP_GQ(2, 2); }
+    if (vb == 4) hipLaunchKernelGGL((lp_conv_gatherq_kernel<T, 2, 2, 4>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    else if (cb == 2) { if (gk == 4) LP_GQ(2, 4); else LP_GQ(2, 2); }
     else { if (gk == 4) LP_GQ(1, 4); else LP_GQ(1, 2); }
 #undef LP_GQ
     if (prof) bts_prof_end(stream);

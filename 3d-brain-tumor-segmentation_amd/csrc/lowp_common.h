@@ -142,6 +142,15 @@ __device__ __forceinline__ void k1_pair_transpose(u32x4 (&r)[2], int b) {
   r[0] = s[0]; r[1] = s[1];
 }
 
+// Cache policy of the conv kernels' OUTPUT stores (the aux operand of buffer_store: bit 0 sc0, bit 1 nt, bit 4 sc1).  The outputs of a
+// conv are not read again by the same launch, while its INPUT lines are (a k-step fetches 32 bytes of a 128-byte line, the other k-steps
+// and the neighbouring tiles want the rest): stores that allocate in L2 could push those lines out.  Measured in round 5
+// (profiles/r05_ab_e7_store_policy.txt; make variantf FILE=lowp_s1d NAME=st2 EXTRA=-DLP_OUT_STORE_AUX=2): non-temporal stores make the
+// batch-8 step 4 % SLOWER (79.7 against 76.5 ms; sc0+nt and nt+sc1 the same or worse) and the inference forward 3 % -- the default stays 0.
+#ifndef LP_OUT_STORE_AUX
+#define LP_OUT_STORE_AUX 0
+#endif
+
 // GroupNorm-apply on the way IN: the conv reads the RAW output c of the previous conv and applies a = relu((c - mean) rstd gamma + beta)
 // (group_norm.py:110-122 + the ReLU of resnet.py:133-136) to each input plane after it has landed in LDS -- inference only, where no
 // backward needs the applied tensor: the 1 read + 1 write pass of bts_lp_gn_apply goes away.  Slab semantics with whole z planes per

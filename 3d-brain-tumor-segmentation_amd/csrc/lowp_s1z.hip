@@ -310,7 +310,7 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
 #ifdef S1Z_EXP_NOSTORE   // timing experiment (wrong results)
         if (z == -12345)
 #endif
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{d0, d1, d2, d3}, yr, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{d0, d1, d2, d3}, yr, off, 0, LP_OUT_STORE_AUX);
         if constexpr (GNB) {      // (after the exchange: the STORED couts co .. co + 7 of voxel l32, as a reduce pass would read them)
           dst_ = u32x4{d0, d1, d2, d3};
           zst = z;
