@@ -335,6 +335,27 @@ def block_epilogue(code, res, c2, out, wsp, ch, gamma, beta, mean, rstd, groups,
     return out
 
 
+def first_block(code, tdt, x, w3, b3, w1, b1, f, norm):
+    """the first ResnetBlock's conv1 and shortcut from the RAW fp32 2-channel volume x (N,D,H,W,2) in one pass (csrc/lowp_c2.hip) ->
+    (c1, mean1, rstd1, res, gap), or None where the kernel does not take the shape (the caller casts the volume into a zero-padded
+    16-channel tensor and runs the generic kernels)"""
+    if norm._mode != ops.GN_SLAB or x.dtype != torch.float32 or x.shape[-1] != 2 or not x.is_contiguous():
+        return None
+    n, d, h, w, _ = x.shape
+    nb = lib().probe('bts_lp_first_block_workspace', n, d, h, w, f, norm.groups)
+    if nb < 0:
+        return None
+    ws = ops.workspace(nb, x.device)
+    c1 = torch.empty((n, d, h, w, f), dtype=tdt, device=x.device)
+    res = torch.empty((n, d, h, w, f), dtype=tdt, device=x.device)
+    mean = torch.empty(n * norm.groups, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(n * norm.groups, dtype=torch.float32, device=x.device)
+    gap = torch.empty((n, f), dtype=torch.float32, device=x.device)
+    lib().call('bts_lp_first_block_fwd', code, _p(x), _p(w3), _p(b3), _p(w1), _p(b1), _p(c1), _p(res), _p(mean), _p(rstd), _p(gap), _p(ws), nb,
+               n, d, h, w, f, norm.groups, float(norm.epsilon), _stream())
+    return c1, mean, rstd, res, gap
+
+
 def block_epilogue_head(code, res, c2, wsp, ch, gamma, beta, mean, rstd, groups, mode, head_w, head_b, sigmoid=True):
     """the last block's epilogue and the 1x1x1 output head in one pass (the block output is never written) -> y (N,D,H,W,K) fp32, or None
     where the fused kernel does not take the shape (the caller runs block_epilogue + head)"""
@@ -497,6 +518,7 @@ class LowPrecisionForward(object):
                 raise NotImplementedError('unknown up-sampling layer %r' % type(up).__name__)
         self.channels_first = model.data_format == 'channels_first'
         self.fuse_head = os.environ.get('BTS_LP_FUSE_HEAD', '1') != '0'      # (=0: block epilogue and output head as two launches; A/B)
+        self.fuse_first = os.environ.get('BTS_LP_C2', '1') != '0'            # (=0: padded 16-channel copy + generic kernels for the first block; A/B)
         bf = getattr(model.encoder, 'base_filters', 16)
         if bf % 16 != 0:
             # every 16-bit convolution contracts over whole matrix steps of 16 input channels (v_mfma_f32_32x32x16): an 8-filter level
@@ -515,7 +537,7 @@ class LowPrecisionForward(object):
         m, r = gn_stats(self.code, c, norm.groups, norm._mode, norm.epsilon)
         return gn_apply(self.code, c, norm.gamma.t, norm.beta.t, m, r, norm.groups, norm._mode, relu, out=out)
 
-    def _block(self, blk, x, out, fold=None, head=None):
+    def _block(self, blk, x, out, fold=None, head=None, first=None):
         """ResnetBlock.call (resnet.py:116-138); x: 16-bit view, out: 16-bit view or None.  head = (W (C,K), b (K)): this is the last block
         and its only reader is the sigmoid output head -- returns ('head', y_pred) where the fused epilogue takes the shape"""
         code, tdt = self.code, self.tdt
@@ -524,15 +546,20 @@ class LowPrecisionForward(object):
         dup_start, dup_shift = fold if fold else (0, 0)
         v = d * h * w
         key = id(blk)
-        if cin % 16 != 0:
+        if first is None and cin % 16 != 0:
             raise RuntimeError('16-bit convolutions step over 16 input channels; got a %d-channel view' % cin)
         # (the 2-channel input volume arrives zero-padded to 16 channels, see __call__: blk.cin_ref real channels, the rest
         # of the k-step multiplies zeros in both operands)
         cin_slab = min(cin, blk.cin_ref) if fold is None else cin
-        wp_pt = self._packed((key, 'pt'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
-        wp_c1 = self._packed((key, 'c1'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
-        res, gap, (_, ch), gate = gate_branch(code, tdt, x, wp_pt, blk.ptwise_b.t, f, blk.se_w1.t, blk.se_w2.t)
-        c1, m1, r1 = conv_gn(code, tdt, x, wp_c1, blk.conv1_b.t, f, blk.norm1)      # conv + the statistics of its output
+        if first is not None:      # conv1, its statistics, the shortcut and the squeeze came out of the first-block kernel
+            c1, m1, r1, res, gap = first
+            _, ch = ops.se_mlp_fwd(gap, blk.se_w1.t, blk.se_w2.t)
+            gate = None
+        else:
+            wp_pt = self._packed((key, 'pt'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
+            wp_c1 = self._packed((key, 'c1'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
+            res, gap, (_, ch), gate = gate_branch(code, tdt, x, wp_pt, blk.ptwise_b.t, f, blk.se_w1.t, blk.se_w2.t)
+            c1, m1, r1 = conv_gn(code, tdt, x, wp_c1, blk.conv1_b.t, f, blk.norm1)      # conv + the statistics of its output
         wp_c2 = self._packed((id(blk), 'c2'), ops.K3S1, blk.conv2_k, f, f)
         # conv2 reads relu(GN1(c1)); nobody else does in a forward without a backward: where the library can, GN1 + ReLU are applied to
         # conv2's input planes inside the conv kernel and the apply pass (1 read + 1 write of the tensor) goes away
@@ -589,8 +616,15 @@ class LowPrecisionForward(object):
         x = x.contiguous()
         if any(s % (2 ** (m.encoder.depth - 1)) for s in x.shape[1:4]):
             raise ValueError('spatial sizes must be multiples of %d (test.py:164-178 pads to that)' % 2 ** (m.encoder.depth - 1))
+        enc0 = m.encoder.levels[0][0][0]
+        first = None
+        if self.fuse_first and x.shape[-1] == 2 and enc0.cin_ref == 2:
+            # the raw 2-channel volume straight into the first block's two convolutions (csrc/lowp_c2.hip): no padded 16-channel copy
+            first = first_block(self.code, self.tdt, x, enc0.conv1_k.t, enc0.conv1_b.t, enc0.ptwise_k.t, enc0.ptwise_b.t, enc0.filters, enc0.norm1)
         # the input volume in the storage type, zero-padded to one 16-channel matrix step (in_ch = 2: model.py:18)
-        if x.shape[-1] <= 4:
+        if first is not None:
+            pass
+        elif x.shape[-1] <= 4:
             x = cast_pad16(self.code, self.tdt, x)
         else:
             cpad = (x.shape[-1] + 15) // 16 * 16
@@ -610,7 +644,7 @@ class LowPrecisionForward(object):
             for j, blk in enumerate(convs):
                 out = slab[..., j * f:(j + 1) * f]
                 if j == 0:
-                    self._block(blk, cur, out)
+                    self._block(blk, cur, out, first=first if i == 0 else None)
                 else:
                     self._block(blk, slab[..., :j * f], out, fold=((j - 1) * f, f))       # encoder.py:83-87
             residuals.append((slab, nb * f))

@@ -69,6 +69,8 @@ def kernel_symbol(sym, detail=False):
         return 'lp_s1z_kernel'
     if sym == 39:
         return 'lp_s2t_kernel'
+    if sym == 40:
+        return 'lp_c2_kernel'
     if sym >= 100:  # 100 + (MODE << 2 | FIXG)
         return 'wgrad_kernel<%d,%d>' % ((sym - 100) >> 2, (sym - 100) & 3)
     return 'igemm_kernel<%s,%d>' % (_CFG[sym & 7], 4 if sym & 8 else 1)

@@ -325,6 +325,16 @@ int bts_lp_colsum(int dtype, const void* x, float* out, void* workspace, long wo
 int bts_lp_block_epilogue(int dtype, const void* res, const void* c2, void* out, float* sp_out, const float* wsp, const float* ch, const float* gamma,
                           const float* beta, const float* mean, const float* rstd, int N, long V, int C, int ldo, int G, int mode,
                           bts_stream_t stream);
+/* The FIRST ResnetBlock's two convolutions of the raw in_ch = 2 volume in a forward without a backward (resnet.py:30-37,80-87,118 at encoder
+ * level 0; model.py:63-68): c1 = conv3x3x3(x) + b3 and res = conv1x1x1(x) + b1 in the storage type (dense, F channels) from ONE pass over the
+ * fp32 input x (N,D,H,W,2), GroupNorm-1's BTS_GN_SLAB statistics of c1 (mean, rstd [N*G]) and gap[n][c] = mean over voxels of res (the
+ * gate's squeeze, resnet.py:121).  w3 (3,3,3,2,F), w1 (1,1,1,2,F): the reference's fp32 kernels, unpacked.  Replaces bts_lp_cast_pad16 +
+ * bts_lp_conv1_gap + bts_lp_conv3d_fwd_gn on the zero-padded 16-channel copy.  Workspace query -1 / BTS_ERR_UNSUPPORTED outside its shapes
+ * (F in {8,16,24,32}, D % G == 0, F % G == 0). */
+long bts_lp_first_block_workspace(int N, int D, int H, int W, int F, int G);
+int bts_lp_first_block_fwd(int dtype, const float* x, const float* w3, const float* b3, const float* w1, const float* b1, void* c1, void* res,
+                           float* mean, float* rstd, float* gap, void* workspace, long workspace_bytes, int N, int D, int H, int W, int F,
+                           int G, float eps, bts_stream_t stream);
 /* The last decoder block's epilogue with the output head in it (decoder.py:55-63: Conv3D 1x1x1 -> out_ch, sigmoid; model.py:63-68 in a
  * forward without a backward): y_head [N*V][K] fp32 = sigmoid?(out . head_w + head_b) with `out` as bts_lp_block_epilogue forms it, never
  * written.  head_w (C, K) fp32 row-major, head_b (K) or NULL.  BTS_ERR_UNSUPPORTED outside the fused kernel's shapes (K <= 4, C <= 64,

@@ -958,3 +958,67 @@ def test_inference_forward_with_and_without_the_fused_head(monkeypatch):
     d = (y1 - y0).abs()
     assert 0.0 < float(d.max()) <= 2e-3, float(d.max())        # (different roundings: not bitwise equal, and not far apart)
     assert float((y1.argmax(-1) != y0.argmax(-1)).float().mean()) <= 1e-3
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('shape,f,groups', [((1, 8, 8, 64), 32, 8), ((2, 6, 10, 40), 16, 2), ((1, 12, 7, 33), 24, 4)],
+                         ids=['aligned-32', 'ragged-16', 'ragged-24'])
+def test_first_block_kernel_on_the_raw_two_channel_volume(shape, f, groups, dtype):
+    """bts_lp_first_block_fwd (csrc/lowp_c2.hip): conv1 (3x3x3, 2 -> F) + its GroupNorm statistics, the shortcut (1x1x1, 2 -> F) and the
+    squeeze of the first ResnetBlock from ONE pass over the fp32 volume (resnet.py:30-37,80-87,118,121 at encoder level 0), against the
+    oracle's ops on the operands rounded to the storage type, |err| <= 8 * 2^-24 * sum|a b| + u |ref|; whole and ragged tiles, F = 16 / 24 / 32"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    from bts_amd.layers.group_norm import GroupNormalization
+    code, tdt = lowp.DTYPES[dtype]
+    u = U[dtype]
+    n, d, h, w = shape
+    g = torch.Generator().manual_seed(31 + f)
+    x = torch.randn((n, d, h, w, 2), generator=g) * 1.3 + 0.2
+    w3 = torch.randn((3, 3, 3, 2, f), generator=g) * 0.2
+    b3 = torch.randn(f, generator=g) * 0.3
+    w1 = torch.randn((1, 1, 1, 2, f), generator=g) * 0.5
+    b1 = torch.randn(f, generator=g) * 0.3
+    xr, w3r, w1r = _round(x, tdt), _round(w3, tdt), _round(w1, tdt)
+    c1_ref = R.conv3d(xr, w3r, b3.double())
+    c1_bound = 8 * 2.0 ** -24 * (R.conv3d(xr.abs(), w3r.abs(), None) + b3.double().abs()) + u * c1_ref.abs() + 1e-30
+    res_ref = R.conv3d(xr, w1r, b1.double())
+    res_bound = 8 * 2.0 ** -24 * (R.conv3d(xr.abs(), w1r.abs(), None) + b1.double().abs()) + u * res_ref.abs() + 1e-30
+    norm = GroupNormalization(groups=groups, axis=-1)
+    norm.build((None, None, None, None, f))
+    out = lowp.first_block(code, tdt, x.to(DEV), w3.to(DEV), b3.to(DEV), w1.to(DEV), b1.to(DEV), f, norm)
+    torch.cuda.synchronize()
+    assert out is not None
+    c1, mean, rstd, res, gap = out
+    assert float(((c1.double().cpu() - c1_ref).abs() / c1_bound).max()) <= 1.0
+    assert float(((res.double().cpu() - res_ref).abs() / res_bound).max()) <= 1.0
+    # GroupNorm-1 statistics (slab semantics: group g = z planes [g D/G, (g+1) D/G), all channels) of the UNROUNDED conv output
+    zt = d // groups
+    for i in range(n):
+        for gq in range(groups):
+            blk = c1_ref[i, gq * zt:(gq + 1) * zt]
+            m_ref, v_ref = float(blk.mean()), float(blk.var(unbiased=False))
+            assert abs(float(mean[i * groups + gq]) - m_ref) <= 1e-5 * (1 + abs(m_ref))
+            assert abs(float(rstd[i * groups + gq]) * (v_ref + 1e-5) ** 0.5 - 1.0) <= 1e-4
+    gap_ref = res_ref.mean(dim=(1, 2, 3))
+    assert float((gap.double().cpu() - gap_ref).abs().max()) <= 1e-5 * (1 + float(gap_ref.abs().max()))
+
+
+def test_inference_forward_with_and_without_the_first_block_kernel(monkeypatch):
+    """LowPrecisionForward takes the raw volume through bts_lp_first_block_fwd by default; BTS_LP_C2=0 restores the zero-padded 16-channel
+    copy and the generic kernels.  Same operands, different summation order: probabilities within the 16-bit route's own noise"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    m = _model(dict(base_filters=16, groups=8, reduction=2, depth=3), (32, 32, 32), 5)
+    x = torch.randn((1, 32, 32, 32, 2), generator=torch.Generator().manual_seed(9)).to(DEV)
+    ops.profile_enable(True)
+    y1 = lowp.LowPrecisionForward(m, 'float16')(x)
+    torch.cuda.synchronize()
+    ops.profile_enable(False)
+    assert 'lp_c2_kernel' in [s for s, _, _ in ops.profile_records()]
+    monkeypatch.setenv('BTS_LP_C2', '0')
+    y0 = lowp.LowPrecisionForward(m, 'float16')(x)
+    torch.cuda.synchronize()
+    d = (y1 - y0).abs()
+    assert float(d.max()) <= 5e-3 and float(d.mean()) <= 2e-4, (float(d.max()), float(d.mean()))
+    assert float((y1.argmax(-1) != y0.argmax(-1)).float().mean()) <= 2e-3
