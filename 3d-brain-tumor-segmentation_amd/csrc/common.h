@@ -54,6 +54,25 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   v += dpp_move_f64<0x143, 0xc>(v);      // row_bcast31 into rows 2 and 3: lane 63 holds the total
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
+// Sum over aligned groups of n ADJACENT lanes (n a power of two <= 32), the result in every lane of the group -- the per-voxel dot
+// products of the element-wise kernels (a voxel's C / 8 lanes sit side by side).  DPP moves for the steps inside a row of 16 (quad
+// permutes, then row_half_mirror / row_mirror: after the quad steps every lane of a quad holds the same bits, so the mirrored partner
+// is as good as the xor partner) instead of __shfl_xor's ds_bpermute round trips; bit-identical to the xor butterfly (fp add commutes).
+template <int CTRL> __device__ __forceinline__ float dpp_move_f32(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_group_sum_f32(float v, int n) {
+#ifdef BTS_GROUP_SUM_SHFL      // A/B builds only
+  for (int m = 1; m < n; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+#endif
+  if (n >= 2) v += dpp_move_f32<0xB1>(v);
+  if (n >= 4) v += dpp_move_f32<0x4E>(v);
+  if (n >= 8) v += dpp_move_f32<0x141>(v);
+  if (n >= 16) v += dpp_move_f32<0x140>(v);
+  if (n >= 32) v += __shfl_xor(v, 16, 64);
+  return v;
+}
 __device__ __forceinline__ float wave_sum_f32(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

@@ -1660,7 +1660,7 @@ __global__ __launch_bounds__(256) void lp_block_epilogue_kernel(const unsigned s
     float dot = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) dot = fmaf(a[e], wsp[c + e], dot);
-    for (int m = 1; m < oct; m <<= 1) dot += __shfl_xor(dot, m, 64);   // (oct is a power of two <= 32; lanes of a voxel are adjacent)
+    dot = lane_group_sum_f32(dot, oct);   // (oct is a power of two <= 32; lanes of a voxel are adjacent)
     const float sp = 1.f / (1.f + __expf(-dot));
     if (sp_out != nullptr && c == 0) sp_out[pix] = sp;   // the spatial gate, kept for the backward pass (resnet.py:127)
     const int gsl = (int)(r / L);
@@ -1710,7 +1710,7 @@ __global__ __launch_bounds__(256) void lp_block_epilogue_chunk_kernel(const unsi
     float dot = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) dot = fmaf(va[e], ws[e], dot);
-    for (int m = 1; m < oct; m <<= 1) dot += __shfl_xor(dot, m, 64);
+    dot = lane_group_sum_f32(dot, oct);
     const float sp = 1.f / (1.f + __expf(-dot));
     if (sp_out != nullptr && c == 0) sp_out[px] = sp;
 #pragma unroll
@@ -1810,7 +1810,7 @@ __global__ __launch_bounds__(256) void lp_block_epilogue_head_kernel(const unsig
     float dot = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) dot = fmaf(va[e], ws[e], dot);
-    for (int m = 1; m < oct; m <<= 1) dot += __shfl_xor(dot, m, 64);
+    dot = lane_group_sum_f32(dot, oct);
     const float sp = 1.f / (1.f + __expf(-dot));
     float hk[K];
 #pragma unroll
@@ -1824,7 +1824,7 @@ __global__ __launch_bounds__(256) void lp_block_epilogue_head_kernel(const unsig
     }
 #pragma unroll
     for (int k = 0; k < K; ++k)
-      for (int m = 1; m < oct; m <<= 1) hk[k] += __shfl_xor(hk[k], m, 64);
+      hk[k] = lane_group_sum_f32(hk[k], oct);
     if (c == 0) {
 #pragma unroll
       for (int k = 0; k < K; ++k) {
@@ -2086,7 +2086,7 @@ __global__ __launch_bounds__(256) void lp_head_oct_kernel(const unsigned short* 
       float s = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) s = fmaf(t[e], wr[e][k], s);
-      for (int m = 1; m < C8; m <<= 1) s += __shfl_xor(s, m, 64);
+      s = lane_group_sum_f32(s, C8);
       acc[k] = s;
     }
     if (live && o == 0) {
