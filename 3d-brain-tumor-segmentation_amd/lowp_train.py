@@ -244,7 +244,7 @@ class LowPrecisionTrainer(object):
         # relu(GN1(c1)) has two readers, conv2's forward and conv2's weight gradient: where both kernels can normalise their input planes
         # themselves (the streaming kernels of the 128^3 level), the tensor is never written (a = None: the backward knows)
         a = None
-        if self.fuse_gn1_apply and f % 16 == 0 and lowp.wgrad_supported(ops.K3S1, f, f) and lowp.gnin_train_ok(c1, f, blk.norm1, blk.norm2):
+        if self.fuse_gn1_apply and lowp.wgrad_supported(ops.K3S1, f, f) and lowp.gnin_train_ok(c1, f, blk.norm1, blk.norm2):
             c2, m2, r2 = lowp.conv_gn_normed_input(code, tdt, c1, blk.norm1, m1, r1, True, wp_c2, blk.conv2_b.t, f, blk.norm2)
         else:
             a = gn_apply(code, c1, blk.norm1.gamma.t, blk.norm1.beta.t, m1, r1, g, blk.norm1._mode, True)
@@ -271,17 +271,16 @@ class LowPrecisionTrainer(object):
         key = id(blk)
         x = s['x']
         cin_slab = s['cin_slab']
-        # conv2's weight gradient on the 16-bit kernel?  (f % 16: the GroupNorm backward hands dc over zero-padded to whole matrix steps
-        # of 16 channels; with 8 filters the padded gradient is wider than the kernel's slot -- those blocks stay on the fp32 kernels)
-        lp2 = f % 16 == 0 and lowp.wgrad_supported(ops.K3S1, f, f)
+        # conv2's weight gradient on the 16-bit kernel?  (f is a multiple of 16 here: LowPrecisionForward refuses other models at construction)
+        lp2 = lowp.wgrad_supported(ops.K3S1, f, f)
         # conv1 / shortcut weight gradients on the 16-bit kernel; the first block reads the 2-channel volume zero-padded to one matrix
         # step: its gradients are taken over all 16 stored channels into a scratch tensor and the live rows added to the real slots
         pad_in = cin_slab < x.shape[-1]
-        lp1 = f % 16 == 0 and lowp.wgrad_supported(ops.K3S1, x.shape[-1], f)
+        lp1 = lowp.wgrad_supported(ops.K3S1, x.shape[-1], f)
         # conv branch: GN2 (+ReLU) -> conv2 -> GN1 (+ReLU) -> conv1
         # gate backward and GroupNorm-2 backward both read dout: one pair of passes where the fused kernels' tiling fits
         fused = None
-        if lp2 and lp1 and n2._mode == ops.GN_SLAB and f % 16 == 0 and self.fuse_block_bwd:
+        if lp2 and lp1 and n2._mode == ops.GN_SLAB and self.fuse_block_bwd:
             fused = lowp.block_bwd(code, self.tdt, dout, s['res'], s['c2'], s['sp'], s['gap'], s['hbuf'], s['ch'], blk.se_w1.t, blk.se_w2.t,
                                    blk.spatial_k.t.reshape(-1), n2.gamma.t, n2.beta.t, s['m2'], s['r2'], n2.groups, self._gslot(blk.se_w1),
                                    self._gslot(blk.se_w2), self._gslot(blk.spatial_k).reshape(-1), self._gslot(n2.gamma), self._gslot(n2.beta),
@@ -307,7 +306,7 @@ class LowPrecisionTrainer(object):
                                                              accumulate=True))
         wp_c2b = self._pk((key, 'c2b'), ops.K3S1, blk.conv2_k, f, f, role=ops.ROLE_BWD)
         both = None
-        if self.fuse_gn1_bwd and n1._mode == ops.GN_SLAB and f % 16 == 0 and dc2_16.shape[-1] == f:
+        if self.fuse_gn1_bwd and n1._mode == ops.GN_SLAB and dc2_16.shape[-1] == f:
             # conv2's data gradient and GroupNorm-1's backward as one library call: on the layers the z-marching conv takes, the class
             # sums of GroupNorm's backward leave the conv's epilogue (no reduce pass over da and c1)
             both = lowp.conv_bwd_data_gn_bwd(code, self.tdt, dc2_16, wp_c2b, s['c1'], n1.gamma.t, n1.beta.t, s['m1'], s['r1'], self._gslot(n1.gamma),
