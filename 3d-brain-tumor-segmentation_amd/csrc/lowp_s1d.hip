@@ -61,6 +61,11 @@ struct LpS1dParams {
   double* gnp;       // fused GroupNorm partial sums (slab semantics) [N*G][gn_B][2], or NULL
   int gn_G, gn_zt;
   long gn_B;
+  // SC kernels: a second contraction at the CENTRE tap only -- y += x2 (N,D,H,W,K) . w2, the 1x1x1 image [k-step][cout block][k-half][32][8]
+  // (lowp.hip's first part of a K1 image) -- the shortcut conv's data gradient riding on conv1's (resnet.py:96-103 / 80-87 under train.py:151)
+  const unsigned short* x2;
+  const unsigned short* wp2;
+  int ldx2;
 };
 
 template <int MODE, int TXL>
@@ -91,7 +96,7 @@ __device__ __forceinline__ void s1d_barrier() {
   asm volatile("" ::: "memory");
 }
 
-template <typename T, int MODE, int TXL>
+template <typename T, int MODE, int TXL, bool SC = false>
 __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
   // (the host pass of hipcc 7.2 silently drops this template's launch stub when it instantiates the body -- the array-indexed
   // LDS-DMA offsets trigger it -- so the body exists in the device pass only; there is no other code path)
@@ -212,6 +217,36 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (lds_ptr_t)(lds + G::OFF_BIAS + slot * 256), 4, off, 0, 0, 0);
   };
 
+  // ---- SC: the centre-tap operand pair of a k-step, global -> registers (no LDS: a lane's B fragment is its own voxel's 16 bytes) ----
+  // B2[v]: voxel (z, y0 + v, lx) of the tile, channels 16 ks + 8 h .. + 7 of x2; A2: couts 32 cb + l32, the same 8 channels of w2.
+  // Requested in stage 2 of the k-step BEFORE (ahead of its last weight stage: the next stage-0 wait covers them), used after the
+  // centre group of stage 1: one register set.
+  u32x4 A2, B2[4];
+  unsigned sc_off[4], sc_aoff = 0x80000000u;
+  __amdgpu_buffer_rsrc_t x2r, w2r;
+  auto sc_item = [&](const Item& t, bool live) {
+    if constexpr (SC) {
+      x2r = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 + (long)t.n * p.D * p.H * p.W * (long)p.ldx2), 0, 0x7fffffff, 0x00020000);
+      const int oz = t.oz0 + zz * ZP + lz, ox = t.ox0 + lx;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int oy = t.oy0 + y0 + v;
+        const bool ok = live && oz < p.D && oy < p.H && ox < p.W;
+        sc_off[v] = ok ? (unsigned)((((oz * p.H + oy) * p.W + ox) * p.ldx2 + 8 * h) * 2) : 0x80000000u;
+      }
+      const int cb = t.cg * CBW + cbw;
+      sc_aoff = (live && cb < p.NB) ? (unsigned)(cb * 1024 + h * 512 + l32 * 16) : 0x80000000u;
+    }
+  };
+  auto sc_issue = [&](int ks) {
+    if constexpr (SC) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) B2[v] = __builtin_amdgcn_raw_buffer_load_b128(x2r, sc_off[v], (unsigned)ks * 32u, 0);
+      A2 = __builtin_amdgcn_raw_buffer_load_b128(w2r, sc_aoff, (unsigned)(ks * p.NB) * 1024u, 0);
+    }
+  };
+  if constexpr (SC) w2r = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp2, 0, 0x7fffffff, 0x00020000);
+
   // ---- compute side ----
   // A k-step is nine groups (dz, dx) of 12 matrix instructions: 6 input rows (they serve the three dy taps of the wave's four output
   // rows) + 3 weight fragments.  The fragments of group g+1 are read from LDS while group g multiplies (two register sets; the
@@ -266,6 +301,8 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
 #pragma unroll
   for (int r = NHA; r < NH; ++r) issue_halo1(r, ks0, 0);
   issue_bias(ci.cg, 0);
+  sc_item(ci, true);
+  sc_issue(ks0);
 #pragma unroll
   for (int r = 0; r < NW; ++r) issue_w1(r, w_soff(ci.cg, ks0, 1, true), 1);
   bool after_out = false;
@@ -325,6 +362,13 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
       ldB(Bn, hb, I1(), I2()); ldA(An, I1(), I2());
       __builtin_amdgcn_sched_barrier(0);
       mm(Ac, Bc, [&](int i) { hook1(i + 3); });
+      if constexpr (SC) {      // the shortcut's k-step: centre tap only
+        if (!(BTS_DBG(p) & 4)) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[v] = T::mfma(A2, B2[v], acc[v]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       ldB(Bc, hb, I2(), I0());
       __builtin_amdgcn_sched_barrier(0);
       mm(An, Bn, [&](int i) { hook1(i + 6); });
@@ -333,6 +377,10 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
       s1d_barrier();
       ldA(Ac, I2(), I0());
       const unsigned so2 = w_soff(ncg_, nks, 1, nlive);
+      if constexpr (SC) {      // the next k-step's centre-tap pair (ahead of W(next, 1): covered by the next stage-0 wait)
+        if (last) sc_item(ni, have_next);
+        sc_issue(nks);
+      }
       ldB(Bn, hb, I2(), I1()); ldA(An, I2(), I1());
       __builtin_amdgcn_sched_barrier(0);
       mm(Ac, Bc, [&](int i) { if (i < NW) issue_w1(i, so2, 1); });
@@ -553,10 +601,10 @@ long bts_lp_s1d_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn) {
   return (long)(D / Gn) * pl.nty * pl.ntx * pl.ncg * 2;
 }
 
-template <typename T, int MODE, int TXL>
+template <typename T, int MODE, int TXL, bool SC = false>
 static int s1d_launch_t(const LpS1dParams& p, hipStream_t stream) {
   typedef S1dGeo<MODE, TXL> G;
-  auto kern = lp_s1d_kernel<T, MODE, TXL>;
+  auto kern = lp_s1d_kernel<T, MODE, TXL, SC>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
@@ -572,10 +620,17 @@ static int s1d_launch_t(const LpS1dParams& p, hipStream_t stream) {
 }
 
 // BTS_OK = ran, 1 = declined.  wp_dma = the DMA part of the K3S1 image.  gn_B (out, may be NULL): partial slots per (n, group) written.
+// x2 / wp2 / ldx2 (may be NULL): the SC form -- y += x2 . w2 at the centre tap, x2 (N,D,H,W,Cin) with voxel stride ldx2, wp2 the first
+// part of a K1 image with the same K = Cin and N = Cout (64-cout items only: 32-cout items have no registers left for the operand pair)
 int bts_lp_s1d_launch_(int dtype, const void* x, const void* wp_dma, const float* bias, void* y, void* ws, long ws_bytes, int N, int D, int H,
-                       int W, int Cin, int ldx, int Cout, int ldy, int accum, double* gnp, int gn_G, hipStream_t stream) {
+                       int W, int Cin, int ldx, int Cout, int ldy, int accum, double* gnp, int gn_G, hipStream_t stream, const void* x2,
+                       const void* wp2, int ldx2) {
   S1dPlan pl;
   if (!s1d_plan(N, D, H, W, Cin, Cout, pl)) return 1;
+  const bool sc = x2 != nullptr;
+  if (sc && (pl.mode != 1 || wp2 == nullptr || ldx2 < Cin || ldx2 % 8 != 0 || (((uintptr_t)x2) & 15) || (((uintptr_t)wp2) & 15) ||
+             (long)D * H * W * (long)ldx2 * 2 >= 0x7fffff00L))
+    return 1;
   if (((long)(D + 2) * H * W + 64) * (long)ldx * 2 >= 0x7fffffffL) return 1;
   const long omax = (long)ldy > (long)((Cout + 31) / 32) * 32 * 2 ? ldy : (long)((Cout + 31) / 32) * 32 * 2;
   if ((long)D * H * W * omax * 2 >= 0x7fffff00L) return 1;
@@ -600,6 +655,7 @@ int bts_lp_s1d_launch_(int dtype, const void* x, const void* wp_dma, const float
 #ifdef BTS_TIMING_EXPERIMENTS
   { const char* e = getenv("BTS_S1D_DBG"); if (e) p.dbg = atoi(e); }
 #endif
+  p.x2 = (const unsigned short*)x2; p.wp2 = (const unsigned short*)wp2; p.ldx2 = ldx2;
   p.gnp = gnp; p.gn_G = gn_G; p.gn_zt = gn_G > 0 ? D / gn_G : 1;
   p.gn_B = gn_G > 0 ? (long)p.gn_zt * pl.nty * pl.ntx * pl.ncg * 2 : 0;
   const bool split_gn = gnp != nullptr && p.ksplit > 1;      // statistics from the split-K finish (dense y, whole 32-cout blocks)
@@ -608,8 +664,12 @@ int bts_lp_s1d_launch_(int dtype, const void* x, const void* wp_dma, const float
     p.gnp = nullptr; p.gn_G = 0; p.gn_zt = 1; p.gn_B = 0;
   }
   const bool prof = bts_prof_on();
-  if (prof) bts_prof_begin(33 | ((1 + pl.mode * 2 + (pl.txl == 4 ? 1 : 0)) << 16), 2.0 * 27.0 * Cin * (double)Cout * (double)nvox, stream);   // (bits 16+: the variant, for bench.py's per-variant table)
+  if (prof) bts_prof_begin(33 | ((1 + pl.mode * 2 + (pl.txl == 4 ? 1 : 0)) << 16), 2.0 * (sc ? 28.0 : 27.0) * Cin * (double)Cout * (double)nvox, stream);   // (bits 16+: the variant, for bench.py's per-variant table)
   int r;
+  if (sc) {
+    if (pl.txl == 5) r = dtype == LP_F16 ? s1d_launch_t<TF16, 1, 5, true>(p, stream) : s1d_launch_t<TBF16, 1, 5, true>(p, stream);
+    else r = dtype == LP_F16 ? s1d_launch_t<TF16, 1, 4, true>(p, stream) : s1d_launch_t<TBF16, 1, 4, true>(p, stream);
+  } else
 #define S1D_CASE(M_, X_)                                                                                                  \
   if (pl.mode == M_ && pl.txl == X_)                                                                                      \
     r = dtype == LP_F16 ? s1d_launch_t<TF16, M_, X_>(p, stream) : s1d_launch_t<TBF16, M_, X_>(p, stream);

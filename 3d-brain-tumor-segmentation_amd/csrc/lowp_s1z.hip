@@ -44,6 +44,11 @@ struct LpS1zParams {
   int gb_zt;         // planes per group
   LpGnaFuse ga;      // GNA kernels: GroupNorm (+ReLU) applied to the input planes in LDS (lowp_common.h)
   int ga_zt;         // planes per group of the input's GroupNorm
+  // SC kernels: a second contraction at the CENTRE tap only -- y += x2 (N,D,H,W,Cin) . w2, the 1x1x1 image [k-step][k-half][32][8] (first
+  // part of a K1 image with one cout block): the shortcut conv's data gradient riding on conv1's (resnet.py:96-103 / 80-87 under train.py:151)
+  const unsigned short* x2;
+  const unsigned short* wp2;
+  int ldx2;
 };
 #define S1Z_TX 32
 #define S1Z_TY 16
@@ -59,7 +64,7 @@ __device__ __forceinline__ u32x4 s1z_rsrc(const void* base) {
   return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
 }
 
-template <typename T, int KS, bool GNB = false, bool GNA = false>
+template <typename T, int KS, bool GNB = false, bool GNA = false, bool SC = false>
 __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int SX = S1Z_SX, SY = S1Z_SY, NVOX = SX * SY, NCHK = S1Z_NCHK;
@@ -192,6 +197,22 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
     }
   };
   __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, 0x7fffffff, 0x00020000);
+  // SC: the operand pair of the centre tap, global -> registers (a lane's B fragment is its own voxel's 16 bytes; the weights stay in
+  // registers for the whole launch).  The rows of plane z + 1 are requested inside stage z (after its plane requests) and multiplied at
+  // the head of stage z + 1, into the accumulator set of that stage's centre tap.
+  u32x4 A2[SC ? KS : 1], B2[SC ? KS : 1][2];
+  __amdgpu_buffer_rsrc_t x2r = yr;
+  unsigned sc_off[2] = {0x80000000u, 0x80000000u}, x2plane = 0;
+  auto sc_request = [&](int z) {
+    if constexpr (SC) {
+      const bool pok = z >= zlo && z < zhi;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+          B2[ks][r] = __builtin_amdgcn_raw_buffer_load_b128(x2r, pok ? sc_off[r] : 0x80000000u, pok ? (unsigned)z * x2plane + (unsigned)ks * 32u : 0u, 0);
+    }
+  };
   // GNB (GroupNorm-backward class sums, LpGnbFuse).  Element e of a lane's stored 8 couts is channel co + e with co a multiple of 8, so
   // its class (channel mod cg, cg | 4) is e mod cg for every lane.  With t = c * g' + b' (g' = rstd * gamma_j, b' = beta_j - mean * g':
   // per sample and channel, in LDS) the masked gradient is dE = [t > 0] da and the class sums are B_j = S0_j, A_j = rstd * (S1_j - mean *
@@ -374,6 +395,14 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
     ldB(B[0], 0);
     ldA(A[0], 0);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SC) {      // centre tap (kz = 1) of output plane zp: set R
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        acc[R][0] = T::mfma(A2[ks], B2[ks][0], acc[R][0]);
+        acc[R][1] = T::mfma(A2[ks], B2[ks][1], acc[R][1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int kz = g % 3;
@@ -395,6 +424,9 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
 #endif
       if constexpr (GNB) {
         if (g == (NR < NG ? NR : NG - 1)) gnb_request(zp - 1);       // (after this stage's plane requests)
+      }
+      if constexpr (SC) {
+        if (g == (NR < NG ? NR : NG - 1)) sc_request(zp + 1);
       }
       __builtin_amdgcn_sched_barrier(0);
       const int s = (R + 4 - kz) % 3;
@@ -423,6 +455,12 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
     const u32x4 wr = s1z_rsrc(p.wp);
     for (int c = wave; c < 27 * KS; c += 8) s1z_dma16(wr, lds0 + (unsigned)(c * 1024), (unsigned)(lane * 16), (unsigned)(c * 1024));
     if (tid < 32) reinterpret_cast<float*>(lds + OFF_BIAS)[tid] = (p.bias != nullptr && tid < p.Cout) ? p.bias[tid] : 0.f;
+    if constexpr (SC) {
+      const __amdgpu_buffer_rsrc_t w2r = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp2, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) A2[ks] = __builtin_amdgcn_raw_buffer_load_b128(w2r, (unsigned)(h * 512 + l32 * 16), (unsigned)ks * 1024u, 0);
+      x2plane = (unsigned)(p.H * p.W * p.ldx2 * 2);
+    }
   }
   const int w = blockIdx.x;
   int it0 = w * p.ipw;
@@ -432,6 +470,12 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
   for (int item = it0; item < it1; ++item) {
     setup(item);
     yr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long)cn * p.D * p.H * p.W * (long)p.ldy), 0, 0x7fffffff, 0x00020000);
+    if constexpr (SC) {
+      x2r = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 + (long)cn * p.D * p.H * p.W * (long)p.ldx2), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) sc_off[r] = (unsigned)((((cy0 + r0 + r) * p.W + cx0 + l32) * p.ldx2 + 8 * h) * 2);
+      sc_request(zlo - 1);      // (outside the chunk: zeros)
+    }
     if constexpr (GNB) {
       cr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.gb.x + (long)cn * p.D * p.H * p.W * (long)p.Cout), 0, 0x7fffffff, 0x00020000);
       // (the previous item's last reads lie behind its closing barrier; the barrier below publishes these)
@@ -570,16 +614,21 @@ bool bts_lp_s1z_gna_ok_(int N, int D, int H, int W, int Cin, int ldx, int Cout, 
   return cg <= 8 && 8 % cg == 0;
 }
 int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bias, void* y, int N, int D, int H, int W, int Cin, int ldx,
-                       int Cout, int ldy, int accum, double* gn_part, int gn_G, hipStream_t stream, const LpGnbFuse* gb, const LpGnaFuse* ga) {
+                       int Cout, int ldy, int accum, double* gn_part, int gn_G, hipStream_t stream, const LpGnbFuse* gb, const LpGnaFuse* ga,
+                       const void* x2, const void* wp2, int ldx2) {
   S1zPlan pl;
   if (!s1z_plan(pl, N, D, H, W, Cin, ldx, Cout, ldy)) return 1;
+  const bool sc = x2 != nullptr;
+  if (sc && (Cin == 64 || gb != nullptr || ga != nullptr || gn_part != nullptr || wp2 == nullptr || ldx2 < Cin || ldx2 % 8 != 0 ||
+             (((uintptr_t)x2) & 15) || (((uintptr_t)wp2) & 15) || (long)D * H * W * (long)ldx2 * 2 >= 0x7fffffffL))
+    return 1;
   if (Cin == 64) {      // two 32-channel passes (see s1z_plan): channels [0, 32) write (or accumulate, as asked), [32, 64) accumulate and count
     if (gb != nullptr || ga != nullptr) return 1;
-    const int r = bts_lp_s1z_launch_(dtype, x, wp, bias, y, N, D, H, W, 32, ldx, Cout, ldy, accum, nullptr, 0, stream, nullptr, nullptr);
+    const int r = bts_lp_s1z_launch_(dtype, x, wp, bias, y, N, D, H, W, 32, ldx, Cout, ldy, accum, nullptr, 0, stream, nullptr, nullptr, nullptr, nullptr, 0);
     if (r != BTS_OK) return r;
     // (image: [k-step][dz][tap][k-half][32 couts][8 cin], 27 KB per k-step: the second half starts two k-steps in)
     return bts_lp_s1z_launch_(dtype, reinterpret_cast<const unsigned short*>(x) + 32, reinterpret_cast<const char*>(wp) + 2 * 27 * 1024, nullptr, y,
-                              N, D, H, W, 32, ldx, Cout, ldy, 1, gn_part, gn_G, stream, nullptr, nullptr);
+                              N, D, H, W, 32, ldx, Cout, ldy, 1, gn_part, gn_G, stream, nullptr, nullptr, nullptr, nullptr, 0);
   }
   if (ga != nullptr && (gb != nullptr || !bts_lp_s1z_gna_ok_(N, D, H, W, Cin, ldx, Cout, ldy, ga->G) || ga->cg != Cin / ga->G)) return 1;
   if ((((uintptr_t)x) & 15) || (((uintptr_t)y) & 15) || (((uintptr_t)wp) & 15)) return 1;
@@ -596,13 +645,14 @@ int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bi
   p.gn_B = gn_G > 0 ? s1z_gn_B(pl, p.gn_zt) : 0;
   if (gb != nullptr) { p.gb = *gb; p.gb_zt = D / gb->G; } else { p.gb = LpGnbFuse{}; p.gb_zt = 1; }
   if (ga != nullptr) { p.ga = *ga; p.ga_zt = D / ga->G; } else { p.ga = LpGnaFuse{}; p.ga_zt = 1; }
+  p.x2 = (const unsigned short*)x2; p.wp2 = (const unsigned short*)wp2; p.ldx2 = ldx2;
   const int KS = Cin / 16;
   const size_t shmem = (size_t)(27 * KS * 1024 + 2 * S1Z_NCHK * 1024 * KS + 256 + 1024 + 512);
   (void)hipGetLastError();
-#define S1Z_LAUNCH(TT, KS_) do { if (gb != nullptr) S1Z_LAUNCH_(TT, KS_, true, false); else if (ga != nullptr) S1Z_LAUNCH_(TT, KS_, false, true); else S1Z_LAUNCH_(TT, KS_, false, false); } while (0)
-#define S1Z_LAUNCH_(TT, KS_, GB_, GA_)                                                                                       \
+#define S1Z_LAUNCH(TT, KS_) do { if (sc) S1Z_LAUNCH_(TT, KS_, false, false, true); else if (gb != nullptr) S1Z_LAUNCH_(TT, KS_, true, false, false); else if (ga != nullptr) S1Z_LAUNCH_(TT, KS_, false, true, false); else S1Z_LAUNCH_(TT, KS_, false, false, false); } while (0)
+#define S1Z_LAUNCH_(TT, KS_, GB_, GA_, SC_)                                                                                  \
   do {                                                                                                                       \
-    auto kern = lp_s1z_kernel<TT, KS_, GB_, GA_>;                                                                            \
+    auto kern = lp_s1z_kernel<TT, KS_, GB_, GA_, SC_>;                                                                          \
     static bool done = false;                                                                                                \
     if (!done) {                                                                                                             \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
@@ -612,7 +662,7 @@ int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bi
     hipLaunchKernelGGL(kern, dim3(pl.nwg), dim3(512), shmem, stream, p);                                                     \
   } while (0)
   const bool prof = bts_prof_on();
-  if (prof) bts_prof_begin(38, 2.0 * 27.0 * (double)Cin * Cout * (double)N * D * H * W, stream);
+  if (prof) bts_prof_begin(38, 2.0 * (sc ? 28.0 : 27.0) * (double)Cin * Cout * (double)N * D * H * W, stream);
   if (dtype == LP_F16) { if (KS == 2) S1Z_LAUNCH(TF16, 2); else S1Z_LAUNCH(TF16, 1); }
   else { if (KS == 2) S1Z_LAUNCH(TBF16, 2); else S1Z_LAUNCH(TBF16, 1); }
 #undef S1Z_LAUNCH

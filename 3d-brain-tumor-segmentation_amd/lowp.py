@@ -98,6 +98,21 @@ def conv_bwd_data(kind, code, dy, wp_bwd, dx, accumulate):
     return dx
 
 
+def conv_bwd_data_sc(code, dy, wp_bwd, dy2, wp2_bwd, dx, accumulate):
+    """dx (+)= conv3x3x3^T(dy) + conv1x1x1^T(dy2): conv1's and the shortcut's data gradients of a ResnetBlock (resnet.py:80-87,96-103 read
+    the same `inputs`) in one launch where the fused kernels take the shape, else as the two launches; -> True if fused"""
+    n, d, h, w, cin = dx.shape
+    cout = dy.shape[-1]
+    if tuple(dy2.shape) != tuple(dy.shape):
+        raise RuntimeError('conv_bwd_data_sc: dy %s and dy2 %s differ' % (tuple(dy.shape), tuple(dy2.shape)))
+    nb = lib().query('bts_lp_conv3d_bwd_data_sc_workspace', n, d, h, w, cin, cout)
+    ws = ops.workspace(nb, dx.device) if nb > 0 else None
+    fused = ctypes.c_int(0)
+    lib().call('bts_lp_conv3d_bwd_data_sc', code, _p(dy), _p(wp_bwd), _p(dy2), _p(wp2_bwd), _p(dx), _p(ws) if ws is not None else None, nb,
+               n, d, h, w, cin, _ld(dx), cout, _ld(dy), _ld(dy2), 1 if accumulate else 0, ctypes.byref(fused), _stream())
+    return bool(fused.value)
+
+
 def conv(kind, code, tdt, x, wp, bias, cout, out=None):
     n, d, h, w, cin = x.shape
     do, ho, wo = (d, h, w) if kind in (ops.K1, ops.K3S1) else ((d + 1) // 2, (h + 1) // 2, (w + 1) // 2) if kind == ops.K3S2 \

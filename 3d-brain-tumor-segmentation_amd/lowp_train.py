@@ -358,10 +358,14 @@ class LowPrecisionTrainer(object):
             cin = x.shape[-1]
             wpb1 = self._pk((key, 'c1b'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin, dup_start, dup_shift, role=ops.ROLE_BWD)
             wpbp = self._pk((key, 'ptb'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin, dup_start, dup_shift, role=ops.ROLE_BWD)
-            # (the other order where this block is the first writer -- shortcut gradient as a plain write, the matrix-bound 3x3x3 gradient
-            # accumulating -- was measured in round 5: 74.69-74.90 against 74.84-74.97 ms per batch-8 step, inside the noise; not kept)
-            conv_bwd_data(ops.K3S1, code, dc1_16, wpb1, dx, not first)
-            conv_bwd_data(ops.K1, code, dres_16, wpbp, dx, True)
+            # conv1's and the shortcut's data gradients in ONE launch (round 6): the shortcut is an extra K-segment at the centre tap of
+            # conv1's data-gradient kernel -- no second launch that read-modify-writes the Cin-wide dx (bts_lp_conv3d_bwd_data_sc; shapes the
+            # fused kernels decline run as the two launches inside the same call)
+            if dc1_16.shape == dres_16.shape:
+                lowp.conv_bwd_data_sc(code, dc1_16, wpb1, dres_16, wpbp, dx, not first)
+            else:
+                conv_bwd_data(ops.K3S1, code, dc1_16, wpb1, dx, not first)
+                conv_bwd_data(ops.K1, code, dres_16, wpbp, dx, True)
         self._written(blk.trainable_variables)
 
     def _sampler_fwd(self, lay, kind, x, out=None):

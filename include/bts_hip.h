@@ -274,6 +274,17 @@ int bts_lp_conv3d_fwd(int kind, int dtype, const void* x, const void* wp, const 
 long bts_lp_conv3d_bwd_data_workspace(int kind, int N, int D, int H, int W, int Cin, int Cout);
 int bts_lp_conv3d_bwd_data(int kind, int dtype, const void* dy, const void* wp_bwd, void* dx, void* workspace, long workspace_bytes,
                            int N, int D, int H, int W, int Cin, int lddx, int Cout, int lddy, int accum, bts_stream_t stream);
+/* dx (+)= conv3x3x3^T(dy) + conv1x1x1^T(dy2) in ONE launch: the data gradients of the two convolutions that read a ResnetBlock's input
+ * (conv1 resnet.py:80-87 and the shortcut resnet.py:96-103, both applied to `inputs`: resnet.py:118,134) meet in dx under train.py:151.
+ * The shortcut's contraction rides on conv1's as an extra K-segment at the centre tap (1/27 more matrix work) with dy2 read straight
+ * into the matrix instruction -- instead of a second launch that read-modify-writes the Cin-wide dx.  dy / dy2: (N,D,H,W,Cout), voxel
+ * strides lddy / lddy2; wp_bwd / wp2_bwd = bts_lp_pack(K3S1 / K1, BTS_ROLE_BWD_DATA, ...) with the same Cin_slab and fold.  Shapes the
+ * fused kernels do not take run as the two launches (the call always completes); *fused (may be NULL) = 1 if the one-launch form ran.
+ * BTS_LP_SC=0 in the environment: always the two launches (A/B aid) */
+long bts_lp_conv3d_bwd_data_sc_workspace(int N, int D, int H, int W, int Cin, int Cout);
+int bts_lp_conv3d_bwd_data_sc(int dtype, const void* dy, const void* wp_bwd, const void* dy2, const void* wp2_bwd, void* dx, void* workspace,
+                              long workspace_bytes, int N, int D, int H, int W, int Cin, int lddx, int Cout, int lddy, int lddy2, int accum,
+                              int* fused, bts_stream_t stream);
 /* dw (fp32, Keras layout (kd,kh,kw,Cin_ref,Cout)) (+)= the weight gradient of a stride-1 3x3x3 / 1x1x1 conv from 16-bit x and dy
  * (voxel contraction on the 16-bit matrix pipe, fp32 partials, fixed-order finalize); db (may be NULL; dy dense then) (+)= sum dy.
  * dup_start / dup_shift as bts_conv_pack: Cin + dup_shift == Cin_ref, both copies of the folded slice receive the gradient.
