@@ -54,7 +54,8 @@ int bts_lp_up_launch_(int dtype, const void* x, const void* wp_dma, const float*
 long bts_lp_up_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn);
 int bts_lp_s1d_launch_(int dtype, const void* x, const void* wp_dma, const float* bias, void* y, void* ws, long ws_bytes, int N, int D, int H,
                        int W, int Cin, int ldx, int Cout, int ldy, int accum, double* gnp, int gn_G, hipStream_t stream,
-                       const void* x2 = nullptr, const void* wp2 = nullptr, int ldx2 = 0);
+                       const void* x2 = nullptr, const void* wp2 = nullptr, int ldx2 = 0, long ysplit = 0);
+bool bts_lp_s1d_sc_split_ok_(int N, int D, int H, int W, int K, int Ncols);
 
 // =====================================================================================================================
 // weight packing: Keras layout fp32 -> [tap][k-step of 16 cin][cout block of 32][h][32 couts][8 cin] 16-bit
@@ -1285,12 +1286,21 @@ extern "C" int bts_lp_conv3d_bwd_data(int kind, int dtype, const void* dy, const
 // dy, dy2: (N,D,H,W,Cout) with voxel strides lddy / lddy2; wp_bwd / wp2_bwd: bts_lp_pack(K3S1 / K1, BTS_ROLE_BWD_DATA, ...) of the two
 // kernels with the same Cin_slab / fold.  Shapes the fused kernels do not take run as the two launches they replace (same result up to the
 // one extra rounding of the stored intermediate): the call always completes.  *fused (may be NULL): 1 if the one-launch form ran.
+// dx_split (elements; 0 = dx is one (N,D,H,W,Cin) view): columns [32 b, 32 b + 32) of the result go to dx + b * dx_split, each block a
+// tensor of its own with voxel stride lddx -- the gradient of a concat of 32-channel tensors (decoder.py:75) leaves as dense tensors whose
+// readers fetch whole lines.  Only the fused tiled kernel writes that form: ask bts_lp_conv3d_bwd_data_sc_split_ok first.
 extern "C" long bts_lp_conv3d_bwd_data_sc_workspace(int N, int D, int H, int W, int Cin, int Cout) {
   return lp_s1_workspace(N, D, H, W, Cout, Cin);
 }
+extern "C" int bts_lp_conv3d_bwd_data_sc_split_ok(int N, int D, int H, int W, int Cin, int Cout) {
+  static const bool off = [] { const char* e = getenv("BTS_LP_SC"); return e && atoi(e) == 0; }();
+  static const bool off2 = [] { const char* e = getenv("BTS_LP_SC_SPLIT"); return e && atoi(e) == 0; }();      // BTS_LP_SC_SPLIT=0: never (A/B)
+  if (off || off2 || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cout % 16 != 0) return 0;
+  return bts_lp_s1d_sc_split_ok_(N, D, H, W, Cout, Cin) ? 1 : 0;
+}
 extern "C" int bts_lp_conv3d_bwd_data_sc(int dtype, const void* dy, const void* wp_bwd, const void* dy2, const void* wp2_bwd, void* dx,
-                                         void* workspace, long workspace_bytes, int N, int D, int H, int W, int Cin, int lddx, int Cout,
-                                         int lddy, int lddy2, int accum, int* fused, hipStream_t stream) {
+                                         long dx_split, void* workspace, long workspace_bytes, int N, int D, int H, int W, int Cin, int lddx,
+                                         int Cout, int lddy, int lddy2, int accum, int* fused, hipStream_t stream) {
   if (fused) *fused = 0;
   if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return BTS_ERR_SHAPE;
@@ -1298,18 +1308,21 @@ extern "C" int bts_lp_conv3d_bwd_data_sc(int dtype, const void* dy, const void* 
   // (role-swapped: the contraction runs over the forward's Cout, the columns are the forward's Cin)
   const int K = Cout, Nc = Cin;
   static const bool off = [] { const char* e = getenv("BTS_LP_SC"); return e && atoi(e) == 0; }();      // BTS_LP_SC=0: always the two launches (A/B)
-  if (!off && K % 16 == 0 && lddy % 8 == 0 && lddy2 % 8 == 0 && lddy >= K && lddy2 >= K && lddx >= Nc && lddx % 4 == 0 &&
-      !(((uintptr_t)dy) & 15) && !(((uintptr_t)dy2) & 15) && !(((uintptr_t)dx) & 7) && !(((uintptr_t)wp_bwd) & 15) && !(((uintptr_t)wp2_bwd) & 15) &&
+  if (!off && K % 16 == 0 && lddy % 8 == 0 && lddy2 % 8 == 0 && lddy >= K && lddy2 >= K && lddx >= (dx_split ? 32 : Nc) && lddx % 4 == 0 &&
+      !(((uintptr_t)dy) & 15) && !(((uintptr_t)dy2) & 15) && !(((uintptr_t)dx) & 7) && dx_split % 4 == 0 && !(((uintptr_t)wp_bwd) & 15) && !(((uintptr_t)wp2_bwd) & 15) &&
       ((long)(D + 2) * H * W + 64) * (long)lddy * 2 < 0x7fffffffL) {
     const char* dma = reinterpret_cast<const char*>(wp_bwd) + lp_s1d_part_offset(K, Nc);
-    int r = bts_lp_s1z_launch_(dtype, dy, dma, nullptr, dx, N, D, H, W, K, lddy, Nc, lddx, accum, nullptr, 0, stream, nullptr, nullptr, dy2, wp2_bwd, lddy2);
+    int r = 1;
+    if (dx_split == 0)
+      r = bts_lp_s1z_launch_(dtype, dy, dma, nullptr, dx, N, D, H, W, K, lddy, Nc, lddx, accum, nullptr, 0, stream, nullptr, nullptr, dy2, wp2_bwd, lddy2);
     if (r == 1) r = bts_lp_s1d_launch_(dtype, dy, dma, nullptr, dx, workspace, workspace_bytes, N, D, H, W, K, lddy, Nc, lddx, accum, nullptr, 0, stream,
-                                       dy2, wp2_bwd, lddy2);
+                                       dy2, wp2_bwd, lddy2, dx_split);
     if (r != 1) {
       if (r == BTS_OK && fused) *fused = 1;
       return r;
     }
   }
+  if (dx_split != 0) return BTS_ERR_UNSUPPORTED;      // (the two-launch route writes one tensor)
   const int r = lp_conv_run(1, dtype, dy, wp_bwd, nullptr, dx, workspace, workspace_bytes, N, D, H, W, K, lddy, Nc, lddx, accum, stream);
   if (r != BTS_OK) return r;
   return lp_conv_run(0, dtype, dy2, wp2_bwd, nullptr, dx, nullptr, 0, N, D, H, W, K, lddy2, Nc, lddx, 1, stream);

@@ -66,6 +66,11 @@ struct LpS1dParams {
   const unsigned short* x2;
   const unsigned short* wp2;
   int ldx2;
+  // split output (0 = off): the columns of cout block cb go to y + cb * ysplit (elements) as a tensor of its own with voxel stride ldy --
+  // the 64-wide gradient of the decoder's [skip | up-sampled] concat (decoder.py:75) leaves as two DENSE 32-channel tensors, so that its
+  // readers (the skip level's block backward, the up-sampler's GroupNorm backward) do not fetch 64-byte halves of 128-byte lines
+  long ysplit;        // elements between the tensors of consecutive cout blocks (0: one tensor)
+  int ycol;           // columns a cout block advances inside its tensor: 32 (one tensor) | 0 (split)
 };
 
 template <int MODE, int TXL>
@@ -407,21 +412,24 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
                 __builtin_bit_cast(u32x4, f32x4{acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]}), pr, off, 0, 0);
           }
       } else {
-        const __amdgpu_buffer_rsrc_t yr =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long)ci.n * p.D * p.H * p.W * (long)p.ldy), 0, 0x7fffffff, 0x00020000);
+        // (SC kernels: a split output moves the BASE of the wave's cout block -- a run-time scalar offset operand on these loads / stores
+        // made the fp16 variants produce garbage, in the block the compiler already mis-handled once, see below)
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.y + (long)ci.n * p.D * p.H * p.W * (long)p.ldy + (SC ? (long)cb * p.ysplit : 0L)), 0, 0x7fffffff, 0x00020000);
         const bool gn_on = p.gnp != nullptr;
         float gn_s = 0.f, gn_q = 0.f;
         // The matrix instruction leaves a lane (voxel, h) with couts 8q + 4h + {0..3}: four 8-byte pieces of the voxel's 64-byte
         // row.  v_permlane32_swap between the two lanes of a voxel (q even of the upper lane <-> q odd of the lower one) gives each
         // lane EIGHT consecutive couts = one 16-byte store, the pair of lanes 32 contiguous bytes: half the store instructions and
         // half the L2 write requests of the 8-byte form (the 128^3 layers are bound by L2 requests, not bytes).
+        const int cb_col = SC ? cb * p.ycol : cb * 32;
 #pragma unroll
         for (int qp = 0; qp < 2; ++qp) {
           const int co = cb * 32 + 16 * qp + 8 * h;
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             const bool ok = co < p.Cout && oz < p.D && oy + v < p.H && ox < p.W;
-            const unsigned off = (ok && !(BTS_DBG(p) & 1)) ? (unsigned)((((oz * p.H + oy + v) * p.W + ox) * p.ldy + co) * 2) : 0x80000000u;
+            const unsigned off = (ok && !(BTS_DBG(p) & 1)) ? (unsigned)((((oz * p.H + oy + v) * p.W + ox) * p.ldy + cb_col + 16 * qp + 8 * h) * 2) : 0x80000000u;
             float f[4], g2[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) { f[j] = acc[v][8 * qp + j]; g2[j] = acc[v][8 * qp + 4 + j]; }
@@ -601,6 +609,12 @@ long bts_lp_s1d_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn) {
   return (long)(D / Gn) * pl.nty * pl.ntx * pl.ncg * 2;
 }
 
+// does the SC form with a split output take this shape?  (K contraction channels, Ncols output columns)
+bool bts_lp_s1d_sc_split_ok_(int N, int D, int H, int W, int K, int Ncols) {
+  S1dPlan pl;
+  return s1d_plan(N, D, H, W, K, Ncols, pl) && pl.mode == 1 && pl.ksplit == 1 && Ncols % 32 == 0;
+}
+
 template <typename T, int MODE, int TXL, bool SC = false>
 static int s1d_launch_t(const LpS1dParams& p, hipStream_t stream) {
   typedef S1dGeo<MODE, TXL> G;
@@ -624,9 +638,11 @@ static int s1d_launch_t(const LpS1dParams& p, hipStream_t stream) {
 // part of a K1 image with the same K = Cin and N = Cout (64-cout items only: 32-cout items have no registers left for the operand pair)
 int bts_lp_s1d_launch_(int dtype, const void* x, const void* wp_dma, const float* bias, void* y, void* ws, long ws_bytes, int N, int D, int H,
                        int W, int Cin, int ldx, int Cout, int ldy, int accum, double* gnp, int gn_G, hipStream_t stream, const void* x2,
-                       const void* wp2, int ldx2) {
+                       const void* wp2, int ldx2, long ysplit) {
   S1dPlan pl;
   if (!s1d_plan(N, D, H, W, Cin, Cout, pl)) return 1;
+  // split output: whole 32-column blocks, no split-K (its finish writes one tensor), no fused statistics, 32-bit scalar offsets
+  if (ysplit != 0 && (x2 == nullptr || ysplit < 0 || Cout % 32 != 0 || ldy < 32 || pl.ksplit > 1 || gnp != nullptr)) return 1;
   const bool sc = x2 != nullptr;
   if (sc && (pl.mode != 1 || wp2 == nullptr || ldx2 < Cin || ldx2 % 8 != 0 || (((uintptr_t)x2) & 15) || (((uintptr_t)wp2) & 15) ||
              (long)D * H * W * (long)ldx2 * 2 >= 0x7fffff00L))
@@ -656,6 +672,7 @@ int bts_lp_s1d_launch_(int dtype, const void* x, const void* wp_dma, const float
   { const char* e = getenv("BTS_S1D_DBG"); if (e) p.dbg = atoi(e); }
 #endif
   p.x2 = (const unsigned short*)x2; p.wp2 = (const unsigned short*)wp2; p.ldx2 = ldx2;
+  p.ysplit = ysplit; p.ycol = ysplit ? 0 : 32;
   p.gnp = gnp; p.gn_G = gn_G; p.gn_zt = gn_G > 0 ? D / gn_G : 1;
   p.gn_B = gn_G > 0 ? (long)p.gn_zt * pl.nty * pl.ntx * pl.ncg * 2 : 0;
   const bool split_gn = gnp != nullptr && p.ksplit > 1;      // statistics from the split-K finish (dense y, whole 32-cout blocks)

@@ -100,17 +100,32 @@ def conv_bwd_data(kind, code, dy, wp_bwd, dx, accumulate):
 
 def conv_bwd_data_sc(code, dy, wp_bwd, dy2, wp2_bwd, dx, accumulate):
     """dx (+)= conv3x3x3^T(dy) + conv1x1x1^T(dy2): conv1's and the shortcut's data gradients of a ResnetBlock (resnet.py:80-87,96-103 read
-    the same `inputs`) in one launch where the fused kernels take the shape, else as the two launches; -> True if fused"""
-    n, d, h, w, cin = dx.shape
+    the same `inputs`) in one launch where the fused kernels take the shape, else as the two launches; -> True if fused.
+    dx: an (N,D,H,W,Cin) view, or a contiguous (B,N,D,H,W,32) tensor = the Cin = 32 B columns as B dense tensors (the gradient of a concat
+    of 32-channel tensors, decoder.py:75; only where conv_bwd_data_sc_split_ok says so)"""
+    split = 0
+    if dx.dim() == 6:
+        if not dx.is_contiguous() or dx.shape[-1] != 32:
+            raise RuntimeError('conv_bwd_data_sc: a split dx is a contiguous (B,N,D,H,W,32) tensor')
+        nblk, n, d, h, w, _ = dx.shape
+        cin, lddx, split = 32 * nblk, 32, dx.stride(0)
+    else:
+        n, d, h, w, cin = dx.shape
+        lddx = _ld(dx)
     cout = dy.shape[-1]
     if tuple(dy2.shape) != tuple(dy.shape):
         raise RuntimeError('conv_bwd_data_sc: dy %s and dy2 %s differ' % (tuple(dy.shape), tuple(dy2.shape)))
     nb = lib().query('bts_lp_conv3d_bwd_data_sc_workspace', n, d, h, w, cin, cout)
     ws = ops.workspace(nb, dx.device) if nb > 0 else None
     fused = ctypes.c_int(0)
-    lib().call('bts_lp_conv3d_bwd_data_sc', code, _p(dy), _p(wp_bwd), _p(dy2), _p(wp2_bwd), _p(dx), _p(ws) if ws is not None else None, nb,
-               n, d, h, w, cin, _ld(dx), cout, _ld(dy), _ld(dy2), 1 if accumulate else 0, ctypes.byref(fused), _stream())
+    lib().call('bts_lp_conv3d_bwd_data_sc', code, _p(dy), _p(wp_bwd), _p(dy2), _p(wp2_bwd), _p(dx), split, _p(ws) if ws is not None else None,
+               nb, n, d, h, w, cin, lddx, cout, _ld(dy), _ld(dy2), 1 if accumulate else 0, ctypes.byref(fused), _stream())
     return bool(fused.value)
+
+
+def conv_bwd_data_sc_split_ok(n, d, h, w, cin, cout):
+    """does the fused launch write its (cin = 32 B)-column result as B dense 32-channel tensors at this shape?"""
+    return cin % 32 == 0 and cin >= 64 and bool(lib().probe('bts_lp_conv3d_bwd_data_sc_split_ok', n, d, h, w, cin, cout))
 
 
 def conv(kind, code, tdt, x, wp, bias, cout, out=None):

@@ -356,12 +356,17 @@ class LowPrecisionTrainer(object):
             self._wg((x32, dc1, dres), wgrads)
         if dx is not None:
             cin = x.shape[-1]
+            assert dx.shape[-1] == cin or (dx.dim() == 6 and dx.shape[0] * 32 == cin)
             wpb1 = self._pk((key, 'c1b'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin, dup_start, dup_shift, role=ops.ROLE_BWD)
             wpbp = self._pk((key, 'ptb'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin, dup_start, dup_shift, role=ops.ROLE_BWD)
             # conv1's and the shortcut's data gradients in ONE launch (round 6): the shortcut is an extra K-segment at the centre tap of
             # conv1's data-gradient kernel -- no second launch that read-modify-writes the Cin-wide dx (bts_lp_conv3d_bwd_data_sc; shapes the
             # fused kernels decline run as the two launches inside the same call)
-            if dc1_16.shape == dres_16.shape:
+            if dx.dim() == 6:           # the concat's gradient as dense 32-channel tensors (see step(): gsplit)
+                assert first and dc1_16.shape == dres_16.shape
+                if not lowp.conv_bwd_data_sc(code, dc1_16, wpb1, dres_16, wpbp, dx, False):
+                    raise RuntimeError('split data gradient: the fused launch declined a shape its query accepted')
+            elif dc1_16.shape == dres_16.shape:
                 lowp.conv_bwd_data_sc(code, dc1_16, wpb1, dres_16, wpbp, dx, not first)
             else:
                 conv_bwd_data(ops.K3S1, code, dc1_16, wpb1, dx, not first)
@@ -575,8 +580,29 @@ class LowPrecisionTrainer(object):
         # slab gradients: uninitialised -- the first writer of each one writes, every later contribution accumulates.  Levels below the
         # top: the decoder block's conv1 data gradient (its view [0, cres + f) is the whole slab); the top level: the VAE's
         # down-sampling conv's data gradient (its view [0, top_used) is the whole slab, which has no spare channels)
-        gslabs = [torch.empty_like(slab) for slab, _, _, _ in levels]
         assert levels[-1][0].shape[-1] == top_used
+        # Level 0 of the CLI model: the slab is [o_0 (32) | up-sampled (32)] and its gradient has two readers that each want ONE half -- the
+        # encoder block's backward (dout = [0, 32)) and the up-sampler's GroupNorm backward (dy = [32, 64)) -- twice each (reduce + apply
+        # pass): as channel slices of a 64-wide slab they fetch 64-byte halves of 128-byte lines.  Where the fused data-gradient launch can
+        # write its 64 columns as two dense tensors, the gradient "slab" is a (2, N, D, H, W, 32) buffer instead (round 6)
+        gsplit = None
+        if len(levels) > 1 and dsaves:
+            slab0, used0 = levels[0][0], levels[0][1]
+            f0 = dsaves[-1][4]
+            blk0 = dsaves[-1][1]['blk']
+            if used0 == 32 and f0 == 32 and slab0.shape[-1] == 64 and len(levels[0][2]) == 1 and \
+                    lowp.conv_bwd_data_sc_split_ok(n, slab0.shape[1], slab0.shape[2], slab0.shape[3], 64, blk0.filters):
+                gsplit = torch.empty((2,) + tuple(slab0.shape[:4]) + (32,), dtype=tdt, device=dev)
+        gslabs = [None if (i == 0 and gsplit is not None) else torch.empty_like(lv[0]) for i, lv in enumerate(levels)]
+
+        def gview(i, c0, c1):
+            """channels [c0, c1) of level i's slab gradient"""
+            if i == 0 and gsplit is not None:
+                if c0 % 32 == 0 and c1 == c0 + 32:
+                    return gsplit[c0 // 32]
+                assert (c0, c1) == (0, 64)
+                return gsplit
+            return gslabs[i][..., c0:c1]
         # The backward walks vae -> decoder -> encoder level 3 .. 0: the order of the model's flat gradient buffer (model._backward_groups),
         # so that with a process group (SURVEY 8e, C1) finished buckets are all-reduced from inside the backward pass, as the fp32
         # tape does (parallel.GradSync); the regulariser term goes into each bucket just before its exchange
@@ -651,28 +677,26 @@ class LowPrecisionTrainer(object):
         self._written([dec.out_k, dec.out_b])
         for idx in range(len(dsaves) - 1, -1, -1):
             us, bs, li, cres, f = dsaves[idx]
-            gs = gslabs[li]
-            assert gs.shape[-1] == cres + f
-            self._block_bwd(bs, dcur, gs[..., :cres + f], first=True)        # skip part [0, cres) and the up-sampled part [cres, cres + f)
+            assert levels[li][0].shape[-1] == cres + f
+            self._block_bwd(bs, dcur, gview(li, 0, cres + f), first=True)    # skip part [0, cres) and the up-sampled part [cres, cres + f)
             if idx == 0:                                         # the first up layer read the top level's slab view
-                self._sampler_bwd(us, gs[..., cres:cres + f], gslabs[-1][..., :top_used], True)
+                self._sampler_bwd(us, gview(li, cres, cres + f), gslabs[-1][..., :top_used], True)
             else:                                                # the others read the previous decoder block's output
                 dcur = torch.empty(us['x'].shape, dtype=tdt, device=dev)
-                self._sampler_bwd(us, gs[..., cres:cres + f], dcur, False)
+                self._sampler_bwd(us, gview(li, cres, cres + f), dcur, False)
         # encoder backward (encoder.py:69-101 in reverse)
         for i in range(len(levels) - 1, -1, -1):
             slab, used, saves, dsave = levels[i]
-            gs = gslabs[i]
             f = enc.base_filters * 2 ** i
             for j in range(len(saves) - 1, -1, -1):
-                dout = gs[..., j * f:(j + 1) * f]
+                dout = gview(i, j * f, (j + 1) * f)
                 if j > 0:
-                    self._block_bwd(saves[j], dout, gs[..., :j * f])
+                    self._block_bwd(saves[j], dout, gview(i, 0, j * f))
                 elif i > 0:
                     dprev = torch.empty(saves[0]['x'].shape, dtype=tdt, device=dev)
                     self._block_bwd(saves[0], dout, dprev, first=True)
                     pslab, pused, _, pds = levels[i - 1]
-                    self._sampler_bwd(pds, dprev, gslabs[i - 1][..., :pused], True)
+                    self._sampler_bwd(pds, dprev, gview(i - 1, 0, pused), True)
                 else:
                     self._block_bwd(saves[0], dout, None)
         # regulariser (train.py:146), exchange, optimiser (train.py:151-152)

@@ -280,11 +280,16 @@ int bts_lp_conv3d_bwd_data(int kind, int dtype, const void* dy, const void* wp_b
  * into the matrix instruction -- instead of a second launch that read-modify-writes the Cin-wide dx.  dy / dy2: (N,D,H,W,Cout), voxel
  * strides lddy / lddy2; wp_bwd / wp2_bwd = bts_lp_pack(K3S1 / K1, BTS_ROLE_BWD_DATA, ...) with the same Cin_slab and fold.  Shapes the
  * fused kernels do not take run as the two launches (the call always completes); *fused (may be NULL) = 1 if the one-launch form ran.
- * BTS_LP_SC=0 in the environment: always the two launches (A/B aid) */
+ * dx_split (elements; 0 = dx is one (N,D,H,W,Cin) view): columns [32 b, 32 b + 32) go to dx + b * dx_split, every block a tensor of its
+ * own with voxel stride lddx -- the gradient of the decoder's concat of 32-channel tensors (decoder.py:75) leaves as DENSE tensors whose
+ * readers fetch whole 128-byte lines.  Only the fused tiled kernel writes that form: bts_lp_conv3d_bwd_data_sc_split_ok (1 / 0) says
+ * whether it takes the shape; BTS_ERR_UNSUPPORTED otherwise.  BTS_LP_SC=0 in the environment: always the two launches, BTS_LP_SC_SPLIT=0:
+ * _split_ok answers 0 (A/B aids) */
 long bts_lp_conv3d_bwd_data_sc_workspace(int N, int D, int H, int W, int Cin, int Cout);
-int bts_lp_conv3d_bwd_data_sc(int dtype, const void* dy, const void* wp_bwd, const void* dy2, const void* wp2_bwd, void* dx, void* workspace,
-                              long workspace_bytes, int N, int D, int H, int W, int Cin, int lddx, int Cout, int lddy, int lddy2, int accum,
-                              int* fused, bts_stream_t stream);
+int bts_lp_conv3d_bwd_data_sc_split_ok(int N, int D, int H, int W, int Cin, int Cout);
+int bts_lp_conv3d_bwd_data_sc(int dtype, const void* dy, const void* wp_bwd, const void* dy2, const void* wp2_bwd, void* dx, long dx_split,
+                              void* workspace, long workspace_bytes, int N, int D, int H, int W, int Cin, int lddx, int Cout, int lddy,
+                              int lddy2, int accum, int* fused, bts_stream_t stream);
 /* dw (fp32, Keras layout (kd,kh,kw,Cin_ref,Cout)) (+)= the weight gradient of a stride-1 3x3x3 / 1x1x1 conv from 16-bit x and dy
  * (voxel contraction on the 16-bit matrix pipe, fp32 partials, fixed-order finalize); db (may be NULL; dy dense then) (+)= sum dy.
  * dup_start / dup_shift as bts_conv_pack: Cin + dup_shift == Cin_ref, both copies of the folded slice receive the gradient.

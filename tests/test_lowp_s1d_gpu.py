@@ -175,3 +175,27 @@ def test_two_runs_are_bitwise_identical():
     b = lowp.conv(ops.K3S1, code, tdt, x, wp, None, 64)
     torch.cuda.synchronize()
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('shape', [(2, 16, 16, 16, 32, 32), (1, 16, 24, 40, 32, 32), (2, 16, 16, 16, 64, 64), (2, 16, 16, 16, 96, 32)],
+                         ids=lambda c: '%dx%dx%dx%d-%d-%d' % c)
+def test_repeated_launches_are_bitwise_identical(shape, dtype):
+    """every variant, other work in between (round 6: a build whose fp16 32-cout variant stored through a run-time scalar offset returned
+    different garbage on every launch while bf16 and the 64-cout variants were fine -- scripts/s1d_stress.py is the long form)"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    code, tdt = lowp.DTYPES[dtype]
+    n, d, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((n, d, h, w, cin), generator=g).to(tdt).to(DEV)
+    wt = (torch.randn((3, 3, 3, cin, cout), generator=g) * 0.05).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    wp = lowp.pack(ops.K3S1, code, wt, cin, cout)
+    first, syms = _ran_s1d(lambda: lowp.conv(ops.K3S1, code, tdt, x, wp, b, cout).clone())
+    assert 'lp_s1d_kernel' in syms, syms
+    for _ in range(6):
+        torch.randn((1 << 18,), device=DEV).sin_()
+        y = lowp.conv(ops.K3S1, code, tdt, x, wp, b, cout)
+        torch.cuda.synchronize()
+        assert torch.equal(y, first)

@@ -109,6 +109,37 @@ def test_fused_data_gradients(case, dtype):
         assert bool((slab[..., :16] == 3.0).all()) and bool((slab[..., 16 + cin:] == 3.0).all())
 
 
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('shape', [(1, 16, 20, 40, 64, 32), (2, 8, 16, 36, 128, 16)], ids=['2x32', '4x32-ragged'])
+def test_split_output(shape, dtype):
+    """the gradient of a concat of 32-channel tensors (decoder.py:75) written as dense 32-channel tensors, one per column block"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    n, d, h, w, cin, f = shape
+    code, tdt = lowp.DTYPES[dtype]
+    u = U[dtype]
+    g = torch.Generator().manual_seed(77)
+    dy = torch.randn((n, d, h, w, f), generator=g)
+    dy2 = torch.randn((n, d, h, w, f), generator=g)
+    w3 = torch.randn((3, 3, 3, cin, f), generator=g) * (2.0 / (27 * f)) ** 0.5
+    w1 = torch.randn((1, 1, 1, cin, f), generator=g) * (2.0 / f) ** 0.5
+    dyr, dy2r, w3r, w1r = _round(dy, tdt), _round(dy2, tdt), _round(w3, tdt), _round(w1, tdt)
+    g3, g1, gabs = _reference(dyr, dy2r, w3r, w1r, (n, d, h, w, cin))
+    ref = g3 + g1
+    assert lowp.conv_bwd_data_sc_split_ok(n, d, h, w, cin, f)
+    parts = torch.full((cin // 32 + 1, n, d, h, w, 32), 9.0, dtype=tdt, device=DEV)      # (one guard block behind)
+    wpb3 = lowp.pack(ops.K3S1, code, w3.to(DEV), cin, f, role=ops.ROLE_BWD)
+    wpb1 = lowp.pack(ops.K1, code, w1.to(DEV), cin, f, role=ops.ROLE_BWD)
+    fused, syms = _ran(lambda: lowp.conv_bwd_data_sc(code, dy.to(tdt).to(DEV), wpb3, dy2.to(tdt).to(DEV), wpb1, parts[:cin // 32], False))
+    assert fused and 'lp_s1d_kernel' in syms, (fused, syms)
+    got = torch.cat([parts[b].double().cpu() for b in range(cin // 32)], dim=-1)
+    bound = 8 * 2.0 ** -24 * gabs + u * ref.abs() + 1e-30
+    assert float(((got - ref.detach()).abs() / bound).max()) <= 1.0
+    assert bool((parts[cin // 32] == 9.0).all())
+    # shapes the fused tiled kernel does not take say so up front
+    assert not lowp.conv_bwd_data_sc_split_ok(1, 16, 32, 64, 32, 32)
+
+
 def test_folded_duplicate_slice():
     """encoder.py:83-87: block j reads [o_{j-1}, o_0 .. o_{j-1}] through the slab [o_0 .. o_{j-1}] with the duplicated slice folded into the
     weights; in the data-gradient role the fold sits on the COLUMNS (dx's channels) of both images -- the fused launch must add the
