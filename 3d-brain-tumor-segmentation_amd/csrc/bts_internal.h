@@ -32,4 +32,6 @@ int bts_se_bwd_middle_(double* partial, double* red, double* scratch, const floa
 
 // conv_igemm.hip: a kernel is about to read part `bit` (1 implicit-GEMM, 2 F(2x2,3x3) x direct, 4 F(2x2x2,3x3x3)) of the K3S1 weight image
 // that starts at `base`: recorded (re-packs then write the parts in use only), and packed on the spot where the last re-pack left it out
-void bts_img_note_use_(const float* base, unsigned bit, hipStream_t stream);
+int bts_img_note_use_(const float* base, unsigned bit, hipStream_t stream);
+int bts_img_ensure_(const float* base, unsigned bit, hipStream_t stream);
+void bts_img_mark_used_(const float* base, unsigned bit);

@@ -40,7 +40,16 @@ __device__ __forceinline__ double dpp_move_f64(double x) {      // lanes the con
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROWS, 0xf, false);
   return __hiloint2double(hi, lo);
 }
+// PRECONDITION: all 64 lanes of the wave are active (EXEC = ~0) -- DPP leaves 0 where the source lane is inactive and the total is read
+// from lane 63, so a partial wave would return a partial (or zero) sum in silence.  Every caller is wave-uniform (lanes that have nothing
+// to add pass 0); -DBTS_DEBUG_FULL_WAVE turns the contract into a trap.  lane_group_sum_f32 below: whole groups active, likewise.
+__device__ __forceinline__ void bts_assert_full_wave() {
+#ifdef BTS_DEBUG_FULL_WAVE
+  if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap();
+#endif
+}
 __device__ __forceinline__ double wave_sum_f64(double v) {
+  bts_assert_full_wave();
 #ifdef BTS_WAVE_SUM_SHFL      // A/B builds only (make alt NAME=shfl EXTRA=-DBTS_WAVE_SUM_SHFL): the ds_bpermute form
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

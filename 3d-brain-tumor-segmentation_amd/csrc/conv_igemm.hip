@@ -759,41 +759,68 @@ static bool img_masks_enabled() {   // BTS_PACK_USED=0: every pack writes all th
   const char* e = getenv("BTS_PACK_USED");
   return !(e && atoi(e) == 0);
 }
-// (re)register an image; returns the parts a table built now should pack
+// (re)register an image; returns the parts a table built now should describe.  table_mask is what the table LAST RUN on the image
+// wrote (set by bts_conv_pack_batch from the host copy of that table), never what some table merely describes: with two tables for one
+// image, or a cached narrow table behind a bts_conv_pack of the whole image, the parts a batch did NOT write must go stale (round-5
+// advisor finding: a re-registration through bts_conv_pack used to mark all three parts as table-covered).
 static unsigned img_register(const float* wp, int kind, int role, const float* w, int Cin_ref, int Cout, int Cin_slab, int dup_start,
                              int dup_shift, bool all_parts) {
   std::lock_guard<std::mutex> lk(g_img_mu);
   ImgState& e = g_img[wp];
   const bool same = e.w == w && e.kind == kind && e.role == role && e.Cin_ref == Cin_ref && e.Cout == Cout && e.Cin_slab == Cin_slab &&
                     e.dup_start == dup_start && e.dup_shift == dup_shift;
-  if (!same) { e = ImgState{kind, role, Cin_ref, Cout, Cin_slab, dup_start, dup_shift, w, 0u, 7u, 0u}; }
+  if (!same) { e = ImgState{kind, role, Cin_ref, Cout, Cin_slab, dup_start, dup_shift, w, 0u, 0u, 0u}; }      // (another image at this address: nothing is known)
+  if (all_parts) {      // bts_conv_pack writes every part: all fresh until the next batch re-pack over this image
+    e.fresh_extra = 7u;
+    return 7u;
+  }
   unsigned m = 7u;
-  if (!all_parts && kind == BTS_CONV_K3S1 && e.used != 0u && img_masks_enabled()) m = e.used;
-  e.table_mask = m;
-  e.fresh_extra = 0u;
+  if (kind == BTS_CONV_K3S1 && e.used != 0u && img_masks_enabled()) m = e.used;
   return m;
 }
 extern "C" long bts_conv_pack_generation(void) {
   std::lock_guard<std::mutex> lk(g_img_mu);
   return g_img_gen;
 }
+extern "C" int bts_conv_pack_forget(const float* wp) {      // the image's memory is being released: drop its registry entry
+  std::lock_guard<std::mutex> lk(g_img_mu);
+  return g_img.erase(wp) ? 1 : 0;
+}
 __global__ void pack_kernel(const PackParams q);
-// called right before a kernel reads part `bit` of the K3S1 image at `base`
-void bts_img_note_use_(const float* base, unsigned bit, hipStream_t stream) {
+// Called right before a kernel reads part `bit` of the K3S1 image at `base`: packs the part on `stream` from the recorded source when the
+// last re-pack left it out.  The part counts as fresh only after the pack launch was accepted; an error is the caller's to return.
+int bts_img_ensure_(const float* base, unsigned bit, hipStream_t stream) {
   PackParams q;
   {
     std::lock_guard<std::mutex> lk(g_img_mu);
     auto it = g_img.find(base);
-    if (it == g_img.end() || it->second.kind != BTS_CONV_K3S1) return;      // (an image this registry never saw: packed whole by its owner)
-    ImgState& e = it->second;
-    if (!(e.used & bit)) { e.used |= bit; ++g_img_gen; }
-    if ((e.table_mask | e.fresh_extra) & bit) return;
-    e.fresh_extra |= bit;
-    if (pack_params(q, e.kind, e.role, e.w, const_cast<float*>(base), e.Cin_ref, e.Cout, e.Cin_slab, e.dup_start, e.dup_shift, bit) != BTS_OK) return;
+    if (it == g_img.end() || it->second.kind != BTS_CONV_K3S1) return BTS_OK;      // (an image this registry never saw: packed whole by its owner)
+    const ImgState& e = it->second;
+    if ((e.table_mask | e.fresh_extra) & bit) return BTS_OK;
+    const int r = pack_params(q, e.kind, e.role, e.w, const_cast<float*>(base), e.Cin_ref, e.Cout, e.Cin_slab, e.dup_start, e.dup_shift, bit);
+    if (r != BTS_OK) return r;
   }
   long blocks = (q.items + 255) / 256;
   if (blocks > 4096) blocks = 4096;
+  (void)hipGetLastError();
   hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, q);
+  BTS_LAUNCH_CHECK();
+  std::lock_guard<std::mutex> lk(g_img_mu);
+  auto it = g_img.find(base);
+  if (it != g_img.end()) it->second.fresh_extra |= bit;
+  return BTS_OK;
+}
+// a launcher has ACCEPTED a launch that reads part `bit`: descriptor tables built from now on describe it (generation moves once per new form)
+void bts_img_mark_used_(const float* base, unsigned bit) {
+  std::lock_guard<std::mutex> lk(g_img_mu);
+  auto it = g_img.find(base);
+  if (it == g_img.end() || it->second.kind != BTS_CONV_K3S1) return;
+  if (!(it->second.used & bit)) { it->second.used |= bit; ++g_img_gen; }
+}
+int bts_img_note_use_(const float* base, unsigned bit, hipStream_t stream) {      // both, for launchers that have already accepted
+  const int r = bts_img_ensure_(base, bit, stream);
+  if (r == BTS_OK) bts_img_mark_used_(base, bit);
+  return r;
 }
 
 extern "C" int bts_conv_pack(int kind, int role, const float* w, float* wp, int Cin_ref, int Cout, int Cin_slab,
@@ -828,12 +855,26 @@ extern "C" long bts_conv_pack_desc(void* host_table, int index, long first_block
   return (d.total + PACK_BLOCK_ELEMS - 1) / PACK_BLOCK_ELEMS;
 }
 
-// table_dev: the host table copied to device memory by the caller; total_blocks = sum of all block counts
-extern "C" int bts_conv_pack_batch(const void* table_dev, int n, long total_blocks, hipStream_t stream) {
+// table_dev: the host table copied to device memory by the caller; table_host: that host table (still readable; may be NULL);
+// total_blocks = sum of all block counts.  A batch pack follows a weight change: for every image IN THE TABLE the parts this table
+// writes are fresh afterwards and every other part is stale (packed on demand at its next use).  Without the host copy the library cannot
+// know which images / parts the table covers: every registered image then counts as stale in every part (correct, but each K3S1 launch
+// re-packs its part once per weight change).
+extern "C" int bts_conv_pack_batch(const void* table_dev, const void* table_host, int n, long total_blocks, hipStream_t stream) {
   if (n <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffL) return BTS_ERR_SHAPE;
-  {   // a batch pack follows a weight change: parts packed on demand since the last one are stale again
+  {
     std::lock_guard<std::mutex> lk(g_img_mu);
-    for (auto& kv : g_img) kv.second.fresh_extra = 0u;
+    if (table_host != nullptr) {
+      const PackDesc* t = reinterpret_cast<const PackDesc*>(table_host);
+      for (int i = 0; i < n; ++i) {
+        auto it = g_img.find(t[i].q.wp);
+        if (it == g_img.end()) continue;
+        it->second.table_mask = (it->second.kind == BTS_CONV_K3S1) ? (t[i].q.parts & 7u) : 7u;
+        it->second.fresh_extra = 0u;
+      }
+    } else {
+      for (auto& kv : g_img) { kv.second.table_mask = 0u; kv.second.fresh_extra = 0u; }
+    }
   }
   (void)hipGetLastError(); hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream,
                      reinterpret_cast<const PackDesc*>(table_dev), n);
@@ -1620,14 +1661,14 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
                         const float* x2 = nullptr, int ldx2 = 0) {
   if (gn_B) *gn_B = 0;  // stays 0 unless the tiled kernel took the launch and emitted the GroupNorm partials
   if (geo == GEO_S1 && wp2 == nullptr && need_out == nullptr && Cout <= 4) {
-    bts_img_note_use_(wp, 1u, stream);
+    { const int e = bts_img_ensure_(wp, 1u, stream); if (e != BTS_OK) return e; }      // (a declined launch costs at most one early pack)
     const int r = launch_dsc(x, wp, bias, y, N, Di, Hi, Wi, Cin, ldx, Cout, ldy, flags, stream);
-    if (r != 1) return r;
+    if (r != 1) { bts_img_mark_used_(wp, 1u); return r; }
   }
   if (geo == GEO_S1 && need_out == nullptr && Cin == 2 && x2 == nullptr && (wp2 == nullptr) == (y2 == nullptr)) {
-    bts_img_note_use_(wp, 1u, stream);
+    { const int e = bts_img_ensure_(wp, 1u, stream); if (e != BTS_OK) return e; }
     const int r = launch_c2(x, wp, bias, y, N, Di, Hi, Wi, Cin, ldx, Cout, ldy, flags, wp2, bias2, y2, ldy2, gnp, gnG, gn_B, stream);
-    if (r != 1) return r;
+    if (r != 1) { bts_img_mark_used_(wp, 1u); return r; }
   }
   if (geo == GEO_S1 && need_out == nullptr && !(flags & IG_FLAG_SIGMOID)) {
     // Winograd form (conv_wino.hip) on the second part of the K3S1 image; the fused shortcut output / second input of the
@@ -1667,7 +1708,10 @@ static int launch_igemm(int geo, const float* x, const float* wp, const float* b
       if (r != 1) return r;
     }
   }
-  if (geo == GEO_S1 && need_out == nullptr) bts_img_note_use_(wp, 1u, stream);      // the implicit-GEMM form reads the first part
+  if (geo == GEO_S1 && need_out == nullptr) {      // the implicit-GEMM form reads the first part
+    const int e = bts_img_note_use_(wp, 1u, stream);
+    if (e != BTS_OK) return e;
+  }
   IgemmParams p;
   p.wp2 = wp2; p.bias2 = bias2; p.y2 = y2; p.ldy2 = ldy2;
   p.x2 = x2; p.ldx2 = ldx2;   // second input (x2 + wp2 without y2): see IgemmParams

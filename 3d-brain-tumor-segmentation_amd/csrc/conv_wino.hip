@@ -518,7 +518,7 @@ static int wino_launch_cfg(const WinoParams& p, const WinoPlan& q, double flops,
     attr_done = true;
   }
   // (p.up = image base + 27 x the padded (cin, cout) pairs: conv_igemm.hip's image layout; p.KG = Cin / 8, q.nb = cout blocks of 32)
-  bts_img_note_use_(p.up - 27L * ((long)p.KG * 2 * (q.nb * 32) * 4), 2u, stream);
+  { const int e = bts_img_note_use_(p.up - 27L * ((long)p.KG * 2 * (q.nb * 32) * 4), 2u, stream); if (e != BTS_OK) return e; }
   const bool prof = bts_prof_on();
   if (prof) bts_prof_begin(23, flops, stream);
   (void)hipGetLastError();

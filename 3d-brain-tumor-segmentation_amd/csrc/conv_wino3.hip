@@ -544,7 +544,7 @@ int bts_w3_launch_(const float* x, const float* up3, const float* bias, float* y
     attr_done = true;
   }
   // (up3 = image base + (27 + 48) x the padded (cin, cout) pairs: conv_igemm.hip's image layout)
-  bts_img_note_use_(up3 - 75L * ((long)((Cin + 7) / 8) * 2 * (((Cout + 31) / 32) * 32) * 4), 4u, stream);
+  { const int e = bts_img_note_use_(up3 - 75L * ((long)((Cin + 7) / 8) * 2 * (((Cout + 31) / 32) * 32) * 4), 4u, stream); if (e != BTS_OK) return e; }
   const double flops = 2.0 * 27 * Cin * Cout * (double)N * D * H * W;
   const bool prof = bts_prof_on();
   if (prof) bts_prof_begin(27, flops, stream);

@@ -624,11 +624,17 @@ int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bi
     return 1;
   if (Cin == 64) {      // two 32-channel passes (see s1z_plan): channels [0, 32) write (or accumulate, as asked), [32, 64) accumulate and count
     if (gb != nullptr || ga != nullptr) return 1;
+    // everything either pass checks, BEFORE the first one touches y: a decline after pass 1 would leave a half-summed output behind (and
+    // the caller's fallback would add the first half twice when accumulating)
+    if ((((uintptr_t)x) & 15) || (((uintptr_t)y) & 15) || (((uintptr_t)wp) & 15)) return 1;      // (x + 32 channels = + 64 bytes, wp + 54 KB: aligned with them)
+    if (gn_part != nullptr && (gn_G <= 0 || D % gn_G != 0)) return 1;
     const int r = bts_lp_s1z_launch_(dtype, x, wp, bias, y, N, D, H, W, 32, ldx, Cout, ldy, accum, nullptr, 0, stream, nullptr, nullptr, nullptr, nullptr, 0);
     if (r != BTS_OK) return r;
-    // (image: [k-step][dz][tap][k-half][32 couts][8 cin], 27 KB per k-step: the second half starts two k-steps in)
-    return bts_lp_s1z_launch_(dtype, reinterpret_cast<const unsigned short*>(x) + 32, reinterpret_cast<const char*>(wp) + 2 * 27 * 1024, nullptr, y,
-                              N, D, H, W, 32, ldx, Cout, ldy, 1, gn_part, gn_G, stream, nullptr, nullptr, nullptr, nullptr, 0);
+    // (image: [k-step][dz][tap][k-half][32 couts][8 cin], 27 KB per k-step: the second half starts two k-steps in.  The first half's sum
+    // passes through the storage type once before the second is added: one extra rounding, carried by the test bounds)
+    const int r2 = bts_lp_s1z_launch_(dtype, reinterpret_cast<const unsigned short*>(x) + 32, reinterpret_cast<const char*>(wp) + 2 * 27 * 1024, nullptr, y,
+                                      N, D, H, W, 32, ldx, Cout, ldy, 1, gn_part, gn_G, stream, nullptr, nullptr, nullptr, nullptr, 0);
+    return r2 == 1 ? BTS_ERR_UNSUPPORTED : r2;      // (y has been written: "declined" is no longer an answer)
   }
   if (ga != nullptr && (gb != nullptr || !bts_lp_s1z_gna_ok_(N, D, H, W, Cin, ldx, Cout, ldy, ga->G) || ga->cg != Cin / ga->G)) return 1;
   if ((((uintptr_t)x) & 15) || (((uintptr_t)y) & 15) || (((uintptr_t)wp) & 15)) return 1;

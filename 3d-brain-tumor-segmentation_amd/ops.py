@@ -6,6 +6,7 @@ Activations are [N,D,H,W,C] fp32 tensors whose last-dim stride is 1 and whose vo
 (channel slices of a slab).
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -248,9 +249,22 @@ def conv_pack(kind, role, w, cin_ref, cout, cin_slab=None, dup_start=0, dup_shif
     cin_slab = cin_ref if cin_slab is None else cin_slab
     n = lib().query('bts_conv_packed_floats', kind, role, cin_slab, cout)
     wp = torch.empty(n, dtype=torch.float32, device=w.device)
-    lib().call('bts_conv_pack', kind, role, _p(w.contiguous()), _p(wp), cin_ref, cout, cin_slab, dup_start, dup_shift,
+    wc = w.contiguous()
+    lib().call('bts_conv_pack', kind, role, _p(wc), _p(wp), cin_ref, cout, cin_slab, dup_start, dup_shift,
                _stream())
+    if wc is not w:      # packed from a temporary copy: the library must not re-pack a form on demand from that address later
+        lib()._bts_conv_pack_forget(_p(wp))
+    else:                # the library keys its record of the image by address: drop it with the tensor
+        fin = weakref.finalize(wp, _forget_image, wp.data_ptr())
+        fin.atexit = False
     return wp
+
+
+def _forget_image(ptr):
+    try:
+        lib()._bts_conv_pack_forget(ctypes.c_void_p(ptr))
+    except Exception:      # (interpreter shutdown)
+        pass
 
 
 class PackTable(object):
@@ -261,6 +275,7 @@ class PackTable(object):
     def __init__(self):
         self.key = None
         self.dev = None
+        self.host = None
         self.n = 0
         self.blocks = 0
 
@@ -287,8 +302,9 @@ class PackTable(object):
                 first += r
             dev = entries[0][3].device
             self.dev = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
+            self.host = host      # (kept: the library reads each entry's forms from the host copy of the table it is asked to run)
             self.key, self.n, self.blocks = key, len(entries), first
-        lib().call('bts_conv_pack_batch', _p(self.dev), self.n, self.blocks, _stream())
+        lib().call('bts_conv_pack_batch', _p(self.dev), ctypes.cast(self.host, ctypes.c_void_p), self.n, self.blocks, _stream())
 
 
 def conv_packed_empty(kind, role, cin_slab, cout, device):

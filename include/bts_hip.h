@@ -52,17 +52,23 @@ int bts_conv_pack(int kind, int role, const float* w, float* wp, int Cin_ref, in
 /* All weight images in one launch (every image goes stale together at the optimiser step, train.py:152): the caller
  * fills a HOST table of bts_conv_pack_desc_bytes()-sized descriptors with bts_conv_pack_desc (arguments as bts_conv_pack;
  * returns the entry's block count > 0, or a negative engine code; first_block = running sum of those counts), copies it
- * to device memory and passes it with the total block count. */
+ * to device memory and passes both copies with the total block count (table_host may be NULL: see below). */
 long bts_conv_pack_desc_bytes(void);
 long bts_conv_pack_desc(void* host_table, int index, long first_block, int kind, int role, const float* w, float* wp,
                         int Cin_ref, int Cout, int Cin_slab, int dup_start, int dup_shift);
-int bts_conv_pack_batch(const void* table_dev, int n, long total_blocks, bts_stream_t stream);
+int bts_conv_pack_batch(const void* table_dev, const void* table_host, int n, long total_blocks, bts_stream_t stream);
 /* A BTS_CONV_K3S1 image holds three forms of the same weights (implicit GEMM, F(2x2,3x3) x direct, F(2x2x2,3x3x3)); a layer reads the one
  * its geometry selects.  The library records which forms each image has been read in and bts_conv_pack_desc describes those only (all
  * three for an image never read); a form a launch selects although the last re-pack left it out is packed on the spot on the launch's
  * stream.  The counter below grows whenever an image is read in a form it had not been read in before: a host table built at an older
- * value should be rebuilt at the next re-pack (it stays CORRECT either way). */
+ * value should be rebuilt at the next re-pack (it stays CORRECT either way).  What counts as written is what the table actually RUN
+ * wrote: bts_conv_pack_batch reads the forms of each entry from table_host (the host copy the device table was made from), so several
+ * tables over one image, or a bts_conv_pack of the whole image between two runs of a narrower cached table, cannot leave a stale form
+ * marked fresh.  table_host == NULL: the library cannot tell what the table covers and treats every form of every registered image as
+ * stale (correct; each launch then re-packs its form once per weight change).  bts_conv_pack_forget drops the record of an image whose
+ * memory is being released (returns 1 if there was one). */
 long bts_conv_pack_generation(void);
+int bts_conv_pack_forget(const float* wp);
 /* y = act(conv(x) + bias). x (N,D,H,W,Cin) stride ldx; y (N,D',H',W',Cout) stride ldy; D' = D | D/2 | 2D. */
 /* workspace (may be NULL / 0) lets grids too small to fill the chip split the contraction over workgroups (deterministic
  * two-stage reduction); size from bts_conv3d_fwd_workspace (0 when the shape does not need it). */

@@ -47,6 +47,14 @@ def main():
         parallel.init_from_env(backend)
         assert parallel.world() == world and parallel.rank() == rank
         assert torch.distributed.get_backend() == backend
+        # bring-up ends HERE: one collective on a device buffer forces the backend to connect the ranks (RCCL connects lazily).  The marker
+        # tells the test which side of that line a failure fell on: before it the box could not connect its devices (skip), after it any
+        # failure is the product's (fail)
+        probe = torch.ones(8, device=dev)
+        torch.distributed.all_reduce(probe)
+        torch.cuda.synchronize()
+        assert float(probe[0]) == world
+        open(out + '.pg_ready', 'w').write('ok')
     latent = KW['base_filters'] * 2 ** (KW['depth'] - 2)
     x, y, mask, eps = synthetic_batch(GLOBAL_BATCH, CROP, latent=latent, seed=77)
     sl = slice(0, GLOBAL_BATCH) if world == 0 else slice(rank, GLOBAL_BATCH, world)
