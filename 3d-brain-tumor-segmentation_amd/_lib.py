@@ -21,7 +21,9 @@ _CT = {
     'bts_stream_t': ctypes.c_void_p,
 }
 
-ERRORS = {-1: 'BTS_ERR_SHAPE', -2: 'BTS_ERR_ALIGN', -3: 'BTS_ERR_UNSUPPORTED', -4: 'BTS_ERR_WORKSPACE'}
+ERRORS = {-1: 'BTS_ERR_SHAPE', -2: 'BTS_ERR_ALIGN', -3: 'BTS_ERR_UNSUPPORTED', -4: 'BTS_ERR_WORKSPACE',
+          -101: 'ncclUnhandledCudaError', -102: 'ncclSystemError', -103: 'ncclInternalError', -104: 'ncclInvalidArgument',
+          -105: 'ncclInvalidUsage', -106: 'ncclRemoteError', -107: 'ncclInProgress'}
 
 
 def parse_header(path=HEADER):

@@ -250,24 +250,29 @@ def oracle_agreement(first, cpu, agreement_dir):
     lab_o, yp_o = z['labels'], z['y_pred']
     lab = first['labels'].reshape(lab_o.shape)
     top2 = np.sort(yp_o, axis=-1)[..., -2:]
-    near = (np.abs(top2[..., 1] - 0.5) < 1e-4) | (np.abs(top2[..., 1] - top2[..., 0]) < 1e-4)     # (the band the y_pred tolerance implies)
+    # pointwise criterion (tests/test_oracle_fullsize_gpu.py::_label_check): a label may differ only where the oracle's own margin (|p_max -
+    # 0.5| or the top-2 gap) is at most twice the engine's |y_pred - oracle| at THAT voxel; and no more voxels than the 1e-5 band holds
+    margin = np.minimum(np.abs(top2[..., 1] - 0.5), np.abs(top2[..., 1] - top2[..., 0]))
+    dvox = np.abs(first['y_pred'].reshape(yp_o.shape) - yp_o).max(axis=-1)
+    near = margin <= 2.0 * dvox
+    band5 = int((margin < 1e-5).sum())
     differ = lab != lab_o
     dpar = 0.0
     for name, arr in first['params'].items():
         dpar = max(dpar, float(np.abs(arr.reshape(-1) - z['P/' + name].reshape(-1)).max()))
     return {'dloss_rel': abs(first['loss'] - cpu['loss']) / max(1.0, abs(cpu['loss'])),
             'ddice_macro': abs(first['macro'] - cpu['macro_dice']), 'ddice_micro': abs(first['micro'] - cpu['micro_dice']),
-            'label_mismatch': int(differ.sum()), 'label_mismatch_outside_near_ties': int((differ & ~near).sum()),
-            'near_tie_voxels': int(near.sum()), 'voxels': int(lab_o.size),
+            'label_mismatch': int(differ.sum()), 'label_mismatch_outside_pointwise_criterion': int((differ & ~near).sum()),
+            'voxels_inside_1e-5_band': band5, 'voxels': int(lab_o.size),
             'y_pred_max_abs_diff': float(np.abs(first['y_pred'].reshape(yp_o.shape) - yp_o).max()),
             'max_param_diff_after_adam': dpar,
             'engine': {'loss': first['loss'], 'macro_dice': first['macro'], 'micro_dice': first['micro']},
             'oracle': {'loss': cpu['loss'], 'macro_dice': cpu['macro_dice'], 'micro_dice': cpu['micro_dice']},
             'within_north_star': bool(abs(first['macro'] - cpu['macro_dice']) <= 1e-4 and abs(first['micro'] - cpu['micro_dice']) <= 1e-4
-                                      and int((differ & ~near).sum()) == 0),
+                                      and int((differ & ~near).sum()) == 0 and int(differ.sum()) <= band5),
             'what': 'first train step of this run (initial weights, seed-1234 volume, injected dropout mask / eps) vs oracle/torch_ref.py '
-                    'in fp32 from the same weights and draws (the cpu_baseline child); tolerance |dDice| <= 1e-4, label map identical '
-                    'outside near-ties (|p-0.5| or top-2 gap < 1e-4, the y_pred tolerance)'}
+                    'in fp32 from the same weights and draws (the cpu_baseline child); tolerance |dDice| <= 1e-4; a label may differ only where '
+                    'the oracle margin (|p-0.5| or top-2 gap) <= 2 |dp| at that voxel, and at no more voxels than the 1e-5 band holds'}
 
 
 def active_overrides():
@@ -746,7 +751,7 @@ def main():
     ap.add_argument('--cpu-baseline-crop', type=int, default=128)
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--no-also', action='store_true',
-                    help='headline only: skip the BASELINE configs[2] / configs[4] measurements nested under "also"')
+                    help='headline only: skip the BASELINE configs[2] / configs[4] (N = 1) or configs[3] (N > 1) measurements nested under "also"')
     ap.add_argument('--serial-streams', action='store_true',
                     help='one HIP stream for the whole step (the per-kernel rocprofv3 capture that backs `roofline` is taken this way)')
     ap.add_argument('--infer', action='store_true', help='BASELINE configs[4]: full-volume inference (VAE off) instead of the train step')
@@ -822,6 +827,23 @@ def main():
             except Exception as e:   # the headline stands on its own; a failure here is reported, not hidden
                 also['error'] = '%s: %s' % (type(e).__name__, str(e)[:300])
             out['also'] = also
+        if world > 1 and args.dtype in (None, 'f32', 'fp32', 'float32') and args.batch == 1 and not args.no_also:
+            # N > 1 (the driver's scaling run: `bench.py --gpus N` with its default arguments): after the fp32 weak-scaling headline, whose
+            # N = 1 value is the single-GPU line, BASELINE configs[3] itself -- configs[2]'s step (bf16 storage, batch 8 per GPU) on every
+            # rank with the gradient buckets all-reduced from inside the backward -- nested under "also" with its own `ranks_seen`,
+            # `exchange` (per-bucket all-reduce alone, exposed wait) and `step_rooflines`.  EVERY rank runs it (collectives); rank 0 reports.
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            also = {}
+            try:
+                r3 = measure_train(args, world, rank, dev, overrides, dtype='bf16', batch=8, steps=10, warmup=5, shared=shared)
+                if r3 is not None:
+                    also['configs[3]'] = r3
+            except Exception as e:      # (a rank that fails here leaves the others in a collective: the launcher's timeout ends the run)
+                also['error'] = '%s: %s' % (type(e).__name__, str(e)[:300])
+            if out is not None:
+                out['also'] = also
         if world == 1 and not args.no_cpu_baseline and out is not None:
             out['cpu_baseline'] = cpu_baseline(args.cpu_baseline_crop, agreement_dir=agreement_dir)
             if agreement_dir:
@@ -843,7 +865,7 @@ def main():
                 summary[k] = tri(v)
         if 'oracle_agreement' in out and out['oracle_agreement'] and 'ddice_macro' in out['oracle_agreement']:
             oa = out['oracle_agreement']
-            summary['oracle_agreement'] = {k: oa[k] for k in ('dloss_rel', 'ddice_macro', 'ddice_micro', 'label_mismatch_outside_near_ties')}
+            summary['oracle_agreement'] = {k: oa[k] for k in ('dloss_rel', 'ddice_macro', 'ddice_micro', 'label_mismatch_outside_pointwise_criterion')}
         full = dict(out)
         full['summary'] = summary
         detail = None
@@ -860,10 +882,11 @@ def main():
             line = _compact(out, 8)
             if 'also' in out:
                 line['also'] = {k: (_compact(v, 5) if isinstance(v, dict) else v) for k, v in out['also'].items()}
-                for v in line['also'].values():     # (the nested results repeat the contract boiler-plate: keep what differs)
+                for name, v in line['also'].items():     # (the nested results repeat the contract boiler-plate: keep what differs)
                     if isinstance(v, dict):
                         for k in ('unit', 'n_gpus', 'ranks_seen', 'higher_is_better', 'scaling', 'vs_baseline', 'data', 'streams'):
-                            v.pop(k, None)
+                            if not (name == 'configs[3]' and k in ('n_gpus', 'ranks_seen', 'scaling')):
+                                v.pop(k, None)
                         for k in ('measured', 'traffic_source', 'clock_ghz_in_capture', 'algorithmic_gflop_per_launch', 'achieved_algorithmic',
                                   'frac_algorithmic'):
                             (v.get('roofline') or {}).pop(k, None)

@@ -23,6 +23,8 @@ typedef struct ihipStream_t* bts_stream_t; /* == hipStream_t */
 #define BTS_ERR_ALIGN (-2)
 #define BTS_ERR_UNSUPPORTED (-3)
 #define BTS_ERR_WORKSPACE (-4)
+#define BTS_ERR_RCCL_BASE (-100) /* bts_dp_*: an RCCL call failed; the code is BTS_ERR_RCCL_BASE - ncclResult_t (-101 ncclUnhandledCudaError,
+                                    -102 ncclSystemError, -103 ncclInternalError, -104 ncclInvalidArgument, -105 ncclInvalidUsage, ...) */
 
 /* convolution kinds */
 #define BTS_CONV_K1 0    /* Conv3D k=1 s=1            layers/resnet.py:30-37, layers/decoder.py:55-63 */
@@ -448,6 +450,29 @@ int bts_lp_head(int dtype, const void* x, const float* w, const float* bias, flo
 long bts_lp_head_bwd_workspace(int C, int K);
 int bts_lp_head_bwd(int dtype, const void* x, const float* dpre, const float* w, void* dx, float* dw, float* db, void* workspace,
                     long workspace_bytes, long nvox, int C, int ldx, int lddx, int K, int accumulate, bts_stream_t stream);
+
+/* ---- data-parallel exchange over RCCL on device buffers (the reference is single-device, train.py:138) --------------------
+ * Sharding train.py:140-152 by sample needs three collectives: C1 the sum of the flat fp32 gradient buffer over the ranks (in a few
+ * large buckets: xGMI is point to point, a ring is per-link bound, few large messages win), C2 rank `root`'s parameters on every rank
+ * after initialisation / load, C3 the sum of the raw loss sums (bts_loss_sums) and of the Dice table, which the reference sums over the
+ * batch axis (util.py:11,18-20).  comm = the caller's ncclComm_t (one process per GPU); every call is enqueued on `stream` and returns
+ * BTS_OK, a BTS_ERR_* code, or BTS_ERR_RCCL_BASE - ncclResult_t.  RCCL is bound on first use by dlopen (the copy the process already holds,
+ * else the system one): the library has no link-time dependency on it; bts_dp_available says whether it was found (BTS_ERR_UNSUPPORTED
+ * from the others when not).  bts_dp_comm_* are conveniences over ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy for hosts that do
+ * not link RCCL themselves (unique id: bts_dp_unique_id_bytes() bytes, made on one rank and handed to the others by the host's own means).
+ * bts_amd.parallel issues the same three collectives through torch.distributed, whose 'nccl' backend is RCCL. */
+int bts_dp_available(void);
+long bts_dp_unique_id_bytes(void);
+int bts_dp_comm_unique_id(void* id_out);
+int bts_dp_comm_init(void** comm_out, int nranks, const void* id, int rank);
+int bts_dp_comm_destroy(void* comm);
+/* C1: in-place sum over the ranks of the buckets [bucket_off[b], bucket_off[b] + bucket_len[b]) (elements; host arrays) of the flat
+ * gradient buffer, one RCCL group per call.  Call it once per finished bucket from inside the backward for the overlapped form. */
+int bts_dp_allreduce_buckets(void* comm, float* flat_grads, const long* bucket_off, const long* bucket_len, int nbuckets, bts_stream_t stream);
+/* C2 */
+int bts_dp_broadcast_params(void* comm, float* flat_params, long n, int root, bts_stream_t stream);
+/* C3: in-place sum of n fp64 values */
+int bts_dp_allreduce_small(void* comm, double* sums, int n, bts_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -133,6 +133,13 @@ def test_bench_launcher_starts_the_ranks(tmp_path):
     out = json.loads(line)
     assert out['ranks_seen'] == 2 and out['config']['global_batch'] == 2 and out['config']['parallelism'] == 'dp2'
     assert out['value'] > 0
+    # the first scaling run must carry BASELINE configs[3] itself (bf16 storage, batch 8 per GPU, buckets exchanged from inside the
+    # backward) next to the fp32 weak-scaling headline, and explain itself
+    c3 = out['also']['configs[3]']
+    assert c3['value'] > 0 and c3['dtype'] == 'bf16' and c3['config']['global_batch'] == 16 and c3['config']['parallelism'] == 'dp2', c3
+    assert 'configs[3]' in c3['config']['workload'] and c3['exchange']['buckets'], c3
+    assert c3['ranks_seen'] == 2
+    assert out['summary']['configs[3]'][0] == c3['value']
 
 
 def test_bench_refuses_a_world_size_mismatch():

@@ -90,11 +90,27 @@ def train_case():
                 macro=float(macro), micro=float(micro), labels=labels)
 
 
-def _ambiguous(yp, width=1e-4):
-    """voxels whose label the stated y_pred tolerance (1e-4) cannot pin: winning probability within `width` of the 0.5 threshold, or
-    the top two classes within `width` of each other (util.py:36-44: argmax, then the > 0.5 cut)"""
+def _margin(yp):
+    """the oracle's own decision margin per voxel (util.py:36-44: argmax, then the > 0.5 cut): distance of the winning probability from
+    0.5, or of the two largest probabilities from each other, whichever is smaller"""
     top2 = yp.topk(2, dim=-1).values
-    return ((yp.max(dim=-1).values - 0.5).abs() < width) | ((top2[..., 0] - top2[..., 1]).abs() < width)
+    return torch.minimum((top2[..., 0] - 0.5).abs(), (top2[..., 0] - top2[..., 1]).abs())
+
+
+def _label_check(differ, y_engine, yp, what):
+    """The POINTWISE label-map criterion (round-5 review, weak 1(i)): a voxel's label may differ from the oracle's only where the oracle's
+    own margin there is at most twice the engine's |y_pred - oracle| AT THAT VOXEL (an argmax flip needs the top-2 gap <= |d_i| + |d_j|,
+    a threshold flip |p - 0.5| <= |d|), and no more voxels may differ than sit inside the 1e-5 band of SURVEY 8c.  -> (differing, outside
+    the pointwise criterion, voxels inside the 1e-5 band)"""
+    d = (y_engine.detach().double().cpu() - yp).abs().max(dim=-1).values
+    margin = _margin(yp)
+    outside = differ & (margin > 2.0 * d)
+    n_diff, n_out, n_band5 = int(differ.sum()), int(outside.sum()), int((margin < 1e-5).sum())
+    worst = float(margin[differ].max()) if n_diff else 0.0
+    print('%s: %d of %d labels differ from the oracle\'s; %d of them outside the pointwise criterion (margin <= 2 |dp| at the voxel); largest '
+          'oracle margin among them %.2e; voxels inside the 1e-5 band %d, inside a 1e-4 band %d' %
+          (what, n_diff, differ.numel(), n_out, worst, n_band5, int((margin < 1e-4).sum())))
+    return n_diff, n_out, n_band5
 
 
 def _maxerr(a, b):
@@ -136,16 +152,12 @@ def test_fp32_train_step_at_128_against_the_fp64_oracle(train_case):
     assert ev <= 1e-4 * max(1.0, float(yv_r.abs().max())), 'y_vae err %.3e' % ev
     assert _maxerr(z_mean.t, zm_r) <= 1e-4 and _maxerr(z_logvar.t, zl_r) <= 1e-4
     assert abs(float(loss) - c['loss']) <= 1e-5 * max(1.0, abs(c['loss'])), (float(loss), c['loss'])
-    # label map: identical wherever the oracle's own margin exceeds the y_pred tolerance; the voxels that differ are counted (an
-    # untrained net with randomised affines puts ~4 % of this volume within 1e-4 of a decision boundary)
-    amb = _ambiguous(yp_r)
+    # label map: the pointwise criterion (no blanket band), and no more differing voxels than the 1e-5 band of SURVEY 8c holds
     lab = dice_fn.last_labels.cpu().long()
     differ = lab != c['labels'].long()
-    n_diff = int(differ.sum())
-    print('label map: %d of %d voxels differ from the oracle\'s (all inside the 1e-4 margin band: %s); voxels in the band %d, in a 1e-5 band %d'
-          % (n_diff, amb.numel(), bool((differ & ~amb).sum() == 0), int(amb.sum()), int(_ambiguous(yp_r, 1e-5).sum())))
-    assert torch.equal(lab[~amb], c['labels'].long()[~amb]), 'argmax label map differs from the oracle outside near-ties'
-    assert n_diff <= 1e-3 * amb.numel()
+    n_diff, n_out, n_band5 = _label_check(differ.reshape(yp_r.shape[:-1]), y_pred.t, yp_r, 'label map at 128^3')
+    assert n_out == 0, 'argmax label map differs from the oracle at %d voxels whose margin exceeds twice the local y_pred error' % n_out
+    assert n_diff <= n_band5, (n_diff, n_band5)
     assert abs(float(macro) - c['macro']) <= 1e-4 and abs(float(micro) - c['micro']) <= 1e-4
     # gradients: the rule of tests/test_model_gpu.py, with the oracle's own fp32 evaluation as the yardstick
     g64, g32 = c['g64'], c['g32']
@@ -195,14 +207,11 @@ def test_fp32_train_step_at_128_against_the_fp64_oracle(train_case):
     assert flipped <= 1e-2 * total
 
 
-def test_bf16_train_step_at_128_against_the_fp64_oracle(train_case):
-    """BASELINE configs[2]'s engine on one 128^3 volume vs the REFERENCE arithmetic: what 16-bit storage moves (stated; bounded
-    like the small-size case tests/test_lowp_train_gpu.py bounds against the fp32 engine)"""
-    import bts_amd  # noqa: F401
+def _lowp_step_vs_oracle(c, dtype):
+    """one step of the 16-bit engine on the 128^3 fixture -> (loss rel, |d macro|, |d micro|, label mismatch rate, gradient rel L2, cosine)"""
     from bts_amd.lowp_train import LowPrecisionTrainer
     from bts_amd.model import Model
     from bts_amd.util import DiceCoefficient, ScheduledOptim
-    c = train_case
     model = Model(**CLI)
     model.build((1,) + CROP + (2,))
     model.set_weights_from(c['P'])
@@ -210,16 +219,19 @@ def test_bf16_train_step_at_128_against_the_fp64_oracle(train_case):
     model.vae.set_eps(c['eps'])
     opt = ScheduledOptim(1e-4)
     opt(epoch=0)
-    tr = LowPrecisionTrainer(model, 'bfloat16')
+    tr = LowPrecisionTrainer(model, dtype)
     df = DiceCoefficient()
     loss, macro, micro = tr.step(opt, df, c['x'], c['y'])
     torch.cuda.synchronize()
+    tr.settle()
+    assert tr.skipped_steps == 0, 'the loss-scaled step overflowed'
     g64 = c['g64']
     flat = model.flat_grads
+    inv = 1.0 / tr.last_grad_scale           # (fp16: the buffer keeps the loss scale, Adam un-scales as it reads)
     num = den = dot = n2 = 0.0
     for p in model.trainable_variables:
         off = (p._gview.data_ptr() - flat.data_ptr()) // 4
-        a = flat[off:off + p._gview.numel()].detach().cpu().double().reshape(-1)
+        a = flat[off:off + p._gview.numel()].detach().cpu().double().reshape(-1) * inv
         b = g64[model.oracle_name(p)].reshape(-1)
         num += float((a - b).pow(2).sum())
         den += float(b.pow(2).sum())
@@ -229,14 +241,33 @@ def test_bf16_train_step_at_128_against_the_fp64_oracle(train_case):
     lab = df.last_labels.cpu().long()
     mism = float((lab != c['labels'].long()).float().mean())
     dl = abs(float(loss) - c['loss']) / abs(c['loss'])
-    print('bf16 storage at 128^3 vs fp64 oracle: loss %.6f vs %.6f (rel %.2e), macro Dice %.5f vs %.5f, micro %.5f vs %.5f, label changes '
-          '%.4f %%, gradient rel L2 %.3e cosine %.6f' % (float(loss), c['loss'], dl, float(macro), c['macro'], float(micro), c['micro'],
+    print('%s storage at 128^3 vs fp64 oracle: loss %.6f vs %.6f (rel %.2e), macro Dice %.5f vs %.5f, micro %.5f vs %.5f, label changes '
+          '%.4f %%, gradient rel L2 %.3e cosine %.6f' % (dtype, float(loss), c['loss'], dl, float(macro), c['macro'], float(micro), c['micro'],
                                                        100 * mism, rel, cos))
-    assert dl <= 5e-3 and abs(float(macro) - c['macro']) <= 5e-3 and abs(float(micro) - c['micro']) <= 5e-3 and mism <= 1e-2
-    # measured (round 5): gradient rel L2 0.152, cosine 0.9888, loss rel 6.4e-4, label changes 0.43 % -- one 128^3 volume of an untrained,
-    # randomly re-scaled net, 8-bit mantissas on every stored activation and activation gradient (the 32^3 case against the fp32 engine:
-    # 0.12 / 0.99, tests/test_lowp_train_gpu.py)
-    assert rel <= 0.2 and cos >= 0.98
+    del tr, model
+    torch.cuda.empty_cache()
+    return dl, abs(float(macro) - c['macro']), abs(float(micro) - c['micro']), mism, rel, cos
+
+
+def test_16bit_train_step_at_128_against_the_fp64_oracle(train_case):
+    """BASELINE configs[2]'s engine on one 128^3 volume vs the REFERENCE arithmetic: what 16-bit storage moves.  bf16 (the benched type) and
+    fp16 (loss-scaled, 11-bit mantissa) side by side on the SAME oracle evaluation, so that bf16's gradient error has a yardstick: the
+    regression guards are per type, and the statement that matters is their ratio (DESIGN section 4 / INTEGRATION: choosing compute_dtype)"""
+    import bts_amd  # noqa: F401
+    c = train_case
+    b = _lowp_step_vs_oracle(c, 'bfloat16')
+    f = _lowp_step_vs_oracle(c, 'float16')
+    print('gradient relative L2 error vs the fp64 oracle at 128^3: bf16 %.3e, fp16 %.3e (ratio %.1f); cosine %.5f / %.5f; label changes %.3f %% / %.3f %%'
+          % (b[4], f[4], b[4] / max(f[4], 1e-30), b[5], f[5], 100 * b[3], 100 * f[3]))
+    for name, r, lim in (('bfloat16', b, dict(l2=0.2, cos=0.98)), ('float16', f, dict(l2=0.08, cos=0.996))):
+        dl, dma, dmi, mism, rel, cos = r
+        assert dl <= 5e-3 and dma <= 5e-3 and dmi <= 5e-3 and mism <= 1e-2, (name, r)
+        # measured (round 5, bf16): gradient rel L2 0.152, cosine 0.9888, loss rel 6.4e-4, label changes 0.43 % -- one 128^3 volume of an
+        # untrained, randomly re-scaled net, 8-bit mantissas on every stored activation and activation gradient (the 32^3 case against the
+        # fp32 engine: 0.12 / 0.99, tests/test_lowp_train_gpu.py).  fp16 carries three more mantissa bits: its bound is the tighter one,
+        # and it must not be WORSE than bf16
+        assert rel <= lim['l2'] and cos >= lim['cos'], (name, rel, cos)
+    assert f[4] <= b[4]
 
 
 @pytest.fixture(scope='module')
@@ -272,16 +303,13 @@ def test_fp32_full_volume_forward_against_the_fp64_oracle(infer_case):
     assert a is None and b is None and d is None and y_pred.shape == (1, 160, 192, 160, 3)
     yp = c['yp']
     e = _maxerr(y_pred.t, yp)
-    amb = _ambiguous(yp)
     yh = y_pred.t.cpu().double()
-    n_arg = int((yh.argmax(-1) != yp.argmax(-1)).sum())
-    n_thr = int(((yh.max(-1).values > 0.5) != (yp.max(-1).values > 0.5)).sum())
-    print('160x192x160 fp32 engine vs fp64 oracle: y_pred max |d| %.2e; argmax differs at %d voxels, threshold at %d, near-ties %d of %d' %
-          (e, n_arg, n_thr, int(amb.sum()), amb.numel()))
+    arg_d = yh.argmax(-1) != yp.argmax(-1)
+    thr_d = (yh.max(-1).values > 0.5) != (yp.max(-1).values > 0.5)
+    print('160x192x160 fp32 engine vs fp64 oracle: y_pred max |d| %.2e; argmax differs at %d voxels, threshold at %d' % (e, int(arg_d.sum()), int(thr_d.sum())))
     assert e <= 1e-4
-    assert n_arg + n_thr <= 1e-3 * amb.numel()
-    assert torch.equal(yh.argmax(-1)[~amb], yp.argmax(-1)[~amb])
-    assert torch.equal((yh.max(-1).values > 0.5)[~amb], (yp.max(-1).values > 0.5)[~amb])
+    n_diff, n_out, n_band5 = _label_check(arg_d | thr_d, yh, yp, 'label map at 160x192x160')
+    assert n_out == 0 and n_diff <= n_band5, (n_diff, n_out, n_band5)
 
 
 def test_fp16_full_volume_forward_against_the_fp64_oracle(infer_case):
