@@ -39,7 +39,9 @@ long bts_lp_s1d_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn);
 long bts_lp_s1z_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn);
 int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bias, void* y, int N, int D, int H, int W, int Cin, int ldx,
                        int Cout, int ldy, int accum, double* gn_part, int gn_G, hipStream_t stream, const LpGnbFuse* gb = nullptr,
-                       const LpGnaFuse* ga = nullptr, const void* x2 = nullptr, const void* wp2 = nullptr, int ldx2 = 0);
+                       const LpGnaFuse* ga = nullptr, const void* x2 = nullptr, const void* wp2 = nullptr, int ldx2 = 0, void* y2 = nullptr,
+                       const float* bias2 = nullptr, double* gap_part = nullptr, int ldy2 = 0, int Cout2 = 0);
+long bts_lp_s1z_fs_B_(int N, int D, int H, int W, int Cin, int ldx, int Cout, int Cout2);
 bool bts_lp_s1z_gna_ok_(int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, int in_G);
 long bts_lp_s1z_gnb_B_(int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, int Gn);
 // lowp_k1.hip: streaming 1x1x1 kernel (offered first; 1 = declined); gap partials per block of bts_lp_k1_gap_block_ positions
@@ -1153,6 +1155,47 @@ extern "C" int bts_lp_conv3d_fwd_gn(int dtype, const void* x, const void* wp, co
   const int r = lp_conv_run(1, dtype, x, wp, bias, y, workspace, conv_ws, N, D, H, W, Cin, ldx, Cout, Cout, 0, stream);
   if (r != BTS_OK) return r;
   return bts_lp_gn_stats(dtype, y, mean, rstd, tail, workspace_bytes - conv_ws, N, V, Cout, G, BTS_GN_SLAB, eps, stream);
+}
+// conv1 AND the shortcut of a ResnetBlock from ONE pass over the block input (resnet.py:118 `res = conv3d_ptwise(inputs)` and resnet.py:134
+// `x = conv3d_1(inputs)` read the same tensor): y = conv3x3x3(x) + bias with GroupNorm `G`'s statistics of y (as bts_lp_conv3d_fwd_gn), res =
+// conv1x1x1(x) + bias_pt and gap[n][c] = mean over the voxels of the unrounded res (as bts_lp_conv1_gap) -- the shortcut is a second set of
+// output columns at the centre tap of the z-marching kernel's input planes (lowp_s1z.hip, FS form): x is read once, the 1x1x1 launch and
+// its read of x go away.  wp = bts_lp_pack(K3S1, FWD), wp_pt = bts_lp_pack(K1, FWD) with the same Cin_slab / fold; y and res dense
+// (N,D,H,W,Cout).  The workspace query returns -1 and the call 1 (nothing launched) where the streaming kernel does not take the shape:
+// the caller runs bts_lp_conv1_gap + bts_lp_conv3d_fwd_gn.  BTS_LP_FS=0 in the environment: never (A/B aid).
+__global__ __launch_bounds__(256) void lp_colsum_finalize_kernel(const double* partial, float* out, int N, int C, int B, double scale);
+extern "C" long bts_lp_conv3d_fwd_gn_shortcut_workspace(int N, int D, int H, int W, int Cin, int ldx, int Cout, int G) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || G <= 0 || Cout % G != 0 || D % G != 0 || Cin % 16 != 0) return -1;
+  static const bool off = [] { const char* e = getenv("BTS_LP_FS"); return e && atoi(e) == 0; }();
+  if (off) return -1;
+  const long Bg = bts_lp_s1z_gn_B_(N, D, H, W, Cin, Cout, G), Bf = bts_lp_s1z_fs_B_(N, D, H, W, Cin, ldx, Cout, Cout);
+  if (Bg <= 0 || Bf <= 0) return -1;
+  return (long)N * G * Bg * 16 + 64 + (long)N * Bf * Cout * 8 + 64;
+}
+extern "C" int bts_lp_conv3d_fwd_gn_shortcut(int dtype, const void* x, const void* wp, const float* bias, void* y, float* mean, float* rstd,
+                                             const void* wp_pt, const float* bias_pt, void* res, float* gap, void* workspace,
+                                             long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int G, float eps,
+                                             hipStream_t stream) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  const long need = bts_lp_conv3d_fwd_gn_shortcut_workspace(N, D, H, W, Cin, ldx, Cout, G);
+  if (need < 0) return 1;
+  if (workspace == nullptr || workspace_bytes < need || (((uintptr_t)workspace) & 15)) return BTS_ERR_WORKSPACE;
+  if (x == nullptr || wp == nullptr || wp_pt == nullptr || y == nullptr || res == nullptr || gap == nullptr || mean == nullptr || rstd == nullptr)
+    return BTS_ERR_ALIGN;
+  if (ldx % 8 != 0 || ldx < Cin || (((uintptr_t)x) & 15) || (((uintptr_t)wp) & 15)) return BTS_ERR_ALIGN;
+  const long Bg = bts_lp_s1z_gn_B_(N, D, H, W, Cin, Cout, G), Bf = bts_lp_s1z_fs_B_(N, D, H, W, Cin, ldx, Cout, Cout);
+  double* gpart = reinterpret_cast<double*>(workspace);
+  double* fpart = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + (((long)N * G * Bg * 16 + 63) / 64) * 64);
+  const long V = (long)D * H * W;
+  const int r = bts_lp_s1z_launch_(dtype, x, reinterpret_cast<const char*>(wp) + lp_s1d_part_offset(Cin, Cout), bias, y, N, D, H, W, Cin, ldx, Cout,
+                                   Cout, 0, gpart, G, stream, nullptr, nullptr, nullptr, wp_pt, 0, res, bias_pt, fpart, Cout, Cout);
+  if (r != BTS_OK) return r;
+  const int r2 = bts_gn_finalize_partials_(gpart, mean, rstd, N * G, Bg, (double)(V * Cout / G), eps, stream);
+  if (r2 != BTS_OK) return r2;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(lp_colsum_finalize_kernel, dim3((N * Cout + 3) / 4), dim3(256), 0, stream, fpart, gap, N, Cout, (int)Bf, 1.0 / (double)V);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
 }
 // The same with GroupNorm + ReLU of the INPUT applied on the way in (in_relu must be 1): y = conv3x3x3(relu(GN_in(x))) + bias and the statistics of y --
 // conv2 of a ResnetBlock reading conv1's raw output (resnet.py:133-136: conv -> GroupNormalization -> relu -> conv) where no backward

@@ -428,7 +428,8 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
           const int co = cb * 32 + 16 * qp + 8 * h;
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
-            const bool ok = co < p.Cout && oz < p.D && oy + v < p.H && ox < p.W;
+            const bool oks = oz < p.D && oy + v < p.H && ox < p.W;
+            const bool ok = co < p.Cout && oks;
             const unsigned off = (ok && !(BTS_DBG(p) & 1)) ? (unsigned)((((oz * p.H + oy + v) * p.W + ox) * p.ldy + cb_col + 16 * qp + 8 * h) * 2) : 0x80000000u;
             float f[4], g2[4];
 #pragma unroll
@@ -442,7 +443,10 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) { f[j] += old[j]; g2[j] += old[4 + j]; }
             }
-            if (gn_on && ok) {      // (own values, before the exchange: the sums run over all lanes anyway)
+            // (own values, before the exchange: this lane's couts 16 qp + 4 h + j / 16 qp + 8 + 4 h + j, NOT the stored piece's -- so the
+            // gate is the voxel's validity only; columns >= Cout carry zero weights and a zero bias and add exact zeros.  Gating on the
+            // stored piece's `ok` dropped real columns where Cout % 16 == 8: round-6 finding)
+            if (gn_on && oks) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 gn_s += f[j] + g2[j];

@@ -49,6 +49,14 @@ struct LpS1zParams {
   const unsigned short* x2;
   const unsigned short* wp2;
   int ldx2;
+  // FS kernels (forward): a second set of OUTPUT columns at the centre tap only -- y2 = x . w2 + bias2, the block's 1x1x1 shortcut conv
+  // (resnet.py:96-103,118: it reads the same `inputs` as conv1, resnet.py:134) from the input planes this kernel already holds in LDS, and
+  // the column sums of its unrounded output (the gate's squeeze, resnet.py:121) as fp64 partial rows [N][fs_B][Cout2].  wp2 as above
+  // (first part of the K1 forward image, one cout block).
+  unsigned short* y2;
+  const float* bias2;
+  double* gap_part;
+  int ldy2, Cout2, fs_B;
 };
 #define S1Z_TX 32
 #define S1Z_TY 16
@@ -64,12 +72,14 @@ __device__ __forceinline__ u32x4 s1z_rsrc(const void* base) {
   return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
 }
 
-template <typename T, int KS, bool GNB = false, bool GNA = false, bool SC = false>
+template <typename T, int KS, bool GNB = false, bool GNA = false, int XC = 0>      // XC: 0 plain, 1 SC (extra K-segment), 2 FS (extra output columns)
 __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  constexpr bool SC = XC == 1, FS = XC == 2;
   constexpr int SX = S1Z_SX, SY = S1Z_SY, NVOX = SX * SY, NCHK = S1Z_NCHK;
   constexpr int WB = 27 * KS * 1024, PLB = NCHK * 1024 * KS;
   constexpr int OFF_P = WB, OFF_BIAS = WB + 2 * PLB, OFF_SCR = OFF_BIAS + 256;
+  constexpr int OFF_BIAS2 = OFF_BIAS + 128;   // FS: the shortcut's bias (32 floats)
   constexpr int OFF_GB = OFF_SCR + 1024;      // GNB: gamma'[32] | beta'[32] | mean[32] | rstd[32] of the current sample (floats); GNA: gamma | beta | mean | rstd
 #ifdef S1Z_EXP_2ISSUE   // timing experiment: two waves issue all plane requests of a stage (is request back-pressure what stalls the others?)
   constexpr int NREQ = NCHK * KS, NR = NREQ / 2;
@@ -213,6 +223,72 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
           B2[ks][r] = __builtin_amdgcn_raw_buffer_load_b128(x2r, pok ? sc_off[r] : 0x80000000u, pok ? (unsigned)z * x2plane + (unsigned)ks * 32u : 0u, 0);
     }
   };
+  // FS: the shortcut's accumulators of the CENTRE output plane (two rows), its weights (registers, whole launch) and the per-lane column
+  // sums of the item (lane (h, voxel l32) holds couts 8 q + 4 h + j at index 4 q + j)
+  f32x16 acc2[FS ? 2 : 1];
+  u32x4 Apt[FS ? KS : 1];
+  float gsum[FS ? 16 : 1];
+  __amdgpu_buffer_rsrc_t y2r = yr;
+  auto init_res = [&]() {
+    if constexpr (FS) {
+      const float* b2 = reinterpret_cast<const float*>(lds + OFF_BIAS2) + 4 * h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(b2 + 8 * q);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc2[r][4 * q + j] = bq[j];
+      }
+    }
+  };
+  // plane z of the shortcut output leaves (16-byte stores of 8 consecutive couts, as store_set); the unrounded values join the column sums
+  auto store_res = [&](int z) {
+    if constexpr (FS) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gsum[i] += acc2[r][i];
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp) {
+        const int co = 16 * qp + 8 * h;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const unsigned off = co < p.Cout2 ? (unsigned)((((z * p.H + cy0 + r0 + r) * p.W + cx0 + l32) * p.ldy2 + co) * 2) : 0x80000000u;
+          unsigned d0 = pack2<T>(acc2[r][8 * qp], acc2[r][8 * qp + 1]), d1 = pack2<T>(acc2[r][8 * qp + 2], acc2[r][8 * qp + 3]);
+          unsigned d2 = pack2<T>(acc2[r][8 * qp + 4], acc2[r][8 * qp + 5]), d3 = pack2<T>(acc2[r][8 * qp + 6], acc2[r][8 * qp + 7]);
+          asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\tv_nop"
+                       : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{d0, d1, d2, d3}, y2r, off, 0, LP_OUT_STORE_AUX);
+        }
+      }
+      init_res();
+    }
+  };
+  // the item's column sums: over the 32 voxels of a lane half, then one fp64 partial row per (item, wave)
+  auto gap_flush = [&](int item) {
+    if constexpr (FS) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float v = gsum[i];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        gsum[i] = v;
+      }
+      if (l32 == 0) {
+        const int per = p.fs_B / 8;                       // items per sample
+        const int li = item - cn * per;
+        double* dst = p.gap_part + ((long)cn * p.fs_B + (long)li * 8 + wave) * p.Cout2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int co = 8 * (i >> 2) + 4 * h + (i & 3);
+          if (co < p.Cout2) dst[co] = (double)gsum[i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) gsum[i] = 0.f;
+    }
+  };
   // GNB (GroupNorm-backward class sums, LpGnbFuse).  Element e of a lane's stored 8 couts is channel co + e with co a multiple of 8, so
   // its class (channel mod cg, cg | 4) is e mod cg for every lane.  With t = c * g' + b' (g' = rstd * gamma_j, b' = beta_j - mean * g':
   // per sample and channel, in LDS) the masked gradient is dE = [t > 0] da and the class sums are B_j = S0_j, A_j = rstd * (S1_j - mean *
@@ -318,7 +394,10 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { f[j] += old[j]; g2[j] += old[4 + j]; }
         }
-        if (gn_on && ok) {
+        // (own values, BEFORE the exchange: this lane's couts 16 qp + 4 h + j and 16 qp + 8 + 4 h + j, not the stored piece's 16 qp + 8 h ..
+        // + 7 -- gating the sums on the STORED piece's `ok` dropped real columns where Cout % 16 == 8 (round-6 finding: statistics of a
+        // 24-cout conv off by 50 % of the mean).  Columns >= Cout carry zero weights and a zero bias: they add exact zeros)
+        if (gn_on) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             gn_s += f[j] + g2[j];
@@ -430,6 +509,12 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
       }
       __builtin_amdgcn_sched_barrier(0);
       const int s = (R + 4 - kz) % 3;
+      if constexpr (FS) {      // centre tap of the 1x1x1 conv: x tap 1, rows r0 / r0 + 1 = fragments 1 and 2 of this x tap
+        if ((g / 3) % 3 == 1 && kz == 1) {
+          acc2[0] = T::mfma(Apt[g / 9], B[bs][1], acc2[0]);
+          acc2[1] = T::mfma(Apt[g / 9], B[bs][2], acc2[1]);
+        }
+      }
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
 #ifdef S1Z_EXP_NOMFMA   // timing experiment (wrong results)
@@ -461,6 +546,14 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
       for (int ks = 0; ks < KS; ++ks) A2[ks] = __builtin_amdgcn_raw_buffer_load_b128(w2r, (unsigned)(h * 512 + l32 * 16), (unsigned)ks * 1024u, 0);
       x2plane = (unsigned)(p.H * p.W * p.ldx2 * 2);
     }
+    if constexpr (FS) {
+      const __amdgpu_buffer_rsrc_t w2r = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp2, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) Apt[ks] = __builtin_amdgcn_raw_buffer_load_b128(w2r, (unsigned)(h * 512 + l32 * 16), (unsigned)ks * 1024u, 0);
+      if (tid >= 32 && tid < 64) reinterpret_cast<float*>(lds + OFF_BIAS2)[tid - 32] = (p.bias2 != nullptr && tid - 32 < p.Cout2) ? p.bias2[tid - 32] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) gsum[i] = 0.f;
+    }
   }
   const int w = blockIdx.x;
   int it0 = w * p.ipw;
@@ -470,6 +563,7 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
   for (int item = it0; item < it1; ++item) {
     setup(item);
     yr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long)cn * p.D * p.H * p.W * (long)p.ldy), 0, 0x7fffffff, 0x00020000);
+    if constexpr (FS) y2r = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y2 + (long)cn * p.D * p.H * p.W * (long)p.ldy2), 0, 0x7fffffff, 0x00020000);
     if constexpr (SC) {
       x2r = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 + (long)cn * p.D * p.H * p.W * (long)p.ldx2), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
@@ -512,6 +606,7 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
       asm volatile("" ::: "memory");
     }
     init_set(0); init_set(1); init_set(2);
+    init_res();
     int zp = zlo - 1, buf = 0;
     // stage zp completes output plane zp - 1 (set of tap kz = 2)
 #define S1Z_STAGE(RR)                                                                        \
@@ -526,6 +621,7 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
       asm volatile("" ::: "memory");                                                         \
     }                                                                                        \
     if (zp - 1 >= zlo) store_set(S1zIC<(RR + 2) % 3>{}, zp - 1); else init_set((RR + 2) % 3);  \
+    if constexpr (FS) { if (zp >= zlo && zp < zhi) store_res(zp); else init_res(); }         \
     buf ^= 1;                                                                                \
     if (++zp > zhi) break;
     for (;;) {
@@ -534,6 +630,7 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
       S1Z_STAGE(2)
     }
 #undef S1Z_STAGE
+    gap_flush(item);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the last plane's stores and fillers) before the buffers change hands
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -604,6 +701,12 @@ long bts_lp_s1z_gnb_B_(int N, int D, int H, int W, int Cin, int ldx, int Cout, i
   if (pl.ZC % zt != 0 && zt % pl.ZC != 0) return 0;
   return (long)(pl.ZC < zt ? zt / pl.ZC : 1) * pl.nty * pl.ntx * 8;
 }
+// FS form: partial rows per sample of the shortcut's column sums (8 per item), or 0 where the kernel does not take the shape
+long bts_lp_s1z_fs_B_(int N, int D, int H, int W, int Cin, int ldx, int Cout, int Cout2) {
+  S1zPlan pl;
+  if (Cin == 64 || Cout2 <= 0 || Cout2 > 32 || Cout2 % 8 != 0 || !s1z_plan(pl, N, D, H, W, Cin, ldx, Cout, Cout)) return 0;
+  return (long)pl.ntx * pl.nty * pl.nzc * 8;
+}
 // BTS_OK = ran, 1 = declined.  wp = the DMA part of the K3S1 image.  gb (may be NULL): see LpGnbFuse; its B must be bts_lp_s1z_gnb_B_'s
 // does the kernel take the shape with GroupNorm `in_G` applied to its input planes (LpGnaFuse)?
 bool bts_lp_s1z_gna_ok_(int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, int in_G) {
@@ -615,10 +718,15 @@ bool bts_lp_s1z_gna_ok_(int N, int D, int H, int W, int Cin, int ldx, int Cout, 
 }
 int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bias, void* y, int N, int D, int H, int W, int Cin, int ldx,
                        int Cout, int ldy, int accum, double* gn_part, int gn_G, hipStream_t stream, const LpGnbFuse* gb, const LpGnaFuse* ga,
-                       const void* x2, const void* wp2, int ldx2) {
+                       const void* x2, const void* wp2, int ldx2, void* y2, const float* bias2, double* gap_part, int ldy2, int Cout2) {
   S1zPlan pl;
   if (!s1z_plan(pl, N, D, H, W, Cin, ldx, Cout, ldy)) return 1;
   const bool sc = x2 != nullptr;
+  const bool fs = y2 != nullptr;
+  if (fs && (sc || Cin == 64 || gb != nullptr || ga != nullptr || accum || wp2 == nullptr || gap_part == nullptr || Cout2 <= 0 || Cout2 > 32 ||
+             Cout2 % 8 != 0 || ldy2 < Cout2 || ldy2 % 8 != 0 || (((uintptr_t)y2) & 15) || (((uintptr_t)wp2) & 15) ||
+             (long)D * H * W * (long)ldy2 * 2 >= 0x7fffffffL))
+    return 1;
   if (sc && (Cin == 64 || gb != nullptr || ga != nullptr || gn_part != nullptr || wp2 == nullptr || ldx2 < Cin || ldx2 % 8 != 0 ||
              (((uintptr_t)x2) & 15) || (((uintptr_t)wp2) & 15) || (long)D * H * W * (long)ldx2 * 2 >= 0x7fffffffL))
     return 1;
@@ -628,12 +736,13 @@ int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bi
     // the caller's fallback would add the first half twice when accumulating)
     if ((((uintptr_t)x) & 15) || (((uintptr_t)y) & 15) || (((uintptr_t)wp) & 15)) return 1;      // (x + 32 channels = + 64 bytes, wp + 54 KB: aligned with them)
     if (gn_part != nullptr && (gn_G <= 0 || D % gn_G != 0)) return 1;
-    const int r = bts_lp_s1z_launch_(dtype, x, wp, bias, y, N, D, H, W, 32, ldx, Cout, ldy, accum, nullptr, 0, stream, nullptr, nullptr, nullptr, nullptr, 0);
+    const int r = bts_lp_s1z_launch_(dtype, x, wp, bias, y, N, D, H, W, 32, ldx, Cout, ldy, accum, nullptr, 0, stream, nullptr, nullptr, nullptr, nullptr, 0,
+                                     nullptr, nullptr, nullptr, 0, 0);
     if (r != BTS_OK) return r;
     // (image: [k-step][dz][tap][k-half][32 couts][8 cin], 27 KB per k-step: the second half starts two k-steps in.  The first half's sum
     // passes through the storage type once before the second is added: one extra rounding, carried by the test bounds)
     const int r2 = bts_lp_s1z_launch_(dtype, reinterpret_cast<const unsigned short*>(x) + 32, reinterpret_cast<const char*>(wp) + 2 * 27 * 1024, nullptr, y,
-                                      N, D, H, W, 32, ldx, Cout, ldy, 1, gn_part, gn_G, stream, nullptr, nullptr, nullptr, nullptr, 0);
+                                      N, D, H, W, 32, ldx, Cout, ldy, 1, gn_part, gn_G, stream, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, 0);
     return r2 == 1 ? BTS_ERR_UNSUPPORTED : r2;      // (y has been written: "declined" is no longer an answer)
   }
   if (ga != nullptr && (gb != nullptr || !bts_lp_s1z_gna_ok_(N, D, H, W, Cin, ldx, Cout, ldy, ga->G) || ga->cg != Cin / ga->G)) return 1;
@@ -652,10 +761,12 @@ int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bi
   if (gb != nullptr) { p.gb = *gb; p.gb_zt = D / gb->G; } else { p.gb = LpGnbFuse{}; p.gb_zt = 1; }
   if (ga != nullptr) { p.ga = *ga; p.ga_zt = D / ga->G; } else { p.ga = LpGnaFuse{}; p.ga_zt = 1; }
   p.x2 = (const unsigned short*)x2; p.wp2 = (const unsigned short*)wp2; p.ldx2 = ldx2;
+  p.y2 = (unsigned short*)y2; p.bias2 = bias2; p.gap_part = gap_part; p.ldy2 = ldy2; p.Cout2 = Cout2;
+  p.fs_B = pl.ntx * pl.nty * pl.nzc * 8;
   const int KS = Cin / 16;
   const size_t shmem = (size_t)(27 * KS * 1024 + 2 * S1Z_NCHK * 1024 * KS + 256 + 1024 + 512);
   (void)hipGetLastError();
-#define S1Z_LAUNCH(TT, KS_) do { if (sc) S1Z_LAUNCH_(TT, KS_, false, false, true); else if (gb != nullptr) S1Z_LAUNCH_(TT, KS_, true, false, false); else if (ga != nullptr) S1Z_LAUNCH_(TT, KS_, false, true, false); else S1Z_LAUNCH_(TT, KS_, false, false, false); } while (0)
+#define S1Z_LAUNCH(TT, KS_) do { if (sc) S1Z_LAUNCH_(TT, KS_, false, false, 1); else if (fs) S1Z_LAUNCH_(TT, KS_, false, false, 2); else if (gb != nullptr) S1Z_LAUNCH_(TT, KS_, true, false, 0); else if (ga != nullptr) S1Z_LAUNCH_(TT, KS_, false, true, 0); else S1Z_LAUNCH_(TT, KS_, false, false, 0); } while (0)
 #define S1Z_LAUNCH_(TT, KS_, GB_, GA_, SC_)                                                                                  \
   do {                                                                                                                       \
     auto kern = lp_s1z_kernel<TT, KS_, GB_, GA_, SC_>;                                                                          \
@@ -668,7 +779,7 @@ int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bi
     hipLaunchKernelGGL(kern, dim3(pl.nwg), dim3(512), shmem, stream, p);                                                     \
   } while (0)
   const bool prof = bts_prof_on();
-  if (prof) bts_prof_begin(38, 2.0 * (sc ? 28.0 : 27.0) * (double)Cin * Cout * (double)N * D * H * W, stream);
+  if (prof) bts_prof_begin(38, 2.0 * ((double)(sc ? 28 : 27) * Cout + (fs ? Cout2 : 0)) * (double)Cin * (double)N * D * H * W, stream);
   if (dtype == LP_F16) { if (KS == 2) S1Z_LAUNCH(TF16, 2); else S1Z_LAUNCH(TF16, 1); }
   else { if (KS == 2) S1Z_LAUNCH(TBF16, 2); else S1Z_LAUNCH(TBF16, 1); }
 #undef S1Z_LAUNCH

@@ -268,7 +268,8 @@ __global__ __launch_bounds__(512, 2) void lp_up_kernel(const LpUpParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { f[j] += old[j]; g2[j] += old[4 + j]; }
           }
-          if (gn_on && ok) {      // (own values, before the exchange: the sums run over all lanes anyway)
+          // (own values, before the exchange: the gate is the voxel's validity, not the stored piece's column range -- see lowp_s1d.hip)
+          if (gn_on && inb) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               gn_s[pz] += f[j] + g2[j];

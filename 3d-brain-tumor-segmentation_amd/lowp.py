@@ -211,6 +211,31 @@ def conv_gn(code, tdt, x, wp, bias, cout, norm):
     return y, mean, rstd
 
 
+def conv_gn_shortcut(code, tdt, x, wp, bias, cout, norm, wp_pt, bias_pt):
+    """(y, mean, rstd, res, gap) -- conv1 with `norm`'s statistics AND the block's shortcut conv with the gate's squeeze from ONE pass over
+    the block input (resnet.py:118,134 read the same `inputs`), or None where the streaming kernel does not take the shape (the caller
+    runs conv1_gap + conv_gn)"""
+    if norm._mode != ops.GN_SLAB:
+        return None
+    n, d, h, w, cin = x.shape
+    nb = lib().probe('bts_lp_conv3d_fwd_gn_shortcut_workspace', n, d, h, w, cin, _ld(x), cout, norm.groups)
+    if nb < 0:
+        return None
+    y = torch.empty((n, d, h, w, cout), dtype=tdt, device=x.device)
+    res = torch.empty((n, d, h, w, cout), dtype=tdt, device=x.device)
+    mean = torch.empty(n * norm.groups, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(n * norm.groups, dtype=torch.float32, device=x.device)
+    gap = torch.empty((n, cout), dtype=torch.float32, device=x.device)
+    ws = ops.workspace(nb, x.device)
+    r = lib().probe('bts_lp_conv3d_fwd_gn_shortcut', code, _p(x), _p(wp), _p(bias), _p(y), _p(mean), _p(rstd), _p(wp_pt), _p(bias_pt), _p(res),
+                    _p(gap), _p(ws), nb, n, d, h, w, cin, _ld(x), cout, norm.groups, float(norm.epsilon), _stream())
+    if r == 1:
+        return None
+    if r != 0:
+        raise RuntimeError('bts_lp_conv3d_fwd_gn_shortcut failed: %s' % ERRORS.get(r, 'hipError %d' % r))
+    return y, mean, rstd, res, gap
+
+
 def conv_gn_normed_input(code, tdt, x, norm_in, mean_in, rstd_in, relu_in, wp, bias, cout, norm):
     """(y, mean, rstd) with y = conv3x3x3([relu](norm_in(x))) + bias and `norm`'s statistics of y: the GroupNorm of the conv's INPUT is
     applied to each input plane inside the conv kernel (bts_lp_conv3d_gnin_fwd_gn) -- for forwards whose normalised tensor nobody else

@@ -100,6 +100,9 @@ class LowPrecisionTrainer(object):
         # GroupNorm-1 + ReLU applied inside conv2's forward and weight-gradient kernels where both can (the normalised tensor is never
         # written); BTS_LP_FUSE_GN1_APPLY=0: the separate apply pass everywhere (A/B)
         self.fuse_gn1_apply = os.environ.get('BTS_LP_FUSE_GN1_APPLY', '1') != '0'
+        # conv1 + shortcut + squeeze from one pass over the block input (bts_lp_conv3d_fwd_gn_shortcut); BTS_LP_FS=0 in the library's
+        # environment is the A/B switch
+        self.fuse_shortcut_fwd = True
         self.last_labels = None
         self._clock = None
 
@@ -237,9 +240,17 @@ class LowPrecisionTrainer(object):
         key = id(blk)
         wp_pt = self._pk((key, 'pt'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
         wp_c1 = self._pk((key, 'c1'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
-        # shortcut conv + the gate's squeeze in one pass, then the SE-MLP (main stream: see lowp.gate_branch)
-        res, gap, (hbuf, ch), gate = lowp.gate_branch(code, tdt, x, wp_pt, blk.ptwise_b.t, f, blk.se_w1.t, blk.se_w2.t, side=False)
-        c1, m1, r1 = conv_gn(code, tdt, x, wp_c1, blk.conv1_b.t, f, blk.norm1)      # conv + the statistics of its output
+        # conv1 (+ the statistics of its output) and the shortcut conv (+ the gate's squeeze) from ONE pass over x where the z-marching
+        # kernel takes the layer (round 6: the shortcut is a second set of output columns at the centre tap); else the shortcut conv +
+        # squeeze in one pass of their own.  Then the SE-MLP (main stream: see lowp.gate_branch)
+        both = lowp.conv_gn_shortcut(code, tdt, x, wp_c1, blk.conv1_b.t, f, blk.norm1, wp_pt, blk.ptwise_b.t) if self.fuse_shortcut_fwd else None
+        if both is not None:
+            c1, m1, r1, res, gap = both
+            hbuf, ch = ops.se_mlp_fwd(gap, blk.se_w1.t, blk.se_w2.t)
+            gate = None
+        else:
+            res, gap, (hbuf, ch), gate = lowp.gate_branch(code, tdt, x, wp_pt, blk.ptwise_b.t, f, blk.se_w1.t, blk.se_w2.t, side=False)
+            c1, m1, r1 = conv_gn(code, tdt, x, wp_c1, blk.conv1_b.t, f, blk.norm1)      # conv + the statistics of its output
         wp_c2 = self._pk((key, 'c2'), ops.K3S1, blk.conv2_k, f, f)
         # relu(GN1(c1)) has two readers, conv2's forward and conv2's weight gradient: where both kernels can normalise their input planes
         # themselves (the streaming kernels of the 128^3 level), the tensor is never written (a = None: the backward knows)

@@ -116,6 +116,9 @@ def pmc_traffic(symbol, suffix=''):
             'rdreq_64b_raw': opt('TCC_EA0_RDREQ_64B_sum_mean'), 'rdreq_128b_raw': opt('TCC_EA0_RDREQ_128B_sum_mean'),
             # clock the part held under this kernel in the capture: GRBM_GUI_ACTIVE (summed over the 8 XCDs) over the dispatch duration
             'clock_ghz': (opt('GRBM_GUI_ACTIVE_mean') / 8.0 / opt('duration_ns_mean')) if (opt('GRBM_GUI_ACTIVE_mean') and opt('duration_ns_mean')) else None,
+            # the matrix pipe's own counter, same capture: SQ_VALU_MFMA_BUSY_CYCLES / (launch cycles x 1024 SIMDs) -- to hold against the
+            # FLOP / time fraction (`frac`): the two agree when the kernel's matrix instructions are the ones its FLOP count assumes
+            'mfma_busy': opt('mfma_busy'),
             'launches_in_capture': int(n), 'variants_in_capture': len(hits), 'source': 'committed capture ' + src}
 
 
@@ -469,6 +472,9 @@ def _roofline_from_records(prof, steps_p, dt_p, traffic_of, measured):
         'achieved_algorithmic': alg, 'frac_algorithmic': alg / peak,
         'traffic': traffic['bytes'] if traffic else None, 'traffic_detail': traffic,
         'hbm_frac_of_launch': (t_hbm / t_launch) if traffic else None,
+        # the matrix pipe's own busy counter for this kernel (committed capture: SQ_VALU_MFMA_BUSY_CYCLES over launch cycles x 1024 SIMDs):
+        # cycles, so it is a fraction of the clock the part HELD in the capture, where `frac` prices against the nominal-clock peak
+        'mfma_busy_counter': traffic.get('mfma_busy') if traffic else None,
         # clock the part held under this kernel IN THE CAPTURE (GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration).  The counter passes run
         # the kernels one at a time with idle gaps: the sustained step runs hotter and lower-clocked; what the power envelope costs
         # the 16-bit matrix kernels is measured in profiles/r04_power_limit.txt (zero-operand runs, library-GEMM yardstick)
@@ -493,6 +499,8 @@ def _roofline_from_records(prof, steps_p, dt_p, traffic_of, measured):
             e['hbm_tbs'] = tr['bytes'] / (v[0] / v[2]) / 1e12
             e['hbm_frac'] = e['hbm_tbs'] / PEAK_HBM_TBS
             e['bound'] = 'hbm' if e['hbm_frac'] > e['mfma_frac'] else 'mfma'
+            if tr.get('mfma_busy') is not None:
+                e['mfma_busy'] = tr['mfma_busy']
         brk[k] = e
     return {'roofline': roof, 'kernel_breakdown': brk}
 
@@ -731,7 +739,7 @@ def _compact(out, top):
     if 'kernel_breakdown' in out:
         rows = sorted(out['kernel_breakdown'].items(), key=lambda kv: -kv[1]['ms_per_step'])
         c['kernel_breakdown'] = {k: {'ms': v['ms_per_step'], 'n': v['launches_per_step'], 'mfma_frac': v['mfma_frac'],
-                                     'hbm_frac': v.get('hbm_frac'), 'bound': v.get('bound')} for k, v in rows[:top]}
+                                     'mfma_busy': v.get('mfma_busy'), 'hbm_frac': v.get('hbm_frac'), 'bound': v.get('bound')} for k, v in rows[:top]}
         c['kernel_breakdown_rest_ms'] = sum(v['ms_per_step'] for _, v in rows[top:])
     return c
 

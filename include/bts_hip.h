@@ -372,6 +372,16 @@ long bts_lp_conv3d_fwd_gn_workspace(int N, int D, int H, int W, int Cin, int Cou
 int bts_lp_conv3d_fwd_gn(int dtype, const void* x, const void* wp, const float* bias, void* y, float* mean, float* rstd, void* workspace,
                          long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int G, float eps,
                          bts_stream_t stream);
+/* conv1 AND the shortcut of a ResnetBlock from ONE pass over the block input (resnet.py:118 and resnet.py:134 read the same `inputs`):
+ * y = conv3x3x3(x) + bias with GroupNorm G's statistics of y (as bts_lp_conv3d_fwd_gn), res = conv1x1x1(x) + bias_pt and gap[n][c] = mean
+ * over the voxels of the unrounded res (as bts_lp_conv1_gap).  The shortcut is a second set of output columns at the centre tap of the
+ * z-marching kernel's input planes: x is read once.  wp / wp_pt = bts_lp_pack(K3S1 / K1, BTS_ROLE_FWD, ...) with the same Cin_slab and
+ * fold; y, res dense (N,D,H,W,Cout).  Workspace query -1 / return value 1 (nothing launched) outside the kernel's shapes: run
+ * bts_lp_conv1_gap + bts_lp_conv3d_fwd_gn.  BTS_LP_FS=0 in the environment: never (A/B aid) */
+long bts_lp_conv3d_fwd_gn_shortcut_workspace(int N, int D, int H, int W, int Cin, int ldx, int Cout, int G);
+int bts_lp_conv3d_fwd_gn_shortcut(int dtype, const void* x, const void* wp, const float* bias, void* y, float* mean, float* rstd,
+                                  const void* wp_pt, const float* bias_pt, void* res, float* gap, void* workspace, long workspace_bytes,
+                                  int N, int D, int H, int W, int Cin, int ldx, int Cout, int G, float eps, bts_stream_t stream);
 /* The same with the GroupNorm + ReLU of the INPUT applied on the way in (in_relu = 1): y = conv3x3x3(relu(GN_in(x))) + bias and the statistics of y.
  * conv2 of a ResnetBlock reading conv1's raw output (layers/resnet.py:133-136: conv -> GroupNormalization -> relu -> conv) in a forward
  * whose normalised tensor nobody else reads (Model.call(inference=True), model.py:58-71; test.py:128-151): the separate apply pass of

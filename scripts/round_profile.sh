@@ -63,7 +63,9 @@ traffic_passes() {   # traffic_passes <suffix> <bench args...>
   local sfx=$1; shift
   # (GRBM_GUI_ACTIVE rides on the WRITE_SIZE pass -- the GRBM block has its own slots: busy cycles summed over the 8 XCDs, which over
   # the launch's duration in the same pass is the clock the part held under that kernel)
-  for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE GRBM_GUI_ACTIVE" "req:$REQ"; do
+  # Fourth pass (round 6, review item 6): the matrix pipe's own busy counter next to the launch cycles of the SAME pass --
+  # mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), the counter-side check of bench.py's FLOP / time fraction
+  for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE GRBM_GUI_ACTIVE" "req:$REQ" "sq:SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"; do
     local name=${pass%%:*} ctr=${pass#*:}
     rm -rf "$O/pmc_${TAG}${sfx}_$name"
     # shellcheck disable=SC2086
@@ -81,13 +83,16 @@ import collections, csv, glob, json, sys
 O, TAG = sys.argv[1], sys.argv[2]
 for sfx in ('', '_bf16_b8', '_infer_f16'):
     out = {}
-    for name in ('fetch', 'write', 'req'):
+    for name in ('fetch', 'write', 'req', 'sq'):
         files = glob.glob('%s/pmc_%s%s_%s/**/%s_counter_collection.csv' % (O, TAG, sfx, name, name), recursive=True)
         assert len(files) == 1, files
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(files[0])):
-            agg[r['Kernel_Name'].split('(')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
-            if r['Counter_Name'] == 'GRBM_GUI_ACTIVE':       # duration of the same dispatch, for the clock
+            ctr = r['Counter_Name']
+            if name == 'sq' and ctr == 'GRBM_GUI_ACTIVE':
+                ctr = 'GRBM_GUI_ACTIVE_sqpass'                # (the launch cycles of the pass the SQ counters were taken in)
+            agg[r['Kernel_Name'].split('(')[0]][ctr].append(float(r['Counter_Value']))
+            if ctr == 'GRBM_GUI_ACTIVE':       # duration of the same dispatch, for the clock
                 agg[r['Kernel_Name'].split('(')[0]]['duration_ns'].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
         assert agg, 'no rows in %s' % files[0]
         for k, cs in agg.items():
@@ -95,6 +100,9 @@ for sfx in ('', '_bf16_b8', '_infer_f16'):
                 key = ctr + ('_KiB' if ctr in ('FETCH_SIZE', 'WRITE_SIZE') else '')
                 out.setdefault(k, {})[key + '_mean'] = sum(v) / len(v)
                 out[k]['launches'] = len(v)
+    for k, v in out.items():       # matrix-pipe busy fraction per kernel (0 for kernels without matrix instructions)
+        if 'SQ_VALU_MFMA_BUSY_CYCLES_mean' in v and v.get('GRBM_GUI_ACTIVE_sqpass_mean'):
+            v['mfma_busy'] = v['SQ_VALU_MFMA_BUSY_CYCLES_mean'] / (v['GRBM_GUI_ACTIVE_sqpass_mean'] / 8.0 * 1024.0)
     # 3 steps per capture (1 warm-up + 2 timed; --no-profile: no further ones); one-time construction kernels are in there too
     out['_meta'] = {'steps_in_capture': 3, 'command': 'bench.py%s --steps 2 --warmup 1 --serial-streams under rocprofv3 --kernel-trace --pmc <group>'
                     % {'': '', '_bf16_b8': ' --dtype bf16 --batch 8', '_infer_f16': ' --infer --dtype f16'}[sfx]}

@@ -133,7 +133,8 @@ def test_folded_duplicate_slice():
 
 
 @pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
-@pytest.mark.parametrize('shape', [(2, 16, 24, 32, 32, 32), (1, 16, 24, 36, 16, 64)], ids=['32cout', '64cout-ragged'])
+@pytest.mark.parametrize('shape', [(2, 16, 24, 32, 32, 32), (1, 16, 24, 36, 16, 64), (1, 16, 24, 36, 32, 24), (1, 16, 24, 32, 16, 40)],
+                         ids=['32cout', '64cout-ragged', '24cout-ragged', '40cout'])
 def test_fused_groupnorm_statistics(shape, dtype):
     """bts_lp_conv3d_fwd_gn: the slab-mode GroupNorm (sum, sumsq) partials leave the conv's output side (group_norm.py:100-107 on the
     conv of resnet.py:80-93): mean / rstd against the statistics of the unrounded fp64 conv result"""

@@ -259,13 +259,14 @@ def test_16bit_train_step_at_128_against_the_fp64_oracle(train_case):
     f = _lowp_step_vs_oracle(c, 'float16')
     print('gradient relative L2 error vs the fp64 oracle at 128^3: bf16 %.3e, fp16 %.3e (ratio %.1f); cosine %.5f / %.5f; label changes %.3f %% / %.3f %%'
           % (b[4], f[4], b[4] / max(f[4], 1e-30), b[5], f[5], 100 * b[3], 100 * f[3]))
-    for name, r, lim in (('bfloat16', b, dict(l2=0.2, cos=0.98)), ('float16', f, dict(l2=0.08, cos=0.996))):
+    for name, r, lim in (('bfloat16', b, dict(l2=0.2, cos=0.98)), ('float16', f, dict(l2=0.05, cos=0.999))):
         dl, dma, dmi, mism, rel, cos = r
         assert dl <= 5e-3 and dma <= 5e-3 and dmi <= 5e-3 and mism <= 1e-2, (name, r)
         # measured (round 5, bf16): gradient rel L2 0.152, cosine 0.9888, loss rel 6.4e-4, label changes 0.43 % -- one 128^3 volume of an
         # untrained, randomly re-scaled net, 8-bit mantissas on every stored activation and activation gradient (the 32^3 case against the
-        # fp32 engine: 0.12 / 0.99, tests/test_lowp_train_gpu.py).  fp16 carries three more mantissa bits: its bound is the tighter one,
-        # and it must not be WORSE than bf16
+        # fp32 engine: 0.12 / 0.99, tests/test_lowp_train_gpu.py).  fp16 carries three more mantissa bits: measured (round 6) gradient rel L2
+        # 0.0325 (4.7x smaller), cosine 0.99947, loss rel 1.3e-5, label changes 0.061 % -- its bound is the tighter one, and it must not
+        # be WORSE than bf16
         assert rel <= lim['l2'] and cos >= lim['cos'], (name, rel, cos)
     assert f[4] <= b[4]
 
