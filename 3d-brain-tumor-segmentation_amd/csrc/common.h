@@ -104,3 +104,16 @@ __device__ __forceinline__ double block_sum_f64(double v, double* sh /*>=4*/) {
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// counter-based uniform generator of the dropout mask / the VAE's eps (pointwise.hip) and of lowp.hip's fused dropout + cast: element i of a
+// stream `seed` is a pure function of (seed, i), so every kernel that draws element i gets the same value
+__device__ __forceinline__ uint32_t mix32(uint64_t z) {  // splitmix64 finaliser
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+__device__ __forceinline__ float u01(uint64_t seed, uint64_t i) {  // [0,1)
+  return (float)(mix32(seed * 0xD1342543DE82EF95ull + i) >> 8) * (1.0f / 16777216.0f);
+}

@@ -1459,6 +1459,38 @@ extern "C" int bts_lp_cast_pad16(int dtype, const float* src, long ld_src, void*
   BTS_LAUNCH_CHECK();
   return BTS_OK;
 }
+// The input dropout of the encoder (encoder.py:39,71: Dropout(0.2) on the 2-channel volume) AND the cast into the zero-padded 16-channel
+// matrix step in ONE pass: element i of the dense (rows, C) fp32 volume is kept (and scaled by 1 / (1 - rate)) where the counter-based
+// generator of bts_dropout_mask says so -- the SAME draw, element for element (u01(seed, i) >= rate) -- so the result equals
+// bts_dropout_mask + bts_dropout_apply + bts_lp_cast_pad16 bit for bit, without the mask and the dropped fp32 volume ever being written
+// (three launches, 0.30 ms per 8 x 128^3 step -> one).  The first block's input has no gradient: nothing downstream needs the mask.
+template <typename T, int C>
+__global__ __launch_bounds__(256) void lp_dropout_cast_pad16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long rows, float rate,
+                                                                    float scale, uint64_t seed) {
+  for (long r = blockIdx.x * 256L + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c] = u01(seed, (uint64_t)(r * C + c)) >= rate ? src[r * C + c] * scale : 0.f;
+    u32x4* o = reinterpret_cast<u32x4*>(dst + r * 16);
+    o[0] = u32x4{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), 0u, 0u};
+    o[1] = u32x4{0u, 0u, 0u, 0u};
+  }
+}
+extern "C" int bts_lp_dropout_cast_pad16(int dtype, const float* src, void* dst, long rows, int C, float rate, uint64_t seed, hipStream_t stream) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  if (rows <= 0 || C <= 0 || C > 4 || rate < 0.f || rate >= 1.f) return BTS_ERR_SHAPE;
+  if (((uintptr_t)dst) & 15) return BTS_ERR_ALIGN;
+  long blocks = (rows + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  const float scale = 1.0f / (1.0f - rate);
+  (void)hipGetLastError();
+#define LP_DCP(TT, C_) hipLaunchKernelGGL((lp_dropout_cast_pad16_kernel<TT, C_>), dim3((unsigned)blocks), dim3(256), 0, stream, src, (unsigned short*)dst, rows, rate, scale, seed)
+  if (dtype == LP_F16) { if (C == 1) LP_DCP(TF16, 1); else if (C == 2) LP_DCP(TF16, 2); else if (C == 3) LP_DCP(TF16, 3); else LP_DCP(TF16, 4); }
+  else { if (C == 1) LP_DCP(TBF16, 1); else if (C == 2) LP_DCP(TBF16, 2); else if (C == 3) LP_DCP(TBF16, 3); else LP_DCP(TBF16, 4); }
+#undef LP_DCP
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
+}
 extern "C" int bts_lp_uncast(int dtype, const void* src, long ld_src, float* dst, long ld_dst, long rows, int C, hipStream_t stream) {
   if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
   if (rows <= 0 || C <= 0) return BTS_ERR_SHAPE;

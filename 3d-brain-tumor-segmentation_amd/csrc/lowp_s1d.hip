@@ -224,8 +224,8 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
 
   // ---- SC: the centre-tap operand pair of a k-step, global -> registers (no LDS: a lane's B fragment is its own voxel's 16 bytes) ----
   // B2[v]: voxel (z, y0 + v, lx) of the tile, channels 16 ks + 8 h .. + 7 of x2; A2: couts 32 cb + l32, the same 8 channels of w2.
-  // Requested in stage 2 of the k-step BEFORE (ahead of its last weight stage: the next stage-0 wait covers them), used after the
-  // centre group of stage 1: one register set.
+  // Requested in stage 1 of the k-step BEFORE, right after that k-step's own pair has been multiplied (one register set), used after the
+  // centre group of stage 1.
   u32x4 A2, B2[4];
   unsigned sc_off[4], sc_aoff = 0x80000000u;
   __amdgpu_buffer_rsrc_t x2r, w2r;
@@ -322,7 +322,14 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
       const unsigned char* hb = lds + (buf ? G::HBUF : 0);
       const int nbuf = buf ^ 1;
       // ---- stage 0 (dz = 0): requests W(ks, 2) then the first half of the next k-step's halo tile ----
-      if (after_out) s1d_wait<NW + G::NST>(); else s1d_wait<NW>();
+      // (SC: the centre-tap pair of THIS k-step, requested after the second group of the stage 1 before, may still be in flight here -- it
+      // sits behind every request this stage needs and ahead of W(ks, 1), so the stage-1 wait below covers it)
+#ifdef S1D_SC_LATE      // A/B build (make variantf FILE=lowp_s1d NAME=sclate EXTRA=-DS1D_SC_LATE): the pair requested in stage 2, as first built
+      constexpr int NSC = 0;
+#else
+      constexpr int NSC = SC ? 5 : 0;
+#endif
+      if (after_out) s1d_wait<NW + NSC + G::NST>(); else s1d_wait<NW + NSC>();
       s1d_barrier();
       after_out = false;
       ldB(Bc, hb, I0(), I0()); ldA(Ac, I0(), I0());
@@ -373,19 +380,30 @@ __global__ __launch_bounds__(512, 2) void lp_s1d_kernel(const LpS1dParams p) {
           for (int v = 0; v < 4; ++v) acc[v] = T::mfma(A2, B2[v], acc[v]);
         }
         __builtin_amdgcn_sched_barrier(0);
+        // ... and the NEXT k-step's pair right away, into the registers just read: behind all of this stage's requests (they went out with
+        // the first two groups), a stage ahead of W(next, 1) -- two and a third stages of flight time before the matrix pipe asks for it
+        // (requested in stage 2, ahead of a wait one third of a k-step later, the pair cost the 128^3 launch 17 %: HBM latency exposed)
+        static_assert(NW + NHB + 1 <= 6, "the stage's requests leave with its first two groups");
+#ifndef S1D_SC_LATE
+        if (last) sc_item(ni, have_next);
+        sc_issue(nks);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
       }
       ldB(Bc, hb, I2(), I0());
       __builtin_amdgcn_sched_barrier(0);
       mm(An, Bn, [&](int i) { hook1(i + 6); });
       // ---- stage 2: W(next k-step, 1) ----
-      s1d_wait<NHA + NW + NHB + 1>();
+      s1d_wait<NHA + NW + NHB + 1 + NSC>();
       s1d_barrier();
       ldA(Ac, I2(), I0());
       const unsigned so2 = w_soff(ncg_, nks, 1, nlive);
-      if constexpr (SC) {      // the next k-step's centre-tap pair (ahead of W(next, 1): covered by the next stage-0 wait)
+#ifdef S1D_SC_LATE
+      if constexpr (SC) {
         if (last) sc_item(ni, have_next);
         sc_issue(nks);
       }
+#endif
       ldB(Bn, hb, I2(), I1()); ldA(An, I2(), I1());
       __builtin_amdgcn_sched_barrier(0);
       mm(Ac, Bc, [&](int i) { if (i < NW) issue_w1(i, so2, 1); });

@@ -13,16 +13,7 @@ static inline int ew_blocks(long n, int per_thread = 1) {
   return (int)b;
 }
 
-__device__ __forceinline__ uint32_t mix32(uint64_t z) {  // splitmix64 finaliser
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
-}
-__device__ __forceinline__ float u01(uint64_t seed, uint64_t i) {  // [0,1)
-  return (float)(mix32(seed * 0xD1342543DE82EF95ull + i) >> 8) * (1.0f / 16777216.0f);
-}
+// (mix32 / u01: common.h -- the 16-bit engine's fused dropout + cast draws from the same generator)
 
 __global__ void dropout_mask_kernel(uint8_t* mask, long n, float rate, uint64_t seed) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)

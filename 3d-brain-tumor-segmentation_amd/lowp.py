@@ -186,6 +186,16 @@ def cast_pad16(code, tdt, src):
     return out
 
 
+def dropout_cast_pad16(code, tdt, src, rate, seed):
+    """dropout (the draw of ops.dropout_mask for the same seed) + cast_pad16 of a dense fp32 (..., C <= 4) volume in one pass"""
+    c = src.shape[-1]
+    if not src.is_contiguous():
+        raise RuntimeError('dropout_cast_pad16: dense volume expected')
+    out = torch.empty(tuple(src.shape[:-1]) + (16,), dtype=tdt, device=src.device)
+    lib().call('bts_lp_dropout_cast_pad16', code, _p(src), _p(out), src.numel() // c, c, float(rate), int(seed) & (2 ** 64 - 1), _stream())
+    return out
+
+
 def uncast(code, src):
     c = src.shape[-1]
     rows = src.numel() // c

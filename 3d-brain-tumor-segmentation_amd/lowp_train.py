@@ -485,6 +485,7 @@ class LowPrecisionTrainer(object):
         ops.fill(m.flat_grads, 0.0)
         # ------------------------------------------------ forward ------------------------------------------------
         xin = x
+        cur = None
         if enc.dropout_rate > 0:                                                      # encoder.py:39,71
             if enc._mask is not None:
                 msk = torch.as_tensor(enc._mask)
@@ -492,11 +493,16 @@ class LowPrecisionTrainer(object):
                     msk = msk.permute(0, 2, 3, 4, 1)
                 msk = (msk != 0).to(torch.uint8).to(dev).contiguous()
                 enc._mask = None
+                xin = ops.dropout_apply(x, msk, enc.dropout_rate)
             else:
                 enc._seed += 1
-                msk = ops.dropout_mask(x.shape, enc.dropout_rate, enc._seed, dev)
-            xin = ops.dropout_apply(x, msk, enc.dropout_rate)
-        if x.shape[-1] <= 4 and xin.is_contiguous():      # in_ch = 2 (model.py:18): one pass writes the whole 16-channel matrix step
+                if x.shape[-1] <= 4:      # the draw, the scaling and the cast into the 16-channel matrix step in one pass (same generator, same seed)
+                    cur = lowp.dropout_cast_pad16(code, tdt, x, enc.dropout_rate, enc._seed)
+                else:
+                    xin = ops.dropout_apply(x, ops.dropout_mask(x.shape, enc.dropout_rate, enc._seed, dev), enc.dropout_rate)
+        if cur is not None:
+            pass
+        elif x.shape[-1] <= 4 and xin.is_contiguous():      # in_ch = 2 (model.py:18): one pass writes the whole 16-channel matrix step
             cur = lowp.cast_pad16(code, tdt, xin)
         else:
             cpad = (x.shape[-1] + 15) // 16 * 16

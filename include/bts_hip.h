@@ -308,6 +308,10 @@ int bts_lp_conv3d_bwd_weight(int kind, int dtype, const void* x, const void* dy,
                              bts_stream_t stream);
 /* fp32 <-> storage type, `rows` rows of C elements with row strides (the 2-channel input block runs in fp32: K = 16 is its floor) */
 int bts_lp_cast(int dtype, const float* src, long ld_src, void* dst, long ld_dst, long rows, int C, bts_stream_t stream);
+/* encoder.py:39,71 (Dropout(rate) on the input volume) AND the cast of the dense (rows, C <= 4) fp32 volume into the zero-padded 16-channel
+ * matrix step, in one pass: element i is kept (scaled by 1 / (1 - rate)) where bts_dropout_mask's generator says so for the same (seed, i)
+ * -- bit-identical to bts_dropout_mask + bts_dropout_apply + bts_lp_cast_pad16, without the mask and the dropped volume being written */
+int bts_lp_dropout_cast_pad16(int dtype, const float* src, void* dst, long rows, int C, float rate, uint64_t seed, bts_stream_t stream);
 int bts_lp_uncast(int dtype, const void* src, long ld_src, float* dst, long ld_dst, long rows, int C, bts_stream_t stream);
 /* fp32 rows of C <= 4 channels -> dense storage-type rows of 16 channels with a zero tail, in one pass: the 2-channel input volume
  * (model.py:58, after encoder.py:71's dropout), the 2-channel VAE-output gradient and the 1-channel VAE tensor (vae.py:110-111) as

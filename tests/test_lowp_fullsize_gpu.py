@@ -121,7 +121,11 @@ def test_16bit_step_at_128_cubed_against_the_fp32_engine(dtype, N, lim):
         # the rest of the plan at this batch: streaming 1x1x1 kernel (shortcuts, their data gradients), the LDS-tiled stride-2 conv of
         # the 32-channel level, the merged transposed form, the transposing-read weight gradients of the samplers
         if os.environ.get('BTS_LP_K1') != '0':
-            assert counts.get('lp_k1_kernel', 0) >= 20, counts
+            # (round 6: the 16 shortcut DATA gradients ride on conv1's data-gradient launches (bts_lp_conv3d_bwd_data_sc) and the two
+            # top-level shortcuts of the z-marching kernel's layers on conv1's forward (bts_lp_conv3d_fwd_gn_shortcut): 32 -> ~15 launches
+            # of the streaming 1x1x1 kernel -- the forward shortcuts of the other 14 blocks and the head; more than 18 would mean one of
+            # the fused forms no longer takes its layers)
+            assert 12 <= counts.get('lp_k1_kernel', 0) <= 18 or os.environ.get('BTS_LP_SC') == '0' or os.environ.get('BTS_LP_FS') == '0', counts
         if os.environ.get('BTS_LP_S2T') != '0':
             assert counts.get('lp_s2t_kernel', 0) >= 1, counts
         if os.environ.get('BTS_LP_UP') != '0':

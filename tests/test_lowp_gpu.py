@@ -1022,3 +1022,27 @@ def test_inference_forward_with_and_without_the_first_block_kernel(monkeypatch):
     d = (y1 - y0).abs()
     assert float(d.max()) <= 5e-3 and float(d.mean()) <= 2e-4, (float(d.max()), float(d.mean()))
     assert float((y1.argmax(-1) != y0.argmax(-1)).float().mean()) <= 2e-3
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'bfloat16'])
+@pytest.mark.parametrize('c', [1, 2, 3])
+def test_dropout_and_cast_in_one_pass_equal_the_three_passes(dtype, c):
+    """encoder.py:39,71 on the way into the first block: bts_lp_dropout_cast_pad16 draws what bts_dropout_mask draws for the same seed
+    (checked against the mask itself: kept elements scaled by 1 / (1 - rate), dropped ones zero, the 16-channel tail zero) and is
+    bit-identical to bts_dropout_mask + bts_dropout_apply + bts_lp_cast_pad16"""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    code, tdt = lowp.DTYPES[dtype]
+    dev = torch.device('cuda', 0)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 9, 10, 11, c), generator=g).to(dev)
+    rate, seed = 0.2, 12345
+    mask = ops.dropout_mask(x.shape, rate, seed, dev)
+    want = lowp.cast_pad16(code, tdt, ops.dropout_apply(x, mask, rate))
+    got = lowp.dropout_cast_pad16(code, tdt, x, rate, seed)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    keep = mask.bool()
+    assert 0.7 < float(keep.float().mean()) < 0.9
+    ref = torch.where(keep, x * (1.0 / (1.0 - rate)), torch.zeros_like(x)).to(tdt)
+    assert torch.equal(got[..., :c], ref) and bool((got[..., c:] == 0).all())
