@@ -1470,7 +1470,13 @@ __global__ __launch_bounds__(256) void lp_dropout_cast_pad16_kernel(const float*
   for (long r = blockIdx.x * 256L + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
     float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < C; ++c) v[c] = u01(seed, (uint64_t)(r * C + c)) >= rate ? src[r * C + c] * scale : 0.f;
+    for (int c = 0; c < C; ++c) {
+      // (the product must be rounded to fp32 BEFORE the cast, as the three-pass route stores it: left to the compiler -- __fmul_rn
+      // included -- multiply and fp16 conversion become one mixed-precision instruction, rounded once: 1 element in 30,000 differs)
+      float pr = src[r * C + c] * scale;
+      asm volatile("" : "+v"(pr));
+      v[c] = u01(seed, (uint64_t)(r * C + c)) >= rate ? pr : 0.f;
+    }
     u32x4* o = reinterpret_cast<u32x4*>(dst + r * 16);
     o[0] = u32x4{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), 0u, 0u};
     o[1] = u32x4{0u, 0u, 0u, 0u};
