@@ -3078,7 +3078,7 @@ __global__ __launch_bounds__(256) void lp_wgrad_finalize_kernel(const LpWfParams
       c = (int)(r % f.Cp);
       t = (int)(r / f.Cp);
       const int cpt = c / 32, row = c % 32, cqg = k / (32 * f.NQ), col = k % (32 * f.NQ);
-      const int s0 = f.ntaps == 27 ? t : 0, s1 = f.ntaps == 27 ? t + 1 : 8;
+      const int s0 = f.ntaps == 27 ? t : 0, s1 = f.ntaps == 27 ? t + 1 : f.nslot;      // (1x1x1: the general kernel's 8 wave slots, the streaming kernel's one)
       for (int wg = sl; wg < f.nwg; wg += 8) {
         const float* pb = f.part + (((long)wg * f.ncp + cpt) * f.ncqg + cqg) * (long)f.nslot * 32 * (32 * f.NQ);
         for (int q = s0; q < s1; ++q) s += pb[((long)q * 32 + row) * (32 * f.NQ) + col];
@@ -3175,7 +3175,8 @@ int bts_lp_wgs_launch_(int dtype, const void* P, const void* Q, float* dw, void*
 // lowp_wgd.hip: the streaming weight-gradient kernel of the stride-1 3x3x3 convolutions with Cout <= 32
 long bts_lp_wgd_workspace_(int N, int D, int H, int W, int Cp, int Cq);
 int bts_lp_wgd_launch_(int dtype, const void* x, const void* dy, float* dw, void* ws, long ws_bytes, int N, int D, int H, int W, int Cp, int ldp,
-                       int Cq, int ldq, int dup_start, int dup_shift, int accum, hipStream_t stream, const LpGnaFuse* ga = nullptr);
+                       int Cq, int ldq, int dup_start, int dup_shift, int accum, hipStream_t stream, const LpGnaFuse* ga = nullptr,
+                       const void* dy2 = nullptr, float* dw1 = nullptr, int lddy2 = 0);
 bool bts_lp_wgd_gna_ok_(int N, int D, int H, int W, int Cp, int Cq, int in_G);
 // db[k] (+)= sum_n colsum[n][k]
 __global__ void lp_bias_grad_kernel(const float* cs, float* db, int N, int C, int accum) {
@@ -3317,6 +3318,48 @@ extern "C" int bts_lp_conv3d_bwd_weight(int kind, int dtype, const void* x, cons
     const int r = bts_lp_colsum(dtype, dy, cs, cws, bts_lp_colsum_workspace(N, (long)D * H * W, Cout), N, (long)D * H * W, Cout, 1.0f, stream);
     if (r != BTS_OK) return r;
     hipLaunchKernelGGL(lp_bias_grad_kernel, dim3((Cout + 255) / 256), dim3(256), 0, stream, cs, db, N, Cout, accumulate);
+    BTS_LAUNCH_CHECK();
+  }
+  return BTS_OK;
+}
+// The weight gradients of the TWO convolutions that read a ResnetBlock's input (resnet.py:134 conv1, 3x3x3; resnet.py:118 shortcut, 1x1x1)
+// from ONE pass over that input: dw3[t][c][k] (+)= sum_v x[v + off_t][c] dy3[v][k] and dw1[c][k] (+)= sum_v x[v][c] dy1[v][k].  The streaming
+// weight-gradient kernel (lowp_wgd.hip) holds a P fragment of the centre tap anyway; the shortcut's gradient is one more accumulator per
+// wave fed by planes of dy1 that ride in the Q-ring slots the 3x3x3 contraction no longer needs (its older planes live in registers).
+// The 1x1x1 weight-gradient launch -- HBM-bound, its own read of the Cin-wide x -- goes away.  db3 (may be NULL; dy3 dense then) (+)= sum dy3.
+// Same conventions as bts_lp_conv3d_bwd_weight (dup_start / dup_shift fold both kernels alike).  The workspace query returns -1 and the
+// call 1 (nothing launched) where the streaming kernel does not take the shape: run bts_lp_conv3d_bwd_weight twice.  BTS_LP_K1F=0: never.
+extern "C" long bts_lp_conv3d_bwd_weight_pair_workspace(int N, int D, int H, int W, int Cin, int Cout) {
+  static const bool off = [] { const char* e = getenv("BTS_LP_K1F"); return e && atoi(e) == 0; }();
+  if (off || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin % 8 != 0 || Cout % 8 != 0) return -1;
+  const long alt = bts_lp_wgd_workspace_(N, D, H, W, Cin, Cout);
+  if (alt <= 0) return -1;
+  const long part = ((alt / 27 * 28 + 255) & ~255L);
+  return part + (long)N * ((Cout + 7) / 8 * 8) * 4 + bts_lp_colsum_workspace(N, (long)D * H * W, (Cout + 7) / 8 * 8) + 512;
+}
+extern "C" int bts_lp_conv3d_bwd_weight_pair(int dtype, const void* x, const void* dy3, const void* dy1, float* dw3, float* dw1, float* db3,
+                                             void* workspace, long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout,
+                                             int lddy3, int lddy1, int dup_start, int dup_shift, int accumulate, hipStream_t stream) {
+  if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
+  const long need = bts_lp_conv3d_bwd_weight_pair_workspace(N, D, H, W, Cin, Cout);
+  if (need < 0) return 1;
+  if (x == nullptr || dy3 == nullptr || dy1 == nullptr || dw3 == nullptr || dw1 == nullptr) return BTS_ERR_ALIGN;
+  if (ldx % 8 != 0 || lddy3 % 8 != 0 || lddy1 % 8 != 0 || ldx < Cin || lddy3 < Cout || lddy1 < Cout) return BTS_ERR_SHAPE;
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)dy3) & 15) || (((uintptr_t)dy1) & 15) || (((uintptr_t)workspace) & 15)) return BTS_ERR_ALIGN;
+  if (dup_shift < 0 || (dup_shift > 0 && dup_start + dup_shift > Cin)) return BTS_ERR_SHAPE;
+  if (workspace == nullptr || workspace_bytes < need) return BTS_ERR_WORKSPACE;
+  if (db3 != nullptr && lddy3 != Cout) return BTS_ERR_UNSUPPORTED;
+  const long part_bytes = ((bts_lp_wgd_workspace_(N, D, H, W, Cin, Cout) / 27 * 28 + 255) & ~255L);
+  const int r = bts_lp_wgd_launch_(dtype, x, dy3, dw3, workspace, part_bytes, N, D, H, W, Cin, ldx, Cout, lddy3, dup_start, dup_shift, accumulate, stream,
+                                   nullptr, dy1, dw1, lddy1);
+  if (r != BTS_OK) return r;      // (1: declined, nothing launched)
+  if (db3 != nullptr) {
+    char* wsb = reinterpret_cast<char*>(workspace) + part_bytes;
+    float* cs = reinterpret_cast<float*>(wsb);
+    void* cws = wsb + (((long)N * Cout * 4 + 255) & ~255L);
+    const int r2 = bts_lp_colsum(dtype, dy3, cs, cws, bts_lp_colsum_workspace(N, (long)D * H * W, Cout), N, (long)D * H * W, Cout, 1.0f, stream);
+    if (r2 != BTS_OK) return r2;
+    hipLaunchKernelGGL(lp_bias_grad_kernel, dim3((Cout + 255) / 256), dim3(256), 0, stream, cs, db3, N, Cout, accumulate);
     BTS_LAUNCH_CHECK();
   }
   return BTS_OK;

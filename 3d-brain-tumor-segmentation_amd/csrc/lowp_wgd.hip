@@ -47,6 +47,12 @@ struct LpWgdParams {
   int nitems, ipw, ncp, ncq, xcd_order;
   LpGnaFuse ga;              // GNA kernels: P is the RAW GroupNorm input; relu(GroupNorm(P)) is formed on the planes in LDS (lowp_common.h)
   int ga_zt;                 // planes per group
+  // K1F kernels: the 1x1x1 weight gradient of a SECOND convolution that reads the same input (resnet.py:118 shortcut next to resnet.py:134
+  // conv1): dW1[c][k] = sum_v P[v][c] * Q2[v][k], Q2 = the gradient of the shortcut's output -- one more accumulator per wave, fed by the P
+  // fragments of the centre tap this kernel reads anyway: the 1x1x1 weight-gradient launch and its own pass over P go away
+  const unsigned short* q2;  // (N, D, H, W, Cq) voxel stride ldq2
+  float* part2;              // [workgroup][cp block][cq block][32][32]
+  int ldq2;
 };
 #define WGD_TX 32
 #define WGD_TY 8
@@ -85,7 +91,7 @@ template <> struct Mfma16<TBF16> {
   }
 };
 
-template <typename T, bool GNA = false>
+template <typename T, bool GNA = false, bool K1F = false>
 __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // (see lp_s1d_kernel: the host pass drops the launch stub of this template otherwise)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -99,9 +105,10 @@ __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
   // pieces of 16 slots of a P plane, 25..40 = Q rows x 2 segments, 41..47 = fillers (out of range: no traffic, 1 KB of scratch) ----
   const int vi = lane >> 2, pos = lane & 3;
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;      // LDS byte address of the dynamic segment
-  u32x4 pr, qr;
+  u32x4 pr, qr, q2r;
   unsigned voff[6];               // this lane's byte offset inside a plane for request j of the current item (bit 31: masked = zeros)
-  unsigned pplane, qplane;        // bytes per plane
+  unsigned voff2[2];              // K1F: the same for this wave's two requests of a Q2 plane (16 = rows x 2 segments: id j * 8 + wave)
+  unsigned pplane, qplane, q2plane = 0;        // bytes per plane
   int zlo = 0, zhi = 0;
   unsigned ga_ok = 0;
   int ga_n = 0, ga_g = -1;
@@ -128,6 +135,16 @@ __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
     const long qvox = ((long)n * p.D * p.H + y0) * p.W + x0;
     pr = wgd_rsrc(p.p + pvox * p.ldp);
     qr = wgd_rsrc(p.q + qvox * p.ldq);
+    if constexpr (K1F) {
+      q2r = wgd_rsrc(p.q2 + qvox * p.ldq2);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int qi = j * 8 + wave;
+        const int row = qi >> 1, xl = (qi & 1) * 16 + vi;
+        const int oct = pos ^ (2 * ((xl >> 3) & 1));
+        voff2[j] = (cq0 + oct * 8 < p.Cq && x0 + xl < p.W && y0 + row < p.H) ? (unsigned)(((row * p.W + xl) * p.ldq2 + cq0 + oct * 8) * 2) : 0x80000000u;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const int id = j * 8 + wave;
@@ -222,6 +239,20 @@ __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
       wgd_dma16(pr, lds0 + (unsigned)(live ? r.pbuf * WGD_PPL + dst_of(j) : WGD_SCR), (live && r.pok) ? voff[j] : 0x80000000u, r.pso);
     }
   };
+  // K1F: Q2 plane z2 -> Q-ring slot `slot` (the slot of Q plane z2 - 1, dead since the stage before last: the Q fragments of a plane live in
+  // registers after their first stage).  ONE stage ahead, so these two requests open a stage: the counted wait at its end leaves exactly the
+  // stage's six two-ahead requests in flight and has these behind it.
+  auto issue_q2 = [&](int z2, int slot) {
+    if constexpr (K1F) {
+      const bool ok = z2 >= zlo && z2 < zhi;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int qi = j * 8 + wave;
+        wgd_dma16(q2r, lds0 + (unsigned)(WGD_QBASE + slot * WGD_QPL + (qi >> 1) * WGD_QROW + (qi & 1) * 1024), ok ? voff2[j] : 0x80000000u,
+                  ok ? (unsigned)z2 * q2plane : 0u);
+      }
+    }
+  };
   auto issue = [&](int zq, int qslot, int zp, int pbuf, bool want_p) {
     const StageReq r = make_req(zq, qslot, zp, pbuf, want_p);
 #pragma unroll
@@ -252,9 +283,11 @@ __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
   f32x4 acc[27];
 #pragma unroll
   for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};      // K1F: the 1x1x1 tap
 
   pplane = (unsigned)(p.H * p.W * p.ldp * 2);
   qplane = (unsigned)(p.H * p.W * p.ldq * 2);
+  if constexpr (K1F) q2plane = (unsigned)(p.H * p.W * p.ldq2 * 2);
   const int w = blockIdx.x;
   int it0 = w * p.ipw;
   if (p.xcd_order) it0 = ((w & 7) * (gridDim.x >> 3) + (w >> 3)) * p.ipw;      // consecutive item ranges stay on one XCD (its L2 holds the halos)
@@ -266,8 +299,14 @@ __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
   u32x4 pf[3];
   // One stage, straight-line: 18 steps (P row, x tap) of 3..9 matrix instructions; P fragments are read two steps ahead, the new Q
   // plane's rows just before their first use, the six requests of the stage after next are dealt over the steps.
-  auto stage = [&](auto rotc, const unsigned char* pb, const unsigned char* qnew, const StageReq& rq) {
+  auto stage = [&](auto rotc, const unsigned char* pb, const unsigned char* qnew, const StageReq& rq, const unsigned char* q2p) {
     constexpr int R = decltype(rotc)::value;
+    // K1F: row qrow of the Q2 plane of THIS stage's P plane (same layout and offsets as a Q plane)
+    auto rdq2 = [&](int qrow) -> u32x4 {
+      const u32x2 lo = trd(q2p + qoff[0] + qrow * WGD_QROW), hi = trd(q2p + qoff[1] + qrow * WGD_QROW);
+      return u32x4{lo[0], lo[1], hi[0], hi[1]};
+    };
+    u32x4 q2f = u32x4{0u, 0u, 0u, 0u};
     auto rdp = [&](int st) -> u32x4 {
       const int prow = st / 3, kx = st - prow * 3;
       const unsigned sw = (prow & 1) ? 32u : 0u;
@@ -302,6 +341,10 @@ __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
       if (st == 1 || st == 4 || st == 7 || st == 10 || st == 13) issue1(rq, (st + 2) / 3);
 #endif
       const u32x4 a = pf[st % 3];
+      if constexpr (K1F) {      // centre tap (ky = 1, kx = 1) of the 1x1x1 conv: P row prow against Q2 row prow - 1 of the same plane
+        if (kx == 0 && prow >= 1 && prow <= 4) q2f = rdq2(prow - 1);        // (read one step ahead of its use)
+        if (kx == 1 && prow >= 1 && prow <= 4) acc1 = Mfma16<T>::run(a, q2f, acc1);
+      }
       // resident planes first: the new plane's fragments (kz 0) have had the longest to arrive by the time they are used
 #pragma unroll
       for (int kz = 2; kz >= 0; --kz)
@@ -347,7 +390,10 @@ __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
       const unsigned char* pb = lds + pb_i * WGD_PPL;
       int sl = qs + 2; if (sl >= WGD_NQS) sl -= WGD_NQS;
       const unsigned char* qnew = lds + sl * WGD_QPL;
-      stage(WgdIC<0>{}, pb, qnew, rq);
+      // K1F: this stage's Q2 plane zp sits in the slot of Q plane zp - 1 (qs); plane zp + 1 is requested NOW into the slot of Q plane zp
+      // (dead since the barrier that ended the stage before: Q planes are read from LDS once, in the stage they are new)
+      if constexpr (K1F) { int q2n = qs + 1; if (q2n >= WGD_NQS) q2n -= WGD_NQS; issue_q2(zp + 1, q2n); }
+      stage(WgdIC<0>{}, pb, qnew, rq, lds + qs * WGD_QPL);
 #pragma unroll
       for (int qrow = 0; qrow < 4; ++qrow) { qfp[2][qrow] = qfp[1][qrow]; qfp[1][qrow] = qfp[0][qrow]; }
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // the next stage's planes have landed; this stage's requests stay in flight
@@ -383,6 +429,19 @@ __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
     for (int t = 0; t < 27; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) pbw[(t * 32 + row0 + r) * 32 + col] = acc[t][r] + xl[(t * 32 + row0 + r) * 32 + col];
+  }
+  if constexpr (K1F) {      // the 1x1x1 tap: the same meeting of the two row halves, one more [32][32] slab per (workgroup, cp, cq)
+    __syncthreads();
+    if (hv == 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xl[(row0 + r) * 32 + col] = acc1[r];
+    }
+    __syncthreads();
+    if (hv == 0) {
+      float* pb1 = p.part2 + (((long)blockIdx.x * p.ncp + cpt) * p.ncq + cqt) * 1024L;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pb1[(row0 + r) * 32 + col] = acc1[r] + xl[(row0 + r) * 32 + col];
+    }
   }
 #endif
 }
@@ -433,22 +492,31 @@ bool bts_lp_wgd_gna_ok_(int N, int D, int H, int W, int Cp, int Cq, int in_G) {
   return cg <= 8 && 8 % cg == 0;
 }
 // BTS_OK = ran (dw written by the shared finalize), 1 = declined
+// dy2 / dw1 / lddy2 (may be NULL / 0): the K1F form -- dw1 (Keras layout (1,1,1,Cin_ref,Cout)) (+)= the 1x1x1 weight gradient of a second conv
+// on the same input, from dy2 (N,D,H,W,Cq); its partial slabs sit behind the 27-tap ones in `ws` (bts_lp_wgd_workspace_ x 28 / 27)
 int bts_lp_wgd_launch_(int dtype, const void* x, const void* dy, float* dw, void* ws, long ws_bytes, int N, int D, int H, int W, int Cp, int ldp,
-                       int Cq, int ldq, int dup_start, int dup_shift, int accum, hipStream_t stream, const LpGnaFuse* ga) {
+                       int Cq, int ldq, int dup_start, int dup_shift, int accum, hipStream_t stream, const LpGnaFuse* ga, const void* dy2,
+                       float* dw1, int lddy2) {
   WgdPlan pl;
   if (!wgd_plan(pl, N, D, H, W, Cp, ldp, Cq, ldq)) return 1;
   if (ga != nullptr && (ldp != Cp || dup_shift != 0 || !bts_lp_wgd_gna_ok_(N, D, H, W, Cp, Cq, ga->G) || ga->cg != Cp / ga->G)) return 1;
-  if (ws_bytes < (long)pl.nwg * pl.ncp * pl.ncq * 27 * 1024 * 4) return 1;
+  const bool k1f = dy2 != nullptr;
+  if (k1f && (ga != nullptr || dw1 == nullptr || lddy2 < Cq || lddy2 % 8 != 0 || (((uintptr_t)dy2) & 15) ||
+              (long)D * H * W * (long)lddy2 * 2 >= 0x7fffffffL))
+    return 1;
+  if (ws_bytes < (long)pl.nwg * pl.ncp * pl.ncq * (k1f ? 28 : 27) * 1024 * 4) return 1;
   LpWgdParams p;
   p.p = (const unsigned short*)x; p.q = (const unsigned short*)dy; p.part = reinterpret_cast<float*>(ws);
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cp = Cp; p.ldp = ldp; p.Cq = Cq; p.ldq = ldq;
   p.ntx = pl.ntx; p.nty = pl.nty; p.nzc = pl.nzc; p.ZC = pl.ZC; p.nitems = pl.nitems; p.ipw = pl.ipw; p.ncp = pl.ncp; p.ncq = pl.ncq; p.xcd_order = pl.xcd;
   if (ga != nullptr) { p.ga = *ga; p.ga_zt = D / ga->G; } else { p.ga = LpGnaFuse{}; p.ga_zt = 1; }
+  p.q2 = (const unsigned short*)dy2; p.ldq2 = lddy2;
+  p.part2 = p.part + (long)pl.nwg * pl.ncp * pl.ncq * 27 * 1024;
   (void)hipGetLastError();
-#define WGD_LAUNCH(TT) do { if (ga != nullptr) WGD_LAUNCH_(TT, true); else WGD_LAUNCH_(TT, false); } while (0)
-#define WGD_LAUNCH_(TT, GA_)                                                                                                 \
+#define WGD_LAUNCH(TT) do { if (ga != nullptr) WGD_LAUNCH_(TT, true, false); else if (k1f) WGD_LAUNCH_(TT, false, true); else WGD_LAUNCH_(TT, false, false); } while (0)
+#define WGD_LAUNCH_(TT, GA_, K1_)                                                                                            \
   do {                                                                                                                       \
-    auto kern = lp_wgd_kernel<TT, GA_>;                                                                                      \
+    auto kern = lp_wgd_kernel<TT, GA_, K1_>;                                                                                   \
     static bool done = false;                                                                                                \
     if (!done) {                                                                                                             \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WGD_LDS); \
@@ -458,11 +526,13 @@ int bts_lp_wgd_launch_(int dtype, const void* x, const void* dy, float* dw, void
     hipLaunchKernelGGL(kern, dim3(pl.nwg, pl.ncp, pl.ncq), dim3(512), WGD_LDS, stream, p);                                           \
   } while (0)
   const bool prof = bts_prof_on();
-  if (prof) bts_prof_begin(37, 2.0 * 27.0 * (double)Cp * Cq * (double)N * D * H * W, stream);
+  if (prof) bts_prof_begin(37, 2.0 * (k1f ? 28.0 : 27.0) * (double)Cp * Cq * (double)N * D * H * W, stream);
   if (dtype == LP_F16) WGD_LAUNCH(TF16); else WGD_LAUNCH(TBF16);
 #undef WGD_LAUNCH
 #undef WGD_LAUNCH_
   if (prof) bts_prof_end(stream);
   BTS_LAUNCH_CHECK();
-  return bts_lp_wgrad_finalize_(p.part, dw, pl.nwg, pl.ncp, pl.ncq, 27, 27, 1, Cp, Cq, Cp + dup_shift, dup_start, dup_shift, accum, stream);
+  const int r = bts_lp_wgrad_finalize_(p.part, dw, pl.nwg, pl.ncp, pl.ncq, 27, 27, 1, Cp, Cq, Cp + dup_shift, dup_start, dup_shift, accum, stream);
+  if (r != BTS_OK || !k1f) return r;
+  return bts_lp_wgrad_finalize_(p.part2, dw1, pl.nwg, pl.ncp, pl.ncq, 1, 1, 1, Cp, Cq, Cp + dup_shift, dup_start, dup_shift, accum, stream);
 }

@@ -168,6 +168,27 @@ def conv_bwd_weight(kind, code, x, dy, dw, db, dup_start=0, dup_shift=0, accumul
     return True
 
 
+def conv_bwd_weight_pair(code, x, dy3, dy1, dw3, dw1, db3, dup_start=0, dup_shift=0, accumulate=True):
+    """The weight gradients of conv1 (3x3x3, from dy3) and of the shortcut (1x1x1, from dy1) of a ResnetBlock -- both read the block input x
+    (resnet.py:118,134) -- from ONE pass over x (bts_lp_conv3d_bwd_weight_pair) -> True, or False (nothing launched) where the streaming
+    kernel does not take the shape: the caller runs conv_bwd_weight twice"""
+    n, d, h, w, cin = x.shape
+    cout = dy3.shape[-1]
+    if tuple(dy1.shape) != tuple(dy3.shape) or not wgrad_supported(ops.K3S1, cin, cout) or (db3 is not None and not dy3.is_contiguous()):
+        return False
+    nb = lib().probe('bts_lp_conv3d_bwd_weight_pair_workspace', n, d, h, w, cin, cout)
+    if nb < 0:
+        return False
+    ws = ops.workspace(nb, x.device)
+    r = lib().probe('bts_lp_conv3d_bwd_weight_pair', code, _p(x), _p(dy3), _p(dy1), _p(dw3), _p(dw1), _p(db3) if db3 is not None else None, _p(ws),
+                    nb, n, d, h, w, cin, _ld(x), cout, _ld(dy3), _ld(dy1), dup_start, dup_shift, 1 if accumulate else 0, _stream())
+    if r == 1:
+        return False
+    if r != 0:
+        raise RuntimeError('bts_lp_conv3d_bwd_weight_pair failed: %s' % ERRORS.get(r, 'hipError %d' % r))
+    return True
+
+
 def cast(code, tdt, src, out=None):
     c = src.shape[-1]
     rows = src.numel() // c

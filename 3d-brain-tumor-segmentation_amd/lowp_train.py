@@ -347,14 +347,20 @@ class LowPrecisionTrainer(object):
             def wgrads():
                 tk = torch.empty((3, 3, 3, x.shape[-1], f), dtype=torch.float32, device=x.device)
                 tp = torch.empty((1, 1, 1, x.shape[-1], f), dtype=torch.float32, device=x.device)
-                _wgrad16(ops.K3S1, code, x, dc1_16, tk, db1, 0, 0, False)
-                _wgrad16(ops.K1, code, x, dres_16, tp, None, 0, 0, False)
+                # (both from one pass over x where the streaming kernel takes the layer: see the branch below)
+                if not lowp.conv_bwd_weight_pair(code, x, dc1_16, dres_16, tk, tp, db1, 0, 0, False):
+                    _wgrad16(ops.K3S1, code, x, dc1_16, tk, db1, 0, 0, False)
+                    _wgrad16(ops.K1, code, x, dres_16, tp, None, 0, 0, False)
                 # live rows of the padded gradients into the real slots (library kernel: rows = taps, columns = the cin_slab x f prefix)
                 ops.add_strided(self._gslot(blk.conv1_k).view(27, cin_slab * f), tk.view(27, -1)[:, :cin_slab * f], True)
                 ops.add_strided(self._gslot(blk.ptwise_k).view(1, cin_slab * f), tp.view(1, -1)[:, :cin_slab * f], True)
             self._wg((x, dc1_16, dres_16), wgrads)
         elif lp1:
             def wgrads():
+                # conv1's and the shortcut's weight gradients from ONE pass over the block input (round 6: the 1x1x1 gradient is one more
+                # accumulator of the streaming 3x3x3 kernel; bts_lp_conv3d_bwd_weight_pair) where that kernel takes the layer
+                if lowp.conv_bwd_weight_pair(code, x, dc1_16, dres_16, self._gslot(blk.conv1_k), self._gslot(blk.ptwise_k), db1, dup_start, dup_shift, True):
+                    return
                 _wgrad16(ops.K3S1, code, x, dc1_16, self._gslot(blk.conv1_k), db1, dup_start, dup_shift, True)
                 _wgrad16(ops.K1, code, x, dres_16, self._gslot(blk.ptwise_k), None, dup_start, dup_shift, True)   # (bias: se_bwd)
             self._wg((x, dc1_16, dres_16), wgrads)

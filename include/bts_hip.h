@@ -298,6 +298,16 @@ int bts_lp_conv3d_bwd_data_sc_split_ok(int N, int D, int H, int W, int Cin, int 
 int bts_lp_conv3d_bwd_data_sc(int dtype, const void* dy, const void* wp_bwd, const void* dy2, const void* wp2_bwd, void* dx, long dx_split,
                               void* workspace, long workspace_bytes, int N, int D, int H, int W, int Cin, int lddx, int Cout, int lddy,
                               int lddy2, int accum, int* fused, bts_stream_t stream);
+/* The weight gradients of the TWO convolutions that read a ResnetBlock's input (resnet.py:134 conv1, 3x3x3; resnet.py:118 shortcut, 1x1x1)
+ * from ONE pass over that input (train.py:151): dw3 (+)= from dy3 as bts_lp_conv3d_bwd_weight(K3S1), dw1 (Keras layout (1,1,1,Cin_ref,Cout))
+ * (+)= sum_v x[v][c] dy1[v][k] -- one more accumulator per wave of the streaming kernel, fed by the centre-tap fragments of x it reads anyway;
+ * the HBM-bound 1x1x1 weight-gradient launch and its own read of the Cin-wide x go away.  db3 (may be NULL; dy3 dense then) (+)= sum dy3.
+ * dup_start / dup_shift fold both kernels alike.  Workspace query -1 / return value 1 (nothing launched) outside the streaming kernel's
+ * shapes (W % 32, H % 8, large volumes): run bts_lp_conv3d_bwd_weight twice.  BTS_LP_K1F=0 in the environment: never (A/B aid) */
+long bts_lp_conv3d_bwd_weight_pair_workspace(int N, int D, int H, int W, int Cin, int Cout);
+int bts_lp_conv3d_bwd_weight_pair(int dtype, const void* x, const void* dy3, const void* dy1, float* dw3, float* dw1, float* db3, void* workspace,
+                                  long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int lddy3, int lddy1,
+                                  int dup_start, int dup_shift, int accumulate, bts_stream_t stream);
 /* dw (fp32, Keras layout (kd,kh,kw,Cin_ref,Cout)) (+)= the weight gradient of a stride-1 3x3x3 / 1x1x1 conv from 16-bit x and dy
  * (voxel contraction on the 16-bit matrix pipe, fp32 partials, fixed-order finalize); db (may be NULL; dy dense then) (+)= sum dy.
  * dup_start / dup_shift as bts_conv_pack: Cin + dup_shift == Cin_ref, both copies of the folded slice receive the gradient.
