@@ -1136,9 +1136,27 @@ extern "C" long bts_lp_conv3d_fwd_gn_workspace(int N, int D, int H, int W, int C
   const long stats = bts_lp_gn_workspace(N, (long)D * H * W, Cout, G);
   return conv + (fused > stats ? fused : stats) + 64;
 }
+static int lp_conv3d_fwd_gn_impl(int dtype, const void* x, const void* wp, const float* bias, void* y, float* mean, float* rstd,
+                                 void* workspace, long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int G,
+                                 float eps, int accum, hipStream_t stream);
 extern "C" int bts_lp_conv3d_fwd_gn(int dtype, const void* x, const void* wp, const float* bias, void* y, float* mean, float* rstd,
                                     void* workspace, long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int G,
                                     float eps, hipStream_t stream) {
+  return lp_conv3d_fwd_gn_impl(dtype, x, wp, bias, y, mean, rstd, workspace, workspace_bytes, N, D, H, W, Cin, ldx, Cout, G, eps, 0, stream);
+}
+// The same, ADDING the convolution to what y already holds (accumulate != 0), the statistics taken of the final sums: a contraction
+// split over its input channels whose parts become available at different times -- the decoder's conv1 over [skip | up-sampled]
+// (decoder.py:75, resnet.py:134): the skip part (with the bias) can run as soon as the encoder level is done, the up-sampled part adds to
+// it later (pass bias = NULL then).  The partial sum passes through the storage type once (as in the two-pass form of lowp_s1z.hip).
+extern "C" int bts_lp_conv3d_fwd_gn_acc(int dtype, const void* x, const void* wp, const float* bias, void* y, float* mean, float* rstd,
+                                        void* workspace, long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int G,
+                                        float eps, int accumulate, hipStream_t stream) {
+  return lp_conv3d_fwd_gn_impl(dtype, x, wp, bias, y, mean, rstd, workspace, workspace_bytes, N, D, H, W, Cin, ldx, Cout, G, eps, accumulate ? 1 : 0,
+                               stream);
+}
+static int lp_conv3d_fwd_gn_impl(int dtype, const void* x, const void* wp, const float* bias, void* y, float* mean, float* rstd,
+                                 void* workspace, long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int G,
+                                 float eps, int accum, hipStream_t stream) {
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || G <= 0 || Cout % G != 0) return BTS_ERR_SHAPE;
   if (workspace == nullptr || workspace_bytes < bts_lp_conv3d_fwd_gn_workspace(N, D, H, W, Cin, Cout, G) || (((uintptr_t)workspace) & 15))
     return BTS_ERR_WORKSPACE;
@@ -1146,13 +1164,16 @@ extern "C" int bts_lp_conv3d_fwd_gn(int dtype, const void* x, const void* wp, co
   char* tail = reinterpret_cast<char*>(workspace) + conv_ws;
   const long V = (long)D * H * W;
   long B = 0;
-  if (lp_s1_gn_plan(N, D, H, W, Cin, Cout, G, &B)) {
+  // (accumulating: the split-K finish writes y from its partial sums and cannot add to it with statistics -- such grids take the
+  // statistics from the stored result)
+  const bool split = bts_lp_s1z_gn_B_(N, D, H, W, Cin, Cout, 1) <= 0 && bts_lp_s1d_workspace_(N, D, H, W, Cin, Cout) > 0;
+  if (!(accum && split) && lp_s1_gn_plan(N, D, H, W, Cin, Cout, G, &B)) {
     double* part = reinterpret_cast<double*>(tail);
-    const int r = lp_conv_run(1, dtype, x, wp, bias, y, workspace, conv_ws, N, D, H, W, Cin, ldx, Cout, Cout, 0, stream, nullptr, part, G);
+    const int r = lp_conv_run(1, dtype, x, wp, bias, y, workspace, conv_ws, N, D, H, W, Cin, ldx, Cout, Cout, accum, stream, nullptr, part, G);
     if (r != BTS_OK) return r;
     return bts_gn_finalize_partials_(part, mean, rstd, N * G, B, (double)(V * Cout / G), eps, stream);
   }
-  const int r = lp_conv_run(1, dtype, x, wp, bias, y, workspace, conv_ws, N, D, H, W, Cin, ldx, Cout, Cout, 0, stream);
+  const int r = lp_conv_run(1, dtype, x, wp, bias, y, workspace, conv_ws, N, D, H, W, Cin, ldx, Cout, Cout, accum, stream);
   if (r != BTS_OK) return r;
   return bts_lp_gn_stats(dtype, y, mean, rstd, tail, workspace_bytes - conv_ws, N, V, Cout, G, BTS_GN_SLAB, eps, stream);
 }
@@ -1263,8 +1284,21 @@ extern "C" long bts_lp_conv1_gap_workspace(int N, long V, int Cout) {
   const long b = bts_lp_colsum_workspace(N, V, Cout);
   return a > b ? a : b;
 }
+static int lp_conv1_gap_impl(int dtype, const void* x, const void* wp, const float* bias, void* res, float* gap, void* workspace,
+                             long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldres, int accum, hipStream_t stream);
 extern "C" int bts_lp_conv1_gap(int dtype, const void* x, const void* wp, const float* bias, void* res, float* gap, void* workspace,
                                 long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldres, hipStream_t stream) {
+  return lp_conv1_gap_impl(dtype, x, wp, bias, res, gap, workspace, workspace_bytes, N, D, H, W, Cin, ldx, Cout, ldres, 0, stream);
+}
+// The same, ADDING to what res already holds (the shortcut over [skip | up-sampled], the skip part computed earlier: see
+// bts_lp_conv3d_fwd_gn_acc); gap = mean of the final sums
+extern "C" int bts_lp_conv1_gap_acc(int dtype, const void* x, const void* wp, const float* bias, void* res, float* gap, void* workspace,
+                                    long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldres, int accumulate,
+                                    hipStream_t stream) {
+  return lp_conv1_gap_impl(dtype, x, wp, bias, res, gap, workspace, workspace_bytes, N, D, H, W, Cin, ldx, Cout, ldres, accumulate ? 1 : 0, stream);
+}
+static int lp_conv1_gap_impl(int dtype, const void* x, const void* wp, const float* bias, void* res, float* gap, void* workspace,
+                             long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldres, int accum, hipStream_t stream) {
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0) return BTS_ERR_SHAPE;
   const long V = (long)D * H * W;
   if (workspace == nullptr || workspace_bytes < bts_lp_conv1_gap_workspace(N, V, Cout) || (((uintptr_t)workspace) & 15)) return BTS_ERR_WORKSPACE;
@@ -1276,7 +1310,7 @@ extern "C" int bts_lp_conv1_gap(int dtype, const void* x, const void* wp, const 
     if (kb == 0 && N == 1 && bts_lp_k1_gap_block_(V, 256, Cin, Cout) > 0) kb = 256;
     if (kb > 0 && (V % kb == 0 || N == 1) && ldres == Cout) {
       double* part = reinterpret_cast<double*>(workspace);
-      const int r = bts_lp_k1_launch_(dtype, x, wp, bias, res, (long)N * V, Cin, ldx, Cout, ldres, 0, part, kb, stream);
+      const int r = bts_lp_k1_launch_(dtype, x, wp, bias, res, (long)N * V, Cin, ldx, Cout, ldres, accum, part, kb, stream);
       if (r == BTS_OK) {
         hipLaunchKernelGGL(lp_colsum_finalize_kernel, dim3((N * Cout + 3) / 4), dim3(256), 0, stream, part, gap, N, Cout, (int)((V + kb - 1) / kb), 1.0 / (double)V);
         BTS_LAUNCH_CHECK();
@@ -1286,14 +1320,14 @@ extern "C" int bts_lp_conv1_gap(int dtype, const void* x, const void* wp, const 
     }
   }
   const long ppb = 128L * lp_gather_vb((long)N * V, NB);     // positions per block
-  if (V % ppb != 0 || ldres != Cout) {
-    const int r = lp_conv_run(0, dtype, x, wp, bias, res, nullptr, 0, N, D, H, W, Cin, ldx, Cout, ldres, 0, stream);
+  if (accum || V % ppb != 0 || ldres != Cout) {      // (the gather kernel's fused column sums do not see the old values: sums of the stored result)
+    const int r = lp_conv_run(0, dtype, x, wp, bias, res, nullptr, 0, N, D, H, W, Cin, ldx, Cout, ldres, accum, stream);
     if (r != BTS_OK) return r;
     if (ldres != Cout) return BTS_ERR_UNSUPPORTED;
     return bts_lp_colsum(dtype, res, gap, workspace, workspace_bytes, N, V, Cout, (float)(1.0 / (double)V), stream);
   }
   double* part = reinterpret_cast<double*>(workspace);
-  const int r = lp_conv_run(0, dtype, x, wp, bias, res, nullptr, 0, N, D, H, W, Cin, ldx, Cout, ldres, 0, stream, part);
+  const int r = lp_conv_run(0, dtype, x, wp, bias, res, nullptr, 0, N, D, H, W, Cin, ldx, Cout, ldres, accum, stream, part);
   if (r != BTS_OK) return r;
   hipLaunchKernelGGL(lp_colsum_finalize_kernel, dim3((N * Cout + 3) / 4), dim3(256), 0, stream, part, gap, N, Cout, (int)(V / ppb),
                      1.0 / (double)V);

@@ -225,20 +225,30 @@ def uncast(code, src):
     return out
 
 
-def conv_gn(code, tdt, x, wp, bias, cout, norm):
+def conv_gn(code, tdt, x, wp, bias, cout, norm, acc_into=None):
     """(y, mean, rstd): y = conv3x3x3(x) + bias (dense, storage type) and GroupNorm `norm`'s statistics of y -- from the conv's
-    epilogue where the library can (slab mode: the layout the reference's channels_last GroupNormalization reduces over)"""
+    epilogue where the library can (slab mode: the layout the reference's channels_last GroupNormalization reduces over).
+    acc_into: a dense tensor that already holds part of the contraction (other input channels, with the bias): the conv is ADDED to it
+    and the statistics are those of the sums (bts_lp_conv3d_fwd_gn_acc)"""
+    n, d, h, w, cin = x.shape
     if norm._mode != ops.GN_SLAB:
+        if acc_into is not None:
+            raise NotImplementedError('conv_gn(acc_into=...) is the slab-mode (channels_last) form only')
         y = conv(ops.K3S1, code, tdt, x, wp, bias, cout)
         return (y,) + tuple(gn_stats(code, y, norm.groups, norm._mode, norm.epsilon))
-    n, d, h, w, cin = x.shape
-    y = torch.empty((n, d, h, w, cout), dtype=tdt, device=x.device)
+    y = acc_into if acc_into is not None else torch.empty((n, d, h, w, cout), dtype=tdt, device=x.device)
+    if acc_into is not None and (tuple(y.shape) != (n, d, h, w, cout) or not y.is_contiguous()):
+        raise RuntimeError('conv_gn: acc_into must be a dense %s tensor' % ((n, d, h, w, cout),))
     mean = torch.empty(n * norm.groups, dtype=torch.float32, device=x.device)
     rstd = torch.empty(n * norm.groups, dtype=torch.float32, device=x.device)
     nb = lib().query('bts_lp_conv3d_fwd_gn_workspace', n, d, h, w, cin, cout, norm.groups)
     ws = ops.workspace(nb, x.device)
-    lib().call('bts_lp_conv3d_fwd_gn', code, _p(x), _p(wp), _p(bias), _p(y), _p(mean), _p(rstd), _p(ws), nb, n, d, h, w, cin, _ld(x), cout,
-               norm.groups, float(norm.epsilon), _stream())
+    if acc_into is not None:
+        lib().call('bts_lp_conv3d_fwd_gn_acc', code, _p(x), _p(wp), _p(bias) if bias is not None else None, _p(y), _p(mean), _p(rstd), _p(ws), nb,
+                   n, d, h, w, cin, _ld(x), cout, norm.groups, float(norm.epsilon), 1, _stream())
+    else:
+        lib().call('bts_lp_conv3d_fwd_gn', code, _p(x), _p(wp), _p(bias), _p(y), _p(mean), _p(rstd), _p(ws), nb, n, d, h, w, cin, _ld(x), cout,
+                   norm.groups, float(norm.epsilon), _stream())
     return y, mean, rstd
 
 
@@ -391,15 +401,20 @@ def conv_bwd_data_gn_bwd(code, tdt, dy, wp_bwd, c, gamma, beta, mean, rstd, dgam
     return da, dc, dc32, bool(fused.value)
 
 
-def conv1_gap(code, x, wp, bias, cout, tdt):
-    """(res, gap): the block's 1x1x1 shortcut conv and the mean over voxels of its output (the gate's squeeze) in one pass"""
+def conv1_gap(code, x, wp, bias, cout, tdt, acc_into=None):
+    """(res, gap): the block's 1x1x1 shortcut conv and the mean over voxels of its output (the gate's squeeze) in one pass.
+    acc_into: a dense tensor holding part of the contraction already (see conv_gn): the conv is added to it, gap = mean of the sums"""
     n, d, h, w, cin = x.shape
-    res = torch.empty((n, d, h, w, cout), dtype=tdt, device=x.device)
+    res = acc_into if acc_into is not None else torch.empty((n, d, h, w, cout), dtype=tdt, device=x.device)
     gap = torch.empty((n, cout), dtype=torch.float32, device=x.device)
     nb = lib().query('bts_lp_conv1_gap_workspace', n, d * h * w, cout)
     ws = ops.workspace(nb, x.device)
-    lib().call('bts_lp_conv1_gap', code, _p(x), _p(wp), _p(bias), _p(res), _p(gap), _p(ws), nb, n, d, h, w, cin, _ld(x), cout, cout,
-               _stream())
+    if acc_into is not None:
+        lib().call('bts_lp_conv1_gap_acc', code, _p(x), _p(wp), _p(bias) if bias is not None else None, _p(res), _p(gap), _p(ws), nb, n, d, h, w,
+                   cin, _ld(x), cout, cout, 1, _stream())
+    else:
+        lib().call('bts_lp_conv1_gap', code, _p(x), _p(wp), _p(bias), _p(res), _p(gap), _p(ws), nb, n, d, h, w, cin, _ld(x), cout, cout,
+                   _stream())
     return res, gap
 
 
@@ -558,7 +573,7 @@ def head(code, x, w, bias, sigmoid=True):
 
 
 # ---- the forward graph -------------------------------------------------------------------------------------------------
-def gate_branch(code, tdt, x, wp_pt, bias_pt, f, se_w1, se_w2, side=True):
+def gate_branch(code, tdt, x, wp_pt, bias_pt, f, se_w1, se_w2, side=True, acc_into=None, after=None):
     """A ResnetBlock's shortcut / squeeze-excitation branch (resnet.py:118-126: 1x1x1 conv with the gate's squeeze from its epilogue,
     then the two small dense layers) -> (res, gap, (h, ch), stream it ran on or None).  HBM-bound and independent of the conv branch
     until the block epilogue, so -- like the fp32 engine -- it goes to the 'gate' side stream next to the matrix-pipe-bound convs
@@ -567,15 +582,21 @@ def gate_branch(code, tdt, x, wp_pt, bias_pt, f, se_w1, se_w2, side=True):
     convs already fill the chip, is unchanged (and pays for a second allocator pool), so the trainer keeps it on the main stream"""
     gate = ops.side_stream('gate') if side else None
     if gate is None:
-        res, gap = conv1_gap(code, x, wp_pt, bias_pt, f, tdt)
+        if after is not None:
+            torch.cuda.current_stream().wait_event(after)
+        res, gap = conv1_gap(code, x, wp_pt, bias_pt, f, tdt, acc_into=acc_into)
         hbuf, ch = ops.se_mlp_fwd(gap, se_w1, se_w2)
         return res, gap, (hbuf, ch), None
     main = torch.cuda.current_stream()
     gate.wait_stream(main)                     # x is complete once the main stream gets here
+    if after is not None:                      # (acc_into: the partial result another stream wrote)
+        gate.wait_event(after)
     with torch.cuda.stream(gate):
-        res, gap = conv1_gap(code, x, wp_pt, bias_pt, f, tdt)
+        res, gap = conv1_gap(code, x, wp_pt, bias_pt, f, tdt, acc_into=acc_into)
         hbuf, ch = ops.se_mlp_fwd(gap, se_w1, se_w2)
     x.record_stream(gate)
+    if acc_into is not None:
+        acc_into.record_stream(gate)
     for t in (res, gap, hbuf, ch):             # allocated on the gate stream, consumed (and later freed) on the main one
         t.record_stream(main)
     return res, gap, (hbuf, ch), gate
@@ -603,6 +624,15 @@ class LowPrecisionForward(object):
             if not isinstance(up, (ConvUpsample, LinearUpsample)):
                 raise NotImplementedError('unknown up-sampling layer %r' % type(up).__name__)
         self.channels_first = model.data_format == 'channels_first'
+        # MEASURED AND CLOSED (round 6, OFF by default; BTS_LP_EARLY_SKIP=1 switches it on for A/B and the parity test).  Decoder blocks read
+        # [skip | up-sampled] (decoder.py:75): the skip part of conv1 and of the shortcut (with their biases) needs only the ENCODER level's
+        # output, so it can run on a side stream next to the two deepest levels, whose grids leave half the chip idle on a single volume
+        # (round 4's batch sweep: 150 -> 185 volumes/s from batch 1 to 8), and the decoder adds the up-sampled part to it
+        # (bts_lp_conv3d_fwd_gn_acc / bts_lp_conv1_gap_acc).  The same contraction split over its input channels; the partial sum passes
+        # through the storage type once.  Result: 6.26 -> 6.56 ms started right away, 6.26 -> 6.62 ms started where the main stream enters
+        # the deep levels (profiles/r06_ab_e6*.txt): the split costs a read-modify-write of c1 and res per decoder block and two launches
+        # more, and the side kernels (one 137-KB workgroup per CU) find no CU to run on until a main-stream kernel drains
+        self.early_skip = os.environ.get('BTS_LP_EARLY_SKIP', '0') == '1'
         self.fuse_head = os.environ.get('BTS_LP_FUSE_HEAD', '1') != '0'      # (=0: block epilogue and output head as two launches; A/B)
         self.fuse_first = os.environ.get('BTS_LP_C2', '1') != '0'            # (=0: padded 16-channel copy + generic kernels for the first block; A/B)
         bf = getattr(model.encoder, 'base_filters', 16)
@@ -619,11 +649,45 @@ class LowPrecisionForward(object):
             self._packs[key] = ent
         return ent[2]
 
+    def _packed_rows(self, key, kind, param, c0, c1, cout):
+        """packed image of the input-channel rows [c0, c1) of a kernel (the part of a conv over a concat that reads one operand)"""
+        ent = self._packs.get(key)
+        sig = (kind, c0, c1, cout, id(param))
+        if ent is None or ent[0] != weights_epoch() or ent[1] != sig:
+            rows = param.t[..., c0:c1, :].contiguous()
+            ent = (weights_epoch(), sig, pack(kind, self.code, rows, c1 - c0, cout))
+            self._packs[key] = ent
+        return ent[2]
+
+    def _skip_part(self, blk, skip):
+        """conv1 and shortcut of decoder block `blk` over its SKIP operand only (with the biases), on the 'skip' side stream ->
+        (c1 partial, res partial, event) or None"""
+        side = ops.side_stream('skip')
+        if side is None or blk.norm1._mode != ops.GN_SLAB:
+            return None
+        code, tdt = self.code, self.tdt
+        f = blk.filters
+        cres = skip.shape[-1]
+        key = id(blk)
+        wp3 = self._packed_rows((key, 'c1s'), ops.K3S1, blk.conv1_k, 0, cres, f)
+        wp1 = self._packed_rows((key, 'pts'), ops.K1, blk.ptwise_k, 0, cres, f)
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)                      # the encoder level is complete once the main stream gets here
+        with torch.cuda.stream(side):
+            c1p = conv(ops.K3S1, code, tdt, skip, wp3, blk.conv1_b.t, f)
+            resp = conv(ops.K1, code, tdt, skip, wp1, blk.ptwise_b.t, f)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        skip.record_stream(side)
+        for t in (c1p, resp):                       # allocated on the side stream, finished and freed on others
+            t.record_stream(main)
+        return c1p, resp, ev
+
     def _gn(self, norm, c, relu, out=None):
         m, r = gn_stats(self.code, c, norm.groups, norm._mode, norm.epsilon)
         return gn_apply(self.code, c, norm.gamma.t, norm.beta.t, m, r, norm.groups, norm._mode, relu, out=out)
 
-    def _block(self, blk, x, out, fold=None, head=None, first=None):
+    def _block(self, blk, x, out, fold=None, head=None, first=None, early=None, cres=0):
         """ResnetBlock.call (resnet.py:116-138); x: 16-bit view, out: 16-bit view or None.  head = (W (C,K), b (K)): this is the last block
         and its only reader is the sigmoid output head -- returns ('head', y_pred) where the fused epilogue takes the shape"""
         code, tdt = self.code, self.tdt
@@ -641,6 +705,14 @@ class LowPrecisionForward(object):
             c1, m1, r1, res, gap = first
             _, ch = ops.se_mlp_fwd(gap, blk.se_w1.t, blk.se_w2.t)
             gate = None
+        elif early is not None:    # a decoder block whose skip part is (being) computed on the side stream: add the up-sampled part
+            c1p, resp, ev = early
+            xu = x[..., cres:]
+            wp_pt = self._packed_rows((key, 'ptu'), ops.K1, blk.ptwise_k, cres, cin, f)
+            wp_c1 = self._packed_rows((key, 'c1u'), ops.K3S1, blk.conv1_k, cres, cin, f)
+            torch.cuda.current_stream().wait_event(ev)
+            res, gap, (_, ch), gate = gate_branch(code, tdt, xu, wp_pt, None, f, blk.se_w1.t, blk.se_w2.t, acc_into=resp, after=ev)
+            c1, m1, r1 = conv_gn(code, tdt, xu, wp_c1, None, f, blk.norm1, acc_into=c1p)
         else:
             wp_pt = self._packed((key, 'pt'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
             wp_c1 = self._packed((key, 'c1'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
@@ -720,6 +792,8 @@ class LowPrecisionForward(object):
         enc, dec = m.encoder, m.decoder
         n = x.shape[0]
         residuals = []
+        early, pending = {}, []
+        deep = max(len(enc.levels) - 2, 1)            # first of the two deepest levels
         cur = x
         for i, (convs, down) in enumerate(enc.levels):
             d, h, w = cur.shape[1:4]
@@ -735,7 +809,17 @@ class LowPrecisionForward(object):
                     self._block(blk, slab[..., :j * f], out, fold=((j - 1) * f, f))       # encoder.py:83-87
             residuals.append((slab, nb * f))
             if down is not None:
+                if self.early_skip and i < len(dec.levels):
+                    # the decoder block of this level reads [this level's output | up-sampled]: its skip part is ready to run from here on
+                    pending.append((i, dec.levels[len(dec.levels) - 1 - i][1], slab[..., :nb * f]))
                 cur = self._down(down, slab[..., :nb * f])                                # encoder.py:97-98
+            if i + 1 >= deep:
+                # ... and is STARTED where the main stream enters the two deepest levels: their grids (360 and 120-144 workgroups on the
+                # full inference volume) leave CUs idle, the levels above fill the chip (started right away the side work only competed
+                # with them: 6.26 -> 6.56 ms, profiles/r06_ab_e6.txt)
+                for lv, dblk, view in pending:
+                    early[lv] = self._skip_part(dblk, view)
+                pending = []
         slab, used = residuals[-1]
         y = slab[..., :used]
         hw = dec.out_k.t.reshape(dec.out_k.t.shape[-2], dec.out_k.t.shape[-1])
@@ -744,7 +828,9 @@ class LowPrecisionForward(object):
             f = up.filters
             self._up(up, y, slab[..., cres:cres + f])                                     # decoder.py:72
             # (the top block's output has one reader, the output head: folded into its epilogue where the library can)
-            y = self._block(blk, slab[..., :cres + f], None, head=(hw, dec.out_b.t) if li == nlev - 1 else None)   # decoder.py:75-78
+            lvl = nlev - 1 - li                                                            # the encoder level whose output is the skip
+            y = self._block(blk, slab[..., :cres + f], None, head=(hw, dec.out_b.t) if li == nlev - 1 else None,  # decoder.py:75-78
+                            early=early.get(lvl), cres=cres)
         if isinstance(y, tuple):
             yp = y[1]
         else:

@@ -386,6 +386,17 @@ long bts_lp_conv3d_fwd_gn_workspace(int N, int D, int H, int W, int Cin, int Cou
 int bts_lp_conv3d_fwd_gn(int dtype, const void* x, const void* wp, const float* bias, void* y, float* mean, float* rstd, void* workspace,
                          long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int G, float eps,
                          bts_stream_t stream);
+/* bts_lp_conv3d_fwd_gn / bts_lp_conv1_gap ADDING to what y / res already hold (accumulate != 0), statistics / squeeze of the final sums: a
+ * contraction split over its input channels whose parts become available at different times -- the decoder block's conv1 and shortcut over
+ * [skip | up-sampled] (decoder.py:75; resnet.py:118,134): the skip part (with the bias) can run as soon as the encoder level is done, next
+ * to the under-filled deep levels, the up-sampled part adds to it later (bias = NULL then).  The partial sum passes through the storage type
+ * once.  Workspaces: bts_lp_conv3d_fwd_gn_workspace / bts_lp_conv1_gap_workspace */
+int bts_lp_conv3d_fwd_gn_acc(int dtype, const void* x, const void* wp, const float* bias, void* y, float* mean, float* rstd, void* workspace,
+                             long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int G, float eps, int accumulate,
+                             bts_stream_t stream);
+int bts_lp_conv1_gap_acc(int dtype, const void* x, const void* wp, const float* bias, void* res, float* gap, void* workspace,
+                         long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldres, int accumulate,
+                         bts_stream_t stream);
 /* conv1 AND the shortcut of a ResnetBlock from ONE pass over the block input (resnet.py:118 and resnet.py:134 read the same `inputs`):
  * y = conv3x3x3(x) + bias with GroupNorm G's statistics of y (as bts_lp_conv3d_fwd_gn), res = conv1x1x1(x) + bias_pt and gap[n][c] = mean
  * over the voxels of the unrounded res (as bts_lp_conv1_gap).  The shortcut is a second set of output columns at the centre tap of the

@@ -1046,3 +1046,25 @@ def test_dropout_and_cast_in_one_pass_equal_the_three_passes(dtype, c):
     assert 0.7 < float(keep.float().mean()) < 0.9
     ref = torch.where(keep, x * (1.0 / (1.0 - rate)), torch.zeros_like(x)).to(tdt)
     assert torch.equal(got[..., :c], ref) and bool((got[..., c:] == 0).all())
+
+
+def test_inference_forward_with_the_skip_part_of_the_decoder_blocks_on_a_side_stream(monkeypatch):
+    """BTS_LP_EARLY_SKIP=1 (measured and closed in round 6: slower; kept as an A/B switch): a decoder block's conv1 and shortcut over
+    [skip | up-sampled] (decoder.py:75) as the skip part, started next to the deepest levels on a side stream, plus the up-sampled part added
+    to it (bts_lp_conv3d_fwd_gn_acc / bts_lp_conv1_gap_acc).  The same contraction split over its input channels, one more rounding of the
+    partial sum: same labels, probabilities within the storage rounding; and the entry points' statistics / squeeze are those of the SUMS
+    (a GroupNorm over the partial only would move y_pred by far more than 2e-3)."""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    m = _model(dict(base_filters=16, groups=8, reduction=2, depth=3), (32, 32, 32), 5)
+    x = torch.randn((1, 32, 32, 32, 2), generator=torch.Generator().manual_seed(9)).to(DEV)
+    y0 = lowp.LowPrecisionForward(m, 'float16')(x)
+    monkeypatch.setenv('BTS_LP_EARLY_SKIP', '1')
+    ops.profile_enable(True)
+    y1 = lowp.LowPrecisionForward(m, 'float16')(x)
+    torch.cuda.synchronize()
+    ops.profile_enable(False)
+    assert y1.shape == y0.shape == (1, 32, 32, 32, 3)
+    d = (y1 - y0).abs()
+    assert 0.0 < float(d.max()) <= 2e-3, float(d.max())
+    assert float((y1.argmax(-1) != y0.argmax(-1)).float().mean()) <= 1e-3
