@@ -101,7 +101,10 @@ def pmc_traffic(symbol, suffix=''):
             continue
         base = nk.split('<')[0]
         fam = base == key or (key == 'lp_k1_kernel' and base == 'lp_k1f_kernel') or (key == 'lp_conv_gather_kernel' and base == 'lp_conv_gatherq_kernel')
-        if (nk == key or (('<' not in key) and fam)) and _kernel_bytes(v) is not None:
+        # (a variant name of the library's launch records -- lp_s1d_kernel<MODE,TXL> -- covers the instantiations that carry further template
+        # arguments: lp_s1d_kernel<1,5,false> and <1,5,true>, the plain and the fused-shortcut form)
+        pref = ('<' in key) and nk.startswith(key[:-1] + ',')
+        if (nk == key or pref or (('<' not in key) and fam)) and _kernel_bytes(v) is not None:
             hits.append(v)
     if not hits:
         return None
