@@ -3362,9 +3362,9 @@ extern "C" int bts_lp_conv3d_bwd_weight(int kind, int dtype, const void* x, cons
 // wave fed by planes of dy1 that ride in the Q-ring slots the 3x3x3 contraction no longer needs (its older planes live in registers).
 // The 1x1x1 weight-gradient launch -- HBM-bound, its own read of the Cin-wide x -- goes away.  db3 (may be NULL; dy3 dense then) (+)= sum dy3.
 // Same conventions as bts_lp_conv3d_bwd_weight (dup_start / dup_shift fold both kernels alike).  The workspace query returns -1 and the
-// call 1 (nothing launched) where the streaming kernel does not take the shape: run bts_lp_conv3d_bwd_weight twice.  BTS_LP_K1F=0: never.
+// call 1 (nothing launched) where the streaming kernel does not take the shape: run bts_lp_conv3d_bwd_weight twice.  BTS_LP_WPAIR=0: never.
 extern "C" long bts_lp_conv3d_bwd_weight_pair_workspace(int N, int D, int H, int W, int Cin, int Cout) {
-  static const bool off = [] { const char* e = getenv("BTS_LP_K1F"); return e && atoi(e) == 0; }();
+  static const bool off = [] { const char* e = getenv("BTS_LP_WPAIR"); return e && atoi(e) == 0; }();
   if (off || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin % 8 != 0 || Cout % 8 != 0) return -1;
   const long alt = bts_lp_wgd_workspace_(N, D, H, W, Cin, Cout);
   if (alt <= 0) return -1;

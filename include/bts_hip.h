@@ -303,7 +303,7 @@ int bts_lp_conv3d_bwd_data_sc(int dtype, const void* dy, const void* wp_bwd, con
  * (+)= sum_v x[v][c] dy1[v][k] -- one more accumulator per wave of the streaming kernel, fed by the centre-tap fragments of x it reads anyway;
  * the HBM-bound 1x1x1 weight-gradient launch and its own read of the Cin-wide x go away.  db3 (may be NULL; dy3 dense then) (+)= sum dy3.
  * dup_start / dup_shift fold both kernels alike.  Workspace query -1 / return value 1 (nothing launched) outside the streaming kernel's
- * shapes (W % 32, H % 8, large volumes): run bts_lp_conv3d_bwd_weight twice.  BTS_LP_K1F=0 in the environment: never (A/B aid) */
+ * shapes (W % 32, H % 8, large volumes): run bts_lp_conv3d_bwd_weight twice.  BTS_LP_WPAIR=0 in the environment: never (A/B aid) */
 long bts_lp_conv3d_bwd_weight_pair_workspace(int N, int D, int H, int W, int Cin, int Cout);
 int bts_lp_conv3d_bwd_weight_pair(int dtype, const void* x, const void* dy3, const void* dy1, float* dw3, float* dw1, float* db3, void* workspace,
                                   long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int lddy3, int lddy1,
