@@ -40,7 +40,8 @@ long bts_lp_s1z_gn_B_(int N, int D, int H, int W, int Cin, int Cout, int Gn);
 int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bias, void* y, int N, int D, int H, int W, int Cin, int ldx,
                        int Cout, int ldy, int accum, double* gn_part, int gn_G, hipStream_t stream, const LpGnbFuse* gb = nullptr,
                        const LpGnaFuse* ga = nullptr, const void* x2 = nullptr, const void* wp2 = nullptr, int ldx2 = 0, void* y2 = nullptr,
-                       const float* bias2 = nullptr, double* gap_part = nullptr, int ldy2 = 0, int Cout2 = 0);
+                       const float* bias2 = nullptr, double* gap_part = nullptr, int ldy2 = 0, int Cout2 = 0, int accum2 = 0,
+                       const void* xb = nullptr, int ldxb = 0);
 long bts_lp_s1z_fs_B_(int N, int D, int H, int W, int Cin, int ldx, int Cout, int Cout2);
 bool bts_lp_s1z_gna_ok_(int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, int in_G);
 long bts_lp_s1z_gnb_B_(int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy, int Gn);
@@ -1188,13 +1189,14 @@ __global__ __launch_bounds__(256) void lp_colsum_finalize_kernel(const double* p
 extern "C" long bts_lp_conv3d_fwd_gn_shortcut_workspace(int N, int D, int H, int W, int Cin, int ldx, int Cout, int G) {
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || G <= 0 || Cout % G != 0 || D % G != 0 || Cin % 16 != 0) return -1;
   static const bool off = [] { const char* e = getenv("BTS_LP_FS"); return e && atoi(e) == 0; }();
-  if (off) return -1;
+  static const bool off64 = [] { const char* e = getenv("BTS_LP_FS_PAIR"); return e && atoi(e) == 0; }();      // BTS_LP_FS_PAIR=0: not on the two-pass 64-channel form (A/B)
+  if (off || (off64 && Cin == 64)) return -1;
   const long Bg = bts_lp_s1z_gn_B_(N, D, H, W, Cin, Cout, G), Bf = bts_lp_s1z_fs_B_(N, D, H, W, Cin, ldx, Cout, Cout);
   if (Bg <= 0 || Bf <= 0) return -1;
   return (long)N * G * Bg * 16 + 64 + (long)N * Bf * Cout * 8 + 64;
 }
-extern "C" int bts_lp_conv3d_fwd_gn_shortcut(int dtype, const void* x, const void* wp, const float* bias, void* y, float* mean, float* rstd,
-                                             const void* wp_pt, const float* bias_pt, void* res, float* gap, void* workspace,
+extern "C" int bts_lp_conv3d_fwd_gn_shortcut(int dtype, const void* x, long x_split, const void* wp, const float* bias, void* y, float* mean,
+                                             float* rstd, const void* wp_pt, const float* bias_pt, void* res, float* gap, void* workspace,
                                              long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int G, float eps,
                                              hipStream_t stream) {
   if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
@@ -1203,13 +1205,15 @@ extern "C" int bts_lp_conv3d_fwd_gn_shortcut(int dtype, const void* x, const voi
   if (workspace == nullptr || workspace_bytes < need || (((uintptr_t)workspace) & 15)) return BTS_ERR_WORKSPACE;
   if (x == nullptr || wp == nullptr || wp_pt == nullptr || y == nullptr || res == nullptr || gap == nullptr || mean == nullptr || rstd == nullptr)
     return BTS_ERR_ALIGN;
-  if (ldx % 8 != 0 || ldx < Cin || (((uintptr_t)x) & 15) || (((uintptr_t)wp) & 15)) return BTS_ERR_ALIGN;
+  if (ldx % 8 != 0 || ldx < (x_split ? 32 : Cin) || (((uintptr_t)x) & 15) || (((uintptr_t)wp) & 15)) return BTS_ERR_ALIGN;
+  if (x_split != 0 && (Cin != 64 || x_split < 0 || x_split % 8 != 0)) return BTS_ERR_SHAPE;      // (two 32-channel operands: the two-pass form)
   const long Bg = bts_lp_s1z_gn_B_(N, D, H, W, Cin, Cout, G), Bf = bts_lp_s1z_fs_B_(N, D, H, W, Cin, ldx, Cout, Cout);
   double* gpart = reinterpret_cast<double*>(workspace);
   double* fpart = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + (((long)N * G * Bg * 16 + 63) / 64) * 64);
   const long V = (long)D * H * W;
   const int r = bts_lp_s1z_launch_(dtype, x, reinterpret_cast<const char*>(wp) + lp_s1d_part_offset(Cin, Cout), bias, y, N, D, H, W, Cin, ldx, Cout,
-                                   Cout, 0, gpart, G, stream, nullptr, nullptr, nullptr, wp_pt, 0, res, bias_pt, fpart, Cout, Cout);
+                                   Cout, 0, gpart, G, stream, nullptr, nullptr, nullptr, wp_pt, 0, res, bias_pt, fpart, Cout, Cout, 0,
+                                   x_split ? static_cast<const void*>(reinterpret_cast<const unsigned short*>(x) + x_split) : nullptr, x_split ? ldx : 0);
   if (r != BTS_OK) return r;
   const int r2 = bts_gn_finalize_partials_(gpart, mean, rstd, N * G, Bg, (double)(V * Cout / G), eps, stream);
   if (r2 != BTS_OK) return r2;
@@ -3210,7 +3214,7 @@ int bts_lp_wgs_launch_(int dtype, const void* P, const void* Q, float* dw, void*
 long bts_lp_wgd_workspace_(int N, int D, int H, int W, int Cp, int Cq);
 int bts_lp_wgd_launch_(int dtype, const void* x, const void* dy, float* dw, void* ws, long ws_bytes, int N, int D, int H, int W, int Cp, int ldp,
                        int Cq, int ldq, int dup_start, int dup_shift, int accum, hipStream_t stream, const LpGnaFuse* ga = nullptr,
-                       const void* dy2 = nullptr, float* dw1 = nullptr, int lddy2 = 0);
+                       const void* dy2 = nullptr, float* dw1 = nullptr, int lddy2 = 0, long psplit = 0);
 bool bts_lp_wgd_gna_ok_(int N, int D, int H, int W, int Cp, int Cq, int in_G);
 // db[k] (+)= sum_n colsum[n][k]
 __global__ void lp_bias_grad_kernel(const float* cs, float* db, int N, int C, int accum) {
@@ -3371,21 +3375,22 @@ extern "C" long bts_lp_conv3d_bwd_weight_pair_workspace(int N, int D, int H, int
   const long part = ((alt / 27 * 28 + 255) & ~255L);
   return part + (long)N * ((Cout + 7) / 8 * 8) * 4 + bts_lp_colsum_workspace(N, (long)D * H * W, (Cout + 7) / 8 * 8) + 512;
 }
-extern "C" int bts_lp_conv3d_bwd_weight_pair(int dtype, const void* x, const void* dy3, const void* dy1, float* dw3, float* dw1, float* db3,
-                                             void* workspace, long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout,
-                                             int lddy3, int lddy1, int dup_start, int dup_shift, int accumulate, hipStream_t stream) {
+extern "C" int bts_lp_conv3d_bwd_weight_pair(int dtype, const void* x, long x_split, const void* dy3, const void* dy1, float* dw3, float* dw1,
+                                             float* db3, void* workspace, long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx,
+                                             int Cout, int lddy3, int lddy1, int dup_start, int dup_shift, int accumulate, hipStream_t stream) {
   if (dtype != LP_F16 && dtype != LP_BF16) return BTS_ERR_UNSUPPORTED;
   const long need = bts_lp_conv3d_bwd_weight_pair_workspace(N, D, H, W, Cin, Cout);
   if (need < 0) return 1;
   if (x == nullptr || dy3 == nullptr || dy1 == nullptr || dw3 == nullptr || dw1 == nullptr) return BTS_ERR_ALIGN;
-  if (ldx % 8 != 0 || lddy3 % 8 != 0 || lddy1 % 8 != 0 || ldx < Cin || lddy3 < Cout || lddy1 < Cout) return BTS_ERR_SHAPE;
+  if (ldx % 8 != 0 || lddy3 % 8 != 0 || lddy1 % 8 != 0 || ldx < (x_split ? 32 : Cin) || lddy3 < Cout || lddy1 < Cout) return BTS_ERR_SHAPE;
+  if (x_split != 0 && (x_split < 0 || x_split % 8 != 0 || Cin % 32 != 0 || dup_shift != 0)) return BTS_ERR_SHAPE;
   if ((((uintptr_t)x) & 15) || (((uintptr_t)dy3) & 15) || (((uintptr_t)dy1) & 15) || (((uintptr_t)workspace) & 15)) return BTS_ERR_ALIGN;
   if (dup_shift < 0 || (dup_shift > 0 && dup_start + dup_shift > Cin)) return BTS_ERR_SHAPE;
   if (workspace == nullptr || workspace_bytes < need) return BTS_ERR_WORKSPACE;
   if (db3 != nullptr && lddy3 != Cout) return BTS_ERR_UNSUPPORTED;
   const long part_bytes = ((bts_lp_wgd_workspace_(N, D, H, W, Cin, Cout) / 27 * 28 + 255) & ~255L);
   const int r = bts_lp_wgd_launch_(dtype, x, dy3, dw3, workspace, part_bytes, N, D, H, W, Cin, ldx, Cout, lddy3, dup_start, dup_shift, accumulate, stream,
-                                   nullptr, dy1, dw1, lddy1);
+                                   nullptr, dy1, dw1, lddy1, x_split);
   if (r != BTS_OK) return r;      // (1: declined, nothing launched)
   if (db3 != nullptr) {
     char* wsb = reinterpret_cast<char*>(workspace) + part_bytes;

@@ -55,8 +55,9 @@ struct LpS1zParams {
   // (first part of the K1 forward image, one cout block).
   unsigned short* y2;
   const float* bias2;
-  double* gap_part;
+  double* gap_part;          // (may be NULL: the first of two passes over the halves of a 64-channel input leaves no sums)
   int ldy2, Cout2, fs_B;
+  int accum2;                // y2 += (second pass: the column sums are those of the final values)
 };
 #define S1Z_TX 32
 #define S1Z_TY 16
@@ -246,17 +247,26 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
   auto store_res = [&](int z) {
     if constexpr (FS) {
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) gsum[i] += acc2[r][i];
-#pragma unroll
       for (int qp = 0; qp < 2; ++qp) {
         const int co = 16 * qp + 8 * h;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           const unsigned off = co < p.Cout2 ? (unsigned)((((z * p.H + cy0 + r0 + r) * p.W + cx0 + l32) * p.ldy2 + co) * 2) : 0x80000000u;
-          unsigned d0 = pack2<T>(acc2[r][8 * qp], acc2[r][8 * qp + 1]), d1 = pack2<T>(acc2[r][8 * qp + 2], acc2[r][8 * qp + 3]);
-          unsigned d2 = pack2<T>(acc2[r][8 * qp + 4], acc2[r][8 * qp + 5]), d3 = pack2<T>(acc2[r][8 * qp + 6], acc2[r][8 * qp + 7]);
+          float f[4], g2[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { f[j] = acc2[r][8 * qp + j]; g2[j] = acc2[r][8 * qp + 4 + j]; }
+          if (p.accum2) {     // old values arrive in the exchanged layout: the exchange is its own inverse
+            u32x4 e = __builtin_amdgcn_raw_buffer_load_b128(y2r, off, 0, 0);
+            asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\tv_nop"
+                         : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]));
+            float old[8];
+            unpack8<T>(e, old);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { f[j] += old[j]; g2[j] += old[4 + j]; }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { gsum[8 * qp + j] += f[j]; gsum[8 * qp + 4 + j] += g2[j]; }
+          unsigned d0 = pack2<T>(f[0], f[1]), d1 = pack2<T>(f[2], f[3]), d2 = pack2<T>(g2[0], g2[1]), d3 = pack2<T>(g2[2], g2[3]);
           asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\tv_nop"
                        : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
           __builtin_amdgcn_raw_buffer_store_b128(u32x4{d0, d1, d2, d3}, y2r, off, 0, LP_OUT_STORE_AUX);
@@ -275,7 +285,7 @@ __global__ __launch_bounds__(512, 1) void lp_s1z_kernel(const LpS1zParams p) {
         for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         gsum[i] = v;
       }
-      if (l32 == 0) {
+      if (l32 == 0 && p.gap_part != nullptr) {
         const int per = p.fs_B / 8;                       // items per sample
         const int li = item - cn * per;
         double* dst = p.gap_part + ((long)cn * p.fs_B + (long)li * 8 + wave) * p.Cout2;
@@ -704,7 +714,7 @@ long bts_lp_s1z_gnb_B_(int N, int D, int H, int W, int Cin, int ldx, int Cout, i
 // FS form: partial rows per sample of the shortcut's column sums (8 per item), or 0 where the kernel does not take the shape
 long bts_lp_s1z_fs_B_(int N, int D, int H, int W, int Cin, int ldx, int Cout, int Cout2) {
   S1zPlan pl;
-  if (Cin == 64 || Cout2 <= 0 || Cout2 > 32 || Cout2 % 8 != 0 || !s1z_plan(pl, N, D, H, W, Cin, ldx, Cout, Cout)) return 0;
+  if (Cout2 <= 0 || Cout2 > 32 || Cout2 % 8 != 0 || !s1z_plan(pl, N, D, H, W, Cin, ldx, Cout, Cout)) return 0;      // (Cin = 64: the two-pass form, where it is taken)
   return (long)pl.ntx * pl.nty * pl.nzc * 8;
 }
 // BTS_OK = ran, 1 = declined.  wp = the DMA part of the K3S1 image.  gb (may be NULL): see LpGnbFuse; its B must be bts_lp_s1z_gnb_B_'s
@@ -718,31 +728,41 @@ bool bts_lp_s1z_gna_ok_(int N, int D, int H, int W, int Cin, int ldx, int Cout, 
 }
 int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bias, void* y, int N, int D, int H, int W, int Cin, int ldx,
                        int Cout, int ldy, int accum, double* gn_part, int gn_G, hipStream_t stream, const LpGnbFuse* gb, const LpGnaFuse* ga,
-                       const void* x2, const void* wp2, int ldx2, void* y2, const float* bias2, double* gap_part, int ldy2, int Cout2) {
+                       const void* x2, const void* wp2, int ldx2, void* y2, const float* bias2, double* gap_part, int ldy2, int Cout2, int accum2,
+                       const void* xb, int ldxb) {
   S1zPlan pl;
   if (!s1z_plan(pl, N, D, H, W, Cin, ldx, Cout, ldy)) return 1;
   const bool sc = x2 != nullptr;
   const bool fs = y2 != nullptr;
-  if (fs && (sc || Cin == 64 || gb != nullptr || ga != nullptr || accum || wp2 == nullptr || gap_part == nullptr || Cout2 <= 0 || Cout2 > 32 ||
+  // (FS: accum / accum2 / a NULL gap_part are the two-pass form's own business -- callers ask for a plain launch)
+  if (fs && (sc || gb != nullptr || ga != nullptr || wp2 == nullptr || Cout2 <= 0 || Cout2 > 32 ||
              Cout2 % 8 != 0 || ldy2 < Cout2 || ldy2 % 8 != 0 || (((uintptr_t)y2) & 15) || (((uintptr_t)wp2) & 15) ||
              (long)D * H * W * (long)ldy2 * 2 >= 0x7fffffffL))
     return 1;
+  if (xb != nullptr && (Cin != 64 || ldxb < 32 || ldxb % 8 != 0 || (((uintptr_t)xb) & 15) || (long)D * H * W * (long)ldxb * 2 >= 0x7fffffffL)) return 1;
   if (sc && (Cin == 64 || gb != nullptr || ga != nullptr || gn_part != nullptr || wp2 == nullptr || ldx2 < Cin || ldx2 % 8 != 0 ||
              (((uintptr_t)x2) & 15) || (((uintptr_t)wp2) & 15) || (long)D * H * W * (long)ldx2 * 2 >= 0x7fffffffL))
     return 1;
   if (Cin == 64) {      // two 32-channel passes (see s1z_plan): channels [0, 32) write (or accumulate, as asked), [32, 64) accumulate and count
-    if (gb != nullptr || ga != nullptr) return 1;
+    if (gb != nullptr || ga != nullptr || sc) return 1;
     // everything either pass checks, BEFORE the first one touches y: a decline after pass 1 would leave a half-summed output behind (and
     // the caller's fallback would add the first half twice when accumulating)
     if ((((uintptr_t)x) & 15) || (((uintptr_t)y) & 15) || (((uintptr_t)wp) & 15)) return 1;      // (x + 32 channels = + 64 bytes, wp + 54 KB: aligned with them)
     if (gn_part != nullptr && (gn_G <= 0 || D % gn_G != 0)) return 1;
-    const int r = bts_lp_s1z_launch_(dtype, x, wp, bias, y, N, D, H, W, 32, ldx, Cout, ldy, accum, nullptr, 0, stream, nullptr, nullptr, nullptr, nullptr, 0,
-                                     nullptr, nullptr, nullptr, 0, 0);
+    if (fs && (accum || accum2)) return 1;
+    // (FS: the shortcut's two halves likewise -- the first pass writes res = x[0:32] . W[0:32] + bias, the second adds x[32:64] . W[32:64] and
+    // leaves the column sums of the result; the 1x1x1 image is [k-step][k-half][32][8]: the second half starts two k-steps = 2 KB in)
+    const int r = bts_lp_s1z_launch_(dtype, x, wp, bias, y, N, D, H, W, 32, ldx, Cout, ldy, accum, nullptr, 0, stream, nullptr, nullptr, nullptr,
+                                     fs ? wp2 : nullptr, 0, fs ? y2 : nullptr, bias2, nullptr, ldy2, Cout2, 0, nullptr, 0);
     if (r != BTS_OK) return r;
     // (image: [k-step][dz][tap][k-half][32 couts][8 cin], 27 KB per k-step: the second half starts two k-steps in.  The first half's sum
-    // passes through the storage type once before the second is added: one extra rounding, carried by the test bounds)
-    const int r2 = bts_lp_s1z_launch_(dtype, reinterpret_cast<const unsigned short*>(x) + 32, reinterpret_cast<const char*>(wp) + 2 * 27 * 1024, nullptr, y,
-                                      N, D, H, W, 32, ldx, Cout, ldy, 1, gn_part, gn_G, stream, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, 0);
+    // passes through the storage type once before the second is added: one extra rounding, carried by the test bounds.  xb: the second
+    // half as a tensor of its own -- the two operands of a concat, decoder.py:75 -- instead of channels 32..63 of x)
+    const void* x2nd = xb != nullptr ? xb : static_cast<const void*>(reinterpret_cast<const unsigned short*>(x) + 32);
+    const int r2 = bts_lp_s1z_launch_(dtype, x2nd, reinterpret_cast<const char*>(wp) + 2 * 27 * 1024, nullptr, y, N, D, H, W, 32,
+                                      xb != nullptr ? ldxb : ldx, Cout, ldy, 1, gn_part, gn_G, stream, nullptr, nullptr, nullptr,
+                                      fs ? reinterpret_cast<const char*>(wp2) + 2 * 1024 : nullptr, 0, fs ? y2 : nullptr, nullptr, fs ? gap_part : nullptr,
+                                      ldy2, Cout2, fs ? 1 : 0, nullptr, 0);
     return r2 == 1 ? BTS_ERR_UNSUPPORTED : r2;      // (y has been written: "declined" is no longer an answer)
   }
   if (ga != nullptr && (gb != nullptr || !bts_lp_s1z_gna_ok_(N, D, H, W, Cin, ldx, Cout, ldy, ga->G) || ga->cg != Cin / ga->G)) return 1;
@@ -761,7 +781,7 @@ int bts_lp_s1z_launch_(int dtype, const void* x, const void* wp, const float* bi
   if (gb != nullptr) { p.gb = *gb; p.gb_zt = D / gb->G; } else { p.gb = LpGnbFuse{}; p.gb_zt = 1; }
   if (ga != nullptr) { p.ga = *ga; p.ga_zt = D / ga->G; } else { p.ga = LpGnaFuse{}; p.ga_zt = 1; }
   p.x2 = (const unsigned short*)x2; p.wp2 = (const unsigned short*)wp2; p.ldx2 = ldx2;
-  p.y2 = (unsigned short*)y2; p.bias2 = bias2; p.gap_part = gap_part; p.ldy2 = ldy2; p.Cout2 = Cout2;
+  p.y2 = (unsigned short*)y2; p.bias2 = bias2; p.gap_part = gap_part; p.ldy2 = ldy2; p.Cout2 = Cout2; p.accum2 = accum2;
   p.fs_B = pl.ntx * pl.nty * pl.nzc * 8;
   const int KS = Cin / 16;
   const size_t shmem = (size_t)(27 * KS * 1024 + 2 * S1Z_NCHK * 1024 * KS + 256 + 1024 + 512);

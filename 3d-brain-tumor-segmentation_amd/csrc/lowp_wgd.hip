@@ -53,6 +53,9 @@ struct LpWgdParams {
   const unsigned short* q2;  // (N, D, H, W, Cq) voxel stride ldq2
   float* part2;              // [workgroup][cp block][cq block][32][32]
   int ldq2;
+  // P as a LIST of 32-channel tensors (the operands of a concat, decoder.py:75): cp block b reads p + b * psplit with voxel stride ldp
+  // (0: one (N, D, H, W, Cp) tensor) -- a workgroup owns one 32-channel block of P anyway
+  long psplit;
 };
 #define WGD_TX 32
 #define WGD_TY 8
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
     // origins: P at (x0 - 1, y0 - 1) of plane 0 -- possibly before the sample's first voxel: every lane that would reach there is masked
     const long pvox = ((long)n * p.D * p.H + (y0 - 1)) * p.W + (x0 - 1);
     const long qvox = ((long)n * p.D * p.H + y0) * p.W + x0;
-    pr = wgd_rsrc(p.p + pvox * p.ldp);
+    pr = wgd_rsrc(p.p + pvox * p.ldp + (p.psplit ? (long)cpt * p.psplit : 0L));
     qr = wgd_rsrc(p.q + qvox * p.ldq);
     if constexpr (K1F) {
       q2r = wgd_rsrc(p.q2 + qvox * p.ldq2);
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(512, 1) void lp_wgd_kernel(const LpWgdParams p) {
         const int row = slot / 40, xl = slot - row * 40;
         const int oct = pos ^ (2 * ((slot >> 3) & 1));
         if (xl < 34 && cp0 + oct * 8 < p.Cp && (unsigned)(x0 - 1 + xl) < (unsigned)p.W && (unsigned)(y0 - 1 + row) < (unsigned)p.H)
-          v = (unsigned)(((row * p.W + xl) * p.ldp + cp0 + oct * 8) * 2);
+          v = (unsigned)(((row * p.W + xl) * p.ldp + (p.psplit ? 0 : cp0) + oct * 8) * 2);
       } else if (id < 41) {
         const int qi = id - 25;
         const int row = qi >> 1, xl = (qi & 1) * 16 + vi;
@@ -496,9 +499,10 @@ bool bts_lp_wgd_gna_ok_(int N, int D, int H, int W, int Cp, int Cq, int in_G) {
 // on the same input, from dy2 (N,D,H,W,Cq); its partial slabs sit behind the 27-tap ones in `ws` (bts_lp_wgd_workspace_ x 28 / 27)
 int bts_lp_wgd_launch_(int dtype, const void* x, const void* dy, float* dw, void* ws, long ws_bytes, int N, int D, int H, int W, int Cp, int ldp,
                        int Cq, int ldq, int dup_start, int dup_shift, int accum, hipStream_t stream, const LpGnaFuse* ga, const void* dy2,
-                       float* dw1, int lddy2) {
+                       float* dw1, int lddy2, long psplit) {
   WgdPlan pl;
   if (!wgd_plan(pl, N, D, H, W, Cp, ldp, Cq, ldq)) return 1;
+  if (psplit != 0 && (psplit < 0 || ga != nullptr || Cp % 32 != 0 || ldp < 32 || psplit % 8 != 0)) return 1;
   if (ga != nullptr && (ldp != Cp || dup_shift != 0 || !bts_lp_wgd_gna_ok_(N, D, H, W, Cp, Cq, ga->G) || ga->cg != Cp / ga->G)) return 1;
   const bool k1f = dy2 != nullptr;
   if (k1f && (ga != nullptr || dw1 == nullptr || lddy2 < Cq || lddy2 % 8 != 0 || (((uintptr_t)dy2) & 15) ||
@@ -510,7 +514,7 @@ int bts_lp_wgd_launch_(int dtype, const void* x, const void* dy, float* dw, void
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cp = Cp; p.ldp = ldp; p.Cq = Cq; p.ldq = ldq;
   p.ntx = pl.ntx; p.nty = pl.nty; p.nzc = pl.nzc; p.ZC = pl.ZC; p.nitems = pl.nitems; p.ipw = pl.ipw; p.ncp = pl.ncp; p.ncq = pl.ncq; p.xcd_order = pl.xcd;
   if (ga != nullptr) { p.ga = *ga; p.ga_zt = D / ga->G; } else { p.ga = LpGnaFuse{}; p.ga_zt = 1; }
-  p.q2 = (const unsigned short*)dy2; p.ldq2 = lddy2;
+  p.q2 = (const unsigned short*)dy2; p.ldq2 = lddy2; p.psplit = psplit;
   p.part2 = p.part + (long)pl.nwg * pl.ncp * pl.ncq * 27 * 1024;
   (void)hipGetLastError();
 #define WGD_LAUNCH(TT) do { if (ga != nullptr) WGD_LAUNCH_(TT, true, false); else if (k1f) WGD_LAUNCH_(TT, false, true); else WGD_LAUNCH_(TT, false, false); } while (0)

@@ -44,6 +44,23 @@ def _ld(t):
     return ld
 
 
+def is_split(t):
+    """a concat of 32-channel tensors kept as a contiguous (B, N, D, H, W, 32) buffer: its operands never sit side by side (decoder.py:75;
+    SURVEY K13: virtual concat as a list of (ptr, C) segments)"""
+    return t.dim() == 6
+
+
+def xdims(t):
+    """(n, d, h, w, channels, voxel stride, elements between the 32-channel operands or 0) of a block input: a 5-d view or a split concat"""
+    if is_split(t):
+        if not t.is_contiguous() or t.shape[-1] != 32:
+            raise RuntimeError('a split concat is a contiguous (B, N, D, H, W, 32) tensor')
+        b, n, d, h, w, _ = t.shape
+        return n, d, h, w, 32 * b, 32, t.stride(0)
+    n, d, h, w, c = t.shape
+    return n, d, h, w, c, _ld(t), 0
+
+
 # ---- C-ABI wrappers ----------------------------------------------------------------------------------------------------
 def pack(kind, code, w, cin_ref, cout, cin_slab=None, dup_start=0, dup_shift=0, role=ops.ROLE_FWD):
     cin_slab = cin_ref if cin_slab is None else cin_slab
@@ -172,7 +189,7 @@ def conv_bwd_weight_pair(code, x, dy3, dy1, dw3, dw1, db3, dup_start=0, dup_shif
     """The weight gradients of conv1 (3x3x3, from dy3) and of the shortcut (1x1x1, from dy1) of a ResnetBlock -- both read the block input x
     (resnet.py:118,134) -- from ONE pass over x (bts_lp_conv3d_bwd_weight_pair) -> True, or False (nothing launched) where the streaming
     kernel does not take the shape: the caller runs conv_bwd_weight twice"""
-    n, d, h, w, cin = x.shape
+    n, d, h, w, cin, ldx, xsplit = xdims(x)
     cout = dy3.shape[-1]
     if tuple(dy1.shape) != tuple(dy3.shape) or not wgrad_supported(ops.K3S1, cin, cout) or (db3 is not None and not dy3.is_contiguous()):
         return False
@@ -180,8 +197,8 @@ def conv_bwd_weight_pair(code, x, dy3, dy1, dw3, dw1, db3, dup_start=0, dup_shif
     if nb < 0:
         return False
     ws = ops.workspace(nb, x.device)
-    r = lib().probe('bts_lp_conv3d_bwd_weight_pair', code, _p(x), _p(dy3), _p(dy1), _p(dw3), _p(dw1), _p(db3) if db3 is not None else None, _p(ws),
-                    nb, n, d, h, w, cin, _ld(x), cout, _ld(dy3), _ld(dy1), dup_start, dup_shift, 1 if accumulate else 0, _stream())
+    r = lib().probe('bts_lp_conv3d_bwd_weight_pair', code, _p(x), xsplit, _p(dy3), _p(dy1), _p(dw3), _p(dw1), _p(db3) if db3 is not None else None,
+                    _p(ws), nb, n, d, h, w, cin, ldx, cout, _ld(dy3), _ld(dy1), dup_start, dup_shift, 1 if accumulate else 0, _stream())
     if r == 1:
         return False
     if r != 0:
@@ -258,8 +275,10 @@ def conv_gn_shortcut(code, tdt, x, wp, bias, cout, norm, wp_pt, bias_pt):
     runs conv1_gap + conv_gn)"""
     if norm._mode != ops.GN_SLAB:
         return None
-    n, d, h, w, cin = x.shape
-    nb = lib().probe('bts_lp_conv3d_fwd_gn_shortcut_workspace', n, d, h, w, cin, _ld(x), cout, norm.groups)
+    n, d, h, w, cin, ldx, xsplit = xdims(x)
+    if xsplit and cin != 64:
+        return None
+    nb = lib().probe('bts_lp_conv3d_fwd_gn_shortcut_workspace', n, d, h, w, cin, ldx, cout, norm.groups)
     if nb < 0:
         return None
     y = torch.empty((n, d, h, w, cout), dtype=tdt, device=x.device)
@@ -268,8 +287,8 @@ def conv_gn_shortcut(code, tdt, x, wp, bias, cout, norm, wp_pt, bias_pt):
     rstd = torch.empty(n * norm.groups, dtype=torch.float32, device=x.device)
     gap = torch.empty((n, cout), dtype=torch.float32, device=x.device)
     ws = ops.workspace(nb, x.device)
-    r = lib().probe('bts_lp_conv3d_fwd_gn_shortcut', code, _p(x), _p(wp), _p(bias), _p(y), _p(mean), _p(rstd), _p(wp_pt), _p(bias_pt), _p(res),
-                    _p(gap), _p(ws), nb, n, d, h, w, cin, _ld(x), cout, norm.groups, float(norm.epsilon), _stream())
+    r = lib().probe('bts_lp_conv3d_fwd_gn_shortcut', code, _p(x), xsplit, _p(wp), _p(bias), _p(y), _p(mean), _p(rstd), _p(wp_pt), _p(bias_pt), _p(res),
+                    _p(gap), _p(ws), nb, n, d, h, w, cin, ldx, cout, norm.groups, float(norm.epsilon), _stream())
     if r == 1:
         return None
     if r != 0:

@@ -103,6 +103,8 @@ class LowPrecisionTrainer(object):
         # conv1 + shortcut + squeeze from one pass over the block input (bts_lp_conv3d_fwd_gn_shortcut); BTS_LP_FS=0 in the library's
         # environment is the A/B switch
         self.fuse_shortcut_fwd = True
+        # level 0's [skip | up-sampled] as two dense operands (see step()); BTS_LP_FWD_SPLIT=0: the 64-wide slab (A/B)
+        self.split_level0 = os.environ.get('BTS_LP_FWD_SPLIT', '1') != '0'
         self.last_labels = None
         self._clock = None
 
@@ -216,6 +218,19 @@ class LowPrecisionTrainer(object):
         clock.nodes_replayed += 1
         clock.sync.params_written(params)
 
+    def _level0_split_ok(self, n, d, h, w, nb, f, spare, dec):
+        """level 0 as two dense 32-channel operands: only where EVERY reader of the pair takes the list (there is no single-tensor fallback)"""
+        if not self.split_level0 or nb != 1 or f != 32 or spare != 32 or not dec.levels or not self.fuse_shortcut_fwd:
+            return False
+        up, blk = dec.levels[-1]
+        from ._lib import lib
+        if up.filters != 32 or blk.norm1._mode != ops.GN_SLAB or not lowp.wgrad_supported(ops.K3S1, 64, blk.filters):
+            return False
+        L = lib()
+        return (lowp.conv_bwd_data_sc_split_ok(n, d, h, w, 64, blk.filters)
+                and L.probe('bts_lp_conv3d_fwd_gn_shortcut_workspace', n, d, h, w, 64, 32, blk.filters, blk.norm1.groups) >= 0
+                and L.probe('bts_lp_conv3d_bwd_weight_pair_workspace', n, d, h, w, 64, blk.filters) >= 0)
+
     @staticmethod
     def _backward_stages(n_vae, n_dec, blocks_per_level):
         """stages of the explicit backward that report parameters: vae.out, (block, up) per VAE level, vae.upsample, the dense pair,
@@ -233,7 +248,7 @@ class LowPrecisionTrainer(object):
     def _block_fwd(self, blk, x, out, fold=None):
         code, tdt = self.code, self.tdt
         f, g = blk.filters, blk.groups
-        n, d, h, w, cin = x.shape
+        n, d, h, w, cin = lowp.xdims(x)[:5]      # (x: a 5-d view, or the two operands of the level-0 concat as a (2, N, D, H, W, 32) buffer)
         dup_start, dup_shift = fold if fold else (0, 0)
         v = d * h * w
         cin_slab = min(cin, blk.cin_ref) if fold is None else cin       # (the zero-padded 2-channel input: cin 16, cin_ref 2)
@@ -248,6 +263,8 @@ class LowPrecisionTrainer(object):
             c1, m1, r1, res, gap = both
             hbuf, ch = ops.se_mlp_fwd(gap, blk.se_w1.t, blk.se_w2.t)
             gate = None
+        elif lowp.is_split(x):
+            raise RuntimeError('split concat input: the fused two-pass launch declined a shape its query accepted')
         else:
             res, gap, (hbuf, ch), gate = lowp.gate_branch(code, tdt, x, wp_pt, blk.ptwise_b.t, f, blk.se_w1.t, blk.se_w2.t, side=False)
             c1, m1, r1 = conv_gn(code, tdt, x, wp_c1, blk.conv1_b.t, f, blk.norm1)      # conv + the statistics of its output
@@ -286,8 +303,9 @@ class LowPrecisionTrainer(object):
         lp2 = lowp.wgrad_supported(ops.K3S1, f, f)
         # conv1 / shortcut weight gradients on the 16-bit kernel; the first block reads the 2-channel volume zero-padded to one matrix
         # step: its gradients are taken over all 16 stored channels into a scratch tensor and the live rows added to the real slots
-        pad_in = cin_slab < x.shape[-1]
-        lp1 = lowp.wgrad_supported(ops.K3S1, x.shape[-1], f)
+        xc = lowp.xdims(x)[4]
+        pad_in = cin_slab < xc
+        lp1 = lowp.wgrad_supported(ops.K3S1, xc, f)
         # conv branch: GN2 (+ReLU) -> conv2 -> GN1 (+ReLU) -> conv1
         # gate backward and GroupNorm-2 backward both read dout: one pair of passes where the fused kernels' tiling fits
         fused = None
@@ -361,6 +379,8 @@ class LowPrecisionTrainer(object):
                 # accumulator of the streaming 3x3x3 kernel; bts_lp_conv3d_bwd_weight_pair) where that kernel takes the layer
                 if lowp.conv_bwd_weight_pair(code, x, dc1_16, dres_16, self._gslot(blk.conv1_k), self._gslot(blk.ptwise_k), db1, dup_start, dup_shift, True):
                     return
+                if lowp.is_split(x):
+                    raise RuntimeError('split concat input: the paired weight-gradient launch declined a shape its query accepted')
                 _wgrad16(ops.K3S1, code, x, dc1_16, self._gslot(blk.conv1_k), db1, dup_start, dup_shift, True)
                 _wgrad16(ops.K1, code, x, dres_16, self._gslot(blk.ptwise_k), None, dup_start, dup_shift, True)   # (bias: se_bwd)
             self._wg((x, dc1_16, dres_16), wgrads)
@@ -372,7 +392,7 @@ class LowPrecisionTrainer(object):
                 ops.conv_bwd_weight(ops.K1, x32, dres, self._gslot(blk.ptwise_k), self._gslot(blk.ptwise_b), dup_start, dup_shift, accumulate=True)
             self._wg((x32, dc1, dres), wgrads)
         if dx is not None:
-            cin = x.shape[-1]
+            cin = xc
             assert dx.shape[-1] == cin or (dx.dim() == 6 and dx.shape[0] * 32 == cin)
             wpb1 = self._pk((key, 'c1b'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin, dup_start, dup_shift, role=ops.ROLE_BWD)
             wpbp = self._pk((key, 'ptb'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin, dup_start, dup_shift, role=ops.ROLE_BWD)
@@ -521,10 +541,19 @@ class LowPrecisionTrainer(object):
             f = enc.base_filters * 2 ** i
             nb = len(convs)
             spare = f if i < enc.depth - 1 else 0
-            slab = torch.empty((n, d, h, w, nb * f + spare), dtype=tdt, device=dev)
+            # Level 0 of the CLI model: [o_0 (32) | up-sampled (32)] (decoder.py:75) as TWO dense tensors instead of a 64-wide slab (SURVEY K13:
+            # virtual concat as a list of segments) where every reader of the pair takes the list -- conv1 + shortcut of the decoder's top
+            # block ride on two z-marching passes, one per operand (bts_lp_conv3d_fwd_gn_shortcut, x_split), their weight gradients read
+            # one 32-channel block of P per workgroup anyway (bts_lp_conv3d_bwd_weight_pair, x_split), the data gradient leaves split as well
+            # (gsplit below).  The readers of ONE operand (the down-sampler, the skip level's kernels) then fetch whole 128-byte lines.
+            split0 = i == 0 and self._level0_split_ok(n, d, h, w, nb, f, spare, dec)
+            if split0:
+                slab = torch.empty((2, n, d, h, w, 32), dtype=tdt, device=dev)
+            else:
+                slab = torch.empty((n, d, h, w, nb * f + spare), dtype=tdt, device=dev)
             saves = []
             for j, blk in enumerate(convs):
-                out = slab[..., j * f:(j + 1) * f]
+                out = slab[0] if split0 else slab[..., j * f:(j + 1) * f]
                 if j == 0:
                     _, sv = self._block_fwd(blk, cur, out)
                 else:
@@ -532,7 +561,7 @@ class LowPrecisionTrainer(object):
                 saves.append(sv)
             dsave = None
             if down is not None:
-                cur, dsave = self._sampler_fwd(down, ops.K3S2, slab[..., :nb * f])
+                cur, dsave = self._sampler_fwd(down, ops.K3S2, slab[0] if split0 else slab[..., :nb * f])
             levels.append((slab, nb * f, saves, dsave))
         top_slab, top_used = levels[-1][0], levels[-1][1]
         top = top_slab[..., :top_used]
@@ -543,8 +572,12 @@ class LowPrecisionTrainer(object):
             li = len(levels) - 2 - k
             slab, cres = levels[li][0], levels[li][1]
             f = up.filters
-            _, us = self._sampler_fwd(up, ops.K3S2T, yk, out=slab[..., cres:cres + f])
-            yk, bs = self._block_fwd(blk, slab[..., :cres + f], None)
+            if lowp.is_split(slab):       # (level 0 as two dense operands: see above)
+                _, us = self._sampler_fwd(up, ops.K3S2T, yk, out=slab[1])
+                yk, bs = self._block_fwd(blk, slab, None)
+            else:
+                _, us = self._sampler_fwd(up, ops.K3S2T, yk, out=slab[..., cres:cres + f])
+                yk, bs = self._block_fwd(blk, slab[..., :cres + f], None)
             dsaves.append((us, bs, li, cres, f))
         y_last = yk
         y_pred = head(code, y_last, dec.out_k.t.reshape(dec.out_k.t.shape[-2], dec.out_k.t.shape[-1]), dec.out_b.t, True)
@@ -613,9 +646,11 @@ class LowPrecisionTrainer(object):
             slab0, used0 = levels[0][0], levels[0][1]
             f0 = dsaves[-1][4]
             blk0 = dsaves[-1][1]['blk']
-            if used0 == 32 and f0 == 32 and slab0.shape[-1] == 64 and len(levels[0][2]) == 1 and \
-                    lowp.conv_bwd_data_sc_split_ok(n, slab0.shape[1], slab0.shape[2], slab0.shape[3], 64, blk0.filters):
-                gsplit = torch.empty((2,) + tuple(slab0.shape[:4]) + (32,), dtype=tdt, device=dev)
+            n0, d0, h0, w0, width0 = lowp.xdims(slab0)[:5]
+            if used0 == 32 and f0 == 32 and width0 == 64 and len(levels[0][2]) == 1 and \
+                    lowp.conv_bwd_data_sc_split_ok(n, d0, h0, w0, 64, blk0.filters):
+                gsplit = torch.empty((2, n, d0, h0, w0, 32), dtype=tdt, device=dev)
+            assert gsplit is not None or not lowp.is_split(slab0)      # (_level0_split_ok asked the same question)
         gslabs = [None if (i == 0 and gsplit is not None) else torch.empty_like(lv[0]) for i, lv in enumerate(levels)]
 
         def gview(i, c0, c1):
@@ -700,7 +735,7 @@ class LowPrecisionTrainer(object):
         self._written([dec.out_k, dec.out_b])
         for idx in range(len(dsaves) - 1, -1, -1):
             us, bs, li, cres, f = dsaves[idx]
-            assert levels[li][0].shape[-1] == cres + f
+            assert lowp.xdims(levels[li][0])[4] == cres + f
             self._block_bwd(bs, dcur, gview(li, 0, cres + f), first=True)    # skip part [0, cres) and the up-sampled part [cres, cres + f)
             if idx == 0:                                         # the first up layer read the top level's slab view
                 self._sampler_bwd(us, gview(li, cres, cres + f), gslabs[-1][..., :top_used], True)

@@ -302,12 +302,13 @@ int bts_lp_conv3d_bwd_data_sc(int dtype, const void* dy, const void* wp_bwd, con
  * from ONE pass over that input (train.py:151): dw3 (+)= from dy3 as bts_lp_conv3d_bwd_weight(K3S1), dw1 (Keras layout (1,1,1,Cin_ref,Cout))
  * (+)= sum_v x[v][c] dy1[v][k] -- one more accumulator per wave of the streaming kernel, fed by the centre-tap fragments of x it reads anyway;
  * the HBM-bound 1x1x1 weight-gradient launch and its own read of the Cin-wide x go away.  db3 (may be NULL; dy3 dense then) (+)= sum dy3.
- * dup_start / dup_shift fold both kernels alike.  Workspace query -1 / return value 1 (nothing launched) outside the streaming kernel's
+ * dup_start / dup_shift fold both kernels alike.  x_split (elements; 0 = one tensor): x as a list of Cin / 32 dense 32-channel tensors x +
+ * b * x_split with voxel stride ldx (the operands of a concat; no fold then).  Workspace query -1 / return value 1 (nothing launched) outside the streaming kernel's
  * shapes (W % 32, H % 8, large volumes): run bts_lp_conv3d_bwd_weight twice.  BTS_LP_WPAIR=0 in the environment: never (A/B aid) */
 long bts_lp_conv3d_bwd_weight_pair_workspace(int N, int D, int H, int W, int Cin, int Cout);
-int bts_lp_conv3d_bwd_weight_pair(int dtype, const void* x, const void* dy3, const void* dy1, float* dw3, float* dw1, float* db3, void* workspace,
-                                  long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int lddy3, int lddy1,
-                                  int dup_start, int dup_shift, int accumulate, bts_stream_t stream);
+int bts_lp_conv3d_bwd_weight_pair(int dtype, const void* x, long x_split, const void* dy3, const void* dy1, float* dw3, float* dw1, float* db3,
+                                  void* workspace, long workspace_bytes, int N, int D, int H, int W, int Cin, int ldx, int Cout, int lddy3,
+                                  int lddy1, int dup_start, int dup_shift, int accumulate, bts_stream_t stream);
 /* dw (fp32, Keras layout (kd,kh,kw,Cin_ref,Cout)) (+)= the weight gradient of a stride-1 3x3x3 / 1x1x1 conv from 16-bit x and dy
  * (voxel contraction on the 16-bit matrix pipe, fp32 partials, fixed-order finalize); db (may be NULL; dy dense then) (+)= sum dy.
  * dup_start / dup_shift as bts_conv_pack: Cin + dup_shift == Cin_ref, both copies of the folded slice receive the gradient.
@@ -401,10 +402,13 @@ int bts_lp_conv1_gap_acc(int dtype, const void* x, const void* wp, const float* 
  * y = conv3x3x3(x) + bias with GroupNorm G's statistics of y (as bts_lp_conv3d_fwd_gn), res = conv1x1x1(x) + bias_pt and gap[n][c] = mean
  * over the voxels of the unrounded res (as bts_lp_conv1_gap).  The shortcut is a second set of output columns at the centre tap of the
  * z-marching kernel's input planes: x is read once.  wp / wp_pt = bts_lp_pack(K3S1 / K1, BTS_ROLE_FWD, ...) with the same Cin_slab and
- * fold; y, res dense (N,D,H,W,Cout).  Workspace query -1 / return value 1 (nothing launched) outside the kernel's shapes: run
- * bts_lp_conv1_gap + bts_lp_conv3d_fwd_gn.  BTS_LP_FS=0 in the environment: never (A/B aid) */
+ * fold; y, res dense (N,D,H,W,Cout).  Cin = 64 on volumes of >= 8 M voxels: both ride on the two z-marching passes over the channel halves.
+ * x_split (elements; 0 = x is one (N,D,H,W,Cin) view): Cin = 64 as TWO 32-channel tensors x and x + x_split with voxel stride ldx each -- the
+ * operands of a concat (decoder.py:75) never materialised side by side, each read in whole lines (virtual concat as a list of
+ * (ptr, C) segments).  Workspace query -1 / return value 1 (nothing launched) outside the kernel's shapes: run bts_lp_conv1_gap +
+ * bts_lp_conv3d_fwd_gn.  BTS_LP_FS=0 in the environment: never, BTS_LP_FS_PAIR=0: not on the two-pass form (A/B aids) */
 long bts_lp_conv3d_fwd_gn_shortcut_workspace(int N, int D, int H, int W, int Cin, int ldx, int Cout, int G);
-int bts_lp_conv3d_fwd_gn_shortcut(int dtype, const void* x, const void* wp, const float* bias, void* y, float* mean, float* rstd,
+int bts_lp_conv3d_fwd_gn_shortcut(int dtype, const void* x, long x_split, const void* wp, const float* bias, void* y, float* mean, float* rstd,
                                   const void* wp_pt, const float* bias_pt, void* res, float* gap, void* workspace, long workspace_bytes,
                                   int N, int D, int H, int W, int Cin, int ldx, int Cout, int G, float eps, bts_stream_t stream);
 /* The same with the GroupNorm + ReLU of the INPUT applied on the way in (in_relu = 1): y = conv3x3x3(relu(GN_in(x))) + bias and the statistics of y.
