@@ -1191,7 +1191,8 @@ extern "C" long bts_lp_conv3d_fwd_gn_shortcut_workspace(int N, int D, int H, int
   static const bool off = [] { const char* e = getenv("BTS_LP_FS"); return e && atoi(e) == 0; }();
   static const bool off64 = [] { const char* e = getenv("BTS_LP_FS_PAIR"); return e && atoi(e) == 0; }();      // BTS_LP_FS_PAIR=0: not on the two-pass 64-channel form (A/B)
   if (off || (off64 && Cin == 64)) return -1;
-  const long Bg = bts_lp_s1z_gn_B_(N, D, H, W, Cin, Cout, G), Bf = bts_lp_s1z_fs_B_(N, D, H, W, Cin, ldx, Cout, Cout);
+  // (two dense 32-channel operands -- voxel stride 32 under 64 channels: the two-pass form at any size, planned like one of its passes)
+  const long Bg = bts_lp_s1z_gn_B_(N, D, H, W, (Cin == 64 && ldx < 64) ? 32 : Cin, Cout, G), Bf = bts_lp_s1z_fs_B_(N, D, H, W, Cin, ldx, Cout, Cout);
   if (Bg <= 0 || Bf <= 0) return -1;
   return (long)N * G * Bg * 16 + 64 + (long)N * Bf * Cout * 8 + 64;
 }
@@ -1207,7 +1208,7 @@ extern "C" int bts_lp_conv3d_fwd_gn_shortcut(int dtype, const void* x, long x_sp
     return BTS_ERR_ALIGN;
   if (ldx % 8 != 0 || ldx < (x_split ? 32 : Cin) || (((uintptr_t)x) & 15) || (((uintptr_t)wp) & 15)) return BTS_ERR_ALIGN;
   if (x_split != 0 && (Cin != 64 || x_split < 0 || x_split % 8 != 0)) return BTS_ERR_SHAPE;      // (two 32-channel operands: the two-pass form)
-  const long Bg = bts_lp_s1z_gn_B_(N, D, H, W, Cin, Cout, G), Bf = bts_lp_s1z_fs_B_(N, D, H, W, Cin, ldx, Cout, Cout);
+  const long Bg = bts_lp_s1z_gn_B_(N, D, H, W, (Cin == 64 && ldx < 64) ? 32 : Cin, Cout, G), Bf = bts_lp_s1z_fs_B_(N, D, H, W, Cin, ldx, Cout, Cout);
   double* gpart = reinterpret_cast<double*>(workspace);
   double* fpart = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + (((long)N * G * Bg * 16 + 63) / 64) * 64);
   const long V = (long)D * H * W;

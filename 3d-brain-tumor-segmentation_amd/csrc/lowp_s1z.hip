@@ -669,7 +669,9 @@ static bool s1z_pair_takes(long voxels) {
   return voxels >= (8L << 20);
 }
 static bool s1z_plan(S1zPlan& pl, int N, int D, int H, int W, int Cin, int ldx, int Cout, int ldy) {
-  if (Cin == 64 && s1z_pair_takes((long)N * D * H * W)) Cin = 32;       // (the geometry of both passes: the plan does not depend on the channel half)
+  // (the geometry of both passes: the plan does not depend on the channel half.  A voxel stride below 64 says the halves are two dense
+  // tensors -- the operands of a concat -- which no other kernel reads as one: the pair at any size)
+  if (Cin == 64 && (ldx < 64 || s1z_pair_takes((long)N * D * H * W))) Cin = 32;
   if (!s1z_enabled() || (Cin != 16 && Cin != 32) || Cout > 32 || Cout % 8 != 0 || W % S1Z_TX != 0 || H % S1Z_TY != 0 || D < 8) return false;
   if (ldx % 8 != 0 || ldy % 8 != 0) return false;
   if ((long)D * H * W * (long)ldx * 2 >= 0x7fffffffL || (long)D * H * W * (long)ldy * 2 >= 0x7fffffffL) return false;

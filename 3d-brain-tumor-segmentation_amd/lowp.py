@@ -654,6 +654,10 @@ class LowPrecisionForward(object):
         self.early_skip = os.environ.get('BTS_LP_EARLY_SKIP', '0') == '1'
         self.fuse_head = os.environ.get('BTS_LP_FUSE_HEAD', '1') != '0'      # (=0: block epilogue and output head as two launches; A/B)
         self.fuse_first = os.environ.get('BTS_LP_C2', '1') != '0'            # (=0: padded 16-channel copy + generic kernels for the first block; A/B)
+        # the top decoder block's [skip | up-sampled] input (decoder.py:75) as two DENSE 32-channel operands instead of a 64-channel slab: its
+        # conv1, shortcut and squeeze are then two z-marching passes over whole 128-byte lines (bts_lp_conv3d_fwd_gn_shortcut with x_split),
+        # and the level's other readers (down-sampler, up-sampler's GroupNorm) see dense tensors too (=0: the slab; A/B)
+        self.split_level0 = os.environ.get('BTS_LP_INF_SPLIT', '1') != '0'
         bf = getattr(model.encoder, 'base_filters', 16)
         if bf % 16 != 0:
             # every 16-bit convolution contracts over whole matrix steps of 16 input channels (v_mfma_f32_32x32x16): an 8-filter level
@@ -711,7 +715,7 @@ class LowPrecisionForward(object):
         and its only reader is the sigmoid output head -- returns ('head', y_pred) where the fused epilogue takes the shape"""
         code, tdt = self.code, self.tdt
         f, g = blk.filters, blk.groups
-        n, d, h, w, cin = x.shape
+        n, d, h, w, cin = xdims(x)[:5]      # (x: a 5-d view, or the two operands of the level-0 concat as a (2, N, D, H, W, 32) buffer)
         dup_start, dup_shift = fold if fold else (0, 0)
         v = d * h * w
         key = id(blk)
@@ -732,6 +736,15 @@ class LowPrecisionForward(object):
             torch.cuda.current_stream().wait_event(ev)
             res, gap, (_, ch), gate = gate_branch(code, tdt, xu, wp_pt, None, f, blk.se_w1.t, blk.se_w2.t, acc_into=resp, after=ev)
             c1, m1, r1 = conv_gn(code, tdt, xu, wp_c1, None, f, blk.norm1, acc_into=c1p)
+        elif is_split(x):          # conv1 + statistics, shortcut + squeeze: one launch pair over the two dense operands
+            wp_pt = self._packed((key, 'pt'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin_slab, 0, 0)
+            wp_c1 = self._packed((key, 'c1'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin_slab, 0, 0)
+            both = conv_gn_shortcut(code, tdt, x, wp_c1, blk.conv1_b.t, f, blk.norm1, wp_pt, blk.ptwise_b.t)
+            if both is None:
+                raise RuntimeError('split concat input: the fused two-pass launch declined a shape its query accepted')
+            c1, m1, r1, res, gap = both
+            _, ch = ops.se_mlp_fwd(gap, blk.se_w1.t, blk.se_w2.t)
+            gate = None
         else:
             wp_pt = self._packed((key, 'pt'), ops.K1, blk.ptwise_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
             wp_c1 = self._packed((key, 'c1'), ops.K3S1, blk.conv1_k, blk.cin_ref, f, cin_slab, dup_start, dup_shift)
@@ -759,6 +772,17 @@ class LowPrecisionForward(object):
             out = torch.empty((n, d, h, w, f), dtype=tdt, device=res.device)
         return block_epilogue(code, res, c2, out, blk.spatial_k.t.reshape(-1), ch, blk.norm2.gamma.t, blk.norm2.beta.t, m2, r2, g,
                               blk.norm2._mode)
+
+    def _level0_split_ok(self, n, d, h, w, nb, f):
+        """can level 0 live as two dense 32-channel operands?  One encoder block there (its output is the whole skip), a decoder that
+        concatenates [skip | up-sampled] of 32 channels each, and the library taking the pair in its fused two-pass form"""
+        m = self.model
+        if not self.split_level0 or self.early_skip or nb != 1 or f != 32 or len(m.decoder.levels) < 1 or len(m.encoder.levels) < 2:
+            return False
+        up, blk = m.decoder.levels[-1]
+        if up.filters != f or blk.filters != f or blk.norm1._mode != ops.GN_SLAB:
+            return False
+        return lib().probe('bts_lp_conv3d_fwd_gn_shortcut_workspace', n, d, h, w, 2 * f, f, f, blk.norm1.groups) >= 0
 
     def _down(self, lay, x):
         if isinstance(lay, self._max):                                                   # downsample.py:51-70
@@ -819,6 +843,14 @@ class LowPrecisionForward(object):
             f = enc.base_filters * 2 ** i
             nb = len(convs)
             spare = f if i < enc.depth - 1 else 0
+            if i == 0 and self._level0_split_ok(n, d, h, w, nb, f):
+                # level 0 as two dense operands: [0] this level's output (the skip), [1] the up-sampled tensor the decoder writes later
+                pair = torch.empty((2, n, d, h, w, f), dtype=self.tdt, device=x.device)
+                self._block(convs[0], cur, pair[0], first=first)
+                residuals.append((pair, f))
+                if down is not None:
+                    cur = self._down(down, pair[0])
+                continue
             slab = torch.empty((n, d, h, w, nb * f + spare), dtype=self.tdt, device=x.device)
             for j, blk in enumerate(convs):
                 out = slab[..., j * f:(j + 1) * f]
@@ -845,9 +877,13 @@ class LowPrecisionForward(object):
         nlev = len(dec.levels)
         for li, ((up, blk), (slab, cres)) in enumerate(zip(dec.levels, residuals[-2::-1])):
             f = up.filters
+            lvl = nlev - 1 - li                                                            # the encoder level whose output is the skip
+            if is_split(slab):
+                self._up(up, y, slab[1])
+                y = self._block(blk, slab, None, head=(hw, dec.out_b.t) if li == nlev - 1 else None)
+                continue
             self._up(up, y, slab[..., cres:cres + f])                                     # decoder.py:72
             # (the top block's output has one reader, the output head: folded into its epilogue where the library can)
-            lvl = nlev - 1 - li                                                            # the encoder level whose output is the skip
             y = self._block(blk, slab[..., :cres + f], None, head=(hw, dec.out_b.t) if li == nlev - 1 else None,  # decoder.py:75-78
                             early=early.get(lvl), cres=cres)
         if isinstance(y, tuple):

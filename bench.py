@@ -147,24 +147,39 @@ def step_rooflines(alg_tflop, alg_gb, sec, dt, suffix):
         nsteps = float(tab['_meta']['steps_in_capture'])
         rd = wr = 0.0
         hows = set()
-        once = 0.0      # bytes of launches that are not per-step work (weight packing at construction, first-use initialisation):
-        for k, v in tab.items():   # a kernel whose launch count is not a multiple of the captured steps ran outside the step loop
+        once = 0.0      # bytes of launches that are not per-step work (weight packing at construction, first-use initialisation)
+        steady = bool(tab['_meta'].get('steady_step_launches'))
+        for k, v in tab.items():
             if k.startswith('_'):
                 continue
             b = _kernel_bytes(v)
             if b is None:
                 continue
+            hows.add(b[2].split(':')[0].split(' (')[0])
+            if steady:
+                # the capture names its last full step (scripts/pmc_aggregate.py: the dispatches between the last two Adam dispatches):
+                # a step's bytes are that step's launches x their own counter means; everything else a kernel moved in the capture
+                # beyond (steps x that) ran once (every weight image is packed by a launch of its own at first use)
+                sv = v.get('steady')
+                sb = _kernel_bytes(sv) if sv else None
+                if sb is not None:
+                    rd += sb[0] * sv['launches'] * nsteps
+                    wr += sb[1] * sv['launches'] * nsteps
+                once += max((b[0] + b[1]) * v['launches'] - ((sb[0] + sb[1]) * sv['launches'] * nsteps if sb else 0.0), 0.0)
+                continue
+            # older captures: a kernel whose launch count is not a multiple of the captured steps ran outside the step loop
             extra = v['launches'] % int(nsteps)
             per_step = v['launches'] - extra
             rd += b[0] * per_step
             wr += b[1] * per_step
             once += (b[0] + b[1]) * extra
-            hows.add(b[2].split(':')[0].split(' (')[0])
         out.update({'measured_hbm_gb_per_step': (rd + wr) / nsteps / 1e9, 'measured_read_gb_per_step': rd / nsteps / 1e9,
                     'measured_write_gb_per_step': wr / nsteps / 1e9, 'wasted_traffic_ratio': (rd + wr) / nsteps / 1e9 / alg_gb,
                     'measured_hbm_frac_of_step': (rd + wr) / nsteps / sec / (PEAK_HBM_TBS * 1e12),
                     'outside_the_step_loop_gb': once / 1e9,
-                    'read_side': sorted(hows), 'source': 'committed capture ' + src + ' (all kernels, %d steps)' % nsteps})
+                    'read_side': sorted(hows),
+                    'source': 'committed capture ' + src + (' (all kernels of its last full step: %d launches)' % tab['_meta']['steady_step_launches']
+                                                            if steady else ' (all kernels, %d steps)' % nsteps)})
     return out
 
 

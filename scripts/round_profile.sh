@@ -78,35 +78,10 @@ traffic_passes ""
 traffic_passes "_bf16_b8" --dtype bf16 --batch 8
 traffic_passes "_infer_f16" --infer --dtype f16
 
+python3 "$R/scripts/pmc_aggregate.py" "$O" "$TAG"
 python3 - "$O" "$TAG" <<'PY'
-import collections, csv, glob, json, sys
+import csv, sys
 O, TAG = sys.argv[1], sys.argv[2]
-for sfx in ('', '_bf16_b8', '_infer_f16'):
-    out = {}
-    for name in ('fetch', 'write', 'req', 'sq'):
-        files = glob.glob('%s/pmc_%s%s_%s/**/%s_counter_collection.csv' % (O, TAG, sfx, name, name), recursive=True)
-        assert len(files) == 1, files
-        agg = collections.defaultdict(lambda: collections.defaultdict(list))
-        for r in csv.DictReader(open(files[0])):
-            ctr = r['Counter_Name']
-            if name == 'sq' and ctr == 'GRBM_GUI_ACTIVE':
-                ctr = 'GRBM_GUI_ACTIVE_sqpass'                # (the launch cycles of the pass the SQ counters were taken in)
-            agg[r['Kernel_Name'].split('(')[0]][ctr].append(float(r['Counter_Value']))
-            if ctr == 'GRBM_GUI_ACTIVE':       # duration of the same dispatch, for the clock
-                agg[r['Kernel_Name'].split('(')[0]]['duration_ns'].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
-        assert agg, 'no rows in %s' % files[0]
-        for k, cs in agg.items():
-            for ctr, v in cs.items():
-                key = ctr + ('_KiB' if ctr in ('FETCH_SIZE', 'WRITE_SIZE') else '')
-                out.setdefault(k, {})[key + '_mean'] = sum(v) / len(v)
-                out[k]['launches'] = len(v)
-    for k, v in out.items():       # matrix-pipe busy fraction per kernel (0 for kernels without matrix instructions)
-        if 'SQ_VALU_MFMA_BUSY_CYCLES_mean' in v and v.get('GRBM_GUI_ACTIVE_sqpass_mean'):
-            v['mfma_busy'] = v['SQ_VALU_MFMA_BUSY_CYCLES_mean'] / (v['GRBM_GUI_ACTIVE_sqpass_mean'] / 8.0 * 1024.0)
-    # 3 steps per capture (1 warm-up + 2 timed; --no-profile: no further ones); one-time construction kernels are in there too
-    out['_meta'] = {'steps_in_capture': 3, 'command': 'bench.py%s --steps 2 --warmup 1 --serial-streams under rocprofv3 --kernel-trace --pmc <group>'
-                    % {'': '', '_bf16_b8': ' --dtype bf16 --batch 8', '_infer_f16': ' --infer --dtype f16'}[sfx]}
-    json.dump(out, open('%s/%s_pmc_traffic%s.json' % (O, TAG, sfx), 'w'), indent=1, sort_keys=True)
 rows = list(csv.DictReader(open('%s/%s_bench_kernel_stats.csv' % (O, TAG))))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 print('kernel time per step (7 steps in the trace): %.2f ms' % (tot / 7e6))

@@ -1068,3 +1068,45 @@ def test_inference_forward_with_the_skip_part_of_the_decoder_blocks_on_a_side_st
     d = (y1 - y0).abs()
     assert 0.0 < float(d.max()) <= 2e-3, float(d.max())
     assert float((y1.argmax(-1) != y0.argmax(-1)).float().mean()) <= 1e-3
+
+
+@pytest.mark.parametrize('dtype,scale', [('float16', 1.0), ('bfloat16', 8.0)])
+def test_inference_forward_with_level_0_as_two_dense_operands(dtype, scale, monkeypatch):
+    """decoder.py:75 at the top level as a list of (ptr, C) segments: the encoder's level-0 output and the up-sampled tensor are two
+    dense 32-channel tensors, the top decoder block's conv1 + GroupNorm statistics + shortcut + squeeze one fused launch pair over them
+    (bts_lp_conv3d_fwd_gn_shortcut, x_split).  Held against the fp64 ORACLE and the fp32 engine like the slab route, next to the slab route
+    (BTS_LP_INF_SPLIT=0) itself; the launch records say which form ran."""
+    import bts_amd  # noqa: F401
+    from bts_amd import lowp, ops
+    kw = dict(base_filters=32, groups=8, reduction=4, depth=3)
+    crop = (40, 16, 96)
+    m = _model(kw, crop, 11)
+    x = torch.randn((1,) + crop + (2,), generator=torch.Generator().manual_seed(3)).to(DEV)
+    y32 = m(x, training=False, inference=True)[0].t
+
+    def run():
+        ops.profile_enable(True)
+        y = lowp.LowPrecisionForward(m, dtype)(x)
+        torch.cuda.synchronize()
+        names = [r[0] for r in ops.profile_records()]
+        ops.profile_enable(False)
+        return y, names
+    y1, n1 = run()
+    monkeypatch.setenv('BTS_LP_INF_SPLIT', '0')
+    y0, n0 = run()
+    # split: the top decoder block's conv1 and shortcut are two z-marching launches (one per operand) instead of a tiled conv + a 1x1x1 conv
+    cnt = lambda names, k: sum(1 for q in names if q == k)
+    print('profiled launches: split %s ; slab %s' % (sorted(set((k, cnt(n1, k)) for k in n1)), sorted(set((k, cnt(n0, k)) for k in n0))))
+    assert cnt(n1, 'lp_s1z_kernel') > cnt(n0, 'lp_s1z_kernel') and cnt(n1, 'lp_k1_kernel') == cnt(n0, 'lp_k1_kernel') - 1
+    cfg = R.default_config(**kw)
+    P = R.ParamSet()
+    for p in m.trainable_variables:
+        P[m.oracle_name(p)] = p.t.detach().cpu().double()
+    yo = R.model(x.cpu().double(), P, cfg, training=False, inference=True)[0]
+    for tag, y in (('split', y1), ('slab', y0)):
+        mx, mean, mism = _compare(y, y32, '%s %s vs fp32 engine' % (dtype, tag))
+        assert mx <= 2e-2 * scale and mean <= 1e-3 * scale and mism <= 2e-3 * scale
+        mx, mean, mism = _compare(y.cpu().double(), yo, '%s %s vs fp64 oracle' % (dtype, tag))
+        assert mx <= 2e-2 * scale and mean <= 1e-3 * scale and mism <= 2e-3 * scale
+    d = (y1 - y0).abs()
+    assert 0.0 < float(d.max()) <= 5e-3 * scale, float(d.max())
