@@ -26,6 +26,8 @@ long bts_w3_workspace_(int N, int D, int H, int W, int Cin, int Cout);
 int bts_igemm_reduce_(const float* part, const float* bias, float* y, long nvox, int Cout, int Npad, int ldy, int ksplit,
                       int with_bias, int accum, hipStream_t stream);
 // se.hip: stages 2a + 2 of the gate backward (sum the per-block partials [n][b][F][{ch, w}], SE-MLP backward, dgap / V)
+int bts_se_mlp_bwd_sample_(const double* red, double* scratch, const float* h, const float* ch, const float* w1, const float* w2, float* dgap, int N,
+                           long V, int F, int R, hipStream_t stream);
 int bts_se_bwd_middle_(double* partial, double* red, double* scratch, const float* gap, const float* h, const float* ch, const float* w1,
                        const float* w2, float* dw1, float* dw2, float* dwsp, float* dgap, int N, int B, long V, int F, int R,
                        int accumulate_params, hipStream_t stream);

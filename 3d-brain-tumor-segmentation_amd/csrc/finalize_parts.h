@@ -69,3 +69,31 @@ __device__ __forceinline__ void se_bwd_partial_reduce_body(const double* partial
   b = wave_sum_f64(b);
   if (lane == 0) { red[i * 2] = a; red[i * 2 + 1] = b; }
 }
+
+// gate backward, the sums over the samples (dW2, dW1, dw_sp) for workgroup `blk` of ceil(R * F / 256): se.hip's se_mlp_bwd_param_kernel, and one
+// role of the 16-bit block backward's tail launch (lowp.hip).  red: [N][F][2] summed partials; scratch: dz2 [N][F] | dz1 [N][R] of the per-sample pass.
+__device__ __forceinline__ void se_mlp_bwd_param_body(const double* red, const float* gap, const float* hbuf, float* dw1, float* dw2, float* dwsp,
+                                                      const double* scratch, int N, int F, int R, int accum, int blk) {
+  const double* dz2 = scratch;
+  const double* dz1 = scratch + (long)N * F;
+  const int i = blk * 256 + threadIdx.x;
+  if (i < R * F) {
+    {
+      const int k = i / F, c = i % F;
+      double s = 0.0;
+      for (int n = 0; n < N; ++n) s += (double)hbuf[n * R + k] * dz2[n * F + c];
+      dw2[i] = accum ? dw2[i] + (float)s : (float)s;
+    }
+    {
+      const int c = i / R, k = i % R;
+      double s = 0.0;
+      for (int n = 0; n < N; ++n) s += (double)gap[n * F + c] * dz1[n * R + k];
+      dw1[i] = accum ? dw1[i] + (float)s : (float)s;
+    }
+  }
+  if (i < F) {
+    double s = 0.0;
+    for (int n = 0; n < N; ++n) s += red[((long)n * F + i) * 2 + 1];
+    dwsp[i] = accum ? dwsp[i] + (float)s : (float)s;
+  }
+}

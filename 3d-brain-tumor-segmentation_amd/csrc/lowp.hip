@@ -29,6 +29,7 @@ void bts_prof_begin(int sym, double flops, hipStream_t stream);
 void bts_prof_end(hipStream_t stream);
 
 #include "lowp_common.h"
+#include "finalize_parts.h"
 
 // lowp_s1d.hip: LDS-DMA staged stride-1 3x3x3 kernel (offered first; 1 = declined) and its part of the K3S1 image
 long bts_lp_s1d_image_bytes_(int K, int N);
@@ -2423,14 +2424,16 @@ __device__ __forceinline__ void lp_dbias_block(const float (&cs)[8], int oct, in
   }
   (void)oct;
 }
-__global__ __launch_bounds__(256) void lp_dbias_finalize_kernel(const double* part, float* db, int nblocks, int C, int accum) {
-  // one workgroup per channel: threads split the block rows, fixed-order combine
-  __shared__ double sh[4];
-  const int c = blockIdx.x;
+// one workgroup per channel c: threads split the block rows, fixed-order combine (sh: 4 doubles of LDS)
+__device__ __forceinline__ void lp_dbias_finalize_body(const double* part, float* db, int nblocks, int C, int accum, int c, double* sh) {
   double s = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += 256) s += part[(long)b * C + c];
   s = block_sum_f64(s, sh);
   if (threadIdx.x == 0) db[c] = accum ? db[c] + (float)s : (float)s;
+}
+__global__ __launch_bounds__(256) void lp_dbias_finalize_kernel(const double* part, float* db, int nblocks, int C, int accum) {
+  __shared__ double sh[4];
+  lp_dbias_finalize_body(part, db, nblocks, C, accum, blockIdx.x, sh);
 }
 // =====================================================================================================================
 // GroupNormalization backward on 16-bit tensors (channels_last = slab semantics; group_norm.py:83-124 under TF autodiff).
@@ -2510,11 +2513,10 @@ __global__ __launch_bounds__(256) void lp_gn_bwd_reduce_kernel(const unsigned sh
 // one block per group g: for every sample the class sums over the blocks -> c1, c2; the sums over the samples -> dgamma, dbeta.
 // Up to 256 / cg samples side by side (thread = (slice of the blocks, sample, class)): the loop over the samples of a batch of 8 was
 // eight dependent rounds, 15 us on the critical path between the reduce and the apply pass of every GroupNorm backward.
-__global__ __launch_bounds__(256) void lp_gn_bwd_finalize_kernel(const double* partial, const float* gamma, float* dgamma, float* dbeta, float* c1,
-                                                                 float* c2, int N, int G, int B, int cg, double L, int accum) {
-  __shared__ double sh[256 * 2];
-  __shared__ double tot[256 * 2];      // [sample slot][class] totals of the current round
-  const int g = blockIdx.x, t = threadIdx.x;
+__device__ __forceinline__ void lp_gn_bwd_finalize_body(const double* partial, const float* gamma, float* dgamma, float* dbeta, float* c1,
+                                                        float* c2, int N, int G, int B, int cg, double L, int accum, int g, double* sh,
+                                                        double* tot /* [sample slot][class] totals of the current round */) {
+  const int t = threadIdx.x;
   int Np = 1;
   while (Np * 2 <= N && cg * Np * 2 <= 256) Np *= 2;
   const int S = 256 / (cg * Np);
@@ -2558,6 +2560,12 @@ __global__ __launch_bounds__(256) void lp_gn_bwd_finalize_kernel(const double* p
     dgamma[idx] = accum ? dgamma[idx] + (float)ga : (float)ga;
     dbeta[idx] = accum ? dbeta[idx] + (float)gb : (float)gb;
   }
+}
+__global__ __launch_bounds__(256) void lp_gn_bwd_finalize_kernel(const double* partial, const float* gamma, float* dgamma, float* dbeta, float* c1,
+                                                                 float* c2, int N, int G, int B, int cg, double L, int accum) {
+  __shared__ double sh[256 * 2];
+  __shared__ double tot[256 * 2];
+  lp_gn_bwd_finalize_body(partial, gamma, dgamma, dbeta, c1, c2, N, G, B, cg, L, accum, blockIdx.x, sh, tot);
 }
 // apply pass, chunked like lp_gn_apply_chunk_kernel: a workgroup streams one contiguous piece of one (n, group) unit, a thread's
 // channels / statistics / c1, c2 are loop constants (the grid-stride form did 5 64-bit divisions per 16 bytes: 3.9 TB/s)
@@ -3702,6 +3710,31 @@ extern "C" long bts_lp_block_bwd_workspace(int N, long V, int F, int R, int G) {
          + (long)N * Bse * F * 2 * 8 + ((long)N * F * 3 + (long)N * R) * 8 + 128      // gate partials, red, scratch
          + 2 * ((N * (long)G > 2048 ? N * (long)G : 2048L) * F * 8 + 64);      // two sets of bias-gradient rows (one per apply workgroup)
 }
+// The two small launches of the fused block backward (see bts_lp_block_bwd).  Middle: workgroups [0, G) finish GroupNorm-2's class sums
+// (lp_gn_bwd_finalize_kernel's work), the rest sum the gate partials per (n, c) (se_bwd_partial_reduce_kernel's).  Tail: workgroups [0, np)
+// form the SE-MLP's parameter gradients from the per-sample pass's scratch (se_mlp_bwd_param_kernel's work), the next F finish conv2's bias
+// gradient, the last F the shortcut conv's (lp_dbias_finalize_kernel's).  Same bodies, same summation order: bit-identical to the six launches.
+__global__ __launch_bounds__(256) void lp_blk_bwd_middle_kernel(const double* partial, const float* gamma, float* dgamma, float* dbeta, float* c1,
+                                                                float* c2, const double* se_partial, double* red, int N, int G, int B, int cg,
+                                                                double L, int Bse, int F) {
+  __shared__ double sh[256 * 2];
+  __shared__ double tot[256 * 2];
+  if ((int)blockIdx.x < G) lp_gn_bwd_finalize_body(partial, gamma, dgamma, dbeta, c1, c2, N, G, B, cg, L, 1, blockIdx.x, sh, tot);
+  else se_bwd_partial_reduce_body(se_partial, red, N, Bse, F, (int)blockIdx.x - G);
+}
+__global__ __launch_bounds__(256) void lp_blk_bwd_tail_kernel(const double* red, const float* gap, const float* hbuf, float* dw1, float* dw2, float* dwsp,
+                                                              const double* scratch, int N, int F, int R, int np, const double* dbp1, float* db1,
+                                                              const double* dbp2, float* db2, int nblocks) {
+  __shared__ double sh[4];
+  int b = blockIdx.x;
+  if (b < np) { se_mlp_bwd_param_body(red, gap, hbuf, dw1, dw2, dwsp, scratch, N, F, R, 1, b); return; }
+  b -= np;
+  if (db1 != nullptr) {
+    if (b < F) { lp_dbias_finalize_body(dbp1, db1, nblocks, F, 1, b, sh); return; }
+    b -= F;
+  }
+  lp_dbias_finalize_body(dbp2, db2, nblocks, F, 1, b, sh);
+}
 // dout (N,V,F) rows of lddo; res, c2 dense; dres, dc2 dense outputs in the storage type; ds (N*V) and dgap (N,F) fp32 scratch outputs;
 // parameter gradients accumulate (+=); dbias_pt / dbias_c2 (may be NULL): the shortcut conv's / conv2's bias gradients (+=).
 // BTS_ERR_UNSUPPORTED outside the kernels' tiling: the caller runs bts_lp_gn_bwd and bts_lp_se_bwd.
@@ -3750,10 +3783,23 @@ extern "C" int bts_lp_block_bwd(int dtype, const void* dout, int lddo, const voi
 #undef LP_BB_R
   }
   BTS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(lp_gn_bwd_finalize_kernel, dim3(G), dim3(256), 0, stream, partial, gamma, dgamma, dbeta, c1, c2, N, G, B, cg, (double)L, 1);
-  BTS_LAUNCH_CHECK();
-  const int r = bts_se_bwd_middle_(sep, red, scratch, gap, h, ch, w1, w2, dw1, dw2, dwsp, dgap, N, Bse, V, F, R, 1, stream);
-  if (r != BTS_OK) return r;
+  // Between the reduce and the apply pass (review: ~100 launches of 5-10 us on this chain per step): ONE launch for the two finalizes that
+  // only need the reduce pass's partials (GroupNorm class sums -> dgamma / dbeta / c1 / c2; gate partials -> per-(n, c) sums), then the
+  // per-sample SE-MLP backward (dgap: the apply pass needs it).  The sums over the samples (dW1, dW2, dw_sp) and the two bias-gradient
+  // finalizes wait for the tail launch behind the apply pass: nothing on the chain reads them.  BTS_LP_BLK_BWD_MERGE=0: the six launches (A/B).
+  static const bool merge = [] { const char* e = getenv("BTS_LP_BLK_BWD_MERGE"); return !(e && atoi(e) == 0); }();
+  if (merge) {
+    hipLaunchKernelGGL(lp_blk_bwd_middle_kernel, dim3(G + (N * F + 3) / 4), dim3(256), 0, stream, partial, gamma, dgamma, dbeta, c1, c2, sep, red, N, G, B, cg,
+                       (double)L, Bse, F);
+    BTS_LAUNCH_CHECK();
+    const int r = bts_se_mlp_bwd_sample_(red, scratch, h, ch, w1, w2, dgap, N, V, F, R, stream);
+    if (r != BTS_OK) return r;
+  } else {
+    hipLaunchKernelGGL(lp_gn_bwd_finalize_kernel, dim3(G), dim3(256), 0, stream, partial, gamma, dgamma, dbeta, c1, c2, N, G, B, cg, (double)L, 1);
+    BTS_LAUNCH_CHECK();
+    const int r = bts_se_bwd_middle_(sep, red, scratch, gap, h, ch, w1, w2, dw1, dw2, dwsp, dgap, N, Bse, V, F, R, 1, stream);
+    if (r != BTS_OK) return r;
+  }
   int Ba;
   const long per = lp_chunk_per(L, (long)N * G, &Ba, 2048);
   const long blocks = (long)N * G * Ba;
@@ -3761,6 +3807,13 @@ extern "C" int bts_lp_block_bwd(int dtype, const void* dout, int lddo, const voi
   if (dtype == LP_F16) LP_BB_A(TF16); else LP_BB_A(TBF16);
 #undef LP_BB_A
   BTS_LAUNCH_CHECK();
+  if (merge) {
+    const int np = (R * F + 255) / 256;
+    hipLaunchKernelGGL(lp_blk_bwd_tail_kernel, dim3(np + (dbias_c2 ? F : 0) + (dbias_pt ? F : 0)), dim3(256), 0, stream, red, gap, h, dw1, dw2, dwsp, scratch,
+                       N, F, R, np, dbias_c2 ? dbp1 : (const double*)nullptr, dbias_c2, dbias_pt ? dbp2 : (const double*)nullptr, dbias_pt, (int)blocks);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+  }
   if (dbias_c2 != nullptr) {
     hipLaunchKernelGGL(lp_dbias_finalize_kernel, dim3(F), dim3(256), 0, stream, dbp1, dbias_c2, (int)blocks, F, 1);
     BTS_LAUNCH_CHECK();

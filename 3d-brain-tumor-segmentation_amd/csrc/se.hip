@@ -371,28 +371,15 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_sample_kernel(const double* pa
 // sums over the samples: dW2, dW1, dw_sp
 __global__ __launch_bounds__(256) void se_mlp_bwd_param_kernel(const double* partial, const float* gap, const float* hbuf, float* dw1, float* dw2,
                                                                float* dwsp, const double* scratch, int N, int F, int R, int accum) {
-  const double* dz2 = scratch;
-  const double* dz1 = scratch + (long)N * F;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < R * F) {
-    {
-      const int k = i / F, c = i % F;
-      double s = 0.0;
-      for (int n = 0; n < N; ++n) s += (double)hbuf[n * R + k] * dz2[n * F + c];
-      dw2[i] = accum ? dw2[i] + (float)s : (float)s;
-    }
-    {
-      const int c = i / R, k = i % R;
-      double s = 0.0;
-      for (int n = 0; n < N; ++n) s += (double)gap[n * F + c] * dz1[n * R + k];
-      dw1[i] = accum ? dw1[i] + (float)s : (float)s;
-    }
-  }
-  if (i < F) {
-    double s = 0.0;
-    for (int n = 0; n < N; ++n) s += partial[((long)n * F + i) * 2 + 1];
-    dwsp[i] = accum ? dwsp[i] + (float)s : (float)s;
-  }
+  se_mlp_bwd_param_body(partial, gap, hbuf, dw1, dw2, dwsp, scratch, N, F, R, accum, blockIdx.x);
+}
+// the per-sample pass alone (dz2, dz1 into scratch, dgap): callers that run the sums over the samples themselves (lowp.hip's tail launch)
+int bts_se_mlp_bwd_sample_(const double* red, double* scratch, const float* h, const float* ch, const float* w1, const float* w2, float* dgap, int N,
+                           long V, int F, int R, hipStream_t stream) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(se_mlp_bwd_sample_kernel, dim3(N), dim3(256), 0, stream, red, h, ch, w1, w2, dgap, scratch, N, F, R, 1.0 / (double)V);
+  BTS_LAUNCH_CHECK();
+  return BTS_OK;
 }
 static int se_mlp_bwd_launch(const double* red, const float* gap, const float* h, const float* ch, const float* w1, const float* w2, float* dw1,
                              float* dw2, float* dwsp, float* dgap, double* scratch, int N, int B, long V, int F, int R, int accumulate_params,
