@@ -227,10 +227,13 @@ def test_bench_line_helpers_on_the_committed_captures():
         assert tab is not None and tab.get('_meta', {}).get('steps_in_capture'), (sfx, src)
         tr = bench.pmc_traffic(sym, sfx)
         assert tr is not None and tr['bytes'] > 0 and tr['read_side'].startswith('request counters'), (sfx, sym, tr)
-        # all requests are 128-byte ones (the two counters come from separate profiler passes).  The bf16 entry averages the plain and the
-        # fused-shortcut form of the kernel; the latter's FETCH_SIZE reads 11 % above its request count (its shortcut rows are 64-byte
-        # register loads that the request counter files under 128 bytes' worth of one line), 6 % on the launch-weighted mean
-        assert abs(tr['read_bytes'] - 2.0 * tr['fetch_size_kib_raw'] * 1024.0) <= (0.08 if sfx == '_bf16_b8' else 0.03) * tr['read_bytes']
+        # all requests are 128-byte ones: request counters and 2 x FETCH_SIZE agree (the two come from separate profiler passes, i.e. separate
+        # runs).  The bf16 name covers two instantiations, the plain and the fused-shortcut form; the latter's re-reads of the shortcut's rows
+        # depend on what its L2 happens to hold, 12-17 % apart between the two passes of one capture -- the plain form is the yardstick
+        chk = bench.pmc_traffic('lp_s1d_kernel<1,5,false>', sfx) if sfx == '_bf16_b8' else tr
+        if sfx == '_bf16_b8':
+            assert tr['variants_in_capture'] == 2 and chk['variants_in_capture'] == 1, (tr, chk)
+        assert abs(chk['read_bytes'] - 2.0 * chk['fetch_size_kib_raw'] * 1024.0) <= 0.03 * chk['read_bytes']
     # records of two fake launches -> the contract's objects
     rec = [('lp_s1d_kernel<1,5>', 4.0e11, 0.30), ('lp_s1d_kernel<1,5>', 4.0e11, 0.34), ('lp_k1_kernel', 1.0e9, 0.10)]
     out = bench._roofline_from_records(rec, 1, 1e-3, lambda s: bench.pmc_traffic(s, '_bf16_b8'), 'test')
