@@ -405,7 +405,8 @@ int bts_lp_conv1_gap_acc(int dtype, const void* x, const void* wp, const float* 
  * fold; y, res dense (N,D,H,W,Cout).  Cin = 64 on volumes of >= 8 M voxels: both ride on the two z-marching passes over the channel halves.
  * x_split (elements; 0 = x is one (N,D,H,W,Cin) view): Cin = 64 as TWO 32-channel tensors x and x + x_split with voxel stride ldx each -- the
  * operands of a concat (decoder.py:75) never materialised side by side, each read in whole lines (virtual concat as a list of
- * (ptr, C) segments).  Workspace query -1 / return value 1 (nothing launched) outside the kernel's shapes: run bts_lp_conv1_gap +
+ * (ptr, C) segments); the two passes at any volume size (pass ldx = 32 to the workspace query).  Workspace query -1 / return value 1 (nothing
+ * launched) outside the kernel's shapes: run bts_lp_conv1_gap +
  * bts_lp_conv3d_fwd_gn.  BTS_LP_FS=0 in the environment: never, BTS_LP_FS_PAIR=0: not on the two-pass form (A/B aids) */
 long bts_lp_conv3d_fwd_gn_shortcut_workspace(int N, int D, int H, int W, int Cin, int ldx, int Cout, int G);
 int bts_lp_conv3d_fwd_gn_shortcut(int dtype, const void* x, long x_split, const void* wp, const float* bias, void* y, float* mean, float* rstd,
