@@ -242,3 +242,54 @@ def test_bench_line_helpers_on_the_committed_captures():
     assert out['kernel_breakdown']['lp_k1_kernel']['bound'] == 'hbm' and out['kernel_breakdown']['lp_s1d_kernel<1,5>']['bound'] == 'mfma'
     sr = bench.step_rooflines(52.136, 127.2, 0.0765, 'bf16', '_bf16_b8')
     assert 1.0 < sr['wasted_traffic_ratio'] < 4.0 and 0.2 < sr['mfma_frac'] < 0.35 and sr['read_side'] == ['request counters']
+
+
+def test_pmc_aggregate_takes_the_last_full_step(tmp_path):
+    """scripts/pmc_aggregate.py on a synthetic three-step capture: one-time launches of the first step (weight packs) and a cold first step must
+    not leak into the per-step figure -- `steady` holds the launches between the last two Adam dispatches and their own counter means, and
+    bench.py's step total is built from it"""
+    import csv
+    import importlib.util
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cols = ['Dispatch_Id', 'Kernel_Name', 'Counter_Name', 'Counter_Value', 'Start_Timestamp', 'End_Timestamp']
+    # step 1: 3 packs (once) + conv (cold: 200 KiB) + adam; steps 2, 3: pack_batch + conv (100 KiB) + adam
+    seq = [('lp_pack_kernel<T>(P)', 50.0)] * 3 + [('conv_kernel(P)', 200.0), ('adam_kernel(float*)', 10.0)]
+    seq += [('lp_pack_batch_kernel<T>(P)', 30.0), ('conv_kernel(P)', 100.0), ('adam_kernel(float*)', 10.0)] * 2
+    for sfx in ('', '_bf16_b8', '_infer_f16'):
+        for name, ctrs in (('fetch', ['FETCH_SIZE']), ('write', ['WRITE_SIZE', 'GRBM_GUI_ACTIVE']),
+                           ('req', ['TCC_EA0_RDREQ_sum', 'TCC_EA0_RDREQ_32B_sum', 'TCC_EA0_RDREQ_64B_sum', 'TCC_EA0_RDREQ_128B_sum'])):
+            d = tmp_path / ('pmc_T%s_%s' % (sfx, name))
+            d.mkdir()
+            with open(d / ('%s_counter_collection.csv' % name), 'w', newline='') as f:
+                w = csv.DictWriter(f, fieldnames=cols)
+                w.writeheader()
+                for i, (k, kib) in enumerate(seq):
+                    if sfx == '_infer_f16' and 'adam' in k:
+                        continue                                # a forward has no optimiser step: no steady segment
+                    for c in ctrs:
+                        val = {'FETCH_SIZE': kib / 2.0, 'WRITE_SIZE': kib / 4.0, 'GRBM_GUI_ACTIVE': 8000.0, 'TCC_EA0_RDREQ_sum': kib * 8.0,
+                               'TCC_EA0_RDREQ_32B_sum': 0.0, 'TCC_EA0_RDREQ_64B_sum': 0.0, 'TCC_EA0_RDREQ_128B_sum': kib * 8.0}[c]
+                        w.writerow({'Dispatch_Id': i + 1, 'Kernel_Name': k, 'Counter_Name': c, 'Counter_Value': val,
+                                    'Start_Timestamp': 1000 * i, 'End_Timestamp': 1000 * i + 500})
+    r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'pmc_aggregate.py'), str(tmp_path), 'T'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    tab = json.load(open(tmp_path / 'T_pmc_traffic_bf16_b8.json'))
+    assert tab['_meta']['steady_step_launches'] == 3
+    assert 'steady' not in tab['lp_pack_kernel<T>'] and tab['lp_pack_kernel<T>']['launches'] == 3
+    assert tab['conv_kernel']['launches'] == 3 and tab['conv_kernel']['steady']['launches'] == 1
+    assert abs(tab['conv_kernel']['FETCH_SIZE_KiB_mean'] - (100 + 50 + 50) / 3.0) < 1e-9 and tab['conv_kernel']['steady']['FETCH_SIZE_KiB_mean'] == 50.0
+    assert 'steady_step_launches' not in json.load(open(tmp_path / 'T_pmc_traffic_infer_f16.json'))['_meta']
+    # bench.py's step total from such a table: the steady step only; everything else in the capture is "outside the step loop"
+    spec = importlib.util.spec_from_file_location('bench_mod2', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    bench._traffic_table = lambda suffix='': (tab, 'synthetic')
+    sr = bench.step_rooflines(1.0, 1.0, 1.0, 'bf16', '_bf16_b8')
+    kib = 1024.0
+    steady = (128.0 * (30 + 100 + 10) * 8.0) + (30 + 100 + 10) / 4.0 * kib        # request-counter reads + WRITE_SIZE writes of one step
+    assert abs(sr['measured_hbm_gb_per_step'] * 1e9 - steady) < 1e-3 * steady, (sr, steady)
+    assert sr['outside_the_step_loop_gb'] > 0
